@@ -1,0 +1,234 @@
+#!/usr/bin/env python3
+"""Headline benchmark: follower rollout throughput in agent-steps/s (BASELINE.json).
+
+One "step" of this script = one follower episode batch on every rank: EncoderLSTM over the
+(<=80-token) instructions + `--decode-steps` AttnDecoderLSTM steps with on-device argmax
+feedback, masking, cross-entropy and u_prev gather, over index-form observations gathered
+from the HBM-resident 36x2048 feature table.  With --workload train the step also runs
+BPTT, the (data-parallel) gradient all-reduce and two Adam updates (train.py:263-268).
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.  value = B * decode_steps * world * K / max-over-ranks time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FLOPS_LSTM = lambda B, I, H: 2.0 * B * (I + H) * 4 * H      # noqa: E731  gate GEMM of one LSTMCell step
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', choices=['rollout', 'train'], default='rollout')
+    ap.add_argument('--batch', type=int, default=100)
+    ap.add_argument('--decode-steps', type=int, default=20)
+    ap.add_argument('--n-viewpoints', type=int, default=10567)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-reps', type=int, default=2)
+    return ap.parse_args()
+
+
+def build_models(seed, device):
+    from speaker_follower_amd import synth, model
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights(seed)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    return enc.to(device), dec.to(device), enc_w, dec_w
+
+
+def device_table(n_vp, seed, device):
+    """ResNet-pool5-like table generated on the device (0.5*N(0,1) clipped at 0), 3.1 GB at
+    the full 10 567 viewpoints."""
+    g = torch.Generator(device=device)
+    g.manual_seed(seed)
+    t = torch.empty(n_vp, 36, 2048, device=device, dtype=torch.float32)
+    chunk = 512
+    for i in range(0, n_vp, chunk):
+        blk = t[i:i + chunk]
+        blk.normal_(0.0, 0.5, generator=g)
+        blk.clamp_(min=0.0)
+    return t
+
+
+def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps):
+    """The numpy oracle (a port of the reference modules, oracle/np_model.py) on ONE host thread,
+    on the same batch the GPU ran: full rollout, `reps` repetitions."""
+    from threadpoolctl import threadpool_limits
+    from oracle import np_env, np_model
+    import copy
+    fbc = copy.copy(fb)
+    fbc.vp = np.vectorize(row_of.get)(fb.vp).astype(np.int32)
+    loc = np_env.static_loc_embeddings()
+    seq, mask, lens = np_env.batch_instructions_from_encoded(fb.instr, 80, reverse=True)
+    B = len(lens)
+    best = None
+    with threadpool_limits(limits=1):
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = np_model.follower_rollout(
+                enc_w, dec_w, seq, lens, mask, decode_steps,
+                lambda t: np_env.dense_follower_step(table_rows, loc, fbc, t), fb.target, 'argmax',
+                2176)
+            dt = time.perf_counter() - t0
+            n = len(res['logits'])
+            rate = B * n / dt
+            best = rate if best is None else max(best, rate)
+    return dict(value=best, unit='agent-steps/s', cores=1, kind='port',
+                sample='%d full rollouts of the same batch (B=%d, %d decode steps, encoder included), '
+                       'numpy oracle, 1 thread, best of %d' % (reps, B, n, reps)), res
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local = int(os.environ.get('LOCAL_RANK', '0'))
+    assert torch.cuda.is_available(), 'bench.py needs a GPU'
+    torch.cuda.set_device(local)
+    device = torch.device('cuda', local)
+    group = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=device)
+        group = dist.group.WORLD
+
+    from speaker_follower_amd import synth, features, follower
+    enc, dec, enc_w, dec_w = build_models(101, device)
+    B, S = args.batch, args.decode_steps
+    table = device_table(args.n_viewpoints, 1234, device)
+    store = features.FeatureStore(table, device=device)
+    fb = synth.follower_batch(seed=rank, batch=B, steps=S, n_viewpoints=args.n_viewpoints)
+    batch = follower.DeviceFollowerBatch.from_synth(fb, device=device, row0=rank * B)
+    train = args.workload == 'train'
+    engine = follower.FollowerEngine(enc, dec, store, group=group if train else None)
+    if train:
+        enc.train()
+        dec.train()
+        params_e = [p for p in enc.parameters() if p.requires_grad]
+        params_d = [p for p in dec.parameters() if p.requires_grad]
+        opt_e = torch.optim.Adam(params_e, lr=1e-4, weight_decay=5e-4)     # train.py:263-268
+        opt_d = torch.optim.Adam(params_d, lr=1e-4, weight_decay=5e-4)
+    else:
+        enc.eval()
+        dec.eval()
+
+    def one_step():
+        if train:
+            opt_e.zero_grad(set_to_none=False)
+            opt_d.zero_grad(set_to_none=False)
+            st = engine.rollout(batch, S, 'argmax', train=True)
+            st.loss.backward()
+            if world > 1:
+                from speaker_follower_amd import dp
+                dp.allreduce_gradients(params_e + params_d, group)
+            opt_e.step()
+            opt_d.step()
+        else:
+            with torch.no_grad():
+                st = engine.rollout(batch, S, 'argmax', train=False)
+        return st
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        st = one_step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        st = one_step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt)
+    agent_steps = B * S * world * args.steps
+    value = agent_steps / elapsed
+
+    if rank != 0:
+        if world > 1:
+            torch.distributed.destroy_process_group()
+        return
+
+    # ---- roofline of the dominant kernel: the decoder LSTMCell gate GEMM [B,4864]x[4864,2048]
+    from speaker_follower_amd import ops
+    H, I = 512, 4352
+    x = torch.randn(B, I, device=device)
+    h0 = torch.randn(B, H, device=device)
+    c0 = torch.randn(B, H, device=device)
+    w4 = [dec.lstm.weight_ih.detach(), dec.lstm.weight_hh.detach(), dec.lstm.bias_ih.detach(),
+          dec.lstm.bias_hh.detach()]
+    from speaker_follower_amd.runtime import ptr, ws_args, struct_of
+    from speaker_follower_amd import _lib
+    import ctypes as C
+    xin = torch.cat((x, h0), 1).contiguous()
+    wcat = torch.cat((w4[0], w4[1]), 1).contiguous()
+    y = torch.empty(B, 4 * H, device=device)
+    reps = 50
+    for _ in range(5):
+        _lib.call('sf_linear_fwd', ptr(xin), I + H, ptr(wcat), None, B, 4 * H, I + H, 0, ptr(y),
+                  4 * H, *ws_args(device))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        _lib.call('sf_linear_fwd', ptr(xin), I + H, ptr(wcat), None, B, 4 * H, I + H, 0, ptr(y),
+                  4 * H, *ws_args(device))
+    e1.record()
+    torch.cuda.synchronize()
+    gemm_ms = e0.elapsed_time(e1) / reps
+    flops = FLOPS_LSTM(B, I, H)
+    achieved = flops / (gemm_ms * 1e-3) / 1e12
+    roofline = dict(bound='mfma', achieved=achieved, peak=157.3, unit='TFLOP/s',
+                    frac=achieved / 157.3, traffic=None,
+                    kernel='gemm_nt_kernel<7> + reduce_slabs (decoder LSTMCell gates, '
+                           '[%d,%d]x[%d,%d]^T fp32)' % (B, I + H, 4 * H, I + H),
+                    launch_ms=gemm_ms, flops_per_launch=flops)
+
+    out = dict(metric='agent-steps/sec (follower rollout, batch %d)' % B, value=value,
+               unit='agent-steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
+               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak',
+               vs_baseline=None, dtype='f32', data='synthetic',
+               config=dict(workload='follower %s: batch %d per GPU, 36 views x 2048-d features from a '
+                                    '%d-viewpoint HBM table, <=80-token instructions, %d decode steps, '
+                                    'argmax (student-forcing) feedback, encoder included'
+                                    % (args.workload, B, args.n_viewpoints, S),
+                           global_batch=B * world, parallelism='dp%d' % world),
+               roofline=roofline, loss=float(st.loss))
+
+    if not args.no_cpu_baseline:
+        used = np.unique(fb.vp)
+        rows = table[torch.from_numpy(used).to(device)].cpu().numpy()
+        row_of = {int(v): i for i, v in enumerate(used)}
+        cb, ref = cpu_baseline(enc_w, dec_w, fb, rows, row_of, S, args.cpu_reps)
+        out['cpu_baseline'] = cb
+        if not train:
+            n = len(ref['logits'])
+            same = bool(np.array_equal(st.actions.cpu().numpy()[:n], ref['actions']))
+            out['parity_vs_cpu_port'] = dict(actions_bit_exact=same,
+                                             loss_abs_diff=abs(float(st.loss) - float(ref['loss'])))
+    print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

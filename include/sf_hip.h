@@ -1,0 +1,327 @@
+/* sf_hip.h -- C ABI of libsf_hip.so: the speaker/follower hot path on MI355X (gfx950).
+ *
+ * The reference (ronghanghu/speaker_follower) has no C FFI for this path: its operator API is
+ * the set of torch.nn.Module classes in tasks/R2R/model.py plus the per-step tensor glue in
+ * tasks/R2R/follower.py and speaker.py.  Each entry point below replaces the arithmetic of one of
+ * those functions (cited as file:line under /root/reference) and is what a binding written
+ * against the reference would call -- see INTEGRATION.md for the ctypes stub.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless stated; fp32 row-major; leading dimensions in
+ *     elements; index arrays int32 unless stated; masks uint8 (1 = masked / padded);
+ *   - nothing allocates, frees or synchronises: outputs, saved activations and the scratch
+ *     workspace are passed in; all work is enqueued on `stream` (a hipStream_t; NULL = default);
+ *     calls are safe inside hipGraph stream capture;
+ *   - return value: SF_OK or an SF_ERR_* code; no global state, thread-safe per stream as long as
+ *     concurrent calls use different workspaces;
+ *   - "accumulate" outputs (weight gradients, dctx) are read-modify-write: the caller zeroes them
+ *     once per backward pass.  Gradient structs mirror the weight structs; a NULL member skips
+ *     that gradient.
+ *   - dropout is counter based: keep(seed, stream_id, global_row, col) -- see sf_dropout.
+ */
+#ifndef SF_HIP_H_
+#define SF_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_ABI_VERSION 1
+
+enum {
+    SF_OK = 0,
+    SF_ERR_ARG = 1,         /* null pointer, non-positive size, misaligned leading dimension */
+    SF_ERR_UNSUPPORTED = 2, /* shape outside what the kernels are built for */
+    SF_ERR_LAUNCH = 3,      /* hipGetLastError() reported a launch failure */
+    SF_ERR_WORKSPACE = 4    /* workspace too small (see sf_workspace_bytes) */
+};
+
+typedef void* sf_stream;
+
+/* nn.Dropout(p) replacement (model.py:52, 370, 414, 473).  p == 0 => eval mode.  The mask for
+ * element (row, col) of dropout site `stream_id` is a pure function of (seed, stream_id,
+ * row0 + row, col); oracle/rng.py mirrors it bit for bit. */
+typedef struct sf_dropout {
+    float p;
+    uint32_t seed;
+    int32_t row0; /* global id of local row 0 (data-parallel shards pass their offset) */
+} sf_dropout;
+
+/* Panorama rows of a batch: either the dense [B,V,F] tensor the reference's
+ * Seq2SeqAgent._feature_variables builds (follower.py:291-298, env.py:330-332, 771-773) or the
+ * HBM-resident feature table addressed by index (replaces env.py:380-383 dict lookup + np.stack +
+ * H2D copy): row v of sample b = table[vp[b], v, :] || loc_table[view[b], v, :]. */
+typedef struct sf_pano {
+    const float* dense;     /* [B,V,IMG+LOC] or NULL */
+    const float* table;     /* [n_viewpoints, V, IMG] */
+    const float* loc_table; /* [V, V, LOC]  (env.py:78-101) */
+    const int32_t* vp;      /* [B]; < 0 => all-zero panorama (speaker.py:93-95 padded step) */
+    const int32_t* view;    /* [B] */
+    int32_t V, IMG, LOC;
+} sf_pano;
+
+/* Candidate-action rows: dense all_u_t [B,A,F] (follower.py:300-320) or by index
+ * (env.py:60-75): row a>0 = table[vp[b], cand_view[b,a], :] || sin/cos(rel_heading, rel_elevation)
+ * each repeated LOC/4 times; row 0 (stop) and rows >= a_num[b] are zero. */
+typedef struct sf_cands {
+    const float* dense;       /* [B,A,IMG+LOC] or NULL */
+    const float* table;
+    const int32_t* vp;        /* [B] */
+    const int32_t* cand_view; /* [B,A] */
+    const float* cand_sincos; /* [B,A,4]: sin h, cos h, sin e, cos e */
+    const int32_t* a_num;     /* [B] */
+    int32_t A, V, IMG, LOC;
+} sf_cands;
+
+/* ---- weights (pointer sets keyed like the reference state_dicts) -------------------------- */
+typedef struct sf_lstm_w { /* nn.LSTMCell / nn.LSTM layer 0: weight_ih [4H,I], weight_hh [4H,H] */
+    const float *w_ih, *w_hh, *b_ih, *b_hh;
+} sf_lstm_w;
+typedef struct sf_lstm_g { float *w_ih, *w_hh, *b_ih, *b_hh; } sf_lstm_g;
+
+typedef struct sf_visual_w { /* VisualSoftDotAttention model.py:303-308 */
+    const float *w_h, *b_h; /* linear_in_h [D,H],[D] */
+    const float *w_v, *b_v; /* linear_in_v [D,F],[D]; b_v cannot change the output (softmax shift) */
+} sf_visual_w;
+typedef struct sf_visual_g { float *w_h, *b_h, *w_v, *b_v; } sf_visual_g;
+
+typedef struct sf_softdot_w { /* SoftDotAttention model.py:114-120 */
+    const float *w_in;  /* linear_in  [H,H]  (no bias) */
+    const float *w_out; /* linear_out [H,2H] (no bias) */
+} sf_softdot_w;
+typedef struct sf_softdot_g { float *w_in, *w_out; } sf_softdot_g;
+
+typedef struct sf_scoring_w { /* EltwiseProdScoring model.py:335-340 */
+    const float *w_h, *b_h;     /* linear_in_h [D,H],[D] */
+    const float *w_a, *b_a;     /* linear_in_a [D,F],[D] */
+    const float *w_out, *b_out; /* linear_out  [1,D],[1] */
+} sf_scoring_w;
+typedef struct sf_scoring_g { float *w_h, *b_h, *w_a, *b_a, *w_out, *b_out; } sf_scoring_g;
+
+typedef struct sf_decoder_w { /* AttnDecoderLSTM model.py:361-375 */
+    sf_lstm_w lstm;       /* LSTMCell(2F -> H) */
+    sf_visual_w visual;
+    sf_softdot_w text;
+    sf_scoring_w action;
+} sf_decoder_w;
+typedef struct sf_decoder_g { sf_lstm_g lstm; sf_visual_g visual; sf_softdot_g text; sf_scoring_g action; } sf_decoder_g;
+
+/* ---- saved activations of one AttnDecoderLSTM step (all written by fwd, read by bwd) ------- */
+typedef struct sf_decoder_tape {
+    float* t_v;     /* [B,D]   linear_in_h(h0) */
+    float* q;       /* [B,F]   t_v folded through linear_in_v */
+    float* alpha_v; /* [B,V] */
+    float* xin;     /* [B,2F]  dropout(cat(u_prev, feature)) -- LSTM input */
+    float* gates;   /* [B,4H]  activated gates i,f,g,o */
+    float* c1;      /* [B,H] */
+    float* h1;      /* [B,H]   (un-dropped, returned) */
+    float* cat2;    /* [B,2H]  cat(weighted_ctx, dropout(h1)) -- linear_out input */
+    float* t_text;  /* [B,H]   linear_in(dropout(h1)) */
+    float* alpha;   /* [B,L] */
+    float* h_tilde; /* [B,H] */
+    float* t_a;     /* [B,D]   linear_in_h(h_tilde) (before the w_out product) */
+    float* wt;      /* [B,D]   t_a * linear_out.weight */
+    float* r;       /* [B,F]   wt folded through linear_in_a */
+    float* logit;   /* [B,A]   raw logits (unmasked) */
+} sf_decoder_tape;
+
+/* Scratch any call may need (split-K partial slabs etc.); a constant, independent of batch. */
+size_t sf_workspace_bytes(void);
+int sf_abi_version(void);
+const char* sf_status_string(int status);
+
+/* ---- nn.Linear (model.py:64, 99, 117-119, 306-307, 338-340, 419, 485) ------------------------
+ * y[M,N] = act(x[M,K] w[N,K]^T + b);  act: 0 none, 1 tanh.  K % 4 == 0, ldx % 4 == 0. */
+int sf_linear_fwd(const float* x, int ldx, const float* w, const float* b, int M, int N, int K,
+                  int act, float* y, int ldy, void* ws, size_t ws_bytes, sf_stream stream);
+/* dy is the gradient wrt the activation output; y is the saved output (needed for act = tanh).
+ * dx [M,K] overwritten (accumulate_dx = 0) or added to; dw [N,K], db [N] accumulated. */
+int sf_linear_bwd(const float* x, int ldx, const float* w, const float* y, int ldy,
+                  const float* dy, int lddy, int M, int N, int K, int act, float* dx, int lddx,
+                  int accumulate_dx, float* dw, float* db, void* ws, size_t ws_bytes,
+                  sf_stream stream);
+
+/* ---- nn.LSTMCell (model.py:371/393, 417-418/434, 483/515), gate order i,f,g,o -----------------
+ * x [B,I] (I % 4 == 0).  Writes h1,c1 [B,H] and the activated gates [B,4H] for the backward.
+ * If h1_drop != NULL also writes dropout(h1) there (row stride ld_h1_drop; site `drop_stream`). */
+int sf_lstm_cell_fwd(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx,
+                     const float* h0, const float* c0, float* h1, float* c1, float* gates,
+                     float* h1_drop, int ld_h1_drop, const sf_dropout* drop, uint32_t drop_stream,
+                     void* ws, size_t ws_bytes, sf_stream stream);
+/* dh1,dc1 [B,H] in (NULL = zero); dx [B,I] (lddx), dh0, dc0 out (overwritten); weight grads
+ * accumulated. */
+int sf_lstm_cell_bwd(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, const float* x,
+                     int ldx, const float* h0, const float* c0, const float* c1,
+                     const float* gates, const float* dh1, const float* dc1, float* dx, int lddx,
+                     float* dh0, float* dc0, void* ws, size_t ws_bytes, sf_stream stream);
+
+/* ---- VisualSoftDotAttention.forward (model.py:310-326) ---------------------------------------
+ * out[b, :F] (row stride ldo) = sum_v alpha[b,v] X[b,v,:], alpha = softmax_v((W_v x_v + b_v).t),
+ * t = W_h h + b_h.  Implemented as softmax_v(x_v . q), q = W_v^T t (b_v.t is a per-row constant and
+ * cancels in the softmax), so X is read once and the [B*V,F]x[F,D] product disappears.
+ * Optional dropout on `out` (site drop_stream, column offset drop_col0 -- the fused decoder writes
+ * straight into the LSTM input buffer).  t_v [B,D] and q [B,F] are saved for the backward. */
+int sf_visual_attention_fwd(const sf_visual_w* w, const sf_pano* X, int B, int H, int D,
+                            const float* h, float* out, int ldo, float* alpha, float* t_v,
+                            float* q, const sf_dropout* drop, uint32_t drop_stream,
+                            int drop_col0, void* ws, size_t ws_bytes, sf_stream stream);
+/* dout [B,F] (row stride lddo) is the gradient wrt the (dropped) output; dh [B,H] is ADDED to. */
+int sf_visual_attention_bwd(const sf_visual_w* w, const sf_visual_g* g, const sf_pano* X, int B,
+                            int H, int D, const float* h, const float* alpha, const float* t_v,
+                            const float* dout, int lddo, const sf_dropout* drop,
+                            uint32_t drop_stream, int drop_col0, float* dh, void* ws,
+                            size_t ws_bytes, sf_stream stream);
+
+/* ---- SoftDotAttention.forward (model.py:122-143) ---------------------------------------------
+ * h [B,H] (row stride ldh); ctx [B,L,H]; mask [B,L] uint8 or NULL.  Writes alpha [B,L], h_tilde
+ * [B,H] and the saved cat2 = [weighted_ctx ; h] [B,2H], t_text = linear_in(h) [B,H]. */
+int sf_soft_dot_attention_fwd(const sf_softdot_w* w, int B, int L, int H, const float* h, int ldh,
+                              const float* ctx, const uint8_t* mask, float* h_tilde, float* alpha,
+                              float* cat2, float* t_text, void* ws, size_t ws_bytes,
+                              sf_stream stream);
+/* dh_tilde [B,H] in; dh [B,H] (row stride lddh) overwritten; dctx [B,L,H] ADDED to (NULL = skip). */
+int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, int H,
+                              const float* ctx, const float* alpha, const float* cat2,
+                              const float* t_text, const float* h_tilde, const float* dh_tilde,
+                              float* dh, int lddh, float* dctx, void* ws, size_t ws_bytes,
+                              sf_stream stream);
+
+/* ---- EltwiseProdScoring.forward (model.py:342-352) -------------------------------------------
+ * logit[b,a] = w_out . (t_a[b] * (W_a u[b,a] + b_a)) + b_out,  t_a = W_h h + b_h; implemented as
+ * u[b,a] . r[b] + wt[b] . b_a + b_out with wt = w_out * t_a, r = W_a^T wt.  Saves t_a, wt [B,D], r. */
+int sf_eltwise_prod_scoring_fwd(const sf_scoring_w* w, const sf_cands* U, int B, int H, int D,
+                                const float* h, float* logit, float* t_a, float* wt, float* r,
+                                void* ws, size_t ws_bytes, sf_stream stream);
+/* dlogit [B,A] in; dh [B,H] overwritten. */
+int sf_eltwise_prod_scoring_bwd(const sf_scoring_w* w, const sf_scoring_g* g, const sf_cands* U,
+                                int B, int H, int D, const float* h, const float* t_a,
+                                const float* wt, const float* dlogit, float* dh, void* ws,
+                                size_t ws_bytes, sf_stream stream);
+
+/* ---- AttnDecoderLSTM.forward (model.py:377-397): one follower decode step --------------------
+ * u_prev [B,F]; X panorama; U candidates; h0,c0 [B,H]; ctx [B,L,H]; ctx_mask [B,L].
+ * Returns h1,c1 (tape->h1, tape->c1), alpha (tape->alpha), raw logit (tape->logit), alpha_v.
+ * Dropout sites: 2*step for the LSTM input, 2*step+1 for h1 (step = `step_id`). */
+int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands* U, int B, int H,
+                        int D, int L, const float* u_prev, const float* h0, const float* c0,
+                        const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tape,
+                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                        sf_stream stream);
+/* Gradients in: dlogit [B,A], dh1, dc1 [B,H] (NULL = zero).  Out: dh0, dc0 [B,H] overwritten,
+ * dctx [B,L,H] ADDED to.  u_prev is detached in the reference (follower.py:502): no du_prev. */
+int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
+                        const sf_cands* U, int B, int H, int D, int L, const float* h0,
+                        const float* c0, const float* ctx, const sf_decoder_tape* tape,
+                        const float* dlogit, const float* dh1, const float* dc1, float* dh0,
+                        float* dc0, float* dctx, const sf_dropout* drop, uint32_t step_id,
+                        void* ws, size_t ws_bytes, sf_stream stream);
+
+/* ---- follower per-step glue (follower.py:476-505) ---------------------------------------------
+ * Masks logits of invalid candidates to -inf in place (logit [B,A]; valid = a < a_num[b], or
+ * is_valid[b,a] != 0 when is_valid is given), computes the cross-entropy term against
+ * target[b] (int64, -1 = ignore; rows with ended[b] != 0 are forced to -1), chooses the next
+ * action (feedback 0 = teacher: max(target,0); 1 = argmax, first maximum), writes this step's
+ * score[b] = log p(a_t) (the caller sums steps: follower.py:504-505), writes
+ * u_next[b,:] = U[b, a_t, :] (NULL = skip), updates
+ * ended[b] |= (a_t == 0).  ce_term[b] / live[b] receive the row's CE term and 0/1 liveness;
+ * target_used [B] int64 receives the effective targets for the backward. */
+int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const float* is_valid,
+                         const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
+                         int64_t* target_used, float* score, float* u_next, float* ce_term,
+                         float* live, sf_stream stream);
+/* dlogit[b,a] = gscale[0] * (softmax(logit)[b,a] - [a == target_used[b]]) for live rows, else 0
+ * (gscale = dloss / live count: a device scalar, so no host sync is needed). */
+int sf_follower_glue_bwd(int B, int A, const float* logit, const int64_t* target_used,
+                         const float* gscale, float* dlogit, sf_stream stream);
+/* Loss bookkeeping without host syncs or atomics (deterministic order):
+ * sum_cnt[t] = (sum_b term[t,b], sum_b live[t,b]) for t < T;  then, optionally after a
+ * data-parallel all-reduce of sum_cnt, loss[0] = sum_t sum/cnt (0 where cnt == 0) which is the
+ * reference's "sum over steps of per-step means" (follower.py:481, speaker.py:182), and
+ * gscale[t] = 1/cnt[t] (0 where cnt == 0) for the backward. */
+int sf_reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
+                    sf_stream stream);
+int sf_loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, sf_stream stream);
+
+/* ---- EncoderLSTM.forward (model.py:81-104) ----------------------------------------------------
+ * seq [B,Lpad] int64 (PAD = 0 after each row's length), lengths [B] int32, T = max length.
+ * Packed-sequence semantics: row b advances for t < lengths[b]; ctx [B,T,H] is zero beyond.
+ * Writes ctx (dropout site `drop_stream` when training), decoder_init = tanh(W h_T + b), c_T.
+ * tape: emb_t [T,B,E], xg [T,B,4H] (hoisted input product), gates [T,B,4H], hs [T+1,B,H],
+ * cs [T+1,B,H] (state before/after every step). */
+typedef struct sf_encoder_w {
+    const float* embedding; /* [vocab,E] */
+    sf_lstm_w lstm;         /* weight_ih_l0 [4H,E] ... */
+    const float *w_e2d, *b_e2d; /* encoder2decoder [H,H],[H] */
+} sf_encoder_w;
+typedef struct sf_encoder_g { sf_lstm_g lstm; float *w_e2d, *b_e2d; } sf_encoder_g;
+typedef struct sf_encoder_tape { float *emb, *xg, *gates, *hs, *cs; } sf_encoder_tape;
+int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, int H,
+                        const int64_t* seq, const int32_t* lengths, float* ctx,
+                        float* decoder_init, float* c_t, const sf_encoder_tape* tape,
+                        const sf_dropout* drop, uint32_t drop_stream, void* ws, size_t ws_bytes,
+                        sf_stream stream);
+/* dctx [B,T,H] (gradient wrt the dropped ctx), d_init, d_ct [B,H] in (NULL = zero). */
+int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int T, int E, int H,
+                        const int32_t* lengths, const float* decoder_init, const float* dctx,
+                        const float* d_init, const float* d_ct, const sf_encoder_tape* tape,
+                        const sf_dropout* drop, uint32_t drop_stream, void* ws, size_t ws_bytes,
+                        sf_stream stream);
+
+/* ---- batched feature gathers (env.py:380-383, 771-774, 60-75; follower.py:291-320) ------------
+ * Materialise the dense tensors the reference builds on the host, from the HBM table. */
+int sf_gather_panorama(const sf_pano* X, int B, float* out /* [B,V,F] */, sf_stream stream);
+int sf_gather_candidates(const sf_cands* U, int B, float* all_u /* [B,A,F] */,
+                         float* is_valid /* [B,A] */, sf_stream stream);
+/* rows [B,F] of single chosen actions (speaker.py:104): a == 0 / vp < 0 => zeros */
+int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf_stream stream);
+
+/* ---- speaker (model.py:429-457, 487-519; speaker.py:158-197) ---------------------------------- */
+typedef struct sf_spk_decoder_w {
+    const float* embedding; /* [vocab,E] */
+    sf_lstm_w lstm;         /* LSTMCell(E -> H) */
+    sf_softdot_w attn;
+    const float *w_out, *b_out; /* decoder2action [vocab,H],[vocab] */
+} sf_spk_decoder_w;
+typedef struct sf_spk_decoder_g { sf_lstm_g lstm; sf_softdot_g attn; float *w_out, *b_out; } sf_spk_decoder_g;
+typedef struct sf_spk_decoder_tape {
+    float *emb;     /* [B,E] */
+    float *gates, *c1, *h1, *cat2, *t_text, *alpha, *h_tilde;
+    float *logit;   /* [B,ldv] raw vocabulary logits, ldv = vocab rounded up to 4 */
+} sf_spk_decoder_tape;
+/* SpeakerDecoderLSTM.forward, non-att-feed branch (model.py:514-518).  prev_word [B] int64. */
+int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab,
+                           const int64_t* prev_word, const float* h0, const float* c0,
+                           const float* ctx, const uint8_t* ctx_mask,
+                           const sf_spk_decoder_tape* tape, const sf_dropout* drop,
+                           uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream);
+int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E,
+                           int H, int Tp, int vocab, const float* h0, const float* c0,
+                           const float* ctx, const sf_spk_decoder_tape* tape, const float* dlogit,
+                           const float* dh1, const float* dc1, float* dh0, float* dc0, float* dctx,
+                           const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                           sf_stream stream);
+/* speaker.py:163-191: log-softmax over the vocabulary, NLL terms against target (PAD ignored),
+ * next word (feedback 0 = teacher, 1 = argmax), score[b] = log p(w_t) (0 if w_t == PAD),
+ * ended[b] |= (w_t == EOS).  nll_term/live as in sf_follower_glue_fwd. */
+int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
+                        int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
+                        float* score, float* nll_term, float* live, sf_stream stream);
+int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
+                        int pad_idx, const float* gscale, float* dlogit, sf_stream stream);
+
+/* Small utilities used by the host mirror (kept on the stream so rollouts never sync). */
+int sf_fill_f32(float* p, size_t n, float v, sf_stream stream);
+/* dst[b, :N] (row stride ldd) = dropout(src[b, :N]) at site `drop_stream`, columns col0.. */
+int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,
+                    const sf_dropout* drop, uint32_t drop_stream, int col0, sf_stream stream);
+/* embedding rows: out[b,:] = table[idx[b],:]  (model.py:497) */
+int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float* out,
+                     sf_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SF_HIP_H_ */

@@ -1,0 +1,163 @@
+"""ctypes binding of libsf_hip.so (C ABI in include/sf_hip.h).
+
+There is deliberately NO fallback: if the library is missing or an entry point is
+absent, importing this module raises.  A non-zero status from any call raises
+SfError.  PyTorch only supplies device memory (`tensor.data_ptr()`) and the
+current HIP stream.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libsf_hip.so')
+
+c_f = C.c_void_p          # device float*
+c_p = C.c_void_p
+
+
+class SfError(RuntimeError):
+    pass
+
+
+class Dropout(C.Structure):
+    _fields_ = [('p', C.c_float), ('seed', C.c_uint32), ('row0', C.c_int32)]
+
+
+class Pano(C.Structure):
+    _fields_ = [('dense', c_p), ('table', c_p), ('loc_table', c_p), ('vp', c_p), ('view', c_p),
+                ('V', C.c_int32), ('IMG', C.c_int32), ('LOC', C.c_int32)]
+
+
+class Cands(C.Structure):
+    _fields_ = [('dense', c_p), ('table', c_p), ('vp', c_p), ('cand_view', c_p),
+                ('cand_sincos', c_p), ('a_num', c_p),
+                ('A', C.c_int32), ('V', C.c_int32), ('IMG', C.c_int32), ('LOC', C.c_int32)]
+
+
+def _ptr_struct(name, fields):
+    return type(name, (C.Structure,), {'_fields_': [(f, c_p) for f in fields]})
+
+
+LstmW = _ptr_struct('LstmW', ['w_ih', 'w_hh', 'b_ih', 'b_hh'])
+VisualW = _ptr_struct('VisualW', ['w_h', 'b_h', 'w_v', 'b_v'])
+SoftdotW = _ptr_struct('SoftdotW', ['w_in', 'w_out'])
+ScoringW = _ptr_struct('ScoringW', ['w_h', 'b_h', 'w_a', 'b_a', 'w_out', 'b_out'])
+
+
+class DecoderW(C.Structure):
+    _fields_ = [('lstm', LstmW), ('visual', VisualW), ('text', SoftdotW), ('action', ScoringW)]
+
+
+DecoderTape = _ptr_struct('DecoderTape', ['t_v', 'q', 'alpha_v', 'xin', 'gates', 'c1', 'h1', 'cat2',
+                                          't_text', 'alpha', 'h_tilde', 't_a', 'wt', 'r', 'logit'])
+
+
+class EncoderW(C.Structure):
+    _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p)]
+
+
+class EncoderG(C.Structure):
+    _fields_ = [('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p)]
+
+
+EncoderTape = _ptr_struct('EncoderTape', ['emb', 'xg', 'gates', 'hs', 'cs'])
+
+
+class SpkDecoderW(C.Structure):
+    _fields_ = [('embedding', c_p), ('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p),
+                ('b_out', c_p)]
+
+
+class SpkDecoderG(C.Structure):
+    _fields_ = [('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p), ('b_out', c_p)]
+
+
+SpkDecoderTape = _ptr_struct('SpkDecoderTape', ['emb', 'gates', 'c1', 'h1', 'cat2', 't_text',
+                                                'alpha', 'h_tilde', 'logit'])
+
+i32, u32, i64p = C.c_int, C.c_uint32, C.c_void_p
+P = C.POINTER
+WS = [c_p, C.c_size_t, c_p]          # ws, ws_bytes, stream
+
+_SIGNATURES = {
+    'sf_workspace_bytes': (C.c_size_t, []),
+    'sf_abi_version': (C.c_int, []),
+    'sf_status_string': (C.c_char_p, [C.c_int]),
+    'sf_linear_fwd': (C.c_int, [c_f, i32, c_f, c_f, i32, i32, i32, i32, c_f, i32] + WS),
+    'sf_linear_bwd': (C.c_int, [c_f, i32, c_f, c_f, i32, c_f, i32, i32, i32, i32, i32, c_f, i32,
+                                i32, c_f, c_f] + WS),
+    'sf_lstm_cell_fwd': (C.c_int, [P(LstmW), i32, i32, i32, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f,
+                                   i32, P(Dropout), u32] + WS),
+    'sf_lstm_cell_bwd': (C.c_int, [P(LstmW), P(LstmW), i32, i32, i32, c_f, i32, c_f, c_f, c_f, c_f,
+                                   c_f, c_f, c_f, i32, c_f, c_f] + WS),
+    'sf_visual_attention_fwd': (C.c_int, [P(VisualW), P(Pano), i32, i32, i32, c_f, c_f, i32, c_f,
+                                          c_f, c_f, P(Dropout), u32, i32] + WS),
+    'sf_visual_attention_bwd': (C.c_int, [P(VisualW), P(VisualW), P(Pano), i32, i32, i32, c_f, c_f,
+                                          c_f, c_f, i32, P(Dropout), u32, i32, c_f] + WS),
+    'sf_soft_dot_attention_fwd': (C.c_int, [P(SoftdotW), i32, i32, i32, c_f, i32, c_f, c_p, c_f,
+                                            c_f, c_f, c_f] + WS),
+    'sf_soft_dot_attention_bwd': (C.c_int, [P(SoftdotW), P(SoftdotW), i32, i32, i32, c_f, c_f, c_f,
+                                            c_f, c_f, c_f, c_f, i32, c_f] + WS),
+    'sf_eltwise_prod_scoring_fwd': (C.c_int, [P(ScoringW), P(Cands), i32, i32, i32, c_f, c_f, c_f,
+                                              c_f, c_f] + WS),
+    'sf_eltwise_prod_scoring_bwd': (C.c_int, [P(ScoringW), P(ScoringW), P(Cands), i32, i32, i32,
+                                              c_f, c_f, c_f, c_f, c_f] + WS),
+    'sf_attn_decoder_fwd': (C.c_int, [P(DecoderW), P(Pano), P(Cands), i32, i32, i32, i32, c_f, c_f,
+                                      c_f, c_f, c_p, P(DecoderTape), P(Dropout), u32] + WS),
+    'sf_attn_decoder_bwd': (C.c_int, [P(DecoderW), P(DecoderW), P(Pano), P(Cands), i32, i32, i32,
+                                      i32, c_f, c_f, c_f, P(DecoderTape), c_f, c_f, c_f, c_f, c_f,
+                                      c_f, P(Dropout), u32] + WS),
+    'sf_follower_glue_fwd': (C.c_int, [P(Cands), i32, c_f, c_f, i64p, i32, c_p, i64p, i64p, c_f,
+                                       c_f, c_f, c_f, c_p]),
+    'sf_follower_glue_bwd': (C.c_int, [i32, i32, c_f, i64p, c_f, c_f, c_p]),
+    'sf_reduce_terms': (C.c_int, [c_f, c_f, i32, i32, c_f, c_p]),
+    'sf_loss_finalize': (C.c_int, [c_f, i32, c_f, c_f, c_p]),
+    'sf_encoder_lstm_fwd': (C.c_int, [P(EncoderW), i32, i32, i32, i32, i32, i64p, c_p, c_f, c_f,
+                                      c_f, P(EncoderTape), P(Dropout), u32] + WS),
+    'sf_encoder_lstm_bwd': (C.c_int, [P(EncoderW), P(EncoderG), i32, i32, i32, i32, c_p, c_f, c_f,
+                                      c_f, c_f, P(EncoderTape), P(Dropout), u32] + WS),
+    'sf_gather_panorama': (C.c_int, [P(Pano), i32, c_f, c_p]),
+    'sf_gather_candidates': (C.c_int, [P(Cands), i32, c_f, c_f, c_p]),
+    'sf_gather_actions': (C.c_int, [P(Cands), i32, c_p, c_f, c_p]),
+    'sf_speaker_decoder_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i64p, c_f, c_f,
+                                         c_f, c_p, P(SpkDecoderTape), P(Dropout), u32] + WS),
+    'sf_speaker_decoder_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32,
+                                         c_f, c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, c_f,
+                                         c_f, P(Dropout), u32] + WS),
+    'sf_speaker_glue_fwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, i32, i32, c_p, i64p, c_f, c_f,
+                                      c_f, c_p]),
+    'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),
+    'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
+    'sf_dropout_copy': (C.c_int, [c_f, i32, i32, i32, c_f, i32, P(Dropout), u32, i32, c_p]),
+    'sf_embedding_fwd': (C.c_int, [c_f, i32, i64p, i32, c_f, c_p]),
+}
+
+EXPORTS = tuple(_SIGNATURES)
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            'libsf_hip.so is missing (%s). Build it with `python -m speaker_follower_amd.build`; '
+            'there is no CPU fallback for the speaker/follower hot path.' % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    if lib.sf_abi_version() != 1:
+        raise ImportError('libsf_hip.so ABI version mismatch')
+    return lib
+
+
+lib = _load()
+
+
+def check(status, what=''):
+    if status != 0:
+        raise SfError('%s failed: %s (status %d)' % (what or 'libsf_hip call',
+                                                      lib.sf_status_string(status).decode(), status))
+
+
+def call(name, *args):
+    check(getattr(lib, name)(*args), name)

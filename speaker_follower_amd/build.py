@@ -1,0 +1,71 @@
+"""Build libsf_hip.so (the C-ABI HIP library) in-tree with hipcc for gfx950.
+
+    python -m speaker_follower_amd.build          # incremental
+    python -m speaker_follower_amd.build --force  # rebuild everything
+
+hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU
+box with the working tree.
+"""
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(PKG, 'csrc')
+OBJ = os.path.join(CSRC, 'build')
+LIB = os.path.join(PKG, 'libsf_hip.so')
+ARCH = 'gfx950'
+SOURCES = ['sf_gemm.hip', 'sf_attention.hip', 'sf_pointwise.hip', 'sf_api.hip']
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'
+        ]
+
+
+def _hipcc():
+    exe = shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(exe):
+        raise RuntimeError('hipcc not found: cannot build libsf_hip.so')
+    return exe
+
+
+def _deps_mtime():
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
+    headers.append(os.path.join(os.path.dirname(PKG), 'include', 'sf_hip.h'))
+    return max(os.path.getmtime(h) for h in headers)
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+    path = os.path.join(CSRC, src)
+    if (not force and os.path.exists(obj)
+            and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime())):
+        return obj, False
+    cmd = [_hipcc()] + FLAGS + ['-c', path, '-o', obj]
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, res.stdout, res.stderr))
+    if res.stderr.strip():
+        sys.stderr.write(res.stderr)
+    return obj, True
+
+
+def build_lib(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+    objs = [o for o, _ in results]
+    rebuilt = any(r for _, r in results)
+    if rebuilt or not os.path.exists(LIB):
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (res.stdout, res.stderr))
+    if verbose:
+        print('libsf_hip.so %s (%d bytes)' % ('rebuilt' if rebuilt else 'up to date',
+                                              os.path.getsize(LIB)))
+    return LIB
+
+
+if __name__ == '__main__':
+    build_lib(force='--force' in sys.argv)

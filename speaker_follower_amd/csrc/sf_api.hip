@@ -1,0 +1,583 @@
+// extern "C" entry points of libsf_hip.so (see include/sf_hip.h) and the host-side sequencing of
+// kernels for the composite operators.  Nothing here allocates or synchronises.
+#include "sf_kernels.h"
+
+using namespace sf;
+
+namespace {
+
+constexpr size_t WORKSPACE_BYTES = 64u << 20;
+
+// Bump allocator over the caller's workspace.  Passed BY VALUE into helpers so that their
+// temporaries are released on return; whatever is left is handed to the GEMMs for split-K slabs.
+struct Arena {
+    float* base;
+    size_t cap, off;
+    float* take(size_t n) {
+        n = (n + 63) & ~(size_t)63;
+        if (off + n > cap) return nullptr;
+        float* p = base + off;
+        off += n;
+        return p;
+    }
+    float* rest() const { return base + off; }
+    size_t rest_n() const { return cap - off; }
+};
+
+inline Arena arena(void* ws, size_t bytes) { return Arena{(float*)ws, ws ? bytes / 4 : 0, 0}; }
+inline hipStream_t S(sf_stream s) { return (hipStream_t)s; }
+
+inline PanoSrc pano(const sf_pano* p) {
+    return PanoSrc{p->dense, p->table, p->loc_table, p->vp, p->view, p->V, p->IMG, p->LOC};
+}
+inline CandSrc cands(const sf_cands* c) {
+    return CandSrc{c->dense, c->table, c->vp, c->cand_view, c->cand_sincos, c->a_num,
+                   c->A, c->V, c->IMG, c->LOC};
+}
+
+#define TRY(expr)                     \
+    do {                              \
+        int _st = (expr);             \
+        if (_st != SF_OK) return _st; \
+    } while (0)
+#define NEED(ptr) \
+    if (!(ptr)) return SF_ERR_WORKSPACE
+
+int linear_plain(const float* x, int ldx, const float* w, int ldw, const float* b, int M, int N,
+                 int K, Epi epi, float* y, int ldy, Arena ar, hipStream_t st) {
+    Seg sg{x, ldx, w, ldw, K};
+    LinearOut o{};
+    o.y = y;
+    o.ldy = ldy;
+    o.bias = b;
+    o.epi = epi;
+    return linear_nt(&sg, 1, M, N, o, ar.rest(), ar.rest_n(), st);
+}
+
+// ---- a2 LSTMCell --------------------------------------------------------------------------------
+int lstm_fwd_i(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx, const float* h0,
+               const float* c0, float* h1, float* c1, float* gates, float* h1_drop, int ld_h1_drop,
+               const Dropout& drop, Arena ar, hipStream_t st) {
+    Seg segs[2] = {{x, ldx, w->w_ih, I, I}, {h0, H, w->w_hh, H, H}};
+    LinearOut o{};
+    float* slabs = nullptr;
+    int ks = 1;
+    TRY(linear_nt(segs, 2, B, 4 * H, o, ar.rest(), ar.rest_n(), st, &slabs, &ks));
+    LstmPwFwd p{};
+    p.slabs = slabs; p.ks = ks; p.xg = nullptr; p.b_ih = w->b_ih; p.b_hh = w->b_hh;
+    p.c0 = c0; p.h0 = h0; p.B = B; p.H = H; p.gates = gates; p.h1 = h1; p.c1 = c1;
+    p.h1_drop = h1_drop; p.ld_h1_drop = ld_h1_drop; p.drop = drop; p.lengths = nullptr;
+    return lstm_pointwise_fwd(p, st);
+}
+
+int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, const float* x, int ldx,
+               const float* h0, const float* c0, const float* c1, const float* gates,
+               const float* dh1, const float* dh1_b, const float* dc1, float* dx, int lddx,
+               float* dh0, float* dc0, Arena ar, hipStream_t st) {
+    float* dgates = ar.take((size_t)B * 4 * H);
+    NEED(dgates);
+    LstmPwBwd p{};
+    p.gates = gates; p.c0 = c0; p.c1 = c1; p.dh1 = dh1; p.dh1_b = dh1_b; p.dc1 = dc1;
+    p.B = B; p.H = H; p.dgates = dgates; p.dc0 = dc0; p.lengths = nullptr; p.dh0_pass = nullptr;
+    TRY(lstm_pointwise_bwd(p, st));
+    if (dx) TRY(gemm_nn_ws(dgates, 4 * H, w->w_ih, I, B, I, 4 * H, dx, lddx, 0, ar.rest(), ar.rest_n(), st));
+    if (dh0) TRY(gemm_nn_ws(dgates, 4 * H, w->w_hh, H, B, H, 4 * H, dh0, H, 0, ar.rest(), ar.rest_n(), st));
+    if (g) {
+        if (g->w_ih) TRY(gemm_tn(dgates, 4 * H, x, ldx, B, 4 * H, I, g->w_ih, I, 1, st));
+        if (g->w_hh) TRY(gemm_tn(dgates, 4 * H, h0, H, B, 4 * H, H, g->w_hh, H, 1, st));
+        if (g->b_ih) TRY(colsum(dgates, 4 * H, B, 4 * H, g->b_ih, 1, st));
+        if (g->b_hh) TRY(colsum(dgates, 4 * H, B, 4 * H, g->b_hh, 1, st));
+    }
+    return SF_OK;
+}
+
+// ---- a1 VisualSoftDotAttention ---------------------------------------------------------------------
+int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, const float* h,
+                 float* out, int ldo, float* alpha, float* t_v, float* q, const Dropout& drop,
+                 int col0, Arena ar, hipStream_t st) {
+    const int F = X.IMG + X.LOC;
+    TRY(linear_plain(h, H, w->w_h, H, w->b_h, B, D, H, EPI_NONE, t_v, D, ar, st));
+    TRY(gemm_nn_ws(t_v, D, w->w_v, F, B, F, D, q, F, 0, ar.rest(), ar.rest_n(), st));
+    return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st);
+}
+
+int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, int B, int H, int D,
+                 const float* h, const float* alpha, const float* t_v, const float* dout, int lddo,
+                 const Dropout& drop, int col0, float* dh, Arena ar, hipStream_t st) {
+    const int F = X.IMG + X.LOC;
+    float* dq = ar.take((size_t)B * F);
+    float* dt = ar.take((size_t)B * D);
+    NEED(dq && dt);
+    TRY(visual_attn(1, X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0, st));
+    TRY(linear_plain(dq, F, w->w_v, F, nullptr, B, D, F, EPI_NONE, dt, D, ar, st));
+    if (g && g->w_v) TRY(gemm_tn(t_v, D, dq, F, B, D, F, g->w_v, F, 1, st));
+    // g->b_v: the bias shifts all V scores of a row equally; its gradient is identically zero.
+    if (dh) TRY(gemm_nn_ws(dt, D, w->w_h, H, B, H, D, dh, H, 1, ar.rest(), ar.rest_n(), st));
+    if (g && g->w_h) TRY(gemm_tn(dt, D, h, H, B, D, H, g->w_h, H, 1, st));
+    if (g && g->b_h) TRY(colsum(dt, D, B, D, g->b_h, 1, st));
+    return SF_OK;
+}
+
+// ---- a3 SoftDotAttention ----------------------------------------------------------------------------
+// h lives in cat2[:, H:2H] already (copy_from != null copies it there first).
+int softdot_fwd_i(const sf_softdot_w* w, int B, int L, int H, const float* copy_from, int ldh,
+                  const float* ctx, const uint8_t* mask, float* h_tilde, float* alpha, float* cat2,
+                  float* t_text, Arena ar, hipStream_t st) {
+    if (copy_from) {
+        Dropout none = make_dropout(nullptr, 0);
+        TRY(dropout_copy(copy_from, ldh, B, H, cat2 + H, 2 * H, none, 0, st));
+    }
+    TRY(linear_plain(cat2 + H, 2 * H, w->w_in, H, nullptr, B, H, H, EPI_NONE, t_text, H, ar, st));
+    TRY(text_attn_fwd(ctx, mask, B, L, H, t_text, H, alpha, cat2, 2 * H, st));
+    return linear_plain(cat2, 2 * H, w->w_out, 2 * H, nullptr, B, H, 2 * H, EPI_TANH, h_tilde, H, ar,
+                        st);
+}
+
+int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, int H,
+                  const float* ctx, const float* alpha, const float* cat2, const float* t_text,
+                  const float* h_tilde, const float* dh_tilde, float* dh, int lddh, float* dctx,
+                  Arena ar, hipStream_t st) {
+    float* dpre = ar.take((size_t)B * H);
+    float* dcat2 = ar.take((size_t)B * 2 * H);
+    float* dt = ar.take((size_t)B * H);
+    NEED(dpre && dcat2 && dt);
+    TRY(tanh_bwd(h_tilde, H, dh_tilde, H, B, H, dpre, H, st));
+    TRY(gemm_nn_ws(dpre, H, w->w_out, 2 * H, B, 2 * H, H, dcat2, 2 * H, 0, ar.rest(), ar.rest_n(), st));
+    if (g && g->w_out) TRY(gemm_tn(dpre, H, cat2, 2 * H, B, H, 2 * H, g->w_out, 2 * H, 1, st));
+    TRY(text_attn_bwd(ctx, B, L, H, dcat2, 2 * H, t_text, H, alpha, dt, H, dctx, st));
+    TRY(add2(dcat2 + H, 2 * H, nullptr, 0, B, H, dh, lddh, st));
+    TRY(gemm_nn_ws(dt, H, w->w_in, H, B, H, H, dh, lddh, 1, ar.rest(), ar.rest_n(), st));
+    if (g && g->w_in) TRY(gemm_tn(dt, H, cat2 + H, 2 * H, B, H, H, g->w_in, H, 1, st));
+    return SF_OK;
+}
+
+// ---- a4 EltwiseProdScoring --------------------------------------------------------------------------
+int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, const float* h,
+                  float* logit, float* t_a, float* wt, float* r, Arena ar, hipStream_t st) {
+    const int F = U.IMG + U.LOC;
+    Seg sg{h, H, w->w_h, H, H};
+    LinearOut o{};
+    o.y = wt; o.ldy = D; o.bias = w->b_h; o.mul = w->w_out; o.y_pre = t_a; o.ldy_pre = D;
+    o.epi = EPI_MUL;
+    TRY(linear_nt(&sg, 1, B, D, o, ar.rest(), ar.rest_n(), st));
+    TRY(gemm_nn_ws(wt, D, w->w_a, F, B, F, D, r, F, 0, ar.rest(), ar.rest_n(), st));
+    return score_fwd(U, B, D, r, wt, w->b_a, w->b_out, logit, st);
+}
+
+int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U, int B, int H,
+                  int D, const float* h, const float* t_a, const float* wt, const float* dlogit,
+                  float* dh, Arena ar, hipStream_t st) {
+    const int F = U.IMG + U.LOC;
+    float* dr = ar.take((size_t)B * F);
+    float* dc = ar.take((size_t)B);
+    float* dwt = ar.take((size_t)B * D);
+    float* dta = ar.take((size_t)B * D);
+    NEED(dr && dc && dwt && dta);
+    TRY(score_bwd(U, B, dlogit, dr, dc, st));
+    TRY(linear_plain(dr, F, w->w_a, F, nullptr, B, D, F, EPI_NONE, dwt, D, ar, st));
+    TRY(rank1_add(dc, w->b_a, B, D, dwt, D, st));
+    if (g) {
+        if (g->w_a) TRY(gemm_tn(wt, D, dr, F, B, D, F, g->w_a, F, 1, st));
+        if (g->b_a) TRY(dot_rows_accum(dc, wt, D, B, D, g->b_a, st));
+        if (g->b_out) TRY(sum_accum(dc, B, g->b_out, st));
+        if (g->w_out) TRY(colsum_prod(dwt, D, t_a, D, B, D, g->w_out, st));
+    }
+    TRY(scale_cols(dwt, D, w->w_out, B, D, dta, D, st));
+    if (dh) TRY(gemm_nn_ws(dta, D, w->w_h, H, B, H, D, dh, H, 0, ar.rest(), ar.rest_n(), st));
+    if (g && g->w_h) TRY(gemm_tn(dta, D, h, H, B, D, H, g->w_h, H, 1, st));
+    if (g && g->b_h) TRY(colsum(dta, D, B, D, g->b_h, 1, st));
+    return SF_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sf_workspace_bytes(void) { return WORKSPACE_BYTES; }
+int sf_abi_version(void) { return SF_ABI_VERSION; }
+const char* sf_status_string(int s) {
+    switch (s) {
+        case SF_OK: return "ok";
+        case SF_ERR_ARG: return "invalid argument";
+        case SF_ERR_UNSUPPORTED: return "unsupported shape";
+        case SF_ERR_LAUNCH: return "kernel launch failed";
+        case SF_ERR_WORKSPACE: return "workspace too small";
+        default: return "unknown status";
+    }
+}
+
+int sf_linear_fwd(const float* x, int ldx, const float* w, const float* b, int M, int N, int K,
+                  int act, float* y, int ldy, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0 && (act == 0 || act == 1));
+    return linear_plain(x, ldx, w, K, b, M, N, K, act ? EPI_TANH : EPI_NONE, y, ldy,
+                        arena(ws, ws_bytes), S(stream));
+}
+
+int sf_linear_bwd(const float* x, int ldx, const float* w, const float* y, int ldy, const float* dy,
+                  int lddy, int M, int N, int K, int act, float* dx, int lddx, int accumulate_dx,
+                  float* dw, float* db, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(x && w && dy && M > 0 && N > 0 && K > 0 && (N % 4 == 0) && (K % 4 == 0));
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const float* dpre = dy;
+    int ldp = lddy;
+    if (act == 1) {
+        SF_CHECK_ARG(y);
+        float* t = ar.take((size_t)M * N);
+        NEED(t);
+        TRY(tanh_bwd(y, ldy, dy, lddy, M, N, t, N, st));
+        dpre = t;
+        ldp = N;
+    }
+    if (dx) TRY(gemm_nn_ws(dpre, ldp, w, K, M, K, N, dx, lddx, accumulate_dx, ar.rest(), ar.rest_n(), st));
+    if (dw) TRY(gemm_tn(dpre, ldp, x, ldx, M, N, K, dw, K, 1, st));
+    if (db) TRY(colsum(dpre, ldp, M, N, db, 1, st));
+    return SF_OK;
+}
+
+int sf_lstm_cell_fwd(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx,
+                     const float* h0, const float* c0, float* h1, float* c1, float* gates,
+                     float* h1_drop, int ld_h1_drop, const sf_dropout* drop, uint32_t drop_stream,
+                     void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && x && h0 && c0 && h1 && c1 && B > 0 && I > 0 && H > 0 && H % 4 == 0);
+    return lstm_fwd_i(w, B, I, H, x, ldx, h0, c0, h1, c1, gates, h1_drop, ld_h1_drop,
+                      make_dropout(drop, drop_stream), arena(ws, ws_bytes), S(stream));
+}
+
+int sf_lstm_cell_bwd(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, const float* x,
+                     int ldx, const float* h0, const float* c0, const float* c1, const float* gates,
+                     const float* dh1, const float* dc1, float* dx, int lddx, float* dh0, float* dc0,
+                     void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && x && h0 && c0 && c1 && gates && dc0 && B > 0 && H % 4 == 0 && I % 4 == 0);
+    return lstm_bwd_i(w, g, B, I, H, x, ldx, h0, c0, c1, gates, dh1, nullptr, dc1, dx, lddx, dh0,
+                      dc0, arena(ws, ws_bytes), S(stream));
+}
+
+int sf_visual_attention_fwd(const sf_visual_w* w, const sf_pano* X, int B, int H, int D,
+                            const float* h, float* out, int ldo, float* alpha, float* t_v, float* q,
+                            const sf_dropout* drop, uint32_t drop_stream, int drop_col0, void* ws,
+                            size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && X && h && out && alpha && t_v && q && B > 0);
+    return visual_fwd_i(w, pano(X), B, H, D, h, out, ldo, alpha, t_v, q,
+                        make_dropout(drop, drop_stream), drop_col0, arena(ws, ws_bytes), S(stream));
+}
+
+int sf_visual_attention_bwd(const sf_visual_w* w, const sf_visual_g* g, const sf_pano* X, int B,
+                            int H, int D, const float* h, const float* alpha, const float* t_v,
+                            const float* dout, int lddo, const sf_dropout* drop,
+                            uint32_t drop_stream, int drop_col0, float* dh, void* ws,
+                            size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && X && h && alpha && t_v && dout && B > 0);
+    return visual_bwd_i(w, g, pano(X), B, H, D, h, alpha, t_v, dout, lddo,
+                        make_dropout(drop, drop_stream), drop_col0, dh, arena(ws, ws_bytes),
+                        S(stream));
+}
+
+int sf_soft_dot_attention_fwd(const sf_softdot_w* w, int B, int L, int H, const float* h, int ldh,
+                              const float* ctx, const uint8_t* mask, float* h_tilde, float* alpha,
+                              float* cat2, float* t_text, void* ws, size_t ws_bytes,
+                              sf_stream stream) {
+    SF_CHECK_ARG(w && h && ctx && h_tilde && alpha && cat2 && t_text && B > 0 && L > 0);
+    return softdot_fwd_i(w, B, L, H, h, ldh, ctx, mask, h_tilde, alpha, cat2, t_text,
+                         arena(ws, ws_bytes), S(stream));
+}
+
+int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, int H,
+                              const float* ctx, const float* alpha, const float* cat2,
+                              const float* t_text, const float* h_tilde, const float* dh_tilde,
+                              float* dh, int lddh, float* dctx, void* ws, size_t ws_bytes,
+                              sf_stream stream) {
+    SF_CHECK_ARG(w && ctx && alpha && cat2 && t_text && h_tilde && dh_tilde && dh && B > 0);
+    return softdot_bwd_i(w, g, B, L, H, ctx, alpha, cat2, t_text, h_tilde, dh_tilde, dh, lddh, dctx,
+                         arena(ws, ws_bytes), S(stream));
+}
+
+int sf_eltwise_prod_scoring_fwd(const sf_scoring_w* w, const sf_cands* U, int B, int H, int D,
+                                const float* h, float* logit, float* t_a, float* wt, float* r,
+                                void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && U && h && logit && t_a && wt && r && B > 0);
+    return scoring_fwd_i(w, cands(U), B, H, D, h, logit, t_a, wt, r, arena(ws, ws_bytes), S(stream));
+}
+
+int sf_eltwise_prod_scoring_bwd(const sf_scoring_w* w, const sf_scoring_g* g, const sf_cands* U,
+                                int B, int H, int D, const float* h, const float* t_a,
+                                const float* wt, const float* dlogit, float* dh, void* ws,
+                                size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && U && h && t_a && wt && dlogit && B > 0);
+    return scoring_bwd_i(w, g, cands(U), B, H, D, h, t_a, wt, dlogit, dh, arena(ws, ws_bytes),
+                         S(stream));
+}
+
+// ---- a6 AttnDecoderLSTM.forward (model.py:377-397) -------------------------------------------------
+int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands* U, int B, int H,
+                        int D, int L, const float* u_prev, const float* h0, const float* c0,
+                        const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tp,
+                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                        sf_stream stream) {
+    SF_CHECK_ARG(w && X && U && u_prev && h0 && c0 && ctx && tp && B > 0 && L > 0);
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const PanoSrc xs = pano(X);
+    const int F = xs.IMG + xs.LOC;
+    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+    // model.py:389  feature, alpha_v = visual_attention(h_0, X)  -> straight into xin[:, F:2F]
+    TRY(visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
+                     d_in, F, ar, st));
+    // model.py:391-392  drop(cat(u_prev, feature))
+    TRY(dropout_copy(u_prev, F, B, F, tp->xin, 2 * F, d_in, 0, st));
+    // model.py:393-394  LSTMCell; dropout(h_1) lands in cat2[:, H:2H]
+    TRY(lstm_fwd_i(&w->lstm, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->h1, tp->c1, tp->gates,
+                   tp->cat2 + H, 2 * H, d_h, ar, st));
+    // model.py:395  text attention
+    TRY(softdot_fwd_i(&w->text, B, L, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2,
+                      tp->t_text, ar, st));
+    // model.py:396  action logits
+    return scoring_fwd_i(&w->action, cands(U), B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt,
+                         tp->r, ar, st);
+}
+
+int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
+                        const sf_cands* U, int B, int H, int D, int L, const float* h0,
+                        const float* c0, const float* ctx, const sf_decoder_tape* tp,
+                        const float* dlogit, const float* dh1, const float* dc1, float* dh0,
+                        float* dc0, float* dctx, const sf_dropout* drop, uint32_t step_id, void* ws,
+                        size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0 && L > 0);
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const PanoSrc xs = pano(X);
+    const int F = xs.IMG + xs.LOC;
+    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+    float* dht = ar.take((size_t)B * H);       // d h_tilde
+    float* dh1d = ar.take((size_t)B * H);      // d dropout(h1)
+    float* dh1m = ar.take((size_t)B * H);      // the same through the dropout mask
+    float* dxin = ar.take((size_t)B * 2 * F);  // d LSTM input
+    NEED(dht && dh1d && dh1m && dxin);
+    TRY(scoring_bwd_i(&w->action, g ? &g->action : nullptr, cands(U), B, H, D, tp->h_tilde, tp->t_a,
+                      tp->wt, dlogit, dht, ar, st));
+    TRY(softdot_bwd_i(&w->text, g ? &g->text : nullptr, B, L, H, ctx, tp->alpha, tp->cat2,
+                      tp->t_text, tp->h_tilde, dht, dh1d, H, dctx, ar, st));
+    TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
+    TRY(lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->c1,
+                   tp->gates, dh1, dh1m, dc1, dxin, 2 * F, dh0, dc0, ar, st));
+    return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
+                        dxin + F, 2 * F, d_in, F, dh0, ar, st);
+}
+
+int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const float* is_valid,
+                         const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
+                         int64_t* target_used, float* score, float* u_next, float* ce_term,
+                         float* live, sf_stream stream) {
+    SF_CHECK_ARG(U && logit && target && ended && a_t && target_used && score && ce_term && live &&
+                 B > 0 && (feedback == 0 || feedback == 1) && (is_valid || U->a_num));
+    return follower_glue_fwd(cands(U), B, logit, is_valid, target, feedback, ended, a_t,
+                             target_used, score, u_next, ce_term, live, S(stream));
+}
+
+int sf_follower_glue_bwd(int B, int A, const float* logit, const int64_t* target_used,
+                         const float* gscale, float* dlogit, sf_stream stream) {
+    SF_CHECK_ARG(logit && target_used && gscale && dlogit && B > 0 && A > 0);
+    return softmax_ce_bwd(B, A, A, logit, target_used, -1, gscale, dlogit, S(stream));
+}
+
+int sf_reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
+                    sf_stream stream) {
+    SF_CHECK_ARG(term && live && sum_cnt && T > 0 && B > 0);
+    return reduce_terms(term, live, T, B, sum_cnt, S(stream));
+}
+
+int sf_loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, sf_stream stream) {
+    SF_CHECK_ARG(sum_cnt && loss && gscale && T > 0);
+    return loss_finalize(sum_cnt, T, loss, gscale, S(stream));
+}
+
+// ---- a5 EncoderLSTM.forward (model.py:81-104) --------------------------------------------------------
+int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, int H,
+                        const int64_t* seq, const int32_t* lengths, float* ctx, float* decoder_init,
+                        float* c_t, const sf_encoder_tape* tp, const sf_dropout* drop,
+                        uint32_t drop_stream, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_CHECK_ARG(w && seq && lengths && ctx && decoder_init && c_t && tp && B > 0 && T > 0 &&
+                 T <= Lpad && E % 4 == 0 && H % 4 == 0);
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const size_t BH = (size_t)B * H;
+    // model.py:85  embedding, time-major so each step reads one contiguous [B,E] block
+    TRY(embedding_tm(w->embedding, E, seq, B, Lpad, T, tp->emb, st));
+    // hoisted input product for all steps at once: [T*B,E] x [E,4H]
+    TRY(linear_plain(tp->emb, E, w->lstm.w_ih, E, nullptr, T * B, 4 * H, E, EPI_NONE, tp->xg, 4 * H,
+                     ar, st));
+    TRY(fill(tp->hs, BH, 0.f, st));   // model.py:67-79 init_state
+    TRY(fill(tp->cs, BH, 0.f, st));
+    const Dropout dctx = make_dropout(drop, drop_stream);
+    for (int t = 0; t < T; ++t) {
+        Seg sg{tp->hs + t * BH, H, w->lstm.w_hh, H, H};
+        LinearOut o{};
+        float* slabs = nullptr;
+        int ks = 1;
+        TRY(linear_nt(&sg, 1, B, 4 * H, o, ar.rest(), ar.rest_n(), st, &slabs, &ks));
+        LstmPwFwd p{};
+        p.slabs = slabs; p.ks = ks; p.xg = tp->xg + (size_t)t * B * 4 * H;
+        p.b_ih = w->lstm.b_ih; p.b_hh = w->lstm.b_hh;
+        p.c0 = tp->cs + t * BH; p.h0 = tp->hs + t * BH; p.B = B; p.H = H;
+        p.gates = tp->gates + (size_t)t * B * 4 * H;
+        p.h1 = tp->hs + (t + 1) * BH; p.c1 = tp->cs + (t + 1) * BH;
+        p.h1_drop = nullptr; p.drop = make_dropout(nullptr, 0);
+        p.lengths = lengths; p.t = t; p.ctx_out = ctx; p.ld_ctx = T * H; p.ctx_drop = dctx;
+        TRY(lstm_pointwise_fwd(p, st));
+    }
+    // model.py:96-99  decoder_init = tanh(encoder2decoder(h_T)); c_T raw
+    TRY(linear_plain(tp->hs + T * BH, H, w->w_e2d, H, w->b_e2d, B, H, H, EPI_TANH, decoder_init, H,
+                     ar, st));
+    return add2(tp->cs + T * BH, H, nullptr, 0, B, H, c_t, H, st);
+}
+
+int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int T, int E, int H,
+                        const int32_t* lengths, const float* decoder_init, const float* dctx,
+                        const float* d_init, const float* d_ct, const sf_encoder_tape* tp,
+                        const sf_dropout* drop, uint32_t drop_stream, void* ws, size_t ws_bytes,
+                        sf_stream stream) {
+    SF_CHECK_ARG(w && lengths && decoder_init && tp && B > 0 && T > 0);
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const size_t BH = (size_t)B * H, BG = (size_t)B * 4 * H;
+    float* dh = ar.take(BH);        // gradient wrt h after step t
+    float* dc = ar.take(BH);
+    float* dcn = ar.take(BH);
+    float* dctx_t = ar.take(BH);
+    float* dpass = ar.take(BH);
+    float* dpre = ar.take(BH);
+    NEED(dh && dc && dcn && dctx_t && dpass && dpre);
+    // through decoder_init = tanh(W h_T + b)
+    if (d_init) {
+        TRY(tanh_bwd(decoder_init, H, d_init, H, B, H, dpre, H, st));
+        TRY(gemm_nn_ws(dpre, H, w->w_e2d, H, B, H, H, dh, H, 0, ar.rest(), ar.rest_n(), st));
+        if (g && g->w_e2d) TRY(gemm_tn(dpre, H, tp->hs + T * BH, H, B, H, H, g->w_e2d, H, 1, st));
+        if (g && g->b_e2d) TRY(colsum(dpre, H, B, H, g->b_e2d, 1, st));
+    } else {
+        TRY(fill(dh, BH, 0.f, st));
+    }
+    TRY(add2(d_ct, H, nullptr, 0, B, H, dc, H, st));
+    const Dropout dd = make_dropout(drop, drop_stream);
+    // dgates for step t overwrite tp->xg[t] (the hoisted product is dead after the forward)
+    for (int t = T - 1; t >= 0; --t) {
+        const float* dctx_in = nullptr;
+        if (dctx) {
+            TRY(ctx_grad_slice(dctx, T, H, B, t, dd, dctx_t, st));
+            dctx_in = dctx_t;
+        }
+        LstmPwBwd p{};
+        p.gates = tp->gates + t * BG; p.c0 = tp->cs + t * BH; p.c1 = tp->cs + (t + 1) * BH;
+        p.dh1 = dh; p.dh1_b = dctx_in; p.dc1 = dc; p.B = B; p.H = H;
+        p.dgates = tp->xg + t * BG; p.dc0 = dcn; p.lengths = lengths; p.t = t; p.dh0_pass = dpass;
+        TRY(lstm_pointwise_bwd(p, st));
+        // dh_{t} = dgates W_hh (live rows) + passthrough (dead rows)
+        TRY(add2(dpass, H, nullptr, 0, B, H, dh, H, st));
+        TRY(gemm_nn_ws(tp->xg + t * BG, 4 * H, w->lstm.w_hh, H, B, H, 4 * H, dh, H, 1, ar.rest(),
+                       ar.rest_n(), st));
+        std::swap(dc, dcn);
+    }
+    if (g) {
+        // all time steps in one product each: reduction depth T*B
+        if (g->lstm.w_hh) TRY(gemm_tn(tp->xg, 4 * H, tp->hs, H, T * B, 4 * H, H, g->lstm.w_hh, H, 1, st));
+        if (g->lstm.w_ih) TRY(gemm_tn(tp->xg, 4 * H, tp->emb, E, T * B, 4 * H, E, g->lstm.w_ih, E, 1, st));
+        if (g->lstm.b_ih) TRY(colsum(tp->xg, 4 * H, T * B, 4 * H, g->lstm.b_ih, 1, st));
+        if (g->lstm.b_hh) TRY(colsum(tp->xg, 4 * H, T * B, 4 * H, g->lstm.b_hh, 1, st));
+    }
+    return SF_OK;
+}
+
+// ---- a11 gathers ---------------------------------------------------------------------------------------
+int sf_gather_panorama(const sf_pano* X, int B, float* out, sf_stream stream) {
+    SF_CHECK_ARG(X && out && B > 0 && X->table && X->loc_table && X->vp && X->view);
+    return gather_panorama(pano(X), B, out, S(stream));
+}
+int sf_gather_candidates(const sf_cands* U, int B, float* all_u, float* is_valid, sf_stream stream) {
+    SF_CHECK_ARG(U && all_u && B > 0 && U->table && U->vp && U->cand_view && U->cand_sincos && U->a_num);
+    return gather_candidates(cands(U), B, all_u, is_valid, S(stream));
+}
+int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf_stream stream) {
+    SF_CHECK_ARG(U && a && out && B > 0);
+    return gather_actions(cands(U), B, a, out, S(stream));
+}
+
+// ---- a9 SpeakerDecoderLSTM.forward (model.py:497-519) -----------------------------------------------------
+int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab,
+                           const int64_t* prev_word, const float* h0, const float* c0,
+                           const float* ctx, const uint8_t* ctx_mask, const sf_spk_decoder_tape* tp,
+                           const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                           sf_stream stream) {
+    SF_CHECK_ARG(w && prev_word && h0 && c0 && ctx && tp && B > 0 && Tp > 0 && vocab > 0);
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const int ldv = (vocab + 3) & ~3;
+    const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
+    TRY(embedding_rows(w->embedding, E, prev_word, B, tp->emb, st));             // :497-498
+    TRY(lstm_fwd_i(&w->lstm, B, E, H, tp->emb, E, h0, c0, tp->h1, tp->c1, tp->gates, tp->cat2 + H,
+                   2 * H, d_h, ar, st));                                          // :515-516
+    TRY(softdot_fwd_i(&w->attn, B, Tp, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2,
+                      tp->t_text, ar, st));                                       // :517
+    if (ldv != vocab) TRY(fill(tp->logit, (size_t)B * ldv, 0.f, st));
+    return linear_plain(tp->h_tilde, H, w->w_out, H, w->b_out, B, vocab, H, EPI_NONE, tp->logit, ldv,
+                        ar, st);                                                  // :518
+}
+
+int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H,
+                           int Tp, int vocab, const float* h0, const float* c0, const float* ctx,
+                           const sf_spk_decoder_tape* tp, const float* dlogit, const float* dh1,
+                           const float* dc1, float* dh0, float* dc0, float* dctx,
+                           const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                           sf_stream stream) {
+    SF_CHECK_ARG(w && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0);
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const int ldv = (vocab + 3) & ~3;
+    const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
+    float* dht = ar.take((size_t)B * H);
+    float* dh1d = ar.take((size_t)B * H);
+    float* dh1m = ar.take((size_t)B * H);
+    NEED(dht && dh1d && dh1m);
+    // dlogit [B,ldv] has zeros in its padding columns
+    TRY(gemm_nn_ws(dlogit, ldv, w->w_out, H, B, H, vocab, dht, H, 0, ar.rest(), ar.rest_n(), st));
+    if (g && g->w_out) TRY(gemm_tn(dlogit, ldv, tp->h_tilde, H, B, vocab, H, g->w_out, H, 1, st));
+    if (g && g->b_out) TRY(colsum(dlogit, ldv, B, vocab, g->b_out, 1, st));
+    TRY(softdot_bwd_i(&w->attn, g ? &g->attn : nullptr, B, Tp, H, ctx, tp->alpha, tp->cat2,
+                      tp->t_text, tp->h_tilde, dht, dh1d, H, dctx, ar, st));
+    TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
+    // the GloVe embedding is frozen (model.py:472): no gradient wrt the LSTM input is needed
+    return lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, E, H, tp->emb, E, h0, c0, tp->c1,
+                      tp->gates, dh1, dh1m, dc1, nullptr, 0, dh0, dc0, ar, st);
+}
+
+int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
+                        int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
+                        float* score, float* nll_term, float* live, sf_stream stream) {
+    SF_CHECK_ARG(logit && target && ended && w_t && score && nll_term && live && B > 0 &&
+                 vocab > 0 && ldv >= vocab);
+    return speaker_glue_fwd(B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t,
+                            score, nll_term, live, S(stream));
+}
+
+int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
+                        int pad_idx, const float* gscale, float* dlogit, sf_stream stream) {
+    SF_CHECK_ARG(logit && target && gscale && dlogit && B > 0 && vocab > 0 && ldv >= vocab);
+    return softmax_ce_bwd(B, vocab, ldv, logit, target, pad_idx, gscale, dlogit, S(stream));
+}
+
+int sf_fill_f32(float* p, size_t n, float v, sf_stream stream) {
+    SF_CHECK_ARG(p || n == 0);
+    return fill(p, n, v, S(stream));
+}
+
+int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,
+                    const sf_dropout* drop, uint32_t drop_stream, int col0, sf_stream stream) {
+    SF_CHECK_ARG(src && dst && B > 0 && N > 0);
+    return dropout_copy(src, lds, B, N, dst, ldd, make_dropout(drop, drop_stream), col0, S(stream));
+}
+
+int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float* out,
+                     sf_stream stream) {
+    SF_CHECK_ARG(table && idx && out && B > 0 && E > 0);
+    return embedding_rows(table, E, idx, B, out, S(stream));
+}
+
+}  // extern "C"

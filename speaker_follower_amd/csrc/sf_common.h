@@ -1,0 +1,97 @@
+// Shared device/host helpers for the speaker/follower HIP hot path (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <algorithm>
+
+#include "../../include/sf_hip.h"
+
+namespace sf {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int WAVE = 64;
+
+#define SF_CHECK_ARG(cond) \
+    do {                   \
+        if (!(cond)) return SF_ERR_ARG; \
+    } while (0)
+
+// Launch-error check that does not synchronise (safe under stream capture).
+static inline int launch_status() {
+    return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+__device__ __forceinline__ float dot4(const float4 a, const float4 b) {
+    return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------------------------------------
+// Counter-based dropout (mirrored bit-for-bit by oracle/rng.py).  keep iff hash >= p * 2^32.
+// `row` is the GLOBAL row id of the sample (so results do not depend on how a batch is sharded
+// over ranks), `stream` identifies the dropout site and time step.
+// ---------------------------------------------------------------------------------------------
+__host__ __device__ __forceinline__ uint32_t fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+
+__host__ __device__ __forceinline__ uint32_t dropout_row_key(uint32_t seed, uint32_t stream,
+                                                             uint32_t row) {
+    uint32_t key = fmix32(seed + 0x9E3779B9u * stream);
+    return fmix32(key ^ (row * 0x85EBCA6Bu));
+}
+
+__host__ __device__ __forceinline__ bool dropout_keep(uint32_t row_key, uint32_t col,
+                                                      uint32_t thresh) {
+    return fmix32(row_key + col * 0x9E3779B9u) >= thresh;
+}
+
+struct Dropout {            // p == 0 (thresh == 0) means "eval mode": everything kept, scale 1
+    uint32_t seed;
+    uint32_t stream;
+    uint32_t thresh;        // p * 2^32
+    float scale;            // 1 / (1 - p)
+    int row0;               // global row id of local row 0
+    __host__ __device__ bool on() const { return thresh != 0; }
+};
+
+static inline Dropout make_dropout(const sf_dropout* d, uint32_t stream) {
+    Dropout r;
+    r.seed = d ? d->seed : 0;
+    r.stream = stream;
+    double p = d ? (double)d->p : 0.0;
+    if (p <= 0.0) {
+        r.thresh = 0;
+        r.scale = 1.0f;
+    } else {
+        double t = p * 4294967296.0;
+        r.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+        r.scale = (float)(1.0 / (1.0 - p));
+    }
+    r.row0 = d ? d->row0 : 0;
+    return r;
+}
+
+}  // namespace sf

@@ -1,0 +1,100 @@
+// Internal kernel-launch interface between the .hip translation units.
+#pragma once
+#include "sf_common.h"
+#include "sf_gemm.h"
+#include "sf_rows.h"
+
+namespace sf {
+
+// ---- sf_attention.hip ---------------------------------------------------------------------------
+int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
+                float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st);
+int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t,
+                  int ldt, float* alpha, float* wc, int ldwc, hipStream_t st);
+int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc,
+                  const float* t, int ldt, const float* alpha, float* dt, int lddt, float* dctx,
+                  hipStream_t st);
+int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
+              const float* b_out, float* logit, hipStream_t st);
+int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* dc, hipStream_t st);
+
+// ---- sf_gemm.hip (workspace-aware NN) -------------------------------------------------------------
+int gemm_nn_ws(const float* A, int lda, const float* W, int ldw, int M, int N, int K, float* y,
+               int ldy, int accumulate, float* ws, size_t ws_floats, hipStream_t st);
+size_t gemm_nn_ws_floats(int M, int N, int K);
+
+// ---- sf_pointwise.hip ---------------------------------------------------------------------------
+// LSTM gates: reduce `ks` split-K slabs [ks][B][4H] + b_ih + b_hh (+ xg [B,4H] hoisted input
+// product, may be null), activate, update state.  live (may be null) = per-row "t < length" flag
+// for the packed-sequence encoder: dead rows copy h0/c0 through and write zeros to ctx_out.
+struct LstmPwFwd {
+    const float* slabs; int ks;
+    const float* xg;             // [B,4H] or null
+    const float* b_ih; const float* b_hh;
+    const float* c0; const float* h0;
+    int B, H;
+    float* gates;                // [B,4H] activated (may be null)
+    float* h1; float* c1;        // [B,H]
+    float* h1_drop; int ld_h1_drop; Dropout drop;   // optional dropped copy
+    const int* lengths; int t;   // encoder only (lengths null otherwise)
+    float* ctx_out; int ld_ctx;  // encoder only: ctx[b, t, :] row stride (= T*H)
+    Dropout ctx_drop;
+};
+int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st);
+
+struct LstmPwBwd {
+    const float* gates; const float* c0; const float* c1;
+    const float* dh1; const float* dh1_b;   // two optional contributions to dh1 (either may be null)
+    const float* dc1;
+    int B, H;
+    float* dgates;               // [B,4H] pre-activation gate gradients
+    float* dc0;                  // [B,H]
+    const int* lengths; int t;   // encoder: dead rows pass dh1/dc1 through untouched, dgates = 0
+    float* dh0_pass;             // encoder: for dead rows dh0 = dh1 (written here), live rows 0
+};
+int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st);
+
+int dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd, const Dropout& d,
+                 int col0, hipStream_t st);
+// dst = (a ? a : 0) + (b ? b : 0)   [M,N] with row strides
+int add2(const float* a, int lda, const float* b, int ldb, int M, int N, float* dst, int ldd,
+         hipStream_t st);
+// dpre = dy * (1 - y^2)
+int tanh_bwd(const float* y, int ldy, const float* dy, int lddy, int M, int N, float* dpre,
+             int ldp, hipStream_t st);
+// dst[m, n] = src[m, n] * v[n]   and optionally accum[n] += sum_m src[m,n] * other[m,n]
+int scale_cols(const float* src, int lds, const float* v, int M, int N, float* dst, int ldd,
+               hipStream_t st);
+int colsum_prod(const float* a, int lda, const float* b, int ldb, int M, int N, float* out,
+                hipStream_t st);           // out[n] += sum_m a[m,n]*b[m,n]
+int rank1_add(const float* s, const float* v, int M, int N, float* dst, int ldd,
+              hipStream_t st);             // dst[m,n] += s[m] * v[n]
+int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float* out,
+                   hipStream_t st);        // out[n] += sum_m s[m] * x[m,n]
+int sum_accum(const float* s, int M, float* out, hipStream_t st);   // out[0] += sum_m s[m]
+int fill(float* p, size_t n, float v, hipStream_t st);
+int embedding_tm(const float* table, int E, const int64_t* seq, int B, int Lpad, int T, float* out,
+                 hipStream_t st);          // out[t, b, :] = table[seq[b, t], :]
+int embedding_rows(const float* table, int E, const int64_t* idx, int B, float* out,
+                   hipStream_t st);        // out[b, :] = table[idx[b], :]
+int ctx_grad_slice(const float* dctx, int T, int H, int B, int t, const Dropout& d, float* out,
+                   hipStream_t st);        // out[b,:] = dropout_mask(dctx[b,t,:])
+
+int gather_panorama(const PanoSrc& s, int B, float* out, hipStream_t st);
+int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hipStream_t st);
+int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st);
+
+int follower_glue_fwd(const CandSrc& s, int B, float* logit, const float* is_valid,
+                      const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
+                      int64_t* target_used, float* score, float* u_next, float* ce_term,
+                      float* live, hipStream_t st);
+int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,
+                   const float* gscale, float* dlogit, hipStream_t st);
+int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
+                     int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
+                     float* score, float* nll_term, float* live, hipStream_t st);
+int reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
+                 hipStream_t st);
+int loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, hipStream_t st);
+
+}  // namespace sf

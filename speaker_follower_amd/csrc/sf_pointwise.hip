@@ -1,0 +1,534 @@
+// Streaming (HBM-bound) kernels of the path: LSTM gate math, dropout, gathers from the feature
+// table, the follower/speaker per-step glue, and the small vector helpers the backward needs.
+#include "sf_kernels.h"
+
+namespace sf {
+
+namespace {
+
+constexpr int TPB = 256;
+inline int grid1d(size_t n) { return (int)std::min<size_t>((n + TPB - 1) / TPB, 4096); }
+
+// -------------------------------------------------------------------------------------------------
+// LSTM pointwise forward: one thread per (row, hidden unit)
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(TPB) void lstm_pw_fwd_kernel(LstmPwFwd a) {
+    const int H = a.H, B = a.B;
+    const size_t slab = (size_t)B * 4 * H;
+    for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
+        const int b = idx / H, j = idx - b * H;
+        float g4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const size_t o = (size_t)b * 4 * H + g * H + j;
+            float v = a.b_ih[g * H + j] + a.b_hh[g * H + j];
+            if (a.xg) v += a.xg[o];
+            for (int s = 0; s < a.ks; ++s) v += a.slabs[s * slab + o];
+            g4[g] = v;
+        }
+        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]),
+                    og = sigmoidf_(g4[3]);
+        const float c0 = a.c0[idx];
+        float c1 = fg * c0 + ig * gg;
+        float h1 = og * tanhf(c1);
+        if (a.gates) {
+            float* gp = a.gates + (size_t)b * 4 * H + j;
+            gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+        }
+        bool live = true;
+        if (a.lengths) {
+            live = a.t < a.lengths[b];
+            if (!live) { c1 = c0; h1 = a.h0[idx]; }
+            float cv = live ? h1 : 0.f;
+            if (live && a.ctx_drop.on()) {
+                const uint32_t rk = dropout_row_key(a.ctx_drop.seed, a.ctx_drop.stream,
+                                                    (uint32_t)(a.ctx_drop.row0 + b));
+                cv = dropout_keep(rk, (uint32_t)(a.t * H + j), a.ctx_drop.thresh)
+                         ? cv * a.ctx_drop.scale : 0.f;
+            }
+            a.ctx_out[(size_t)b * a.ld_ctx + (size_t)a.t * H + j] = cv;
+        }
+        a.c1[idx] = c1;
+        a.h1[idx] = h1;
+        if (a.h1_drop) {
+            float hd = h1;
+            if (a.drop.on()) {
+                const uint32_t rk = dropout_row_key(a.drop.seed, a.drop.stream,
+                                                    (uint32_t)(a.drop.row0 + b));
+                hd = dropout_keep(rk, (uint32_t)j, a.drop.thresh) ? hd * a.drop.scale : 0.f;
+            }
+            a.h1_drop[(size_t)b * a.ld_h1_drop + j] = hd;
+        }
+    }
+}
+
+// LSTM pointwise backward: dgates (pre-activation), dc0
+__global__ __launch_bounds__(TPB) void lstm_pw_bwd_kernel(LstmPwBwd a) {
+    const int H = a.H, B = a.B;
+    for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
+        const int b = idx / H, j = idx - b * H;
+        float dh = 0.f;
+        if (a.dh1) dh += a.dh1[idx];
+        if (a.dh1_b) dh += a.dh1_b[idx];
+        float dc = a.dc1 ? a.dc1[idx] : 0.f;
+        float* dg = a.dgates + (size_t)b * 4 * H + j;
+        if (a.lengths && a.t >= a.lengths[b]) {      // packed sequence: step did not happen
+            dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
+            a.dc0[idx] = dc;
+            if (a.dh0_pass) a.dh0_pass[idx] = dh;
+            continue;
+        }
+        const float* gp = a.gates + (size_t)b * 4 * H + j;
+        const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+        const float tc = tanhf(a.c1[idx]);
+        const float dout = dh * tc;
+        dc += dh * og * (1.f - tc * tc);
+        dg[0] = dc * gg * ig * (1.f - ig);
+        dg[H] = dc * a.c0[idx] * fg * (1.f - fg);
+        dg[2 * H] = dc * ig * (1.f - gg * gg);
+        dg[3 * H] = dout * og * (1.f - og);
+        a.dc0[idx] = dc * fg;
+        if (a.dh0_pass) a.dh0_pass[idx] = 0.f;
+    }
+}
+
+__global__ __launch_bounds__(TPB) void dropout_copy_kernel(const float* src, int lds, int B, int N,
+                                                           float* dst, int ldd, Dropout d,
+                                                           int col0) {
+    const size_t total = (size_t)B * N;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int b = (int)(i / N), n = (int)(i % N);
+        float v = src[(size_t)b * lds + n];
+        if (d.on()) {
+            const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
+            v = dropout_keep(rk, (uint32_t)(col0 + n), d.thresh) ? v * d.scale : 0.f;
+        }
+        dst[(size_t)b * ldd + n] = v;
+    }
+}
+
+// enc: dctx for the encoder arrives per (b, t, :) and must be dropout-masked with col = t*H + j
+__global__ __launch_bounds__(TPB) void ctx_grad_slice_kernel(const float* dctx, int T, int H, int B,
+                                                             int t, Dropout d, float* out) {
+    for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
+        const int b = idx / H, j = idx - b * H;
+        float v = dctx[((size_t)b * T + t) * H + j];
+        if (d.on()) {
+            const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
+            v = dropout_keep(rk, (uint32_t)(t * H + j), d.thresh) ? v * d.scale : 0.f;
+        }
+        out[idx] = v;
+    }
+}
+
+enum EwOp { EW_ADD2, EW_TANH_BWD, EW_SCALE_COLS, EW_RANK1_ADD };
+struct EwArgs {
+    const float* a; int lda;
+    const float* b; int ldb;
+    int M, N;
+    float* dst; int ldd;
+};
+template <int OP>
+__global__ __launch_bounds__(TPB) void ew_kernel(EwArgs e) {
+    const size_t total = (size_t)e.M * e.N;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int m = (int)(i / e.N), n = (int)(i % e.N);
+        float* o = e.dst + (size_t)m * e.ldd + n;
+        if (OP == EW_ADD2) {
+            float v = 0.f;
+            if (e.a) v += e.a[(size_t)m * e.lda + n];
+            if (e.b) v += e.b[(size_t)m * e.ldb + n];
+            *o = v;
+        } else if (OP == EW_TANH_BWD) {
+            const float y = e.a[(size_t)m * e.lda + n];
+            *o = e.b[(size_t)m * e.ldb + n] * (1.f - y * y);
+        } else if (OP == EW_SCALE_COLS) {
+            *o = e.a[(size_t)m * e.lda + n] * e.b[n];
+        } else {                                   // dst[m,n] += a[m] * b[n]
+            *o += e.a[m] * e.b[n];
+        }
+    }
+}
+
+// out[n] += sum_m a[m,n] * b[m,n]     (b == null: a[m] scalar per row times x -> see below)
+__global__ __launch_bounds__(TPB) void colsum_prod_kernel(const float* a, int lda, const float* b,
+                                                          int ldb, int M, int N, float* out) {
+    const int n = blockIdx.x * TPB + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int m = 0; m < M; ++m) s += a[(size_t)m * lda + n] * b[(size_t)m * ldb + n];
+    out[n] += s;
+}
+__global__ __launch_bounds__(TPB) void dot_rows_kernel(const float* s, const float* x, int ldx,
+                                                       int M, int N, float* out) {
+    const int n = blockIdx.x * TPB + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int m = 0; m < M; ++m) acc += s[m] * x[(size_t)m * ldx + n];
+    out[n] += acc;
+}
+__global__ void sum_accum_kernel(const float* s, int M, float* out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float acc = 0.f;
+        for (int m = 0; m < M; ++m) acc += s[m];
+        out[0] += acc;
+    }
+}
+__global__ __launch_bounds__(TPB) void fill_kernel(float* p, size_t n, float v) {
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB)
+        p[i] = v;
+}
+
+// out[t, b, :] = table[seq[b, t], :]      (time-major so that step t is one contiguous [B,E] block)
+__global__ __launch_bounds__(TPB) void embedding_tm_kernel(const float* table, int E,
+                                                           const int64_t* seq, int B, int Lpad,
+                                                           int T, float* out) {
+    const int e4 = E >> 2;
+    const size_t total = (size_t)T * B * e4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % e4);
+        const size_t tb = i / e4;
+        const int b = (int)(tb % B), t = (int)(tb / B);
+        const int64_t w = seq[(size_t)b * Lpad + t];
+        reinterpret_cast<float4*>(out)[i] = reinterpret_cast<const float4*>(table)[(size_t)w * e4 + c];
+    }
+}
+__global__ __launch_bounds__(TPB) void embedding_rows_kernel(const float* table, int E,
+                                                             const int64_t* idx, int B, float* out) {
+    const int e4 = E >> 2;
+    const size_t total = (size_t)B * e4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % e4), b = (int)(i / e4);
+        reinterpret_cast<float4*>(out)[i] =
+            reinterpret_cast<const float4*>(table)[(size_t)idx[b] * e4 + c];
+    }
+}
+
+// ---- batched gathers from the HBM feature table (a11) -------------------------------------------
+__global__ __launch_bounds__(TPB) void gather_pano_kernel(PanoSrc s, int B, float* out) {
+    const int n4 = (s.IMG + s.LOC) >> 2;
+    const size_t total = (size_t)B * s.V * n4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % n4);
+        const size_t bv = i / n4;
+        const int v = (int)(bv % s.V), b = (int)(bv / s.V);
+        reinterpret_cast<float4*>(out)[i] = pano_chunk(s, b, v, c);
+    }
+}
+__global__ __launch_bounds__(TPB) void gather_cand_kernel(CandSrc s, int B, float* all_u,
+                                                          float* is_valid) {
+    const int n4 = (s.IMG + s.LOC) >> 2;
+    const size_t total = (size_t)B * s.A * n4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % n4);
+        const size_t ba = i / n4;
+        const int a = (int)(ba % s.A), b = (int)(ba / s.A);
+        reinterpret_cast<float4*>(all_u)[i] = cand_chunk(s, b, a, c);
+        if (c == 0 && is_valid) is_valid[ba] = a < s.a_num[b] ? 1.f : 0.f;
+    }
+}
+__global__ __launch_bounds__(TPB) void gather_action_kernel(CandSrc s, int B, const int* act,
+                                                            float* out) {
+    const int n4 = (s.IMG + s.LOC) >> 2;
+    const size_t total = (size_t)B * n4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % n4), b = (int)(i / n4);
+        const int a = act[b];
+        float4 v = f4zero();
+        if (a > 0 && s.vp[b] >= 0) v = cand_chunk(s, b, a, c);
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
+// ---- follower per-step glue (follower.py:476-505): one wave per sample -----------------------------
+struct FGlue {
+    CandSrc src;
+    int B;
+    float* logit;            // [B,A] masked in place
+    const float* is_valid;   // [B,A] or null
+    const int64_t* target;
+    int feedback;
+    uint8_t* ended;
+    int64_t* a_t;
+    int64_t* target_used;
+    float* score;
+    float* u_next;           // [B,F] or null
+    float* ce_term;          // [B]
+    float* live;             // [B]
+};
+__global__ __launch_bounds__(TPB) void follower_glue_kernel(FGlue g) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (b >= g.B) return;
+    const int A = g.src.A;
+    bool valid = false;
+    if (lane < A)
+        valid = g.is_valid ? (g.is_valid[(size_t)b * A + lane] != 0.f) : (lane < g.src.a_num[b]);
+    float l = -INFINITY;
+    if (lane < A) {
+        if (valid) l = g.logit[(size_t)b * A + lane];
+        g.logit[(size_t)b * A + lane] = l;                       // follower.py:477
+    }
+    const float m = wave_max(l);
+    const float e = (lane < A && valid) ? expf(l - m) : 0.f;
+    const float lse = m + logf(wave_sum(e));
+    const bool was_ended = g.ended[b] != 0;
+    int64_t tgt = was_ended ? -1 : g.target[b];                  // follower.py:322-328
+    const float lt = __shfl(l, tgt >= 0 ? (int)tgt : 0, WAVE);
+    const float ce = tgt >= 0 ? (lse - lt) : 0.f;                // CrossEntropyLoss(ignore_index=-1)
+    int at;
+    if (g.feedback == 0) {
+        at = tgt > 0 ? (int)tgt : 0;                             // follower.py:486
+    } else {
+        const unsigned long long hit = __ballot(lane < A && l == m);
+        at = hit ? (int)__ffsll((long long)hit) - 1 : 0;         // first maximum, follower.py:488
+    }
+    const float la = __shfl(l, at, WAVE);
+    if (lane == 0) {
+        g.a_t[b] = at;
+        g.target_used[b] = tgt;
+        g.score[b] = la - lse;                                   // follower.py:504 (per-step term)
+        g.ce_term[b] = ce;
+        g.live[b] = tgt >= 0 ? 1.f : 0.f;
+        g.ended[b] = (was_ended || at == 0) ? 1 : 0;             // follower.py:527-530
+    }
+    if (g.u_next) {                                              // follower.py:502
+        const int n4 = (g.src.IMG + g.src.LOC) >> 2;
+        for (int c = lane; c < n4; c += 64)
+            reinterpret_cast<float4*>(g.u_next)[(size_t)b * n4 + c] = cand_chunk(g.src, b, at, c);
+    }
+}
+
+// softmax - onehot, scaled; rows with target == ignore get zeros.  One wave per row, any N.
+__global__ __launch_bounds__(TPB) void softmax_ce_bwd_kernel(int B, int N, int ld,
+                                                             const float* logit,
+                                                             const int64_t* target, int ignore,
+                                                             const float* gscale, float* dlogit) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (b >= B) return;
+    const int64_t tgt = target[b];
+    float* out = dlogit + (size_t)b * ld;
+    if (tgt == ignore) {
+        for (int n = lane; n < ld; n += 64) out[n] = 0.f;
+        return;
+    }
+    const float* row = logit + (size_t)b * ld;
+    float m = -INFINITY;
+    for (int n = lane; n < N; n += 64) m = fmaxf(m, row[n]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) s += expf(row[n] - m);
+    s = wave_sum(s);
+    const float gs = gscale[0];
+    for (int n = lane; n < ld; n += 64) {
+        float v = 0.f;
+        if (n < N) v = gs * (expf(row[n] - m) / s - (n == tgt ? 1.f : 0.f));
+        out[n] = v;
+    }
+}
+
+// speaker.py:163-191: one wave per sample over the vocabulary
+struct SGlue {
+    int B, vocab, ldv;
+    const float* logit;
+    const int64_t* target;
+    int feedback, pad_idx, eos_idx;
+    uint8_t* ended;
+    int64_t* w_t;
+    float* score;
+    float* nll_term;
+    float* live;
+};
+__global__ __launch_bounds__(TPB) void speaker_glue_kernel(SGlue g) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (b >= g.B) return;
+    const float* row = g.logit + (size_t)b * g.ldv;
+    float m = -INFINITY;
+    int am = 0;
+    for (int n = lane; n < g.vocab; n += 64) {
+        const float v = row[n];
+        if (v > m) { m = v; am = n; }                  // strict > keeps the lowest index per lane
+    }
+    // wave arg-max with lowest-index tie break (torch.max semantics, speaker.py:169)
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const float om = __shfl_xor(m, off, WAVE);
+        const int oa = __shfl_xor(am, off, WAVE);
+        if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+    }
+    float s = 0.f;
+    for (int n = lane; n < g.vocab; n += 64) s += expf(row[n] - m);
+    const float lse = m + logf(wave_sum(s));
+    if (lane == 0) {
+        const int64_t tgt = g.target[b];
+        const int64_t w = g.feedback == 0 ? tgt : (int64_t)am;
+        g.w_t[b] = w;
+        g.score[b] = (w != g.pad_idx) ? row[w] - lse : 0.f;      // speaker.py:179-180 (per-step term)
+        const bool lv = tgt != g.pad_idx;
+        g.nll_term[b] = lv ? lse - row[tgt] : 0.f;               // speaker.py:182
+        g.live[b] = lv ? 1.f : 0.f;
+        if (w == g.eos_idx) g.ended[b] = 1;                      // speaker.py:190-191
+    }
+}
+
+// deterministic per-step reduction of the loss terms: sum_cnt[t] = (sum_b term, sum_b live)
+__global__ __launch_bounds__(64) void reduce_terms_kernel(const float* term, const float* live,
+                                                          int B, float* sum_cnt) {
+    const int t = blockIdx.x, lane = threadIdx.x;
+    float s = 0.f, c = 0.f;
+    for (int b = lane; b < B; b += 64) {
+        s += term[(size_t)t * B + b];
+        c += live[(size_t)t * B + b];
+    }
+    s = wave_sum(s);
+    c = wave_sum(c);
+    if (lane == 0) {
+        sum_cnt[2 * t] = s;
+        sum_cnt[2 * t + 1] = c;
+    }
+}
+__global__ void loss_finalize_kernel(const float* sum_cnt, int T, float* loss, float* gscale) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        float acc = 0.f;
+        for (int t = 0; t < T; ++t) {
+            const float c = sum_cnt[2 * t + 1];
+            acc += c > 0.f ? sum_cnt[2 * t] / c : 0.f;           // follower.py:481 / speaker.py:182
+            gscale[t] = c > 0.f ? 1.f / c : 0.f;
+        }
+        loss[0] = acc;
+    }
+}
+
+}  // namespace
+
+int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st) {
+    hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(grid1d((size_t)a.B * a.H)), dim3(TPB), 0, st, a);
+    return launch_status();
+}
+int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st) {
+    hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(grid1d((size_t)a.B * a.H)), dim3(TPB), 0, st, a);
+    return launch_status();
+}
+int dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd, const Dropout& d,
+                 int col0, hipStream_t st) {
+    hipLaunchKernelGGL(dropout_copy_kernel, dim3(grid1d((size_t)B * N)), dim3(TPB), 0, st, src, lds,
+                       B, N, dst, ldd, d, col0);
+    return launch_status();
+}
+int ctx_grad_slice(const float* dctx, int T, int H, int B, int t, const Dropout& d, float* out,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(ctx_grad_slice_kernel, dim3(grid1d((size_t)B * H)), dim3(TPB), 0, st, dctx, T,
+                       H, B, t, d, out);
+    return launch_status();
+}
+template <int OP>
+static int ew(const float* a, int lda, const float* b, int ldb, int M, int N, float* dst, int ldd,
+              hipStream_t st) {
+    EwArgs e{a, lda, b, ldb, M, N, dst, ldd};
+    hipLaunchKernelGGL(ew_kernel<OP>, dim3(grid1d((size_t)M * N)), dim3(TPB), 0, st, e);
+    return launch_status();
+}
+int add2(const float* a, int lda, const float* b, int ldb, int M, int N, float* dst, int ldd,
+         hipStream_t st) {
+    return ew<EW_ADD2>(a, lda, b, ldb, M, N, dst, ldd, st);
+}
+int tanh_bwd(const float* y, int ldy, const float* dy, int lddy, int M, int N, float* dpre, int ldp,
+             hipStream_t st) {
+    return ew<EW_TANH_BWD>(y, ldy, dy, lddy, M, N, dpre, ldp, st);
+}
+int scale_cols(const float* src, int lds, const float* v, int M, int N, float* dst, int ldd,
+               hipStream_t st) {
+    return ew<EW_SCALE_COLS>(src, lds, v, 0, M, N, dst, ldd, st);
+}
+int rank1_add(const float* s, const float* v, int M, int N, float* dst, int ldd, hipStream_t st) {
+    return ew<EW_RANK1_ADD>(s, 0, v, 0, M, N, dst, ldd, st);
+}
+int colsum_prod(const float* a, int lda, const float* b, int ldb, int M, int N, float* out,
+                hipStream_t st) {
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3(ceil_div(N, TPB)), dim3(TPB), 0, st, a, lda, b, ldb,
+                       M, N, out);
+    return launch_status();
+}
+int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float* out,
+                   hipStream_t st) {
+    hipLaunchKernelGGL(dot_rows_kernel, dim3(ceil_div(N, TPB)), dim3(TPB), 0, st, s, x, ldx, M, N,
+                       out);
+    return launch_status();
+}
+int sum_accum(const float* s, int M, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(sum_accum_kernel, dim3(1), dim3(64), 0, st, s, M, out);
+    return launch_status();
+}
+int fill(float* p, size_t n, float v, hipStream_t st) {
+    if (n == 0) return SF_OK;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid1d(n)), dim3(TPB), 0, st, p, n, v);
+    return launch_status();
+}
+int embedding_tm(const float* table, int E, const int64_t* seq, int B, int Lpad, int T, float* out,
+                 hipStream_t st) {
+    if (E & 3) return SF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(embedding_tm_kernel, dim3(grid1d((size_t)T * B * (E >> 2))), dim3(TPB), 0, st,
+                       table, E, seq, B, Lpad, T, out);
+    return launch_status();
+}
+int embedding_rows(const float* table, int E, const int64_t* idx, int B, float* out,
+                   hipStream_t st) {
+    if (E & 3) return SF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(embedding_rows_kernel, dim3(grid1d((size_t)B * (E >> 2))), dim3(TPB), 0, st,
+                       table, E, idx, B, out);
+    return launch_status();
+}
+int gather_panorama(const PanoSrc& s, int B, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_pano_kernel,
+                       dim3(grid1d((size_t)B * s.V * ((s.IMG + s.LOC) >> 2))), dim3(TPB), 0, st, s, B,
+                       out);
+    return launch_status();
+}
+int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hipStream_t st) {
+    hipLaunchKernelGGL(gather_cand_kernel,
+                       dim3(grid1d((size_t)B * s.A * ((s.IMG + s.LOC) >> 2))), dim3(TPB), 0, st, s, B,
+                       all_u, is_valid);
+    return launch_status();
+}
+int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(gather_action_kernel, dim3(grid1d((size_t)B * ((s.IMG + s.LOC) >> 2))),
+                       dim3(TPB), 0, st, s, B, a, out);
+    return launch_status();
+}
+int follower_glue_fwd(const CandSrc& s, int B, float* logit, const float* is_valid,
+                      const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
+                      int64_t* target_used, float* score, float* u_next, float* ce_term,
+                      float* live, hipStream_t st) {
+    if (s.A > 64) return SF_ERR_UNSUPPORTED;
+    FGlue g{s, B, logit, is_valid, target, feedback, ended, a_t, target_used, score, u_next,
+            ce_term, live};
+    hipLaunchKernelGGL(follower_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
+    return launch_status();
+}
+int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,
+                   const float* gscale, float* dlogit, hipStream_t st) {
+    hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, B, N,
+                       ld, logit, target, ignore, gscale, dlogit);
+    return launch_status();
+}
+int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
+                     int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
+                     float* score, float* nll_term, float* live, hipStream_t st) {
+    SGlue g{B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t, score, nll_term,
+            live};
+    hipLaunchKernelGGL(speaker_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
+    return launch_status();
+}
+int reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
+                 hipStream_t st) {
+    hipLaunchKernelGGL(reduce_terms_kernel, dim3(T), dim3(64), 0, st, term, live, B, sum_cnt);
+    return launch_status();
+}
+int loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, hipStream_t st) {
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sum_cnt, T, loss, gscale);
+    return launch_status();
+}
+
+}  // namespace sf

@@ -1,0 +1,92 @@
+"""Data parallelism for follower / speaker training: one process per GPU, RCCL over xGMI
+(torch.distributed backend "nccl" on ROCm; "gloo" in the CPU tests).
+
+The R2R minibatch is sharded by rows; samples never interact in the forward or backward
+pass except through the per-step loss normaliser (CrossEntropyLoss averages over the
+non-ignored rows of the WHOLE batch, follower.py:278,481).  So exactly two exchanges exist:
+
+  1. `allreduce_step_counts`: the [steps, 2] (sum of CE terms, live-row count) table -- a few
+     hundred bytes -- so every rank scales its loss by the global denominator;
+  2. `FlatGrads.allreduce`: ONE sum all-reduce of the flat fp32 gradient buffer (56 MB for the
+     follower's 14.06 M trainable parameters) between backward() and Adam.step().  xGMI is
+     point-to-point, so one large buffer (which RCCL splits over all 7 links) beats many
+     per-tensor calls.
+
+Gradients are SUMMED, not averaged: each rank's loss already carries the global normaliser.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_rows(n_rows, rank, world):
+    """Contiguous row range of `rank` (remainder spread over the first ranks)."""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return slice(start, start + base + (1 if rank < rem else 0))
+
+
+def allreduce_step_counts(sum_cnt, group=None):
+    """In-place sum over ranks of the [steps, 2] (term sum, live count) table."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(sum_cnt, op=dist.ReduceOp.SUM, group=group)
+    return sum_cnt
+
+
+def step_losses(sum_cnt):
+    """loss = sum_t sum_t / cnt_t (0 where cnt_t == 0); gscale_t = 1 / cnt_t (0 where empty)."""
+    s, c = sum_cnt[:, 0], sum_cnt[:, 1]
+    live = c > 0
+    safe = torch.where(live, c, torch.ones_like(c))
+    return torch.where(live, s / safe, torch.zeros_like(s)).sum(), torch.where(
+        live, 1.0 / safe, torch.zeros_like(c))
+
+
+class FlatGrads:
+    """One contiguous fp32 gradient buffer; every trainable parameter's .grad is a view of it.
+
+    The HIP backward accumulates weight gradients in place into param.grad
+    (runtime.grad_ptr), i.e. straight into this buffer, so the all-reduce needs no packing.
+    Use optimizer.zero_grad(set_to_none=False) (or FlatGrads.zero()) to keep the views."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError('no trainable parameters')
+        dev = self.params[0].device
+        total = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            p.grad = self.flat[off:off + n].view_as(p)
+            off += n
+
+    def attached(self):
+        base = self.flat.data_ptr()
+        end = base + self.flat.numel() * 4
+        return all(p.grad is not None and base <= p.grad.data_ptr() < end for p in self.params)
+
+    def zero(self):
+        self.flat.zero_()
+
+    def allreduce(self, group=None):
+        if not self.attached():
+            raise RuntimeError('a parameter .grad was replaced (zero_grad(set_to_none=True)?); '
+                               'FlatGrads views are gone')
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
+        return self.flat
+
+
+def allreduce_gradients(params, group=None):
+    """Fallback for parameters whose grads are not in a FlatGrads buffer: pack, reduce, unpack."""
+    ps = [p for p in params if p.requires_grad and p.grad is not None]
+    if not ps or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    off = 0
+    for p in ps:
+        n = p.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p))
+        off += n

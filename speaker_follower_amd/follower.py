@@ -1,0 +1,240 @@
+"""Follower rollout on the HIP path.
+
+* `batch_instructions_from_encoded` -- host-side instruction batching with the reference's
+  semantics (follower.py:75-105).
+* `DeviceFollowerBatch` / `FollowerEngine` -- the whole follower episode
+  (Seq2SeqAgent._rollout_with_loss, follower.py:430-539, and
+  _score_obs_actions_and_instructions, :342-428) as a sync-free sequence of C-ABI calls over
+  index-form observations: encoder, then per step decoder + glue, with the argmax /
+  teacher feedback, `ended` flags, u_prev gather and loss terms all kept on the device.
+  Training: `engine.rollout(...).loss.backward()` runs BPTT through the C-ABI backward
+  entry points, accumulating weight gradients in place.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+from .features import cand_sincos
+from .model import (decoder_params, decoder_w_struct, _encoder_structs, _TAPE_KEYS, grad_ptr)
+from .runtime import ptr, stream, ws_args, dropout_arg
+
+byref = C.byref
+
+PAD, UNK, EOS, BOS = 0, 1, 2, 3      # utils.py:19-24
+FEEDBACK = {'teacher': 0, 'argmax': 1}
+
+
+def batch_instructions_from_encoded(encoded_instructions, max_length, reverse=False, sort=False,
+                                    device=None):
+    """follower.py:75-105.  Returns (seq [B,max_length] int64, mask [B,max(len)] bool
+    (True = PAD), lengths list[, perm list]); tensors on `device` (default: cuda if present)."""
+    n = len(encoded_instructions)
+    seq = np.full((n, max_length), PAD, np.int64)
+    lengths = []
+    for i, inst in enumerate(encoded_instructions):
+        inst = np.asarray(inst, np.int64)
+        if len(inst) > 0:
+            assert inst[-1] != EOS
+        if reverse:
+            inst = inst[::-1]
+        inst = np.concatenate((inst, [EOS]))[:max_length]
+        seq[i, :len(inst)] = inst
+        lengths.append(len(inst))
+    perm = None
+    if sort:
+        perm = np.argsort(-np.asarray(lengths), kind='stable')
+        lengths = [lengths[i] for i in perm]
+        seq = seq[perm]
+    mask = (seq == PAD)[:, :max(lengths)]
+    if device is None:
+        device = 'cuda' if torch.cuda.is_available() else 'cpu'
+    seq_t = torch.from_numpy(seq).to(device)
+    mask_t = torch.from_numpy(np.ascontiguousarray(mask)).to(device)
+    if sort:
+        return seq_t, mask_t, lengths, list(perm)
+    return seq_t, mask_t, lengths
+
+
+@dataclass
+class DeviceFollowerBatch:
+    """Index-form episode batch resident in HBM (see synth.FollowerBatch for the fields)."""
+    seq: torch.Tensor          # [B,Lpad] int64
+    lengths: list
+    lengths_dev: torch.Tensor  # [B] int32
+    mask: torch.Tensor         # [B,T] uint8, 1 = PAD
+    vp: torch.Tensor           # [S,B] int32
+    view: torch.Tensor         # [S,B] int32
+    a_num: torch.Tensor        # [S,B] int32
+    cand_view: torch.Tensor    # [S,B,A] int32
+    sincos: torch.Tensor       # [S,B,A,4] fp32
+    target: torch.Tensor       # [S,B] int64
+    a_max: int
+    row0: int = 0              # global id of row 0 (data-parallel shard offset)
+
+    @property
+    def batch_size(self):
+        return self.seq.shape[0]
+
+    @classmethod
+    def from_synth(cls, fb, device='cuda', max_length=80, reverse=True, rows=None, row0=0):
+        """Upload a synth.FollowerBatch (optionally only `rows`, a slice, for data parallelism)."""
+        sl = rows if rows is not None else slice(None)
+        instr = fb.instr[sl]
+        seq, mask, lengths = batch_instructions_from_encoded(instr, max_length, reverse=reverse,
+                                                             device=device)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)  # noqa: E731
+        return cls(seq=seq, lengths=lengths,
+                   lengths_dev=torch.tensor(lengths, dtype=torch.int32, device=device),
+                   mask=mask.to(torch.uint8).contiguous(),
+                   vp=dev(fb.vp[:, sl], torch.int32), view=dev(fb.view[:, sl], torch.int32),
+                   a_num=dev(fb.a_num[:, sl], torch.int32),
+                   cand_view=dev(fb.cand_view[:, sl], torch.int32),
+                   sincos=dev(cand_sincos(fb.cand_heading[:, sl], fb.cand_elevation[:, sl]),
+                              torch.float32),
+                   target=dev(fb.target[:, sl], torch.int64), a_max=fb.a_max, row0=row0)
+
+
+class RolloutState:
+    """Everything one rollout keeps in HBM: per-step tapes and the glue outputs."""
+    pass
+
+
+class _RolloutLossFn(torch.autograd.Function):
+    """Connects the engine's device-side loss to torch autograd: backward() runs BPTT."""
+
+    @staticmethod
+    def forward(ctx, engine, state, *params):
+        ctx.engine, ctx.state = engine, state
+        return state.loss_buf.clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        ctx.engine._backward(ctx.state, dloss)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+class FollowerEngine:
+    def __init__(self, encoder, decoder, store, group=None):
+        self.encoder, self.decoder, self.store = encoder, decoder, store
+        self.group = group              # torch.distributed process group for data parallelism
+        self.iteration = 0
+        self.dropout_seed = None
+
+    # ------------------------------------------------------------------------------ forward
+    def rollout(self, batch, steps, feedback='argmax', train=None):
+        """Runs encoder + `steps` decode steps.  Returns a RolloutState with
+        .logits [S,B,A] (masked), .actions [S,B], .step_scores [S,B], .loss (0-dim tensor,
+        differentiable when parameters require grad and grad mode is on), .h, .c, .ctx."""
+        enc, dec, store = self.encoder, self.decoder, self.store
+        dev = store.device
+        B, A, S = batch.batch_size, batch.a_max, steps
+        H, E = enc.hidden_size, enc.embedding_size
+        F, V = store.F, store.V
+        D = dec.visual_attention_layer.linear_in_h.weight.shape[0]
+        T = max(batch.lengths)
+        Lpad = batch.seq.shape[1]
+        training = dec.training if train is None else train
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        st = RolloutState()
+        st.batch, st.steps, st.dims = batch, S, (B, A, H, E, F, V, D, T)
+        st.feedback = FEEDBACK[feedback]
+
+        # dropout configuration: one seed per engine, site ids advance with the iteration
+        p_dec = dec.drop.p if training else 0.0
+        p_enc = enc.drop.p if training else 0.0
+        if self.dropout_seed is None:
+            self.dropout_seed = torch.initial_seed() & 0xFFFFFFFF
+        st.drop_dec = (p_dec, self.dropout_seed, batch.row0)
+        st.drop_enc = (p_enc, self.dropout_seed ^ 0x5BD1E995, batch.row0)
+        st.site0 = self.iteration * 64
+        self.iteration += 1
+
+        # ---- encoder (model.py:81-104)
+        st.ctx, st.h_init, st.c_init = new(B, T, H), new(B, H), new(B, H)
+        st.enc_tape = dict(emb=new(T, B, E), xg=new(T, B, 4 * H), gates=new(T, B, 4 * H),
+                           hs=new(T + 1, B, H), cs=new(T + 1, B, H))
+        etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
+        ew = _encoder_structs(enc)
+        call('sf_encoder_lstm_fwd', byref(ew), B, Lpad, T, E, H, ptr(batch.seq),
+             ptr(batch.lengths_dev), ptr(st.ctx), ptr(st.h_init), ptr(st.c_init), byref(etp),
+             dropout_arg(*st.drop_enc), st.site0, *ws_args(dev))
+
+        # ---- decode steps
+        shapes = dict(t_v=(D,), q=(F,), alpha_v=(V,), xin=(2 * F,), gates=(4 * H,), c1=(H,),
+                      h1=(H,), cat2=(2 * H,), t_text=(H,), alpha=(T,), h_tilde=(H,), t_a=(D,),
+                      wt=(D,), r=(F,), logit=(A,))
+        st.tape = {k: new(S, B, *shapes[k]) for k in _TAPE_KEYS}
+        st.u = torch.zeros(S + 1, B, F, device=dev, dtype=torch.float32)     # u[0] = u_begin
+        st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
+        st.actions = torch.empty(S, B, dtype=torch.int64, device=dev)
+        st.target_used = torch.empty(S, B, dtype=torch.int64, device=dev)
+        st.step_scores, st.ce_term, st.live = new(S, B), new(S, B), new(S, B)
+        st.sum_cnt, st.gscale, st.loss_buf = new(S, 2), new(S), new(1)
+        params = decoder_params(dec)
+        dw = decoder_w_struct(params)
+        ws = ws_args(dev)
+        for t in range(S):
+            pano = store.pano(batch.vp[t], batch.view[t])
+            cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
+            tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
+            h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
+            c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
+            call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T,
+                 ptr(st.u[t]), ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), byref(tp),
+                 dropout_arg(*st.drop_dec), st.site0 + t, *ws)
+            call('sf_follower_glue_fwd', byref(cnd), B, ptr(st.tape['logit'][t]), None,
+                 ptr(batch.target[t]), st.feedback, ptr(st.ended), ptr(st.actions[t]),
+                 ptr(st.target_used[t]), ptr(st.step_scores[t]), ptr(st.u[t + 1]),
+                 ptr(st.ce_term[t]), ptr(st.live[t]), ws[2])
+        call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
+        if self.group is not None:
+            # global per-step normaliser so that the sharded loss equals the reference's batch mean
+            torch.distributed.all_reduce(st.sum_cnt, group=self.group)
+        call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
+        st.logits = st.tape['logit']
+        st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
+
+        all_params = list(params) + [p for p in enc.parameters()]
+        if torch.is_grad_enabled() and any(p.requires_grad for p in all_params):
+            st.loss = _RolloutLossFn.apply(self, st, *all_params)
+        else:
+            st.loss = st.loss_buf.clone().reshape(())
+        return st
+
+    # ------------------------------------------------------------------------------ backward
+    def _backward(self, st, dloss):
+        enc, dec, store = self.encoder, self.decoder, self.store
+        batch, S = st.batch, st.steps
+        B, A, H, E, F, V, D, T = st.dims
+        dev = store.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        gscale = st.gscale * dloss.to(torch.float32)        # d loss / d step-loss, per step
+        params = decoder_params(dec)
+        dw, dg = decoder_w_struct(params), decoder_w_struct(params, grad=True)
+        dlogit = new(B, A)
+        dh_a, dc_a, dh_b, dc_b = new(B, H), new(B, H), new(B, H), new(B, H)
+        dctx = torch.zeros(B, T, H, device=dev, dtype=torch.float32)
+        ws = ws_args(dev)
+        dh1 = dc1 = None
+        for t in range(S - 1, -1, -1):
+            pano = store.pano(batch.vp[t], batch.view[t])
+            cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
+            tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
+            h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
+            c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
+            call('sf_follower_glue_bwd', B, A, ptr(st.tape['logit'][t]), ptr(st.target_used[t]),
+                 ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
+            call('sf_attn_decoder_bwd', byref(dw), byref(dg), byref(pano), byref(cnd), B, H, D, T,
+                 ptr(h0), ptr(c0), ptr(st.ctx), byref(tp), ptr(dlogit), ptr(dh1), ptr(dc1),
+                 ptr(dh_a), ptr(dc_a), ptr(dctx), dropout_arg(*st.drop_dec), st.site0 + t, *ws)
+            dh1, dc1 = dh_a, dc_a
+            dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
+        etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
+        ew, eg = _encoder_structs(enc), _encoder_structs(enc, grad=True)
+        call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
+             ptr(st.h_init), ptr(dctx), ptr(dh1), ptr(dc1), byref(etp), dropout_arg(*st.drop_enc),
+             st.site0, *ws)

@@ -1,0 +1,104 @@
+"""Host-side plumbing between torch tensors and the C ABI: raw pointers, the current
+HIP stream, the scratch workspace, and the pointer structs of include/sf_hip.h.
+
+PyTorch is used for device memory and streams only; every arithmetic op on the hot
+path goes through libsf_hip.so.  There is no CPU implementation: tensors that are
+not on a GPU raise.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import lib, check  # noqa: F401
+
+_workspaces = {}
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                'speaker_follower_amd: the hot path runs on MI355X through libsf_hip.so only; '
+                'got a %s tensor (there is no CPU fallback)' % t.device)
+
+
+def ptr(t):
+    """Device pointer of a contiguous fp32/int tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_contiguous():
+        raise ValueError('non-contiguous tensor passed to the C ABI')
+    return C.c_void_p(t.data_ptr())
+
+
+def f32(t):
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise TypeError('expected float32, got %s' % t.dtype)
+    return t.contiguous()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(device):
+    """One scratch buffer per (device, stream): split-K slabs and backward temporaries."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None:
+        ws = torch.empty(lib.sf_workspace_bytes(), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def ws_args(device):
+    ws = workspace(device)
+    return C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), stream()
+
+
+def dropout_arg(p, seed, row0=0):
+    """sf_dropout* (NULL when p == 0: eval mode)."""
+    if not p:
+        return None
+    return C.byref(_lib.Dropout(float(p), int(seed) & 0xFFFFFFFF, int(row0)))
+
+
+def grad_ptr(param):
+    """Pointer to the in-place gradient accumulator of a parameter (NULL if frozen).
+
+    Weight gradients are accumulated by the kernels directly into `param.grad`
+    (allocated zero-filled on first use), which is also the buffer the
+    data-parallel all-reduce works on -- no per-step temporaries."""
+    if param is None or not param.requires_grad:
+        return None
+    if param.grad is None:
+        param.grad = torch.zeros_like(param, memory_format=torch.contiguous_format)
+    return C.c_void_p(param.grad.data_ptr())
+
+
+def lstm_w(w_ih, w_hh, b_ih, b_hh, grad=False):
+    g = grad_ptr if grad else ptr
+    return _lib.LstmW(*(_v(g(t)) for t in (w_ih, w_hh, b_ih, b_hh)))
+
+
+def _v(p):
+    return p.value if p is not None else None
+
+
+def struct_of(cls, tensors, grad=False):
+    g = grad_ptr if grad else ptr
+    return cls(*(_v(g(t)) for t in tensors))
+
+
+def pano_dense(X):
+    B, V, F = X.shape
+    return _lib.Pano(X.data_ptr(), None, None, None, None, V, F, 0)
+
+
+def cands_dense(U):
+    B, A, F = U.shape
+    return _lib.Cands(U.data_ptr(), None, None, None, None, None, A, 1, F, 0)

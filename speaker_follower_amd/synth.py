@@ -5,7 +5,7 @@ rollout, batch 100, 36 views x 2048-d, <=80-token instructions, 20 decode
 steps) and S3 (speaker).  Everything here is plain numpy so that the very same
 arrays feed the oracle (tests / cpu_baseline) and, after upload, the HIP path.
 
-Reference shapes this mirrors (read-only citations into /root/reference):
+Reference shapes this mirrors (read-only citations into the reference tree):
   * feature store 36 x 2048 fp32 per viewpoint       tasks/R2R/env.py:350-383
   * candidate list = stop + neighbours                tasks/R2R/env.py:60-75, 149-224
   * instruction encoding (no BOS/EOS, PAD=0, EOS=2)   tasks/R2R/follower.py:75-105

@@ -1,0 +1,259 @@
+"""GPU parity of the composite follower path against the golden vectors of the reference
+(module API: EncoderLSTM / AttnDecoderLSTM) and of the fused rollout engine (index form)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_env, np_model, rng as orng, torch_ref          # noqa: E402
+from speaker_follower_amd import synth                                # noqa: E402
+
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def load_np(module, state):
+    module.load_state_dict({k: torch.tensor(v) for k, v in state.items()})
+    return module
+
+
+@pytest.fixture(scope='module')
+def follower_modules():
+    from speaker_follower_amd import model
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights(101)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    load_np(enc, enc_w).cuda().eval()
+    load_np(dec, dec_w).cuda().eval()
+    return enc, dec, enc_w, dec_w
+
+
+@pytest.fixture(scope='module')
+def batch8():
+    fb = synth.follower_batch(seed=7, batch=8, steps=10, n_viewpoints=64, min_len=3, max_len=19,
+                              a_max=8)
+    return fb, synth.feature_table(7, 64)
+
+
+def test_state_dict_keys_match_reference(follower_modules):
+    enc, dec, enc_w, dec_w = follower_modules
+    assert list(enc.state_dict().keys()) == list(enc_w.keys())
+    assert list(dec.state_dict().keys()) == list(dec_w.keys())
+
+
+def test_encoder_module_golden(follower_modules, batch8, golden):
+    enc, dec, _, _ = follower_modules
+    fb, _ = batch8
+    from speaker_follower_amd.follower import batch_instructions_from_encoded
+    g = golden('g3_encoder')
+    seq, mask, lens = batch_instructions_from_encoded(fb.instr, 80, reverse=True)
+    with torch.no_grad():
+        ctx, h0, c0 = enc(seq, lens)
+    np.testing.assert_allclose(ctx.cpu().numpy(), g['ctx'], **TOL)
+    np.testing.assert_allclose(h0.cpu().numpy(), g['decoder_init'], **TOL)
+    np.testing.assert_allclose(c0.cpu().numpy(), g['c_t'], **TOL)
+
+
+def test_decoder_step_module_golden(follower_modules, batch8, golden):
+    enc, dec, _, _ = follower_modules
+    fb, table = batch8
+    from speaker_follower_amd.follower import batch_instructions_from_encoded
+    g3, g = golden('g3_encoder'), golden('g2_decoder_step')
+    seq, mask, lens = batch_instructions_from_encoded(fb.instr, 80, reverse=True)
+    X, all_u, is_valid = np_env.dense_follower_step(table, np_env.static_loc_embeddings(), fb, 0)
+    with torch.no_grad():
+        h1, c1, alpha, logit, alpha_v = dec(dev(g['u_prev']), dev(all_u), dev(X),
+                                            dev(g3['decoder_init']), dev(g3['c_t']),
+                                            dev(g3['ctx']), mask)
+    np.testing.assert_allclose(h1.cpu().numpy(), g['h1'], **TOL)
+    np.testing.assert_allclose(c1.cpu().numpy(), g['c1'], **TOL)
+    np.testing.assert_allclose(alpha.cpu().numpy(), g['alpha'], **TOL)
+    np.testing.assert_allclose(alpha_v.cpu().numpy(), g['alpha_v'], **TOL)
+    np.testing.assert_allclose(logit.cpu().numpy(), g['logit'], **TOL)
+
+
+def _engine(follower_modules, table):
+    from speaker_follower_amd import features, follower
+    enc, dec, _, _ = follower_modules
+    store = features.FeatureStore(table)
+    return follower.FollowerEngine(enc, dec, store), follower
+
+
+def _check_rollout(st, g, steps):
+    n = int(g['n_steps'])
+    actions = st.actions.cpu().numpy()
+    logits = st.logits.cpu().numpy()
+    np.testing.assert_array_equal(actions[:n], g['actions'])                 # bit-exact argmax
+    ref = g['logits']
+    A = min(ref.shape[2], logits.shape[2])
+    fin = np.isfinite(ref[:, :, :A])
+    assert np.array_equal(np.isfinite(logits[:n, :, :A]), fin)
+    np.testing.assert_allclose(logits[:n, :, :A][fin], ref[:, :, :A][fin], **TOL)
+    np.testing.assert_allclose(float(st.loss), g['loss'], rtol=1e-4)
+    np.testing.assert_allclose(st.step_scores.cpu().numpy()[:n].sum(0), g['scores'], **TOL)
+    if n == steps:
+        np.testing.assert_allclose(st.h.cpu().numpy(), g['h'], **TOL)
+        np.testing.assert_allclose(st.c.cpu().numpy(), g['c'], **TOL)
+
+
+@pytest.mark.parametrize('feedback', ['teacher', 'argmax'])
+def test_engine_rollout_b8_golden(follower_modules, batch8, golden, feedback):
+    fb, table = batch8
+    engine, follower = _engine(follower_modules, table)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    g = golden('g4_rollout_b8_' + feedback)
+    n = int(g['n_steps'])
+    with torch.no_grad():
+        st = engine.rollout(batch, n, feedback)
+    _check_rollout(st, g, n)
+
+
+def test_engine_rollout_b100_headline_shape_golden(follower_modules, golden):
+    """BASELINE.json headline shape: batch 100, 20 decode steps, <=80-token instructions."""
+    fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=256)
+    table = synth.feature_table(0, 256)
+    engine, follower = _engine(follower_modules, table)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    with torch.no_grad():
+        st = engine.rollout(batch, 20, 'argmax')
+    _check_rollout(st, golden('g4_rollout_b100_argmax'), 20)
+
+
+def _check_grads(named, g, prefix, rtol=3e-3):
+    seen = 0
+    for name, grad in named.items():
+        key = prefix + 'gnorm/' + name
+        if key not in g:
+            continue
+        seen += 1
+        flat = grad.detach().cpu().numpy().ravel()
+        norm = np.sqrt(np.sum(flat.astype(np.float64) ** 2))
+        if g[key] < 1e-6:          # shift-invariant biases: true gradient is zero
+            assert norm < 1e-5, name
+            continue
+        np.testing.assert_allclose(norm, g[key], rtol=rtol, err_msg=name)
+        np.testing.assert_allclose(flat[g[prefix + 'gidx/' + name]], g[prefix + 'gval/' + name],
+                                   rtol=rtol, atol=rtol * g[key] / np.sqrt(flat.size) + 1e-7,
+                                   err_msg=name)
+    assert seen > 0
+
+
+@pytest.mark.parametrize('case', ['b8', 'b100'])
+def test_engine_teacher_gradients_golden(follower_modules, batch8, golden, case):
+    """Full BPTT through the C-ABI backward vs the reference's autograd gradients."""
+    enc, dec, _, _ = follower_modules
+    if case == 'b8':
+        fb, table = batch8
+        steps = 10
+    else:
+        fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=256)
+        table = synth.feature_table(0, 256)
+        steps = 20
+    g = golden('g4_rollout_%s_teacher' % case)
+    engine, follower = _engine(follower_modules, table)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+    st = engine.rollout(batch, int(g['n_steps']), 'teacher', train=False)
+    np.testing.assert_allclose(float(st.loss), g['loss'], rtol=1e-4)
+    st.loss.backward()
+    _check_grads({k: p.grad for k, p in enc.named_parameters() if p.grad is not None}, g, 'enc/')
+    _check_grads({k: p.grad for k, p in dec.named_parameters() if p.grad is not None}, g, 'dec/')
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+
+
+def test_module_api_teacher_gradients_match_engine(follower_modules, batch8):
+    """The per-step nn.Module path (autograd Functions) and the fused engine agree."""
+    enc, dec, _, _ = follower_modules
+    fb, table = batch8
+    engine, follower = _engine(follower_modules, table)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    steps = 6
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+    st = engine.rollout(batch, steps, 'teacher', train=False)
+    st.loss.backward()
+    ref = {k: p.grad.clone() for k, p in list(enc.named_parameters()) + list(dec.named_parameters())
+           if p.grad is not None}
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+    loc = np_env.static_loc_embeddings()
+    seq, mask, lens = follower.batch_instructions_from_encoded(fb.instr, 80, reverse=True)
+    ctx, h, c = enc(seq, lens)
+    B = len(lens)
+    u_prev = dec.u_begin.expand(B, -1)
+    loss = 0
+    ended = np.zeros(B, bool)
+    for t in range(steps):
+        X, all_u, is_valid = np_env.dense_follower_step(table, loc, fb, t)
+        all_u_t = dev(all_u)
+        h, c, alpha, logit, alpha_v = dec(u_prev, all_u_t, dev(X), h, c, ctx, mask)
+        logit = logit.masked_fill(dev(is_valid) == 0, float('-inf'))
+        target = dev(np.where(ended, -1, fb.target[t]))
+        if (target != -1).any():
+            loss = loss + torch.nn.functional.cross_entropy(logit, target, ignore_index=-1)
+        a_t = target.clamp(min=0)
+        u_prev = all_u_t[torch.arange(B), a_t].detach()
+        ended |= (a_t.cpu().numpy() == 0)
+    np.testing.assert_allclose(float(loss), float(st.loss), rtol=1e-5)
+    loss.backward()
+    for k, p in list(enc.named_parameters()) + list(dec.named_parameters()):
+        if k in ref:
+            np.testing.assert_allclose(p.grad.cpu().numpy(), ref[k].cpu().numpy(), rtol=2e-4,
+                                       atol=2e-6, err_msg=k)
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+
+
+def test_engine_train_mode_dropout_matches_oracle_with_same_masks(follower_modules, batch8):
+    """Train mode: the device derives its dropout masks from (seed, site, row, col); the
+    oracle gets the very same masks from oracle/rng.py and must produce the same loss/grads."""
+    enc, dec, enc_w, dec_w = follower_modules
+    fb, table = batch8
+    engine, follower = _engine(follower_modules, table)
+    engine.dropout_seed = 4242
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    steps, B, F, H = 5, 8, 2176, 512
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+    st = engine.rollout(batch, steps, 'teacher', train=True)
+    st.loss.backward()
+    site0 = st.site0
+    seq, mask, lens = np_env.batch_instructions_from_encoded(fb.instr, 80, reverse=True)
+    T = max(lens)
+    rows = np.arange(B)
+
+    def masks(t):
+        if t == 'ctx':
+            m = orng.dropout_mask(4242 ^ 0x5BD1E995, site0, rows, T * H, 0.5)
+            return torch.tensor(m.reshape(B, T, H))
+        return (torch.tensor(orng.dropout_mask(4242, 2 * (site0 + t), rows, 2 * F, 0.5)),
+                torch.tensor(orng.dropout_mask(4242, 2 * (site0 + t) + 1, rows, H, 0.5)))
+
+    e = torch_ref.to_torch(enc_w, True, frozen=('embedding.weight',))
+    d = torch_ref.to_torch(dec_w, True)
+    loc = np_env.static_loc_embeddings()
+    res = torch_ref.follower_rollout(e, d, torch.tensor(seq), lens, torch.tensor(mask), steps,
+                                     lambda t: np_env.dense_follower_step(table, loc, fb, t),
+                                     torch.tensor(fb.target), 'teacher', F, drop_masks=masks)
+    np.testing.assert_allclose(float(st.loss), res['loss'].item(), rtol=1e-4)
+    res['loss'].backward()
+    for k, p in dec.named_parameters():
+        if d[k].grad is not None and float(d[k].grad.abs().max()) > 1e-6:
+            np.testing.assert_allclose(p.grad.cpu().numpy(), d[k].grad.numpy(), rtol=2e-3,
+                                       atol=1e-5, err_msg=k)
+    for k, p in enc.named_parameters():
+        if p.grad is not None and e[k].grad is not None:
+            np.testing.assert_allclose(p.grad.cpu().numpy(), e[k].grad.numpy(), rtol=2e-3,
+                                       atol=1e-5, err_msg=k)
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)

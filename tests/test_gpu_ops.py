@@ -1,0 +1,269 @@
+"""GPU parity: every C-ABI operator against the oracle on the same seeded inputs.
+Tolerances: 1e-4 on logits / activations (BASELINE.json north_star), bit-exact argmax."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import np_env, np_model, rng as orng, torch_ref          # noqa: E402
+from speaker_follower_amd import synth                                # noqa: E402
+
+TOL = dict(rtol=1e-4, atol=1e-4)
+
+
+@pytest.fixture(scope='module')
+def sf():
+    assert torch.cuda.is_available(), 'gpu tests need a GPU'
+    from speaker_follower_amd import _lib, ops, model, features, follower
+    import types
+    return types.SimpleNamespace(lib=_lib, ops=ops, model=model, features=features,
+                                 follower=follower)
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda()
+
+
+def rnd(rng, *shape, scale=1.0):
+    return (rng.standard_normal(shape) * scale).astype(np.float32)
+
+
+# ------------------------------------------------------------------------------------ GEMMs
+@pytest.mark.parametrize('M,N,K', [(100, 2048, 512), (8, 256, 512), (3, 512, 1024), (100, 991, 512),
+                                   (7, 2048, 300), (128, 64, 16), (250, 2048, 300), (1, 16, 4)])
+@pytest.mark.parametrize('act', [0, 1])
+def test_linear_fwd_bwd(sf, M, N, K, act):
+    rng = np.random.default_rng(M * 7 + N + K)
+    x, w, b = rnd(rng, M, K), rnd(rng, N, K, scale=K ** -0.5), rnd(rng, N)
+    y = sf.ops.linear_fwd(dev(x), dev(w), dev(b), act)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    if act:
+        ref = np.tanh(ref)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-5, atol=2e-5)
+    if N % 4 or K % 4:
+        return
+    dy = rnd(rng, M, N)
+    dw = torch.zeros(N, K, device='cuda')
+    db = torch.zeros(N, device='cuda')
+    dx = sf.ops.linear_bwd(dev(x), dev(w), y, dev(dy), act, True, dw, db)
+    dpre = dy.astype(np.float64) * ((1 - ref ** 2) if act else 1.0)
+    np.testing.assert_allclose(dx.cpu().numpy(), dpre @ w, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(dw.cpu().numpy(), dpre.T @ x, rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(db.cpu().numpy(), dpre.sum(0), rtol=1e-4, atol=1e-4)
+
+
+def test_gemm_is_transpose_safe(sf):
+    """Asymmetric operands: catches a row/column swap in the MFMA fragment mapping."""
+    M, N, K = 48, 80, 32
+    x = np.arange(M * K, dtype=np.float32).reshape(M, K) / 97.0
+    w = (np.arange(N * K, dtype=np.float32).reshape(N, K) % 13) / 5.0 - 1.0
+    y = sf.ops.linear_fwd(dev(x), dev(w)).cpu().numpy()
+    np.testing.assert_allclose(y, x.astype(np.float64) @ w.astype(np.float64).T, rtol=1e-5, atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------ LSTMCell
+@pytest.mark.parametrize('B,I,H', [(8, 4352, 512), (100, 4352, 512), (5, 300, 512), (3, 48, 16)])
+def test_lstm_cell(sf, B, I, H):
+    rng = np.random.default_rng(B + I)
+    k = H ** -0.5
+    w = [rnd(rng, 4 * H, I, scale=k), rnd(rng, 4 * H, H, scale=k), rnd(rng, 4 * H, scale=k),
+         rnd(rng, 4 * H, scale=k)]
+    x, h, c = rnd(rng, B, I), rnd(rng, B, H), rnd(rng, B, H)
+    wd = [dev(a) for a in w]
+    h1, c1, gates = sf.ops.lstm_cell_fwd(wd, dev(x), dev(h), dev(c))
+    rh, rc = np_model.lstm_cell(x, h, c, *w)
+    np.testing.assert_allclose(h1.cpu().numpy(), rh, **TOL)
+    np.testing.assert_allclose(c1.cpu().numpy(), rc, **TOL)
+    # backward against torch autograd
+    tw = [torch.tensor(a, requires_grad=True) for a in w]
+    tx, th, tc = (torch.tensor(a, requires_grad=True) for a in (x, h, c))
+    th1, tc1 = torch_ref.lstm_cell(tx, th, tc, *tw)
+    gh, gc = rnd(rng, B, H), rnd(rng, B, H)
+    ((th1 * torch.tensor(gh)).sum() + (tc1 * torch.tensor(gc)).sum()).backward()
+    g = [torch.zeros_like(a) for a in wd]
+    dx, dh0, dc0 = sf.ops.lstm_cell_bwd(wd, g, dev(x), dev(h), dev(c), c1, gates, dev(gh), dev(gc))
+    np.testing.assert_allclose(dx.cpu().numpy(), tx.grad.numpy(), **TOL)
+    np.testing.assert_allclose(dh0.cpu().numpy(), th.grad.numpy(), **TOL)
+    np.testing.assert_allclose(dc0.cpu().numpy(), tc.grad.numpy(), **TOL)
+    for got, ref in zip(g, tw):
+        np.testing.assert_allclose(got.cpu().numpy(), ref.grad.numpy(), rtol=1e-4, atol=2e-4)
+
+
+# ------------------------------------------------------------------------------------ attentions
+def _small_modules_golden(golden, prefix):
+    g = golden('g1_modules_small')
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def test_visual_attention_module_small_golden(sf, golden):
+    """VisualSoftDotAttention module (dense API) on the reference's own small-dim vectors."""
+    g = _small_modules_golden(golden, 'vsda/')
+    H, F, D = g['h'].shape[1], g['X'].shape[2], g['linear_in_h.weight'].shape[0]
+    m = sf.model.VisualSoftDotAttention(H, F, dot_dim=D).cuda()
+    m.load_state_dict({k: torch.tensor(g[k]) for k in
+                       ('linear_in_h.weight', 'linear_in_h.bias', 'linear_in_v.weight', 'linear_in_v.bias')})
+    h = dev(g['h']).requires_grad_(True)
+    out, alpha = m(h, dev(g['X']))
+    np.testing.assert_allclose(out.detach().cpu().numpy(), g['out'], **TOL)
+    np.testing.assert_allclose(alpha.cpu().numpy(), g['alpha'], **TOL)
+    (out * dev(g['go'])).sum().backward()
+    np.testing.assert_allclose(h.grad.cpu().numpy(), g['dh'], **TOL)
+    np.testing.assert_allclose(m.linear_in_h.weight.grad.cpu().numpy(), g['d_linear_in_h.weight'], **TOL)
+    np.testing.assert_allclose(m.linear_in_h.bias.grad.cpu().numpy(), g['d_linear_in_h.bias'], **TOL)
+    np.testing.assert_allclose(m.linear_in_v.weight.grad.cpu().numpy(), g['d_linear_in_v.weight'], **TOL)
+
+
+def test_soft_dot_attention_module_small_golden(sf, golden):
+    g = _small_modules_golden(golden, 'sda/')
+    H = g['h'].shape[1]
+    m = sf.model.SoftDotAttention(H).cuda()
+    m.load_state_dict({k: torch.tensor(g[k]) for k in ('linear_in.weight', 'linear_out.weight')})
+    h = dev(g['h']).requires_grad_(True)
+    ctx = dev(g['ctx']).requires_grad_(True)
+    ht, alpha = m(h, ctx, dev(g['mask']))
+    np.testing.assert_allclose(ht.detach().cpu().numpy(), g['h_tilde'], **TOL)
+    np.testing.assert_allclose(alpha.cpu().numpy(), g['alpha'], **TOL)
+    (ht * dev(g['go'])).sum().backward()
+    np.testing.assert_allclose(h.grad.cpu().numpy(), g['dh'], **TOL)
+    np.testing.assert_allclose(ctx.grad.cpu().numpy(), g['dctx'], **TOL)
+    np.testing.assert_allclose(m.linear_in.weight.grad.cpu().numpy(), g['d_linear_in.weight'], **TOL)
+    np.testing.assert_allclose(m.linear_out.weight.grad.cpu().numpy(), g['d_linear_out.weight'], **TOL)
+
+
+def test_eltwise_prod_scoring_module_small_golden(sf, golden):
+    g = _small_modules_golden(golden, 'eps/')
+    H, F, D = g['h'].shape[1], g['U'].shape[2], g['linear_in_h.weight'].shape[0]
+    m = sf.model.EltwiseProdScoring(H, F, dot_dim=D).cuda()
+    names = ('linear_in_h.weight', 'linear_in_h.bias', 'linear_in_a.weight', 'linear_in_a.bias',
+             'linear_out.weight', 'linear_out.bias')
+    m.load_state_dict({k: torch.tensor(g[k]) for k in names})
+    h = dev(g['h']).requires_grad_(True)
+    logit = m(h, dev(g['U']))
+    np.testing.assert_allclose(logit.detach().cpu().numpy(), g['logit'], **TOL)
+    (logit * dev(g['go'])).sum().backward()
+    np.testing.assert_allclose(h.grad.cpu().numpy(), g['dh'], **TOL)
+    for n in names:
+        mod, attr = n.split('.')
+        got = getattr(getattr(m, mod), attr).grad.cpu().numpy()
+        np.testing.assert_allclose(got, g['d_' + n], rtol=1e-4, atol=1e-4, err_msg=n)
+
+
+@pytest.mark.parametrize('B', [5, 100])
+def test_visual_attention_full_dims_dense_and_indexed(sf, B):
+    rng = np.random.default_rng(B)
+    d = synth.FULL
+    H, F, D, V = d.hidden, d.feat, d.dot, d.views
+    table = synth.feature_table(3, 40)
+    loc = np_env.static_loc_embeddings()
+    vp = rng.integers(0, 40, B).astype(np.int32)
+    view = rng.integers(0, 36, B).astype(np.int32)
+    X = np.stack([np_env.panorama_feature(table[vp[b]], view[b], loc) for b in range(B)])
+    w = [rnd(rng, D, H, scale=H ** -0.5), rnd(rng, D, scale=0.1), rnd(rng, D, F, scale=F ** -0.5),
+         rnd(rng, D, scale=0.1)]
+    h = rnd(rng, B, H)
+    ref_out, ref_alpha = np_model.visual_soft_dot_attention(h, X, *w)
+    wd = [dev(a) for a in w]
+    store = sf.features.FeatureStore(table)
+    np.testing.assert_array_equal(store.loc_table.cpu().numpy(), loc)
+    vp_d, view_d = dev(vp), dev(view)          # index tensors must outlive the enqueued kernels
+    Xg = store.gather_panorama(vp_d, view_d)
+    np.testing.assert_array_equal(Xg.cpu().numpy(), X)                        # a11 gather: bit-exact
+    for pano in (sf.ops.pano_dense(Xg), store.pano(vp_d, view_d)):
+        out, alpha, t_v, q = sf.ops.visual_attention_fwd(wd, pano, B, V, F, dev(h))
+        np.testing.assert_allclose(out.cpu().numpy(), ref_out, **TOL)
+        np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, **TOL)
+    # backward vs autograd
+    tw = [torch.tensor(a, requires_grad=True) for a in w]
+    th = torch.tensor(h, requires_grad=True)
+    tout, _ = torch_ref.visual_soft_dot_attention(th, torch.tensor(X), *tw)
+    go = rnd(rng, B, F)
+    (tout * torch.tensor(go)).sum().backward()
+    g = [torch.zeros_like(a) for a in wd]
+    dh = sf.ops.visual_attention_bwd(wd, g, store.pano(vp_d, view_d), B, dev(h), alpha, t_v,
+                                     dev(go))
+    np.testing.assert_allclose(dh.cpu().numpy(), th.grad.numpy(), **TOL)
+    np.testing.assert_allclose(g[0].cpu().numpy(), tw[0].grad.numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(g[1].cpu().numpy(), tw[1].grad.numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(g[2].cpu().numpy(), tw[2].grad.numpy(), rtol=1e-4, atol=2e-4)
+    assert float(g[3].abs().max()) == 0.0          # b_v: exactly zero by construction
+
+
+@pytest.mark.parametrize('B,L', [(6, 80), (100, 37), (4, 7), (3, 1), (5, 128)])
+def test_soft_dot_attention_full_dims(sf, B, L):
+    rng = np.random.default_rng(B * 100 + L)
+    H = 512
+    w_in, w_out = rnd(rng, H, H, scale=H ** -0.5), rnd(rng, H, 2 * H, scale=(2 * H) ** -0.5)
+    h, ctx = rnd(rng, B, H), rnd(rng, B, L, H)
+    lens = rng.integers(1, L + 1, B)
+    lens[0] = L
+    mask = np.arange(L)[None, :] >= lens[:, None]
+    ref_ht, ref_alpha = np_model.soft_dot_attention(h, ctx, mask, w_in, w_out)
+    wd = (dev(w_in), dev(w_out))
+    ht, alpha, cat2, t_text = sf.ops.soft_dot_attention_fwd(wd, dev(h), dev(ctx), dev(mask))
+    np.testing.assert_allclose(ht.cpu().numpy(), ref_ht, **TOL)
+    np.testing.assert_allclose(alpha.cpu().numpy(), ref_alpha, **TOL)
+    assert float(alpha.cpu().numpy()[mask].sum()) == 0.0
+    tw = [torch.tensor(w_in, requires_grad=True), torch.tensor(w_out, requires_grad=True)]
+    th, tctx = torch.tensor(h, requires_grad=True), torch.tensor(ctx, requires_grad=True)
+    tht, _ = torch_ref.soft_dot_attention(th, tctx, torch.tensor(mask), *tw)
+    go = rnd(rng, B, H)
+    (tht * torch.tensor(go)).sum().backward()
+    g = (torch.zeros_like(wd[0]), torch.zeros_like(wd[1]))
+    dh, dctx = sf.ops.soft_dot_attention_bwd(wd, g, dev(ctx), alpha, cat2, t_text, ht, dev(go))
+    np.testing.assert_allclose(dh.cpu().numpy(), th.grad.numpy(), **TOL)
+    np.testing.assert_allclose(dctx.cpu().numpy(), tctx.grad.numpy(), **TOL)
+    np.testing.assert_allclose(g[0].cpu().numpy(), tw[0].grad.numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(g[1].cpu().numpy(), tw[1].grad.numpy(), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('B,A', [(7, 14), (100, 9), (3, 2), (4, 16)])
+def test_scoring_full_dims_dense_and_indexed(sf, B, A):
+    rng = np.random.default_rng(B + 31 * A)
+    d = synth.FULL
+    H, F, D = d.hidden, d.feat, d.dot
+    fb = synth.follower_batch(seed=B, batch=B, steps=1, n_viewpoints=30, a_max=A)
+    table = synth.feature_table(5, 30)
+    loc = np_env.static_loc_embeddings()
+    X, all_u, is_valid = np_env.dense_follower_step(table, loc, fb, 0)
+    pad = np.zeros((B, A, F), np.float32)
+    pad[:, :all_u.shape[1]] = all_u
+    w = [rnd(rng, D, H, scale=H ** -0.5), rnd(rng, D, scale=0.1), rnd(rng, D, F, scale=F ** -0.5),
+         rnd(rng, D, scale=0.1), rnd(rng, 1, D, scale=D ** -0.5), rnd(rng, 1, scale=0.1)]
+    h = rnd(rng, B, H)
+    ref = np_model.eltwise_prod_scoring(h, pad, *w)
+    wd = [dev(a) for a in w]
+    store = sf.features.FeatureStore(table)
+    idx = [dev(fb.vp[0]), dev(fb.cand_view[0]),
+           dev(sf.features.cand_sincos(fb.cand_heading[0], fb.cand_elevation[0])), dev(fb.a_num[0])]
+    Ug, validg = store.gather_candidates(*idx)
+    np.testing.assert_array_equal(Ug.cpu().numpy(), pad)                      # a11: bit-exact
+    np.testing.assert_array_equal(validg.cpu().numpy()[:, :is_valid.shape[1]], is_valid)
+    for cnd in (sf.ops.cands_dense(Ug), store.cands(*idx, A)):
+        logit, t_a, wt, r = sf.ops.eltwise_prod_scoring_fwd(wd, cnd, B, A, F, dev(h))
+        np.testing.assert_allclose(logit.cpu().numpy(), ref, **TOL)
+    tw = [torch.tensor(a, requires_grad=True) for a in w]
+    th = torch.tensor(h, requires_grad=True)
+    go = rnd(rng, B, A)
+    (torch_ref.eltwise_prod_scoring(th, torch.tensor(pad), *tw) * torch.tensor(go)).sum().backward()
+    g = [torch.zeros_like(a) for a in wd]
+    dh = sf.ops.eltwise_prod_scoring_bwd(wd, g, store.cands(*idx, A), B, dev(h), t_a, wt, dev(go))
+    np.testing.assert_allclose(dh.cpu().numpy(), th.grad.numpy(), **TOL)
+    for got, refp in zip(g, tw):
+        np.testing.assert_allclose(got.cpu().numpy(), refp.grad.numpy(), rtol=1e-4, atol=2e-4)
+
+
+def test_dropout_mask_matches_oracle_mirror(sf):
+    import ctypes as C
+    from speaker_follower_amd.runtime import ptr, stream, dropout_arg
+    B, N = 5, 300
+    x = torch.ones(B, N, device='cuda')
+    out = torch.empty_like(x)
+    sf.lib.call('sf_dropout_copy', ptr(x), N, B, N, ptr(out), N, dropout_arg(0.5, 1234, 17), 9, 40,
+                stream())
+    ref = orng.dropout_mask(1234, 9, np.arange(17, 17 + B), 40 + N, 0.5)[:, 40:]
+    np.testing.assert_array_equal(out.cpu().numpy(), ref)
+    assert 0.4 < (ref == 0).mean() < 0.6

@@ -1,0 +1,140 @@
+"""CPU: host-side logic of the product (no kernels): instruction batching, location table,
+candidate sin/cos, synthetic batches, data-parallel helpers (gloo, world_size 2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from speaker_follower_amd import synth
+
+
+def test_batch_instructions_matches_reference_golden(golden):
+    from speaker_follower_amd.follower import batch_instructions_from_encoded
+    g = golden('g6_env')
+    toks = np.split(g['instr_tokens'], np.cumsum(g['instr_sizes'])[:-1])
+    for tag, rev in (('fwd', False), ('rev', True)):
+        seq, mask, lens = batch_instructions_from_encoded(toks, 80, reverse=rev, device='cpu')
+        np.testing.assert_array_equal(seq.numpy(), g['instr_seq_' + tag])
+        np.testing.assert_array_equal(mask.numpy(), g['instr_mask_' + tag])
+        assert lens == list(g['instr_len_' + tag])
+    seq, mask, lens, perm = batch_instructions_from_encoded(toks, 80, reverse=True, sort=True,
+                                                           device='cpu')
+    np.testing.assert_array_equal(seq.numpy(), g['instr_seq_sorted'])
+    assert lens == list(g['instr_len_sorted'])
+    assert lens == sorted(lens, reverse=True)
+
+
+def test_batch_instructions_edge_cases():
+    from speaker_follower_amd.follower import batch_instructions_from_encoded
+    seq, mask, lens = batch_instructions_from_encoded([[], [5] * 200], 80, reverse=True, device='cpu')
+    assert lens == [1, 80]                      # empty -> just EOS; long -> truncated (EOS dropped)
+    assert int(seq[0, 0]) == 2 and int(seq[1, 79]) == 5
+    assert mask.shape == (2, 80) and bool(mask[0, 1]) and not bool(mask[1, 79])
+
+
+def test_loc_table_and_sincos_match_reference_golden(golden):
+    from speaker_follower_amd import features
+    g = golden('g6_env')
+    np.testing.assert_array_equal(features.build_loc_table(), g['loc_table'])
+    sc = features.cand_sincos(g['act_cand_heading'], g['act_cand_elevation'])
+    emb = g['act_embedding']
+    for a in range(1, len(sc)):
+        np.testing.assert_array_equal(emb[a, 2048:2048 + 128:32], sc[a])
+
+
+def test_synth_batches_are_deterministic_and_well_formed():
+    a = synth.follower_batch(seed=3, batch=16, steps=12, n_viewpoints=50)
+    b = synth.follower_batch(seed=3, batch=16, steps=12, n_viewpoints=50)
+    np.testing.assert_array_equal(a.vp, b.vp)
+    np.testing.assert_array_equal(a.target, b.target)
+    lens = [len(i) for i in a.instr]
+    assert lens == sorted(lens, reverse=True) and min(lens) >= 10 and max(lens) <= 79
+    assert a.a_num.min() >= 2 and a.a_num.max() <= a.a_max
+    live = a.target >= 0
+    assert np.all(a.target[live] < a.a_num[live])
+    assert np.all(live[0])                                    # step 0 is always supervised
+    for bidx in range(16):                                    # -1 forever after the teacher's stop
+        col = a.target[:, bidx]
+        stop = np.where(col == 0)[0]
+        if len(stop):
+            assert np.all(col[stop[0] + 1:] == -1)
+    t = synth.feature_table(3, 4)
+    assert t.shape == (4, 36, 2048) and t.min() >= 0 and t.dtype == np.float32
+    sb = synth.speaker_batch(seed=1, batch=5, n_viewpoints=10)
+    assert np.array_equal(sb.act_is_stop.sum(0), np.ones(5))
+
+
+def test_shard_rows_partitions_the_batch():
+    from speaker_follower_amd import dp
+    for n, w in ((100, 8), (100, 3), (7, 8), (64, 4)):
+        seen = []
+        for r in range(w):
+            s = dp.shard_rows(n, r, w)
+            seen += list(range(n))[s]
+        assert seen == list(range(n))
+
+
+def test_step_losses_global_normaliser_equals_unsharded_mean():
+    """Sharded loss with the all-reduced (sum, count) table == the reference's batch mean."""
+    from speaker_follower_amd import dp
+    rng = np.random.default_rng(0)
+    terms = rng.random((6, 10)).astype(np.float32)
+    live = (rng.random((6, 10)) > 0.4).astype(np.float32)
+    live[5] = 0                                               # a step with no live rows
+    terms *= live
+    full = torch.tensor(np.stack((terms.sum(1), live.sum(1)), 1))
+    want = sum(terms[t].sum() / live[t].sum() for t in range(6) if live[t].sum() > 0)
+    loss, gscale = dp.step_losses(full)
+    np.testing.assert_allclose(float(loss), want, rtol=1e-6)
+    assert float(gscale[5]) == 0.0
+    a = torch.tensor(np.stack((terms[:, :4].sum(1), live[:, :4].sum(1)), 1))
+    b = torch.tensor(np.stack((terms[:, 4:].sum(1), live[:, 4:].sum(1)), 1))
+    loss2, _ = dp.step_losses(a + b)
+    np.testing.assert_allclose(float(loss2), want, rtol=1e-6)
+
+
+def _dp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from speaker_follower_amd import dp
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(6, 4)
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    fg = dp.FlatGrads(list(lin.parameters()) + [frozen])
+    assert fg.attached() and fg.flat.numel() == 6 * 4 + 4
+    # "backward": accumulate in place into the views, like the HIP kernels do
+    lin.weight.grad += float(rank + 1)
+    lin.bias.grad += 10.0 * (rank + 1)
+    fg.allreduce()
+    sc = torch.tensor([[1.0 + rank, 2.0], [0.0, 0.0]])
+    dp.allreduce_step_counts(sc)
+    other = [torch.nn.Parameter(torch.ones(5))]
+    other[0].grad = torch.full((5,), float(rank))
+    dp.allreduce_gradients(other)
+    out[rank] = (lin.weight.grad.clone(), lin.bias.grad.clone(), sc, other[0].grad.clone(),
+                 fg.attached())
+    lin.zero_grad(set_to_none=True)
+    try:
+        fg.allreduce()
+        out[rank] += (False,)
+    except RuntimeError:
+        out[rank] += (True,)
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradient_and_count_allreduce_gloo_world2():
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29500 + os.getpid() % 2000
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        w, b, sc, o, attached, raised = out[r]
+        assert torch.all(w == 3.0) and torch.all(b == 30.0)        # 1+2, 10+20: SUM not mean
+        assert sc.tolist() == [[3.0, 4.0], [0.0, 0.0]]
+        assert torch.all(o == 1.0)
+        assert attached and raised
