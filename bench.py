@@ -84,7 +84,7 @@ def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps):
             res = np_model.follower_rollout(
                 enc_w, dec_w, seq, lens, mask, decode_steps,
                 lambda t: np_env.dense_follower_step(table_rows, loc, fbc, t), fb.target, 'argmax',
-                2176)
+                2176, early_exit=False)       # same work as the GPU: every step for every row
             dt = time.perf_counter() - t0
             n = len(res['logits'])
             rate = B * n / dt
@@ -209,7 +209,7 @@ def main():
                vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='follower %s: batch %d per GPU, 36 views x 2048-d features from a '
                                     '%d-viewpoint HBM table, <=80-token instructions, %d decode steps, '
-                                    'argmax (student-forcing) feedback, encoder included'
+                                    'argmax (student-forcing) feedback, every step executed for every row (no early exit), encoder included'
                                     % (args.workload, B, args.n_viewpoints, S),
                            global_batch=B * world, parallelism='dp%d' % world),
                roofline=roofline, loss=float(st.loss))

@@ -132,6 +132,8 @@ typedef struct sf_decoder_tape {
 size_t sf_workspace_bytes(void);
 int sf_abi_version(void);
 const char* sf_status_string(int status);
+/* hipGetErrorString of the HIP error behind the calling thread's last SF_ERR_LAUNCH */
+const char* sf_last_error_string(void);
 
 /* ---- nn.Linear (model.py:64, 99, 117-119, 306-307, 338-340, 419, 485) ------------------------
  * y[M,N] = act(x[M,K] w[N,K]^T + b);  act: 0 none, 1 tanh.  K % 4 == 0, ldx % 4 == 0. */

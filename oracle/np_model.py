@@ -158,7 +158,7 @@ def follower_glue(logit, is_valid, target, feedback):
 
 
 def follower_rollout(enc, dec, seq, lengths, ctx_mask, steps, step_inputs, targets,
-                     feedback, dims_feat):
+                     feedback, dims_feat, early_exit=True):
     """Env-free restatement of Seq2SeqAgent._rollout_with_loss (follower.py:430-539)
     / _score_obs_actions_and_instructions (:342-428) over precomputed per-step
     observations.  step_inputs(t) -> (X[B,V,F], all_u[B,A,F], is_valid[B,A]).
@@ -184,7 +184,7 @@ def follower_rollout(enc, dec, seq, lengths, ctx_mask, steps, step_inputs, targe
         logits.append(logit)
         actions.append(a_t)
         ended |= (a_t == 0)                                               # :527-530
-        if ended.all():                                                   # :533
+        if early_exit and ended.all():                                    # :533
             break
     return dict(logits=logits, actions=np.stack(actions), loss=loss, losses=losses,
                 scores=seq_scores, h=h, c=c, ctx=ctx)

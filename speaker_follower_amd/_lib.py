@@ -8,6 +8,12 @@ current HIP stream.
 import ctypes as C
 import os
 
+# PyTorch-ROCm ships its own HIP runtime (torch/lib/libamdhip64.so, same SONAME as the system
+# one).  It must be the first HIP runtime loaded into the process, otherwise libsf_hip.so pulls in
+# /opt/rocm's copy and torch -- which provides device memory and streams -- runs on a runtime it was
+# not built against.  Importing torch first makes both share torch's runtime.
+import torch  # noqa: F401  (load order matters)
+
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, 'libsf_hip.so')
 
@@ -83,6 +89,7 @@ _SIGNATURES = {
     'sf_workspace_bytes': (C.c_size_t, []),
     'sf_abi_version': (C.c_int, []),
     'sf_status_string': (C.c_char_p, [C.c_int]),
+    'sf_last_error_string': (C.c_char_p, []),
     'sf_linear_fwd': (C.c_int, [c_f, i32, c_f, c_f, i32, i32, i32, i32, c_f, i32] + WS),
     'sf_linear_bwd': (C.c_int, [c_f, i32, c_f, c_f, i32, c_f, i32, i32, i32, i32, i32, c_f, i32,
                                 i32, c_f, c_f] + WS),
@@ -155,8 +162,10 @@ lib = _load()
 
 def check(status, what=''):
     if status != 0:
-        raise SfError('%s failed: %s (status %d)' % (what or 'libsf_hip call',
-                                                      lib.sf_status_string(status).decode(), status))
+        detail = lib.sf_status_string(status).decode()
+        if status == 3:
+            detail += ': ' + lib.sf_last_error_string().decode()
+        raise SfError('%s failed: %s (status %d)' % (what or 'libsf_hip call', detail, status))
 
 
 def call(name, *args):

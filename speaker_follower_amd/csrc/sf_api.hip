@@ -4,6 +4,10 @@
 
 using namespace sf;
 
+namespace sf {
+thread_local hipError_t g_last_hip_error = hipSuccess;
+}
+
 namespace {
 
 constexpr size_t WORKSPACE_BYTES = 64u << 20;
@@ -195,6 +199,7 @@ extern "C" {
 
 size_t sf_workspace_bytes(void) { return WORKSPACE_BYTES; }
 int sf_abi_version(void) { return SF_ABI_VERSION; }
+const char* sf_last_error_string(void) { return hipGetErrorString(g_last_hip_error); }
 const char* sf_status_string(int s) {
     switch (s) {
         case SF_OK: return "ok";
@@ -208,6 +213,7 @@ const char* sf_status_string(int s) {
 
 int sf_linear_fwd(const float* x, int ldx, const float* w, const float* b, int M, int N, int K,
                   int act, float* y, int ldy, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(x && w && y && M > 0 && N > 0 && K > 0 && (act == 0 || act == 1));
     return linear_plain(x, ldx, w, K, b, M, N, K, act ? EPI_TANH : EPI_NONE, y, ldy,
                         arena(ws, ws_bytes), S(stream));
@@ -216,6 +222,7 @@ int sf_linear_fwd(const float* x, int ldx, const float* w, const float* b, int M
 int sf_linear_bwd(const float* x, int ldx, const float* w, const float* y, int ldy, const float* dy,
                   int lddy, int M, int N, int K, int act, float* dx, int lddx, int accumulate_dx,
                   float* dw, float* db, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(x && w && dy && M > 0 && N > 0 && K > 0 && (N % 4 == 0) && (K % 4 == 0));
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -239,6 +246,7 @@ int sf_lstm_cell_fwd(const sf_lstm_w* w, int B, int I, int H, const float* x, in
                      const float* h0, const float* c0, float* h1, float* c1, float* gates,
                      float* h1_drop, int ld_h1_drop, const sf_dropout* drop, uint32_t drop_stream,
                      void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && x && h0 && c0 && h1 && c1 && B > 0 && I > 0 && H > 0 && H % 4 == 0);
     return lstm_fwd_i(w, B, I, H, x, ldx, h0, c0, h1, c1, gates, h1_drop, ld_h1_drop,
                       make_dropout(drop, drop_stream), arena(ws, ws_bytes), S(stream));
@@ -248,6 +256,7 @@ int sf_lstm_cell_bwd(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H
                      int ldx, const float* h0, const float* c0, const float* c1, const float* gates,
                      const float* dh1, const float* dc1, float* dx, int lddx, float* dh0, float* dc0,
                      void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && x && h0 && c0 && c1 && gates && dc0 && B > 0 && H % 4 == 0 && I % 4 == 0);
     return lstm_bwd_i(w, g, B, I, H, x, ldx, h0, c0, c1, gates, dh1, nullptr, dc1, dx, lddx, dh0,
                       dc0, arena(ws, ws_bytes), S(stream));
@@ -257,6 +266,7 @@ int sf_visual_attention_fwd(const sf_visual_w* w, const sf_pano* X, int B, int H
                             const float* h, float* out, int ldo, float* alpha, float* t_v, float* q,
                             const sf_dropout* drop, uint32_t drop_stream, int drop_col0, void* ws,
                             size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && X && h && out && alpha && t_v && q && B > 0);
     return visual_fwd_i(w, pano(X), B, H, D, h, out, ldo, alpha, t_v, q,
                         make_dropout(drop, drop_stream), drop_col0, arena(ws, ws_bytes), S(stream));
@@ -267,6 +277,7 @@ int sf_visual_attention_bwd(const sf_visual_w* w, const sf_visual_g* g, const sf
                             const float* dout, int lddo, const sf_dropout* drop,
                             uint32_t drop_stream, int drop_col0, float* dh, void* ws,
                             size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && X && h && alpha && t_v && dout && B > 0);
     return visual_bwd_i(w, g, pano(X), B, H, D, h, alpha, t_v, dout, lddo,
                         make_dropout(drop, drop_stream), drop_col0, dh, arena(ws, ws_bytes),
@@ -277,6 +288,7 @@ int sf_soft_dot_attention_fwd(const sf_softdot_w* w, int B, int L, int H, const 
                               const float* ctx, const uint8_t* mask, float* h_tilde, float* alpha,
                               float* cat2, float* t_text, void* ws, size_t ws_bytes,
                               sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && h && ctx && h_tilde && alpha && cat2 && t_text && B > 0 && L > 0);
     return softdot_fwd_i(w, B, L, H, h, ldh, ctx, mask, h_tilde, alpha, cat2, t_text,
                          arena(ws, ws_bytes), S(stream));
@@ -287,6 +299,7 @@ int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int 
                               const float* t_text, const float* h_tilde, const float* dh_tilde,
                               float* dh, int lddh, float* dctx, void* ws, size_t ws_bytes,
                               sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && ctx && alpha && cat2 && t_text && h_tilde && dh_tilde && dh && B > 0);
     return softdot_bwd_i(w, g, B, L, H, ctx, alpha, cat2, t_text, h_tilde, dh_tilde, dh, lddh, dctx,
                          arena(ws, ws_bytes), S(stream));
@@ -295,6 +308,7 @@ int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int 
 int sf_eltwise_prod_scoring_fwd(const sf_scoring_w* w, const sf_cands* U, int B, int H, int D,
                                 const float* h, float* logit, float* t_a, float* wt, float* r,
                                 void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && U && h && logit && t_a && wt && r && B > 0);
     return scoring_fwd_i(w, cands(U), B, H, D, h, logit, t_a, wt, r, arena(ws, ws_bytes), S(stream));
 }
@@ -303,6 +317,7 @@ int sf_eltwise_prod_scoring_bwd(const sf_scoring_w* w, const sf_scoring_g* g, co
                                 int B, int H, int D, const float* h, const float* t_a,
                                 const float* wt, const float* dlogit, float* dh, void* ws,
                                 size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && U && h && t_a && wt && dlogit && B > 0);
     return scoring_bwd_i(w, g, cands(U), B, H, D, h, t_a, wt, dlogit, dh, arena(ws, ws_bytes),
                          S(stream));
@@ -314,6 +329,7 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
                         const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tp,
                         const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
                         sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && X && U && u_prev && h0 && c0 && ctx && tp && B > 0 && L > 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -342,6 +358,7 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
                         const float* dlogit, const float* dh1, const float* dc1, float* dh0,
                         float* dc0, float* dctx, const sf_dropout* drop, uint32_t step_id, void* ws,
                         size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0 && L > 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -368,6 +385,7 @@ int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const float* is
                          const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
                          int64_t* target_used, float* score, float* u_next, float* ce_term,
                          float* live, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(U && logit && target && ended && a_t && target_used && score && ce_term && live &&
                  B > 0 && (feedback == 0 || feedback == 1) && (is_valid || U->a_num));
     return follower_glue_fwd(cands(U), B, logit, is_valid, target, feedback, ended, a_t,
@@ -376,17 +394,20 @@ int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const float* is
 
 int sf_follower_glue_bwd(int B, int A, const float* logit, const int64_t* target_used,
                          const float* gscale, float* dlogit, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(logit && target_used && gscale && dlogit && B > 0 && A > 0);
     return softmax_ce_bwd(B, A, A, logit, target_used, -1, gscale, dlogit, S(stream));
 }
 
 int sf_reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
                     sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(term && live && sum_cnt && T > 0 && B > 0);
     return reduce_terms(term, live, T, B, sum_cnt, S(stream));
 }
 
 int sf_loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(sum_cnt && loss && gscale && T > 0);
     return loss_finalize(sum_cnt, T, loss, gscale, S(stream));
 }
@@ -396,6 +417,7 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
                         const int64_t* seq, const int32_t* lengths, float* ctx, float* decoder_init,
                         float* c_t, const sf_encoder_tape* tp, const sf_dropout* drop,
                         uint32_t drop_stream, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && seq && lengths && ctx && decoder_init && c_t && tp && B > 0 && T > 0 &&
                  T <= Lpad && E % 4 == 0 && H % 4 == 0);
     Arena ar = arena(ws, ws_bytes);
@@ -436,6 +458,7 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
                         const float* d_init, const float* d_ct, const sf_encoder_tape* tp,
                         const sf_dropout* drop, uint32_t drop_stream, void* ws, size_t ws_bytes,
                         sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && lengths && decoder_init && tp && B > 0 && T > 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -488,14 +511,17 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
 
 // ---- a11 gathers ---------------------------------------------------------------------------------------
 int sf_gather_panorama(const sf_pano* X, int B, float* out, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(X && out && B > 0 && X->table && X->loc_table && X->vp && X->view);
     return gather_panorama(pano(X), B, out, S(stream));
 }
 int sf_gather_candidates(const sf_cands* U, int B, float* all_u, float* is_valid, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(U && all_u && B > 0 && U->table && U->vp && U->cand_view && U->cand_sincos && U->a_num);
     return gather_candidates(cands(U), B, all_u, is_valid, S(stream));
 }
 int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(U && a && out && B > 0);
     return gather_actions(cands(U), B, a, out, S(stream));
 }
@@ -506,6 +532,7 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
                            const float* ctx, const uint8_t* ctx_mask, const sf_spk_decoder_tape* tp,
                            const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
                            sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && prev_word && h0 && c0 && ctx && tp && B > 0 && Tp > 0 && vocab > 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -527,6 +554,7 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
                            const float* dc1, float* dh0, float* dc0, float* dctx,
                            const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
                            sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(w && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -551,6 +579,7 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
 int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
                         float* score, float* nll_term, float* live, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(logit && target && ended && w_t && score && nll_term && live && B > 0 &&
                  vocab > 0 && ldv >= vocab);
     return speaker_glue_fwd(B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t,
@@ -559,23 +588,27 @@ int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int
 
 int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int pad_idx, const float* gscale, float* dlogit, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(logit && target && gscale && dlogit && B > 0 && vocab > 0 && ldv >= vocab);
     return softmax_ce_bwd(B, vocab, ldv, logit, target, pad_idx, gscale, dlogit, S(stream));
 }
 
 int sf_fill_f32(float* p, size_t n, float v, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(p || n == 0);
     return fill(p, n, v, S(stream));
 }
 
 int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,
                     const sf_dropout* drop, uint32_t drop_stream, int col0, sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(src && dst && B > 0 && N > 0);
     return dropout_copy(src, lds, B, N, dst, ldd, make_dropout(drop, drop_stream), col0, S(stream));
 }
 
 int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float* out,
                      sf_stream stream) {
+    SF_ENTER();
     SF_CHECK_ARG(table && idx && out && B > 0 && E > 0);
     return embedding_rows(table, E, idx, B, out, S(stream));
 }

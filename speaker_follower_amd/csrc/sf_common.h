@@ -18,10 +18,20 @@ constexpr int WAVE = 64;
         if (!(cond)) return SF_ERR_ARG; \
     } while (0)
 
-// Launch-error check that does not synchronise (safe under stream capture).
+// Launch-error check that does not synchronise (safe under stream capture).  The HIP "last
+// error" is per host thread and sticky: other runtime users in the process (PyTorch's caching
+// allocator polls events and leaves hipErrorNotReady behind) would otherwise be blamed on us, so
+// every extern "C" entry point clears it first (SF_ENTER) and the code of a real failure is kept
+// for sf_last_error_string().
+extern thread_local hipError_t g_last_hip_error;
+static inline void clear_stale_error() { (void)hipGetLastError(); }
 static inline int launch_status() {
-    return hipGetLastError() == hipSuccess ? SF_OK : SF_ERR_LAUNCH;
+    const hipError_t e = hipGetLastError();
+    if (e == hipSuccess) return SF_OK;
+    g_last_hip_error = e;
+    return SF_ERR_LAUNCH;
 }
+#define SF_ENTER() sf::clear_stale_error()
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
