@@ -85,8 +85,10 @@ typedef struct sf_lstm_g { float *w_ih, *w_hh, *b_ih, *b_hh; } sf_lstm_g;
 typedef struct sf_visual_w { /* VisualSoftDotAttention model.py:303-308 */
     const float *w_h, *b_h; /* linear_in_h [D,H],[D] */
     const float *w_v, *b_v; /* linear_in_v [D,F],[D]; b_v cannot change the output (softmax shift) */
+    const float *w_v_t;     /* optional [F,D] transposed copy of w_v (sf_transpose): lets q = t W_v run
+                               as a K-contiguous product; NULL = use w_v directly (slower) */
 } sf_visual_w;
-typedef struct sf_visual_g { float *w_h, *b_h, *w_v, *b_v; } sf_visual_g;
+typedef struct sf_visual_g { float *w_h, *b_h, *w_v, *b_v, *unused; } sf_visual_g;
 
 typedef struct sf_softdot_w { /* SoftDotAttention model.py:114-120 */
     const float *w_in;  /* linear_in  [H,H]  (no bias) */
@@ -98,8 +100,9 @@ typedef struct sf_scoring_w { /* EltwiseProdScoring model.py:335-340 */
     const float *w_h, *b_h;     /* linear_in_h [D,H],[D] */
     const float *w_a, *b_a;     /* linear_in_a [D,F],[D] */
     const float *w_out, *b_out; /* linear_out  [1,D],[1] */
+    const float *w_a_t;         /* optional [F,D] transposed copy of w_a (see sf_visual_w.w_v_t) */
 } sf_scoring_w;
-typedef struct sf_scoring_g { float *w_h, *b_h, *w_a, *b_a, *w_out, *b_out; } sf_scoring_g;
+typedef struct sf_scoring_g { float *w_h, *b_h, *w_a, *b_a, *w_out, *b_out, *unused; } sf_scoring_g;
 
 typedef struct sf_decoder_w { /* AttnDecoderLSTM model.py:361-375 */
     sf_lstm_w lstm;       /* LSTMCell(2F -> H) */
@@ -316,9 +319,12 @@ int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int
 
 /* Small utilities used by the host mirror (kept on the stream so rollouts never sync). */
 int sf_fill_f32(float* p, size_t n, float v, sf_stream stream);
+int sf_add_f32(float* dst, const float* src, size_t n, sf_stream stream); /* dst += src */
 /* dst[b, :N] (row stride ldd) = dropout(src[b, :N]) at site `drop_stream`, columns col0.. */
 int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,
                     const sf_dropout* drop, uint32_t drop_stream, int col0, sf_stream stream);
+/* dst[C,R] = src[R,C]^T -- builds the transposed weight copies (refresh after each optimizer step) */
+int sf_transpose(const float* src, int R, int Ccols, float* dst, sf_stream stream);
 /* embedding rows: out[b,:] = table[idx[b],:]  (model.py:497) */
 int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float* out,
                      sf_stream stream);

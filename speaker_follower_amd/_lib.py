@@ -45,9 +45,9 @@ def _ptr_struct(name, fields):
 
 
 LstmW = _ptr_struct('LstmW', ['w_ih', 'w_hh', 'b_ih', 'b_hh'])
-VisualW = _ptr_struct('VisualW', ['w_h', 'b_h', 'w_v', 'b_v'])
+VisualW = _ptr_struct('VisualW', ['w_h', 'b_h', 'w_v', 'b_v', 'w_v_t'])
 SoftdotW = _ptr_struct('SoftdotW', ['w_in', 'w_out'])
-ScoringW = _ptr_struct('ScoringW', ['w_h', 'b_h', 'w_a', 'b_a', 'w_out', 'b_out'])
+ScoringW = _ptr_struct('ScoringW', ['w_h', 'b_h', 'w_a', 'b_a', 'w_out', 'b_out', 'w_a_t'])
 
 
 class DecoderW(C.Structure):
@@ -135,8 +135,10 @@ _SIGNATURES = {
                                       c_f, c_p]),
     'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),
     'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
+    'sf_add_f32': (C.c_int, [c_f, c_f, C.c_size_t, c_p]),
     'sf_dropout_copy': (C.c_int, [c_f, i32, i32, i32, c_f, i32, P(Dropout), u32, i32, c_p]),
     'sf_embedding_fwd': (C.c_int, [c_f, i32, i64p, i32, c_f, c_p]),
+    'sf_transpose': (C.c_int, [c_f, i32, i32, c_f, c_p]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

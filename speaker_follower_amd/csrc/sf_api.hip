@@ -62,15 +62,23 @@ int linear_plain(const float* x, int ldx, const float* w, int ldw, const float* 
 int lstm_fwd_i(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx, const float* h0,
                const float* c0, float* h1, float* c1, float* gates, float* h1_drop, int ld_h1_drop,
                const Dropout& drop, Arena ar, hipStream_t st) {
+    LstmPwFwd p{};
+    p.xg = nullptr; p.b_ih = w->b_ih; p.b_hh = w->b_hh;
+    p.c0 = c0; p.h0 = h0; p.B = B; p.H = H; p.gates = gates; p.h1 = h1; p.c1 = c1;
+    p.h1_drop = h1_drop; p.ld_h1_drop = ld_h1_drop; p.drop = drop; p.lengths = nullptr;
+    if (I + H <= 1024 && H % 16 == 0) {
+        // short reduction (speaker decoder LSTMCell(300 -> 512)): one fused launch
+        LstmStepArgs f{};
+        f.h0 = h0; f.w_hh = w->w_hh; f.x = x; f.ldx = ldx; f.w_ih = w->w_ih; f.I = I; f.xg = nullptr;
+        f.b_ih = w->b_ih; f.b_hh = w->b_hh; f.B = B; f.H = H; f.pw = p;
+        return lstm_step_fused(f, st);
+    }
     Seg segs[2] = {{x, ldx, w->w_ih, I, I}, {h0, H, w->w_hh, H, H}};
     LinearOut o{};
     float* slabs = nullptr;
     int ks = 1;
     TRY(linear_nt(segs, 2, B, 4 * H, o, ar.rest(), ar.rest_n(), st, &slabs, &ks));
-    LstmPwFwd p{};
-    p.slabs = slabs; p.ks = ks; p.xg = nullptr; p.b_ih = w->b_ih; p.b_hh = w->b_hh;
-    p.c0 = c0; p.h0 = h0; p.B = B; p.H = H; p.gates = gates; p.h1 = h1; p.c1 = c1;
-    p.h1_drop = h1_drop; p.ld_h1_drop = ld_h1_drop; p.drop = drop; p.lengths = nullptr;
+    p.slabs = slabs; p.ks = ks;
     return lstm_pointwise_fwd(p, st);
 }
 
@@ -101,7 +109,10 @@ int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, co
                  int col0, Arena ar, hipStream_t st) {
     const int F = X.IMG + X.LOC;
     TRY(linear_plain(h, H, w->w_h, H, w->b_h, B, D, H, EPI_NONE, t_v, D, ar, st));
-    TRY(gemm_nn_ws(t_v, D, w->w_v, F, B, F, D, q, F, 0, ar.rest(), ar.rest_n(), st));
+    if (w->w_v_t)   // q = t_v W_v as a K-contiguous product against the transposed copy
+        TRY(linear_plain(t_v, D, w->w_v_t, D, nullptr, B, F, D, EPI_NONE, q, F, ar, st));
+    else
+        TRY(gemm_nn_ws(t_v, D, w->w_v, F, B, F, D, q, F, 0, ar.rest(), ar.rest_n(), st));
     return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st);
 }
 
@@ -164,7 +175,10 @@ int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, 
     o.y = wt; o.ldy = D; o.bias = w->b_h; o.mul = w->w_out; o.y_pre = t_a; o.ldy_pre = D;
     o.epi = EPI_MUL;
     TRY(linear_nt(&sg, 1, B, D, o, ar.rest(), ar.rest_n(), st));
-    TRY(gemm_nn_ws(wt, D, w->w_a, F, B, F, D, r, F, 0, ar.rest(), ar.rest_n(), st));
+    if (w->w_a_t)
+        TRY(linear_plain(wt, D, w->w_a_t, D, nullptr, B, F, D, EPI_NONE, r, F, ar, st));
+    else
+        TRY(gemm_nn_ws(wt, D, w->w_a, F, B, F, D, r, F, 0, ar.rest(), ar.rest_n(), st));
     return score_fwd(U, B, D, r, wt, w->b_a, w->b_out, logit, st);
 }
 
@@ -419,7 +433,7 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
                         uint32_t drop_stream, void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && seq && lengths && ctx && decoder_init && c_t && tp && B > 0 && T > 0 &&
-                 T <= Lpad && E % 4 == 0 && H % 4 == 0);
+                 T <= Lpad && E % 4 == 0 && H % 16 == 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
     const size_t BH = (size_t)B * H;
@@ -432,20 +446,17 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     TRY(fill(tp->cs, BH, 0.f, st));
     const Dropout dctx = make_dropout(drop, drop_stream);
     for (int t = 0; t < T; ++t) {
-        Seg sg{tp->hs + t * BH, H, w->lstm.w_hh, H, H};
-        LinearOut o{};
-        float* slabs = nullptr;
-        int ks = 1;
-        TRY(linear_nt(&sg, 1, B, 4 * H, o, ar.rest(), ar.rest_n(), st, &slabs, &ks));
-        LstmPwFwd p{};
-        p.slabs = slabs; p.ks = ks; p.xg = tp->xg + (size_t)t * B * 4 * H;
-        p.b_ih = w->lstm.b_ih; p.b_hh = w->lstm.b_hh;
+        // one fused launch per time step: h_t W_hh^T on the matrix cores + gates + cell update
+        LstmStepArgs f{};
+        f.h0 = tp->hs + t * BH; f.w_hh = w->lstm.w_hh; f.x = nullptr; f.xg = tp->xg + (size_t)t * B * 4 * H;
+        f.b_ih = w->lstm.b_ih; f.b_hh = w->lstm.b_hh; f.B = B; f.H = H;
+        LstmPwFwd& p = f.pw;
         p.c0 = tp->cs + t * BH; p.h0 = tp->hs + t * BH; p.B = B; p.H = H;
         p.gates = tp->gates + (size_t)t * B * 4 * H;
         p.h1 = tp->hs + (t + 1) * BH; p.c1 = tp->cs + (t + 1) * BH;
         p.h1_drop = nullptr; p.drop = make_dropout(nullptr, 0);
         p.lengths = lengths; p.t = t; p.ctx_out = ctx; p.ld_ctx = T * H; p.ctx_drop = dctx;
-        TRY(lstm_pointwise_fwd(p, st));
+        TRY(lstm_step_fused(f, st));
     }
     // model.py:96-99  decoder_init = tanh(encoder2decoder(h_T)); c_T raw
     TRY(linear_plain(tp->hs + T * BH, H, w->w_e2d, H, w->b_e2d, B, H, H, EPI_TANH, decoder_init, H,
@@ -599,11 +610,24 @@ int sf_fill_f32(float* p, size_t n, float v, sf_stream stream) {
     return fill(p, n, v, S(stream));
 }
 
+int sf_add_f32(float* dst, const float* src, size_t n, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG((dst && src) || n == 0);
+    if (n == 0) return SF_OK;
+    return add2(dst, 0, src, 0, 1, (int)n, dst, 0, S(stream));
+}
+
 int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,
                     const sf_dropout* drop, uint32_t drop_stream, int col0, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(src && dst && B > 0 && N > 0);
     return dropout_copy(src, lds, B, N, dst, ldd, make_dropout(drop, drop_stream), col0, S(stream));
+}
+
+int sf_transpose(const float* src, int R, int Ccols, float* dst, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(src && dst && R > 0 && Ccols > 0);
+    return transpose(src, R, Ccols, dst, S(stream));
 }
 
 int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float* out,

@@ -16,6 +16,7 @@
 // runs along that index and defines four "virtual" 16-wide tiles with stride-4 columns, which
 // the epilogue writes back as float4.
 #include "sf_gemm.h"
+#include "sf_lstm.h"
 
 namespace sf {
 
@@ -33,6 +34,8 @@ __device__ __forceinline__ float comp(const float4& v, int c) {
 // ------------------------------------------------------------------------------------------------
 // NT: C[M,N] = sum_s A_s[M,K_s] * W_s[N,K_s]^T        (forward Linear; both operands K-contiguous)
 // grid (ceil(N/64), ksplit, mblocks), block 256 = 4 waves, wave = MT m-tiles x one 16-col n-tile.
+// The k loop runs a 3-deep register prefetch ring: a weight chunk comes straight from HBM
+// (~900 cycles) while one chunk's MFMAs take MT*4*32 cycles, so two chunks stay in flight.
 // ------------------------------------------------------------------------------------------------
 struct NtArgs {
     Seg seg[3];
@@ -44,7 +47,88 @@ struct NtArgs {
     int ldo;               // N for slabs, ldy for direct
     const float* bias;     // direct mode only
     const float* bias2;
+    int epi;               // direct mode only: EPI_*
+    const float* mul;
+    float* y_pre;
+    int ldy_pre;
 };
+
+template <int MT>
+struct Frag {
+    float4 b;
+    float4 a[MT];
+};
+
+template <int MT>
+__device__ __forceinline__ void nt_load(Frag<MT>& f, const float* pb, const float* const (&pa)[MT],
+                                        int chunk) {
+    f.b = ld4(pb + chunk * 16);
+#pragma unroll
+    for (int t = 0; t < MT; ++t) f.a[t] = ld4(pa[t] + chunk * 16);
+}
+
+template <int MT>
+__device__ __forceinline__ void nt_mma(const Frag<MT>& f, f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(f.a[t], c), comp(f.b, c), acc[t]);
+}
+
+// Chunks [lo, hi) of one segment.  The steady-state loop body is branch-free (prefetch indices are
+// clamped instead of predicated) so that the compiler can keep two chunks of loads in flight behind
+// counted s_waitcnt vmcnt(N); a conditional load would force vmcnt(0) at every join.
+template <int MT>
+__device__ __forceinline__ void nt_segment(const Seg& sg, int lo, int hi, int n,
+                                           const int (&mrow)[MT], int kk, f32x4 (&acc)[MT]) {
+    const int full = sg.K >> 4;
+    const float* pb = sg.W + (size_t)n * sg.ldw + 4 * kk;
+    const float* pa[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) pa[t] = sg.A + (size_t)mrow[t] * sg.lda + 4 * kk;
+    const int end = min(hi, full);          // full chunks are [lo, end)
+    if (lo < end) {
+        const int last = end - 1;
+        Frag<MT> f0, f1, f2;
+        nt_load<MT>(f0, pb, pa, lo);
+        nt_load<MT>(f1, pb, pa, min(lo + 1, last));
+        int i = lo;
+        for (; i + 3 <= end; i += 3) {
+            nt_load<MT>(f2, pb, pa, min(i + 2, last));
+            nt_mma<MT>(f0, acc);
+            nt_load<MT>(f0, pb, pa, min(i + 3, last));
+            nt_mma<MT>(f1, acc);
+            nt_load<MT>(f1, pb, pa, min(i + 4, last));
+            nt_mma<MT>(f2, acc);
+        }
+        if (i < end) nt_mma<MT>(f0, acc);
+        if (i + 1 < end) nt_mma<MT>(f1, acc);
+    }
+    if (hi > full) {   // K_s % 16 != 0: one partial chunk, float4 granularity (K_s % 4 == 0)
+        const bool ok = full * 16 + 4 * kk < sg.K;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+        Frag<MT> f;
+        f.b = ok ? ld4(pb + full * 16) : z;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) f.a[t] = ok ? ld4(pa[t] + full * 16) : z;
+        nt_mma<MT>(f, acc);
+    }
+}
+
+template <int MT>
+__device__ __forceinline__ void nt_mainloop(const NtArgs& a, int c0, int c1, int n,
+                                            const int (&mrow)[MT], int kk, f32x4 (&acc)[MT]) {
+    int cs = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s >= a.nseg) break;
+        const Seg sg = a.seg[s];
+        const int nch = (sg.K + 15) >> 4;
+        const int lo = max(c0, cs) - cs, hi = min(c1, cs + nch) - cs;
+        cs += nch;
+        if (lo < hi) nt_segment<MT>(sg, lo, hi, n, mrow, kk, acc);
+    }
+}
 
 template <int MT>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
@@ -67,64 +151,200 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
 
     const int c0 = (int)(((long)split * a.chunks_total) / a.ksplit);
     const int c1 = (int)(((long)(split + 1) * a.chunks_total) / a.ksplit);
-
-    int cs = 0;
-    for (int s = 0; s < a.nseg; ++s) {
-        const Seg sg = a.seg[s];
-        const int nch = (sg.K + 15) >> 4;
-        const int lo = max(c0, cs) - cs, hi = min(c1, cs + nch) - cs;
-        cs += nch;
-        if (lo >= hi) continue;
-        const int full = sg.K >> 4;
-        const float* pb = sg.W + (size_t)n * sg.ldw + lo * 16 + 4 * kk;
-        const float* pa[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t) pa[t] = sg.A + (size_t)mrow[t] * sg.lda + lo * 16 + 4 * kk;
-        const int nfull = min(hi, full) - lo;
-#pragma unroll 2
-        for (int i = 0; i < nfull; ++i) {
-            const float4 b = ld4(pb);
-            float4 av[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) av[t] = ld4(pa[t]);
-            pb += 16;
-#pragma unroll
-            for (int t = 0; t < MT; ++t) pa[t] += 16;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(av[t], c), comp(b, c), acc[t]);
-        }
-        if (hi > full) {   // K_s % 16 != 0: one partial chunk, float4 granularity (K_s % 4 == 0)
-            const bool ok = full * 16 + 4 * kk < sg.K;
-            const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-            const float4 b = ok ? ld4(pb) : z;
-            float4 av[MT];
-#pragma unroll
-            for (int t = 0; t < MT; ++t) av[t] = ok ? ld4(pa[t]) : z;
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(av[t], c), comp(b, c), acc[t]);
-        }
-    }
+    nt_mainloop<MT>(a, c0, c1, n, mrow, kk, acc);
 
     // D layout: col = lane & 15, row = (lane >> 4) * 4 + r
     const int col = n0 + li;
     if (col >= a.N) return;
     float* out = a.out + (a.ksplit > 1 ? (size_t)split * a.M * a.N : 0);
     float bsum = 0.f;
-    if (a.ksplit == 1) {
-        if (a.bias) bsum += a.bias[col];
-        if (a.bias2) bsum += a.bias2[col];
-    }
+    if (a.bias) bsum += a.bias[col];
+    if (a.bias2) bsum += a.bias2[col];
+    const float mulv = a.epi == EPI_MUL ? a.mul[col] : 1.f;
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = m0 + 16 * t + kk * 4 + r;
-            if (row < a.M) out[(size_t)row * a.ldo + col] = acc[t][r] + bsum;
+            if (row >= a.M) continue;
+            float v = acc[t][r] + bsum;
+            if (a.epi == EPI_TANH) v = tanhf(v);
+            if (a.epi == EPI_MUL) {
+                if (a.y_pre) a.y_pre[(size_t)row * a.ldy_pre + col] = v;
+                v *= mulv;
+            }
+            out[(size_t)row * a.ldo + col] = v;
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Short reductions (K <= 1024: every Linear of the decode step except the LSTM gates, and the
+// recurrent h*W_hh^T of the encoder / speaker decoder).  These are LATENCY bound: a wave that walks
+// its K range chunk by chunk pays one HBM round trip per chunk (measured 13 us for K = 512).  So the
+// K range of one output tile is split over the waves of the block, every wave issues ALL its loads
+// before the first MFMA (<= CPW chunks of (1 + MT) float4 per lane), and the partial tiles meet in
+// LDS where the epilogue runs: one HBM round trip per launch, no split-K slabs, no second kernel.
+// ------------------------------------------------------------------------------------------------
+struct Seg2 {             // up to two K segments, resolved per chunk with uniform selects
+    Seg s0, s1;
+    int n0;               // chunks in s0
+    int total;            // chunks in s0 + s1
+};
+
+template <int MT, int CPW>
+struct Frags {
+    float4 b[CPW];
+    float4 a[CPW][MT];
+};
+
+template <int MT, int CPW>
+__device__ __forceinline__ void upfront_load(Frags<MT, CPW>& f, const Seg2& sg, int c_lo, int c_hi,
+                                             int n, const int (&mrow)[MT], int kk) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = min(c_lo + i, c_hi - 1);           // clamped: surplus slots re-load a valid chunk
+        const bool second = c >= sg.n0;
+        const int lc = second ? c - sg.n0 : c;
+        const float* W = second ? sg.s1.W : sg.s0.W;
+        const float* A = second ? sg.s1.A : sg.s0.A;
+        const int ldw = second ? sg.s1.ldw : sg.s0.ldw;
+        const int lda = second ? sg.s1.lda : sg.s0.lda;
+        const int K = second ? sg.s1.K : sg.s0.K;
+        const int k = lc * 16 + 4 * kk;
+        const bool ok = k < K;                           // partial last chunk (K % 16 != 0)
+        const int kc = ok ? k : 0;
+        const float4 bv = ld4(W + (size_t)n * ldw + kc);
+        f.b[i] = ok ? bv : z;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            const float4 av = ld4(A + (size_t)mrow[t] * lda + kc);
+            f.a[i][t] = ok ? av : z;
+        }
+    }
+}
+
+template <int MT, int CPW>
+__device__ __forceinline__ void upfront_mma(const Frags<MT, CPW>& f, int cnt, f32x4 (&acc)[MT]) {
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        if (i < cnt) {                                   // wave-uniform
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    acc[t] = mfma16(comp(f.a[i][t], c), comp(f.b[i], c), acc[t]);
+        }
+    }
+}
+
+constexpr int SMALL_WAVES = 8;
+
+struct SmallArgs {
+    Seg2 sg;
+    int M, N;
+    float* y;
+    int ldy;
+    const float* bias;
+    const float* bias2;
+    int epi;
+    const float* mul;
+    float* y_pre;
+    int ldy_pre;
+};
+
+// grid (ceil(N/16), ceil(mtiles/MT)), block 512 = 8 waves = 8 K-slices of one 16-col n-tile x MT m-tiles
+template <int MT, int CPW>
+__global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_kernel(SmallArgs a) {
+    __shared__ float s_part[SMALL_WAVES][MT][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
+    const int li = lane & 15, kk = lane >> 4;
+    const int n = min(n0 + li, a.N - 1);
+    int mrow[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) mrow[t] = min(m0 + 16 * t + li, a.M - 1);
+
+    const int c_lo = (wave * a.sg.total) / SMALL_WAVES;
+    const int c_hi = ((wave + 1) * a.sg.total) / SMALL_WAVES;
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (c_hi > c_lo) {
+        Frags<MT, CPW> f;
+        upfront_load<MT, CPW>(f, a.sg, c_lo, c_hi, n, mrow, kk);
+        upfront_mma<MT, CPW>(f, c_hi - c_lo, acc);
+    }
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_part[wave][t][(kk * 4 + r) * 16 + li] = acc[t][r];
+    __syncthreads();
+
+    for (int e = threadIdx.x; e < MT * 256; e += SMALL_WAVES * 64) {
+        const int t = e >> 8, rc = e & 255;
+        const int row = m0 + 16 * t + (rc >> 4), col = n0 + (rc & 15);
+        if (row >= a.M || col >= a.N) continue;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < SMALL_WAVES; ++w) v += s_part[w][t][rc];
+        if (a.bias) v += a.bias[col];
+        if (a.bias2) v += a.bias2[col];
+        if (a.epi == EPI_TANH) v = tanhf(v);
+        if (a.epi == EPI_MUL) {
+            if (a.y_pre) a.y_pre[(size_t)row * a.ldy_pre + col] = v;
+            v *= a.mul[col];
+        }
+        a.y[(size_t)row * a.ldy + col] = v;
+    }
+}
+
+// Fused recurrent LSTM step (nn.LSTMCell / one nn.LSTM time step): block = 16 waves = the 4 gate
+// tiles (i,f,g,o) of one 16-row x 16-hidden-unit patch x 4 K-slices; gates meet in LDS and the cell
+// update happens in the same kernel: ONE launch per time step.  grid (H/16, ceil(B/16)).
+constexpr int LSTM_KS = 4;
+
+template <int CPW>
+__global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmStepArgs p) {
+    __shared__ float s_g[4][LSTM_KS][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int gate = wave & 3, ksl = wave >> 2;
+    const int slice = blockIdx.x, m0 = blockIdx.y * 16;
+    const int li = lane & 15, kk = lane >> 4;
+    const int H = p.H;
+
+    Seg2 sg;
+    sg.s0 = Seg{p.h0, H, p.w_hh, H, H};
+    sg.n0 = (H + 15) >> 4;
+    sg.s1 = p.x ? Seg{p.x, p.ldx, p.w_ih, p.I, p.I} : sg.s0;
+    sg.total = sg.n0 + (p.x ? ((p.I + 15) >> 4) : 0);
+    const int n = gate * H + slice * 16 + li;
+    int mrow[1] = {min(m0 + li, p.B - 1)};
+    const int c_lo = (ksl * sg.total) / LSTM_KS, c_hi = ((ksl + 1) * sg.total) / LSTM_KS;
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (c_hi > c_lo) {
+        Frags<1, CPW> f;
+        upfront_load<1, CPW>(f, sg, c_lo, c_hi, n, mrow, kk);
+        upfront_mma<1, CPW>(f, c_hi - c_lo, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_g[gate][ksl][(kk * 4 + r) * 16 + li] = acc[0][r];
+    __syncthreads();
+
+    if (threadIdx.x >= 256) return;
+    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
+    const int b = m0 + row, j = slice * 16 + col;
+    if (b >= p.B) return;
+    float g4[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v = p.b_ih[g * H + j] + p.b_hh[g * H + j];
+#pragma unroll
+        for (int k = 0; k < LSTM_KS; ++k) v += s_g[g][k][threadIdx.x];
+        if (p.xg) v += p.xg[(size_t)b * 4 * H + g * H + j];
+        g4[g] = v;
+    }
+    lstm_cell_update(p.pw, b, j, g4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -306,23 +526,6 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(RedArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void epilogue_inplace_kernel(RedArgs a) {
-    // single-split direct output already holds acc + bias: apply the non-linear part in place
-    const size_t total = (size_t)a.M * a.N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (size_t)gridDim.x * blockDim.x) {
-        const int row = (int)(i / a.N), col = (int)(i % a.N);
-        float* o = a.y + (size_t)row * a.ldy + col;
-        float v = *o;
-        if (a.epi == EPI_TANH) v = tanhf(v);
-        if (a.epi == EPI_MUL) {
-            if (a.y_pre) a.y_pre[(size_t)row * a.ldy_pre + col] = v;
-            v *= a.mul[col];
-        }
-        *o = v;
-    }
-}
-
 __global__ __launch_bounds__(256) void colsum_kernel(const float* Y, int ldy, int M, int N,
                                                      float* out, int accumulate) {
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
@@ -354,12 +557,40 @@ inline int red_grid(size_t total) { return (int)std::min<size_t>((total + 255) /
 
 }  // namespace
 
+// Short-reduction path: K <= 1024 and a small output (decode-step Linears).  Returns false when the
+// streaming kernel should be used instead.
+static bool small_shape(int M, int N, int chunks, int* mt, int* cpw) {
+    const int mtiles = ceil_div(M, 16), ntiles = ceil_div(N, 16);
+    if (chunks > 64 || (long)mtiles * ntiles > 2048) return false;
+    const int c = ceil_div(chunks, SMALL_WAVES);          // chunks per wave: 1..8
+    *cpw = c <= 2 ? 2 : (c <= 4 ? 4 : 8);
+    int m = std::min(mtiles, 32 / *cpw - 1);              // <= 32 float4 of loads per lane
+    m = m >= 4 ? 4 : (m >= 2 ? 2 : 1);
+    while (m > 1 && ntiles * ceil_div(mtiles, m) < 128) m >>= 1;   // keep >= 128 blocks if possible
+    *mt = m;
+    return true;
+}
+
+template <int MT, int CPW>
+static void launch_small(const SmallArgs& a, hipStream_t st) {
+    dim3 grid(ceil_div(a.N, 16), ceil_div(ceil_div(a.M, 16), MT));
+    hipLaunchKernelGGL((gemm_nt_small_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
+}
+
 static void nt_shape(int M, int N, int Ktot_chunks, int* mt, int* mblocks, int* ks) {
-    const int mtiles = ceil_div(M, 16);
+    const int mtiles = ceil_div(M, 16), ntiles = ceil_div(N, 16);
+    if (Ktot_chunks <= 64) {
+        // short reduction with a large output (the hoisted encoder input product): never split K
+        int m = 1;
+        while (m < 8 && (long)ntiles * ceil_div(mtiles, m) > 4096) m *= 2;
+        *mt = std::min(m, mtiles);
+        *mblocks = ceil_div(mtiles, *mt);
+        *ks = 1;
+        return;
+    }
     *mt = mtiles <= 8 ? mtiles : 8;
     *mblocks = ceil_div(mtiles, *mt);
-    const int waves = ceil_div(N, 16) * *mblocks;
-    *ks = pick_ksplit(waves, Ktot_chunks);
+    *ks = pick_ksplit(ntiles * *mblocks, Ktot_chunks);
 }
 
 int linear_ksplit(int M, int N, int Ktot) {
@@ -385,7 +616,29 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         a.seg[s] = segs[s];
         chunks += ceil_div(segs[s].K, 16);
     }
-    int mt, mblocks, ks;
+    int mt, mblocks, ks, cpw;
+    if (!raw_slabs && nseg <= 2 && small_shape(M, N, chunks, &mt, &cpw)) {
+        SmallArgs sa{};
+        sa.sg.s0 = segs[0];
+        sa.sg.n0 = ceil_div(segs[0].K, 16);
+        sa.sg.s1 = nseg == 2 ? segs[1] : segs[0];
+        sa.sg.total = chunks;
+        sa.M = M; sa.N = N; sa.y = out.y; sa.ldy = out.ldy; sa.bias = out.bias; sa.bias2 = out.bias2;
+        sa.epi = out.epi; sa.mul = out.mul; sa.y_pre = out.y_pre; sa.ldy_pre = out.ldy_pre;
+        switch (mt * 16 + cpw) {
+            case 1 * 16 + 2: launch_small<1, 2>(sa, st); break;
+            case 1 * 16 + 4: launch_small<1, 4>(sa, st); break;
+            case 1 * 16 + 8: launch_small<1, 8>(sa, st); break;
+            case 2 * 16 + 2: launch_small<2, 2>(sa, st); break;
+            case 2 * 16 + 4: launch_small<2, 4>(sa, st); break;
+            case 2 * 16 + 8: launch_small<2, 8>(sa, st); break;
+            case 4 * 16 + 2: launch_small<4, 2>(sa, st); break;
+            case 4 * 16 + 4: launch_small<4, 4>(sa, st); break;
+            default: return SF_ERR_UNSUPPORTED;
+        }
+        if (ksplit_out) *ksplit_out = 1;
+        return launch_status();
+    }
     nt_shape(M, N, chunks, &mt, &mblocks, &ks);
     const bool slabs = ks > 1 || raw_slabs;
     if (slabs) {
@@ -395,6 +648,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
     a.N = N;
     a.chunks_total = chunks;
     a.ksplit = ks;
+    a.epi = EPI_NONE;
     if (slabs) {
         a.out = ws;
         a.ldo = N;
@@ -405,6 +659,10 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         a.ldo = out.ldy;
         a.bias = out.bias;
         a.bias2 = out.bias2;
+        a.epi = out.epi;            // single split: epilogue fused into the GEMM
+        a.mul = out.mul;
+        a.y_pre = out.y_pre;
+        a.ldy_pre = out.ldy_pre;
     }
     const NtArgs& k = a;   // raw slabs with ks == 1: slab 0 is written without bias
     dim3 grid(ceil_div(N, 64), ks, mblocks);
@@ -438,10 +696,21 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         r.bias = out.bias;
         r.bias2 = out.bias2;
         hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid((size_t)M * N)), dim3(256), 0, st, r);
-    } else if (out.epi != EPI_NONE) {
-        hipLaunchKernelGGL(epilogue_inplace_kernel, dim3(red_grid((size_t)M * N)), dim3(256), 0,
-                           st, r);
     }
+    return launch_status();
+}
+
+int lstm_step_fused(const LstmStepArgs& p, hipStream_t st) {
+    if (p.H % 16 || (p.x && (p.I % 4 || p.ldx % 4))) return SF_ERR_UNSUPPORTED;
+    const int total = ceil_div(p.H, 16) + (p.x ? ceil_div(p.I, 16) : 0);
+    const int c = ceil_div(total, LSTM_KS);
+    dim3 grid(p.H / 16, ceil_div(p.B, 16)), block(4 * LSTM_KS * 64);
+    if (c <= 8)
+        hipLaunchKernelGGL(lstm_step_fused_kernel<8>, grid, block, 0, st, p);
+    else if (c <= 16)
+        hipLaunchKernelGGL(lstm_step_fused_kernel<16>, grid, block, 0, st, p);
+    else
+        return SF_ERR_UNSUPPORTED;
     return launch_status();
 }
 

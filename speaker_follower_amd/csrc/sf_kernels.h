@@ -2,6 +2,7 @@
 #pragma once
 #include "sf_common.h"
 #include "sf_gemm.h"
+#include "sf_lstm.h"
 #include "sf_rows.h"
 
 namespace sf {
@@ -24,23 +25,9 @@ int gemm_nn_ws(const float* A, int lda, const float* W, int ldw, int M, int N, i
 size_t gemm_nn_ws_floats(int M, int N, int K);
 
 // ---- sf_pointwise.hip ---------------------------------------------------------------------------
-// LSTM gates: reduce `ks` split-K slabs [ks][B][4H] + b_ih + b_hh (+ xg [B,4H] hoisted input
-// product, may be null), activate, update state.  live (may be null) = per-row "t < length" flag
-// for the packed-sequence encoder: dead rows copy h0/c0 through and write zeros to ctx_out.
-struct LstmPwFwd {
-    const float* slabs; int ks;
-    const float* xg;             // [B,4H] or null
-    const float* b_ih; const float* b_hh;
-    const float* c0; const float* h0;
-    int B, H;
-    float* gates;                // [B,4H] activated (may be null)
-    float* h1; float* c1;        // [B,H]
-    float* h1_drop; int ld_h1_drop; Dropout drop;   // optional dropped copy
-    const int* lengths; int t;   // encoder only (lengths null otherwise)
-    float* ctx_out; int ld_ctx;  // encoder only: ctx[b, t, :] row stride (= T*H)
-    Dropout ctx_drop;
-};
+// LSTM gates: reduce `ks` split-K slabs [ks][B][4H] + biases (+ hoisted xg), activate, update state.
 int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st);
+int lstm_step_fused(const LstmStepArgs& p, hipStream_t st);      // sf_gemm.hip
 
 struct LstmPwBwd {
     const float* gates; const float* c0; const float* c1;
@@ -73,6 +60,7 @@ int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float*
                    hipStream_t st);        // out[n] += sum_m s[m] * x[m,n]
 int sum_accum(const float* s, int M, float* out, hipStream_t st);   // out[0] += sum_m s[m]
 int fill(float* p, size_t n, float v, hipStream_t st);
+int transpose(const float* src, int R, int C, float* dst, hipStream_t st);   // dst[C,R] = src^T
 int embedding_tm(const float* table, int E, const int64_t* seq, int B, int Lpad, int T, float* out,
                  hipStream_t st);          // out[t, b, :] = table[seq[b, t], :]
 int embedding_rows(const float* table, int E, const int64_t* idx, int B, float* out,

@@ -1,0 +1,71 @@
+// LSTM cell update shared by the split-K pointwise kernel and the fused recurrent step kernel.
+#pragma once
+#include "sf_common.h"
+
+namespace sf {
+
+// LSTM gates -> state.  live (lengths != null) = per-row "t < length" flag of the
+// packed-sequence encoder: dead rows copy h0/c0 through and write zeros to ctx_out.
+struct LstmPwFwd {
+    const float* slabs; int ks;  // split-K partial slabs [ks][B][4H] (pointwise kernel only)
+    const float* xg;             // [B,4H] hoisted input product or null
+    const float* b_ih; const float* b_hh;
+    const float* c0; const float* h0;
+    int B, H;
+    float* gates;                // [B,4H] activated (may be null)
+    float* h1; float* c1;        // [B,H]
+    float* h1_drop; int ld_h1_drop; Dropout drop;   // optional dropped copy
+    const int* lengths; int t;   // encoder only (lengths null otherwise)
+    float* ctx_out; int ld_ctx;  // encoder only: ctx[b, t, :], row stride T*H
+    Dropout ctx_drop;
+};
+
+struct LstmStepArgs {            // fused recurrent step (sf_gemm.hip: lstm_step_fused_kernel)
+    const float* h0; const float* w_hh;             // [B,H], [4H,H]
+    const float* x; int ldx; const float* w_ih; int I;   // optional input segment (null if xg)
+    const float* xg;                                // [B,4H] hoisted x*W_ih^T or null
+    const float* b_ih; const float* b_hh;
+    int B, H;
+    LstmPwFwd pw;                                   // outputs / state (slabs, xg, biases unused)
+};
+
+// g4 = pre-activation gates (i,f,g,o) of element (b, j), biases already added.
+__device__ __forceinline__ void lstm_cell_update(const LstmPwFwd& a, int b, int j,
+                                                 const float (&g4)[4]) {
+    const int H = a.H;
+    const int idx = b * H + j;
+    const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]),
+                og = sigmoidf_(g4[3]);
+    const float c0 = a.c0[idx];
+    float c1 = fg * c0 + ig * gg;
+    float h1 = og * tanhf(c1);
+    if (a.gates) {
+        float* gp = a.gates + (size_t)b * 4 * H + j;
+        gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+    }
+    if (a.lengths) {
+        const bool live = a.t < a.lengths[b];
+        if (!live) { c1 = c0; h1 = a.h0[idx]; }
+        float cv = live ? h1 : 0.f;
+        if (live && a.ctx_drop.on()) {
+            const uint32_t rk = dropout_row_key(a.ctx_drop.seed, a.ctx_drop.stream,
+                                                (uint32_t)(a.ctx_drop.row0 + b));
+            cv = dropout_keep(rk, (uint32_t)(a.t * H + j), a.ctx_drop.thresh)
+                     ? cv * a.ctx_drop.scale : 0.f;
+        }
+        a.ctx_out[(size_t)b * a.ld_ctx + (size_t)a.t * H + j] = cv;
+    }
+    a.c1[idx] = c1;
+    a.h1[idx] = h1;
+    if (a.h1_drop) {
+        float hd = h1;
+        if (a.drop.on()) {
+            const uint32_t rk = dropout_row_key(a.drop.seed, a.drop.stream,
+                                                (uint32_t)(a.drop.row0 + b));
+            hd = dropout_keep(rk, (uint32_t)j, a.drop.thresh) ? hd * a.drop.scale : 0.f;
+        }
+        a.h1_drop[(size_t)b * a.ld_h1_drop + j] = hd;
+    }
+}
+
+}  // namespace sf

@@ -18,47 +18,23 @@ __global__ __launch_bounds__(TPB) void lstm_pw_fwd_kernel(LstmPwFwd a) {
     for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
         const int b = idx / H, j = idx - b * H;
         float g4[4];
+        float part[4][8];
+        // issue every slab load before the first add (ks <= 8): the slabs were just written by
+        // the split-K GEMM and sit in L2 / Infinity Cache, so this is latency- not bandwidth-bound
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                part[g][s] = s < a.ks ? a.slabs[s * slab + (size_t)b * 4 * H + g * H + j] : 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            const size_t o = (size_t)b * 4 * H + g * H + j;
             float v = a.b_ih[g * H + j] + a.b_hh[g * H + j];
-            if (a.xg) v += a.xg[o];
-            for (int s = 0; s < a.ks; ++s) v += a.slabs[s * slab + o];
+            if (a.xg) v += a.xg[(size_t)b * 4 * H + g * H + j];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) v += part[g][s];
             g4[g] = v;
         }
-        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]),
-                    og = sigmoidf_(g4[3]);
-        const float c0 = a.c0[idx];
-        float c1 = fg * c0 + ig * gg;
-        float h1 = og * tanhf(c1);
-        if (a.gates) {
-            float* gp = a.gates + (size_t)b * 4 * H + j;
-            gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
-        }
-        bool live = true;
-        if (a.lengths) {
-            live = a.t < a.lengths[b];
-            if (!live) { c1 = c0; h1 = a.h0[idx]; }
-            float cv = live ? h1 : 0.f;
-            if (live && a.ctx_drop.on()) {
-                const uint32_t rk = dropout_row_key(a.ctx_drop.seed, a.ctx_drop.stream,
-                                                    (uint32_t)(a.ctx_drop.row0 + b));
-                cv = dropout_keep(rk, (uint32_t)(a.t * H + j), a.ctx_drop.thresh)
-                         ? cv * a.ctx_drop.scale : 0.f;
-            }
-            a.ctx_out[(size_t)b * a.ld_ctx + (size_t)a.t * H + j] = cv;
-        }
-        a.c1[idx] = c1;
-        a.h1[idx] = h1;
-        if (a.h1_drop) {
-            float hd = h1;
-            if (a.drop.on()) {
-                const uint32_t rk = dropout_row_key(a.drop.seed, a.drop.stream,
-                                                    (uint32_t)(a.drop.row0 + b));
-                hd = dropout_keep(rk, (uint32_t)j, a.drop.thresh) ? hd * a.drop.scale : 0.f;
-            }
-            a.h1_drop[(size_t)b * a.ld_h1_drop + j] = hd;
-        }
+        lstm_cell_update(a, b, j, g4);
     }
 }
 
@@ -173,6 +149,17 @@ __global__ void sum_accum_kernel(const float* s, int M, float* out) {
         for (int m = 0; m < M; ++m) acc += s[m];
         out[0] += acc;
     }
+}
+// 32x32 LDS-tiled transpose (both sides coalesced)
+__global__ __launch_bounds__(256) void transpose_kernel(const float* src, int R, int C, float* dst) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(size_t)(r0 + i) * C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 __global__ __launch_bounds__(TPB) void fill_kernel(float* p, size_t n, float v) {
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n; i += (size_t)gridDim.x * TPB)
@@ -404,6 +391,7 @@ __global__ void loss_finalize_kernel(const float* sum_cnt, int T, float* loss, f
 }  // namespace
 
 int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st) {
+    if (a.ks > 8) return SF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(grid1d((size_t)a.B * a.H)), dim3(TPB), 0, st, a);
     return launch_status();
 }
@@ -464,6 +452,11 @@ int sum_accum(const float* s, int M, float* out, hipStream_t st) {
 int fill(float* p, size_t n, float v, hipStream_t st) {
     if (n == 0) return SF_OK;
     hipLaunchKernelGGL(fill_kernel, dim3(grid1d(n)), dim3(TPB), 0, st, p, n, v);
+    return launch_status();
+}
+int transpose(const float* src, int R, int C, float* dst, hipStream_t st) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, st, src,
+                       R, C, dst);
     return launch_status();
 }
 int embedding_tm(const float* table, int E, const int64_t* seq, int B, int Lpad, int T, float* out,

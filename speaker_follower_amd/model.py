@@ -25,7 +25,7 @@ import torch.nn as nn
 from . import _lib, ops
 from ._lib import call
 from .runtime import (require_gpu, ptr, f32, stream, ws_args, dropout_arg, struct_of, grad_ptr,
-                      pano_dense, cands_dense, _v)
+                      pano_dense, cands_dense, transposed, _v)
 
 byref = C.byref
 
@@ -352,9 +352,14 @@ def decoder_params(mod):
 
 
 def decoder_w_struct(params, grad=False):
-    vals = _grads(params) if grad else [p.data_ptr() for p in params]
-    return _lib.DecoderW(_lib.LstmW(*vals[0:4]), _lib.VisualW(*vals[4:8]),
-                         _lib.SoftdotW(*vals[8:10]), _lib.ScoringW(*vals[10:16]))
+    if grad:
+        vals = _grads(params)
+        return _lib.DecoderW(_lib.LstmW(*vals[0:4]), _lib.VisualW(*vals[4:8]),
+                             _lib.SoftdotW(*vals[8:10]), _lib.ScoringW(*vals[10:16]))
+    vals = [p.data_ptr() for p in params]
+    w_v_t, w_a_t = transposed(params[6]), transposed(params[12])
+    return _lib.DecoderW(_lib.LstmW(*vals[0:4]), _lib.VisualW(*vals[4:8], w_v_t.data_ptr()),
+                         _lib.SoftdotW(*vals[8:10]), _lib.ScoringW(*vals[10:16], w_a_t.data_ptr()))
 
 
 class _DecoderStepFn(torch.autograd.Function):

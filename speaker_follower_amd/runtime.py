@@ -102,3 +102,26 @@ def pano_dense(X):
 def cands_dense(U):
     B, A, F = U.shape
     return _lib.Cands(U.data_ptr(), None, None, None, None, None, A, 1, F, 0)
+
+
+_transposed = {}
+
+
+def transposed(w):
+    """Device copy of w^T for a 2-D weight, rebuilt only when the weight changed (torch bumps
+    `_version` on every in-place update, e.g. optimizer.step()).  288 GB of HBM make keeping every
+    hot weight in both layouts free; it turns y = x W into a K-contiguous product."""
+    import weakref
+    key = w.data_ptr()
+    hit = _transposed.get(key)
+    if hit is not None and hit[0]() is w and hit[1] == w._version:
+        return hit[2]
+    R, Cc = w.shape
+    out = hit[2] if (hit is not None and hit[2].shape == (Cc, R) and hit[2].device == w.device) \
+        else torch.empty(Cc, R, device=w.device, dtype=torch.float32)
+    _lib.call('sf_transpose', ptr(w.detach()), R, Cc, ptr(out), stream())
+    if len(_transposed) > 256:                      # dead entries of freed modules
+        for k in [k for k, v in _transposed.items() if v[0]() is None]:
+            del _transposed[k]
+    _transposed[key] = (weakref.ref(w), w._version, out)
+    return out

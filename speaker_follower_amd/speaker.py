@@ -1,0 +1,234 @@
+"""Speaker scoring / decoding on the HIP path.
+
+`SpeakerEngine.score` is Seq2SeqSpeaker._score_obs_actions_and_instructions
+(speaker.py:123-202) over index-form paths: SpeakerEncoderLSTM (model.py:437-457: per path
+step visual attention + LSTMCell, padded steps included, no length masking), then up to
+`instruction_len` SpeakerDecoderLSTM steps (model.py:487-519) with the per-step glue
+(log-softmax, NLL with PAD ignored, teacher / argmax next word, EOS bookkeeping;
+speaker.py:163-191) -- all as C-ABI calls on one stream, no host sync per word.
+`.loss.backward()` runs BPTT through the C-ABI backward entry points.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+from .features import cand_sincos
+from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
+from .model import _grads
+from .runtime import ptr, stream, ws_args, dropout_arg, struct_of
+
+byref = C.byref
+
+
+@dataclass
+class DeviceSpeakerBatch:
+    """Index-form speaker batch in HBM (see synth.SpeakerBatch)."""
+    instr_seq: torch.Tensor     # [B,Lmax] int64 targets (not reversed, EOS appended, PAD after)
+    path_mask: torch.Tensor     # [B,Tp] uint8, 1 = padded path step
+    vp: torch.Tensor            # [Tp,B] int32, -1 on padded steps (zero panorama)
+    view: torch.Tensor          # [Tp,B] int32
+    act: torch.Tensor           # [Tp,B] int32: 1 = move (use act_view/sincos), 0 = stop / padded -> zero row
+    act_view: torch.Tensor      # [Tp,B] int32
+    act_sincos: torch.Tensor    # [Tp,B,4] fp32
+    row0: int = 0
+
+    @property
+    def batch_size(self):
+        return self.instr_seq.shape[0]
+
+    @classmethod
+    def from_synth(cls, sb, device='cuda', max_length=80, row0=0):
+        Tp, B = sb.vp.shape
+        steps = np.arange(Tp)[:, None]
+        live = steps < sb.path_len[None, :]
+        seq, _, _ = batch_instructions_from_encoded(sb.instr, max_length, device=device)
+        dev = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=device, dtype=dt)  # noqa: E731
+        return cls(instr_seq=seq,
+                   path_mask=dev((~live).T.astype(np.uint8), torch.uint8),
+                   vp=dev(np.where(live, sb.vp, -1), torch.int32),
+                   view=dev(sb.view, torch.int32),
+                   act=dev((live & ~sb.act_is_stop).astype(np.int32), torch.int32),
+                   act_view=dev(sb.act_view, torch.int32),
+                   act_sincos=dev(cand_sincos(sb.act_heading, sb.act_elevation), torch.float32),
+                   row0=row0)
+
+
+class SpeakerState:
+    pass
+
+
+class _SpeakerLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, engine, state, *params):
+        ctx.engine, ctx.state = engine, state
+        return state.loss_buf.clone().reshape(())
+
+    @staticmethod
+    def backward(ctx, dloss):
+        ctx.engine._backward(ctx.state, dloss)
+        return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
+
+
+_DEC_TAPE = ('emb', 'gates', 'c1', 'h1', 'cat2', 't_text', 'alpha', 'h_tilde', 'logit')
+
+
+class SpeakerEngine:
+    def __init__(self, encoder, decoder, store, group=None):
+        self.encoder, self.decoder, self.store = encoder, decoder, store
+        self.group = group
+        self.iteration = 0
+        self.dropout_seed = None
+
+    def score(self, batch, steps, feedback='teacher', train=None):
+        """Returns a SpeakerState: .words [S,B], .logits [S,B,vocab], .step_scores [S,B],
+        .loss (differentiable), .ctx [B,Tp,H]."""
+        enc, dec, store = self.encoder, self.decoder, self.store
+        dev = store.device
+        B, S = batch.batch_size, steps
+        Tp = batch.vp.shape[0]
+        H, F, V = enc.hidden_size, store.F, store.V
+        D = enc.visual_attention_layer.linear_in_h.weight.shape[0]
+        E, vocab = dec.vocab_embedding_size, dec.vocab_size
+        ldv = (vocab + 3) & ~3
+        training = dec.training if train is None else train
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        st = SpeakerState()
+        st.batch, st.steps, st.dims = batch, S, (B, Tp, H, F, V, D, E, vocab, ldv)
+        st.feedback = FEEDBACK[feedback]
+        if self.dropout_seed is None:
+            self.dropout_seed = torch.initial_seed() & 0xFFFFFFFF
+        st.drop_enc = (enc.drop.p if training else 0.0, self.dropout_seed ^ 0x2545F491, batch.row0)
+        st.drop_dec = (dec.drop.p if training else 0.0, self.dropout_seed, batch.row0)
+        st.site0 = self.iteration * 256
+        self.iteration += 1
+        ws = ws_args(dev)
+
+        # ---- encoder: Tp x (visual attention -> cat -> dropout -> LSTMCell), model.py:437-451
+        ep = enc._params8()
+        vw, lw = struct_of(_lib.VisualW, ep[0:4]), struct_of(_lib.LstmW, ep[4:8])
+        st.e = dict(xin=new(Tp, B, 2 * F), alpha=new(Tp, B, V), t_v=new(Tp, B, D), q=new(Tp, B, F),
+                    gates=new(Tp, B, 4 * H), hs=torch.zeros(Tp + 1, B, H, device=dev),
+                    cs=torch.zeros(Tp + 1, B, H, device=dev), act_emb=new(Tp, B, F))
+        d_enc = dropout_arg(*st.drop_enc)
+        for t in range(Tp):
+            pano = store.pano(batch.vp[t], batch.view[t])
+            st.e['act_emb'][t] = store.gather_actions(batch.vp[t], batch.act_view[t],
+                                                      batch.act_sincos[t], batch.act[t])
+            xin_f = C.c_void_p(st.e['xin'][t].data_ptr() + 4 * F)
+            call('sf_visual_attention_fwd', byref(vw), byref(pano), B, H, D, ptr(st.e['hs'][t]),
+                 xin_f, 2 * F, ptr(st.e['alpha'][t]), ptr(st.e['t_v'][t]), ptr(st.e['q'][t]), d_enc,
+                 2 * (st.site0 + t), F, *ws)
+            call('sf_dropout_copy', ptr(st.e['act_emb'][t]), F, B, F, ptr(st.e['xin'][t]), 2 * F,
+                 d_enc, 2 * (st.site0 + t), 0, ws[2])
+            call('sf_lstm_cell_fwd', byref(lw), B, 2 * F, H, ptr(st.e['xin'][t]), 2 * F,
+                 ptr(st.e['hs'][t]), ptr(st.e['cs'][t]), ptr(st.e['hs'][t + 1]),
+                 ptr(st.e['cs'][t + 1]), ptr(st.e['gates'][t]), None, 0, None, 0, *ws)
+        # decoder_init = tanh(encoder2decoder(h)) (model.py:453); ctx = dropout(stack(h)) (:455-456)
+        st.h_init = new(B, H)
+        e2d = enc.encoder2decoder
+        call('sf_linear_fwd', ptr(st.e['hs'][Tp]), H, ptr(e2d.weight), ptr(e2d.bias), B, H, H, 1,
+             ptr(st.h_init), H, *ws)
+        st.c_init = st.e['cs'][Tp]
+        ctx_raw = st.e['hs'][1:].permute(1, 0, 2).contiguous()          # [B,Tp,H]
+        st.ctx = new(B, Tp, H)
+        call('sf_dropout_copy', ptr(ctx_raw), Tp * H, B, Tp * H, ptr(st.ctx), Tp * H, d_enc,
+             2 * (st.site0 + Tp) + 1, 0, ws[2])
+
+        # ---- decoder: S x (embedding -> LSTMCell -> dropout -> attention -> vocab projection)
+        shapes = dict(emb=(E,), gates=(4 * H,), c1=(H,), h1=(H,), cat2=(2 * H,), t_text=(H,),
+                      alpha=(Tp,), h_tilde=(H,), logit=(ldv,))
+        st.tape = {k: new(S, B, *shapes[k]) for k in _DEC_TAPE}
+        st.words = torch.empty(S + 1, B, dtype=torch.int64, device=dev)
+        st.words[0] = BOS                                                  # speaker.py:137
+        st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
+        st.step_scores, st.nll_term, st.live = new(S, B), new(S, B), new(S, B)
+        st.sum_cnt, st.gscale, st.loss_buf = new(S, 2), new(S), new(1)
+        dw = dec._w_struct()
+        d_dec = dropout_arg(*st.drop_dec)
+        st.targets = batch.instr_seq[:, :S].t().contiguous()              # [S,B] (speaker.py:163)
+        for t in range(S):
+            tp = _lib.SpkDecoderTape(*(st.tape[k][t].data_ptr() for k in _DEC_TAPE))
+            h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
+            c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
+            call('sf_speaker_decoder_fwd', byref(dw), B, E, H, Tp, vocab, ptr(st.words[t]), ptr(h0),
+                 ptr(c0), ptr(st.ctx), ptr(batch.path_mask), byref(tp), d_dec, st.site0 + t, *ws)
+            call('sf_speaker_glue_fwd', B, vocab, ldv, ptr(st.tape['logit'][t]),
+                 ptr(st.targets[t]), st.feedback, PAD, EOS, ptr(st.ended),
+                 ptr(st.words[t + 1]), ptr(st.step_scores[t]), ptr(st.nll_term[t]),
+                 ptr(st.live[t]), ws[2])
+        call('sf_reduce_terms', ptr(st.nll_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
+        if self.group is not None:
+            torch.distributed.all_reduce(st.sum_cnt, group=self.group)
+        call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
+        st.logits = st.tape['logit'][:, :, :vocab]
+        st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
+        params = list(ep) + [e2d.weight, e2d.bias] + list(dec._params9())
+        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+            st.loss = _SpeakerLossFn.apply(self, st, *params)
+        else:
+            st.loss = st.loss_buf.clone().reshape(())
+        return st
+
+    def _backward(self, st, dloss):
+        enc, dec, store = self.encoder, self.decoder, self.store
+        batch, S = st.batch, st.steps
+        B, Tp, H, F, V, D, E, vocab, ldv = st.dims
+        dev = store.device
+        new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+        ws = ws_args(dev)
+        gscale = st.gscale * dloss.to(torch.float32)
+        dw, dg = dec._w_struct(), dec._w_struct(grad=True)
+        d_dec = dropout_arg(*st.drop_dec)
+        dlogit = new(B, ldv)
+        dh_a, dc_a, dh_b, dc_b = new(B, H), new(B, H), new(B, H), new(B, H)
+        dctx = torch.zeros(B, Tp, H, device=dev, dtype=torch.float32)
+        dh1 = dc1 = None
+        for t in range(S - 1, -1, -1):
+            tp = _lib.SpkDecoderTape(*(st.tape[k][t].data_ptr() for k in _DEC_TAPE))
+            h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
+            c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
+            call('sf_speaker_glue_bwd', B, vocab, ldv, ptr(st.tape['logit'][t]), ptr(st.targets[t]),
+                 PAD, ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
+            call('sf_speaker_decoder_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, ptr(h0), ptr(c0),
+                 ptr(st.ctx), byref(tp), ptr(dlogit), ptr(dh1), ptr(dc1), ptr(dh_a), ptr(dc_a),
+                 ptr(dctx), d_dec, st.site0 + t, *ws)
+            dh1, dc1 = dh_a, dc_a
+            dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
+        # ---- encoder backward
+        d_enc = dropout_arg(*st.drop_enc)
+        ep = enc._params8()
+        vw, vg = struct_of(_lib.VisualW, ep[0:4]), _lib.VisualW(*_grads(ep[0:4]))
+        lw, lg = struct_of(_lib.LstmW, ep[4:8]), _lib.LstmW(*_grads(ep[4:8]))
+        e2d = enc.encoder2decoder
+        g_e2d = _grads((e2d.weight, e2d.bias))
+        # through decoder_init = tanh(W h_Tp + b): dh1 here is d h_init
+        dh = new(B, H)
+        call('sf_linear_bwd', ptr(st.e['hs'][Tp]), H, ptr(e2d.weight), ptr(st.h_init), H, ptr(dh1), H,
+             B, H, H, 1, ptr(dh), H, 0, g_e2d[0], g_e2d[1], *ws)
+        dc_in = dc1                                         # c_init is the raw cell state (model.py:457)
+        # through ctx = dropout(stack(h_1..h_Tp))
+        dctx_raw = new(B, Tp, H)
+        call('sf_dropout_copy', ptr(dctx), Tp * H, B, Tp * H, ptr(dctx_raw), Tp * H, d_enc,
+             2 * (st.site0 + Tp) + 1, 0, ws[2])
+        dctx_t = dctx_raw.permute(1, 0, 2).contiguous()    # [Tp,B,H]
+        dxin = new(B, 2 * F)
+        dh_in, dh_out = dh, new(B, H)
+        dc_bufs, k = (new(B, H), new(B, H)), 0
+        for t in range(Tp - 1, -1, -1):
+            # h_{t+1} also feeds ctx[:, t]
+            call('sf_add_f32', ptr(dh_in), ptr(dctx_t[t]), B * H, ws[2])
+            pano = store.pano(batch.vp[t], batch.view[t])
+            call('sf_lstm_cell_bwd', byref(lw), byref(lg), B, 2 * F, H, ptr(st.e['xin'][t]), 2 * F,
+                 ptr(st.e['hs'][t]), ptr(st.e['cs'][t]), ptr(st.e['cs'][t + 1]),
+                 ptr(st.e['gates'][t]), ptr(dh_in), ptr(dc_in), ptr(dxin), 2 * F, ptr(dh_out),
+                 ptr(dc_bufs[k]), *ws)
+            dxin_f = C.c_void_p(dxin.data_ptr() + 4 * F)
+            call('sf_visual_attention_bwd', byref(vw), byref(vg), byref(pano), B, H, D,
+                 ptr(st.e['hs'][t]), ptr(st.e['alpha'][t]), ptr(st.e['t_v'][t]), dxin_f, 2 * F, d_enc,
+                 2 * (st.site0 + t), F, ptr(dh_out), *ws)
+            dh_in, dh_out = dh_out, dh_in
+            dc_in, k = dc_bufs[k], k ^ 1
