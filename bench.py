@@ -124,19 +124,18 @@ def main():
         params_d = [p for p in dec.parameters() if p.requires_grad]
         opt_e = torch.optim.Adam(params_e, lr=1e-4, weight_decay=5e-4)     # train.py:263-268
         opt_d = torch.optim.Adam(params_d, lr=1e-4, weight_decay=5e-4)
+        from speaker_follower_amd import dp
+        flat = dp.FlatGrads(params_e + params_d)       # kernels accumulate straight into this buffer
     else:
         enc.eval()
         dec.eval()
 
     def one_step():
         if train:
-            opt_e.zero_grad(set_to_none=False)
-            opt_d.zero_grad(set_to_none=False)
+            flat.zero()
             st = engine.rollout(batch, S, 'argmax', train=True)
             st.loss.backward()
-            if world > 1:
-                from speaker_follower_amd import dp
-                dp.allreduce_gradients(params_e + params_d, group)
+            flat.allreduce(group)                      # one RCCL sum all-reduce of 56 MB (no-op at N=1)
             opt_e.step()
             opt_d.step()
         else:
