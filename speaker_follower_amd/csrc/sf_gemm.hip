@@ -18,6 +18,8 @@
 #include "sf_gemm.h"
 #include "sf_lstm.h"
 
+#include <cstdlib>
+
 namespace sf {
 
 namespace {
@@ -174,6 +176,263 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
                 v *= mulv;
             }
             out[(size_t)row * a.ldo + col] = v;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// LDS-tiled NT GEMM for the one MFMA-bound product of the path: the decoder LSTM gates
+// [B<=128, 4864] x [2048, 4864]^T.  The register-streaming kernel above feeds the matrix cores with
+// "fragment shaped" loads (16 rows x 64 B per wave instruction), which keeps the texture addresser
+// busy twice as long as full lines would; here a block stages BK = 64 deep tiles of A (MT*16 rows)
+// and W (64 rows) into LDS with full 256-B row segments (16 lanes per row), double buffered through
+// registers (next stage's global loads are in flight while the current stage's 16*MT MFMAs per wave
+// run), and the four waves read their fragments with conflict-free ds_read_b128 (row stride
+// 68 dwords: 16 rows x 4 banks tile the 64 banks exactly).
+// grid (N/64, ksplit), block 256; a block's stages lie inside one K segment each (K_s % 64 == 0).
+// ------------------------------------------------------------------------------------------------
+constexpr int TBK = 64, TLD = TBK + 4;
+
+// 8 waves per block: waves 0-3 take the first half of every 64-deep stage, waves 4-7 the second
+// half (two waves per SIMD hide each other's barrier and LDS latencies); the halves meet in LDS.
+template <int MT>
+__global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int AROWS = MT * 16, WROWS = 64;
+    constexpr int BUF = (AROWS + WROWS) * TLD;           // floats per stage buffer
+    constexpr int APASS = (MT + 1) / 2;                  // 32 rows x 16 float4 per staging pass
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+    const int wave = wave8 & 3, khalf = wave8 >> 2;
+    const int li = lane & 15, kk = lane >> 4;
+    const int n0 = blockIdx.x * 64;
+    const int split = blockIdx.y;
+    const int ldrow = tid >> 4, ldc4 = tid & 15;         // staging: 32 rows x 16 float4 per pass
+
+    // stage range of this split (stages of 64 k over the concatenated segments)
+    const int st0n = a.seg[0].K / TBK;
+    const int st1n = a.nseg > 1 ? a.seg[1].K / TBK : 0;
+    const int st2n = a.nseg > 2 ? a.seg[2].K / TBK : 0;
+    const int stages = st0n + st1n + st2n;
+    const int s_lo = (int)(((long)split * stages) / a.ksplit);
+    const int s_hi = (int)(((long)(split + 1) * stages) / a.ksplit);
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Regs {
+        float4 a[APASS];
+        float4 w[2];
+    };
+    auto gload = [&](Regs& r, int s) {
+        const float* A;
+        const float* W;
+        int lda, ldw, k0;
+        if (s < st0n) {
+            A = a.seg[0].A; W = a.seg[0].W; lda = a.seg[0].lda; ldw = a.seg[0].ldw; k0 = s * TBK;
+        } else if (s < st0n + st1n) {
+            A = a.seg[1].A; W = a.seg[1].W; lda = a.seg[1].lda; ldw = a.seg[1].ldw; k0 = (s - st0n) * TBK;
+        } else {
+            A = a.seg[2].A; W = a.seg[2].W; lda = a.seg[2].lda; ldw = a.seg[2].ldw;
+            k0 = (s - st0n - st1n) * TBK;
+        }
+#pragma unroll
+        for (int p = 0; p < APASS; ++p) {
+            const int row = min(p * 32 + ldrow, a.M - 1);
+            r.a[p] = ld4(A + (size_t)row * lda + k0 + 4 * ldc4);
+        }
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const int row = min(n0 + p * 32 + ldrow, a.N - 1);
+            r.w[p] = ld4(W + (size_t)row * ldw + k0 + 4 * ldc4);
+        }
+    };
+    auto lstore = [&](const Regs& r, int buf) {
+        float* As = smem + buf * BUF;
+        float* Ws = As + AROWS * TLD;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p)
+            if (p * 32 + ldrow < AROWS)
+                *reinterpret_cast<float4*>(As + (p * 32 + ldrow) * TLD + 4 * ldc4) = r.a[p];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<float4*>(Ws + (p * 32 + ldrow) * TLD + 4 * ldc4) = r.w[p];
+    };
+    auto compute = [&](int buf) {
+        const float* As = smem + buf * BUF;
+        const float* Ws = As + AROWS * TLD + (wave * 16 + li) * TLD;
+#pragma unroll
+        for (int cc = 0; cc < TBK / 32; ++cc) {
+            const int c = khalf * (TBK / 32) + cc;
+            const float4 b = *reinterpret_cast<const float4*>(Ws + 16 * c + 4 * kk);
+            float4 av[MT];
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+                av[t] = *reinterpret_cast<const float4*>(As + (t * 16 + li) * TLD + 16 * c + 4 * kk);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(av[t], j), comp(b, j), acc[t]);
+        }
+    };
+
+    // Two stages of global loads stay in flight (register sets ra / rb alternate) behind the stage
+    // being computed from LDS: one stage of look-ahead measured ~2.9 us of exposed HBM latency per
+    // stage.  Prefetch indices are clamped, not predicated, so the loop body has no branches and the
+    // compiler can use counted vmcnt waits.
+    if (s_lo < s_hi) {
+        const int last = s_hi - 1;
+        Regs ra, rb;
+        gload(ra, s_lo);
+        lstore(ra, 0);
+        gload(ra, min(s_lo + 1, last));
+        gload(rb, min(s_lo + 2, last));
+        __syncthreads();
+        for (int s = s_lo; s < s_hi; s += 2) {
+            compute(0);                       // stage s     (ra: s+1, rb: s+2 in flight)
+            lstore(ra, 1);
+            __syncthreads();
+            gload(ra, min(s + 3, last));
+            if (s + 1 >= s_hi) break;
+            compute(1);                       // stage s+1   (rb: s+2, ra: s+3 in flight)
+            lstore(rb, 0);
+            __syncthreads();
+            gload(rb, min(s + 4, last));
+        }
+    }
+    __syncthreads();
+
+    // the two K halves meet in LDS (the stage buffers are free after the loop's last barrier)
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (khalf == 1) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[(wave * MT + t) * 64 + lane] = acc[t];
+    }
+    __syncthreads();
+    if (khalf == 1) return;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] += red[(wave * MT + t) * 64 + lane];
+
+    const int col = n0 + wave * 16 + li;
+    if (col >= a.N) return;
+    float* out = a.out + (a.ksplit > 1 ? (size_t)split * a.M * a.N : 0);
+    float bsum = 0.f;
+    if (a.bias) bsum += a.bias[col];
+    if (a.bias2) bsum += a.bias2[col];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + kk * 4 + r;
+            if (row < a.M) out[(size_t)row * a.ldo + col] = acc[t][r] + bsum;
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// "A-resident" NT GEMM: the decoder LSTM gates again, without per-stage barriers.  PMC on the
+// tiled kernel above showed waves parked 29 % of their life at the per-stage block barrier with
+// the MFMA pipe ~50 % busy.  Here a block (8 waves = 8 n-tiles = 128 columns, 2 waves per SIMD)
+// first stages its WHOLE K-slice of A (MT*16 rows x 304 k = 138 KB of the 160 KB LDS) with
+// full-line loads -- one barrier -- and then every wave runs free: it streams its own 16 weight
+// rows HBM -> registers through a 4-deep clamped prefetch ring and reads A fragments from LDS
+// (row stride 308 dwords = 52 mod 64: conflict-free ds_read_b128).  ksplit = K / 304.
+// grid (N/128, ksplit), block 512.
+// ------------------------------------------------------------------------------------------------
+constexpr int AR_KS_CHUNKS = 19;                       // 304 k per split
+constexpr int AR_LD = AR_KS_CHUNKS * 16 + 4;           // LDS row stride in floats (308)
+
+template <int MT>
+__global__ __launch_bounds__(512) void gemm_nt_aresident_kernel(NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int n0 = blockIdx.x * 128 + wave * 16;
+    const int split = blockIdx.y;
+    const int c_lo = split * AR_KS_CHUNKS;
+    const int c_hi = min(c_lo + AR_KS_CHUNKS, a.chunks_total);
+    const int n_s0 = a.seg[0].K >> 4;                   // chunks in segment 0 (K_s % 16 == 0)
+    const int n_s1 = a.nseg > 1 ? (a.seg[1].K >> 4) : 0;
+
+    // ---- stage the A slice: 16 lanes cover one 64-float unit of a row (256 B).  All loads are
+    // issued before the first LDS store (one L2 round trip for the whole 138 KB slice).
+    {
+        constexpr int QUADS = (AR_KS_CHUNKS + 3) / 4;    // 64-float units per row
+        constexpr int RP = (MT * 16 + 31) / 32;          // row passes of 32 rows
+        const int r0 = tid >> 4, q4 = tid & 15;
+        float4 v[QUADS][RP];
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            const int c = c_lo + 4 * q + (q4 >> 2);      // chunk this float4 belongs to
+            const int cc = c < c_hi ? c : c_lo;
+            const bool s1 = cc >= n_s0, s2 = cc >= n_s0 + n_s1;
+            const Seg& sg = s2 ? a.seg[2] : (s1 ? a.seg[1] : a.seg[0]);
+            const int kc = (cc - (s2 ? n_s0 + n_s1 : (s1 ? n_s0 : 0))) * 16 + 4 * (q4 & 3);
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                const int row = min(r0 + 32 * p, a.M - 1);
+                v[q][p] = ld4(sg.A + (size_t)row * sg.lda + kc);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < QUADS; ++q) {
+            const int c = c_lo + 4 * q + (q4 >> 2);
+#pragma unroll
+            for (int p = 0; p < RP; ++p) {
+                const int r = r0 + 32 * p;
+                if (c < c_hi && r < MT * 16)
+                    *reinterpret_cast<float4*>(smem + r * AR_LD + (c - c_lo) * 16 + 4 * (q4 & 3)) = v[q][p];
+            }
+        }
+    }
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int n = min(n0 + li, a.N - 1);
+    auto wload = [&](int c) -> float4 {                 // weight fragment of global chunk c
+        const bool s1 = c >= n_s0, s2 = c >= n_s0 + n_s1;
+        const Seg& sg = s2 ? a.seg[2] : (s1 ? a.seg[1] : a.seg[0]);
+        const int k = (c - (s2 ? n_s0 + n_s1 : (s1 ? n_s0 : 0))) * 16 + 4 * kk;
+        return ld4(sg.W + (size_t)n * sg.ldw + k);
+    };
+    auto mma = [&](const float4& b, int lc) {           // lc = chunk index inside the slice
+        float4 av[MT];
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            av[t] = *reinterpret_cast<const float4*>(smem + (t * 16 + li) * AR_LD + lc * 16 + 4 * kk);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(av[t], j), comp(b, j), acc[t]);
+    };
+
+    const int last = c_hi - 1;
+    float4 b0 = wload(min(c_lo, last)), b1 = wload(min(c_lo + 1, last)),
+           b2 = wload(min(c_lo + 2, last)), b3 = wload(min(c_lo + 3, last));
+    __syncthreads();                                    // A slice visible; W ring already in flight
+    int c = c_lo;
+    for (; c + 4 <= c_hi; c += 4) {
+        mma(b0, c - c_lo);     b0 = wload(min(c + 4, last));
+        mma(b1, c - c_lo + 1); b1 = wload(min(c + 5, last));
+        mma(b2, c - c_lo + 2); b2 = wload(min(c + 6, last));
+        mma(b3, c - c_lo + 3); b3 = wload(min(c + 7, last));
+    }
+    if (c < c_hi) mma(b0, c - c_lo);
+    if (c + 1 < c_hi) mma(b1, c - c_lo + 1);
+    if (c + 2 < c_hi) mma(b2, c - c_lo + 2);
+
+    const int col = n0 + li;
+    if (col >= a.N) return;
+    float* out = a.out + (a.ksplit > 1 ? (size_t)split * a.M * a.N : 0);
+    float bsum = 0.f;
+    if (a.bias) bsum += a.bias[col];
+    if (a.bias2) bsum += a.bias2[col];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + kk * 4 + r;
+            if (row < a.M) out[(size_t)row * a.ldo + col] = acc[t][r] + bsum;
         }
 }
 
@@ -664,7 +923,84 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         a.y_pre = out.y_pre;
         a.ldy_pre = out.ldy_pre;
     }
+    static const int variant = [] {          // development switch: SF_GEMM_VARIANT=tiled|ares|stream
+        const char* e = getenv("SF_GEMM_VARIANT");
+        return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'a' ? 2 : 3));
+    }();
+    bool ares = mblocks == 1 && chunks >= 128 && N >= 1024 && N % 128 == 0 && out.epi != EPI_MUL &&
+                variant == 2;   // measured equal to the tiled kernel (27.9 vs 28.1 us) but 2x the slabs
+    for (int s = 0; s < nseg; ++s) ares = ares && segs[s].K % 16 == 0;
+    bool launched = false;
+    if (ares) {
+        const int aks = ceil_div(chunks, AR_KS_CHUNKS);
+        if (aks > 1 && aks <= 16 && ws && ws_floats >= (size_t)aks * M * N) {
+            a.ksplit = aks;
+            a.out = ws;
+            a.ldo = N;
+            a.bias = nullptr;
+            a.bias2 = nullptr;
+            a.epi = EPI_NONE;
+            const size_t lds = (size_t)mt * 16 * AR_LD * sizeof(float);
+            dim3 agrid(N / 128, aks);
+#define SF_ARES(MTV)                                                                                  \
+    case MTV: {                                                                                       \
+        static bool attr_set = false;                                                                 \
+        if (!attr_set) {                                                                              \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_aresident_kernel<MTV>),   \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+            attr_set = true;                                                                          \
+        }                                                                                             \
+        hipLaunchKernelGGL(gemm_nt_aresident_kernel<MTV>, agrid, dim3(512), lds, st, a);              \
+    } break;
+            switch (mt) {
+                SF_ARES(1) SF_ARES(2) SF_ARES(3) SF_ARES(4) SF_ARES(5) SF_ARES(6) SF_ARES(7)
+                default: {
+                    static bool attr8 = false;
+                    if (!attr8) {
+                        (void)hipFuncSetAttribute(
+                            reinterpret_cast<const void*>(&gemm_nt_aresident_kernel<8>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        attr8 = true;
+                    }
+                    hipLaunchKernelGGL(gemm_nt_aresident_kernel<8>, agrid, dim3(512), lds, st, a);
+                }
+            }
+#undef SF_ARES
+            ks = aks;
+            launched = true;
+        }
+    }
     const NtArgs& k = a;   // raw slabs with ks == 1: slab 0 is written without bias
+    bool tiled = !launched && mblocks == 1 && chunks >= 128 && N % 64 == 0 && a.epi == EPI_NONE &&
+                 variant != 3;
+    for (int s = 0; s < nseg; ++s) tiled = tiled && segs[s].K % TBK == 0;
+    if (tiled) {
+        dim3 tgrid(N / 64, ks);
+        const size_t lds = (size_t)2 * (mt * 16 + 64) * TLD * sizeof(float);
+#define SF_TILED(MTV)                                                                              \
+    case MTV: {                                                                                    \
+        static bool attr_set = false;   /* > 64 KB of dynamic LDS must be opted into, once */      \
+        if (!attr_set) {                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_tiled_kernel<MTV>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        hipLaunchKernelGGL(gemm_nt_tiled_kernel<MTV>, tgrid, dim3(512), lds, st, k);               \
+    } break;
+        switch (mt) {
+            SF_TILED(1) SF_TILED(2) SF_TILED(3) SF_TILED(4) SF_TILED(5) SF_TILED(6) SF_TILED(7)
+            default: {
+                static bool attr8 = false;
+                if (!attr8) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_tiled_kernel<8>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                    attr8 = true;
+                }
+                hipLaunchKernelGGL(gemm_nt_tiled_kernel<8>, tgrid, dim3(512), lds, st, k);
+            }
+        }
+#undef SF_TILED
+    } else if (!launched) {
     dim3 grid(ceil_div(N, 64), ks, mblocks);
     switch (mt) {
         case 1: launch_nt<1>(k, grid, st); break;
@@ -675,6 +1011,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         case 6: launch_nt<6>(k, grid, st); break;
         case 7: launch_nt<7>(k, grid, st); break;
         default: launch_nt<8>(k, grid, st); break;
+    }
     }
     if (ksplit_out) *ksplit_out = ks;
     if (raw_slabs) {

@@ -18,20 +18,20 @@ __global__ __launch_bounds__(TPB) void lstm_pw_fwd_kernel(LstmPwFwd a) {
     for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
         const int b = idx / H, j = idx - b * H;
         float g4[4];
-        float part[4][8];
-        // issue every slab load before the first add (ks <= 8): the slabs were just written by
+        float part[4][16];
+        // issue every slab load before the first add (ks <= 16): the slabs were just written by
         // the split-K GEMM and sit in L2 / Infinity Cache, so this is latency- not bandwidth-bound
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
+            for (int s = 0; s < 16; ++s)
                 part[g][s] = s < a.ks ? a.slabs[s * slab + (size_t)b * 4 * H + g * H + j] : 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float v = a.b_ih[g * H + j] + a.b_hh[g * H + j];
             if (a.xg) v += a.xg[(size_t)b * 4 * H + g * H + j];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) v += part[g][s];
+            for (int s = 0; s < 16; ++s) v += part[g][s];
             g4[g] = v;
         }
         lstm_cell_update(a, b, j, g4);
@@ -391,7 +391,7 @@ __global__ void loss_finalize_kernel(const float* sum_cnt, int T, float* loss, f
 }  // namespace
 
 int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st) {
-    if (a.ks > 8) return SF_ERR_UNSUPPORTED;
+    if (a.ks > 16) return SF_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(grid1d((size_t)a.B * a.H)), dim3(TPB), 0, st, a);
     return launch_status();
 }

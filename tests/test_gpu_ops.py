@@ -41,7 +41,8 @@ def rnd(rng, *shape, scale=1.0):
 
 
 # ------------------------------------------------------------------------------------ GEMMs
-@pytest.mark.parametrize('M,N,K', [(100, 2048, 512), (8, 256, 512), (3, 512, 1024), (100, 991, 512),
+@pytest.mark.parametrize('M,N,K', [(100, 2048, 4864), (8, 256, 2176), (128, 2048, 4352), (33, 64, 2048),
+                                   (100, 2048, 512), (8, 256, 512), (3, 512, 1024), (100, 991, 512),
                                    (7, 2048, 300), (128, 64, 16), (250, 2048, 300), (1, 16, 4)])
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_fwd_bwd(sf, M, N, K, act):
