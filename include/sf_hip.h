@@ -206,15 +206,51 @@ int sf_eltwise_prod_scoring_bwd(const sf_scoring_w* w, const sf_scoring_g* g, co
                                 const float* wt, const float* dlogit, float* dh, void* ws,
                                 size_t ws_bytes, sf_stream stream);
 
+/* ---- follower per-step glue (follower.py:476-505) ---------------------------------------------
+ * Masks logits of invalid candidates to -inf in place (valid = a < a_num[b], or is_valid[b,a] != 0
+ * when is_valid is given), computes the cross-entropy term against target[b] (int64, -1 = ignore;
+ * rows with ended[b] != 0 are forced to -1), chooses the next action (feedback 0 = teacher:
+ * max(target,0); 1 = argmax, first maximum; 2 = sample from softmax with a counter-based uniform),
+ * writes this step's score[b] = log p(a_t) (the caller sums steps: follower.py:504-505), writes
+ * u_next[b,:] = U[b, a_t, :] (optionally through the NEXT step's input dropout, so that it can land
+ * directly in that step's LSTM input buffer), updates ended[b] |= (a_t == 0).  ce_term[b] / live[b]
+ * receive the row's CE term and 0/1 liveness; target_used the effective targets for the backward. */
+typedef struct sf_follower_glue {
+    const float* is_valid;    /* [B,A] or NULL */
+    const int64_t* target;    /* [B] */
+    int32_t feedback;
+    uint8_t* ended;           /* [B] in/out */
+    int64_t* a_t;             /* [B] out */
+    int64_t* target_used;     /* [B] out */
+    float* score;             /* [B] out */
+    float* u_next;            /* [B, ld_u_next] out, or NULL */
+    int32_t ld_u_next;
+    const sf_dropout* u_drop; /* NULL = no dropout on u_next */
+    uint32_t u_drop_stream;
+    float* ce_term;           /* [B] out */
+    float* live;              /* [B] out */
+    uint32_t sample_seed, sample_stream; /* feedback 2 only */
+    int32_t row0;                        /* global id of row 0 (sampling stream) */
+} sf_follower_glue;
+int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const sf_follower_glue* glue,
+                         sf_stream stream);
+/* dlogit[b,a] = gscale[0] * (softmax(logit)[b,a] - [a == target_used[b]]) for live rows, else 0
+ * (gscale = dloss / live count: a device scalar, so no host sync is needed). */
+int sf_follower_glue_bwd(int B, int A, const float* logit, const int64_t* target_used,
+                         const float* gscale, float* dlogit, sf_stream stream);
+
 /* ---- AttnDecoderLSTM.forward (model.py:377-397): one follower decode step --------------------
- * u_prev [B,F]; X panorama; U candidates; h0,c0 [B,H]; ctx [B,L,H]; ctx_mask [B,L].
- * Returns h1,c1 (tape->h1, tape->c1), alpha (tape->alpha), raw logit (tape->logit), alpha_v.
+ * u_prev [B,F] (NULL = tape->xin[:, :F] already holds dropout(u_prev), e.g. written by the
+ * previous step's glue); X panorama; U candidates; h0,c0 [B,H]; ctx [B,L,H]; ctx_mask [B,L].
+ * Returns h1,c1 (tape->h1, tape->c1), alpha (tape->alpha), logit (tape->logit), alpha_v.
+ * With glue != NULL the per-step glue runs fused with the scoring kernel and tape->logit holds
+ * the MASKED logits (what sf_follower_glue_bwd wants); otherwise the raw logits.
  * Dropout sites: 2*step for the LSTM input, 2*step+1 for h1 (step = `step_id`). */
 int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands* U, int B, int H,
                         int D, int L, const float* u_prev, const float* h0, const float* c0,
                         const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tape,
-                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
-                        sf_stream stream);
+                        const sf_follower_glue* glue, const sf_dropout* drop, uint32_t step_id,
+                        void* ws, size_t ws_bytes, sf_stream stream);
 /* Gradients in: dlogit [B,A], dh1, dc1 [B,H] (NULL = zero).  Out: dh0, dc0 [B,H] overwritten,
  * dctx [B,L,H] ADDED to.  u_prev is detached in the reference (follower.py:502): no du_prev. */
 int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
@@ -224,23 +260,6 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
                         float* dc0, float* dctx, const sf_dropout* drop, uint32_t step_id,
                         void* ws, size_t ws_bytes, sf_stream stream);
 
-/* ---- follower per-step glue (follower.py:476-505) ---------------------------------------------
- * Masks logits of invalid candidates to -inf in place (logit [B,A]; valid = a < a_num[b], or
- * is_valid[b,a] != 0 when is_valid is given), computes the cross-entropy term against
- * target[b] (int64, -1 = ignore; rows with ended[b] != 0 are forced to -1), chooses the next
- * action (feedback 0 = teacher: max(target,0); 1 = argmax, first maximum), writes this step's
- * score[b] = log p(a_t) (the caller sums steps: follower.py:504-505), writes
- * u_next[b,:] = U[b, a_t, :] (NULL = skip), updates
- * ended[b] |= (a_t == 0).  ce_term[b] / live[b] receive the row's CE term and 0/1 liveness;
- * target_used [B] int64 receives the effective targets for the backward. */
-int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const float* is_valid,
-                         const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
-                         int64_t* target_used, float* score, float* u_next, float* ce_term,
-                         float* live, sf_stream stream);
-/* dlogit[b,a] = gscale[0] * (softmax(logit)[b,a] - [a == target_used[b]]) for live rows, else 0
- * (gscale = dloss / live count: a device scalar, so no host sync is needed). */
-int sf_follower_glue_bwd(int B, int A, const float* logit, const int64_t* target_used,
-                         const float* gscale, float* dlogit, sf_stream stream);
 /* Loss bookkeeping without host syncs or atomics (deterministic order):
  * sum_cnt[t] = (sum_b term[t,b], sum_b live[t,b]) for t < T;  then, optionally after a
  * data-parallel all-reduce of sum_cnt, loss[0] = sum_t sum/cnt (0 where cnt == 0) which is the

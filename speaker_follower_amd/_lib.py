@@ -58,6 +58,14 @@ DecoderTape = _ptr_struct('DecoderTape', ['t_v', 'q', 'alpha_v', 'xin', 'gates',
                                           't_text', 'alpha', 'h_tilde', 't_a', 'wt', 'r', 'logit'])
 
 
+class FollowerGlue(C.Structure):
+    _fields_ = [('is_valid', c_p), ('target', c_p), ('feedback', C.c_int32), ('ended', c_p),
+                ('a_t', c_p), ('target_used', c_p), ('score', c_p), ('u_next', c_p),
+                ('ld_u_next', C.c_int32), ('u_drop', C.POINTER(Dropout)), ('u_drop_stream', C.c_uint32),
+                ('ce_term', c_p), ('live', c_p), ('sample_seed', C.c_uint32),
+                ('sample_stream', C.c_uint32), ('row0', C.c_int32)]
+
+
 class EncoderW(C.Structure):
     _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p)]
 
@@ -110,12 +118,12 @@ _SIGNATURES = {
     'sf_eltwise_prod_scoring_bwd': (C.c_int, [P(ScoringW), P(ScoringW), P(Cands), i32, i32, i32,
                                               c_f, c_f, c_f, c_f, c_f] + WS),
     'sf_attn_decoder_fwd': (C.c_int, [P(DecoderW), P(Pano), P(Cands), i32, i32, i32, i32, c_f, c_f,
-                                      c_f, c_f, c_p, P(DecoderTape), P(Dropout), u32] + WS),
+                                      c_f, c_f, c_p, P(DecoderTape), P(FollowerGlue), P(Dropout),
+                                      u32] + WS),
     'sf_attn_decoder_bwd': (C.c_int, [P(DecoderW), P(DecoderW), P(Pano), P(Cands), i32, i32, i32,
                                       i32, c_f, c_f, c_f, P(DecoderTape), c_f, c_f, c_f, c_f, c_f,
                                       c_f, P(Dropout), u32] + WS),
-    'sf_follower_glue_fwd': (C.c_int, [P(Cands), i32, c_f, c_f, i64p, i32, c_p, i64p, i64p, c_f,
-                                       c_f, c_f, c_f, c_p]),
+    'sf_follower_glue_fwd': (C.c_int, [P(Cands), i32, c_f, P(FollowerGlue), c_p]),
     'sf_follower_glue_bwd': (C.c_int, [i32, i32, c_f, i64p, c_f, c_f, c_p]),
     'sf_reduce_terms': (C.c_int, [c_f, c_f, i32, i32, c_f, c_p]),
     'sf_loss_finalize': (C.c_int, [c_f, i32, c_f, c_f, c_p]),

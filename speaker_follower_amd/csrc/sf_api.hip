@@ -1,6 +1,7 @@
 // extern "C" entry points of libsf_hip.so (see include/sf_hip.h) and the host-side sequencing of
 // kernels for the composite operators.  Nothing here allocates or synchronises.
 #include "sf_kernels.h"
+#include "sf_glue.h"
 
 using namespace sf;
 
@@ -37,6 +38,22 @@ inline PanoSrc pano(const sf_pano* p) {
 inline CandSrc cands(const sf_cands* c) {
     return CandSrc{c->dense, c->table, c->vp, c->cand_view, c->cand_sincos, c->a_num,
                    c->A, c->V, c->IMG, c->LOC};
+}
+
+inline FGlue make_glue(const CandSrc& src, int B, float* logit, const sf_follower_glue* g) {
+    FGlue f{};
+    f.src = src; f.B = B; f.logit = logit; f.is_valid = g->is_valid; f.target = g->target;
+    f.feedback = g->feedback; f.ended = g->ended; f.a_t = g->a_t; f.target_used = g->target_used;
+    f.score = g->score; f.u_next = g->u_next; f.ld_u = g->ld_u_next;
+    f.u_drop = make_dropout(g->u_drop, g->u_drop_stream);
+    f.ce_term = g->ce_term; f.live = g->live; f.sample_seed = g->sample_seed;
+    f.sample_stream = g->sample_stream; f.row0 = g->row0;
+    return f;
+}
+inline bool glue_ok(const sf_cands* U, const sf_follower_glue* g) {
+    return g->target && g->ended && g->a_t && g->target_used && g->score && g->ce_term && g->live &&
+           g->feedback >= 0 && g->feedback <= 2 && (g->is_valid || U->a_num) &&
+           (!g->u_next || g->ld_u_next % 4 == 0);
 }
 
 #define TRY(expr)                     \
@@ -168,7 +185,8 @@ int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, in
 
 // ---- a4 EltwiseProdScoring --------------------------------------------------------------------------
 int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, const float* h,
-                  float* logit, float* t_a, float* wt, float* r, Arena ar, hipStream_t st) {
+                  float* logit, float* t_a, float* wt, float* r, Arena ar, hipStream_t st,
+                  const sf_follower_glue* glue = nullptr) {
     const int F = U.IMG + U.LOC;
     Seg sg{h, H, w->w_h, H, H};
     LinearOut o{};
@@ -179,6 +197,7 @@ int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, 
         TRY(linear_plain(wt, D, w->w_a_t, D, nullptr, B, F, D, EPI_NONE, r, F, ar, st));
     else
         TRY(gemm_nn_ws(wt, D, w->w_a, F, B, F, D, r, F, 0, ar.rest(), ar.rest_n(), st));
+    if (glue) return score_glue_fwd(U, B, D, r, wt, w->b_a, w->b_out, make_glue(U, B, logit, glue), st);
     return score_fwd(U, B, D, r, wt, w->b_a, w->b_out, logit, st);
 }
 
@@ -341,10 +360,10 @@ int sf_eltwise_prod_scoring_bwd(const sf_scoring_w* w, const sf_scoring_g* g, co
 int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands* U, int B, int H,
                         int D, int L, const float* u_prev, const float* h0, const float* c0,
                         const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tp,
-                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
-                        sf_stream stream) {
+                        const sf_follower_glue* glue, const sf_dropout* drop, uint32_t step_id,
+                        void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
-    SF_CHECK_ARG(w && X && U && u_prev && h0 && c0 && ctx && tp && B > 0 && L > 0);
+    SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && B > 0 && L > 0 && (!glue || glue_ok(U, glue)));
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
     const PanoSrc xs = pano(X);
@@ -354,7 +373,7 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
     TRY(visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
                      d_in, F, ar, st));
     // model.py:391-392  drop(cat(u_prev, feature))
-    TRY(dropout_copy(u_prev, F, B, F, tp->xin, 2 * F, d_in, 0, st));
+    if (u_prev) TRY(dropout_copy(u_prev, F, B, F, tp->xin, 2 * F, d_in, 0, st));
     // model.py:393-394  LSTMCell; dropout(h_1) lands in cat2[:, H:2H]
     TRY(lstm_fwd_i(&w->lstm, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->h1, tp->c1, tp->gates,
                    tp->cat2 + H, 2 * H, d_h, ar, st));
@@ -363,7 +382,7 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
                       tp->t_text, ar, st));
     // model.py:396  action logits
     return scoring_fwd_i(&w->action, cands(U), B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt,
-                         tp->r, ar, st);
+                         tp->r, ar, st, glue);
 }
 
 int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
@@ -395,15 +414,11 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
                         dxin + F, 2 * F, d_in, F, dh0, ar, st);
 }
 
-int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const float* is_valid,
-                         const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
-                         int64_t* target_used, float* score, float* u_next, float* ce_term,
-                         float* live, sf_stream stream) {
+int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const sf_follower_glue* glue,
+                         sf_stream stream) {
     SF_ENTER();
-    SF_CHECK_ARG(U && logit && target && ended && a_t && target_used && score && ce_term && live &&
-                 B > 0 && (feedback == 0 || feedback == 1) && (is_valid || U->a_num));
-    return follower_glue_fwd(cands(U), B, logit, is_valid, target, feedback, ended, a_t,
-                             target_used, score, u_next, ce_term, live, S(stream));
+    SF_CHECK_ARG(U && logit && glue && B > 0 && glue_ok(U, glue));
+    return follower_glue_fwd(make_glue(cands(U), B, logit, glue), S(stream));
 }
 
 int sf_follower_glue_bwd(int B, int A, const float* logit, const int64_t* target_used,

@@ -2,6 +2,7 @@
 // One workgroup per sample, row set resident in registers (see sf_rows.h).
 #include "sf_kernels.h"
 #include "sf_rows.h"
+#include "sf_glue.h"
 
 namespace sf {
 
@@ -281,6 +282,45 @@ __global__ __launch_bounds__(SC_NW * 64) void score_fwd_kernel(ScoreArgs a) {
     if (lane == 0) a.logit[(size_t)b * A + wave] = d + cst + a.b_out[0];
 }
 
+// Scoring + per-step glue fused (one dependent stage instead of two): wave a keeps candidate a's row
+// in registers, the 16 logits meet in LDS, wave 0 masks / soft-maxes / picks the action, and the wave
+// that owns the chosen row writes dropout(u_next) straight into the next step's LSTM input.
+__global__ __launch_bounds__(SC_NW * 64) void score_glue_kernel(ScoreArgs a, FGlue g) {
+    __shared__ float s_logit[64];
+    __shared__ int s_at;
+    const int b = blockIdx.x;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int A = a.src.A;
+    const int n4 = (a.src.IMG + a.src.LOC) >> 2;
+    float4 x[SC_CPL];
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < SC_CPL; ++i) {
+        const int c = lane + 64 * i;
+        x[i] = (wave < A && c < n4) ? cand_chunk(a.src, b, wave, c) : f4zero();
+        if (c < n4) d += dot4(x[i], reinterpret_cast<const float4*>(a.r + (size_t)b * (n4 << 2))[c]);
+    }
+    float cst = 0.f;
+    if (wave < A)
+        for (int k = lane; k < a.D; k += 64) cst += a.wt[(size_t)b * a.D + k] * a.b_a[k];
+    d = wave_sum(d);
+    cst = wave_sum(cst);
+    if (lane == 0 && wave < A) s_logit[wave] = d + cst + a.b_out[0];
+    __syncthreads();
+    if (wave == 0) {
+        const int at = follower_glue_row(g, b, lane < A ? s_logit[lane] : 0.f);
+        if (lane == 0) s_at = at;
+    }
+    __syncthreads();
+    if (g.u_next && wave == s_at) {
+#pragma unroll
+        for (int i = 0; i < SC_CPL; ++i) {
+            const int c = lane + 64 * i;
+            if (c < n4) store_u_next(g, b, c, x[i]);
+        }
+    }
+}
+
 __global__ __launch_bounds__(SC_NW * 64) void score_bwd_kernel(ScoreArgs a) {
     __shared__ float4 slots[SC_SLOTS][SC_CPL * 64];
     const int b = blockIdx.x;
@@ -359,6 +399,17 @@ int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
         return SF_ERR_UNSUPPORTED;
     ScoreArgs a{src, r, wt, b_a, b_out, D, logit, nullptr, nullptr};
     hipLaunchKernelGGL(score_fwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
+    return launch_status();
+}
+
+int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
+                   const float* b_a, const float* b_out, const FGlue& g, hipStream_t st) {
+    const int F = src.IMG + src.LOC;
+    if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) ||
+        (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
+        return SF_ERR_UNSUPPORTED;
+    ScoreArgs a{src, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr};
+    hipLaunchKernelGGL(score_glue_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a, g);
     return launch_status();
 }
 

@@ -72,10 +72,11 @@ int gather_panorama(const PanoSrc& s, int B, float* out, hipStream_t st);
 int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hipStream_t st);
 int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st);
 
-int follower_glue_fwd(const CandSrc& s, int B, float* logit, const float* is_valid,
-                      const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
-                      int64_t* target_used, float* score, float* u_next, float* ce_term,
-                      float* live, hipStream_t st);
+struct FGlue;
+int follower_glue_fwd(const FGlue& g, hipStream_t st);
+// scoring + glue in one launch (sf_attention.hip); g.logit receives the masked logits
+int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
+                   const float* b_a, const float* b_out, const FGlue& g, hipStream_t st);
 int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,
                    const float* gscale, float* dlogit, hipStream_t st);
 int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,

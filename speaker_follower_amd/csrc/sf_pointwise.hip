@@ -1,6 +1,7 @@
 // Streaming (HBM-bound) kernels of the path: LSTM gate math, dropout, gathers from the feature
 // table, the follower/speaker per-step glue, and the small vector helpers the backward needs.
 #include "sf_kernels.h"
+#include "sf_glue.h"
 
 namespace sf {
 
@@ -228,61 +229,16 @@ __global__ __launch_bounds__(TPB) void gather_action_kernel(CandSrc s, int B, co
 }
 
 // ---- follower per-step glue (follower.py:476-505): one wave per sample -----------------------------
-struct FGlue {
-    CandSrc src;
-    int B;
-    float* logit;            // [B,A] masked in place
-    const float* is_valid;   // [B,A] or null
-    const int64_t* target;
-    int feedback;
-    uint8_t* ended;
-    int64_t* a_t;
-    int64_t* target_used;
-    float* score;
-    float* u_next;           // [B,F] or null
-    float* ce_term;          // [B]
-    float* live;             // [B]
-};
 __global__ __launch_bounds__(TPB) void follower_glue_kernel(FGlue g) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (b >= g.B) return;
     const int A = g.src.A;
-    bool valid = false;
-    if (lane < A)
-        valid = g.is_valid ? (g.is_valid[(size_t)b * A + lane] != 0.f) : (lane < g.src.a_num[b]);
-    float l = -INFINITY;
-    if (lane < A) {
-        if (valid) l = g.logit[(size_t)b * A + lane];
-        g.logit[(size_t)b * A + lane] = l;                       // follower.py:477
-    }
-    const float m = wave_max(l);
-    const float e = (lane < A && valid) ? expf(l - m) : 0.f;
-    const float lse = m + logf(wave_sum(e));
-    const bool was_ended = g.ended[b] != 0;
-    int64_t tgt = was_ended ? -1 : g.target[b];                  // follower.py:322-328
-    const float lt = __shfl(l, tgt >= 0 ? (int)tgt : 0, WAVE);
-    const float ce = tgt >= 0 ? (lse - lt) : 0.f;                // CrossEntropyLoss(ignore_index=-1)
-    int at;
-    if (g.feedback == 0) {
-        at = tgt > 0 ? (int)tgt : 0;                             // follower.py:486
-    } else {
-        const unsigned long long hit = __ballot(lane < A && l == m);
-        at = hit ? (int)__ffsll((long long)hit) - 1 : 0;         // first maximum, follower.py:488
-    }
-    const float la = __shfl(l, at, WAVE);
-    if (lane == 0) {
-        g.a_t[b] = at;
-        g.target_used[b] = tgt;
-        g.score[b] = la - lse;                                   // follower.py:504 (per-step term)
-        g.ce_term[b] = ce;
-        g.live[b] = tgt >= 0 ? 1.f : 0.f;
-        g.ended[b] = (was_ended || at == 0) ? 1 : 0;             // follower.py:527-530
-    }
+    const float raw = lane < A ? g.logit[(size_t)b * A + lane] : 0.f;
+    const int at = follower_glue_row(g, b, raw);
     if (g.u_next) {                                              // follower.py:502
         const int n4 = (g.src.IMG + g.src.LOC) >> 2;
-        for (int c = lane; c < n4; c += 64)
-            reinterpret_cast<float4*>(g.u_next)[(size_t)b * n4 + c] = cand_chunk(g.src, b, at, c);
+        for (int c = lane; c < n4; c += 64) store_u_next(g, b, c, cand_chunk(g.src, b, at, c));
     }
 }
 
@@ -490,14 +446,9 @@ int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_
                        dim3(TPB), 0, st, s, B, a, out);
     return launch_status();
 }
-int follower_glue_fwd(const CandSrc& s, int B, float* logit, const float* is_valid,
-                      const int64_t* target, int feedback, uint8_t* ended, int64_t* a_t,
-                      int64_t* target_used, float* score, float* u_next, float* ce_term,
-                      float* live, hipStream_t st) {
-    if (s.A > 64) return SF_ERR_UNSUPPORTED;
-    FGlue g{s, B, logit, is_valid, target, feedback, ended, a_t, target_used, score, u_next,
-            ce_term, live};
-    hipLaunchKernelGGL(follower_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
+int follower_glue_fwd(const FGlue& g, hipStream_t st) {
+    if (g.src.A > 64) return SF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(follower_glue_kernel, dim3(ceil_div(g.B, TPB / 64)), dim3(TPB), 0, st, g);
     return launch_status();
 }
 int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,

@@ -25,7 +25,7 @@ from .runtime import ptr, stream, ws_args, dropout_arg
 byref = C.byref
 
 PAD, UNK, EOS, BOS = 0, 1, 2, 3      # utils.py:19-24
-FEEDBACK = {'teacher': 0, 'argmax': 1}
+FEEDBACK = {'teacher': 0, 'argmax': 1, 'sample': 2}
 
 
 def batch_instructions_from_encoded(encoded_instructions, max_length, reverse=False, sort=False,
@@ -167,8 +167,10 @@ class FollowerEngine:
         shapes = dict(t_v=(D,), q=(F,), alpha_v=(V,), xin=(2 * F,), gates=(4 * H,), c1=(H,),
                       h1=(H,), cat2=(2 * H,), t_text=(H,), alpha=(T,), h_tilde=(H,), t_a=(D,),
                       wt=(D,), r=(F,), logit=(A,))
-        st.tape = {k: new(S, B, *shapes[k]) for k in _TAPE_KEYS}
-        st.u = torch.zeros(S + 1, B, F, device=dev, dtype=torch.float32)     # u[0] = u_begin
+        # one extra xin slot: step t's glue writes dropout(u_next) straight into step t+1's LSTM input
+        shapes_x = dict(shapes, xin=(2 * F,))
+        st.tape = {k: new(S + (1 if k == 'xin' else 0), B, *shapes_x[k]) for k in _TAPE_KEYS}
+        call('sf_fill_f32', ptr(st.tape['xin'][0]), B * 2 * F, 0.0, stream())   # u_begin = 0 (model.py:368)
         st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
         st.actions = torch.empty(S, B, dtype=torch.int64, device=dev)
         st.target_used = torch.empty(S, B, dtype=torch.int64, device=dev)
@@ -177,19 +179,23 @@ class FollowerEngine:
         params = decoder_params(dec)
         dw = decoder_w_struct(params)
         ws = ws_args(dev)
+        d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
+        d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
         for t in range(S):
             pano = store.pano(batch.vp[t], batch.view[t])
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
             tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
             h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
             c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
-            call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T,
-                 ptr(st.u[t]), ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), byref(tp),
-                 dropout_arg(*st.drop_dec), st.site0 + t, *ws)
-            call('sf_follower_glue_fwd', byref(cnd), B, ptr(st.tape['logit'][t]), None,
-                 ptr(batch.target[t]), st.feedback, ptr(st.ended), ptr(st.actions[t]),
-                 ptr(st.target_used[t]), ptr(st.step_scores[t]), ptr(st.u[t + 1]),
-                 ptr(st.ce_term[t]), ptr(st.live[t]), ws[2])
+            glue = _lib.FollowerGlue(
+                None, batch.target[t].data_ptr(), st.feedback, st.ended.data_ptr(),
+                st.actions[t].data_ptr(), st.target_used[t].data_ptr(), st.step_scores[t].data_ptr(),
+                st.tape['xin'][t + 1].data_ptr(), 2 * F, d_ptr, 2 * (st.site0 + t + 1),
+                st.ce_term[t].data_ptr(), st.live[t].data_ptr(),
+                int(st.drop_dec[1]) ^ 0x1B873593, st.site0 + t, batch.row0)
+            call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T, None,
+                 ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), byref(tp), byref(glue), d_ptr,
+                 st.site0 + t, *ws)
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         if self.group is not None:
             # global per-step normaliser so that the sharded loss equals the reference's batch mean
@@ -204,6 +210,22 @@ class FollowerEngine:
         else:
             st.loss = st.loss_buf.clone().reshape(())
         return st
+
+    def capture(self, batch, steps, feedback='argmax'):
+        """hipGraph of one inference rollout (eval mode, no autograd): returns (replay, state).
+        `replay()` re-runs encoder + `steps` decode steps on the captured buffers; the state's
+        tensors (.actions, .logits, .loss_buf, ...) are overwritten by every replay."""
+        with torch.no_grad():
+            self.rollout(batch, steps, feedback, train=False)          # warm-up: allocations, caches
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    st = self.rollout(batch, steps, feedback, train=False)
+            torch.cuda.current_stream().wait_stream(side)
+        return graph.replay, st
 
     # ------------------------------------------------------------------------------ backward
     def _backward(self, st, dloss):

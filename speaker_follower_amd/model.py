@@ -376,7 +376,7 @@ class _DecoderStepFn(torch.autograd.Function):
         pano, cnd = pano_dense(X), cands_dense(all_u)
         p, seed, site = drop_cfg
         call('sf_attn_decoder_fwd', byref(w), byref(pano), byref(cnd), B, H, D, L, ptr(u_prev),
-             ptr(h0), ptr(c0), ptr(context), ptr(mask), byref(tp), dropout_arg(p, seed), site,
+             ptr(h0), ptr(c0), ptr(context), ptr(mask), byref(tp), None, dropout_arg(p, seed), site,
              *ws_args(X.device))
         ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, H, D, L, drop_cfg)
         ctx.save_for_backward(all_u, X, h0, c0, context)
