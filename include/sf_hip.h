@@ -77,32 +77,39 @@ typedef struct sf_cands {
 } sf_cands;
 
 /* ---- weights (pointer sets keyed like the reference state_dicts) -------------------------- */
+/* Members ending in _t are OPTIONAL transposed copies (sf_transpose) of the weight of the same
+ * name: with them every product on the path, forward and backward, is K-contiguous (288 GB of HBM
+ * make a second layout of the hot weights free); NULL falls back to the slower in-place form.
+ * Gradient structs mirror the weight structs member for member (the _t slots are ignored). */
 typedef struct sf_lstm_w { /* nn.LSTMCell / nn.LSTM layer 0: weight_ih [4H,I], weight_hh [4H,H] */
     const float *w_ih, *w_hh, *b_ih, *b_hh;
+    const float *w_ih_t, *w_hh_t; /* [I,4H], [H,4H] */
 } sf_lstm_w;
-typedef struct sf_lstm_g { float *w_ih, *w_hh, *b_ih, *b_hh; } sf_lstm_g;
+typedef struct sf_lstm_g { float *w_ih, *w_hh, *b_ih, *b_hh, *unused0, *unused1; } sf_lstm_g;
 
 typedef struct sf_visual_w { /* VisualSoftDotAttention model.py:303-308 */
     const float *w_h, *b_h; /* linear_in_h [D,H],[D] */
     const float *w_v, *b_v; /* linear_in_v [D,F],[D]; b_v cannot change the output (softmax shift) */
-    const float *w_v_t;     /* optional [F,D] transposed copy of w_v (sf_transpose): lets q = t W_v run
-                               as a K-contiguous product; NULL = use w_v directly (slower) */
+    const float *w_v_t;     /* [F,D] */
+    const float *w_h_t;     /* [H,D] */
 } sf_visual_w;
-typedef struct sf_visual_g { float *w_h, *b_h, *w_v, *b_v, *unused; } sf_visual_g;
+typedef struct sf_visual_g { float *w_h, *b_h, *w_v, *b_v, *unused0, *unused1; } sf_visual_g;
 
 typedef struct sf_softdot_w { /* SoftDotAttention model.py:114-120 */
     const float *w_in;  /* linear_in  [H,H]  (no bias) */
     const float *w_out; /* linear_out [H,2H] (no bias) */
+    const float *w_in_t, *w_out_t; /* [H,H], [2H,H] */
 } sf_softdot_w;
-typedef struct sf_softdot_g { float *w_in, *w_out; } sf_softdot_g;
+typedef struct sf_softdot_g { float *w_in, *w_out, *unused0, *unused1; } sf_softdot_g;
 
 typedef struct sf_scoring_w { /* EltwiseProdScoring model.py:335-340 */
     const float *w_h, *b_h;     /* linear_in_h [D,H],[D] */
     const float *w_a, *b_a;     /* linear_in_a [D,F],[D] */
     const float *w_out, *b_out; /* linear_out  [1,D],[1] */
-    const float *w_a_t;         /* optional [F,D] transposed copy of w_a (see sf_visual_w.w_v_t) */
+    const float *w_a_t;         /* [F,D] */
+    const float *w_h_t;         /* [H,D] */
 } sf_scoring_w;
-typedef struct sf_scoring_g { float *w_h, *b_h, *w_a, *b_a, *w_out, *b_out, *unused; } sf_scoring_g;
+typedef struct sf_scoring_g { float *w_h, *b_h, *w_a, *b_a, *w_out, *b_out, *unused0, *unused1; } sf_scoring_g;
 
 typedef struct sf_decoder_w { /* AttnDecoderLSTM model.py:361-375 */
     sf_lstm_w lstm;       /* LSTMCell(2F -> H) */
@@ -251,14 +258,36 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
                         const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tape,
                         const sf_follower_glue* glue, const sf_dropout* drop, uint32_t step_id,
                         void* ws, size_t ws_bytes, sf_stream stream);
+/* Per-step gradient tape: the "dY" operands of every weight-gradient product of one decoder step.
+ * BPTT over S steps keeps them stacked [S][B][..]; sf_attn_decoder_wgrad then forms each weight
+ * gradient ONCE with reduction depth S*B instead of S read-modify-write passes over 12 M weights. */
+typedef struct sf_decoder_gtape {
+    float* dgates;  /* [B,4H] LSTM pre-activation gate gradients */
+    float* dpre;    /* [B,H]  linear_out pre-activation gradient */
+    float* dt_text; /* [B,H]  gradient of linear_in(h1_drop) */
+    float* dt_v;    /* [B,D]  gradient of visual linear_in_h(h0) */
+    float* dq;      /* [B,F]  gradient of the folded visual query */
+    float* dwt;     /* [B,D]  gradient of wt = t_a * w_out */
+    float* dta;     /* [B,D]  gradient of t_a */
+    float* dr;      /* [B,F]  gradient of the folded scoring vector */
+    float* dc;      /* [B]    gradient of the per-row scoring constant */
+} sf_decoder_gtape;
 /* Gradients in: dlogit [B,A], dh1, dc1 [B,H] (NULL = zero).  Out: dh0, dc0 [B,H] overwritten,
- * dctx [B,L,H] ADDED to.  u_prev is detached in the reference (follower.py:502): no du_prev. */
+ * dctx [B,L,H] ADDED to.  u_prev is detached in the reference (follower.py:502): no du_prev.
+ * g != NULL: weight gradients of this step are accumulated immediately; gtape != NULL: the dY
+ * operands are saved there for a later sf_attn_decoder_wgrad (pass g = NULL then). */
 int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
                         const sf_cands* U, int B, int H, int D, int L, const float* h0,
                         const float* c0, const float* ctx, const sf_decoder_tape* tape,
-                        const float* dlogit, const float* dh1, const float* dc1, float* dh0,
-                        float* dc0, float* dctx, const sf_dropout* drop, uint32_t step_id,
-                        void* ws, size_t ws_bytes, sf_stream stream);
+                        const sf_decoder_gtape* gtape, const float* dlogit, const float* dh1,
+                        const float* dc1, float* dh0, float* dc0, float* dctx,
+                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                        sf_stream stream);
+/* Weight gradients of M = S*B stacked rows: `tape` / `gtape` point at step 0 of stacked
+ * [S][B][..] tensors, h0_all [M,H] holds every step's incoming hidden state. */
+int sf_attn_decoder_wgrad(const sf_decoder_w* w, const sf_decoder_g* g, int M, int H, int D, int F,
+                          const float* h0_all, const sf_decoder_tape* tape,
+                          const sf_decoder_gtape* gtape, sf_stream stream);
 
 /* Loss bookkeeping without host syncs or atomics (deterministic order):
  * sum_cnt[t] = (sum_b term[t,b], sum_b live[t,b]) for t < T;  then, optionally after a
@@ -279,6 +308,7 @@ typedef struct sf_encoder_w {
     const float* embedding; /* [vocab,E] */
     sf_lstm_w lstm;         /* weight_ih_l0 [4H,E] ... */
     const float *w_e2d, *b_e2d; /* encoder2decoder [H,H],[H] */
+    const float *w_e2d_t;       /* optional [H,H] transposed */
 } sf_encoder_w;
 typedef struct sf_encoder_g { sf_lstm_g lstm; float *w_e2d, *b_e2d; } sf_encoder_g;
 typedef struct sf_encoder_tape { float *emb, *xg, *gates, *hs, *cs; } sf_encoder_tape;

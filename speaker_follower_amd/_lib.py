@@ -44,16 +44,18 @@ def _ptr_struct(name, fields):
     return type(name, (C.Structure,), {'_fields_': [(f, c_p) for f in fields]})
 
 
-LstmW = _ptr_struct('LstmW', ['w_ih', 'w_hh', 'b_ih', 'b_hh'])
-VisualW = _ptr_struct('VisualW', ['w_h', 'b_h', 'w_v', 'b_v', 'w_v_t'])
-SoftdotW = _ptr_struct('SoftdotW', ['w_in', 'w_out'])
-ScoringW = _ptr_struct('ScoringW', ['w_h', 'b_h', 'w_a', 'b_a', 'w_out', 'b_out', 'w_a_t'])
+LstmW = _ptr_struct('LstmW', ['w_ih', 'w_hh', 'b_ih', 'b_hh', 'w_ih_t', 'w_hh_t'])
+VisualW = _ptr_struct('VisualW', ['w_h', 'b_h', 'w_v', 'b_v', 'w_v_t', 'w_h_t'])
+SoftdotW = _ptr_struct('SoftdotW', ['w_in', 'w_out', 'w_in_t', 'w_out_t'])
+ScoringW = _ptr_struct('ScoringW', ['w_h', 'b_h', 'w_a', 'b_a', 'w_out', 'b_out', 'w_a_t', 'w_h_t'])
 
 
 class DecoderW(C.Structure):
     _fields_ = [('lstm', LstmW), ('visual', VisualW), ('text', SoftdotW), ('action', ScoringW)]
 
 
+DecoderGTape = _ptr_struct('DecoderGTape', ['dgates', 'dpre', 'dt_text', 'dt_v', 'dq', 'dwt', 'dta', 'dr',
+                                            'dc'])
 DecoderTape = _ptr_struct('DecoderTape', ['t_v', 'q', 'alpha_v', 'xin', 'gates', 'c1', 'h1', 'cat2',
                                           't_text', 'alpha', 'h_tilde', 't_a', 'wt', 'r', 'logit'])
 
@@ -67,7 +69,7 @@ class FollowerGlue(C.Structure):
 
 
 class EncoderW(C.Structure):
-    _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p)]
+    _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p), ('w_e2d_t', c_p)]
 
 
 class EncoderG(C.Structure):
@@ -121,8 +123,10 @@ _SIGNATURES = {
                                       c_f, c_f, c_p, P(DecoderTape), P(FollowerGlue), P(Dropout),
                                       u32] + WS),
     'sf_attn_decoder_bwd': (C.c_int, [P(DecoderW), P(DecoderW), P(Pano), P(Cands), i32, i32, i32,
-                                      i32, c_f, c_f, c_f, P(DecoderTape), c_f, c_f, c_f, c_f, c_f,
-                                      c_f, P(Dropout), u32] + WS),
+                                      i32, c_f, c_f, c_f, P(DecoderTape), P(DecoderGTape), c_f, c_f,
+                                      c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),
+    'sf_attn_decoder_wgrad': (C.c_int, [P(DecoderW), P(DecoderW), i32, i32, i32, i32, c_f,
+                                        P(DecoderTape), P(DecoderGTape), c_p]),
     'sf_follower_glue_fwd': (C.c_int, [P(Cands), i32, c_f, P(FollowerGlue), c_p]),
     'sf_follower_glue_bwd': (C.c_int, [i32, i32, c_f, i64p, c_f, c_f, c_p]),
     'sf_reduce_terms': (C.c_int, [c_f, c_f, i32, i32, c_f, c_p]),

@@ -75,6 +75,18 @@ int linear_plain(const float* x, int ldx, const float* w, int ldw, const float* 
     return linear_nt(&sg, 1, M, N, o, ar.rest(), ar.rest_n(), st);
 }
 
+// dx[M,K] (+)= dy[M,N] * W[N,K].  With W^T ([K,N]) at hand this is a K-contiguous NT product.
+int data_grad(const float* dy, int lddy, const float* w, const float* w_t, int M, int N, int K,
+              float* dx, int lddx, int accumulate, Arena ar, hipStream_t st) {
+    if (w_t && N % 4 == 0) {
+        Seg sg{dy, lddy, w_t, N, N};
+        LinearOut o{};
+        o.y = dx; o.ldy = lddx; o.epi = EPI_NONE; o.accumulate = accumulate;
+        return linear_nt(&sg, 1, M, K, o, ar.rest(), ar.rest_n(), st);
+    }
+    return gemm_nn_ws(dy, lddy, w, K, M, K, N, dx, lddx, accumulate, ar.rest(), ar.rest_n(), st);
+}
+
 // ---- a2 LSTMCell --------------------------------------------------------------------------------
 int lstm_fwd_i(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx, const float* h0,
                const float* c0, float* h1, float* c1, float* gates, float* h1_drop, int ld_h1_drop,
@@ -102,15 +114,15 @@ int lstm_fwd_i(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx,
 int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, const float* x, int ldx,
                const float* h0, const float* c0, const float* c1, const float* gates,
                const float* dh1, const float* dh1_b, const float* dc1, float* dx, int lddx,
-               float* dh0, float* dc0, Arena ar, hipStream_t st) {
-    float* dgates = ar.take((size_t)B * 4 * H);
+               float* dh0, float* dc0, Arena ar, hipStream_t st, float* dgates_out = nullptr) {
+    float* dgates = dgates_out ? dgates_out : ar.take((size_t)B * 4 * H);
     NEED(dgates);
     LstmPwBwd p{};
     p.gates = gates; p.c0 = c0; p.c1 = c1; p.dh1 = dh1; p.dh1_b = dh1_b; p.dc1 = dc1;
     p.B = B; p.H = H; p.dgates = dgates; p.dc0 = dc0; p.lengths = nullptr; p.dh0_pass = nullptr;
     TRY(lstm_pointwise_bwd(p, st));
-    if (dx) TRY(gemm_nn_ws(dgates, 4 * H, w->w_ih, I, B, I, 4 * H, dx, lddx, 0, ar.rest(), ar.rest_n(), st));
-    if (dh0) TRY(gemm_nn_ws(dgates, 4 * H, w->w_hh, H, B, H, 4 * H, dh0, H, 0, ar.rest(), ar.rest_n(), st));
+    if (dx) TRY(data_grad(dgates, 4 * H, w->w_ih, w->w_ih_t, B, 4 * H, I, dx, lddx, 0, ar, st));
+    if (dh0) TRY(data_grad(dgates, 4 * H, w->w_hh, w->w_hh_t, B, 4 * H, H, dh0, H, 0, ar, st));
     if (g) {
         if (g->w_ih) TRY(gemm_tn(dgates, 4 * H, x, ldx, B, 4 * H, I, g->w_ih, I, 1, st));
         if (g->w_hh) TRY(gemm_tn(dgates, 4 * H, h0, H, B, 4 * H, H, g->w_hh, H, 1, st));
@@ -135,16 +147,17 @@ int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, co
 
 int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, int B, int H, int D,
                  const float* h, const float* alpha, const float* t_v, const float* dout, int lddo,
-                 const Dropout& drop, int col0, float* dh, Arena ar, hipStream_t st) {
+                 const Dropout& drop, int col0, float* dh, Arena ar, hipStream_t st,
+                 float* dq_out = nullptr, float* dt_out = nullptr) {
     const int F = X.IMG + X.LOC;
-    float* dq = ar.take((size_t)B * F);
-    float* dt = ar.take((size_t)B * D);
+    float* dq = dq_out ? dq_out : ar.take((size_t)B * F);
+    float* dt = dt_out ? dt_out : ar.take((size_t)B * D);
     NEED(dq && dt);
     TRY(visual_attn(1, X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0, st));
     TRY(linear_plain(dq, F, w->w_v, F, nullptr, B, D, F, EPI_NONE, dt, D, ar, st));
     if (g && g->w_v) TRY(gemm_tn(t_v, D, dq, F, B, D, F, g->w_v, F, 1, st));
     // g->b_v: the bias shifts all V scores of a row equally; its gradient is identically zero.
-    if (dh) TRY(gemm_nn_ws(dt, D, w->w_h, H, B, H, D, dh, H, 1, ar.rest(), ar.rest_n(), st));
+    if (dh) TRY(data_grad(dt, D, w->w_h, w->w_h_t, B, D, H, dh, H, 1, ar, st));
     if (g && g->w_h) TRY(gemm_tn(dt, D, h, H, B, D, H, g->w_h, H, 1, st));
     if (g && g->b_h) TRY(colsum(dt, D, B, D, g->b_h, 1, st));
     return SF_OK;
@@ -168,17 +181,17 @@ int softdot_fwd_i(const sf_softdot_w* w, int B, int L, int H, const float* copy_
 int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, int H,
                   const float* ctx, const float* alpha, const float* cat2, const float* t_text,
                   const float* h_tilde, const float* dh_tilde, float* dh, int lddh, float* dctx,
-                  Arena ar, hipStream_t st) {
-    float* dpre = ar.take((size_t)B * H);
+                  Arena ar, hipStream_t st, float* dpre_out = nullptr, float* dt_out = nullptr) {
+    float* dpre = dpre_out ? dpre_out : ar.take((size_t)B * H);
+    float* dt = dt_out ? dt_out : ar.take((size_t)B * H);
     float* dcat2 = ar.take((size_t)B * 2 * H);
-    float* dt = ar.take((size_t)B * H);
     NEED(dpre && dcat2 && dt);
     TRY(tanh_bwd(h_tilde, H, dh_tilde, H, B, H, dpre, H, st));
-    TRY(gemm_nn_ws(dpre, H, w->w_out, 2 * H, B, 2 * H, H, dcat2, 2 * H, 0, ar.rest(), ar.rest_n(), st));
+    TRY(data_grad(dpre, H, w->w_out, w->w_out_t, B, H, 2 * H, dcat2, 2 * H, 0, ar, st));
     if (g && g->w_out) TRY(gemm_tn(dpre, H, cat2, 2 * H, B, H, 2 * H, g->w_out, 2 * H, 1, st));
     TRY(text_attn_bwd(ctx, B, L, H, dcat2, 2 * H, t_text, H, alpha, dt, H, dctx, st));
     TRY(add2(dcat2 + H, 2 * H, nullptr, 0, B, H, dh, lddh, st));
-    TRY(gemm_nn_ws(dt, H, w->w_in, H, B, H, H, dh, lddh, 1, ar.rest(), ar.rest_n(), st));
+    TRY(data_grad(dt, H, w->w_in, w->w_in_t, B, H, H, dh, lddh, 1, ar, st));
     if (g && g->w_in) TRY(gemm_tn(dt, H, cat2 + H, 2 * H, B, H, H, g->w_in, H, 1, st));
     return SF_OK;
 }
@@ -203,12 +216,12 @@ int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, 
 
 int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U, int B, int H,
                   int D, const float* h, const float* t_a, const float* wt, const float* dlogit,
-                  float* dh, Arena ar, hipStream_t st) {
+                  float* dh, Arena ar, hipStream_t st, const sf_decoder_gtape* gt = nullptr) {
     const int F = U.IMG + U.LOC;
-    float* dr = ar.take((size_t)B * F);
-    float* dc = ar.take((size_t)B);
-    float* dwt = ar.take((size_t)B * D);
-    float* dta = ar.take((size_t)B * D);
+    float* dr = gt ? gt->dr : ar.take((size_t)B * F);
+    float* dc = gt ? gt->dc : ar.take((size_t)B);
+    float* dwt = gt ? gt->dwt : ar.take((size_t)B * D);
+    float* dta = gt ? gt->dta : ar.take((size_t)B * D);
     NEED(dr && dc && dwt && dta);
     TRY(score_bwd(U, B, dlogit, dr, dc, st));
     TRY(linear_plain(dr, F, w->w_a, F, nullptr, B, D, F, EPI_NONE, dwt, D, ar, st));
@@ -220,7 +233,7 @@ int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U
         if (g->w_out) TRY(colsum_prod(dwt, D, t_a, D, B, D, g->w_out, st));
     }
     TRY(scale_cols(dwt, D, w->w_out, B, D, dta, D, st));
-    if (dh) TRY(gemm_nn_ws(dta, D, w->w_h, H, B, H, D, dh, H, 0, ar.rest(), ar.rest_n(), st));
+    if (dh) TRY(data_grad(dta, D, w->w_h, w->w_h_t, B, D, H, dh, H, 0, ar, st));
     if (g && g->w_h) TRY(gemm_tn(dta, D, h, H, B, D, H, g->w_h, H, 1, st));
     if (g && g->b_h) TRY(colsum(dta, D, B, D, g->b_h, 1, st));
     return SF_OK;
@@ -388,9 +401,10 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
 int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
                         const sf_cands* U, int B, int H, int D, int L, const float* h0,
                         const float* c0, const float* ctx, const sf_decoder_tape* tp,
-                        const float* dlogit, const float* dh1, const float* dc1, float* dh0,
-                        float* dc0, float* dctx, const sf_dropout* drop, uint32_t step_id, void* ws,
-                        size_t ws_bytes, sf_stream stream) {
+                        const sf_decoder_gtape* gt, const float* dlogit, const float* dh1,
+                        const float* dc1, float* dh0, float* dc0, float* dctx,
+                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                        sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0 && L > 0);
     Arena ar = arena(ws, ws_bytes);
@@ -404,14 +418,46 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
     float* dxin = ar.take((size_t)B * 2 * F);  // d LSTM input
     NEED(dht && dh1d && dh1m && dxin);
     TRY(scoring_bwd_i(&w->action, g ? &g->action : nullptr, cands(U), B, H, D, tp->h_tilde, tp->t_a,
-                      tp->wt, dlogit, dht, ar, st));
+                      tp->wt, dlogit, dht, ar, st, gt));
     TRY(softdot_bwd_i(&w->text, g ? &g->text : nullptr, B, L, H, ctx, tp->alpha, tp->cat2,
-                      tp->t_text, tp->h_tilde, dht, dh1d, H, dctx, ar, st));
+                      tp->t_text, tp->h_tilde, dht, dh1d, H, dctx, ar, st, gt ? gt->dpre : nullptr,
+                      gt ? gt->dt_text : nullptr));
     TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
     TRY(lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->c1,
-                   tp->gates, dh1, dh1m, dc1, dxin, 2 * F, dh0, dc0, ar, st));
+                   tp->gates, dh1, dh1m, dc1, dxin, 2 * F, dh0, dc0, ar, st,
+                   gt ? gt->dgates : nullptr));
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
-                        dxin + F, 2 * F, d_in, F, dh0, ar, st);
+                        dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
+                        gt ? gt->dt_v : nullptr);
+}
+
+// All weight gradients of S stacked decoder steps, each as ONE product of reduction depth M = S*B.
+int sf_attn_decoder_wgrad(const sf_decoder_w* w, const sf_decoder_g* g, int M, int H, int D, int F,
+                          const float* h0_all, const sf_decoder_tape* tp, const sf_decoder_gtape* gt,
+                          sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && g && h0_all && tp && gt && M > 0);
+    hipStream_t st = S(stream);
+    // LSTMCell (model.py:393)
+    if (g->lstm.w_ih) TRY(gemm_tn(gt->dgates, 4 * H, tp->xin, 2 * F, M, 4 * H, 2 * F, g->lstm.w_ih, 2 * F, 1, st));
+    if (g->lstm.w_hh) TRY(gemm_tn(gt->dgates, 4 * H, h0_all, H, M, 4 * H, H, g->lstm.w_hh, H, 1, st));
+    if (g->lstm.b_ih) TRY(colsum(gt->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, 1, st));
+    if (g->lstm.b_hh) TRY(colsum(gt->dgates, 4 * H, M, 4 * H, g->lstm.b_hh, 1, st));
+    // visual attention (model.py:389)
+    if (g->visual.w_v) TRY(gemm_tn(tp->t_v, D, gt->dq, F, M, D, F, g->visual.w_v, F, 1, st));
+    if (g->visual.w_h) TRY(gemm_tn(gt->dt_v, D, h0_all, H, M, D, H, g->visual.w_h, H, 1, st));
+    if (g->visual.b_h) TRY(colsum(gt->dt_v, D, M, D, g->visual.b_h, 1, st));
+    // text attention (model.py:395)
+    if (g->text.w_out) TRY(gemm_tn(gt->dpre, H, tp->cat2, 2 * H, M, H, 2 * H, g->text.w_out, 2 * H, 1, st));
+    if (g->text.w_in) TRY(gemm_tn(gt->dt_text, H, tp->cat2 + H, 2 * H, M, H, H, g->text.w_in, H, 1, st));
+    // action scoring (model.py:396)
+    if (g->action.w_a) TRY(gemm_tn(tp->wt, D, gt->dr, F, M, D, F, g->action.w_a, F, 1, st));
+    if (g->action.b_a) TRY(dot_rows_accum(gt->dc, tp->wt, D, M, D, g->action.b_a, st));
+    if (g->action.b_out) TRY(sum_accum(gt->dc, M, g->action.b_out, st));
+    if (g->action.w_out) TRY(colsum_prod(gt->dwt, D, tp->t_a, D, M, D, g->action.w_out, st));
+    if (g->action.w_h) TRY(gemm_tn(gt->dta, D, tp->h_tilde, H, M, D, H, g->action.w_h, H, 1, st));
+    if (g->action.b_h) TRY(colsum(gt->dta, D, M, D, g->action.b_h, 1, st));
+    return SF_OK;
 }
 
 int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const sf_follower_glue* glue,
@@ -499,7 +545,7 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
     // through decoder_init = tanh(W h_T + b)
     if (d_init) {
         TRY(tanh_bwd(decoder_init, H, d_init, H, B, H, dpre, H, st));
-        TRY(gemm_nn_ws(dpre, H, w->w_e2d, H, B, H, H, dh, H, 0, ar.rest(), ar.rest_n(), st));
+        TRY(data_grad(dpre, H, w->w_e2d, w->w_e2d_t, B, H, H, dh, H, 0, ar, st));
         if (g && g->w_e2d) TRY(gemm_tn(dpre, H, tp->hs + T * BH, H, B, H, H, g->w_e2d, H, 1, st));
         if (g && g->b_e2d) TRY(colsum(dpre, H, B, H, g->b_e2d, 1, st));
     } else {
@@ -521,8 +567,7 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
         TRY(lstm_pointwise_bwd(p, st));
         // dh_{t} = dgates W_hh (live rows) + passthrough (dead rows)
         TRY(add2(dpass, H, nullptr, 0, B, H, dh, H, st));
-        TRY(gemm_nn_ws(tp->xg + t * BG, 4 * H, w->lstm.w_hh, H, B, H, 4 * H, dh, H, 1, ar.rest(),
-                       ar.rest_n(), st));
+        TRY(data_grad(tp->xg + t * BG, 4 * H, w->lstm.w_hh, w->lstm.w_hh_t, B, 4 * H, H, dh, H, 1, ar, st));
         std::swap(dc, dcn);
     }
     if (g) {

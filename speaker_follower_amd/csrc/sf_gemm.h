@@ -29,6 +29,7 @@ struct LinearOut {
     float* y_pre;        // optional: un-multiplied value for EPI_MUL (saved for backward), ld = ldy_pre
     int ldy_pre;
     Epi epi;
+    int accumulate;      // y += result (EPI_NONE only)
 };
 
 // Workspace needed (in floats) for sf::linear_nt on an [M,N] output with total depth K.

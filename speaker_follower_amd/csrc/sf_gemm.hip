@@ -53,6 +53,7 @@ struct NtArgs {
     const float* mul;
     float* y_pre;
     int ldy_pre;
+    int accumulate;        // direct mode only
 };
 
 template <int MT>
@@ -175,7 +176,8 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
                 if (a.y_pre) a.y_pre[(size_t)row * a.ldy_pre + col] = v;
                 v *= mulv;
             }
-            out[(size_t)row * a.ldo + col] = v;
+            float* o = out + (size_t)row * a.ldo + col;
+            *o = (a.accumulate && a.ksplit == 1) ? *o + v : v;
         }
 }
 
@@ -323,7 +325,11 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + kk * 4 + r;
-            if (row < a.M) out[(size_t)row * a.ldo + col] = acc[t][r] + bsum;
+            if (row < a.M) {
+                float* o = out + (size_t)row * a.ldo + col;
+                const float v = acc[t][r] + bsum;
+                *o = (a.accumulate && a.ksplit == 1) ? *o + v : v;
+            }
         }
 }
 
@@ -432,7 +438,11 @@ __global__ __launch_bounds__(512) void gemm_nt_aresident_kernel(NtArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + kk * 4 + r;
-            if (row < a.M) out[(size_t)row * a.ldo + col] = acc[t][r] + bsum;
+            if (row < a.M) {
+                float* o = out + (size_t)row * a.ldo + col;
+                const float v = acc[t][r] + bsum;
+                *o = (a.accumulate && a.ksplit == 1) ? *o + v : v;
+            }
         }
 }
 
@@ -510,6 +520,7 @@ struct SmallArgs {
     const float* mul;
     float* y_pre;
     int ldy_pre;
+    int accumulate;
 };
 
 // grid (ceil(N/16), ceil(mtiles/MT)), block 512 = 8 waves = 8 K-slices of one 16-col n-tile x MT m-tiles
@@ -554,7 +565,8 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_kernel(SmallAr
             if (a.y_pre) a.y_pre[(size_t)row * a.ldy_pre + col] = v;
             v *= a.mul[col];
         }
-        a.y[(size_t)row * a.ldy + col] = v;
+        float* o = a.y + (size_t)row * a.ldy + col;
+        *o = a.accumulate ? *o + v : v;
     }
 }
 
@@ -720,16 +732,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-    for (int m = kk; m < a.M + kk; m += 4) {    // every lane runs the same trip count
-        const bool ok = m < a.M;
-        const float4 yv = (ok && pok) ? ld4(a.Y + (size_t)m * a.ldy + pc) : z;
-        const float4 xv = (ok && qok) ? ld4(a.X + (size_t)m * a.ldx + qc) : z;
+    // 4-deep clamped prefetch ring over the batch rows (4 rows per step): loads of steps s+1..s+3
+    // are in flight while step s feeds 16 MFMAs; clamped (not predicated) addresses keep the loop
+    // body branch-free, rows >= M contribute through a zero multiplier.
+    const int steps = (a.M + 3) >> 2;
+    const int pcl = pok ? pc : 0, qcl = qok ? qc : 0;
+    auto ld = [&](int s, float4& yv, float4& xv) {
+        const int m = min(4 * min(s, steps - 1) + kk, a.M - 1);
+        yv = ld4(a.Y + (size_t)m * a.ldy + pcl);
+        xv = ld4(a.X + (size_t)m * a.ldx + qcl);
+    };
+    auto mma = [&](int s, const float4& yv, const float4& xv) {
+        const float z = (4 * s + kk < a.M && pok) ? 1.f : 0.f;     // tail rows / columns beyond P
+        const float4 y = make_float4(yv.x * z, yv.y * z, yv.z * z, yv.w * z);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(comp(yv, i), comp(xv, j), acc[i][j]);
+            for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(comp(y, i), comp(xv, j), acc[i][j]);
+    };
+    float4 y0, x0, y1, x1, y2, x2, y3, x3;
+    ld(0, y0, x0); ld(1, y1, x1); ld(2, y2, x2); ld(3, y3, x3);
+    int s4 = 0;
+    for (; s4 + 4 <= steps; s4 += 4) {
+        mma(s4, y0, x0);     ld(s4 + 4, y0, x0);
+        mma(s4 + 1, y1, x1); ld(s4 + 5, y1, x1);
+        mma(s4 + 2, y2, x2); ld(s4 + 6, y2, x2);
+        mma(s4 + 3, y3, x3); ld(s4 + 7, y3, x3);
     }
+    if (s4 < steps) mma(s4, y0, x0);
+    if (s4 + 1 < steps) mma(s4 + 1, y1, x1);
+    if (s4 + 2 < steps) mma(s4 + 2, y2, x2);
 
     if (!qok) return;
 #pragma unroll
@@ -785,13 +817,23 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(RedArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* Y, int ldy, int M, int N,
-                                                     float* out, int accumulate) {
-    const int n = blockIdx.x * blockDim.x + threadIdx.x;
-    if (n >= N) return;
+// out[n] (+)= sum_m Y[m,n]: block = 64 columns x 16 row groups, coalesced 256-B row segments
+__global__ __launch_bounds__(1024) void colsum_kernel(const float* Y, int ldy, int M, int N,
+                                                      float* out, int accumulate) {
+    __shared__ float s_p[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += Y[(size_t)m * ldy + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int m = g; m < M; m += 16) s += Y[(size_t)m * ldy + n];
+    s_p[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_p[k][c];
+        out[n] = accumulate ? out[n] + t : t;
+    }
 }
 
 int pick_ksplit(int waves_per_split, int chunks) {
@@ -820,10 +862,10 @@ inline int red_grid(size_t total) { return (int)std::min<size_t>((total + 255) /
 // streaming kernel should be used instead.
 static bool small_shape(int M, int N, int chunks, int* mt, int* cpw) {
     const int mtiles = ceil_div(M, 16), ntiles = ceil_div(N, 16);
-    if (chunks > 64 || (long)mtiles * ntiles > 2048) return false;
-    const int c = ceil_div(chunks, SMALL_WAVES);          // chunks per wave: 1..8
-    *cpw = c <= 2 ? 2 : (c <= 4 ? 4 : 8);
-    int m = std::min(mtiles, 32 / *cpw - 1);              // <= 32 float4 of loads per lane
+    if (chunks > 128 || (long)mtiles * ntiles > (chunks > 64 ? 512 : 2048)) return false;
+    const int c = ceil_div(chunks, SMALL_WAVES);          // chunks per wave: 1..16
+    *cpw = c <= 2 ? 2 : (c <= 4 ? 4 : (c <= 8 ? 8 : 16));
+    int m = std::max(1, std::min(mtiles, 32 / *cpw - 1)); // <= 32 float4 of loads per lane
     m = m >= 4 ? 4 : (m >= 2 ? 2 : 1);
     while (m > 1 && ntiles * ceil_div(mtiles, m) < 128) m >>= 1;   // keep >= 128 blocks if possible
     *mt = m;
@@ -884,15 +926,17 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         sa.sg.total = chunks;
         sa.M = M; sa.N = N; sa.y = out.y; sa.ldy = out.ldy; sa.bias = out.bias; sa.bias2 = out.bias2;
         sa.epi = out.epi; sa.mul = out.mul; sa.y_pre = out.y_pre; sa.ldy_pre = out.ldy_pre;
-        switch (mt * 16 + cpw) {
-            case 1 * 16 + 2: launch_small<1, 2>(sa, st); break;
-            case 1 * 16 + 4: launch_small<1, 4>(sa, st); break;
-            case 1 * 16 + 8: launch_small<1, 8>(sa, st); break;
-            case 2 * 16 + 2: launch_small<2, 2>(sa, st); break;
-            case 2 * 16 + 4: launch_small<2, 4>(sa, st); break;
-            case 2 * 16 + 8: launch_small<2, 8>(sa, st); break;
-            case 4 * 16 + 2: launch_small<4, 2>(sa, st); break;
-            case 4 * 16 + 4: launch_small<4, 4>(sa, st); break;
+        sa.accumulate = out.accumulate;
+        switch (mt * 32 + cpw) {
+            case 1 * 32 + 2: launch_small<1, 2>(sa, st); break;
+            case 1 * 32 + 4: launch_small<1, 4>(sa, st); break;
+            case 1 * 32 + 8: launch_small<1, 8>(sa, st); break;
+            case 1 * 32 + 16: launch_small<1, 16>(sa, st); break;
+            case 2 * 32 + 2: launch_small<2, 2>(sa, st); break;
+            case 2 * 32 + 4: launch_small<2, 4>(sa, st); break;
+            case 2 * 32 + 8: launch_small<2, 8>(sa, st); break;
+            case 4 * 32 + 2: launch_small<4, 2>(sa, st); break;
+            case 4 * 32 + 4: launch_small<4, 4>(sa, st); break;
             default: return SF_ERR_UNSUPPORTED;
         }
         if (ksplit_out) *ksplit_out = 1;
@@ -919,6 +963,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         a.bias = out.bias;
         a.bias2 = out.bias2;
         a.epi = out.epi;            // single split: epilogue fused into the GEMM
+        a.accumulate = out.accumulate;
         a.mul = out.mul;
         a.y_pre = out.y_pre;
         a.ldy_pre = out.ldy_pre;
@@ -1027,6 +1072,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
     r.y_pre = out.y_pre;
     r.ldy_pre = out.ldy_pre;
     r.epi = out.epi;
+    r.accumulate = out.accumulate;
     if (ks > 1) {
         r.slabs = ws;
         r.ks = ks;
@@ -1111,7 +1157,7 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
 
 int colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, hipStream_t st) {
     SF_CHECK_ARG(M > 0 && N > 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, Y, ldy, M, N, out,
+    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, Y, ldy, M, N, out,
                        accumulate);
     return launch_status();
 }

@@ -127,22 +127,41 @@ __global__ __launch_bounds__(TPB) void ew_kernel(EwArgs e) {
     }
 }
 
-// out[n] += sum_m a[m,n] * b[m,n]     (b == null: a[m] scalar per row times x -> see below)
-__global__ __launch_bounds__(TPB) void colsum_prod_kernel(const float* a, int lda, const float* b,
-                                                          int ldb, int M, int N, float* out) {
-    const int n = blockIdx.x * TPB + threadIdx.x;
-    if (n >= N) return;
+// out[n] += sum_m a[m,n] * b[m,n]  /  out[n] += sum_m s[m] * x[m,n]: block = 64 columns x 16 row
+// groups (coalesced 256-B row segments), partials meet in LDS.
+__global__ __launch_bounds__(1024) void colsum_prod_kernel(const float* a, int lda, const float* b,
+                                                           int ldb, int M, int N, float* out) {
+    __shared__ float s_p[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
     float s = 0.f;
-    for (int m = 0; m < M; ++m) s += a[(size_t)m * lda + n] * b[(size_t)m * ldb + n];
-    out[n] += s;
+    if (n < N)
+        for (int m = g; m < M; m += 16) s += a[(size_t)m * lda + n] * b[(size_t)m * ldb + n];
+    s_p[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_p[k][c];
+        out[n] += t;
+    }
 }
-__global__ __launch_bounds__(TPB) void dot_rows_kernel(const float* s, const float* x, int ldx,
-                                                       int M, int N, float* out) {
-    const int n = blockIdx.x * TPB + threadIdx.x;
-    if (n >= N) return;
-    float acc = 0.f;
-    for (int m = 0; m < M; ++m) acc += s[m] * x[(size_t)m * ldx + n];
-    out[n] += acc;
+__global__ __launch_bounds__(1024) void dot_rows_kernel(const float* sv, const float* x, int ldx,
+                                                        int M, int N, float* out) {
+    __shared__ float s_p[16][64];
+    const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float s = 0.f;
+    if (n < N)
+        for (int m = g; m < M; m += 16) s += sv[m] * x[(size_t)m * ldx + n];
+    s_p[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += s_p[k][c];
+        out[n] += t;
+    }
 }
 __global__ void sum_accum_kernel(const float* s, int M, float* out) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
@@ -391,13 +410,13 @@ int rank1_add(const float* s, const float* v, int M, int N, float* dst, int ldd,
 }
 int colsum_prod(const float* a, int lda, const float* b, int ldb, int M, int N, float* out,
                 hipStream_t st) {
-    hipLaunchKernelGGL(colsum_prod_kernel, dim3(ceil_div(N, TPB)), dim3(TPB), 0, st, a, lda, b, ldb,
+    hipLaunchKernelGGL(colsum_prod_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, a, lda, b, ldb,
                        M, N, out);
     return launch_status();
 }
 int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float* out,
                    hipStream_t st) {
-    hipLaunchKernelGGL(dot_rows_kernel, dim3(ceil_div(N, TPB)), dim3(TPB), 0, st, s, x, ldx, M, N,
+    hipLaunchKernelGGL(dot_rows_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, s, x, ldx, M, N,
                        out);
     return launch_status();
 }

@@ -154,7 +154,10 @@ class FollowerEngine:
         self.iteration += 1
 
         # ---- encoder (model.py:81-104)
-        st.ctx, st.h_init, st.c_init = new(B, T, H), new(B, H), new(B, H)
+        st.ctx = new(B, T, H)
+        st.hs_all = new(steps + 1, B, H)
+        st.cs_all = new(steps + 1, B, H)
+        st.h_init, st.c_init = st.hs_all[0], st.cs_all[0]
         st.enc_tape = dict(emb=new(T, B, E), xg=new(T, B, 4 * H), gates=new(T, B, 4 * H),
                            hs=new(T + 1, B, H), cs=new(T + 1, B, H))
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
@@ -169,7 +172,12 @@ class FollowerEngine:
                       wt=(D,), r=(F,), logit=(A,))
         # one extra xin slot: step t's glue writes dropout(u_next) straight into step t+1's LSTM input
         shapes_x = dict(shapes, xin=(2 * F,))
-        st.tape = {k: new(S + (1 if k == 'xin' else 0), B, *shapes_x[k]) for k in _TAPE_KEYS}
+        st.tape = {k: new(S + (1 if k == 'xin' else 0), B, *shapes_x[k]) for k in _TAPE_KEYS
+                   if k not in ('h1', 'c1')}
+        # hidden / cell states of all steps stacked: hs[t] is step t's h0, hs[t+1] its h1 -- the
+        # batched weight-gradient products read hs[0:S] as one [S*B, H] matrix
+        st.hs, st.cs = st.hs_all, st.cs_all
+        st.tape['h1'], st.tape['c1'] = st.hs[1:], st.cs[1:]
         call('sf_fill_f32', ptr(st.tape['xin'][0]), B * 2 * F, 0.0, stream())   # u_begin = 0 (model.py:368)
         st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
         st.actions = torch.empty(S, B, dtype=torch.int64, device=dev)
@@ -229,6 +237,9 @@ class FollowerEngine:
 
     # ------------------------------------------------------------------------------ backward
     def _backward(self, st, dloss):
+        """BPTT.  Per step only the DATA gradients are formed (sequential dependency); every
+        weight gradient is one product over all S*B stacked rows at the end (sf_attn_decoder_wgrad),
+        accumulated in place into param.grad."""
         enc, dec, store = self.encoder, self.decoder, self.store
         batch, S = st.batch, st.steps
         B, A, H, E, F, V, D, T = st.dims
@@ -237,24 +248,33 @@ class FollowerEngine:
         gscale = st.gscale * dloss.to(torch.float32)        # d loss / d step-loss, per step
         params = decoder_params(dec)
         dw, dg = decoder_w_struct(params), decoder_w_struct(params, grad=True)
+        gshapes = dict(dgates=(4 * H,), dpre=(H,), dt_text=(H,), dt_v=(D,), dq=(F,), dwt=(D,),
+                       dta=(D,), dr=(F,), dc=())
+        gkeys = ('dgates', 'dpre', 'dt_text', 'dt_v', 'dq', 'dwt', 'dta', 'dr', 'dc')
+        gt = {k: new(S, B, *gshapes[k]) for k in gkeys}
         dlogit = new(B, A)
         dh_a, dc_a, dh_b, dc_b = new(B, H), new(B, H), new(B, H), new(B, H)
         dctx = torch.zeros(B, T, H, device=dev, dtype=torch.float32)
         ws = ws_args(dev)
+        d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
+        d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
         dh1 = dc1 = None
         for t in range(S - 1, -1, -1):
             pano = store.pano(batch.vp[t], batch.view[t])
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
             tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
-            h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
-            c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
+            gtp = _lib.DecoderGTape(*(gt[k][t].data_ptr() for k in gkeys))
             call('sf_follower_glue_bwd', B, A, ptr(st.tape['logit'][t]), ptr(st.target_used[t]),
                  ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
-            call('sf_attn_decoder_bwd', byref(dw), byref(dg), byref(pano), byref(cnd), B, H, D, T,
-                 ptr(h0), ptr(c0), ptr(st.ctx), byref(tp), ptr(dlogit), ptr(dh1), ptr(dc1),
-                 ptr(dh_a), ptr(dc_a), ptr(dctx), dropout_arg(*st.drop_dec), st.site0 + t, *ws)
+            call('sf_attn_decoder_bwd', byref(dw), None, byref(pano), byref(cnd), B, H, D, T,
+                 ptr(st.hs[t]), ptr(st.cs[t]), ptr(st.ctx), byref(tp), byref(gtp), ptr(dlogit),
+                 ptr(dh1), ptr(dc1), ptr(dh_a), ptr(dc_a), ptr(dctx), d_ptr, st.site0 + t, *ws)
             dh1, dc1 = dh_a, dc_a
             dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
+        tp0 = _lib.DecoderTape(*(st.tape[k].data_ptr() for k in _TAPE_KEYS))
+        gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys))
+        call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
+             byref(gt0), ws[2])
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
         ew, eg = _encoder_structs(enc), _encoder_structs(enc, grad=True)
         call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),

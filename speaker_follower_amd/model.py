@@ -243,8 +243,9 @@ def _encoder_structs(mod, grad=False):
     e2d = (mod.encoder2decoder.weight, mod.encoder2decoder.bias)
     if grad:
         return _lib.EncoderG(_lib.LstmW(*_grads(l4)), *_grads(e2d))
-    return _lib.EncoderW(mod.embedding.weight.data_ptr(), struct_of(_lib.LstmW, l4),
-                         *(p.data_ptr() for p in e2d))
+    lw = _lib.LstmW(*(p.data_ptr() for p in l4), None, transposed(l4[1]).data_ptr())
+    return _lib.EncoderW(mod.embedding.weight.data_ptr(), lw, *(p.data_ptr() for p in e2d),
+                         transposed(e2d[0]).data_ptr())
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -357,9 +358,11 @@ def decoder_w_struct(params, grad=False):
         return _lib.DecoderW(_lib.LstmW(*vals[0:4]), _lib.VisualW(*vals[4:8]),
                              _lib.SoftdotW(*vals[8:10]), _lib.ScoringW(*vals[10:16]))
     vals = [p.data_ptr() for p in params]
-    w_v_t, w_a_t = transposed(params[6]), transposed(params[12])
-    return _lib.DecoderW(_lib.LstmW(*vals[0:4]), _lib.VisualW(*vals[4:8], w_v_t.data_ptr()),
-                         _lib.SoftdotW(*vals[8:10]), _lib.ScoringW(*vals[10:16], w_a_t.data_ptr()))
+    t = lambda i: transposed(params[i]).data_ptr()  # noqa: E731  (cached per weight version)
+    return _lib.DecoderW(_lib.LstmW(*vals[0:4], t(0), t(1)),
+                         _lib.VisualW(*vals[4:8], t(6), t(4)),
+                         _lib.SoftdotW(*vals[8:10], t(8), t(9)),
+                         _lib.ScoringW(*vals[10:16], t(12), t(10)))
 
 
 class _DecoderStepFn(torch.autograd.Function):
@@ -399,8 +402,8 @@ class _DecoderStepFn(torch.autograd.Function):
         dctx = torch.zeros_like(context) if ctx.needs_input_grad[7] else None
         pano, cnd = pano_dense(X), cands_dense(all_u)
         call('sf_attn_decoder_bwd', byref(w), byref(g), byref(pano), byref(cnd), B, H, D, L,
-             ptr(h0), ptr(c0), ptr(context), byref(tp), ptr(dlogit), ptr(dh1), ptr(dc1), ptr(dh0),
-             ptr(dc0), ptr(dctx), dropout_arg(p, seed), site, *ws_args(dev))
+             ptr(h0), ptr(c0), ptr(context), byref(tp), None, ptr(dlogit), ptr(dh1), ptr(dc1),
+             ptr(dh0), ptr(dc0), ptr(dctx), dropout_arg(p, seed), site, *ws_args(dev))
         return (None, None, None, None, None, dh0, dc0, dctx, None) + (None,) * 16
 
 
