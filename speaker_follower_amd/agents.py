@@ -1,0 +1,482 @@
+"""Seq2SeqAgent / Seq2SeqSpeaker with the reference's interface (follower.py:261-1035,
+speaker.py:34-410) on top of the HIP modules, for environments that hand out the reference's
+observation dictionaries (env.py:775-795: 'feature', 'action_embedding', 'adj_loc_list',
+'teacher', 'instr_encoding', ...).  The per-step arithmetic -- decoder step, masking,
+cross-entropy, action choice, u_prev gather -- runs through the C ABI; the loop, the trajectory
+book-keeping and the simulator calls stay in Python exactly where the reference has them.
+
+When observations are available in index form, `FollowerEngine` / `SpeakerEngine` are the fast
+path; this module is the drop-in path.  Beam search and state-factored search
+(follower.py:541-980, speaker.py:211-318) are "next" rows of SURVEY.md section 8(f) and raise.
+"""
+import ctypes as C
+import json
+import random
+import sys
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
+from .runtime import ptr, stream, require_gpu, cands_dense
+
+byref = C.byref
+
+
+def path_element_from_observation(ob):
+    return (ob['viewpoint'], ob['heading'], ob['elevation'])           # follower.py utility
+
+
+class _FollowerGlueFn(torch.autograd.Function):
+    """follower.py:476-505 on dense tensors: returns (ce_term [B], live [B]); a_t, per-step scores
+    and u_next are side outputs.  backward: softmax - onehot through sf_follower_glue_bwd."""
+
+    @staticmethod
+    def forward(ctx, logit, all_u, is_valid, target, feedback, ended_dev, sample_cfg):
+        B, A = logit.shape
+        dev = logit.device
+        masked = logit.detach().clone()
+        new = lambda *s, dt=torch.float32: torch.empty(*s, device=dev, dtype=dt)  # noqa: E731
+        a_t, tused = new(B, dt=torch.int64), new(B, dt=torch.int64)
+        score, ce, live = new(B), new(B), new(B)
+        u_next = new(B, all_u.shape[2])
+        cnd = cands_dense(all_u)
+        g = _lib.FollowerGlue(is_valid.data_ptr(), target.data_ptr(), feedback, ended_dev.data_ptr(),
+                              a_t.data_ptr(), tused.data_ptr(), score.data_ptr(), u_next.data_ptr(),
+                              all_u.shape[2], None, 0, ce.data_ptr(), live.data_ptr(),
+                              sample_cfg[0], sample_cfg[1], 0)
+        call('sf_follower_glue_fwd', byref(cnd), B, ptr(masked), byref(g), stream())
+        ctx.save_for_backward(masked, tused)
+        ctx.mark_non_differentiable(live, a_t, score, u_next, masked)
+        return ce, live, a_t, score, u_next, masked
+
+    @staticmethod
+    def backward(ctx, dce, *_):
+        masked, tused = ctx.saved_tensors
+        B, A = masked.shape
+        one = torch.ones(1, device=masked.device)
+        dlogit = torch.empty_like(masked)
+        call('sf_follower_glue_bwd', B, A, ptr(masked), ptr(tused), ptr(one), ptr(dlogit), stream())
+        return dlogit * dce.reshape(B, 1), None, None, None, None, None, None
+
+
+class BaseAgent(object):
+    """follower.py:107-192."""
+
+    def __init__(self, env, results_path):
+        self.env = env
+        self.results_path = results_path
+        random.seed(1)
+        self.results = {}
+        self.losses = []
+
+    def write_results(self):
+        results = {k: {'instr_id': v['instr_id'], 'trajectory': v['trajectory']}
+                   for k, v in self.results.items()}
+        with open(self.results_path, 'w') as f:
+            json.dump(results, f)
+
+    def rollout(self):
+        raise NotImplementedError
+
+    def test(self):
+        self.env.reset_epoch()
+        self.losses = []
+        self.results = {}
+        looped = False
+        while True:                                                    # follower.py:145-188
+            for result in self.rollout():
+                if result['instr_id'] in self.results:
+                    looped = True
+                else:
+                    self.results[result['instr_id']] = result
+            if looped:
+                break
+        return self.results
+
+
+class Seq2SeqAgent(BaseAgent):
+    """follower.py:261-1035 (greedy / teacher / sample rollouts, scoring, train, save/load)."""
+    feedback_options = ['teacher', 'argmax', 'sample']
+
+    def __init__(self, env, results_path, encoder, decoder, episode_len=10, beam_size=1,
+                 reverse_instruction=True, max_instruction_length=80):
+        super().__init__(env, results_path)
+        self.encoder, self.decoder = encoder, decoder
+        self.episode_len = episode_len
+        self.losses = []
+        self.beam_size = beam_size
+        self.reverse_instruction = reverse_instruction
+        self.max_instruction_length = max_instruction_length
+        self.feedback = 'argmax'
+        self.loss = 0
+        self._sample_seed = torch.initial_seed() & 0xFFFFFFFF
+        self._sample_count = 0
+
+    # ---- tensor assembly (follower.py:291-332): numpy stacks -> device tensors
+    def _device(self):
+        return next(self.decoder.parameters()).device
+
+    def _feature_variables(self, obs):
+        feats = np.stack([ob['feature'][0] for ob in obs])
+        return [torch.from_numpy(feats).to(self._device())]
+
+    def _action_variable(self, obs):
+        max_a = max(len(ob['adj_loc_list']) for ob in obs)
+        dim = obs[0]['action_embedding'].shape[-1]
+        is_valid = np.zeros((len(obs), max_a), np.float32)
+        emb = np.zeros((len(obs), max_a, dim), np.float32)
+        for i, ob in enumerate(obs):
+            n = len(ob['adj_loc_list'])
+            is_valid[i, :n] = 1.0
+            emb[i, :n] = ob['action_embedding']
+        dev = self._device()
+        return torch.from_numpy(emb).to(dev), torch.from_numpy(is_valid).to(dev), is_valid
+
+    def _teacher_action(self, obs, ended):
+        a = torch.tensor([ob['teacher'] if not ended[i] else -1 for i, ob in enumerate(obs)],
+                         dtype=torch.int64)
+        return a.to(self._device())
+
+    def _proc_batch(self, obs):
+        enc = [ob['instr_encoding'] for ob in obs]
+        return batch_instructions_from_encoded(enc, self.max_instruction_length,
+                                               reverse=self.reverse_instruction,
+                                               device=self._device())
+
+    def rollout(self):
+        if self.beam_size != 1:
+            raise NotImplementedError('beam search is a "next" row (SURVEY.md 8f N3)')
+        return self._rollout_with_loss()
+
+    def beam_search(self, *a, **k):
+        raise NotImplementedError('beam_search: SURVEY.md section 8(f) N3 (not built yet)')
+
+    def state_factored_search(self, *a, **k):
+        raise NotImplementedError('state_factored_search: SURVEY.md section 8(f) N3 (not built yet)')
+
+    def set_beam_size(self, beam_size):
+        if getattr(self.env, 'beam_size', 1) < beam_size:
+            self.env.set_beam_size(beam_size)
+        self.beam_size = beam_size
+
+    def _step(self, u_prev, obs, h, c, ctx, seq_mask, target, feedback, ended_dev):
+        """One decoder step + glue on dense observations (follower.py:469-505)."""
+        f_t = self._feature_variables(obs)[0]
+        all_u, is_valid, _ = self._action_variable(obs)
+        h, c, alpha, logit, alpha_v = self.decoder(u_prev, all_u, f_t, h, c, ctx, seq_mask)
+        self._sample_count += 1
+        ce, live, a_t, score, u_next, masked = _FollowerGlueFn.apply(
+            logit, all_u, is_valid, target, FEEDBACK[feedback], ended_dev,
+            (self._sample_seed, self._sample_count))
+        n_live = live.sum()
+        loss_t = ce.sum() / n_live.clamp(min=1.0)                    # CrossEntropyLoss mean over live
+        return h, c, loss_t, a_t, score, u_next
+
+    def _rollout_with_loss(self):
+        """follower.py:430-539."""
+        world_states = self.env.reset(sort=True)
+        obs = np.array(self.env.observe(world_states))
+        B = len(obs)
+        seq, seq_mask, seq_lengths = self._proc_batch(obs)
+        self.loss = 0
+        feedback = self.feedback
+        ctx, h, c = self.encoder(seq, seq_lengths)
+        traj = [{'instr_id': ob['instr_id'], 'trajectory': [path_element_from_observation(ob)],
+                 'actions': [], 'scores': [], 'observations': [ob],
+                 'instr_encoding': ob['instr_encoding']} for ob in obs]
+        dev = self._device()
+        u_prev = self.decoder.u_begin.to(dev).expand(B, -1).contiguous()
+        ended = np.array([False] * B)
+        ended_dev = torch.zeros(B, dtype=torch.uint8, device=dev)
+        seq_scores = torch.zeros(B, device=dev)
+        for t in range(self.episode_len):
+            target = self._teacher_action(obs, ended)
+            ended_dev.zero_()      # `target` already carries -1 for ended rows (follower.py:327)
+            h, c, loss_t, a_t, score, u_prev = self._step(u_prev, obs, h, c, ctx, seq_mask, target,
+                                                          feedback, ended_dev)
+            self.loss = self.loss + loss_t
+            seq_scores = seq_scores + score
+            actions = a_t.tolist()                                     # the per-step D2H sync (:509-511)
+            world_states = self.env.step(world_states, actions, obs)
+            obs = self.env.observe(world_states)
+            sc, ss = score.tolist(), seq_scores.tolist()
+            for i, ob in enumerate(obs):
+                if not ended[i]:
+                    traj[i]['trajectory'].append(path_element_from_observation(ob))
+                    traj[i]['score'] = ss[i]
+                    traj[i]['scores'].append(sc[i])
+                    traj[i]['actions'].append(actions[i])
+                    traj[i]['observations'].append(ob)
+            for i in range(B):
+                if actions[i] == 0:
+                    ended[i] = True
+            if ended.all():
+                break
+        self.losses.append(float(self.loss.detach()) if torch.is_tensor(self.loss) else float(self.loss))
+        return traj
+
+    def _score_obs_actions_and_instructions(self, path_obs, path_actions, encoded_instructions):
+        """follower.py:342-428: teacher-forced scoring of given paths."""
+        B = len(path_obs)
+        assert len(path_actions) == B and len(encoded_instructions) == B
+        dev = self._device()
+        seq, seq_mask, seq_lengths, perm = batch_instructions_from_encoded(
+            encoded_instructions, self.max_instruction_length, reverse=self.reverse_instruction,
+            sort=True, device=dev)
+        loss = 0
+        ctx, h, c = self.encoder(seq, seq_lengths)
+        u_prev = self.decoder.u_begin.to(dev).expand(B, -1).contiguous()
+        ended = np.array([False] * B)
+        ended_dev = torch.zeros(B, dtype=torch.uint8, device=dev)
+        seq_scores = torch.zeros(B, device=dev)
+        traj = [{'instr_id': po[0]['instr_id'], 'trajectory': [path_element_from_observation(po[0])],
+                 'actions': [], 'scores': [], 'observations': [po[0]],
+                 'instr_encoding': po[0]['instr_encoding']} for po in path_obs]
+        obs = None
+        for t in range(self.episode_len):
+            nxt, tgt = [], []
+            for pi, si in enumerate(perm):
+                if t < len(path_actions[si]):
+                    tgt.append(path_actions[si][t])
+                    nxt.append(path_obs[si][t])
+                else:
+                    tgt.append(-1)
+                    nxt.append(obs[pi])
+            obs = nxt
+            target = torch.tensor(tgt, dtype=torch.int64, device=dev)
+            h, c, loss_t, a_t, score, u_prev = self._step(u_prev, obs, h, c, ctx, seq_mask, target,
+                                                          'teacher', ended_dev)
+            ended_dev.zero_()
+            loss = loss + loss_t
+            live = (target != -1).to(score.dtype)
+            seq_scores = seq_scores + score * live                     # :405 ignore_index rows score 0
+            acts, sc, ss = a_t.tolist(), (score * live).tolist(), seq_scores.tolist()
+            for pi, si in enumerate(perm):
+                if not ended[pi]:
+                    traj[si]['trajectory'].append(path_element_from_observation(obs[pi]))
+                    traj[si]['score'] = ss[pi]
+                    traj[si]['scores'].append(sc[pi])
+                    traj[si]['actions'].append(acts[pi])
+            for i in range(B):
+                if acts[i] == 0:
+                    ended[i] = True
+            if ended.all():
+                break
+        return traj, loss
+
+    def test(self, use_dropout=False, feedback='argmax', allow_cheat=False, beam_size=1):
+        """follower.py:987-999."""
+        if not allow_cheat:
+            assert feedback in ['argmax', 'sample']
+        self.feedback = feedback
+        for m in (self.encoder, self.decoder):
+            m.train() if use_dropout else m.eval()
+        self.set_beam_size(beam_size)
+        return super().test()
+
+    def train(self, encoder_optimizer, decoder_optimizer, n_iters, feedback='teacher'):
+        """follower.py:1001-1020."""
+        assert all(f in self.feedback_options for f in feedback.split('+'))
+        self.feedback = feedback
+        self.encoder.train()
+        self.decoder.train()
+        self.losses = []
+        for _ in range(1, n_iters + 1):
+            encoder_optimizer.zero_grad()
+            decoder_optimizer.zero_grad()
+            self._rollout_with_loss()
+            self.loss.backward()
+            encoder_optimizer.step()
+            decoder_optimizer.step()
+
+    def _encoder_and_decoder_paths(self, base_path):
+        return base_path + '_enc', base_path + '_dec'
+
+    def save(self, path):
+        ep, dp = self._encoder_and_decoder_paths(path)
+        torch.save(self.encoder.state_dict(), ep)
+        torch.save(self.decoder.state_dict(), dp)
+
+    def load(self, path, **kwargs):
+        ep, dp = self._encoder_and_decoder_paths(path)
+        self.encoder.load_state_dict(torch.load(ep, **kwargs))
+        self.decoder.load_state_dict(torch.load(dp, **kwargs))
+
+
+class _SpeakerGlueFn(torch.autograd.Function):
+    """speaker.py:163-191 on a [B,vocab] logit tensor."""
+
+    @staticmethod
+    def forward(ctx, logit, target, feedback, ended_dev, pad_idx, eos_idx):
+        B, V = logit.shape
+        ldv = (V + 3) & ~3
+        dev = logit.device
+        lg = torch.zeros(B, ldv, device=dev)
+        lg[:, :V] = logit.detach()
+        w_t = torch.empty(B, dtype=torch.int64, device=dev)
+        score, nll, live = (torch.empty(B, device=dev) for _ in range(3))
+        call('sf_speaker_glue_fwd', B, V, ldv, ptr(lg), ptr(target), feedback, pad_idx, eos_idx,
+             ptr(ended_dev), ptr(w_t), ptr(score), ptr(nll), ptr(live), stream())
+        ctx.save_for_backward(lg, target)
+        ctx.cfg = (B, V, ldv, pad_idx)
+        ctx.mark_non_differentiable(live, w_t, score)
+        return nll, live, w_t, score
+
+    @staticmethod
+    def backward(ctx, dnll, *_):
+        lg, target = ctx.saved_tensors
+        B, V, ldv, pad_idx = ctx.cfg
+        one = torch.ones(1, device=lg.device)
+        dl = torch.empty_like(lg)
+        call('sf_speaker_glue_bwd', B, V, ldv, ptr(lg), ptr(target), pad_idx, ptr(one), ptr(dl),
+             stream())
+        return dl[:, :V] * dnll.reshape(B, 1), None, None, None, None, None
+
+
+class Seq2SeqSpeaker(object):
+    """speaker.py:34-410 (teacher / argmax / sample decoding, scoring, train, save/load)."""
+    feedback_options = ['teacher', 'argmax', 'sample']
+
+    def __init__(self, env, results_path, encoder, decoder, instruction_len, max_episode_len=10):
+        self.env = env
+        self.results_path = results_path
+        random.seed(1)
+        self.results = {}
+        self.losses = []
+        self.encoder, self.decoder = encoder, decoder
+        self.instruction_len = instruction_len
+        self.max_episode_len = max_episode_len
+        self.feedback = 'argmax'
+
+    def write_results(self):
+        with open(self.results_path, 'w') as f:
+            json.dump(self.results, f)
+
+    def _device(self):
+        return next(self.decoder.parameters()).device
+
+    def _batch_observations_and_actions(self, path_obs, path_actions, encoded_instructions):
+        """speaker.py:68-121."""
+        seq_lengths = np.array([len(a) for a in path_actions])
+        Tp = int(seq_lengths.max())
+        B = len(path_obs)
+        dim = path_obs[0][0]['action_embedding'].shape[-1]
+        fshape = path_obs[0][0]['feature'][0].shape
+        mask = np.ones((B, Tp), np.uint8)
+        acts = [np.zeros((B, dim), np.float32) for _ in range(Tp)]
+        feats = [np.zeros((B,) + fshape, np.float32) for _ in range(Tp)]
+        for i, (obs, actions) in enumerate(zip(path_obs, path_actions)):
+            assert len(obs) == len(actions) + 1
+            mask[i, :len(actions)] = 0
+            for t, (ob, a) in enumerate(zip(obs[:-1], actions)):
+                assert a >= 0
+                feats[t][i] = ob['feature'][0]
+                acts[t][i] = ob['action_embedding'][a]
+        dev = self._device()
+        to = lambda x: torch.from_numpy(x).to(dev)  # noqa: E731
+        return ([obs[0] for obs in path_obs], [to(f) for f in feats], [to(a) for a in acts],
+                to(mask), list(seq_lengths), encoded_instructions, list(range(B)))
+
+    def _score_obs_actions_and_instructions(self, path_obs, path_actions, encoded_instructions,
+                                            feedback):
+        """speaker.py:123-202."""
+        assert len(path_obs) == len(path_actions) == len(encoded_instructions)
+        start_obs, feats, acts, path_mask, _, encoded_instructions, perm = \
+            self._batch_observations_and_actions(path_obs, path_actions, encoded_instructions)
+        dev = self._device()
+        instr_seq, _, _ = batch_instructions_from_encoded(encoded_instructions, self.instruction_len,
+                                                         device=dev)
+        B = len(start_obs)
+        ctx, h, c = self.encoder(acts, feats)
+        w_t = torch.full((B,), BOS, dtype=torch.int64, device=dev)
+        ended = np.array([False] * B)
+        ended_dev = torch.zeros(B, dtype=torch.uint8, device=dev)
+        outputs = [{'instr_id': start_obs[i]['instr_id'], 'word_indices': [], 'scores': []}
+                   for i in range(B)]
+        loss = 0
+        seq_scores = torch.zeros(B, device=dev)
+        for t in range(self.instruction_len):
+            h, c, alpha, logit = self.decoder(w_t.view(-1, 1), h, c, ctx, path_mask)
+            target = instr_seq[:, t].contiguous()
+            nll, live, w_t, score = _SpeakerGlueFn.apply(logit, target, FEEDBACK[feedback],
+                                                         ended_dev, PAD, EOS)
+            seq_scores = seq_scores + score
+            loss = loss + nll.sum() / live.sum().clamp(min=1.0)
+            words, sc, ss = w_t.tolist(), score.tolist(), seq_scores.tolist()
+            for i in range(B):
+                if not ended[i]:
+                    outputs[i]['word_indices'].append(int(words[i]))
+                    outputs[i]['score'] = float(ss[i])
+                    outputs[i]['scores'].append(sc[i])
+                if words[i] == EOS:
+                    ended[i] = True
+            if ended.all():
+                break
+        tok = getattr(self.env, 'tokenizer', None)
+        for item in outputs:
+            item['words'] = (tok.decode_sentence(item['word_indices'], break_on_eos=True, join=False)
+                             if tok is not None else list(item['word_indices']))
+        return outputs, loss
+
+    def rollout(self, load_next_minibatch=True):
+        path_obs, path_actions, enc = self.env.gold_obs_actions_and_instructions(
+            self.max_episode_len, load_next_minibatch=load_next_minibatch)
+        outputs, loss = self._score_obs_actions_and_instructions(path_obs, path_actions, enc,
+                                                                 self.feedback)
+        self.loss = loss
+        self.losses.append(float(loss.detach()) if torch.is_tensor(loss) else float(loss))
+        return outputs
+
+    def beam_search(self, *a, **k):
+        raise NotImplementedError('speaker beam_search: SURVEY.md section 8(f) N3 (not built yet)')
+
+    def test(self, use_dropout=False, feedback='argmax', allow_cheat=False, beam_size=1):
+        if not allow_cheat:
+            assert feedback in ['argmax', 'sample']
+        self.feedback = feedback
+        for m in (self.encoder, self.decoder):
+            m.train() if use_dropout else m.eval()
+        self.beam_size = beam_size
+        self.env.reset_epoch()
+        self.losses = []
+        self.results = {}
+        looped = False
+        while True:
+            for result in self.rollout():
+                if result['instr_id'] in self.results:
+                    looped = True
+                else:
+                    self.results[result['instr_id']] = result
+            if looped:
+                break
+        return self.results
+
+    def train(self, encoder_optimizer, decoder_optimizer, n_iters, feedback='teacher'):
+        assert feedback in self.feedback_options
+        self.feedback = feedback
+        self.encoder.train()
+        self.decoder.train()
+        self.losses = []
+        for _ in range(1, n_iters + 1):
+            encoder_optimizer.zero_grad()
+            decoder_optimizer.zero_grad()
+            self.rollout()
+            self.loss.backward()
+            encoder_optimizer.step()
+            decoder_optimizer.step()
+
+    def _encoder_and_decoder_paths(self, base_path):
+        return base_path + '_enc', base_path + '_dec'
+
+    def save(self, path):
+        ep, dp = self._encoder_and_decoder_paths(path)
+        torch.save(self.encoder.state_dict(), ep)
+        torch.save(self.decoder.state_dict(), dp)
+
+    def load(self, path, **kwargs):
+        ep, dp = self._encoder_and_decoder_paths(path)
+        self.encoder.load_state_dict(torch.load(ep, **kwargs))
+        self.decoder.load_state_dict(torch.load(dp, **kwargs))
