@@ -38,6 +38,11 @@ def parse():
     ap.add_argument('--n-viewpoints', type=int, default=10567)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='issue the rollout eagerly instead of replaying a hipGraph')
+    ap.add_argument('--row-shards', type=int, default=1,
+                    help='rollout only: run the batch as this many concurrent row shards (measured: no gain, '
+                         'a half-batch chain is as long as a full one)')
+    ap.add_argument('--in-flight', type=int, default=2,
+                    help='extra measurement: this many independent batch-100 rollouts in flight on separate streams')
     ap.add_argument('--cpu-reps', type=int, default=2)
     return ap.parse_args()
 
@@ -130,11 +135,24 @@ def main():
     else:
         enc.eval()
         dec.eval()
-    replay = graph_state = None
+    replay = graph_state = shard_states = None
     if not train and not args.no_graph:
         # the whole episode (encoder + S decode steps + glue + loss) as ONE hipGraph: ~330 kernels,
         # no host work per step
-        replay, graph_state = engine.capture(batch, S, 'argmax')
+        if args.row_shards > 1:
+            from speaker_follower_amd import dp
+            shards = [follower.DeviceFollowerBatch.from_synth(
+                fb, device=device, rows=dp.shard_rows(B, i, args.row_shards),
+                row0=rank * B + dp.shard_rows(B, i, args.row_shards).start)
+                for i in range(args.row_shards)]
+            replay, shard_states, loss_buf = engine.capture_sharded(shards, S, 'argmax')
+
+            class _Joined:                      # view of the shard results in batch order
+                pass
+            graph_state = _Joined()
+            graph_state.loss_buf = loss_buf
+        else:
+            replay, graph_state = engine.capture(batch, S, 'argmax')
 
     def one_step():
         if train:
@@ -171,6 +189,34 @@ def main():
         elapsed = float(tt)
     agent_steps = B * S * world * args.steps
     value = agent_steps / elapsed
+    if shard_states is not None:                # outside the timed region: stitch shard results
+        graph_state.actions = torch.cat([x.actions for x in shard_states], dim=1)
+
+    # ---- extra (not `value`): serving-style throughput with several independent rollouts in flight.
+    # Every stage of one batch-100 chain is latency-bound and leaves most CUs idle, so independent
+    # episodes overlap on separate streams (validation / data-augmentation decode over many batches).
+    concurrent = None
+    if not train and replay is not None and args.in_flight > 1 and rank == 0:
+        streams = [torch.cuda.Stream() for _ in range(args.in_flight)]
+        reps = []
+        for i, s in enumerate(streams):
+            fbi = synth.follower_batch(seed=1000 + i, batch=B, steps=S, n_viewpoints=args.n_viewpoints)
+            bi = follower.DeviceFollowerBatch.from_synth(fbi, device=device)
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                reps.append(follower.FollowerEngine(enc, dec, store).capture(bi, S, 'argmax') + (bi,))
+        torch.cuda.synchronize()
+        kk = max(args.steps, 2 * args.in_flight)
+        for rnd in range(2):                                  # round 0 = warm-up
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for k in range(kk):
+                with torch.cuda.stream(streams[k % args.in_flight]):
+                    reps[k % args.in_flight][0]()
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+        concurrent = dict(rollouts_in_flight=args.in_flight, value=B * S * kk / dt,
+                          unit='agent-steps/s', ms_per_rollout=1e3 * dt / kk)
 
     if rank != 0:
         if world > 1:
@@ -205,9 +251,13 @@ def main():
     gemm_ms = e0.elapsed_time(e1) / reps
     flops = FLOPS_LSTM(B, I, H)
     achieved = flops / (gemm_ms * 1e-3) / 1e12
+    traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (offline)
+    pmc = os.path.join(ROOT, 'profiles', 'r01_lstm_gemm_pmc.json')
+    if os.path.exists(pmc) and B == 100:
+        traffic = json.load(open(pmc))['hbm_bytes_per_launch']
     roofline = dict(bound='mfma', achieved=achieved, peak=157.3, unit='TFLOP/s',
-                    frac=achieved / 157.3, traffic=None,
-                    kernel='gemm_nt_kernel<7> + reduce_slabs (decoder LSTMCell gates, '
+                    frac=achieved / 157.3, traffic=traffic,
+                    kernel='gemm_nt_tiled_kernel<7> + reduce_slabs (decoder LSTMCell gates, '
                            '[%d,%d]x[%d,%d]^T fp32)' % (B, I + H, 4 * H, I + H),
                     launch_ms=gemm_ms, flops_per_launch=flops)
 
@@ -217,10 +267,13 @@ def main():
                vs_baseline=None, dtype='f32', data='synthetic',
                config=dict(workload='follower %s: batch %d per GPU, 36 views x 2048-d features from a '
                                     '%d-viewpoint HBM table, <=80-token instructions, %d decode steps, '
-                                    'argmax (student-forcing) feedback, every step executed for every row (no early exit), encoder included'
-                                    % (args.workload, B, args.n_viewpoints, S),
+                                    'argmax (student-forcing) feedback, every step executed for every row (no early exit), encoder included%s'
+                                    % (args.workload, B, args.n_viewpoints, S,
+                                       ', batch run as %d concurrent row shards' % args.row_shards
+                                       if shard_states else ''),
                            global_batch=B * world, parallelism='dp%d' % world),
-               roofline=roofline, loss=float(st.loss_buf), launch='hipGraph replay' if replay else 'eager')
+               roofline=roofline, concurrent=concurrent, loss=float(st.loss_buf), launch=('hipGraph replay, %d concurrent row shards' % args.row_shards if shard_states
+                       else 'hipGraph replay') if replay else 'eager')
 
     if not args.no_cpu_baseline:
         used = np.unique(fb.vp)

@@ -584,6 +584,22 @@ __global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmS
     const int li = lane & 15, kk = lane >> 4;
     const int H = p.H;
 
+    // tail operands (hoisted input product, biases) are fetched FIRST: xg[t] is a cold HBM read and
+    // would otherwise sit, fully exposed, between the LDS reduction and the cell update
+    const int prow = threadIdx.x >> 4, pcol = threadIdx.x & 15;
+    const int pb = m0 + prow, pj = slice * 16 + pcol;
+    const bool ptail = threadIdx.x < 256 && pb < p.B;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    float c0v = 0.f;
+    if (ptail) {
+        c0v = p.pw.c0[pb * H + pj];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            pre[g] = p.b_ih[g * H + pj] + p.b_hh[g * H + pj];
+            if (p.xg) pre[g] += p.xg[(size_t)pb * 4 * H + g * H + pj];
+        }
+    }
+
     Seg2 sg;
     sg.s0 = Seg{p.h0, H, p.w_hh, H, H};
     sg.n0 = (H + 15) >> 4;
@@ -602,20 +618,16 @@ __global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmS
     for (int r = 0; r < 4; ++r) s_g[gate][ksl][(kk * 4 + r) * 16 + li] = acc[0][r];
     __syncthreads();
 
-    if (threadIdx.x >= 256) return;
-    const int row = threadIdx.x >> 4, col = threadIdx.x & 15;
-    const int b = m0 + row, j = slice * 16 + col;
-    if (b >= p.B) return;
+    if (!ptail) return;
     float g4[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float v = p.b_ih[g * H + j] + p.b_hh[g * H + j];
+        float v = pre[g];
 #pragma unroll
         for (int k = 0; k < LSTM_KS; ++k) v += s_g[g][k][threadIdx.x];
-        if (p.xg) v += p.xg[(size_t)b * 4 * H + g * H + j];
         g4[g] = v;
     }
-    lstm_cell_update(p.pw, b, j, g4);
+    lstm_cell_update(p.pw, pb, pj, g4, c0v);
 }
 
 // ------------------------------------------------------------------------------------------------

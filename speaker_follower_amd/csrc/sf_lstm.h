@@ -31,12 +31,11 @@ struct LstmStepArgs {            // fused recurrent step (sf_gemm.hip: lstm_step
 
 // g4 = pre-activation gates (i,f,g,o) of element (b, j), biases already added.
 __device__ __forceinline__ void lstm_cell_update(const LstmPwFwd& a, int b, int j,
-                                                 const float (&g4)[4]) {
+                                                 const float (&g4)[4], float c0) {
     const int H = a.H;
     const int idx = b * H + j;
     const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]),
                 og = sigmoidf_(g4[3]);
-    const float c0 = a.c0[idx];
     float c1 = fg * c0 + ig * gg;
     float h1 = og * tanhf(c1);
     if (a.gates) {

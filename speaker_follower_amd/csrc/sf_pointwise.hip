@@ -35,7 +35,7 @@ __global__ __launch_bounds__(TPB) void lstm_pw_fwd_kernel(LstmPwFwd a) {
             for (int s = 0; s < 16; ++s) v += part[g][s];
             g4[g] = v;
         }
-        lstm_cell_update(a, b, j, g4);
+        lstm_cell_update(a, b, j, g4, a.c0[idx]);
     }
 }
 

@@ -125,7 +125,7 @@ class FollowerEngine:
         self.dropout_seed = None
 
     # ------------------------------------------------------------------------------ forward
-    def rollout(self, batch, steps, feedback='argmax', train=None):
+    def rollout(self, batch, steps, feedback='argmax', train=None, finalize=True):
         """Runs encoder + `steps` decode steps.  Returns a RolloutState with
         .logits [S,B,A] (masked), .actions [S,B], .step_scores [S,B], .loss (0-dim tensor,
         differentiable when parameters require grad and grad mode is on), .h, .c, .ctx."""
@@ -205,12 +205,14 @@ class FollowerEngine:
                  ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), byref(tp), byref(glue), d_ptr,
                  st.site0 + t, *ws)
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
+        st.logits = st.tape['logit']
+        st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
+        if not finalize:            # a row shard of a larger batch: the caller combines sum_cnt tables
+            return st
         if self.group is not None:
             # global per-step normaliser so that the sharded loss equals the reference's batch mean
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
         call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
-        st.logits = st.tape['logit']
-        st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
 
         all_params = list(params) + [p for p in enc.parameters()]
         if torch.is_grad_enabled() and any(p.requires_grad for p in all_params):
@@ -234,6 +236,47 @@ class FollowerEngine:
                     st = self.rollout(batch, steps, feedback, train=False)
             torch.cuda.current_stream().wait_stream(side)
         return graph.replay, st
+
+    def capture_sharded(self, shards, steps, feedback='argmax'):
+        """Runs the row shards of ONE batch as concurrent chains (inference): one hipGraph per
+        shard, replayed on its own stream.  Samples never interact in the forward pass, and at batch
+        100 every stage of the chain is latency-bound with most of the 256 CUs idle, so two
+        half-batch chains overlap; the per-step (CE sum, live count) tables are added before the loss
+        is finalised, exactly like the data-parallel path does across GPUs.  (Fork/join branches
+        inside a single hipGraph were measured to execute serially on ROCm 7.2, hence one graph per
+        stream.)  Returns (replay, states, loss_buf)."""
+        dev = self.store.device
+        streams = [torch.cuda.Stream() for _ in shards]
+        graphs, states = [], []
+        with torch.no_grad():
+            for sh, s in zip(shards, streams):
+                s.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s):
+                    self.rollout(sh, steps, feedback, train=False)          # warm-up on this stream
+                    torch.cuda.synchronize()
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g, stream=s):
+                        states.append(self.rollout(sh, steps, feedback, train=False, finalize=False))
+                graphs.append(g)
+            torch.cuda.synchronize()
+        total = torch.empty(steps, 2, device=dev)
+        loss_buf = torch.empty(1, device=dev)
+        gscale = torch.empty(steps, device=dev)
+
+        def replay():
+            cur = torch.cuda.current_stream()
+            for s, g in zip(streams, graphs):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s):
+                    g.replay()
+            for s in streams:
+                cur.wait_stream(s)
+            total.copy_(states[0].sum_cnt)
+            for st in states[1:]:
+                call('sf_add_f32', ptr(total), ptr(st.sum_cnt), total.numel(), stream())
+            call('sf_loss_finalize', ptr(total), steps, ptr(loss_buf), ptr(gscale), stream())
+
+        return replay, states, loss_buf
 
     # ------------------------------------------------------------------------------ backward
     def _backward(self, st, dloss):

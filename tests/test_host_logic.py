@@ -138,3 +138,21 @@ def test_data_parallel_gradient_and_count_allreduce_gloo_world2():
         assert sc.tolist() == [[3.0, 4.0], [0.0, 0.0]]
         assert torch.all(o == 1.0)
         assert attached and raised
+
+
+def test_feature_store_reads_reference_tsv_format(tmp_path):
+    """N4: the ResNet TSV of the reference (env.py:359-370: scanId, viewpointId, image_w, image_h,
+    vfov, base64 fp32 36x2048) -> table + id index."""
+    import base64
+    from speaker_follower_amd.features import FeatureStore
+    rng = np.random.default_rng(5)
+    rows = {('scanA', 'vp%d' % i): rng.random((36, 2048), dtype=np.float32) for i in range(3)}
+    path = tmp_path / 'feats.tsv'
+    with open(path, 'wt') as f:
+        for (scan, vp), feat in rows.items():
+            f.write('\t'.join([scan, vp, '640', '480', '60', base64.b64encode(feat.tobytes()).decode()]) + '\n')
+    store = FeatureStore.from_tsv(str(path), device='cpu')
+    assert store.table.shape == (3, 36, 2048) and store.F == 2176
+    for (scan, vp), feat in rows.items():
+        np.testing.assert_array_equal(store.table[store.row(scan, vp)].numpy(), feat)
+    assert store.loc_table.shape == (36, 36, 128)
