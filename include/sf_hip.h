@@ -111,13 +111,25 @@ typedef struct sf_scoring_w { /* EltwiseProdScoring model.py:335-340 */
 } sf_scoring_w;
 typedef struct sf_scoring_g { float *w_h, *b_h, *w_a, *b_a, *w_out, *b_out, *unused0, *unused1; } sf_scoring_g;
 
+/* Optional INFERENCE-ONLY folding of consecutive Linears (built by sf_decoder_fold_build once per
+ * weight version): the visual query q = W_v^T (W_h h + b_h) becomes ONE product q = M_v h + c_v, and
+ * the scoring vector / constant r = W_a^T (w_out * (W_h h~ + b_h)), c = wt.b_a + b_out become ONE
+ * product [r | c] = M_a h~ + c_a.  Two dependent stages fewer per decode step.  The backward needs
+ * the unfolded intermediates, so training calls leave `fold` NULL. */
+typedef struct sf_decoder_fold {
+    const float* m_v; /* [F,H]   = W_v^T W_h */
+    const float* c_v; /* [F]     = W_v^T b_h */
+    const float* m_a; /* [F+4,H]: rows < F = W_a^T diag(w_out) W_h; row F = W_h^T (w_out*b_a); rest 0 */
+    const float* c_a; /* [F+4]:   [< F] = W_a^T (w_out*b_h); [F] = (w_out*b_h).b_a + b_out; rest 0 */
+} sf_decoder_fold;
 typedef struct sf_decoder_w { /* AttnDecoderLSTM model.py:361-375 */
     sf_lstm_w lstm;       /* LSTMCell(2F -> H) */
     sf_visual_w visual;
     sf_softdot_w text;
     sf_scoring_w action;
+    const sf_decoder_fold* fold; /* NULL = unfolded (required for training) */
 } sf_decoder_w;
-typedef struct sf_decoder_g { sf_lstm_g lstm; sf_visual_g visual; sf_softdot_g text; sf_scoring_g action; } sf_decoder_g;
+typedef struct sf_decoder_g { sf_lstm_g lstm; sf_visual_g visual; sf_softdot_g text; sf_scoring_g action; void* unused; } sf_decoder_g;
 
 /* ---- saved activations of one AttnDecoderLSTM step (all written by fwd, read by bwd) ------- */
 typedef struct sf_decoder_tape {
@@ -272,6 +284,11 @@ typedef struct sf_decoder_gtape {
     float* dr;      /* [B,F]  gradient of the folded scoring vector */
     float* dc;      /* [B]    gradient of the per-row scoring constant */
 } sf_decoder_gtape;
+/* Builds the sf_decoder_fold matrices from the (transposed copies of the) decoder weights:
+ * m_v [F,H], c_v [F], m_a [F+4,H], c_a [F+4] are caller-allocated device buffers. */
+int sf_decoder_fold_build(const sf_decoder_w* w, int H, int D, int F, float* m_v, float* c_v,
+                          float* m_a, float* c_a, void* ws, size_t ws_bytes, sf_stream stream);
+
 /* Gradients in: dlogit [B,A], dh1, dc1 [B,H] (NULL = zero).  Out: dh0, dc0 [B,H] overwritten,
  * dctx [B,L,H] ADDED to.  u_prev is detached in the reference (follower.py:502): no du_prev.
  * g != NULL: weight gradients of this step are accumulated immediately; gtape != NULL: the dY

@@ -50,8 +50,12 @@ SoftdotW = _ptr_struct('SoftdotW', ['w_in', 'w_out', 'w_in_t', 'w_out_t'])
 ScoringW = _ptr_struct('ScoringW', ['w_h', 'b_h', 'w_a', 'b_a', 'w_out', 'b_out', 'w_a_t', 'w_h_t'])
 
 
+DecoderFold = _ptr_struct('DecoderFold', ['m_v', 'c_v', 'm_a', 'c_a'])
+
+
 class DecoderW(C.Structure):
-    _fields_ = [('lstm', LstmW), ('visual', VisualW), ('text', SoftdotW), ('action', ScoringW)]
+    _fields_ = [('lstm', LstmW), ('visual', VisualW), ('text', SoftdotW), ('action', ScoringW),
+                ('fold', C.POINTER(DecoderFold))]
 
 
 DecoderGTape = _ptr_struct('DecoderGTape', ['dgates', 'dpre', 'dt_text', 'dt_v', 'dq', 'dwt', 'dta', 'dr',
@@ -127,6 +131,7 @@ _SIGNATURES = {
                                       c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),
     'sf_attn_decoder_wgrad': (C.c_int, [P(DecoderW), P(DecoderW), i32, i32, i32, i32, c_f,
                                         P(DecoderTape), P(DecoderGTape), c_p]),
+    'sf_decoder_fold_build': (C.c_int, [P(DecoderW), i32, i32, i32, c_f, c_f, c_f, c_f] + WS),
     'sf_follower_glue_fwd': (C.c_int, [P(Cands), i32, c_f, P(FollowerGlue), c_p]),
     'sf_follower_glue_bwd': (C.c_int, [i32, i32, c_f, i64p, c_f, c_f, c_p]),
     'sf_reduce_terms': (C.c_int, [c_f, c_f, i32, i32, c_f, c_p]),

@@ -135,8 +135,12 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
 // ---- a1 VisualSoftDotAttention ---------------------------------------------------------------------
 int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, const float* h,
                  float* out, int ldo, float* alpha, float* t_v, float* q, const Dropout& drop,
-                 int col0, Arena ar, hipStream_t st) {
+                 int col0, Arena ar, hipStream_t st, const sf_decoder_fold* fold = nullptr) {
     const int F = X.IMG + X.LOC;
+    if (fold) {      // inference: q = M_v h + c_v in one product
+        TRY(linear_plain(h, H, fold->m_v, H, fold->c_v, B, F, H, EPI_NONE, q, F, ar, st));
+        return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st);
+    }
     TRY(linear_plain(h, H, w->w_h, H, w->b_h, B, D, H, EPI_NONE, t_v, D, ar, st));
     if (w->w_v_t)   // q = t_v W_v as a K-contiguous product against the transposed copy
         TRY(linear_plain(t_v, D, w->w_v_t, D, nullptr, B, F, D, EPI_NONE, q, F, ar, st));
@@ -199,8 +203,17 @@ int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, in
 // ---- a4 EltwiseProdScoring --------------------------------------------------------------------------
 int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, const float* h,
                   float* logit, float* t_a, float* wt, float* r, Arena ar, hipStream_t st,
-                  const sf_follower_glue* glue = nullptr) {
+                  const sf_follower_glue* glue = nullptr, const sf_decoder_fold* fold = nullptr) {
     const int F = U.IMG + U.LOC;
+    if (fold) {      // inference: [r | c] = M_a h~ + c_a in one product ([B, F+4] scratch)
+        float* rext = ar.take((size_t)B * (F + 4));
+        NEED(rext);
+        TRY(linear_plain(h, H, fold->m_a, H, fold->c_a, B, F + 4, H, EPI_NONE, rext, F + 4, ar, st));
+        if (glue)
+            return score_glue_fwd(U, B, D, rext, nullptr, nullptr, nullptr,
+                                  make_glue(U, B, logit, glue), st, F + 4, rext + F);
+        return score_fwd(U, B, D, rext, nullptr, nullptr, nullptr, logit, st, F + 4, rext + F);
+    }
     Seg sg{h, H, w->w_h, H, H};
     LinearOut o{};
     o.y = wt; o.ldy = D; o.bias = w->b_h; o.mul = w->w_out; o.y_pre = t_a; o.ldy_pre = D;
@@ -384,7 +397,7 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
     const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
     // model.py:389  feature, alpha_v = visual_attention(h_0, X)  -> straight into xin[:, F:2F]
     TRY(visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
-                     d_in, F, ar, st));
+                     d_in, F, ar, st, w->fold));
     // model.py:391-392  drop(cat(u_prev, feature))
     if (u_prev) TRY(dropout_copy(u_prev, F, B, F, tp->xin, 2 * F, d_in, 0, st));
     // model.py:393-394  LSTMCell; dropout(h_1) lands in cat2[:, H:2H]
@@ -395,7 +408,33 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
                       tp->t_text, ar, st));
     // model.py:396  action logits
     return scoring_fwd_i(&w->action, cands(U), B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt,
-                         tp->r, ar, st, glue);
+                         tp->r, ar, st, glue, w->fold);
+}
+
+int sf_decoder_fold_build(const sf_decoder_w* w, int H, int D, int F, float* m_v, float* c_v,
+                          float* m_a, float* c_a, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && m_v && c_v && m_a && c_a && w->visual.w_v_t && w->visual.w_h_t &&
+                 w->action.w_a_t && w->action.w_h_t && F % 4 == 0 && D % 4 == 0 && H % 4 == 0);
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    float* wa_s = ar.take((size_t)F * D);      // W_a^T with columns scaled by w_out
+    float* wo_ba = ar.take(D);                 // w_out * b_a
+    float* wo_bh = ar.take(D);                 // w_out * b_h
+    NEED(wa_s && wo_ba && wo_bh);
+    // visual: M_v = W_v^T W_h  ([F,D] x [D,H]),  c_v = W_v^T b_h
+    TRY(linear_plain(w->visual.w_v_t, D, w->visual.w_h_t, D, nullptr, F, H, D, EPI_NONE, m_v, H, ar, st));
+    TRY(linear_plain(w->visual.b_h, D, w->visual.w_v_t, D, nullptr, 1, F, D, EPI_NONE, c_v, F, ar, st));
+    // scoring
+    TRY(scale_cols(w->action.w_a_t, D, w->action.w_out, F, D, wa_s, D, st));
+    TRY(scale_cols(w->action.b_a, D, w->action.w_out, 1, D, wo_ba, D, st));
+    TRY(scale_cols(w->action.b_h, D, w->action.w_out, 1, D, wo_bh, D, st));
+    TRY(fill(m_a + (size_t)F * H, (size_t)4 * H, 0.f, st));
+    TRY(fill(c_a + F, 4, 0.f, st));
+    TRY(linear_plain(wa_s, D, w->action.w_h_t, D, nullptr, F, H, D, EPI_NONE, m_a, H, ar, st));
+    TRY(linear_plain(wo_ba, D, w->action.w_h_t, D, nullptr, 1, H, D, EPI_NONE, m_a + (size_t)F * H, H, ar, st));
+    TRY(linear_plain(wo_bh, D, w->action.w_a_t, D, nullptr, 1, F, D, EPI_NONE, c_a, F + 4, ar, st));
+    return linear_plain(wo_bh, D, w->action.b_a, D, w->action.b_out, 1, 1, D, EPI_NONE, c_a + F, 4, ar, st);
 }
 
 int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,

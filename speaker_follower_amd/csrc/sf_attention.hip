@@ -251,7 +251,9 @@ constexpr int SC_CPL = 9, SC_NW = 16, SC_SLOTS = 4;
 
 struct ScoreArgs {
     CandSrc src;
-    const float* r;        // fwd [B,F]
+    int ldr;               // row stride of r
+    const float* cst;      // optional per-row constant (stride ldr); null -> wt.b_a + b_out
+    const float* r;        // fwd [B,ldr]
     const float* wt;       // fwd [B,D]
     const float* b_a;      // [D]
     const float* b_out;    // [1]
@@ -273,13 +275,14 @@ __global__ __launch_bounds__(SC_NW * 64) void score_fwd_kernel(ScoreArgs a) {
         const int c = lane + 64 * i;
         if (c < n4)
             d += dot4(cand_chunk(a.src, b, wave, c),
-                      reinterpret_cast<const float4*>(a.r + (size_t)b * (n4 << 2))[c]);
+                      reinterpret_cast<const float4*>(a.r + (size_t)b * a.ldr)[c]);
     }
     float cst = 0.f;
-    for (int k = lane; k < a.D; k += 64) cst += a.wt[(size_t)b * a.D + k] * a.b_a[k];
+    if (!a.cst)
+        for (int k = lane; k < a.D; k += 64) cst += a.wt[(size_t)b * a.D + k] * a.b_a[k];
     d = wave_sum(d);
-    cst = wave_sum(cst);
-    if (lane == 0) a.logit[(size_t)b * A + wave] = d + cst + a.b_out[0];
+    cst = a.cst ? a.cst[(size_t)b * a.ldr] : wave_sum(cst) + a.b_out[0];
+    if (lane == 0) a.logit[(size_t)b * A + wave] = d + cst;
 }
 
 // Scoring + per-step glue fused (one dependent stage instead of two): wave a keeps candidate a's row
@@ -298,14 +301,14 @@ __global__ __launch_bounds__(SC_NW * 64) void score_glue_kernel(ScoreArgs a, FGl
     for (int i = 0; i < SC_CPL; ++i) {
         const int c = lane + 64 * i;
         x[i] = (wave < A && c < n4) ? cand_chunk(a.src, b, wave, c) : f4zero();
-        if (c < n4) d += dot4(x[i], reinterpret_cast<const float4*>(a.r + (size_t)b * (n4 << 2))[c]);
+        if (c < n4) d += dot4(x[i], reinterpret_cast<const float4*>(a.r + (size_t)b * a.ldr)[c]);
     }
     float cst = 0.f;
-    if (wave < A)
+    if (wave < A && !a.cst)
         for (int k = lane; k < a.D; k += 64) cst += a.wt[(size_t)b * a.D + k] * a.b_a[k];
     d = wave_sum(d);
-    cst = wave_sum(cst);
-    if (lane == 0 && wave < A) s_logit[wave] = d + cst + a.b_out[0];
+    cst = a.cst ? a.cst[(size_t)b * a.ldr] : wave_sum(cst) + a.b_out[0];
+    if (lane == 0 && wave < A) s_logit[wave] = d + cst;
     __syncthreads();
     if (wave == 0) {
         const int at = follower_glue_row(g, b, lane < A ? s_logit[lane] : 0.f);
@@ -392,23 +395,26 @@ int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int l
 }
 
 int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
-              const float* b_out, float* logit, hipStream_t st) {
+              const float* b_out, float* logit, hipStream_t st, int ldr, const float* cst) {
     const int F = src.IMG + src.LOC;
+    if (ldr <= 0) ldr = F;
     if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
-    ScoreArgs a{src, r, wt, b_a, b_out, D, logit, nullptr, nullptr};
+    ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, logit, nullptr, nullptr};
     hipLaunchKernelGGL(score_fwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
     return launch_status();
 }
 
 int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
-                   const float* b_a, const float* b_out, const FGlue& g, hipStream_t st) {
+                   const float* b_a, const float* b_out, const FGlue& g, hipStream_t st, int ldr,
+                   const float* cst) {
     const int F = src.IMG + src.LOC;
+    if (ldr <= 0) ldr = F;
     if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
-    ScoreArgs a{src, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr};
+    ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr};
     hipLaunchKernelGGL(score_glue_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a, g);
     return launch_status();
 }
@@ -419,7 +425,7 @@ int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* 
     if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
-    ScoreArgs a{src, nullptr, nullptr, nullptr, nullptr, 0, const_cast<float*>(dlogit), dr, dc};
+    ScoreArgs a{src, F, nullptr, nullptr, nullptr, nullptr, nullptr, 0, const_cast<float*>(dlogit), dr, dc};
     hipLaunchKernelGGL(score_bwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
     return launch_status();
 }

@@ -16,7 +16,7 @@ int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int l
                   const float* t, int ldt, const float* alpha, float* dt, int lddt, float* dctx,
                   hipStream_t st);
 int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
-              const float* b_out, float* logit, hipStream_t st);
+              const float* b_out, float* logit, hipStream_t st, int ldr = 0, const float* cst = nullptr);
 int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* dc, hipStream_t st);
 
 // ---- sf_gemm.hip (workspace-aware NN) -------------------------------------------------------------
@@ -76,7 +76,8 @@ struct FGlue;
 int follower_glue_fwd(const FGlue& g, hipStream_t st);
 // scoring + glue in one launch (sf_attention.hip); g.logit receives the masked logits
 int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
-                   const float* b_a, const float* b_out, const FGlue& g, hipStream_t st);
+                   const float* b_a, const float* b_out, const FGlue& g, hipStream_t st, int ldr = 0,
+                   const float* cst = nullptr);
 int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,
                    const float* gscale, float* dlogit, hipStream_t st);
 int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,

@@ -19,7 +19,8 @@ import torch
 from . import _lib
 from ._lib import call
 from .features import cand_sincos
-from .model import (decoder_params, decoder_w_struct, _encoder_structs, _TAPE_KEYS, grad_ptr)
+from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
+                    grad_ptr)
 from .runtime import ptr, stream, ws_args, dropout_arg
 
 byref = C.byref
@@ -123,6 +124,7 @@ class FollowerEngine:
         self.group = group              # torch.distributed process group for data parallelism
         self.iteration = 0
         self.dropout_seed = None
+        self.fold_inference = False     # model.decoder_fold: correct, but measured no faster (590K vs 596K)
 
     # ------------------------------------------------------------------------------ forward
     def rollout(self, batch, steps, feedback='argmax', train=None, finalize=True):
@@ -185,7 +187,12 @@ class FollowerEngine:
         st.step_scores, st.ce_term, st.live = new(S, B), new(S, B), new(S, B)
         st.sum_cnt, st.gscale, st.loss_buf = new(S, 2), new(S), new(1)
         params = decoder_params(dec)
-        dw = decoder_w_struct(params)
+        all_params = list(params) + [p for p in enc.parameters()]
+        st.differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in all_params)
+        # inference: consecutive Linears folded (two dependent stages fewer per step); the backward
+        # needs the unfolded intermediates, so a differentiable rollout keeps them
+        fold = None if (st.differentiable or training or not self.fold_inference) else decoder_fold(dec)
+        dw = decoder_w_struct(params, fold=fold)
         ws = ws_args(dev)
         d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
@@ -214,8 +221,7 @@ class FollowerEngine:
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
         call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
 
-        all_params = list(params) + [p for p in enc.parameters()]
-        if torch.is_grad_enabled() and any(p.requires_grad for p in all_params):
+        if st.differentiable:
             st.loss = _RolloutLossFn.apply(self, st, *all_params)
         else:
             st.loss = st.loss_buf.clone().reshape(())

@@ -352,7 +352,27 @@ def decoder_params(mod):
             a.linear_out.weight, a.linear_out.bias)
 
 
-def decoder_w_struct(params, grad=False):
+def decoder_fold(mod):
+    """sf_decoder_fold for inference (see include/sf_hip.h), rebuilt only when one of the nine
+    tensors it is made of changed.  Kept on the module so that the pointers stay alive."""
+    params = decoder_params(mod)
+    src = [params[i] for i in (4, 5, 6, 10, 11, 12, 13, 14, 15)]
+    key = tuple((p.data_ptr(), p._version) for p in src)
+    cached = getattr(mod, '_sf_fold', None)
+    if cached is not None and cached[0] == key:
+        return cached[2]
+    H, F, D = mod.hidden_size, mod.feature_size, params[4].shape[0]
+    dev = params[0].device
+    new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
+    bufs = (new(F, H), new(F), new(F + 4, H), new(F + 4))
+    w = decoder_w_struct(params)
+    call('sf_decoder_fold_build', byref(w), H, D, F, *(ptr(b) for b in bufs), *ws_args(dev))
+    fold = _lib.DecoderFold(*(b.data_ptr() for b in bufs))
+    mod._sf_fold = (key, bufs, fold)
+    return fold
+
+
+def decoder_w_struct(params, grad=False, fold=None):
     if grad:
         vals = _grads(params)
         return _lib.DecoderW(_lib.LstmW(*vals[0:4]), _lib.VisualW(*vals[4:8]),
@@ -362,7 +382,8 @@ def decoder_w_struct(params, grad=False):
     return _lib.DecoderW(_lib.LstmW(*vals[0:4], t(0), t(1)),
                          _lib.VisualW(*vals[4:8], t(6), t(4)),
                          _lib.SoftdotW(*vals[8:10], t(8), t(9)),
-                         _lib.ScoringW(*vals[10:16], t(12), t(10)))
+                         _lib.ScoringW(*vals[10:16], t(12), t(10)),
+                         C.pointer(fold) if fold is not None else None)
 
 
 class _DecoderStepFn(torch.autograd.Function):
