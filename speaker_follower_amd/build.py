@@ -67,5 +67,25 @@ def build_lib(force=False, verbose=True):
     return LIB
 
 
+def build_sim(force=False, verbose=True):
+    """The navigation-only MatterSim pybind11 module (g++, no OpenCV / GL / jsoncpp)."""
+    import sysconfig
+    import pybind11
+    sim = os.path.join(PKG, 'sim')
+    out = os.path.join(sim, 'MatterSim' + sysconfig.get_config_var('EXT_SUFFIX'))
+    srcs = [os.path.join(sim, f) for f in ('mattersim_nav.cpp', 'mattersim_py.cpp')]
+    deps = srcs + [os.path.join(sim, 'mattersim_nav.hpp')]
+    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+        cmd = ['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden',
+               '-I' + pybind11.get_include(), '-I' + sysconfig.get_paths()['include']] + srcs + ['-o', out]
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('MatterSim build failed:\n%s\n%s' % (res.stdout, res.stderr))
+        if verbose:
+            print('MatterSim module rebuilt (%d bytes)' % os.path.getsize(out))
+    return out
+
+
 if __name__ == '__main__':
     build_lib(force='--force' in sys.argv)
+    build_sim(force='--force' in sys.argv)

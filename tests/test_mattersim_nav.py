@@ -1,0 +1,193 @@
+"""CPU: the navigation-only MatterSim (N1) against the reference simulator's own known-answer
+tests (src/test/main.cpp: "Continuous Motion" :42-74, "Discrete Motion" :76-109, "Robot Relative
+Coords" :111-167, "Navigable Locations" :169-299), restated over the connectivity files committed
+under tests/golden/connectivity (data copied from the reference's connectivity/ directory)."""
+import json
+import math
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONN = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
+
+# known-answer tables, src/test/main.cpp:34-40 (degrees)
+HEADING = [10, 350, 350, 1, 90, 180, 90, 270, 90, 270]
+HEADING_CHG = [-20, -360, 371, 89, 90, -90, -180, -180, -180, 0]
+DISCRETE_HEADING = [0, 330, 300, 330, 0, 30, 0, 330, 300, 270]
+ELEVATION = [10, 10, -26, -40, -40, -40, 50, 50, 40, 0]
+ELEVATION_CHG = [0, -36, -30, -10, 0, 90, 5, -10, -40, 0]
+DISCRETE_ELEVATION = [0, 0, -30, -30, -30, -30, 0, 30, 0, -30]
+VIEW_INDEX = [12, 23, 10, 11, 0, 1, 12, 35, 22, 9]
+SCANS = ['2t7WUuJeko7', '17DRP5sb8fy']
+VIEWPOINTS = ['cc34e9176bfe47ebb23c58c165203134', '5b9b2794954e4694a45fc424a8643081']
+rad = math.radians
+
+
+@pytest.fixture(scope='module')
+def MatterSim():
+    from speaker_follower_amd.build import build_sim
+    build_sim()
+    import speaker_follower_amd.sim as sim
+    return sim.load()
+
+
+def make_sim(MatterSim, w, h, vfov_deg, discrete=False):
+    sim = MatterSim.Simulator()
+    sim.setCameraResolution(w, h)
+    sim.setCameraVFOV(rad(vfov_deg))
+    sim.setRenderingEnabled(False)
+    sim.setDiscretizedViewingAngles(discrete)
+    sim.setNavGraphPath(CONN)
+    return sim
+
+
+def test_module_surface_matches_reference_binding(MatterSim):
+    """src/lib_python/MatterSimPython.cpp:132-164."""
+    for name in ('Simulator', 'SimState', 'ViewPoint'):
+        assert hasattr(MatterSim, name)
+    for m in ('setDatasetPath', 'setNavGraphPath', 'setCameraResolution', 'setCameraVFOV',
+              'setRenderingEnabled', 'setDiscretizedViewingAngles', 'init', 'setSeed',
+              'setElevationLimits', 'newEpisode', 'getState', 'makeAction', 'close'):
+        assert hasattr(MatterSim.Simulator, m), m
+    sim = make_sim(MatterSim, 200, 100, 45)
+    sim.init()
+    sim.newEpisode(SCANS[0], VIEWPOINTS[0], 0, 0)
+    st = sim.getState()
+    for a in ('scanId', 'step', 'rgb', 'location', 'heading', 'elevation', 'viewIndex',
+              'navigableLocations'):
+        assert hasattr(st, a), a
+    for a in ('viewpointId', 'ix', 'point', 'rel_heading', 'rel_elevation', 'rel_distance'):
+        assert hasattr(st.location, a), a
+    assert isinstance(st.location.point, list) and len(st.location.point) == 3
+    assert sim.getState() is not st                       # copy-out state objects
+
+
+def test_continuous_motion(MatterSim):
+    sim = make_sim(MatterSim, 200, 100, 45)
+    assert sim.setElevationLimits(rad(-40), rad(50))
+    sim.init()
+    for scan, vp in zip(SCANS, VIEWPOINTS):
+        sim.newEpisode(scan, vp, rad(HEADING[0]), rad(ELEVATION[0]))
+        for t in range(10):
+            st = sim.getState()
+            assert st.scanId == scan and st.step == t
+            assert st.heading == pytest.approx(rad(HEADING[t]), abs=1e-9)
+            assert st.elevation == pytest.approx(rad(ELEVATION[t]), abs=1e-9)
+            assert st.location.viewpointId == vp
+            assert st.viewIndex == 0
+            actions = st.navigableLocations
+            ix = t % len(actions)
+            sim.makeAction(ix, rad(HEADING_CHG[t]), rad(ELEVATION_CHG[t]))
+            vp = actions[ix].viewpointId
+    sim.close()
+
+
+def test_discrete_motion(MatterSim):
+    sim = make_sim(MatterSim, 200, 100, 45, discrete=True)
+    assert sim.setElevationLimits(rad(-10), rad(10))      # disregarded in discrete mode
+    sim.init()
+    for scan, vp in zip(SCANS, VIEWPOINTS):
+        sim.newEpisode(scan, vp, rad(HEADING[0]), rad(ELEVATION[0]))
+        for t in range(10):
+            st = sim.getState()
+            assert st.scanId == scan and st.step == t
+            assert st.heading == pytest.approx(rad(DISCRETE_HEADING[t]), abs=1e-9)
+            assert st.elevation == pytest.approx(rad(DISCRETE_ELEVATION[t]), abs=1e-9)
+            assert st.location.viewpointId == vp
+            assert st.viewIndex == VIEW_INDEX[t]
+            actions = st.navigableLocations
+            ix = t % len(actions)
+            sim.makeAction(ix, rad(HEADING_CHG[t]), rad(ELEVATION_CHG[t]))
+            vp = actions[ix].viewpointId
+
+
+def test_robot_relative_coords(MatterSim):
+    sim = make_sim(MatterSim, 200, 100, 45)
+    assert sim.setElevationLimits(rad(-40), rad(50))
+    sim.init()
+    for scan, vp in zip(SCANS, VIEWPOINTS):
+        sim.newEpisode(scan, vp, rad(HEADING[0]), rad(ELEVATION[0]))
+        for t in range(10):
+            st = sim.getState()
+            cur = st.location.point
+            last = 0.0
+            for k, loc in enumerate(st.navigableLocations):
+                if k == 0:
+                    assert st.location.rel_heading == 0 and st.location.rel_elevation == 0
+                    assert st.location.rel_distance == 0
+                    continue
+                ang = math.hypot(loc.rel_heading, loc.rel_elevation)
+                assert ang >= last                        # sorted by angular distance from the centre
+                last = ang
+                h, e = st.heading + loc.rel_heading, st.elevation + loc.rel_elevation
+                off = (math.sin(h) * math.cos(e) * loc.rel_distance,
+                       math.cos(h) * math.cos(e) * loc.rel_distance, math.sin(e) * loc.rel_distance)
+                for c in range(3):
+                    assert loc.point[c] == pytest.approx(cur[c] + off[c], rel=1e-4, abs=1e-4)
+            actions = st.navigableLocations
+            sim.makeAction(t % len(actions), rad(HEADING_CHG[t]), rad(ELEVATION_CHG[t]))
+
+
+def test_navigable_locations_all_fixture_scans(MatterSim):
+    scans = open(os.path.join(CONN, 'scans.txt')).read().split()
+    sim = make_sim(MatterSim, 20, 20, 90)
+    half_hfov = math.pi / 4
+    sim.setSeed(1)
+    sim.init()
+    f32 = lambda x: float(__import__('numpy').float32(x))  # noqa: E731  (the reference reads asFloat)
+    for scan in scans:
+        sim.newEpisode(scan)
+        root = json.load(open(os.path.join(CONN, scan + '_connectivity.json')))
+        included = [v['included'] for v in root]
+        ids = [v['image_id'] for v in root]
+        st = sim.getState()
+        assert included[ids.index(st.location.viewpointId)]           # never spawn at an excluded one
+        for t in range(10):
+            st = sim.getState()
+            assert st.scanId == scan and st.step == t
+            locs = {v.viewpointId: v for v in st.navigableLocations}
+            cur = root[ids.index(st.location.viewpointId)]
+            x, y = f32(cur['pose'][3]), f32(cur['pose'][7])
+            count = 0
+            for i, tgt in enumerate(root):
+                tx, ty, tz = f32(tgt['pose'][3]), f32(tgt['pose'][7]), f32(tgt['pose'][11])
+                if tgt['image_id'] == cur['image_id']:
+                    assert tgt['image_id'] in locs and included[i]
+                    assert locs[tgt['image_id']].point == pytest.approx([tx, ty, tz], rel=1e-5)
+                    count += 1
+                elif not cur['unobstructed'][i] or not included[i]:
+                    assert tgt['image_id'] not in locs
+                else:
+                    vh = math.pi / 2 - math.atan2(ty - y, tx - x)
+                    if vh < 0:
+                        vh += 2 * math.pi
+                    d = min(abs(st.heading - vh), abs(st.heading + 2 * math.pi - vh),
+                            abs(st.heading - (vh + 2 * math.pi)))
+                    if abs(d - half_hfov) < 1e-5:
+                        count += tgt['image_id'] in locs              # on the cone's edge: either way
+                        continue
+                    if d <= half_hfov:
+                        assert tgt['image_id'] in locs
+                        assert locs[tgt['image_id']].point == pytest.approx([tx, ty, tz], rel=1e-5)
+                        count += 1
+                    else:
+                        assert tgt['image_id'] not in locs
+            assert count == len(st.navigableLocations)
+            sim.makeAction(t % len(st.navigableLocations), rad(HEADING_CHG[t]), rad(ELEVATION_CHG[t]))
+
+
+def test_error_behaviour(MatterSim):
+    sim = make_sim(MatterSim, 20, 20, 90)
+    sim.init()
+    with pytest.raises(ValueError):                        # std::invalid_argument, MatterSim.cpp:248
+        sim.newEpisode('no_such_scan')
+    with pytest.raises(ValueError):                        # :421
+        sim.newEpisode(SCANS[0], 'no_such_viewpoint')
+    sim.newEpisode(SCANS[0], VIEWPOINTS[0])
+    with pytest.raises(ValueError):                        # std::domain_error, :476
+        sim.makeAction(99, 0, 0)
+    with pytest.raises(RuntimeError):                      # rendering is not part of this build
+        s2 = MatterSim.Simulator()
+        s2.init()
+    assert not sim.setElevationLimits(0.5, 1.0)
