@@ -1,0 +1,140 @@
+"""CPU: the R2R index environment (N2) over the navigation-only MatterSim on committed
+connectivity fixtures: panorama sweep, candidate ordering, teacher, transitions, index batches."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CONN = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
+SCANS = ['YmJkqBEsHnH', 'gZ6f7yhEvPG', 'GdvgFV5R1Z5', '8194nk5LbLH']
+
+
+@pytest.fixture(scope='module')
+def envmod():
+    from speaker_follower_amd.build import build_sim
+    build_sim()
+    from speaker_follower_amd import env
+    return env
+
+
+@pytest.fixture(scope='module')
+def setup(envmod):
+    graphs = {s: envmod.NavGraph(os.path.join(CONN, s + '_connectivity.json')) for s in SCANS}
+    rng = np.random.default_rng(0)
+    items = envmod.random_items(graphs, 24, rng)
+    row_of, n = {}, 0
+    for s, g in graphs.items():
+        for v in g.ids:
+            row_of[s + '_' + v] = n
+            n += 1
+    table = rng.random((n, 36, 16), dtype=np.float32)       # small feature dim: host logic only
+    e = envmod.R2RIndexEnv(items, row_of, CONN, batch_size=8, host_table=table)
+    return e, graphs, items
+
+
+def test_panorama_sweep_finds_exactly_the_graph_neighbours(envmod, setup):
+    e, graphs, _ = setup
+    for scan, g in graphs.items():
+        for vp in g.nodes()[:12]:
+            for heading in (0.0, 1.3, 4.0):
+                view, adj = e.panorama(envmod.WorldState(scan, vp, heading, 0))
+                assert 12 <= view < 24                                         # horizon row after reset
+                assert adj[0]['absViewIndex'] == -1 and adj[0]['nextViewpointId'] == vp
+                assert {a['nextViewpointId'] for a in adj[1:]} == set(g.adj[vp])   # full 360 degree sweep
+                hs = [abs(a['rel_heading']) for a in adj[1:]]
+                assert hs == sorted(hs)                                        # env.py:221-222
+                for a in adj[1:]:
+                    assert 0 <= a['absViewIndex'] < 36
+                    assert -math.pi <= a['rel_heading'] <= math.pi
+
+
+def test_panorama_cache_hits(setup, envmod):
+    e, graphs, _ = setup
+    scan = SCANS[0]
+    vp = graphs[scan].nodes()[0]
+    n0 = len(e._pano)
+    a = e.panorama(envmod.WorldState(scan, vp, 0.1, 0))
+    n1 = len(e._pano)
+    b = e.panorama(envmod.WorldState(scan, vp, 0.12, 0))               # same discretised heading
+    assert len(e._pano) == n1 >= n0 and a is b
+
+
+def test_teacher_walk_reaches_every_goal(setup):
+    e, graphs, items = setup
+    e.reset_epoch()
+    path_obs, path_actions, enc = e.gold_obs_actions_and_instructions(10)
+    assert len(path_obs) == 8
+    for po, pa, item in zip(path_obs, path_actions, e.batch):
+        assert len(po) == len(pa) + 1 and pa[-1] == 0                  # ends with stop
+        assert po[0]['viewpoint'] == item['path'][0]
+        assert po[-1]['viewpoint'] == item['path'][-1]
+        g = graphs[item['scan']]
+        walked = sum(g.adj[a['viewpoint']][b['viewpoint']] for a, b in zip(po[:-2], po[1:-1]))
+        assert walked == pytest.approx(g.distance(item['path'][0], item['path'][-1]), rel=1e-6)
+        for ob, a in zip(po, pa):
+            assert ob['teacher'] == a and 0 <= a < len(ob['adj_loc_list'])
+
+
+def test_step_transitions_match_simulator_navigation(setup, envmod):
+    e, graphs, _ = setup
+    ws = e.reset()
+    obs = e.observe(ws)
+    actions = [min(1, len(ob['adj_loc_list']) - 1) for ob in obs]
+    nxt = e.step(ws, actions, obs)
+    for w, a, ob, n in zip(ws, actions, obs, nxt):
+        attr = ob['adj_loc_list'][a]
+        if a == 0:
+            assert n == w
+            continue
+        assert n.viewpointId == attr['nextViewpointId']
+        # replay env.py:126-146 on the simulator: turn to the candidate's view, then move
+        sim = e.sim
+        sim.newEpisode(w.scanId, w.viewpointId, w.heading, w.elevation)
+        st = sim.getState()
+        dh = (attr['absViewIndex'] % 12 - st.viewIndex % 12 + 6) % 12 - 6
+        for _ in range(abs(dh)):
+            sim.makeAction(0, np.sign(dh), 0)
+        de = attr['absViewIndex'] // 12 - st.viewIndex // 12
+        for _ in range(abs(de)):
+            sim.makeAction(0, 0, np.sign(de))
+        st = sim.getState()
+        assert st.viewIndex == attr['absViewIndex']
+        idx = [l.viewpointId for l in st.navigableLocations].index(attr['nextViewpointId'])
+        sim.makeAction(idx, 0, 0)
+        st = sim.getState()
+        assert st.location.viewpointId == n.viewpointId
+        assert st.heading == pytest.approx(n.heading, abs=1e-9)
+        assert st.elevation == pytest.approx(n.elevation, abs=1e-9)
+
+
+def test_gold_index_batch_and_dense_observations_agree(setup):
+    e, graphs, _ = setup
+    e.reset_epoch()
+    fb, path_obs, path_actions = e.gold_index_batch(10)
+    S, B = fb.vp.shape
+    assert B == 8 and S == max(len(a) for a in path_actions)
+    lens = [len(i) for i in fb.instr]
+    assert lens == sorted(lens, reverse=True)
+    for b, (po, pa) in enumerate(zip(path_obs, path_actions)):
+        for t in range(S):
+            ob = po[t] if t < len(pa) else po[len(pa) - 1]
+            assert fb.vp[t, b] == ob['vp_row'] and fb.view[t, b] == ob['viewIndex']
+            assert fb.a_num[t, b] == len(ob['adj_loc_list'])
+            assert fb.target[t, b] == (pa[t] if t < len(pa) else -1)
+            emb = ob['action_embedding']
+            for a in range(1, fb.a_num[t, b]):                         # dense row == indexed row
+                np.testing.assert_array_equal(emb[a, :16], e.host_table[fb.vp[t, b], fb.cand_view[t, b, a]])
+                np.testing.assert_allclose(emb[a, 16], math.sin(fb.cand_heading[t, b, a]), atol=1e-6)
+            assert ob['feature'][0].shape == (36, 16 + 128)
+
+
+def test_minibatching_cycles_through_the_data(setup):
+    e, _, items = setup
+    e.reset_epoch()
+    seen = []
+    for _ in range(3):
+        e.reset()
+        seen += [it['instr_id'] for it in e.batch]
+    assert len(seen) == 24 and len(set(seen)) == 24                    # 24 items, batch 8: one epoch
