@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 1
+#define SF_ABI_VERSION 2
 
 enum {
     SF_OK = 0,
@@ -201,11 +201,14 @@ int sf_visual_attention_bwd(const sf_visual_w* w, const sf_visual_g* g, const sf
 
 /* ---- SoftDotAttention.forward (model.py:122-143) ---------------------------------------------
  * h [B,H] (row stride ldh); ctx [B,L,H]; mask [B,L] uint8 or NULL.  Writes alpha [B,L], h_tilde
- * [B,H] and the saved cat2 = [weighted_ctx ; h] [B,2H], t_text = linear_in(h) [B,H]. */
+ * [B,H] and the saved cat2 = [weighted_ctx ; h] [B,2H], t_text = linear_in(h) [B,H].
+ * ctx_row (int32 [B] or NULL): sample b attends over ctx[ctx_row[b]] / mask[ctx_row[b]] -- the
+ * search procedures' `ctx[beam_indices]` (follower.py:580, 790; speaker.py:252) without the copy.
+ * Forward only: the backward entry points expect ctx_row == NULL in the forward pass. */
 int sf_soft_dot_attention_fwd(const sf_softdot_w* w, int B, int L, int H, const float* h, int ldh,
-                              const float* ctx, const uint8_t* mask, float* h_tilde, float* alpha,
-                              float* cat2, float* t_text, void* ws, size_t ws_bytes,
-                              sf_stream stream);
+                              const float* ctx, const uint8_t* mask, const int32_t* ctx_row,
+                              float* h_tilde, float* alpha, float* cat2, float* t_text, void* ws,
+                              size_t ws_bytes, sf_stream stream);
 /* dh_tilde [B,H] in; dh [B,H] (row stride lddh) overwritten; dctx [B,L,H] ADDED to (NULL = skip). */
 int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, int H,
                               const float* ctx, const float* alpha, const float* cat2,
@@ -264,12 +267,14 @@ int sf_follower_glue_bwd(int B, int A, const float* logit, const int64_t* target
  * Returns h1,c1 (tape->h1, tape->c1), alpha (tape->alpha), logit (tape->logit), alpha_v.
  * With glue != NULL the per-step glue runs fused with the scoring kernel and tape->logit holds
  * the MASKED logits (what sf_follower_glue_bwd wants); otherwise the raw logits.
+ * ctx_row: see sf_soft_dot_attention_fwd (search: many states share one instruction context).
  * Dropout sites: 2*step for the LSTM input, 2*step+1 for h1 (step = `step_id`). */
 int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands* U, int B, int H,
                         int D, int L, const float* u_prev, const float* h0, const float* c0,
-                        const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tape,
-                        const sf_follower_glue* glue, const sf_dropout* drop, uint32_t step_id,
-                        void* ws, size_t ws_bytes, sf_stream stream);
+                        const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
+                        const sf_decoder_tape* tape, const sf_follower_glue* glue,
+                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                        sf_stream stream);
 /* Per-step gradient tape: the "dY" operands of every weight-gradient product of one decoder step.
  * BPTT over S steps keeps them stacked [S][B][..]; sf_attn_decoder_wgrad then forms each weight
  * gradient ONCE with reduction depth S*B instead of S read-modify-write passes over 12 M weights. */
@@ -365,7 +370,7 @@ typedef struct sf_spk_decoder_tape {
 /* SpeakerDecoderLSTM.forward, non-att-feed branch (model.py:514-518).  prev_word [B] int64. */
 int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab,
                            const int64_t* prev_word, const float* h0, const float* c0,
-                           const float* ctx, const uint8_t* ctx_mask,
+                           const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
                            const sf_spk_decoder_tape* tape, const sf_dropout* drop,
                            uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream);
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E,
@@ -382,6 +387,19 @@ int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int
                         float* score, float* nll_term, float* live, sf_stream stream);
 int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int pad_idx, const float* gscale, float* dlogit, sf_stream stream);
+
+/* ---- search helpers (follower.py:541-980 beam / state-factored search, speaker.py:211-318) ------
+ * dst[i, :width] = src[idx[i], :width] (idx < 0 => zeros): `h_t[flat_indices]`, `c_t[flat_indices]`
+ * (follower.py:580, speaker.py:252) as one gather; width, ld_src, ld_dst multiples of 4. */
+int sf_gather_rows(const float* src, int ld_src, const int32_t* idx, int n, int width, float* dst,
+                   int ld_dst, sf_stream stream);
+/* follower.py:585-603 / speaker.py:254-257 on the device: per row of logit [N, ld] (n columns,
+ * n <= 1024): columns >= n_valid[row] are set to -inf in place when n_valid is given
+ * (`logit[is_valid == 0] = -inf`), then log_softmax, then the k best columns in descending order
+ * (ties: lower column first): idx [N,k] int32, logp [N,k] = log_softmax(logit)[row, idx].  k == n
+ * returns the whole row sorted, which is what state_factored_search consumes (follower.py:802). */
+int sf_logprob_topk(float* logit, int ld, int N, int n, const int32_t* n_valid, int k, int32_t* idx,
+                    float* logp, sf_stream stream);
 
 /* Small utilities used by the host mirror (kept on the stream so rollouts never sync). */
 int sf_fill_f32(float* p, size_t n, float v, sf_stream stream);

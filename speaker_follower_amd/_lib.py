@@ -115,8 +115,8 @@ _SIGNATURES = {
                                           c_f, c_f, P(Dropout), u32, i32] + WS),
     'sf_visual_attention_bwd': (C.c_int, [P(VisualW), P(VisualW), P(Pano), i32, i32, i32, c_f, c_f,
                                           c_f, c_f, i32, P(Dropout), u32, i32, c_f] + WS),
-    'sf_soft_dot_attention_fwd': (C.c_int, [P(SoftdotW), i32, i32, i32, c_f, i32, c_f, c_p, c_f,
-                                            c_f, c_f, c_f] + WS),
+    'sf_soft_dot_attention_fwd': (C.c_int, [P(SoftdotW), i32, i32, i32, c_f, i32, c_f, c_p, c_p,
+                                            c_f, c_f, c_f, c_f] + WS),
     'sf_soft_dot_attention_bwd': (C.c_int, [P(SoftdotW), P(SoftdotW), i32, i32, i32, c_f, c_f, c_f,
                                             c_f, c_f, c_f, c_f, i32, c_f] + WS),
     'sf_eltwise_prod_scoring_fwd': (C.c_int, [P(ScoringW), P(Cands), i32, i32, i32, c_f, c_f, c_f,
@@ -124,8 +124,8 @@ _SIGNATURES = {
     'sf_eltwise_prod_scoring_bwd': (C.c_int, [P(ScoringW), P(ScoringW), P(Cands), i32, i32, i32,
                                               c_f, c_f, c_f, c_f, c_f] + WS),
     'sf_attn_decoder_fwd': (C.c_int, [P(DecoderW), P(Pano), P(Cands), i32, i32, i32, i32, c_f, c_f,
-                                      c_f, c_f, c_p, P(DecoderTape), P(FollowerGlue), P(Dropout),
-                                      u32] + WS),
+                                      c_f, c_f, c_p, c_p, P(DecoderTape), P(FollowerGlue),
+                                      P(Dropout), u32] + WS),
     'sf_attn_decoder_bwd': (C.c_int, [P(DecoderW), P(DecoderW), P(Pano), P(Cands), i32, i32, i32,
                                       i32, c_f, c_f, c_f, P(DecoderTape), P(DecoderGTape), c_f, c_f,
                                       c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),
@@ -143,8 +143,10 @@ _SIGNATURES = {
     'sf_gather_panorama': (C.c_int, [P(Pano), i32, c_f, c_p]),
     'sf_gather_candidates': (C.c_int, [P(Cands), i32, c_f, c_f, c_p]),
     'sf_gather_actions': (C.c_int, [P(Cands), i32, c_p, c_f, c_p]),
+    'sf_gather_rows': (C.c_int, [c_f, i32, c_p, i32, i32, c_f, i32, c_p]),
+    'sf_logprob_topk': (C.c_int, [c_f, i32, i32, i32, c_p, i32, c_p, c_f, c_p]),
     'sf_speaker_decoder_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i64p, c_f, c_f,
-                                         c_f, c_p, P(SpkDecoderTape), P(Dropout), u32] + WS),
+                                         c_f, c_p, c_p, P(SpkDecoderTape), P(Dropout), u32] + WS),
     'sf_speaker_decoder_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32,
                                          c_f, c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, c_f,
                                          c_f, P(Dropout), u32] + WS),
@@ -159,6 +161,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
+ABI_VERSION = 2
 
 
 def _load():
@@ -171,7 +174,7 @@ def _load():
         fn = getattr(lib, name)            # AttributeError if the symbol is not exported
         fn.restype = res
         fn.argtypes = args
-    if lib.sf_abi_version() != 1:
+    if lib.sf_abi_version() != ABI_VERSION:
         raise ImportError('libsf_hip.so ABI version mismatch')
     return lib
 

@@ -6,8 +6,8 @@ cross-entropy, action choice, u_prev gather -- runs through the C ABI; the loop,
 book-keeping and the simulator calls stay in Python exactly where the reference has them.
 
 When observations are available in index form, `FollowerEngine` / `SpeakerEngine` are the fast
-path; this module is the drop-in path.  Beam search and state-factored search
-(follower.py:541-980, speaker.py:211-318) are "next" rows of SURVEY.md section 8(f) and raise.
+path; this module is the drop-in path.  Beam search, state-factored search and the speaker's beam search
+(follower.py:541-980, speaker.py:211-318) live in search.py and run on index-form observations.
 """
 import ctypes as C
 import json
@@ -114,6 +114,7 @@ class Seq2SeqAgent(BaseAgent):
         self.loss = 0
         self._sample_seed = torch.initial_seed() & 0xFFFFFFFF
         self._sample_count = 0
+        self.store = None          # features.FeatureStore: enables the index-form search procedures
 
     # ---- tensor assembly (follower.py:291-332): numpy stacks -> device tensors
     def _device(self):
@@ -147,15 +148,23 @@ class Seq2SeqAgent(BaseAgent):
                                                device=self._device())
 
     def rollout(self):
-        if self.beam_size != 1:
-            raise NotImplementedError('beam search is a "next" row (SURVEY.md 8f N3)')
-        return self._rollout_with_loss()
+        if self.beam_size == 1:                                        # follower.py:334-340
+            return self._rollout_with_loss()
+        assert self.beam_size >= 1
+        beams, _, _ = self.beam_search(self.beam_size)
+        return [beam[0] for beam in beams]
 
-    def beam_search(self, *a, **k):
-        raise NotImplementedError('beam_search: SURVEY.md section 8(f) N3 (not built yet)')
+    def beam_search(self, beam_size, load_next_minibatch=True, mask_undo=False):
+        """follower.py:541-718 (search.py; needs `self.store` and index-form observations)."""
+        from . import search
+        return search.beam_search(self, beam_size, load_next_minibatch, mask_undo)
 
-    def state_factored_search(self, *a, **k):
-        raise NotImplementedError('state_factored_search: SURVEY.md section 8(f) N3 (not built yet)')
+    def state_factored_search(self, completion_size, successor_size, load_next_minibatch=True,
+                              mask_undo=False, first_n_ws_key=4):
+        """follower.py:720-980."""
+        from . import search
+        return search.state_factored_search(self, completion_size, successor_size,
+                                            load_next_minibatch, mask_undo, first_n_ws_key)
 
     def set_beam_size(self, beam_size):
         if getattr(self.env, 'beam_size', 1) < beam_size:
@@ -430,8 +439,10 @@ class Seq2SeqSpeaker(object):
         self.losses.append(float(loss.detach()) if torch.is_tensor(loss) else float(loss))
         return outputs
 
-    def beam_search(self, *a, **k):
-        raise NotImplementedError('speaker beam_search: SURVEY.md section 8(f) N3 (not built yet)')
+    def beam_search(self, beam_size, path_obs, path_actions):
+        """speaker.py:211-318 (search.py)."""
+        from . import search
+        return search.speaker_beam_search(self, beam_size, path_obs, path_actions)
 
     def test(self, use_dropout=False, feedback='argmax', allow_cheat=False, beam_size=1):
         if not allow_cheat:

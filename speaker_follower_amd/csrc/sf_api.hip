@@ -171,13 +171,13 @@ int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, i
 // h lives in cat2[:, H:2H] already (copy_from != null copies it there first).
 int softdot_fwd_i(const sf_softdot_w* w, int B, int L, int H, const float* copy_from, int ldh,
                   const float* ctx, const uint8_t* mask, float* h_tilde, float* alpha, float* cat2,
-                  float* t_text, Arena ar, hipStream_t st) {
+                  float* t_text, Arena ar, hipStream_t st, const int32_t* ctx_row = nullptr) {
     if (copy_from) {
         Dropout none = make_dropout(nullptr, 0);
         TRY(dropout_copy(copy_from, ldh, B, H, cat2 + H, 2 * H, none, 0, st));
     }
     TRY(linear_plain(cat2 + H, 2 * H, w->w_in, H, nullptr, B, H, H, EPI_NONE, t_text, H, ar, st));
-    TRY(text_attn_fwd(ctx, mask, B, L, H, t_text, H, alpha, cat2, 2 * H, st));
+    TRY(text_attn_fwd(ctx, mask, B, L, H, t_text, H, alpha, cat2, 2 * H, st, ctx_row));
     return linear_plain(cat2, 2 * H, w->w_out, 2 * H, nullptr, B, H, 2 * H, EPI_TANH, h_tilde, H, ar,
                         st);
 }
@@ -344,13 +344,13 @@ int sf_visual_attention_bwd(const sf_visual_w* w, const sf_visual_g* g, const sf
 }
 
 int sf_soft_dot_attention_fwd(const sf_softdot_w* w, int B, int L, int H, const float* h, int ldh,
-                              const float* ctx, const uint8_t* mask, float* h_tilde, float* alpha,
-                              float* cat2, float* t_text, void* ws, size_t ws_bytes,
-                              sf_stream stream) {
+                              const float* ctx, const uint8_t* mask, const int32_t* ctx_row,
+                              float* h_tilde, float* alpha, float* cat2, float* t_text, void* ws,
+                              size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && h && ctx && h_tilde && alpha && cat2 && t_text && B > 0 && L > 0);
     return softdot_fwd_i(w, B, L, H, h, ldh, ctx, mask, h_tilde, alpha, cat2, t_text,
-                         arena(ws, ws_bytes), S(stream));
+                         arena(ws, ws_bytes), S(stream), ctx_row);
 }
 
 int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, int H,
@@ -385,8 +385,9 @@ int sf_eltwise_prod_scoring_bwd(const sf_scoring_w* w, const sf_scoring_g* g, co
 // ---- a6 AttnDecoderLSTM.forward (model.py:377-397) -------------------------------------------------
 int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands* U, int B, int H,
                         int D, int L, const float* u_prev, const float* h0, const float* c0,
-                        const float* ctx, const uint8_t* ctx_mask, const sf_decoder_tape* tp,
-                        const sf_follower_glue* glue, const sf_dropout* drop, uint32_t step_id,
+                        const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
+                        const sf_decoder_tape* tp, const sf_follower_glue* glue,
+                        const sf_dropout* drop, uint32_t step_id,
                         void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && B > 0 && L > 0 && (!glue || glue_ok(U, glue)));
@@ -405,7 +406,7 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
                    tp->cat2 + H, 2 * H, d_h, ar, st));
     // model.py:395  text attention
     TRY(softdot_fwd_i(&w->text, B, L, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2,
-                      tp->t_text, ar, st));
+                      tp->t_text, ar, st, ctx_row));
     // model.py:396  action logits
     return scoring_fwd_i(&w->action, cands(U), B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt,
                          tp->r, ar, st, glue, w->fold);
@@ -636,12 +637,27 @@ int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf
     return gather_actions(cands(U), B, a, out, S(stream));
 }
 
+// ---- search helpers -----------------------------------------------------------------------
+int sf_gather_rows(const float* src, int ld_src, const int32_t* idx, int n, int width, float* dst,
+                   int ld_dst, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(src && idx && dst && n > 0 && width > 0);
+    return gather_rows(src, ld_src, idx, n, width, dst, ld_dst, S(stream));
+}
+
+int sf_logprob_topk(float* logit, int ld, int N, int n, const int32_t* n_valid, int k, int32_t* idx,
+                    float* logp, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(logit && idx && logp && N > 0 && n > 0 && ld >= n);
+    return logprob_topk(logit, ld, N, n, n_valid, k, idx, logp, S(stream));
+}
+
 // ---- a9 SpeakerDecoderLSTM.forward (model.py:497-519) -----------------------------------------------------
 int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab,
                            const int64_t* prev_word, const float* h0, const float* c0,
-                           const float* ctx, const uint8_t* ctx_mask, const sf_spk_decoder_tape* tp,
-                           const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
-                           sf_stream stream) {
+                           const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
+                           const sf_spk_decoder_tape* tp, const sf_dropout* drop, uint32_t step_id,
+                           void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && prev_word && h0 && c0 && ctx && tp && B > 0 && Tp > 0 && vocab > 0);
     Arena ar = arena(ws, ws_bytes);
@@ -652,7 +668,7 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
     TRY(lstm_fwd_i(&w->lstm, B, E, H, tp->emb, E, h0, c0, tp->h1, tp->c1, tp->gates, tp->cat2 + H,
                    2 * H, d_h, ar, st));                                          // :515-516
     TRY(softdot_fwd_i(&w->attn, B, Tp, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2,
-                      tp->t_text, ar, st));                                       // :517
+                      tp->t_text, ar, st, ctx_row));                              // :517
     if (ldv != vocab) TRY(fill(tp->logit, (size_t)B * ldv, 0.f, st));
     return linear_plain(tp->h_tilde, H, w->w_out, H, w->b_out, B, vocab, H, EPI_NONE, tp->logit, ldv,
                         ar, st);                                                  // :518

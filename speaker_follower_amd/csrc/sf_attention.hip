@@ -138,6 +138,7 @@ struct TxtArgs {
     float* out;            // fwd: wc [B, ldo]; bwd: dt [B, ldo]
     int ldo;
     float* dctx;           // bwd, accumulated; may be null
+    const int32_t* ctx_row;  // fwd: sample b attends over ctx / mask row ctx_row[b] (null = b)
 };
 
 template <int RPW, int MODE>
@@ -147,7 +148,8 @@ __global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = a.L, n4 = a.H >> 2;
-    const float4* ctx = reinterpret_cast<const float4*>(a.ctx) + (size_t)b * L * n4;
+    const int bc = a.ctx_row ? a.ctx_row[b] : b;
+    const float4* ctx = reinterpret_cast<const float4*>(a.ctx) + (size_t)bc * L * n4;
 
     float4 x[RPW][TXT_CPL];
 #pragma unroll
@@ -176,7 +178,7 @@ __global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
         d = wave_sum(d);
         const int l = wave * RPW + r;
         if (lane == 0 && l < L) {
-            if (MODE == 0 && a.mask && a.mask[(size_t)b * L + l]) d = -INFINITY;
+            if (MODE == 0 && a.mask && a.mask[(size_t)bc * L + l]) d = -INFINITY;
             s_score[l] = d;
         }
     }
@@ -379,9 +381,10 @@ static int text_attn_launch(const TxtArgs& a, int B, hipStream_t st) {
 }
 
 int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t,
-                  int ldt, float* alpha, float* wc, int ldwc, hipStream_t st) {
+                  int ldt, float* alpha, float* wc, int ldwc, hipStream_t st,
+                  const int32_t* ctx_row) {
     if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (ldwc & 3) || L < 1) return SF_ERR_UNSUPPORTED;
-    TxtArgs a{ctx, mask, L, H, t, ldt, nullptr, 0, alpha, wc, ldwc, nullptr};
+    TxtArgs a{ctx, mask, L, H, t, ldt, nullptr, 0, alpha, wc, ldwc, nullptr, ctx_row};
     return text_attn_launch<0>(a, B, st);
 }
 
@@ -390,7 +393,7 @@ int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int l
                   hipStream_t st) {
     if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (lddwc & 3) || (lddt & 3) || L < 1)
         return SF_ERR_UNSUPPORTED;
-    TxtArgs a{ctx, nullptr, L, H, dwc, lddwc, t, ldt, const_cast<float*>(alpha), dt, lddt, dctx};
+    TxtArgs a{ctx, nullptr, L, H, dwc, lddwc, t, ldt, const_cast<float*>(alpha), dt, lddt, dctx, nullptr};
     return text_attn_launch<1>(a, B, st);
 }
 

@@ -11,7 +11,8 @@ namespace sf {
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
                 float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st);
 int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t,
-                  int ldt, float* alpha, float* wc, int ldwc, hipStream_t st);
+                  int ldt, float* alpha, float* wc, int ldwc, hipStream_t st,
+                  const int32_t* ctx_row = nullptr);
 int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc,
                   const float* t, int ldt, const float* alpha, float* dt, int lddt, float* dctx,
                   hipStream_t st);
@@ -71,6 +72,11 @@ int ctx_grad_slice(const float* dctx, int T, int H, int B, int t, const Dropout&
 int gather_panorama(const PanoSrc& s, int B, float* out, hipStream_t st);
 int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hipStream_t st);
 int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st);
+
+int gather_rows(const float* src, int lds, const int* idx, int n, int w, float* dst, int ldd,
+                hipStream_t st);
+int logprob_topk(float* logit, int ld, int N, int n, const int* n_valid, int k, int* idx,
+                 float* logp, hipStream_t st);
 
 struct FGlue;
 int follower_glue_fwd(const FGlue& g, hipStream_t st);

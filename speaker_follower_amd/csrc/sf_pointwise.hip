@@ -247,6 +247,100 @@ __global__ __launch_bounds__(TPB) void gather_action_kernel(CandSrc s, int B, co
     }
 }
 
+// ---- search helpers (follower.py:541-980, speaker.py:211-318) ---------------------------------------
+// dst[i, :w] = src[idx[i], :w]  (idx < 0 => zeros): `h_t[flat_indices]`, `c_t[flat_indices]`
+__global__ __launch_bounds__(TPB) void gather_rows_kernel(const float* src, int lds, const int* idx,
+                                                          int n, int w, float* dst, int ldd) {
+    const int w4 = w >> 2;
+    const size_t total = (size_t)n * w4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % w4), r = (int)(i / w4);
+        const int s = idx[r];
+        float4 v = f4zero();
+        if (s >= 0) v = reinterpret_cast<const float4*>(src + (size_t)s * lds)[c];
+        reinterpret_cast<float4*>(dst + (size_t)r * ldd)[c] = v;
+    }
+}
+
+// Masked log-softmax + the k best columns of every row in descending order (ties: lower column
+// first).  One block per row, up to TOPK_E * TPB columns, k rounds of a block-wide arg-max.
+constexpr int TOPK_E = 4;
+__global__ __launch_bounds__(TPB) void logprob_topk_kernel(float* logit, int ld, int n,
+                                                           const int* n_valid, int k, int* idx,
+                                                           float* logp) {
+    __shared__ float s_v[TPB / 64];
+    __shared__ int s_i[TPB / 64];
+    __shared__ float s_red[TPB / 64];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float* x = logit + (size_t)row * ld;
+    const int nv = n_valid ? min(n_valid[row], n) : n;
+    float v[TOPK_E];
+    float m = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < TOPK_E; ++e) {
+        const int c = tid + TPB * e;
+        v[e] = c < nv ? x[c] : -INFINITY;
+        if (n_valid && c >= nv && c < n) x[c] = -INFINITY;        // follower.py:585 logit[is_valid == 0] = -inf
+        m = fmaxf(m, v[e]);
+    }
+    m = wave_max(m);
+    if (lane == 0) s_red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+    __syncthreads();
+    float se = 0.f;
+#pragma unroll
+    for (int e = 0; e < TOPK_E; ++e) se += (tid + TPB * e < nv) ? expf(v[e] - m) : 0.f;
+    se = wave_sum(se);
+    if (lane == 0) s_red[wave] = se;
+    __syncthreads();
+    const float lse = logf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+    unsigned taken = 0;
+    for (int r = 0; r < k; ++r) {
+        float bv = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int e = 0; e < TOPK_E; ++e) {
+            const int c = tid + TPB * e;
+            if (c < n && !((taken >> e) & 1u) && (v[e] > bv || bi == 0x7fffffff)) {
+                bv = v[e];
+                bi = c;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ov = __shfl_xor(bv, off, WAVE);
+            const int oi = __shfl_xor(bi, off, WAVE);
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        __syncthreads();
+        if (lane == 0) {
+            s_v[wave] = bv;
+            s_i[wave] = bi;
+        }
+        __syncthreads();
+        bv = s_v[0];
+        bi = s_i[0];
+#pragma unroll
+        for (int w = 1; w < TPB / 64; ++w) {
+            const float ov = s_v[w];
+            const int oi = s_i[w];
+            if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (bi != 0x7fffffff && (bi % TPB) == tid) taken |= 1u << (bi / TPB);
+        if (tid == 0) {
+            idx[(size_t)row * k + r] = bi == 0x7fffffff ? -1 : bi;
+            logp[(size_t)row * k + r] = bi == 0x7fffffff ? -INFINITY : (bv - m) - lse;
+        }
+    }
+}
+
 // ---- follower per-step glue (follower.py:476-505): one wave per sample -----------------------------
 __global__ __launch_bounds__(TPB) void follower_glue_kernel(FGlue g) {
     const int lane = threadIdx.x & 63;
@@ -463,6 +557,20 @@ int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hi
 int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st) {
     hipLaunchKernelGGL(gather_action_kernel, dim3(grid1d((size_t)B * ((s.IMG + s.LOC) >> 2))),
                        dim3(TPB), 0, st, s, B, a, out);
+    return launch_status();
+}
+int gather_rows(const float* src, int lds, const int* idx, int n, int w, float* dst, int ldd,
+                hipStream_t st) {
+    if ((w & 3) || (lds & 3) || (ldd & 3)) return SF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d((size_t)n * (w >> 2))), dim3(TPB), 0, st, src,
+                       lds, idx, n, w, dst, ldd);
+    return launch_status();
+}
+int logprob_topk(float* logit, int ld, int N, int n, const int* n_valid, int k, int* idx,
+                 float* logp, hipStream_t st) {
+    if (n > TOPK_E * TPB || k < 1 || k > n) return SF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(logprob_topk_kernel, dim3(N), dim3(TPB), 0, st, logit, ld, n, n_valid, k, idx,
+                       logp);
     return launch_status();
 }
 int follower_glue_fwd(const FGlue& g, hipStream_t st) {

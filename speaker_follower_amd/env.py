@@ -173,9 +173,17 @@ class R2RIndexEnv:
         self.ix = 0
 
     def reset(self, sort=False, beamed=False, load_next_minibatch=True):
+        """env.py:814-819 / :601-614.  beamed: one list of world states per instance (the search
+        procedures' interface)."""
         if load_next_minibatch:
             self._next_minibatch(sort)
-        return [WorldState(it['scan'], it['path'][0], it['heading'], 0) for it in self.batch]
+        ws = [WorldState(it['scan'], it['path'][0], it['heading'], 0) for it in self.batch]
+        return [[w] for w in ws] if beamed else ws
+
+    def set_beam_size(self, beam_size, force_reload=False):
+        """env.py:700-709.  The reference keeps batch x beam simulators; here ONE simulator and
+        the sweep cache serve any number of states, so this only records the size."""
+        self.beam_size = beam_size
 
     # ---- cached panorama sweep
     def panorama(self, ws):
@@ -198,21 +206,25 @@ class R2RIndexEnv:
 
     def observe(self, world_states, beamed=False, include_teacher=True, dense=None):
         dense = (self.host_table is not None) if dense is None else dense
-        obs = []
-        for ws, item in zip(world_states, self.batch):
-            view, adj = self.panorama(ws)
-            ob = dict(instr_id=item['instr_id'], scan=ws.scanId, viewpoint=ws.viewpointId,
-                      viewIndex=view, heading=ws.heading, elevation=ws.elevation,
-                      adj_loc_list=adj, vp_row=self.row_of[ws.scanId + '_' + ws.viewpointId],
-                      instr_encoding=item['instr_encoding'], instructions=item.get('instructions', ''))
-            if include_teacher:
-                ob['teacher'] = self._teacher(ws, adj, item['path'][-1])
-            if dense:
-                feats = self.host_table[ob['vp_row']]
-                ob['feature'] = [np.concatenate((feats, self.loc_table[view]), axis=-1)]      # env.py:773
-                ob['action_embedding'] = self._action_embedding(adj, feats)                   # env.py:774
-            obs.append(ob)
-        return obs
+        if beamed:                                                            # env.py:766-799, nested
+            return [[self._observe_one(ws, item, include_teacher, dense) for ws in beam]
+                    for beam, item in zip(world_states, self.batch)]
+        return [self._observe_one(ws, item, include_teacher, dense)
+                for ws, item in zip(world_states, self.batch)]
+
+    def _observe_one(self, ws, item, include_teacher, dense):
+        view, adj = self.panorama(ws)
+        ob = dict(instr_id=item['instr_id'], scan=ws.scanId, viewpoint=ws.viewpointId,
+                  viewIndex=view, heading=ws.heading, elevation=ws.elevation,
+                  adj_loc_list=adj, vp_row=self.row_of[ws.scanId + '_' + ws.viewpointId],
+                  instr_encoding=item['instr_encoding'], instructions=item.get('instructions', ''))
+        if include_teacher:
+            ob['teacher'] = self._teacher(ws, adj, item['path'][-1])
+        if dense:
+            feats = self.host_table[ob['vp_row']]
+            ob['feature'] = [np.concatenate((feats, self.loc_table[view]), axis=-1)]      # env.py:773
+            ob['action_embedding'] = self._action_embedding(adj, feats)                   # env.py:774
+        return ob
 
     def _action_embedding(self, adj, feats):
         g = self.loc // 4
@@ -229,16 +241,19 @@ class R2RIndexEnv:
     def step(self, world_states, actions, last_obs, beamed=False):
         """env.py:628-641 + :126-146: turning to the candidate's view and stepping leaves the agent at
         the neighbour, facing that view's heading / elevation; action 0 stays."""
-        out = []
-        for ws, a, ob in zip(world_states, actions, last_obs):
-            attr = ob['adj_loc_list'][int(a)]
-            if int(a) == 0 or attr['nextViewpointId'] == ws.viewpointId:
-                out.append(ws)
-                continue
-            v = attr['absViewIndex']
-            out.append(WorldState(ws.scanId, attr['nextViewpointId'], (v % 12) * ANGLE_INC,
-                                  (v // 12 - 1) * ANGLE_INC))
-        return out
+        if beamed:
+            return [[self._step_one(ws, a, ob) for ws, a, ob in zip(wl, al, ol)]
+                    for wl, al, ol in zip(world_states, actions, last_obs)]
+        return [self._step_one(ws, a, ob) for ws, a, ob in zip(world_states, actions, last_obs)]
+
+    @staticmethod
+    def _step_one(ws, a, ob):
+        attr = ob['adj_loc_list'][int(a)]
+        if int(a) == 0 or attr['nextViewpointId'] == ws.viewpointId:
+            return ws
+        v = attr['absViewIndex']
+        return WorldState(ws.scanId, attr['nextViewpointId'], (v % 12) * ANGLE_INC,
+                          (v // 12 - 1) * ANGLE_INC)
 
     def shortest_paths_to_goals(self, starting_world_states, max_steps):
         """env.py:823-848."""

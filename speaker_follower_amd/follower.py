@@ -209,7 +209,7 @@ class FollowerEngine:
                 st.ce_term[t].data_ptr(), st.live[t].data_ptr(),
                 int(st.drop_dec[1]) ^ 0x1B873593, st.site0 + t, batch.row0)
             call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T, None,
-                 ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), byref(tp), byref(glue), d_ptr,
+                 ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue), d_ptr,
                  st.site0 + t, *ws)
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         st.logits = st.tape['logit']

@@ -400,7 +400,8 @@ class _DecoderStepFn(torch.autograd.Function):
         pano, cnd = pano_dense(X), cands_dense(all_u)
         p, seed, site = drop_cfg
         call('sf_attn_decoder_fwd', byref(w), byref(pano), byref(cnd), B, H, D, L, ptr(u_prev),
-             ptr(h0), ptr(c0), ptr(context), ptr(mask), byref(tp), None, dropout_arg(p, seed), site,
+             ptr(h0), ptr(c0), ptr(context), ptr(mask), None, byref(tp), None, dropout_arg(p, seed),
+             site,
              *ws_args(X.device))
         ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, H, D, L, drop_cfg)
         ctx.save_for_backward(all_u, X, h0, c0, context)
@@ -586,7 +587,8 @@ class _SpeakerDecoderFn(torch.autograd.Function):
         w = mod._w_struct()
         p, seed, site = drop_cfg
         call('sf_speaker_decoder_fwd', byref(w), B, E, H, Tp, vocab, ptr(prev_word), ptr(h0),
-             ptr(c0), ptr(context), ptr(mask), byref(tp), dropout_arg(p, seed), site, *ws_args(dev))
+             ptr(c0), ptr(context), ptr(mask), None, byref(tp), dropout_arg(p, seed), site,
+             *ws_args(dev))
         ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, E, H, Tp, vocab, ldv, drop_cfg)
         ctx.save_for_backward(h0, c0, context)
         ctx.mark_non_differentiable(tape['alpha'])

@@ -111,7 +111,8 @@ def soft_dot_attention_fwd(w2, h, ctx, mask):
     t_text = torch.empty(B, H, device=dev, dtype=torch.float32)
     m = mask_u8(mask)
     ws = struct_of(_lib.SoftdotW, w2)
-    call('sf_soft_dot_attention_fwd', byref(ws), B, L, H, ptr(h), H, ptr(ctx), ptr(m), ptr(h_tilde),
+    call('sf_soft_dot_attention_fwd', byref(ws), B, L, H, ptr(h), H, ptr(ctx), ptr(m), None,
+         ptr(h_tilde),
          ptr(alpha), ptr(cat2), ptr(t_text), *ws_args(dev))
     return h_tilde, alpha, cat2, t_text
 

@@ -155,7 +155,8 @@ class SpeakerEngine:
             h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
             c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
             call('sf_speaker_decoder_fwd', byref(dw), B, E, H, Tp, vocab, ptr(st.words[t]), ptr(h0),
-                 ptr(c0), ptr(st.ctx), ptr(batch.path_mask), byref(tp), d_dec, st.site0 + t, *ws)
+                 ptr(c0), ptr(st.ctx), ptr(batch.path_mask), None, byref(tp), d_dec, st.site0 + t,
+                 *ws)
             call('sf_speaker_glue_fwd', B, vocab, ldv, ptr(st.tape['logit'][t]),
                  ptr(st.targets[t]), st.feedback, PAD, EOS, ptr(st.ended),
                  ptr(st.words[t + 1]), ptr(st.step_scores[t]), ptr(st.nll_term[t]),

@@ -1,0 +1,97 @@
+"""CPU: host logic of the search procedures (no compute calls) and the beamed env interface."""
+import json
+import os
+import sys
+from collections import namedtuple
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import search_world as W          # noqa: E402
+
+WS = namedtuple('WS', 'scanId viewpointId heading elevation')
+
+
+def _chain(search, vps, scores):
+    s = None
+    for i, (v, sc) in enumerate(zip(vps, scores)):
+        s = search.InferenceState(s, WS('s', v, 0.0, 0.0), dict(viewpoint=v, heading=0.0, elevation=0.0),
+                                  None, -1 if i == 0 else 1, None, i, sc, i, i, None if i == 0 else i)
+    return s
+
+
+def test_backchain_and_common_viewpoint_path():
+    from speaker_follower_amd import search
+    a = _chain(search, ['r', 'x', 'a1', 'a2'], [0.0, -1.0, -1.5, -2.25])
+    states, obs, actions, scores, att = search.backchain_inference_states(a)
+    assert [s.viewpointId for s in states] == ['r', 'x', 'a1', 'a2']
+    assert actions == [1, 1, 1] and att == [1, 2, 3]
+    np.testing.assert_allclose(scores, [-1.0, -0.5, -0.75])
+    # b shares the prefix r, x: walking a -> b goes back to x and forward to b
+    b_parent = a.prev_inference_state.prev_inference_state                      # the 'x' state
+    b = search.InferenceState(b_parent, WS('s', 'b1', 0, 0), dict(viewpoint='b1'), None, 2, None, 2,
+                              -3.0, 9, 9, 9)
+    path = search.least_common_viewpoint_path(a, b)
+    assert [s.world_state.viewpointId for s in path] == ['a2', 'a1', 'x', 'b1']
+
+
+def test_scores_accumulate_in_float32_like_the_reference():
+    from speaker_follower_amd import search
+    s = 0.0
+    for v in (np.float32(-0.1), np.float32(-0.2), np.float32(-0.7)):
+        s = search._add_f32(s, v)
+    want = np.float32(np.float32(np.float32(0) + np.float32(-0.1)) + np.float32(-0.2)) + np.float32(-0.7)
+    assert s == float(want)
+
+
+def test_rational_mix_standardises_and_picks():
+    from speaker_follower_amd import search
+    cands = {'a': [dict(follower_score=-1.0, speaker_score=-30.0), dict(follower_score=-2.0, speaker_score=-10.0)],
+             'b': [dict(follower_score=-0.5, speaker_score=-20.0), dict(follower_score=-3.0, speaker_score=-21.0)]}
+    res0, cnt0 = search.rational_mix(cands, 0.0)
+    assert res0['a'] is cands['a'][0] and res0['b'] is cands['b'][0] and cnt0[0] == 2
+    res1, cnt1 = search.rational_mix(cands, 0.95)
+    assert res1['a'] is cands['a'][1] and res1['b'] is cands['b'][0]
+    assert cnt1[1] == 1 and cnt1[0] == 1
+
+
+def test_env_beamed_interface_matches_flat_interface():
+    env, _ = W.build_world(dense=False)
+    env.set_beam_size(3)
+    assert env.beam_size == 3
+    ws_b = env.reset(sort=True, beamed=True)
+    ws = env.reset(sort=True, load_next_minibatch=False)
+    assert [[w] for w in ws] == ws_b
+    obs_b = env.observe(ws_b, beamed=True)
+    obs = env.observe(ws)
+    assert [o[0]['viewpoint'] for o in obs_b] == [o['viewpoint'] for o in obs]
+    # two hypotheses per instance: stop, and the first neighbour
+    beams = [[w, w] for w in ws]
+    last = [[o, o] for o in obs]
+    nxt = env.step(beams, [[0, 1]] * len(ws), last, beamed=True)
+    for (stay, move), o, w in zip(nxt, obs, ws):
+        assert stay == w
+        assert move.viewpointId == o['adj_loc_list'][1]['nextViewpointId']
+    flat = env.step(ws, [1] * len(ws), obs)
+    assert flat == [m for _, m in nxt]
+
+
+def test_golden_search_file_is_consistent():
+    """Every reference candidate's score is the float32 sum of its per-step scores and ends with the
+    stop action or at the episode limit (follower.py:663-666)."""
+    with open(os.path.join(HERE, 'golden', 'g7_search.json')) as f:
+        g = json.load(f)
+    T = g['config']['episode_len']
+    n = 0
+    for beam, res in g['beam'].items():
+        assert len(res) == g['config']['n_items']
+        for cands in res:
+            assert 1 <= len(cands) <= int(beam)
+            assert all(a['score'] >= b['score'] for a, b in zip(cands, cands[1:]))
+            for c in cands:
+                assert c['actions'][-1] == 0 or len(c['actions']) == T
+                assert len(c['viewpoints']) == len(c['actions']) + 1
+                np.testing.assert_allclose(sum(c['scores']), c['score'], rtol=1e-5, atol=1e-5)
+                n += 1
+    assert n > 50
