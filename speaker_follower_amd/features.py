@@ -10,6 +10,7 @@ fp32 tensor that lives in HBM (3.1 GB for the full R2R set; 288 GB available) pl
 import base64
 import csv
 import ctypes as C
+import json
 import sys
 
 import numpy as np
@@ -51,6 +52,24 @@ def cand_sincos(rel_heading, rel_elevation):
     return np.stack((np.sin(h), np.cos(h), np.sin(e), np.cos(e)), axis=-1).astype(np.float32)
 
 
+def tsv_to_bin(tsv_path, bin_path):
+    """One-shot converter (N4): the reference's ResNet TSV -> flat little-endian fp32 file
+    [n][36][2048] + '<bin>.json' {ids, shape}.  Streams row by row (the full table is 3.1 GB)."""
+    csv.field_size_limit(sys.maxsize)
+    names = ['scanId', 'viewpointId', 'image_w', 'image_h', 'vfov', 'features']
+    ids = []
+    with open(tsv_path, 'rt') as f, open(bin_path, 'wb') as out:
+        for item in csv.DictReader(f, delimiter='\t', fieldnames=names):
+            buf = base64.b64decode(item['features'])
+            if len(buf) != NUM_VIEWS * MEAN_POOLED_DIM * 4:
+                raise ValueError('row %s_%s: %d feature bytes' % (item['scanId'], item['viewpointId'], len(buf)))
+            out.write(buf)
+            ids.append(item['scanId'] + '_' + item['viewpointId'])
+    with open(bin_path + '.json', 'w') as f:
+        json.dump({'ids': ids, 'shape': [len(ids), NUM_VIEWS, MEAN_POOLED_DIM]}, f)
+    return len(ids)
+
+
 class FeatureStore:
     """The feature table in HBM + viewpoint-id index."""
 
@@ -78,6 +97,21 @@ class FeatureStore:
                 buf = base64.b64decode(item['features'])
                 rows.append(np.frombuffer(buf, np.float32).reshape(NUM_VIEWS, MEAN_POOLED_DIM))
         return cls(np.stack(rows), ids, device)
+
+    @classmethod
+    def from_bin(cls, path, device='cuda', chunk_rows=512):
+        """Flat table written by `tsv_to_bin` (path + '.json' holds the ids and shape): the file is
+        memory-mapped and uploaded in chunks straight into ONE preallocated HBM tensor, so start-up
+        costs a sequential read instead of minutes of TSV / base64 parsing."""
+        with open(path + '.json') as f:
+            meta = json.load(f)
+        n, V, IMG = meta['shape']
+        mm = np.memmap(path, dtype=np.float32, mode='r', shape=(n, V, IMG))
+        table = torch.empty(n, V, IMG, dtype=torch.float32, device=device)
+        for r0 in range(0, n, chunk_rows):
+            r1 = min(n, r0 + chunk_rows)
+            table[r0:r1].copy_(torch.from_numpy(np.array(mm[r0:r1])))
+        return cls(table, meta['ids'], device)
 
     def row(self, scan_id, viewpoint_id):
         return self.index[scan_id + '_' + viewpoint_id]

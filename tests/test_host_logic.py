@@ -156,3 +156,53 @@ def test_feature_store_reads_reference_tsv_format(tmp_path):
     for (scan, vp), feat in rows.items():
         np.testing.assert_array_equal(store.table[store.row(scan, vp)].numpy(), feat)
     assert store.loc_table.shape == (36, 36, 128)
+
+
+def test_tsv_to_bin_round_trip(tmp_path):
+    """N4: TSV -> flat .bin + id index -> FeatureStore, bit-exact with the TSV reader."""
+    import base64
+    from speaker_follower_amd.features import FeatureStore, tsv_to_bin
+    rng = np.random.default_rng(6)
+    feats = [rng.random((36, 2048), dtype=np.float32) for _ in range(5)]
+    tsv = tmp_path / 'f.tsv'
+    with open(tsv, 'wt') as f:
+        for i, feat in enumerate(feats):
+            f.write('\t'.join(['scan%d' % (i % 2), 'v%d' % i, '640', '480', '60',
+                               base64.b64encode(feat.tobytes()).decode()]) + '\n')
+    assert tsv_to_bin(str(tsv), str(tmp_path / 'f.bin')) == 5
+    assert os.path.getsize(tmp_path / 'f.bin') == 5 * 36 * 2048 * 4
+    a = FeatureStore.from_tsv(str(tsv), device='cpu')
+    b = FeatureStore.from_bin(str(tmp_path / 'f.bin'), device='cpu', chunk_rows=2)
+    assert a.index == b.index
+    assert torch.equal(a.table, b.table)
+    bad = tmp_path / 'bad.tsv'
+    with open(bad, 'wt') as f:
+        f.write('\t'.join(['s', 'v', '640', '480', '60', base64.b64encode(b'1234').decode()]) + '\n')
+    with pytest.raises(ValueError):
+        tsv_to_bin(str(bad), str(tmp_path / 'bad.bin'))
+
+
+def test_checkpoint_files_and_result_json_follow_the_reference_layout(tmp_path):
+    """N4: `<prefix>_enc` / `<prefix>_dec` torch.save(state_dict) pairs (follower.py:1022-1035) and
+    the result file {instr_id: {instr_id, trajectory}} (follower.py:117-125) that eval.py reads."""
+    import json
+    from speaker_follower_amd import model, agents, synth
+    d = synth.SMALL
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5)
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    agent = agents.Seq2SeqAgent(None, str(tmp_path / 'res.json'), enc, dec)
+    agent.save(str(tmp_path / 'snap'))
+    assert os.path.exists(tmp_path / 'snap_enc') and os.path.exists(tmp_path / 'snap_dec')
+    sd = torch.load(tmp_path / 'snap_dec')
+    assert set(sd) == set(dec.state_dict()) and 'lstm.weight_ih' in sd
+    enc2 = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5)
+    dec2 = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    agent2 = agents.Seq2SeqAgent(None, '', enc2, dec2)
+    agent2.load(str(tmp_path / 'snap'), map_location='cpu')
+    for (k, a), (_, b) in zip(dec.state_dict().items(), dec2.state_dict().items()):
+        assert torch.equal(a, b), k
+    agent.results = {'7_0': dict(instr_id='7_0', trajectory=[('vp', 0.0, 0.0)], score=-1.0,
+                                 observations=['not serialisable' for _ in range(2)])}
+    agent.write_results()
+    out = json.load(open(tmp_path / 'res.json'))
+    assert out == {'7_0': {'instr_id': '7_0', 'trajectory': [['vp', 0.0, 0.0]]}}
