@@ -238,10 +238,13 @@ def _u_descriptor(ob, action):
     return (ob['vp_row'], d['absViewIndex'], d['rel_heading'], d['rel_elevation'])
 
 
-def _require_index_form(agent, obs0):
+def _require_store(agent):
     if getattr(agent, 'store', None) is None:
         raise RuntimeError('search runs on index-form observations: give the agent a '
                            'features.FeatureStore (agent.store)')
+
+
+def _require_index_form(agent, obs0):
     if 'vp_row' not in obs0:
         raise RuntimeError("search needs observations with 'vp_row' (env.R2RIndexEnv)")
 
@@ -283,6 +286,7 @@ def _trajs(fd, completed_lists):
 def beam_search(agent, beam_size, load_next_minibatch=True, mask_undo=False):
     """follower.py:541-718.  Returns (trajs, completed, traversed_lists=None)."""
     env = agent.env
+    _require_store(agent)
     assert env.beam_size >= beam_size
     world_states = env.reset(sort=True, beamed=True, load_next_minibatch=load_next_minibatch)
     obs = env.observe(world_states, beamed=True)
@@ -362,6 +366,7 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
                           mask_undo=False, first_n_ws_key=4):
     """follower.py:720-980.  Returns (trajs, completed_list, traversed_lists)."""
     env = agent.env
+    _require_store(agent)
     assert env.beam_size >= successor_size
     world_states = env.reset(sort=True, beamed=True, load_next_minibatch=load_next_minibatch)
     initial_obs = env.observe(world_states, beamed=True)

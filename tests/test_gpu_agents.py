@@ -70,7 +70,7 @@ def test_agent_test_loop_and_results(setup, tmp_path):
     agent.write_results()
     agent.save(str(tmp_path / 'snap'))
     agent.load(str(tmp_path / 'snap'))
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match='index-form'):         # dictionary env, no FeatureStore
         agent.beam_search(2)
 
 
