@@ -29,6 +29,11 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
 }
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4nt(const float* p) {   // streaming load: do not keep in L2
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f v = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
 __device__ __forceinline__ float comp(const float4& v, int c) {
     return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
 }
@@ -192,25 +197,33 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(NtArgs a) {
 // 68 dwords: 16 rows x 4 banks tile the 64 banks exactly).
 // grid (N/64, ksplit), block 256; a block's stages lie inside one K segment each (K_s % 64 == 0).
 // ------------------------------------------------------------------------------------------------
-// Row stride 72 dwords: conflict-free for the ds_read_b128 lane groups of gfx950 ({0-3,12-15,20-27},
-// ...: MI355X_MICROARCH.md, LDS table).  68 gave a 2-way conflict in every group
-// (SQ_LDS_BANK_CONFLICT = 35 % of SQ_LDS_IDX_ACTIVE).
-constexpr int TBK = 64, TLD = TBK + 8;
+#ifndef SF_LAB_TLD
+#define SF_LAB_TLD (TBK + 4)
+#endif
+constexpr int TBK = 64, TLD = SF_LAB_TLD;
 
 // 8 waves per block: waves 0-3 take the first half of every 64-deep stage, waves 4-7 the second
 // half (two waves per SIMD hide each other's barrier and LDS latencies); the halves meet in LDS.
+#ifdef SF_LAB_STAMP
+__device__ long long g_lab_stamps[256][32];
+#define LAB_STAMP(i) do { if (threadIdx.x == 0) g_lab_stamps[blockIdx.x + gridDim.x * blockIdx.y][i] = wall_clock64(); } while (0)
+#else
+#define LAB_STAMP(i) do {} while (0)
+#endif
+
 template <int MT>
 __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    LAB_STAMP(0);
     constexpr int AROWS = MT * 16, WROWS = 64;
     constexpr int BUF = (AROWS + WROWS) * TLD;           // floats per stage buffer
     constexpr int APASS = (MT + 1) / 2;                  // 32 rows x 16 float4 per staging pass
     const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
     const int wave = wave8 & 3, khalf = wave8 >> 2;
     const int li = lane & 15, kk = lane >> 4;
-    // XCD-aware tile map: consecutive workgroup ids go round-robin to the 8 XCDs (each with its own
-    // L2).  Give every XCD a contiguous range of (split, n-tile) pairs, so that its L2 only ever
-    // holds ITS k-slices of the activation operand (M x K/8) instead of all of A.
+#ifdef SF_LAB_XCD
+    // XCD-aware tile map: consecutive workgroup ids go round-robin to the 8 XCDs; give every XCD
+    // a contiguous range of (split, n-tile) pairs so that its L2 only ever sees ITS k-slice of A.
     int n0, split;
     {
         const int total = gridDim.x * gridDim.y;
@@ -220,6 +233,10 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
         split = g / (int)gridDim.x;
         n0 = (g % (int)gridDim.x) * 64;
     }
+#else
+    const int n0 = blockIdx.x * 64;
+    const int split = blockIdx.y;
+#endif
     const int ldrow = tid >> 4, ldc4 = tid & 15;         // staging: 32 rows x 16 float4 per pass
 
     // stage range of this split (stages of 64 k over the concatenated segments)
@@ -250,16 +267,24 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
             A = a.seg[2].A; W = a.seg[2].W; lda = a.seg[2].lda; ldw = a.seg[2].ldw;
             k0 = (s - st0n - st1n) * TBK;
         }
+#ifndef SF_LAB_NO_ALOAD
 #pragma unroll
         for (int p = 0; p < APASS; ++p) {
             const int row = min(p * 32 + ldrow, a.M - 1);
             r.a[p] = ld4(A + (size_t)row * lda + k0 + 4 * ldc4);
         }
+#endif
+#ifndef SF_LAB_NO_WLOAD
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
             const int row = min(n0 + p * 32 + ldrow, a.N - 1);
+#ifdef SF_LAB_NT
+            r.w[p] = ld4nt(W + (size_t)row * ldw + k0 + 4 * ldc4);
+#else
             r.w[p] = ld4(W + (size_t)row * ldw + k0 + 4 * ldc4);
+#endif
         }
+#endif
     };
     auto lstore = [&](const Regs& r, int buf) {
         float* As = smem + buf * BUF;
@@ -284,12 +309,130 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
             for (int t = 0; t < MT; ++t)
                 av[t] = *reinterpret_cast<const float4*>(As + (t * 16 + li) * TLD + 16 * c + 4 * kk);
 #pragma unroll
+#ifdef SF_LAB_NO_MFMA
+            for (int t = 0; t < MT; ++t) acc[t][0] += av[t].x * b.x + av[t].w * b.w;
+#else
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(av[t], j), comp(b, j), acc[t]);
+#endif
         }
     };
 
+#ifdef SF_LAB_PIPE
+    // Software-pipelined main loop.  A stage's 64 k are two 16-k chunks per wave (fragments F0,
+    // F1 in registers).  Per stage: read F1; MFMAs of F0 with the LDS stores of the NEXT stage
+    // interleaved; ONE barrier in the middle of the stage; read the next stage's F0; MFMAs of F1.
+    // Store, barrier and first-read latencies all sit under MFMA work instead of between stages
+    // (timestamps: 1.25 us of every 2.15 us stage were LDS store -> barrier -> read, pipe idle).
+    struct Fr {
+        float4 b;
+        float4 a[MT];
+    };
+    auto rfrag = [&](Fr& f, int buf, int cc) {
+        const float* As = smem + buf * BUF;
+        const float* Ws = As + AROWS * TLD + (wave * 16 + li) * TLD;
+        const int c = khalf * (TBK / 32) + cc;
+        f.b = *reinterpret_cast<const float4*>(Ws + 16 * c + 4 * kk);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            f.a[t] = *reinterpret_cast<const float4*>(As + (t * 16 + li) * TLD + 16 * c + 4 * kk);
+    };
+    auto mm = [&](const Fr& f, int j0, int j1) {
+#pragma unroll
+        for (int j = j0; j < j1; ++j)
+#pragma unroll
+            for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(f.a[t], j), comp(f.b, j), acc[t]);
+    };
+    auto lstore_a = [&](const Regs& r, int buf) {
+        float* As = smem + buf * BUF;
+#pragma unroll
+        for (int p = 0; p < APASS; ++p)
+            if (p * 32 + ldrow < AROWS)
+                *reinterpret_cast<float4*>(As + (p * 32 + ldrow) * TLD + 4 * ldc4) = r.a[p];
+    };
+    auto lstore_w = [&](const Regs& r, int buf) {
+        float* Ws = smem + buf * BUF + AROWS * TLD;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+            *reinterpret_cast<float4*>(Ws + (p * 32 + ldrow) * TLD + 4 * ldc4) = r.w[p];
+    };
+    if (s_lo < s_hi) {
+        const int last = s_hi - 1;
+        Regs ra, rb;
+        Fr f0, f1;
+        gload(ra, s_lo);
+        lstore(ra, 0);
+        gload(ra, min(s_lo + 1, last));
+        gload(rb, min(s_lo + 2, last));
+        __syncthreads();
+        rfrag(f0, 0, 0);
+        LAB_STAMP(1);
+#ifdef SF_LAB_GLOAD_ONLY
+        // pure global-load rate of the staging pattern: no LDS, no MFMA (optionally a barrier)
+        auto eat = [&](const Regs& r) {
+#pragma unroll
+            for (int p = 0; p < APASS; ++p) acc[p][0] += r.a[p].x + r.a[p].w;
+            acc[5][0] += r.w[0].y + r.w[1].z;
+        };
+        for (int s = s_lo; s < s_hi; s += 2) {
+            LAB_STAMP(2 + min(s - s_lo, 20));
+            eat(ra);
+#ifdef SF_LAB_GLOAD_BARRIER
+            __syncthreads();
+#endif
+            gload(ra, min(s + 3, last));
+            if (s + 1 >= s_hi) break;
+            eat(rb);
+#ifdef SF_LAB_GLOAD_BARRIER
+            __syncthreads();
+#endif
+            gload(rb, min(s + 4, last));
+        }
+    }
+#elif defined(SF_LAB_MFMA_ONLY)
+        rfrag(f1, 0, 1);
+        for (int s = s_lo; s < s_hi; ++s) {
+            LAB_STAMP(2 + min(s - s_lo, 20));
+            mm(f0, 0, 4);
+            mm(f1, 0, 4);
+#ifdef SF_LAB_MFMA_BARRIER
+            __syncthreads();
+#endif
+#ifdef SF_LAB_MFMA_LDSR
+            rfrag(f1, 0, 1);
+            rfrag(f0, 0, 0);
+#endif
+        }
+    }
+#else
+        for (int s = s_lo; s < s_hi; s += 2) {
+            LAB_STAMP(2 + min(s - s_lo, 20));
+            // ---- stage s from buffer 0; ra (stage s+1) -> buffer 1
+            rfrag(f1, 0, 1);
+            mm(f0, 0, 2);
+            lstore_w(ra, 1);
+            mm(f0, 2, 4);
+            lstore_a(ra, 1);
+            __syncthreads();
+            gload(ra, min(s + 3, last));
+            rfrag(f0, 1, 0);
+            mm(f1, 0, 4);
+            if (s + 1 >= s_hi) break;
+            // ---- stage s+1 from buffer 1; rb (stage s+2) -> buffer 0
+            rfrag(f1, 1, 1);
+            mm(f0, 0, 2);
+            lstore_w(rb, 0);
+            mm(f0, 2, 4);
+            lstore_a(rb, 0);
+            __syncthreads();
+            gload(rb, min(s + 4, last));
+            rfrag(f0, 0, 0);
+            mm(f1, 0, 4);
+        }
+    }
+#endif
+#else
     // Two stages of global loads stay in flight (register sets ra / rb alternate) behind the stage
     // being computed from LDS: one stage of look-ahead measured ~2.9 us of exposed HBM latency per
     // stage.  Prefetch indices are clamped, not predicated, so the loop body has no branches and the
@@ -302,19 +445,27 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
         gload(ra, min(s_lo + 1, last));
         gload(rb, min(s_lo + 2, last));
         __syncthreads();
+        LAB_STAMP(1);
         for (int s = s_lo; s < s_hi; s += 2) {
+            LAB_STAMP(2 + min(s - s_lo, 20));
             compute(0);                       // stage s     (ra: s+1, rb: s+2 in flight)
             lstore(ra, 1);
             __syncthreads();
+#ifndef SF_LAB_NO_GLOAD
             gload(ra, min(s + 3, last));
+#endif
             if (s + 1 >= s_hi) break;
             compute(1);                       // stage s+1   (rb: s+2, ra: s+3 in flight)
             lstore(rb, 0);
             __syncthreads();
+#ifndef SF_LAB_NO_GLOAD
             gload(rb, min(s + 4, last));
+#endif
         }
     }
+#endif
     __syncthreads();
+    LAB_STAMP(28);
 
     // the two K halves meet in LDS (the stage buffers are free after the loop's last barrier)
     f32x4* red = reinterpret_cast<f32x4*>(smem);
@@ -344,6 +495,250 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
                 *o = (a.accumulate && a.ksplit == 1) ? *o + v : v;
             }
         }
+    LAB_STAMP(29);
+}
+
+// ------------------------------------------------------------------------------------------------
+// "Wide" LDS-tiled NT GEMM: the kernel for the LSTM gate products ([100, 4864] x [2048, 4864]^T).
+//
+// Timestamps + stubbed variants of the 64-column kernel above showed that kernel memory-bound on
+// its ACTIVATION operand: the MFMAs of a 64-deep stage take ~1.6 us per SIMD pair, but re-reading
+// the 112 x 64 A tile (L2 hits, ~16 B/cycle/CU) plus the weight tile took ~2.1 us.  A block here
+// covers 128 columns (8 waves x 16, every wave runs the whole 64-deep stage), so the A bytes per
+// FLOP halve and a stage's loads (~1.7 us) sit under its MFMAs (~3.2 us):
+//  * K is split at 16-k chunk granularity: a block owns chunks [c_lo, c_hi) of the concatenated
+//    segments, a stage is four chunks; the last stage may be partial (wave-uniform skip), so 256
+//    blocks get equal work (4864 k = 16 splits x 19 chunks).  Each staging thread picks the
+//    segment of ITS chunk, so stages may straddle the x | h boundary.
+//  * XCD-aware tile map: consecutive block ids go round-robin to the 8 XCDs; every XCD gets a
+//    contiguous (split, n-tile) range, so its L2 only holds its own k-slices of A (243 KB).
+//  * One barrier per stage, placed in the MIDDLE of the stage's MFMAs: fragments are double
+//    buffered in registers (chunk q+1 is read while chunk q multiplies), next stage's tiles are
+//    stored to the other LDS buffer between MFMA groups, and the first fragment of the next stage
+//    is read right after the barrier under the last chunk's MFMAs.
+//  * LDS row stride 72 dwords: conflict-free for the ds_read_b128 lane groups of gfx950 (68 gave
+//    2-way conflicts on every read: SQ_LDS_BANK_CONFLICT = 35 % of LDS cycles).
+//  * Rows >= M are neither loaded nor meaningful (their accumulators are never written).
+// grid (N/128, ksplit), block 512, dynamic LDS 2 x (MT*16 + 128) x 72 floats; slab output only.
+// ------------------------------------------------------------------------------------------------
+constexpr int WLD = 72, WN = 128;
+
+template <int MT>
+__global__ __launch_bounds__(512) void gemm_nt_wide_kernel(NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int AROWS = MT * 16;
+    constexpr int BUF = (AROWS + WN) * WLD;
+    constexpr int APASS = (AROWS + 31) / 32;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int ldrow = tid >> 4, ldc4 = tid & 15;
+    LAB_STAMP(0);
+
+    int n0, split;
+    {
+        const int total = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        int g = b;
+        if ((total & 7) == 0) g = (b & 7) * (total >> 3) + (b >> 3);
+        split = g / (int)gridDim.x;
+        n0 = (g % (int)gridDim.x) * WN;
+    }
+    const int c0n = a.seg[0].K >> 4;
+    const int c1n = a.nseg > 1 ? a.seg[1].K >> 4 : 0;
+    const int c_lo = (int)(((long)split * a.chunks_total) / a.ksplit);
+    const int c_hi = (int)(((long)(split + 1) * a.chunks_total) / a.ksplit);
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    struct Regs {
+        float4 a[APASS];
+        float4 w[4];
+    };
+    struct Fr {
+        float4 b;
+        float4 a[MT];
+    };
+    // staging thread (ldrow, ldc4): float4 #(ldc4 & 3) of chunk (ldc4 >> 2) of the stage.
+    // Loads and LDS stores are issued ONE AT A TIME between groups of 7 MFMAs: eight back-to-back
+    // global loads from all 8 waves right after the barrier stalled every wave on the address
+    // path (~0.65 us per stage with the matrix pipe idle); spread out, they are free.
+    // A stage never crosses a segment boundary (it is cut short there), so the segment of a stage
+    // is block-uniform: scalar selects, no per-lane indexing of the argument struct.
+    const int M = a.M;
+    struct Src {
+        const float* A;
+        const float* W;
+        int lda, ldw, nv;
+    };
+    int ld_c = c_lo;                                     // next chunk the loader will fetch
+    bool inloop = false;
+    (void)inloop;
+    auto next_src = [&]() __attribute__((always_inline)) {
+        const int c = min(ld_c, c_hi - 1);
+        const int sg = c < c0n ? 0 : (c < c0n + c1n ? 1 : 2);
+        const int seg_end = sg == 0 ? c0n : (sg == 1 ? c0n + c1n : a.chunks_total);
+        const int nv = max(1, min(4, min(seg_end, c_hi) - c));
+        ld_c += nv;
+        const float* A = sg == 0 ? a.seg[0].A : (sg == 1 ? a.seg[1].A : a.seg[2].A);
+        const float* W = sg == 0 ? a.seg[0].W : (sg == 1 ? a.seg[1].W : a.seg[2].W);
+        const int lda = sg == 0 ? a.seg[0].lda : (sg == 1 ? a.seg[1].lda : a.seg[2].lda);
+        const int ldw = sg == 0 ? a.seg[0].ldw : (sg == 1 ? a.seg[1].ldw : a.seg[2].ldw);
+        const int cl = c - (sg == 0 ? 0 : (sg == 1 ? c0n : c0n + c1n));
+        const int kcol = 16 * (cl + min(ldc4 >> 2, nv - 1)) + 4 * (ldc4 & 3);
+        return Src{A + (size_t)min(ldrow, M - 1) * lda + kcol, W + (size_t)(n0 + ldrow) * ldw + kcol,
+                   lda, ldw, nv};
+    };
+    auto gl_a = [&](Regs& r, const Src& sp, int lda, int p) __attribute__((always_inline)) {
+#ifdef SF_LAB_W_NOA
+        if (inloop) return;
+#endif
+        if (p < APASS && p * 32 + 4 * wave < M) {       // wave-uniform: this wave's rows of the pass
+            const int row = min(p * 32 + ldrow, M - 1) - min(ldrow, M - 1);
+            r.a[p < APASS ? p : 0] = ld4(sp.A + (size_t)row * lda);
+        }
+    };
+    auto gl_w = [&](Regs& r, const Src& sp, int ldw, int p) __attribute__((always_inline)) {
+#ifdef SF_LAB_W_NOW
+        if (inloop) return;
+#endif
+        r.w[p] = ld4(sp.W + (size_t)(p * 32) * ldw);
+    };
+    auto st_a = [&](const Regs& r, int buf, int p) __attribute__((always_inline)) {
+        if (p < APASS && p * 32 + 4 * wave < M)
+            *reinterpret_cast<float4*>(smem + buf * BUF + (p * 32 + ldrow) * WLD + 4 * ldc4) =
+                r.a[p < APASS ? p : 0];
+    };
+    auto st_w = [&](const Regs& r, int buf, int p) __attribute__((always_inline)) {
+        *reinterpret_cast<float4*>(smem + buf * BUF + (AROWS + p * 32 + ldrow) * WLD + 4 * ldc4) = r.w[p];
+    };
+    auto gload = [&](Regs& r) __attribute__((always_inline)) {
+        const Src sp = next_src();
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gl_a(r, sp, sp.lda, p);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gl_w(r, sp, sp.ldw, p);
+        return sp.nv;
+    };
+    auto rfrag = [&](Fr& f, int buf, int q) __attribute__((always_inline)) {
+        const float* As = smem + buf * BUF;
+        const float* Ws = As + AROWS * WLD + (wave * 16 + li) * WLD;
+        f.b = *reinterpret_cast<const float4*>(Ws + 16 * q + 4 * kk);
+#pragma unroll
+        for (int t = 0; t < MT; ++t)
+            f.a[t] = *reinterpret_cast<const float4*>(As + (t * 16 + li) * WLD + 16 * q + 4 * kk);
+    };
+    auto mmj = [&](const Fr& f, int j) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(f.a[t], j), comp(f.b, j), acc[t]);
+    };
+
+    if (c_lo < c_hi) {
+        Regs ra, rb;
+        Fr f0, f1;
+        // nv_* = valid chunks of the stage held by: LDS buffer being computed / rb / ra
+        int nv_cur = gload(ra);
+        int nv_b = gload(rb);
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            st_a(ra, 0, p);
+            st_w(ra, 0, p);
+        }
+        int nv_a = gload(ra);         // register sets: rb = stage 1, ra = stage 2
+        __syncthreads();
+        rfrag(f0, 0, 0);
+        LAB_STAMP(1);
+        int done = 0;                 // chunks multiplied so far
+        // one stage: tiles in buffer `cur` (nv valid chunks); `nx` (next stage, in registers) goes
+        // to the other buffer and is refilled with the stage after the other register set's.
+        auto stage = [&](int nv, int cur, Regs& nx, int& nv_nx) __attribute__((always_inline)) {
+            const int nb = cur ^ 1;
+            const Src sp = next_src();
+            const int lda = sp.lda, ldw = sp.ldw;
+            rfrag(f1, cur, 1);
+            mmj(f0, 0);
+            st_w(nx, nb, 0);
+            mmj(f0, 1);
+            st_w(nx, nb, 1);
+            mmj(f0, 2);
+            st_w(nx, nb, 2);
+            mmj(f0, 3);
+            rfrag(f0, cur, 2);
+            st_w(nx, nb, 3);
+            if (nv > 1) {
+                mmj(f1, 0);
+                gl_w(nx, sp, ldw, 0);
+                mmj(f1, 1);
+                gl_w(nx, sp, ldw, 1);
+                mmj(f1, 2);
+                gl_w(nx, sp, ldw, 2);
+                mmj(f1, 3);
+            } else {
+                gl_w(nx, sp, ldw, 0);
+                gl_w(nx, sp, ldw, 1);
+                gl_w(nx, sp, ldw, 2);
+            }
+            rfrag(f1, cur, 3);
+            gl_w(nx, sp, ldw, 3);
+            if (nv > 2) {
+                mmj(f0, 0);
+                st_a(nx, nb, 0);
+                mmj(f0, 1);
+                st_a(nx, nb, 1);
+                mmj(f0, 2);
+                st_a(nx, nb, 2);
+                st_a(nx, nb, 3);
+                mmj(f0, 3);
+            } else {
+                st_a(nx, nb, 0);
+                st_a(nx, nb, 1);
+                st_a(nx, nb, 2);
+                st_a(nx, nb, 3);
+            }
+            __syncthreads();
+            rfrag(f0, nb, 0);
+            if (nv > 3) {
+                mmj(f1, 0);
+                gl_a(nx, sp, lda, 0);
+                mmj(f1, 1);
+                gl_a(nx, sp, lda, 1);
+                mmj(f1, 2);
+                gl_a(nx, sp, lda, 2);
+                mmj(f1, 3);
+                gl_a(nx, sp, lda, 3);
+            } else {
+                gl_a(nx, sp, lda, 0);
+                gl_a(nx, sp, lda, 1);
+                gl_a(nx, sp, lda, 2);
+                gl_a(nx, sp, lda, 3);
+            }
+            done += nv;
+            const int nxt = nv_nx;    // the stage just stored becomes current
+            nv_nx = sp.nv;
+            return nxt;
+        };
+        const int total = c_hi - c_lo;
+        inloop = true;
+        for (int it = 0; done < total; it += 2) {
+            LAB_STAMP(2 + min(it, 20));
+            nv_cur = stage(nv_cur, 0, rb, nv_b);
+            if (done >= total) break;
+            nv_cur = stage(nv_cur, 1, ra, nv_a);
+        }
+    }
+    LAB_STAMP(28);
+
+    const int col = n0 + wave * 16 + li;
+    float* out = a.out + (size_t)split * M * a.N;
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + kk * 4 + r;
+            if (row < M) out[(size_t)row * a.N + col] = acc[t][r];
+        }
+    LAB_STAMP(29);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -919,9 +1314,19 @@ static void nt_shape(int M, int N, int Ktot_chunks, int* mt, int* mblocks, int* 
     *ks = pick_ksplit(ntiles * *mblocks, Ktot_chunks);
 }
 
+// K-splits of the wide kernel: one block per CU (256) if every split keeps >= 8 chunks, <= 16 slabs
+static int wide_ksplit(int N, int chunks) {
+    const int ntiles = N / WN;
+    int ks = std::max(1, 256 / ntiles);
+    ks = std::min(ks, std::max(1, chunks / 8));
+    return std::min(ks, 16);
+}
+
 int linear_ksplit(int M, int N, int Ktot) {
     int mt, mb, ks;
-    nt_shape(M, N, ceil_div(Ktot, 16), &mt, &mb, &ks);
+    const int chunks = ceil_div(Ktot, 16);
+    nt_shape(M, N, chunks, &mt, &mb, &ks);
+    if (mb == 1 && chunks >= 128 && N % WN == 0) ks = std::max(ks, wide_ksplit(N, chunks));
     return ks;
 }
 
@@ -1037,6 +1442,42 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
             }
 #undef SF_ARES
             ks = aks;
+            launched = true;
+        }
+    }
+    // wide kernel: slab output, all segments whole 16-k chunks, N a multiple of 128
+    bool wide = !launched && slabs && mblocks == 1 && chunks >= 128 && N % WN == 0 && variant == 0;
+    for (int s = 0; s < nseg; ++s) wide = wide && segs[s].K % 16 == 0;
+    if (wide) {
+        const int wks = wide_ksplit(N, chunks);
+        if (wks > 1 && ws_floats >= (size_t)wks * M * N) {
+            a.ksplit = ks = wks;
+            dim3 wgrid(N / WN, wks);
+            const size_t lds = (size_t)2 * (mt * 16 + WN) * WLD * sizeof(float);
+#define SF_WIDE(MTV)                                                                                \
+    case MTV: {                                                                                     \
+        static bool attr_set = false;                                                               \
+        if (!attr_set) {                                                                            \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_wide_kernel<MTV>),      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);      \
+            attr_set = true;                                                                        \
+        }                                                                                           \
+        hipLaunchKernelGGL(gemm_nt_wide_kernel<MTV>, wgrid, dim3(512), lds, st, a);                 \
+    } break;
+            switch (mt) {
+                SF_WIDE(1) SF_WIDE(2) SF_WIDE(3) SF_WIDE(4) SF_WIDE(5) SF_WIDE(6) SF_WIDE(7)
+                default: {
+                    static bool attr8 = false;
+                    if (!attr8) {
+                        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_wide_kernel<8>),
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                  160 * 1024);
+                        attr8 = true;
+                    }
+                    hipLaunchKernelGGL(gemm_nt_wide_kernel<8>, wgrid, dim3(512), lds, st, a);
+                }
+            }
+#undef SF_WIDE
             launched = true;
         }
     }
