@@ -151,6 +151,9 @@ typedef struct sf_decoder_tape {
 } sf_decoder_tape;
 
 /* Scratch any call may need (split-K partial slabs etc.); a constant, independent of batch. */
+/* Size of the scratch buffer every composite entry point takes.  The caller ZERO-FILLS it once
+ * after allocation (its last 4 KB hold self-maintaining ticket counters of multi-workgroup
+ * kernels); after that the library owns its contents.  One workspace per concurrently used stream. */
 size_t sf_workspace_bytes(void);
 int sf_abi_version(void);
 const char* sf_status_string(int status);

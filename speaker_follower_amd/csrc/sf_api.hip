@@ -27,9 +27,16 @@ struct Arena {
     }
     float* rest() const { return base + off; }
     size_t rest_n() const { return cap - off; }
+    // the last SYNC_WORDS dwords of the workspace: monotonic ticket counters (zero-initialised by
+    // the caller once, see sf_workspace_bytes); never handed out by take()
+    unsigned* tickets() const { return base ? reinterpret_cast<unsigned*>(base + cap) : nullptr; }
 };
+constexpr size_t SYNC_WORDS = 1024;
 
-inline Arena arena(void* ws, size_t bytes) { return Arena{(float*)ws, ws ? bytes / 4 : 0, 0}; }
+inline Arena arena(void* ws, size_t bytes) {
+    const size_t n = ws ? bytes / 4 : 0;
+    return Arena{(float*)ws, n > SYNC_WORDS ? n - SYNC_WORDS : 0, 0};
+}
 inline hipStream_t S(sf_stream s) { return (hipStream_t)s; }
 
 inline PanoSrc pano(const sf_pano* p) {
@@ -139,14 +146,20 @@ int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, co
     const int F = X.IMG + X.LOC;
     if (fold) {      // inference: q = M_v h + c_v in one product
         TRY(linear_plain(h, H, fold->m_v, H, fold->c_v, B, F, H, EPI_NONE, q, F, ar, st));
-        return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st);
+        float* part = B <= (int)SYNC_WORDS ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+        return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st, part,
+                           part ? ar.tickets() : nullptr);
     }
     TRY(linear_plain(h, H, w->w_h, H, w->b_h, B, D, H, EPI_NONE, t_v, D, ar, st));
     if (w->w_v_t)   // q = t_v W_v as a K-contiguous product against the transposed copy
         TRY(linear_plain(t_v, D, w->w_v_t, D, nullptr, B, F, D, EPI_NONE, q, F, ar, st));
     else
         TRY(gemm_nn_ws(t_v, D, w->w_v, F, B, F, D, q, F, 0, ar.rest(), ar.rest_n(), st));
-    return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st);
+    // (the products above are done with their slabs by the time the attention kernel runs: the
+    // partials may reuse that part of the workspace)
+    float* part = B <= (int)SYNC_WORDS ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+    return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st, part,
+                       part ? ar.tickets() : nullptr);
 }
 
 int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, int B, int H, int D,

@@ -3,6 +3,9 @@
 #include "sf_kernels.h"
 #include "sf_rows.h"
 #include "sf_glue.h"
+#ifndef LAB_VSTAMP
+#define LAB_VSTAMP(i) do {} while (0)
+#endif
 
 namespace sf {
 
@@ -36,6 +39,7 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
     const int V = a.src.V;
     const int n4 = (a.src.IMG + a.src.LOC) >> 2;
 
+    const PanoRow prow = pano_row(a.src, b);
     float4 x[VIS_RPW][VIS_CPL];
 #pragma unroll
     for (int r = 0; r < VIS_RPW; ++r) {
@@ -43,7 +47,7 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
 #pragma unroll
         for (int i = 0; i < VIS_CPL; ++i) {
             const int c = lane + 64 * i;
-            x[r][i] = (v < V && c < n4) ? pano_chunk(a.src, b, v, c) : f4zero();
+            x[r][i] = pano_load(prow, v, c, v < V && c < n4, V, n4);
         }
     }
 
@@ -54,9 +58,9 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
 #pragma unroll
     for (int i = 0; i < VIS_CPL; ++i) {
         const int c = lane + 64 * i;
-        float4 q = f4zero();
-        if (c < n4) {
-            q = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[c];
+        float4 q = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[min(c, n4 - 1)];
+        if (c >= n4) q = f4zero();
+        {
             if (MODE == 1 && a.drop.on()) {
                 const uint32_t col = (uint32_t)(a.drop_col0 + 4 * c);
                 q.x = dropout_keep(rkey, col + 0, a.drop.thresh) ? q.x * a.drop.scale : 0.f;
@@ -85,7 +89,8 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
         w = e / wave_sum(e);
         if (wave == 0 && lane < V) a.alpha[(size_t)b * V + lane] = w;
     } else {
-        const float al = lane < V ? a.alpha[(size_t)b * V + lane] : 0.f;
+        const float alv = a.alpha[(size_t)b * V + min(lane, V - 1)];
+        const float al = lane < V ? alv : 0.f;
         const float d = lane < V ? s : 0.f;
         w = al * (d - wave_sum(al * d));
     }
@@ -116,6 +121,140 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
         }
         reinterpret_cast<float4*>(orow)[c] = t;
     });
+}
+
+// -------------------------------------------------------------------------------------------------
+// Forward visual attention split over TWO workgroups per sample.  One workgroup per sample leaves
+// 156 of 256 CUs idle at batch 100 and a CU sustains only ~20-35 GB/s of loads, so the 313 KB
+// panorama of a sample took ~17 us to arrive; two half-panoramas on two CUs take half of that.
+// Each block keeps flash-style partials of ITS 18 views (max m, sum l = sum e^(s-m), unnormalised
+// weighted sum P, raw scores) in the workspace; the block that finishes second (ticket from a
+// monotonic per-sample counter; partials are published write-through and read back with sc1
+// loads, so no cache-wide fence is needed) merges: no spinning, no extra launch.
+// -------------------------------------------------------------------------------------------------
+constexpr int VSP_NW = 6, VSP_RPG = VSP_NW * VIS_RPW, VSP_SLOTS = 3;
+
+struct VisSplit {
+    float* part;          // [B][2][F + 64]: P | scores[32] | m, l
+    unsigned* counter;    // [B] monotonic tickets (zero before the first launch)
+};
+
+__global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_kernel(VisArgs a, VisSplit sp) {
+    __shared__ float4 slots[VSP_SLOTS][VIS_CPL * 64];
+    __shared__ float s_score[64];
+    __shared__ int s_last;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int V = a.src.V;
+    const int F = a.src.IMG + a.src.LOC, n4 = F >> 2;
+    const int pstride = F + 64;
+    float* rec = sp.part + ((size_t)b * 2 + g) * pstride;
+    LAB_VSTAMP(0);
+
+    const PanoRow prow = pano_row(a.src, b);
+    float4 x[VIS_RPW][VIS_CPL];
+#pragma unroll
+    for (int r = 0; r < VIS_RPW; ++r) {
+        const int v = g * VSP_RPG + wave * VIS_RPW + r;
+#pragma unroll
+        for (int i = 0; i < VIS_CPL; ++i) {
+            const int c = lane + 64 * i;
+            x[r][i] = pano_load(prow, v, c, v < V && c < n4, V, n4);
+        }
+    }
+    LAB_VSTAMP(1);
+    float dot[VIS_RPW];
+#pragma unroll
+    for (int r = 0; r < VIS_RPW; ++r) dot[r] = 0.f;
+#pragma unroll
+    for (int i = 0; i < VIS_CPL; ++i) {
+        const int c = lane + 64 * i;
+        const float4 q = c < n4 ? reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[c]
+                                : f4zero();
+#pragma unroll
+        for (int r = 0; r < VIS_RPW; ++r) dot[r] += dot4(x[r][i], q);
+    }
+#pragma unroll
+    for (int r = 0; r < VIS_RPW; ++r) {
+        const float s = wave_sum(dot[r]);
+        const int vl = wave * VIS_RPW + r;
+        if (lane == 0) s_score[vl] = (g * VSP_RPG + vl < V) ? s : -INFINITY;
+    }
+    __syncthreads();
+    LAB_VSTAMP(2);
+    const float s = lane < VSP_RPG ? s_score[lane] : -INFINITY;
+    const float m = wave_max(s);
+    const float e = s > -INFINITY ? expf(s - m) : 0.f;
+    const float l = wave_sum(e);
+
+    float4 p[VIS_CPL];
+#pragma unroll
+    for (int i = 0; i < VIS_CPL; ++i) p[i] = f4zero();
+#pragma unroll
+    for (int r = 0; r < VIS_RPW; ++r) {
+        const float er = __shfl(e, wave * VIS_RPW + r, WAVE);
+#pragma unroll
+        for (int i = 0; i < VIS_CPL; ++i) f4fma(p[i], er, x[r][i]);
+    }
+    // publish the partials WRITE-THROUGH (sc1: straight to the memory side, visible to every XCD),
+    // drain, then draw a ticket: no release fence (a buffer_wbl2 of the whole L2 costs far more
+    // than this kernel), and the merging block reads them back with sc1 loads: no acquire fence.
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, pstride * 4, 0x00020000);
+    block_row_sum<VIS_CPL, VSP_NW, VSP_SLOTS>(p, slots, n4, [&](int c, float4 t) {
+        const v4u v{__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, c * 16, 0, 16);
+    });
+    if (wave == 0) {
+        if (lane < 32) __hip_atomic_store(rec + F + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) {
+            __hip_atomic_store(rec + F + 32, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + F + 33, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    LAB_VSTAMP(3);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains
+    LAB_VSTAMP(4);
+    __syncthreads();
+    if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(sp.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) == 1u;
+    __syncthreads();
+    LAB_VSTAMP(5);
+    if (!s_last) return;
+
+    float* r0 = sp.part + (size_t)b * 2 * pstride;
+    float* r1 = r0 + pstride;
+    auto ldf = [&](float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    const float m0 = ldf(r0 + F + 32), l0 = ldf(r0 + F + 33), m1 = ldf(r1 + F + 32), l1 = ldf(r1 + F + 33);
+    const float M = fmaxf(m0, m1);
+    const float c0 = expf(m0 - M), c1 = expf(m1 - M);          // m = -inf (empty group): c = 0, l = 0
+    const float inv = 1.0f / (l0 * c0 + l1 * c1);
+    if (tid < V) {
+        const float sc = ldf((tid < VSP_RPG ? r0 : r1) + F + (tid < VSP_RPG ? tid : tid - VSP_RPG));
+        a.alpha[(size_t)b * V + tid] = expf(sc - M) * inv;
+    }
+    const float k0 = c0 * inv, k1 = c1 * inv;
+    float* orow = a.out + (size_t)b * a.ldo;
+    const Dropout dr = a.drop;
+    const uint32_t rkey = dropout_row_key(dr.seed, dr.stream, (uint32_t)(dr.row0 + b));
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(r0, 0, 2 * pstride * 4, 0x00020000);
+    for (int c = tid; c < n4; c += VSP_NW * 64) {
+        const v4u uu = __builtin_amdgcn_raw_buffer_load_b128(rs0, c * 16, 0, 16);
+        const v4u ww = __builtin_amdgcn_raw_buffer_load_b128(rs0, pstride * 4 + c * 16, 0, 16);
+        const float4 u = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
+        const float4 w = make_float4(__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w));
+        float4 t = make_float4(k0 * u.x + k1 * w.x, k0 * u.y + k1 * w.y, k0 * u.z + k1 * w.z,
+                               k0 * u.w + k1 * w.w);
+        if (dr.on()) {
+            const uint32_t col = (uint32_t)(a.drop_col0 + 4 * c);
+            t.x = dropout_keep(rkey, col + 0, dr.thresh) ? t.x * dr.scale : 0.f;
+            t.y = dropout_keep(rkey, col + 1, dr.thresh) ? t.y * dr.scale : 0.f;
+            t.z = dropout_keep(rkey, col + 2, dr.thresh) ? t.z * dr.scale : 0.f;
+            t.w = dropout_keep(rkey, col + 3, dr.thresh) ? t.w * dr.scale : 0.f;
+        }
+        reinterpret_cast<float4*>(orow)[c] = t;
+    }
+    LAB_VSTAMP(6);
 }
 
 // =================================================================================================
@@ -151,24 +290,35 @@ __global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
     const int bc = a.ctx_row ? a.ctx_row[b] : b;
     const float4* ctx = reinterpret_cast<const float4*>(a.ctx) + (size_t)bc * L * n4;
 
+    // straight-line loads (clamped indices, value selects): a load inside a branch costs a full
+    // memory round trip each (see sf_rows.h)
     float4 x[RPW][TXT_CPL];
+    uint8_t mk[RPW];
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int l = wave * RPW + r;
+        const int lc = min(l, L - 1);
 #pragma unroll
         for (int i = 0; i < TXT_CPL; ++i) {
             const int c = lane + 64 * i;
-            x[r][i] = (l < L && c < n4) ? ctx[(size_t)l * n4 + c] : f4zero();
+            const float4 t = ctx[(size_t)lc * n4 + min(c, n4 - 1)];
+            x[r][i] = (l < L && c < n4) ? t : f4zero();
         }
+        mk[r] = 0;
+        if (MODE == 0 && a.mask) mk[r] = a.mask[(size_t)bc * L + lc];       // block-uniform branch
     }
     float4 v1[TXT_CPL], v2[TXT_CPL];
 #pragma unroll
     for (int i = 0; i < TXT_CPL; ++i) {
         const int c = lane + 64 * i;
-        v1[i] = c < n4 ? reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[c] : f4zero();
-        v2[i] = (MODE == 1 && c < n4)
-                    ? reinterpret_cast<const float4*>(a.vec2 + (size_t)b * a.ldvec2)[c]
-                    : f4zero();
+        const int cc = min(c, n4 - 1);
+        const float4 t1 = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[cc];
+        v1[i] = c < n4 ? t1 : f4zero();
+        v2[i] = f4zero();
+        if (MODE == 1) {
+            const float4 t2 = reinterpret_cast<const float4*>(a.vec2 + (size_t)b * a.ldvec2)[cc];
+            v2[i] = c < n4 ? t2 : f4zero();
+        }
     }
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
@@ -177,10 +327,7 @@ __global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
         for (int i = 0; i < TXT_CPL; ++i) d += dot4(x[r][i], v1[i]);
         d = wave_sum(d);
         const int l = wave * RPW + r;
-        if (lane == 0 && l < L) {
-            if (MODE == 0 && a.mask && a.mask[(size_t)bc * L + l]) d = -INFINITY;
-            s_score[l] = d;
-        }
+        if (lane == 0 && l < L) s_score[l] = (MODE == 0 && mk[r]) ? -INFINITY : d;
     }
     __syncthreads();
 
@@ -201,8 +348,10 @@ __global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
             if (l1 < L) a.alpha[(size_t)b * L + l1] = w1;
         }
     } else {
-        const float a0 = l0 < L ? a.alpha[(size_t)b * L + l0] : 0.f;
-        const float a1 = l1 < L ? a.alpha[(size_t)b * L + l1] : 0.f;
+        const float t0 = a.alpha[(size_t)b * L + min(l0, L - 1)];
+        const float t1 = a.alpha[(size_t)b * L + min(l1, L - 1)];
+        const float a0 = l0 < L ? t0 : 0.f;
+        const float a1 = l1 < L ? t1 : 0.f;
         const float d0 = l0 < L ? s_score[l0] : 0.f;
         const float d1 = l1 < L ? s_score[l1] : 0.f;
         const float tot = wave_sum(a0 * d0 + a1 * d1);
@@ -219,22 +368,34 @@ __global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
         const int src = (l < L ? l : 0) & 63;
         const float lo = __shfl(w0, src, WAVE), hi = __shfl(w1, src, WAVE);
         const float wr = (l < 64) ? lo : hi;
-        if (l < L) {
+        const float wl = l < L ? wr : 0.f;                       // x is zero beyond L anyway
 #pragma unroll
-            for (int i = 0; i < TXT_CPL; ++i) f4fma(p[i], wr, x[r][i]);
-            if (MODE == 1 && a.dctx) {
-                const float al = a.alpha[(size_t)b * L + l];
-                float4* drow = reinterpret_cast<float4*>(a.dctx) + ((size_t)b * L + l) * n4;
+        for (int i = 0; i < TXT_CPL; ++i) f4fma(p[i], wl, x[r][i]);
+    }
+    if (MODE == 1 && a.dctx) {                                   // dctx_l += alpha_l dwc + ds_l t
+        float4 g[RPW][TXT_CPL];
+        float al[RPW];
 #pragma unroll
-                for (int i = 0; i < TXT_CPL; ++i) {
-                    const int c = lane + 64 * i;
-                    if (c < n4) {
-                        float4 g = drow[c];
-                        f4fma(g, al, v1[i]);   // alpha_l * dwc
-                        f4fma(g, wr, v2[i]);   // ds_l * t
-                        drow[c] = g;
-                    }
-                }
+        for (int r = 0; r < RPW; ++r) {                          // all read-modify-write loads first
+            const int lc = min(wave * RPW + r, L - 1);
+            al[r] = a.alpha[(size_t)b * L + lc];
+            const float4* drow = reinterpret_cast<const float4*>(a.dctx) + ((size_t)b * L + lc) * n4;
+#pragma unroll
+            for (int i = 0; i < TXT_CPL; ++i) g[r][i] = drow[min(lane + 64 * i, n4 - 1)];
+        }
+#pragma unroll
+        for (int r = 0; r < RPW; ++r) {
+            const int l = wave * RPW + r;
+            const int src = (l < L ? l : 0) & 63;
+            const float lo = __shfl(w0, src, WAVE), hi = __shfl(w1, src, WAVE);
+            const float wr = (l < 64) ? lo : hi;
+            float4* drow = reinterpret_cast<float4*>(a.dctx) + ((size_t)b * L + min(l, L - 1)) * n4;
+#pragma unroll
+            for (int i = 0; i < TXT_CPL; ++i) {
+                const int c = lane + 64 * i;
+                f4fma(g[r][i], al[r], v1[i]);
+                f4fma(g[r][i], wr, v2[i]);
+                if (l < L && c < n4) drow[c] = g[r][i];
             }
         }
     }
@@ -265,25 +426,46 @@ struct ScoreArgs {
     float* dc;             // bwd out [B]
 };
 
+// wt[b] . b_a + b_out (or the precomputed per-row constant): straight-line loads for D <= 256
+__device__ __forceinline__ float score_const(const ScoreArgs& a, int b, int lane) {
+    if (a.cst) return a.cst[(size_t)b * a.ldr];                  // block-uniform
+    float c = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = lane + 64 * i;
+        const float w = a.wt[(size_t)b * a.D + min(k, a.D - 1)] * a.b_a[min(k, a.D - 1)];
+        c += k < a.D ? w : 0.f;
+    }
+    for (int k = lane + 256; k < a.D; k += 64) c += a.wt[(size_t)b * a.D + k] * a.b_a[k];
+    return wave_sum(c) + a.b_out[0];
+}
+
 __global__ __launch_bounds__(SC_NW * 64) void score_fwd_kernel(ScoreArgs a) {
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int A = a.src.A;
     if (wave >= A) return;
     const int n4 = (a.src.IMG + a.src.LOC) >> 2;
-    float d = 0.f;
+    const CandRow row = cand_row(a.src, b, wave);
+    const float4* rv = reinterpret_cast<const float4*>(a.r + (size_t)b * a.ldr);
+    float4 x[SC_CPL], q[SC_CPL];
 #pragma unroll
-    for (int i = 0; i < SC_CPL; ++i) {
-        const int c = lane + 64 * i;
-        if (c < n4)
-            d += dot4(cand_chunk(a.src, b, wave, c),
-                      reinterpret_cast<const float4*>(a.r + (size_t)b * a.ldr)[c]);
+    for (int i = 0; i < SC_CPL; ++i) x[i] = f4zero();
+    if (!row.zero) {        // wave-uniform: stop / padding rows cost no traffic; one block of loads
+#pragma unroll
+        for (int i = 0; i < SC_CPL; ++i) {
+            const int c = lane + 64 * i;
+            x[i] = cand_load(row, c, c < n4, n4);
+            q[i] = rv[min(c, n4 - 1)];
+        }
     }
-    float cst = 0.f;
-    if (!a.cst)
-        for (int k = lane; k < a.D; k += 64) cst += a.wt[(size_t)b * a.D + k] * a.b_a[k];
+    float d = 0.f;
+    if (!row.zero) {
+#pragma unroll
+        for (int i = 0; i < SC_CPL; ++i) d += dot4(x[i], q[i]);  // x is zero beyond n4
+    }
+    const float cst = score_const(a, b, lane);
     d = wave_sum(d);
-    cst = a.cst ? a.cst[(size_t)b * a.ldr] : wave_sum(cst) + a.b_out[0];
     if (lane == 0) a.logit[(size_t)b * A + wave] = d + cst;
 }
 
@@ -297,23 +479,32 @@ __global__ __launch_bounds__(SC_NW * 64) void score_glue_kernel(ScoreArgs a, FGl
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int A = a.src.A;
     const int n4 = (a.src.IMG + a.src.LOC) >> 2;
-    float4 x[SC_CPL];
-    float d = 0.f;
+    const CandRow row = cand_row(a.src, b, wave);
+    const FGlueIn gin = follower_glue_load(g, b);               // (used by wave 0; cheap for the rest)
+    const float4* rv = reinterpret_cast<const float4*>(a.r + (size_t)b * a.ldr);
+    float4 x[SC_CPL], q[SC_CPL];
 #pragma unroll
-    for (int i = 0; i < SC_CPL; ++i) {
-        const int c = lane + 64 * i;
-        x[i] = (wave < A && c < n4) ? cand_chunk(a.src, b, wave, c) : f4zero();
-        if (c < n4) d += dot4(x[i], reinterpret_cast<const float4*>(a.r + (size_t)b * a.ldr)[c]);
+    for (int i = 0; i < SC_CPL; ++i) x[i] = f4zero();
+    const bool have = wave < A && !row.zero;   // wave-uniform: stop / padding rows cost no traffic
+    if (have) {
+#pragma unroll
+        for (int i = 0; i < SC_CPL; ++i) {
+            const int c = lane + 64 * i;
+            x[i] = cand_load(row, c, c < n4, n4);
+            q[i] = rv[min(c, n4 - 1)];
+        }
     }
-    float cst = 0.f;
-    if (wave < A && !a.cst)
-        for (int k = lane; k < a.D; k += 64) cst += a.wt[(size_t)b * a.D + k] * a.b_a[k];
+    float d = 0.f;
+    if (have) {
+#pragma unroll
+        for (int i = 0; i < SC_CPL; ++i) d += dot4(x[i], q[i]);
+    }
+    const float cst = score_const(a, b, lane);
     d = wave_sum(d);
-    cst = a.cst ? a.cst[(size_t)b * a.ldr] : wave_sum(cst) + a.b_out[0];
     if (lane == 0 && wave < A) s_logit[wave] = d + cst;
     __syncthreads();
     if (wave == 0) {
-        const int at = follower_glue_row(g, b, lane < A ? s_logit[lane] : 0.f);
+        const int at = follower_glue_row(g, b, lane < A ? s_logit[lane] : 0.f, gin);
         if (lane == 0) s_at = at;
     }
     __syncthreads();
@@ -332,17 +523,21 @@ __global__ __launch_bounds__(SC_NW * 64) void score_bwd_kernel(ScoreArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int A = a.src.A;
     const int n4 = (a.src.IMG + a.src.LOC) >> 2;
-    const float w = wave < A ? a.logit[(size_t)b * A + wave] : 0.f;
+    const float w = a.logit[(size_t)b * A + min(wave, A - 1)];
+    const CandRow row = cand_row(a.src, b, wave);
     float4 p[SC_CPL];
 #pragma unroll
-    for (int i = 0; i < SC_CPL; ++i) {
-        const int c = lane + 64 * i;
-        p[i] = f4zero();
-        if (wave < A && c < n4 && w != 0.f) f4fma(p[i], w, cand_chunk(a.src, b, wave, c));
+    for (int i = 0; i < SC_CPL; ++i) p[i] = f4zero();
+    if (wave < A && !row.zero && w != 0.f) {                     // wave-uniform
+#pragma unroll
+        for (int i = 0; i < SC_CPL; ++i) {
+            const int c = lane + 64 * i;
+            f4fma(p[i], w, cand_load(row, c, c < n4, n4));
+        }
     }
     if (wave == 0) {
-        const float dl = lane < A ? a.logit[(size_t)b * A + lane] : 0.f;
-        const float tot = wave_sum(dl);
+        const float dlv = a.logit[(size_t)b * A + min(lane, A - 1)];
+        const float tot = wave_sum(lane < A ? dlv : 0.f);
         if (lane == 0) a.dc[b] = tot;
     }
     float* orow = a.dr + (size_t)b * (n4 << 2);
@@ -353,13 +548,23 @@ __global__ __launch_bounds__(SC_NW * 64) void score_bwd_kernel(ScoreArgs a) {
 
 }  // namespace
 
+size_t visual_attn_split_floats(int B, int F) { return (size_t)B * 2 * (F + 64); }
+
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
-                float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st) {
+                float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st,
+                float* split_part, unsigned* split_counter) {
     const int F = src.IMG + src.LOC;
     if (src.V > VIS_RPW * VIS_NW || src.V > 64 || F > VIS_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) || (ldvec & 3) || (ldo & 3))
         return SF_ERR_UNSUPPORTED;
     VisArgs a{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
+    // small batches: two workgroups per sample (see visual_attn_split_kernel)
+    if (mode == 0 && split_part && split_counter && src.V > VSP_RPG && src.V <= 2 * VSP_RPG &&
+        B <= 256) {
+        hipLaunchKernelGGL(visual_attn_split_kernel, dim3(2, B), dim3(VSP_NW * 64), 0, st, a,
+                           VisSplit{split_part, split_counter});
+        return launch_status();
+    }
     if (mode == 0)
         hipLaunchKernelGGL(visual_attn_kernel<0>, dim3(B), dim3(VIS_NW * 64), 0, st, a);
     else

@@ -604,13 +604,23 @@ __global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmS
     const bool ptail = threadIdx.x < 256 && pb < p.B;
     float pre[4] = {0.f, 0.f, 0.f, 0.f};
     float c0v = 0.f;
-    if (ptail) {
-        c0v = p.pw.c0[pb * H + pj];
+    LstmLive lv{true, 0.f};
+    {   // straight-line: rows / threads outside the tail read a clamped (valid) address
+        const int qb = min(pb, p.B - 1);
+        c0v = p.pw.c0[qb * H + pj];
+        lv = lstm_live_load(p.pw, qb, pj);
+        float bi[4], bh[4], xv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            pre[g] = p.b_ih[g * H + pj] + p.b_hh[g * H + pj];
-            if (p.xg) pre[g] += p.xg[(size_t)pb * 4 * H + g * H + pj];
+            bi[g] = p.b_ih[g * H + pj];
+            bh[g] = p.b_hh[g * H + pj];
         }
+        if (p.xg) {                                              // block-uniform
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[g] = p.xg[(size_t)qb * 4 * H + g * H + pj];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = bi[g] + bh[g] + xv[g];
     }
 
     Seg2 sg;
@@ -640,7 +650,7 @@ __global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmS
         for (int k = 0; k < LSTM_KS; ++k) v += s_g[g][k][threadIdx.x];
         g4[g] = v;
     }
-    lstm_cell_update(p.pw, pb, pj, g4, c0v);
+    lstm_cell_update(p.pw, pb, pj, g4, c0v, lv);
 }
 
 // ------------------------------------------------------------------------------------------------

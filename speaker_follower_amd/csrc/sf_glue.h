@@ -26,22 +26,41 @@ struct FGlue {
     int row0;
 };
 
-// One wave handles sample b; lane a holds the raw logit of candidate a (lanes >= A ignored).
-// Returns the chosen action (wave-uniform).
-__device__ __forceinline__ int follower_glue_row(const FGlue& g, int b, float raw) {
+// The glue's inputs, loaded up front with straight-line code (callers issue this BEFORE they wait
+// for the logits, so the loads overlap with the scoring work).
+struct FGlueIn {
+    bool valid;       // lane's candidate is a real one
+    bool was_ended;
+    int64_t target;
+};
+__device__ __forceinline__ FGlueIn follower_glue_load(const FGlue& g, int b) {
     const int lane = threadIdx.x & 63;
     const int A = g.src.A;
-    bool valid = false;
-    if (lane < A)
-        valid = g.is_valid ? (g.is_valid[(size_t)b * A + lane] != 0.f) : (lane < g.src.a_num[b]);
+    const int la = min(lane, A - 1);
+    FGlueIn in;
+    if (g.is_valid)                                              // block-uniform
+        in.valid = lane < A && g.is_valid[(size_t)b * A + la] != 0.f;
+    else
+        in.valid = lane < A && lane < g.src.a_num[b];
+    in.was_ended = g.ended[b] != 0;
+    in.target = g.target[b];
+    return in;
+}
+
+// One wave handles sample b; lane a holds the raw logit of candidate a (lanes >= A ignored).
+// Returns the chosen action (wave-uniform).
+__device__ __forceinline__ int follower_glue_row(const FGlue& g, int b, float raw, const FGlueIn& in) {
+    const int lane = threadIdx.x & 63;
+    const int A = g.src.A;
+    const bool valid = in.valid;
     const float l = (lane < A && valid) ? raw : -INFINITY;
     if (lane < A) g.logit[(size_t)b * A + lane] = l;             // follower.py:477
     const float m = wave_max(l);
     const float e = (lane < A && valid) ? expf(l - m) : 0.f;
     const float se = wave_sum(e);
     const float lse = m + logf(se);
-    const bool was_ended = g.ended[b] != 0;
-    const int64_t tgt = was_ended ? -1 : g.target[b];            // follower.py:322-328
+    const bool was_ended = in.was_ended;
+    const int64_t tgt = was_ended ? -1 : in.target;              // follower.py:322-328
     const float lt = __shfl(l, tgt >= 0 ? (int)tgt : 0, WAVE);
     const float ce = tgt >= 0 ? (lse - lt) : 0.f;                // CrossEntropyLoss(ignore_index=-1)
     int at;

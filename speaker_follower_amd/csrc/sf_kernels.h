@@ -8,8 +8,12 @@
 namespace sf {
 
 // ---- sf_attention.hip ---------------------------------------------------------------------------
+// split_part / split_counter (optional): scratch ([visual_attn_split_floats] floats) and the
+// per-sample ticket counters that let the forward pass use two workgroups per sample.
+size_t visual_attn_split_floats(int B, int F);
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
-                float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st);
+                float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st,
+                float* split_part = nullptr, unsigned* split_counter = nullptr);
 int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t,
                   int ldt, float* alpha, float* wc, int ldwc, hipStream_t st,
                   const int32_t* ctx_row = nullptr);

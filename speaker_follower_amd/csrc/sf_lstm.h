@@ -29,9 +29,25 @@ struct LstmStepArgs {            // fused recurrent step (sf_gemm.hip: lstm_step
     LstmPwFwd pw;                                   // outputs / state (slabs, xg, biases unused)
 };
 
+// Encoder-only operands of the cell update (row liveness at step t, previous h), fetched by the
+// caller up front with its other tail operands so that no load sits behind the gate reduction.
+struct LstmLive {
+    bool live;
+    float h0;
+};
+__device__ __forceinline__ LstmLive lstm_live_load(const LstmPwFwd& a, int b, int j) {
+    LstmLive l{true, 0.f};
+    if (a.lengths) {                                             // block-uniform
+        l.live = a.t < a.lengths[b];
+        l.h0 = a.h0[b * a.H + j];
+    }
+    return l;
+}
+
 // g4 = pre-activation gates (i,f,g,o) of element (b, j), biases already added.
 __device__ __forceinline__ void lstm_cell_update(const LstmPwFwd& a, int b, int j,
-                                                 const float (&g4)[4], float c0) {
+                                                 const float (&g4)[4], float c0,
+                                                 const LstmLive& lv) {
     const int H = a.H;
     const int idx = b * H + j;
     const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]),
@@ -43,8 +59,8 @@ __device__ __forceinline__ void lstm_cell_update(const LstmPwFwd& a, int b, int 
         gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
     }
     if (a.lengths) {
-        const bool live = a.t < a.lengths[b];
-        if (!live) { c1 = c0; h1 = a.h0[idx]; }
+        const bool live = lv.live;
+        if (!live) { c1 = c0; h1 = lv.h0; }
         float cv = live ? h1 : 0.f;
         if (live && a.ctx_drop.on()) {
             const uint32_t rk = dropout_row_key(a.ctx_drop.seed, a.ctx_drop.stream,

@@ -13,29 +13,42 @@ inline int grid1d(size_t n) { return (int)std::min<size_t>((n + TPB - 1) / TPB, 
 // -------------------------------------------------------------------------------------------------
 // LSTM pointwise forward: one thread per (row, hidden unit)
 // -------------------------------------------------------------------------------------------------
+// KS = number of split-K slabs (compile time: every slab load is issued before the first add, in
+// straight-line code).  The slabs were just written by the GEMM and sit in L2 / Infinity Cache:
+// this kernel is latency-bound, so one round trip instead of one per slab is what matters.
+template <int KS>
 __global__ __launch_bounds__(TPB) void lstm_pw_fwd_kernel(LstmPwFwd a) {
     const int H = a.H, B = a.B;
     const size_t slab = (size_t)B * 4 * H;
     for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
         const int b = idx / H, j = idx - b * H;
-        float g4[4];
-        float part[4][16];
-        // issue every slab load before the first add (ks <= 16): the slabs were just written by
-        // the split-K GEMM and sit in L2 / Infinity Cache, so this is latency- not bandwidth-bound
+        float part[4][KS > 0 ? KS : 1];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int s = 0; s < 16; ++s)
-                part[g][s] = s < a.ks ? a.slabs[s * slab + (size_t)b * 4 * H + g * H + j] : 0.f;
+            for (int s = 0; s < KS; ++s)
+                part[g][s] = a.slabs[s * slab + (size_t)b * 4 * H + g * H + j];
+        float bi[4], bh[4], xv[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float v = a.b_ih[g * H + j] + a.b_hh[g * H + j];
-            if (a.xg) v += a.xg[(size_t)b * 4 * H + g * H + j];
+            bi[g] = a.b_ih[g * H + j];
+            bh[g] = a.b_hh[g * H + j];
+        }
+        const float c0 = a.c0[idx];
+        const LstmLive lv = lstm_live_load(a, b, j);
+        if (a.xg) {                                              // block-uniform
 #pragma unroll
-            for (int s = 0; s < 16; ++s) v += part[g][s];
+            for (int g = 0; g < 4; ++g) xv[g] = a.xg[(size_t)b * 4 * H + g * H + j];
+        }
+        float g4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = bi[g] + bh[g] + xv[g];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) v += part[g][s];
             g4[g] = v;
         }
-        lstm_cell_update(a, b, j, g4, a.c0[idx]);
+        lstm_cell_update(a, b, j, g4, c0, lv);
     }
 }
 
@@ -241,9 +254,8 @@ __global__ __launch_bounds__(TPB) void gather_action_kernel(CandSrc s, int B, co
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
         const int c = (int)(i % n4), b = (int)(i / n4);
         const int a = act[b];
-        float4 v = f4zero();
-        if (a > 0 && s.vp[b] >= 0) v = cand_chunk(s, b, a, c);
-        reinterpret_cast<float4*>(out)[i] = v;
+        const CandRow row = cand_row(s, b, a);                   // a <= 0, padding or vp < 0: zeros
+        reinterpret_cast<float4*>(out)[i] = cand_load(row, c, a > 0 && !row.zero, n4);
     }
 }
 
@@ -347,11 +359,22 @@ __global__ __launch_bounds__(TPB) void follower_glue_kernel(FGlue g) {
     const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (b >= g.B) return;
     const int A = g.src.A;
-    const float raw = lane < A ? g.logit[(size_t)b * A + lane] : 0.f;
-    const int at = follower_glue_row(g, b, raw);
+    const FGlueIn gin = follower_glue_load(g, b);
+    const float raw = g.logit[(size_t)b * A + min(lane, A - 1)];
+    const int at = follower_glue_row(g, b, raw, gin);
     if (g.u_next) {                                              // follower.py:502
         const int n4 = (g.src.IMG + g.src.LOC) >> 2;
-        for (int c = lane; c < n4; c += 64) store_u_next(g, b, c, cand_chunk(g.src, b, at, c));
+        const CandRow row = cand_row(g.src, b, at);
+        for (int c0 = 0; c0 < n4; c0 += 64 * 9) {               // 9 straight-line loads per pass
+            float4 x[9];
+#pragma unroll
+            for (int i = 0; i < 9; ++i) x[i] = cand_load(row, c0 + lane + 64 * i, !row.zero, n4);
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                const int c = c0 + lane + 64 * i;
+                if (c < n4) store_u_next(g, b, c, x[i]);
+            }
+        }
     }
 }
 
@@ -460,8 +483,14 @@ __global__ void loss_finalize_kernel(const float* sum_cnt, int T, float* loss, f
 }  // namespace
 
 int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st) {
-    if (a.ks > 16) return SF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(lstm_pw_fwd_kernel, dim3(grid1d((size_t)a.B * a.H)), dim3(TPB), 0, st, a);
+    const dim3 grid(grid1d((size_t)a.B * a.H));
+    switch (a.ks) {
+#define SF_PW(KS) case KS: hipLaunchKernelGGL(lstm_pw_fwd_kernel<KS>, grid, dim3(TPB), 0, st, a); break;
+        SF_PW(0) SF_PW(1) SF_PW(2) SF_PW(3) SF_PW(4) SF_PW(5) SF_PW(6) SF_PW(7) SF_PW(8)
+        SF_PW(9) SF_PW(10) SF_PW(11) SF_PW(12) SF_PW(13) SF_PW(14) SF_PW(15) SF_PW(16)
+#undef SF_PW
+        default: return SF_ERR_UNSUPPORTED;
+    }
     return launch_status();
 }
 int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st) {

@@ -50,7 +50,7 @@ def workspace(device):
            torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
-        ws = torch.empty(lib.sf_workspace_bytes(), dtype=torch.uint8, device=device)
+        ws = torch.zeros(lib.sf_workspace_bytes(), dtype=torch.uint8, device=device)   # zero ONCE: sf_hip.h
         _workspaces[key] = ws
     return ws
 
