@@ -278,6 +278,26 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
                         const sf_decoder_tape* tape, const sf_follower_glue* glue,
                         const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
                         sf_stream stream);
+/* The same step, software-pipelined across steps (what a rollout over index-form observations
+ * uses).  Given h1 of step t, the visual half of step t+1 (linear_in_h, W_v^T t, visual attention:
+ * model.py:389 of the NEXT call) does not depend on the text attention / scoring half of step t,
+ * so the two run side by side in paired launches:
+ *   head(t):  t_v, q, visual attention           -> tape->xin[:, F:2F], alpha_v
+ *   tail(t):  LSTMCell, text attention, scoring (+glue) of step t; if X_next != NULL also head(t+1)
+ *             from h1 of step t into tape_next.
+ * A rollout is head(0), tail(0; X_1), tail(1; X_2), ..., tail(S-1; NULL); results are identical to
+ * S calls of sf_attn_decoder_fwd (same kernels, same tapes: the backward entry points apply). */
+int sf_attn_decoder_head_fwd(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
+                             const float* h0, const sf_decoder_tape* tape, const sf_dropout* drop,
+                             uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream);
+int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
+                             const float* u_prev, const float* h0, const float* c0,
+                             const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
+                             const sf_decoder_tape* tape, const sf_follower_glue* glue,
+                             const sf_dropout* drop, uint32_t step_id, const sf_pano* X_next,
+                             const sf_decoder_tape* tape_next, void* ws, size_t ws_bytes,
+                             sf_stream stream);
+
 /* Per-step gradient tape: the "dY" operands of every weight-gradient product of one decoder step.
  * BPTT over S steps keeps them stacked [S][B][..]; sf_attn_decoder_wgrad then forms each weight
  * gradient ONCE with reduction depth S*B instead of S read-modify-write passes over 12 M weights. */

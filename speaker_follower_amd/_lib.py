@@ -126,6 +126,11 @@ _SIGNATURES = {
     'sf_attn_decoder_fwd': (C.c_int, [P(DecoderW), P(Pano), P(Cands), i32, i32, i32, i32, c_f, c_f,
                                       c_f, c_f, c_p, c_p, P(DecoderTape), P(FollowerGlue),
                                       P(Dropout), u32] + WS),
+    'sf_attn_decoder_head_fwd': (C.c_int, [P(DecoderW), P(Pano), i32, i32, i32, c_f, P(DecoderTape),
+                                           P(Dropout), u32] + WS),
+    'sf_attn_decoder_tail_fwd': (C.c_int, [P(DecoderW), P(Cands), i32, i32, i32, i32, c_f, c_f, c_f,
+                                           c_f, c_p, c_p, P(DecoderTape), P(FollowerGlue), P(Dropout),
+                                           u32, P(Pano), P(DecoderTape)] + WS),
     'sf_attn_decoder_bwd': (C.c_int, [P(DecoderW), P(DecoderW), P(Pano), P(Cands), i32, i32, i32,
                                       i32, c_f, c_f, c_f, P(DecoderTape), P(DecoderGTape), c_f, c_f,
                                       c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),

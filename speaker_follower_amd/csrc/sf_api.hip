@@ -1,6 +1,7 @@
 // extern "C" entry points of libsf_hip.so (see include/sf_hip.h) and the host-side sequencing of
 // kernels for the composite operators.  Nothing here allocates or synchronises.
 #include "sf_kernels.h"
+#include "sf_gemm_small.h"
 #include "sf_glue.h"
 
 using namespace sf;
@@ -423,6 +424,91 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
     // model.py:396  action logits
     return scoring_fwd_i(&w->action, cands(U), B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt,
                          tp->r, ar, st, glue, w->fold);
+}
+
+// ---- a6, software-pipelined across steps ---------------------------------------------------------------
+// head(t)   = visual half of step t: t_v, q, visual attention -> tape->xin[:, F:2F], alpha_v
+// tail(t)   = LSTM cell, text attention, scoring (+ glue) of step t, and -- when X_next is given --
+//             head(t+1) on h1 of step t, run SIDE BY SIDE with the text / scoring half in paired
+//             launches (sf_attention.hip): the two halves are independent given h1.
+int sf_attn_decoder_head_fwd(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
+                             const float* h0, const sf_decoder_tape* tp, const sf_dropout* drop,
+                             uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && X && h0 && tp && B > 0);
+    const PanoSrc xs = pano(X);
+    const int F = xs.IMG + xs.LOC;
+    return visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
+                        make_dropout(drop, 2 * step_id), F, arena(ws, ws_bytes), S(stream), w->fold);
+}
+
+static int plan_linear(const float* x, int ldx, const float* wgt, int ldw, const float* b, int M,
+                       int N, int K, Epi epi, float* y, int ldy, SmallPlan* p) {
+    Seg sg{x, ldx, wgt, ldw, K};
+    LinearOut o{};
+    o.y = y; o.ldy = ldy; o.bias = b; o.epi = epi;
+    return linear_small_plan(&sg, 1, M, N, o, p) ? SF_OK : SF_ERR_UNSUPPORTED;
+}
+
+int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
+                             const float* u_prev, const float* h0, const float* c0,
+                             const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
+                             const sf_decoder_tape* tp, const sf_follower_glue* glue,
+                             const sf_dropout* drop, uint32_t step_id, const sf_pano* X_next,
+                             const sf_decoder_tape* tn, void* ws, size_t ws_bytes,
+                             sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && U && h0 && c0 && ctx && tp && B > 0 && L > 0 && (!glue || glue_ok(U, glue)) &&
+                 (!X_next || tn));
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    const CandSrc us = cands(U);
+    const int F = us.IMG + us.LOC;
+    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+    if (u_prev) TRY(dropout_copy(u_prev, F, B, F, tp->xin, 2 * F, d_in, 0, st));
+    TRY(lstm_fwd_i(&w->lstm, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->h1, tp->c1, tp->gates,
+                   tp->cat2 + H, 2 * H, d_h, ar, st));
+    const sf_softdot_w* tw = &w->text;
+    const sf_visual_w* vw = &w->visual;
+    bool paired = X_next && !w->fold && vw->w_v_t;
+    if (paired) {
+        const PanoSrc xn = pano(X_next);
+        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1));
+        SmallPlan pa, pb;
+        // (1) t_text = W_in dropout(h1)   ||   t_v' = W_h h1 + b_h
+        const bool ok1 =
+            plan_linear(tp->cat2 + H, 2 * H, tw->w_in, H, nullptr, B, H, H, EPI_NONE, tp->t_text, H, &pa) == SF_OK &&
+            plan_linear(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, &pb) == SF_OK;
+        if (!ok1 || pair_small_small(pa, pb, st) != SF_OK) {
+            TRY(linear_plain(tp->cat2 + H, 2 * H, tw->w_in, H, nullptr, B, H, H, EPI_NONE, tp->t_text, H, ar, st));
+            TRY(linear_plain(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, ar, st));
+        }
+        // (2) text attention   ||   q' = W_v^T t_v'
+        const bool ok2 = plan_linear(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, &pa) == SF_OK;
+        if (!ok2 || pair_small_text(pa, ctx, ctx_mask, B, L, H, tp->t_text, H, tp->alpha, tp->cat2,
+                                    2 * H, ctx_row, st) != SF_OK) {
+            TRY(text_attn_fwd(ctx, ctx_mask, B, L, H, tp->t_text, H, tp->alpha, tp->cat2, 2 * H, st, ctx_row));
+            TRY(linear_plain(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, ar, st));
+        }
+        // (3) h~ = tanh(W_out [wc ; h1])   ||   visual attention of step t+1
+        float* part = B <= (int)SYNC_WORDS ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+        const bool ok3 = part && plan_linear(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H,
+                                             EPI_TANH, tp->h_tilde, H, &pb) == SF_OK;
+        if (!ok3 || pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part,
+                                   ar.tickets(), pb, st) != SF_OK) {
+            TRY(linear_plain(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H, EPI_TANH, tp->h_tilde, H, ar, st));
+            TRY(visual_attn(0, xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, st, part,
+                            part ? ar.tickets() : nullptr));
+        }
+    } else {
+        TRY(softdot_fwd_i(tw, B, L, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2,
+                          tp->t_text, ar, st, ctx_row));
+        if (X_next)
+            TRY(visual_fwd_i(vw, pano(X_next), B, H, D, tp->h1, tn->xin + F, 2 * F, tn->alpha_v,
+                             tn->t_v, tn->q, make_dropout(drop, 2 * (step_id + 1)), F, ar, st, w->fold));
+    }
+    return scoring_fwd_i(&w->action, us, B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt, tp->r, ar,
+                         st, glue, w->fold);
 }
 
 int sf_decoder_fold_build(const sf_decoder_w* w, int H, int D, int F, float* m_v, float* c_v,

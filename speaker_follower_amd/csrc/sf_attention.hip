@@ -3,6 +3,7 @@
 #include "sf_kernels.h"
 #include "sf_rows.h"
 #include "sf_glue.h"
+#include "sf_gemm_small.h"
 #ifndef LAB_VSTAMP
 #define LAB_VSTAMP(i) do {} while (0)
 #endif
@@ -139,11 +140,10 @@ struct VisSplit {
     unsigned* counter;    // [B] monotonic tickets (zero before the first launch)
 };
 
-__global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_kernel(VisArgs a, VisSplit sp) {
+__device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSplit& sp, int g, int b) {
     __shared__ float4 slots[VSP_SLOTS][VIS_CPL * 64];
     __shared__ float s_score[64];
     __shared__ int s_last;
-    const int g = blockIdx.x, b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = a.src.V;
     const int F = a.src.IMG + a.src.LOC, n4 = F >> 2;
@@ -257,6 +257,10 @@ __global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_kernel(VisArgs 
     LAB_VSTAMP(6);
 }
 
+__global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_kernel(VisArgs a, VisSplit sp) {
+    visual_split_body(a, sp, blockIdx.x, blockIdx.y);
+}
+
 // =================================================================================================
 // Text / path-context attention core (model.py:129-139): L rows of H floats, CPL = 2 (H <= 512).
 // forward : s_l = ctx_l . t (masked -> -inf), alpha = softmax, wc = sum alpha_l ctx_l
@@ -281,10 +285,9 @@ struct TxtArgs {
 };
 
 template <int RPW, int MODE>
-__global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
+__device__ __forceinline__ void text_attn_body(const TxtArgs& a, int b) {
     __shared__ float4 slots[TXT_SLOTS][TXT_CPL * 64];
     __shared__ float s_score[TXT_NW * RPW];
-    const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = a.L, n4 = a.H >> 2;
     const int bc = a.ctx_row ? a.ctx_row[b] : b;
@@ -403,6 +406,11 @@ __global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
     block_row_sum<TXT_CPL, TXT_NW, TXT_SLOTS>(p, slots, n4, [&](int c, float4 t) {
         reinterpret_cast<float4*>(orow)[c] = t;
     });
+}
+
+template <int RPW, int MODE>
+__global__ __launch_bounds__(TXT_NW * 64) void text_attn_kernel(TxtArgs a) {
+    text_attn_body<RPW, MODE>(a, blockIdx.x);
 }
 
 // =================================================================================================
@@ -546,6 +554,50 @@ __global__ __launch_bounds__(SC_NW * 64) void score_bwd_kernel(ScoreArgs a) {
     });
 }
 
+// =================================================================================================
+// Paired launches.  A decode step is a chain of dependent, latency-bound kernels that each use a
+// fraction of the chip; the visual half of step t+1 (t_v, q, visual attention: needs only h1 of
+// step t) is independent of the text / scoring half of step t.  hipGraph branches execute serially
+// on this stack and a second stream is host-bound, so two independent kernels share ONE grid:
+// blocks [0, nA) run body A, the rest body B.  Threads beyond a body's block size exit at once
+// (whole waves: a workgroup barrier only counts live waves).
+// =================================================================================================
+template <int MTA, int CPWA, int MTB, int CPWB>
+__global__ __launch_bounds__(SMALL_WAVES * 64) void pair_small_small_kernel(SmallArgs a, int gxa,
+                                                                           int na, SmallArgs b,
+                                                                           int gxb) {
+    const int bid = blockIdx.x;
+    if (bid < na)
+        small_gemm_body<MTA, CPWA>(a, bid % gxa, bid / gxa);
+    else
+        small_gemm_body<MTB, CPWB>(b, (bid - na) % gxb, (bid - na) / gxb);
+}
+
+template <int MT, int CPW, int RPW>
+__global__ __launch_bounds__(TXT_NW * 64) void pair_small_text_kernel(SmallArgs a, int gxa, int na,
+                                                                      TxtArgs t) {
+    const int bid = blockIdx.x;
+    if (bid < na) {
+        if (threadIdx.x >= SMALL_WAVES * 64) return;
+        small_gemm_body<MT, CPW>(a, bid % gxa, bid / gxa);
+    } else {
+        text_attn_body<RPW, 0>(t, bid - na);
+    }
+}
+
+template <int MT, int CPW>
+__global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArgs v, VisSplit sp,
+                                                                         int nv, SmallArgs b,
+                                                                         int gxb) {
+    const int bid = blockIdx.x;
+    if (bid < nv) {
+        if (threadIdx.x >= VSP_NW * 64) return;
+        visual_split_body(v, sp, bid & 1, bid >> 1);
+    } else {
+        small_gemm_body<MT, CPW>(b, (bid - nv) % gxb, (bid - nv) / gxb);
+    }
+}
+
 }  // namespace
 
 size_t visual_attn_split_floats(int B, int F) { return (size_t)B * 2 * (F + 64); }
@@ -635,6 +687,50 @@ int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* 
         return SF_ERR_UNSUPPORTED;
     ScoreArgs a{src, F, nullptr, nullptr, nullptr, nullptr, nullptr, 0, const_cast<float*>(dlogit), dr, dc};
     hipLaunchKernelGGL(score_bwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
+    return launch_status();
+}
+
+// ---- paired launches (host side).  SF_ERR_UNSUPPORTED = "not pairable": the caller launches the
+// two kernels one after the other instead.
+int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
+    if (!(a.mt == 1 && a.cpw == 4 && b.mt == 1 && b.cpw == 4)) return SF_ERR_UNSUPPORTED;
+    const int na = a.gx * a.gy, nb = b.gx * b.gy;
+    hipLaunchKernelGGL((pair_small_small_kernel<1, 4, 1, 4>), dim3(na + nb), dim3(SMALL_WAVES * 64), 0,
+                       st, a.args, a.gx, na, b.args, b.gx);
+    return launch_status();
+}
+
+int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, int B, int L, int H,
+                    const float* t, int ldt, float* alpha, float* wc, int ldwc,
+                    const int32_t* ctx_row, hipStream_t st) {
+    if (!(a.mt == 4 && a.cpw == 2)) return SF_ERR_UNSUPPORTED;
+    if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (ldwc & 3) || L < 1 || L > TXT_NW * 8)
+        return SF_ERR_UNSUPPORTED;
+    TxtArgs ta{ctx, mask, L, H, t, ldt, nullptr, 0, alpha, wc, ldwc, nullptr, ctx_row};
+    const int na = a.gx * a.gy;
+    const dim3 grid(na + B), block(TXT_NW * 64);
+    if (L <= TXT_NW)
+        hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 1>), grid, block, 0, st, a.args, a.gx, na, ta);
+    else if (L <= TXT_NW * 5)
+        hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 5>), grid, block, 0, st, a.args, a.gx, na, ta);
+    else
+        hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 8>), grid, block, 0, st, a.args, a.gx, na, ta);
+    return launch_status();
+}
+
+int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
+                   int ldo, const Dropout& drop, int drop_col0, float* split_part,
+                   unsigned* split_counter, const SmallPlan& b, hipStream_t st) {
+    const int F = src.IMG + src.LOC;
+    if (!(b.mt == 1 && b.cpw == 8)) return SF_ERR_UNSUPPORTED;
+    if (!split_part || !split_counter || src.V <= VSP_RPG || src.V > 2 * VSP_RPG || B > 256 ||
+        F > VIS_CPL * 256 || (F & 3) || (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) ||
+        (ldvec & 3) || (ldo & 3))
+        return SF_ERR_UNSUPPORTED;
+    VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
+    const int nv = 2 * B, nb = b.gx * b.gy;
+    hipLaunchKernelGGL((pair_vis_small_kernel<1, 8>), dim3(nv + nb), dim3(SMALL_WAVES * 64), 0, st, va,
+                       VisSplit{split_part, split_counter}, nv, b.args, b.gx);
     return launch_status();
 }
 

@@ -16,6 +16,7 @@
 // runs along that index and defines four "virtual" 16-wide tiles with stride-4 columns, which
 // the epilogue writes back as float4.
 #include "sf_gemm.h"
+#include "sf_gemm_small.h"
 #include "sf_lstm.h"
 
 #include <cstdlib>
@@ -23,15 +24,6 @@
 namespace sf {
 
 namespace {
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float comp(const float4& v, int c) {
-    return c == 0 ? v.x : (c == 1 ? v.y : (c == 2 ? v.z : v.w));
-}
 
 // ------------------------------------------------------------------------------------------------
 // NT: C[M,N] = sum_s A_s[M,K_s] * W_s[N,K_s]^T        (forward Linear; both operands K-contiguous)
@@ -467,120 +459,11 @@ __global__ __launch_bounds__(512) void gemm_nt_aresident_kernel(NtArgs a) {
 // before the first MFMA (<= CPW chunks of (1 + MT) float4 per lane), and the partial tiles meet in
 // LDS where the epilogue runs: one HBM round trip per launch, no split-K slabs, no second kernel.
 // ------------------------------------------------------------------------------------------------
-struct Seg2 {             // up to two K segments, resolved per chunk with uniform selects
-    Seg s0, s1;
-    int n0;               // chunks in s0
-    int total;            // chunks in s0 + s1
-};
-
-template <int MT, int CPW>
-struct Frags {
-    float4 b[CPW];
-    float4 a[CPW][MT];
-};
-
-template <int MT, int CPW>
-__device__ __forceinline__ void upfront_load(Frags<MT, CPW>& f, const Seg2& sg, int c_lo, int c_hi,
-                                             int n, const int (&mrow)[MT], int kk) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-        const int c = min(c_lo + i, c_hi - 1);           // clamped: surplus slots re-load a valid chunk
-        const bool second = c >= sg.n0;
-        const int lc = second ? c - sg.n0 : c;
-        const float* W = second ? sg.s1.W : sg.s0.W;
-        const float* A = second ? sg.s1.A : sg.s0.A;
-        const int ldw = second ? sg.s1.ldw : sg.s0.ldw;
-        const int lda = second ? sg.s1.lda : sg.s0.lda;
-        const int K = second ? sg.s1.K : sg.s0.K;
-        const int k = lc * 16 + 4 * kk;
-        const bool ok = k < K;                           // partial last chunk (K % 16 != 0)
-        const int kc = ok ? k : 0;
-        const float4 bv = ld4(W + (size_t)n * ldw + kc);
-        f.b[i] = ok ? bv : z;
-#pragma unroll
-        for (int t = 0; t < MT; ++t) {
-            const float4 av = ld4(A + (size_t)mrow[t] * lda + kc);
-            f.a[i][t] = ok ? av : z;
-        }
-    }
-}
-
-template <int MT, int CPW>
-__device__ __forceinline__ void upfront_mma(const Frags<MT, CPW>& f, int cnt, f32x4 (&acc)[MT]) {
-#pragma unroll
-    for (int i = 0; i < CPW; ++i) {
-        if (i < cnt) {                                   // wave-uniform
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int t = 0; t < MT; ++t)
-                    acc[t] = mfma16(comp(f.a[i][t], c), comp(f.b[i], c), acc[t]);
-        }
-    }
-}
-
-constexpr int SMALL_WAVES = 8;
-
-struct SmallArgs {
-    Seg2 sg;
-    int M, N;
-    float* y;
-    int ldy;
-    const float* bias;
-    const float* bias2;
-    int epi;
-    const float* mul;
-    float* y_pre;
-    int ldy_pre;
-    int accumulate;
-};
-
-// grid (ceil(N/16), ceil(mtiles/MT)), block 512 = 8 waves = 8 K-slices of one 16-col n-tile x MT m-tiles
+// (Seg2, Frags, upfront_load / upfront_mma, SmallArgs and the kernel body live in sf_gemm_small.h:
+// the paired launches of sf_attention.hip run the same body next to an attention body.)
 template <int MT, int CPW>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_kernel(SmallArgs a) {
-    __shared__ float s_part[SMALL_WAVES][MT][256];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int n0 = blockIdx.x * 16, m0 = blockIdx.y * (16 * MT);
-    const int li = lane & 15, kk = lane >> 4;
-    const int n = min(n0 + li, a.N - 1);
-    int mrow[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) mrow[t] = min(m0 + 16 * t + li, a.M - 1);
-
-    const int c_lo = (wave * a.sg.total) / SMALL_WAVES;
-    const int c_hi = ((wave + 1) * a.sg.total) / SMALL_WAVES;
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (c_hi > c_lo) {
-        Frags<MT, CPW> f;
-        upfront_load<MT, CPW>(f, a.sg, c_lo, c_hi, n, mrow, kk);
-        upfront_mma<MT, CPW>(f, c_hi - c_lo, acc);
-    }
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s_part[wave][t][(kk * 4 + r) * 16 + li] = acc[t][r];
-    __syncthreads();
-
-    for (int e = threadIdx.x; e < MT * 256; e += SMALL_WAVES * 64) {
-        const int t = e >> 8, rc = e & 255;
-        const int row = m0 + 16 * t + (rc >> 4), col = n0 + (rc & 15);
-        if (row >= a.M || col >= a.N) continue;
-        float v = 0.f;
-#pragma unroll
-        for (int w = 0; w < SMALL_WAVES; ++w) v += s_part[w][t][rc];
-        if (a.bias) v += a.bias[col];
-        if (a.bias2) v += a.bias2[col];
-        if (a.epi == EPI_TANH) v = tanhf(v);
-        if (a.epi == EPI_MUL) {
-            if (a.y_pre) a.y_pre[(size_t)row * a.ldy_pre + col] = v;
-            v *= a.mul[col];
-        }
-        float* o = a.y + (size_t)row * a.ldy + col;
-        *o = a.accumulate ? *o + v : v;
-    }
+    small_gemm_body<MT, CPW>(a, blockIdx.x, blockIdx.y);
 }
 
 // Fused recurrent LSTM step (nn.LSTMCell / one nn.LSTM time step): block = 16 waves = the 4 gate
@@ -902,7 +785,9 @@ static bool small_shape(int M, int N, int chunks, int* mt, int* cpw) {
     *cpw = c <= 2 ? 2 : (c <= 4 ? 4 : (c <= 8 ? 8 : 16));
     int m = std::max(1, std::min(mtiles, 32 / *cpw - 1)); // <= 32 float4 of loads per lane
     m = m >= 4 ? 4 : (m >= 2 ? 2 : 1);
-    while (m > 1 && ntiles * ceil_div(mtiles, m) < 128) m >>= 1;   // keep >= 128 blocks if possible
+    // a CU sustains only ~20-35 GB/s of loads, so what matters is the bytes ONE block pulls
+    // (16 W rows + 16*m A rows, K deep): prefer more, lighter blocks until the chip is covered
+    while (m > 1 && ntiles * ceil_div(mtiles, m) < 224) m >>= 1;
     *mt = m;
     return true;
 }
@@ -940,6 +825,49 @@ size_t linear_ws_floats(int M, int N, int Ktot) {
     return ks > 1 ? (size_t)ks * M * N : 0;
 }
 
+bool linear_small_plan(const Seg* segs, int nseg, int M, int N, const LinearOut& out,
+                       SmallPlan* plan) {
+    if (nseg < 1 || nseg > 2) return false;
+    int chunks = 0;
+    for (int s = 0; s < nseg; ++s) {
+        if (segs[s].K <= 0 || segs[s].K % 4 || segs[s].lda % 4 || segs[s].ldw % 4) return false;
+        chunks += ceil_div(segs[s].K, 16);
+    }
+    int mt, cpw;
+    if (!small_shape(M, N, chunks, &mt, &cpw)) return false;
+    SmallArgs& sa = plan->args;
+    sa = SmallArgs{};
+    sa.sg.s0 = segs[0];
+    sa.sg.n0 = ceil_div(segs[0].K, 16);
+    sa.sg.s1 = nseg == 2 ? segs[1] : segs[0];
+    sa.sg.total = chunks;
+    sa.M = M; sa.N = N; sa.y = out.y; sa.ldy = out.ldy; sa.bias = out.bias; sa.bias2 = out.bias2;
+    sa.epi = out.epi; sa.mul = out.mul; sa.y_pre = out.y_pre; sa.ldy_pre = out.ldy_pre;
+    sa.accumulate = out.accumulate;
+    plan->mt = mt;
+    plan->cpw = cpw;
+    plan->gx = ceil_div(N, 16);
+    plan->gy = ceil_div(ceil_div(M, 16), mt);
+    return true;
+}
+
+static int launch_small_plan(const SmallPlan& p, hipStream_t st) {
+    const SmallArgs& sa = p.args;
+    switch (p.mt * 32 + p.cpw) {
+        case 1 * 32 + 2: launch_small<1, 2>(sa, st); break;
+        case 1 * 32 + 4: launch_small<1, 4>(sa, st); break;
+        case 1 * 32 + 8: launch_small<1, 8>(sa, st); break;
+        case 1 * 32 + 16: launch_small<1, 16>(sa, st); break;
+        case 2 * 32 + 2: launch_small<2, 2>(sa, st); break;
+        case 2 * 32 + 4: launch_small<2, 4>(sa, st); break;
+        case 2 * 32 + 8: launch_small<2, 8>(sa, st); break;
+        case 4 * 32 + 2: launch_small<4, 2>(sa, st); break;
+        case 4 * 32 + 4: launch_small<4, 4>(sa, st); break;
+        default: return SF_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
+
 int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, float* ws,
               size_t ws_floats, hipStream_t st, float** raw_slabs, int* ksplit_out) {
     SF_CHECK_ARG(nseg >= 1 && nseg <= 3 && M > 0 && N > 0);
@@ -952,30 +880,12 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         a.seg[s] = segs[s];
         chunks += ceil_div(segs[s].K, 16);
     }
-    int mt, mblocks, ks, cpw;
-    if (!raw_slabs && nseg <= 2 && small_shape(M, N, chunks, &mt, &cpw)) {
-        SmallArgs sa{};
-        sa.sg.s0 = segs[0];
-        sa.sg.n0 = ceil_div(segs[0].K, 16);
-        sa.sg.s1 = nseg == 2 ? segs[1] : segs[0];
-        sa.sg.total = chunks;
-        sa.M = M; sa.N = N; sa.y = out.y; sa.ldy = out.ldy; sa.bias = out.bias; sa.bias2 = out.bias2;
-        sa.epi = out.epi; sa.mul = out.mul; sa.y_pre = out.y_pre; sa.ldy_pre = out.ldy_pre;
-        sa.accumulate = out.accumulate;
-        switch (mt * 32 + cpw) {
-            case 1 * 32 + 2: launch_small<1, 2>(sa, st); break;
-            case 1 * 32 + 4: launch_small<1, 4>(sa, st); break;
-            case 1 * 32 + 8: launch_small<1, 8>(sa, st); break;
-            case 1 * 32 + 16: launch_small<1, 16>(sa, st); break;
-            case 2 * 32 + 2: launch_small<2, 2>(sa, st); break;
-            case 2 * 32 + 4: launch_small<2, 4>(sa, st); break;
-            case 2 * 32 + 8: launch_small<2, 8>(sa, st); break;
-            case 4 * 32 + 2: launch_small<4, 2>(sa, st); break;
-            case 4 * 32 + 4: launch_small<4, 4>(sa, st); break;
-            default: return SF_ERR_UNSUPPORTED;
-        }
+    int mt, mblocks, ks;
+    SmallPlan sp;
+    if (!raw_slabs && linear_small_plan(segs, nseg, M, N, out, &sp)) {
+        const int rc = launch_small_plan(sp, st);
         if (ksplit_out) *ksplit_out = 1;
-        return launch_status();
+        return rc;
     }
     nt_shape(M, N, chunks, &mt, &mblocks, &ks);
     const bool slabs = ks > 1 || raw_slabs;

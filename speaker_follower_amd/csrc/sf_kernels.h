@@ -82,6 +82,16 @@ int gather_rows(const float* src, int lds, const int* idx, int n, int w, float* 
 int logprob_topk(float* logit, int ld, int N, int n, const int* n_valid, int k, int* idx,
                  float* logp, hipStream_t st);
 
+// paired launches (see sf_attention.hip); SF_ERR_UNSUPPORTED = not pairable, launch separately
+struct SmallPlan;
+int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st);
+int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, int B, int L, int H,
+                    const float* t, int ldt, float* alpha, float* wc, int ldwc,
+                    const int32_t* ctx_row, hipStream_t st);
+int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
+                   int ldo, const Dropout& drop, int drop_col0, float* split_part,
+                   unsigned* split_counter, const SmallPlan& b, hipStream_t st);
+
 struct FGlue;
 int follower_glue_fwd(const FGlue& g, hipStream_t st);
 // scoring + glue in one launch (sf_attention.hip); g.logit receives the masked logits

@@ -125,6 +125,7 @@ class FollowerEngine:
         self.iteration = 0
         self.dropout_seed = None
         self.fold_inference = False     # model.decoder_fold: correct, but measured no faster (590K vs 596K)
+        self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
 
     # ------------------------------------------------------------------------------ forward
     def rollout(self, batch, steps, feedback='argmax', train=None, finalize=True):
@@ -196,10 +197,16 @@ class FollowerEngine:
         ws = ws_args(dev)
         d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
+        pipelined = self.pipelined and fold is None
+        tapes = [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS)) for t in range(S)]
+        panos = [store.pano(batch.vp[t], batch.view[t]) for t in range(S)]
+        if pipelined:
+            call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
+                 byref(tapes[0]), d_ptr, st.site0, *ws)
         for t in range(S):
-            pano = store.pano(batch.vp[t], batch.view[t])
+            pano = panos[t]
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
-            tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
+            tp = tapes[t]
             h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
             c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
             glue = _lib.FollowerGlue(
@@ -208,9 +215,16 @@ class FollowerEngine:
                 st.tape['xin'][t + 1].data_ptr(), 2 * F, d_ptr, 2 * (st.site0 + t + 1),
                 st.ce_term[t].data_ptr(), st.live[t].data_ptr(),
                 int(st.drop_dec[1]) ^ 0x1B873593, st.site0 + t, batch.row0)
-            call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T, None,
-                 ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue), d_ptr,
-                 st.site0 + t, *ws)
+            if pipelined:
+                nxt = t + 1 < S
+                call('sf_attn_decoder_tail_fwd', byref(dw), byref(cnd), B, H, D, T, None, ptr(h0),
+                     ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue), d_ptr,
+                     st.site0 + t, byref(panos[t + 1]) if nxt else None,
+                     byref(tapes[t + 1]) if nxt else None, *ws)
+            else:
+                call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T, None,
+                     ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue),
+                     d_ptr, st.site0 + t, *ws)
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         st.logits = st.tape['logit']
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]

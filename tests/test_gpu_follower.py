@@ -257,3 +257,33 @@ def test_engine_train_mode_dropout_matches_oracle_with_same_masks(follower_modul
                                        atol=1e-5, err_msg=k)
     for m in (enc, dec):
         m.zero_grad(set_to_none=True)
+
+
+def test_pipelined_rollout_is_identical_to_step_by_step():
+    """The software-pipelined schedule (head(t+1) beside tail(t) in paired launches) runs the same
+    kernels on the same data as S calls of sf_attn_decoder_fwd: every output is bit-identical,
+    in eval mode and with dropout."""
+    from speaker_follower_amd import synth, model, features, follower
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights(9)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    fb = synth.follower_batch(seed=3, batch=23, steps=5, n_viewpoints=40, min_len=4, max_len=33, a_max=9)
+    store = features.FeatureStore(synth.feature_table(3, 40))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    for train in (False, True):
+        outs = []
+        for pipelined in (True, False):
+            eng = follower.FollowerEngine(enc, dec, store)
+            eng.pipelined = pipelined
+            eng.dropout_seed = 1234
+            with torch.no_grad():
+                st = eng.rollout(batch, 5, 'argmax', train=train)
+            outs.append((st.logits.clone(), st.actions.clone(), st.tape['alpha_v'].clone(),
+                         st.tape['alpha'].clone(), st.hs.clone(), st.loss.clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
