@@ -234,18 +234,20 @@ def main():
     from speaker_follower_amd.runtime import ptr, ws_args, struct_of
     from speaker_follower_amd import _lib
     import ctypes as C
-    xin = torch.cat((x, h0), 1).contiguous()
-    wcat = torch.cat((w4[0], w4[1]), 1).contiguous()
-    y = torch.empty(B, 4 * H, device=device)
-    reps = 50
-    for _ in range(5):
-        _lib.call('sf_linear_fwd', ptr(xin), I + H, ptr(wcat), None, B, 4 * H, I + H, 0, ptr(y),
-                  4 * H, *ws_args(device))
+    # exactly what the rollout launches for the gates: x W_ih^T + h W_hh^T as split-K slabs (the
+    # LSTM pointwise kernel adds slabs + biases); ONE kernel per call, timed with HIP events on the
+    # stream it is launched on, over `reps` back-to-back launches
+    ks = C.c_int(0)
+    reps = 100
+    for _ in range(10):
+        _lib.call('sf_linear_slabs_fwd', ptr(x), I, ptr(w4[0]), I, ptr(h0), H, ptr(w4[1]), H, B, 4 * H,
+                  C.byref(ks), *ws_args(device))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
     e0.record()
     for _ in range(reps):
-        _lib.call('sf_linear_fwd', ptr(xin), I + H, ptr(wcat), None, B, 4 * H, I + H, 0, ptr(y),
-                  4 * H, *ws_args(device))
+        _lib.call('sf_linear_slabs_fwd', ptr(x), I, ptr(w4[0]), I, ptr(h0), H, ptr(w4[1]), H, B, 4 * H,
+                  C.byref(ks), *ws_args(device))
     e1.record()
     torch.cuda.synchronize()
     gemm_ms = e0.elapsed_time(e1) / reps
@@ -257,9 +259,12 @@ def main():
         traffic = json.load(open(pmc))['hbm_bytes_per_launch']
     roofline = dict(bound='mfma', achieved=achieved, peak=157.3, unit='TFLOP/s',
                     frac=achieved / 157.3, traffic=traffic,
-                    kernel='gemm_nt_tiled_kernel<7> + reduce_slabs (decoder LSTMCell gates, '
-                           '[%d,%d]x[%d,%d]^T fp32)' % (B, I + H, 4 * H, I + H),
-                    launch_ms=gemm_ms, flops_per_launch=flops)
+                    kernel='gemm_nt_tiled_kernel<7> (decoder LSTMCell gate product '
+                           '[%d,%d]x[%d,%d]^T fp32 -> %d split-K slabs, summed by lstm_pw_fwd_kernel)'
+                           % (B, I + H, 4 * H, I + H, ks.value),
+                    launch_ms=gemm_ms, flops_per_launch=flops,
+                    note='peak = 2.4 GHz fp32 MFMA; the same MFMA stream alone sustains ~145 TFLOP/s on '
+                         'random operands (tools/exp/mfma_power.hip)')
 
     out = dict(metric='agent-steps/sec (follower rollout, batch %d)' % B, value=value,
                unit='agent-steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup,

@@ -164,6 +164,14 @@ const char* sf_last_error_string(void);
  * y[M,N] = act(x[M,K] w[N,K]^T + b);  act: 0 none, 1 tanh.  K % 4 == 0, ldx % 4 == 0. */
 int sf_linear_fwd(const float* x, int ldx, const float* w, const float* b, int M, int N, int K,
                   int act, float* y, int ldy, void* ws, size_t ws_bytes, sf_stream stream);
+/* The product alone, as split-K partial slabs (what the LSTM cell consumes: its pointwise kernel
+ * adds the slabs, the biases and applies the gates -- model.py:393): x [M,K1] w [N,K1]^T +
+ * h [M,K2] u [N,K2]^T (h, u may be NULL) -> *ksplit slabs [ksplit][M][N] at the START of the
+ * workspace (ksplit >= 1 is returned; the caller sums them).  This is the entry point bench.py
+ * times for its roofline object: exactly one launch of the gate-product kernel. */
+int sf_linear_slabs_fwd(const float* x, int ldx, const float* w, int K1, const float* h, int ldh,
+                        const float* u, int K2, int M, int N, int* ksplit, void* ws, size_t ws_bytes,
+                        sf_stream stream);
 /* dy is the gradient wrt the activation output; y is the saved output (needed for act = tanh).
  * dx [M,K] overwritten (accumulate_dx = 0) or added to; dw [N,K], db [N] accumulated. */
 int sf_linear_bwd(const float* x, int ldx, const float* w, const float* y, int ldy,

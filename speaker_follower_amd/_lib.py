@@ -105,6 +105,7 @@ _SIGNATURES = {
     'sf_status_string': (C.c_char_p, [C.c_int]),
     'sf_last_error_string': (C.c_char_p, []),
     'sf_linear_fwd': (C.c_int, [c_f, i32, c_f, c_f, i32, i32, i32, i32, c_f, i32] + WS),
+    'sf_linear_slabs_fwd': (C.c_int, [c_f, i32, c_f, i32, c_f, i32, c_f, i32, i32, i32, P(C.c_int)] + WS),
     'sf_linear_bwd': (C.c_int, [c_f, i32, c_f, c_f, i32, c_f, i32, i32, i32, i32, i32, c_f, i32,
                                 i32, c_f, c_f] + WS),
     'sf_lstm_cell_fwd': (C.c_int, [P(LstmW), i32, i32, i32, c_f, i32, c_f, c_f, c_f, c_f, c_f, c_f,

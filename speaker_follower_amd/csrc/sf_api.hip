@@ -292,6 +292,18 @@ int sf_linear_fwd(const float* x, int ldx, const float* w, const float* b, int M
                         arena(ws, ws_bytes), S(stream));
 }
 
+int sf_linear_slabs_fwd(const float* x, int ldx, const float* w, int K1, const float* h, int ldh,
+                        const float* u, int K2, int M, int N, int* ksplit, void* ws, size_t ws_bytes,
+                        sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(x && w && ksplit && ws && M > 0 && N > 0 && K1 > 0 && (!h || (u && K2 > 0)));
+    Arena ar = arena(ws, ws_bytes);
+    Seg segs[2] = {{x, ldx, w, K1, K1}, {h, ldh, u, K2, K2}};
+    LinearOut o{};
+    float* slabs = nullptr;
+    return linear_nt(segs, h ? 2 : 1, M, N, o, ar.rest(), ar.rest_n(), S(stream), &slabs, ksplit);
+}
+
 int sf_linear_bwd(const float* x, int ldx, const float* w, const float* y, int ldy, const float* dy,
                   int lddy, int M, int N, int K, int act, float* dx, int lddx, int accumulate_dx,
                   float* dw, float* db, void* ws, size_t ws_bytes, sf_stream stream) {

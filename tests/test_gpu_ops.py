@@ -275,3 +275,22 @@ def test_dropout_mask_matches_oracle_mirror(sf):
     ref = orng.dropout_mask(1234, 9, np.arange(17, 17 + B), 40 + N, 0.5)[:, 40:]
     np.testing.assert_array_equal(out.cpu().numpy(), ref)
     assert 0.4 < (ref == 0).mean() < 0.6
+
+
+def test_linear_slabs_sum_to_the_product():
+    """sf_linear_slabs_fwd: the gate product as split-K slabs (what bench.py's roofline object times)."""
+    import ctypes as C
+    from speaker_follower_amd._lib import call
+    from speaker_follower_amd.runtime import ptr, ws_args, workspace
+    g = torch.Generator().manual_seed(4)
+    M, N, K1, K2 = 100, 2048, 4352, 512
+    x, h = torch.randn(M, K1, generator=g).cuda(), torch.randn(M, K2, generator=g).cuda()
+    w, u = (torch.randn(N, K1, generator=g) * 0.02).cuda(), (torch.randn(N, K2, generator=g) * 0.02).cuda()
+    ks = C.c_int(0)
+    call('sf_linear_slabs_fwd', ptr(x), K1, ptr(w), K1, ptr(h), K2, ptr(u), K2, M, N, C.byref(ks),
+         *ws_args(x.device))
+    torch.cuda.synchronize()
+    assert ks.value >= 1
+    slabs = workspace(x.device)[:ks.value * M * N * 4].view(torch.float32).view(ks.value, M, N)
+    ref = x.double() @ w.double().T + h.double() @ u.double().T
+    torch.testing.assert_close(slabs.sum(0).double(), ref, rtol=1e-4, atol=1e-4)

@@ -1,10 +1,18 @@
+#!/bin/bash
+# On the GPU box: PMC passes over the decoder-LSTM-gate product alone (tools/gemm_only.py).
+# Separate passes per counter group (MI355X_MICROARCH.md: FETCH_SIZE costs 3 TCC slots, WRITE_SIZE 2).
 cd /tmp && export TMPDIR=/tmp
-R=$GRAFT_REPO_ROOT
-rm -rf $R/gpurun_out/pmc2 && mkdir -p $R/gpurun_out/pmc2
-REPS=40 rocprofv3 --kernel-trace --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS -d $R/gpurun_out/pmc2/a -- python3 $R/tools/gemm_only.py > $R/gpurun_out/pmc2/a.log 2>&1
-REPS=40 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_INST_CYCLES_VMEM SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES -d $R/gpurun_out/pmc2/b -- python3 $R/tools/gemm_only.py > $R/gpurun_out/pmc2/b.log 2>&1
-REPS=40 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/pmc2/c -- python3 $R/tools/gemm_only.py > $R/gpurun_out/pmc2/c.log 2>&1
-for d in a b; do f=$(find $R/gpurun_out/pmc2/$d -name "*.db" | head -1); python3 $R/tools/rocpd_pmc.py $f gemm > $R/gpurun_out/pmc2/$d.txt 2>&1; done
-f=$(find $R/gpurun_out/pmc2/c -name "*.db" | head -1); python3 $R/tools/rocpd_stats.py $f > $R/gpurun_out/pmc2/c.txt 2>&1
-find $R/gpurun_out/pmc2 -name "*.db" -delete
-tail -3 $R/gpurun_out/pmc2/a.log
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/pmc_gemm
+rm -rf $O && mkdir -p $O
+pass() { # name counters...
+  n=$1; shift
+  REPS=40 rocprofv3 --kernel-trace --pmc "$@" -d $O/$n -- python3 $R/tools/gemm_only.py > $O/$n.log 2>&1
+  f=$(find $O/$n -name "*.db" | head -1); python3 $R/tools/rocpd_pmc.py $f gemm > $O/$n.txt 2>&1; rm -rf $O/$n
+}
+pass fetch FETCH_SIZE
+pass write WRITE_SIZE
+pass sq1 GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_LDS
+pass sq2 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVES
+REPS=40 rocprofv3 --kernel-trace --stats -d $O/st -- python3 $R/tools/gemm_only.py > $O/st.log 2>&1
+f=$(find $O/st -name "*.db" | head -1); python3 $R/tools/rocpd_stats.py $f > $O/stats.txt 2>&1; rm -rf $O/st
+cat $O/fetch.txt $O/write.txt $O/sq1.txt $O/sq2.txt; head -5 $O/stats.txt
