@@ -340,7 +340,8 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
  * [S][B][..] tensors, h0_all [M,H] holds every step's incoming hidden state. */
 int sf_attn_decoder_wgrad(const sf_decoder_w* w, const sf_decoder_g* g, int M, int H, int D, int F,
                           const float* h0_all, const sf_decoder_tape* tape,
-                          const sf_decoder_gtape* gtape, sf_stream stream);
+                          const sf_decoder_gtape* gtape, void* ws, size_t ws_bytes,
+                          sf_stream stream);
 
 /* Loss bookkeeping without host syncs or atomics (deterministic order):
  * sum_cnt[t] = (sum_b term[t,b], sum_b live[t,b]) for t < T;  then, optionally after a

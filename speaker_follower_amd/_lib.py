@@ -136,7 +136,7 @@ _SIGNATURES = {
                                       i32, c_f, c_f, c_f, P(DecoderTape), P(DecoderGTape), c_f, c_f,
                                       c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),
     'sf_attn_decoder_wgrad': (C.c_int, [P(DecoderW), P(DecoderW), i32, i32, i32, i32, c_f,
-                                        P(DecoderTape), P(DecoderGTape), c_p]),
+                                        P(DecoderTape), P(DecoderGTape)] + WS),
     'sf_decoder_fold_build': (C.c_int, [P(DecoderW), i32, i32, i32, c_f, c_f, c_f, c_f] + WS),
     'sf_follower_glue_fwd': (C.c_int, [P(Cands), i32, c_f, P(FollowerGlue), c_p]),
     'sf_follower_glue_bwd': (C.c_int, [i32, i32, c_f, i64p, c_f, c_f, c_p]),

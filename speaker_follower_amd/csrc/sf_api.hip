@@ -72,6 +72,13 @@ inline bool glue_ok(const sf_cands* U, const sf_follower_glue* g) {
 #define NEED(ptr) \
     if (!(ptr)) return SF_ERR_WORKSPACE
 
+// b_ih and b_hh of an LSTM have the same gradient (the column sums of dgates): one pass, two outputs
+int colsum_pair(const float* Y, int ldy, int M, int N, float* a, float* b, Arena ar, hipStream_t st) {
+    float* first = a ? a : b;
+    if (!first) return SF_OK;
+    return colsum(Y, ldy, M, N, first, 1, st, (a && b) ? b : nullptr, ar.rest(), ar.rest_n());
+}
+
 int linear_plain(const float* x, int ldx, const float* w, int ldw, const float* b, int M, int N,
                  int K, Epi epi, float* y, int ldy, Arena ar, hipStream_t st) {
     Seg sg{x, ldx, w, ldw, K};
@@ -132,10 +139,9 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
     if (dx) TRY(data_grad(dgates, 4 * H, w->w_ih, w->w_ih_t, B, 4 * H, I, dx, lddx, 0, ar, st));
     if (dh0) TRY(data_grad(dgates, 4 * H, w->w_hh, w->w_hh_t, B, 4 * H, H, dh0, H, 0, ar, st));
     if (g) {
-        if (g->w_ih) TRY(gemm_tn(dgates, 4 * H, x, ldx, B, 4 * H, I, g->w_ih, I, 1, st));
-        if (g->w_hh) TRY(gemm_tn(dgates, 4 * H, h0, H, B, 4 * H, H, g->w_hh, H, 1, st));
-        if (g->b_ih) TRY(colsum(dgates, 4 * H, B, 4 * H, g->b_ih, 1, st));
-        if (g->b_hh) TRY(colsum(dgates, 4 * H, B, 4 * H, g->b_hh, 1, st));
+        if (g->w_ih) TRY(gemm_tn(dgates, 4 * H, x, ldx, B, 4 * H, I, g->w_ih, I, 1, st, ar.rest(), ar.rest_n()));
+        if (g->w_hh) TRY(gemm_tn(dgates, 4 * H, h0, H, B, 4 * H, H, g->w_hh, H, 1, st, ar.rest(), ar.rest_n()));
+        TRY(colsum_pair(dgates, 4 * H, B, 4 * H, g->b_ih, g->b_hh, ar, st));
     }
     return SF_OK;
 }
@@ -173,11 +179,11 @@ int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, i
     NEED(dq && dt);
     TRY(visual_attn(1, X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0, st));
     TRY(linear_plain(dq, F, w->w_v, F, nullptr, B, D, F, EPI_NONE, dt, D, ar, st));
-    if (g && g->w_v) TRY(gemm_tn(t_v, D, dq, F, B, D, F, g->w_v, F, 1, st));
+    if (g && g->w_v) TRY(gemm_tn(t_v, D, dq, F, B, D, F, g->w_v, F, 1, st, ar.rest(), ar.rest_n()));
     // g->b_v: the bias shifts all V scores of a row equally; its gradient is identically zero.
     if (dh) TRY(data_grad(dt, D, w->w_h, w->w_h_t, B, D, H, dh, H, 1, ar, st));
-    if (g && g->w_h) TRY(gemm_tn(dt, D, h, H, B, D, H, g->w_h, H, 1, st));
-    if (g && g->b_h) TRY(colsum(dt, D, B, D, g->b_h, 1, st));
+    if (g && g->w_h) TRY(gemm_tn(dt, D, h, H, B, D, H, g->w_h, H, 1, st, ar.rest(), ar.rest_n()));
+    if (g && g->b_h) TRY(colsum(dt, D, B, D, g->b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
     return SF_OK;
 }
 
@@ -206,11 +212,11 @@ int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, in
     NEED(dpre && dcat2 && dt);
     TRY(tanh_bwd(h_tilde, H, dh_tilde, H, B, H, dpre, H, st));
     TRY(data_grad(dpre, H, w->w_out, w->w_out_t, B, H, 2 * H, dcat2, 2 * H, 0, ar, st));
-    if (g && g->w_out) TRY(gemm_tn(dpre, H, cat2, 2 * H, B, H, 2 * H, g->w_out, 2 * H, 1, st));
+    if (g && g->w_out) TRY(gemm_tn(dpre, H, cat2, 2 * H, B, H, 2 * H, g->w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
     TRY(text_attn_bwd(ctx, B, L, H, dcat2, 2 * H, t_text, H, alpha, dt, H, dctx, st));
     TRY(add2(dcat2 + H, 2 * H, nullptr, 0, B, H, dh, lddh, st));
     TRY(data_grad(dt, H, w->w_in, w->w_in_t, B, H, H, dh, lddh, 1, ar, st));
-    if (g && g->w_in) TRY(gemm_tn(dt, H, cat2 + H, 2 * H, B, H, H, g->w_in, H, 1, st));
+    if (g && g->w_in) TRY(gemm_tn(dt, H, cat2 + H, 2 * H, B, H, H, g->w_in, H, 1, st, ar.rest(), ar.rest_n()));
     return SF_OK;
 }
 
@@ -254,15 +260,15 @@ int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U
     TRY(linear_plain(dr, F, w->w_a, F, nullptr, B, D, F, EPI_NONE, dwt, D, ar, st));
     TRY(rank1_add(dc, w->b_a, B, D, dwt, D, st));
     if (g) {
-        if (g->w_a) TRY(gemm_tn(wt, D, dr, F, B, D, F, g->w_a, F, 1, st));
+        if (g->w_a) TRY(gemm_tn(wt, D, dr, F, B, D, F, g->w_a, F, 1, st, ar.rest(), ar.rest_n()));
         if (g->b_a) TRY(dot_rows_accum(dc, wt, D, B, D, g->b_a, st));
         if (g->b_out) TRY(sum_accum(dc, B, g->b_out, st));
         if (g->w_out) TRY(colsum_prod(dwt, D, t_a, D, B, D, g->w_out, st));
     }
     TRY(scale_cols(dwt, D, w->w_out, B, D, dta, D, st));
     if (dh) TRY(data_grad(dta, D, w->w_h, w->w_h_t, B, D, H, dh, H, 0, ar, st));
-    if (g && g->w_h) TRY(gemm_tn(dta, D, h, H, B, D, H, g->w_h, H, 1, st));
-    if (g && g->b_h) TRY(colsum(dta, D, B, D, g->b_h, 1, st));
+    if (g && g->w_h) TRY(gemm_tn(dta, D, h, H, B, D, H, g->w_h, H, 1, st, ar.rest(), ar.rest_n()));
+    if (g && g->b_h) TRY(colsum(dta, D, B, D, g->b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
     return SF_OK;
 }
 
@@ -322,8 +328,8 @@ int sf_linear_bwd(const float* x, int ldx, const float* w, const float* y, int l
         ldp = N;
     }
     if (dx) TRY(gemm_nn_ws(dpre, ldp, w, K, M, K, N, dx, lddx, accumulate_dx, ar.rest(), ar.rest_n(), st));
-    if (dw) TRY(gemm_tn(dpre, ldp, x, ldx, M, N, K, dw, K, 1, st));
-    if (db) TRY(colsum(dpre, ldp, M, N, db, 1, st));
+    if (dw) TRY(gemm_tn(dpre, ldp, x, ldx, M, N, K, dw, K, 1, st, ar.rest(), ar.rest_n()));
+    if (db) TRY(colsum(dpre, ldp, M, N, db, 1, st, nullptr, ar.rest(), ar.rest_n()));
     return SF_OK;
 }
 
@@ -585,29 +591,29 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
 // All weight gradients of S stacked decoder steps, each as ONE product of reduction depth M = S*B.
 int sf_attn_decoder_wgrad(const sf_decoder_w* w, const sf_decoder_g* g, int M, int H, int D, int F,
                           const float* h0_all, const sf_decoder_tape* tp, const sf_decoder_gtape* gt,
-                          sf_stream stream) {
+                          void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && g && h0_all && tp && gt && M > 0);
     hipStream_t st = S(stream);
+    Arena ar = arena(ws, ws_bytes);
     // LSTMCell (model.py:393)
-    if (g->lstm.w_ih) TRY(gemm_tn(gt->dgates, 4 * H, tp->xin, 2 * F, M, 4 * H, 2 * F, g->lstm.w_ih, 2 * F, 1, st));
-    if (g->lstm.w_hh) TRY(gemm_tn(gt->dgates, 4 * H, h0_all, H, M, 4 * H, H, g->lstm.w_hh, H, 1, st));
-    if (g->lstm.b_ih) TRY(colsum(gt->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, 1, st));
-    if (g->lstm.b_hh) TRY(colsum(gt->dgates, 4 * H, M, 4 * H, g->lstm.b_hh, 1, st));
+    if (g->lstm.w_ih) TRY(gemm_tn(gt->dgates, 4 * H, tp->xin, 2 * F, M, 4 * H, 2 * F, g->lstm.w_ih, 2 * F, 1, st, ar.rest(), ar.rest_n()));
+    if (g->lstm.w_hh) TRY(gemm_tn(gt->dgates, 4 * H, h0_all, H, M, 4 * H, H, g->lstm.w_hh, H, 1, st, ar.rest(), ar.rest_n()));
+    TRY(colsum_pair(gt->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
     // visual attention (model.py:389)
-    if (g->visual.w_v) TRY(gemm_tn(tp->t_v, D, gt->dq, F, M, D, F, g->visual.w_v, F, 1, st));
-    if (g->visual.w_h) TRY(gemm_tn(gt->dt_v, D, h0_all, H, M, D, H, g->visual.w_h, H, 1, st));
-    if (g->visual.b_h) TRY(colsum(gt->dt_v, D, M, D, g->visual.b_h, 1, st));
+    if (g->visual.w_v) TRY(gemm_tn(tp->t_v, D, gt->dq, F, M, D, F, g->visual.w_v, F, 1, st, ar.rest(), ar.rest_n()));
+    if (g->visual.w_h) TRY(gemm_tn(gt->dt_v, D, h0_all, H, M, D, H, g->visual.w_h, H, 1, st, ar.rest(), ar.rest_n()));
+    if (g->visual.b_h) TRY(colsum(gt->dt_v, D, M, D, g->visual.b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
     // text attention (model.py:395)
-    if (g->text.w_out) TRY(gemm_tn(gt->dpre, H, tp->cat2, 2 * H, M, H, 2 * H, g->text.w_out, 2 * H, 1, st));
-    if (g->text.w_in) TRY(gemm_tn(gt->dt_text, H, tp->cat2 + H, 2 * H, M, H, H, g->text.w_in, H, 1, st));
+    if (g->text.w_out) TRY(gemm_tn(gt->dpre, H, tp->cat2, 2 * H, M, H, 2 * H, g->text.w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
+    if (g->text.w_in) TRY(gemm_tn(gt->dt_text, H, tp->cat2 + H, 2 * H, M, H, H, g->text.w_in, H, 1, st, ar.rest(), ar.rest_n()));
     // action scoring (model.py:396)
-    if (g->action.w_a) TRY(gemm_tn(tp->wt, D, gt->dr, F, M, D, F, g->action.w_a, F, 1, st));
+    if (g->action.w_a) TRY(gemm_tn(tp->wt, D, gt->dr, F, M, D, F, g->action.w_a, F, 1, st, ar.rest(), ar.rest_n()));
     if (g->action.b_a) TRY(dot_rows_accum(gt->dc, tp->wt, D, M, D, g->action.b_a, st));
     if (g->action.b_out) TRY(sum_accum(gt->dc, M, g->action.b_out, st));
     if (g->action.w_out) TRY(colsum_prod(gt->dwt, D, tp->t_a, D, M, D, g->action.w_out, st));
-    if (g->action.w_h) TRY(gemm_tn(gt->dta, D, tp->h_tilde, H, M, D, H, g->action.w_h, H, 1, st));
-    if (g->action.b_h) TRY(colsum(gt->dta, D, M, D, g->action.b_h, 1, st));
+    if (g->action.w_h) TRY(gemm_tn(gt->dta, D, tp->h_tilde, H, M, D, H, g->action.w_h, H, 1, st, ar.rest(), ar.rest_n()));
+    if (g->action.b_h) TRY(colsum(gt->dta, D, M, D, g->action.b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
     return SF_OK;
 }
 
@@ -697,8 +703,8 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
     if (d_init) {
         TRY(tanh_bwd(decoder_init, H, d_init, H, B, H, dpre, H, st));
         TRY(data_grad(dpre, H, w->w_e2d, w->w_e2d_t, B, H, H, dh, H, 0, ar, st));
-        if (g && g->w_e2d) TRY(gemm_tn(dpre, H, tp->hs + T * BH, H, B, H, H, g->w_e2d, H, 1, st));
-        if (g && g->b_e2d) TRY(colsum(dpre, H, B, H, g->b_e2d, 1, st));
+        if (g && g->w_e2d) TRY(gemm_tn(dpre, H, tp->hs + T * BH, H, B, H, H, g->w_e2d, H, 1, st, ar.rest(), ar.rest_n()));
+        if (g && g->b_e2d) TRY(colsum(dpre, H, B, H, g->b_e2d, 1, st, nullptr, ar.rest(), ar.rest_n()));
     } else {
         TRY(fill(dh, BH, 0.f, st));
     }
@@ -706,27 +712,22 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
     const Dropout dd = make_dropout(drop, drop_stream);
     // dgates for step t overwrite tp->xg[t] (the hoisted product is dead after the forward)
     for (int t = T - 1; t >= 0; --t) {
-        const float* dctx_in = nullptr;
-        if (dctx) {
-            TRY(ctx_grad_slice(dctx, T, H, B, t, dd, dctx_t, st));
-            dctx_in = dctx_t;
-        }
+        // two dependent launches per step: the cell backward reads dctx[:, t, :] itself and leaves
+        // the pass-through of dead rows IN dh (element-wise in place), then dh += dgates W_hh
         LstmPwBwd p{};
         p.gates = tp->gates + t * BG; p.c0 = tp->cs + t * BH; p.c1 = tp->cs + (t + 1) * BH;
-        p.dh1 = dh; p.dh1_b = dctx_in; p.dc1 = dc; p.B = B; p.H = H;
-        p.dgates = tp->xg + t * BG; p.dc0 = dcn; p.lengths = lengths; p.t = t; p.dh0_pass = dpass;
+        p.dh1 = dh; p.dh1_b = nullptr; p.dc1 = dc; p.B = B; p.H = H;
+        p.dgates = tp->xg + t * BG; p.dc0 = dcn; p.lengths = lengths; p.t = t; p.dh0_pass = dh;
+        p.dctx = dctx; p.T = T; p.ctx_drop = dd;
         TRY(lstm_pointwise_bwd(p, st));
-        // dh_{t} = dgates W_hh (live rows) + passthrough (dead rows)
-        TRY(add2(dpass, H, nullptr, 0, B, H, dh, H, st));
         TRY(data_grad(tp->xg + t * BG, 4 * H, w->lstm.w_hh, w->lstm.w_hh_t, B, 4 * H, H, dh, H, 1, ar, st));
         std::swap(dc, dcn);
     }
     if (g) {
         // all time steps in one product each: reduction depth T*B
-        if (g->lstm.w_hh) TRY(gemm_tn(tp->xg, 4 * H, tp->hs, H, T * B, 4 * H, H, g->lstm.w_hh, H, 1, st));
-        if (g->lstm.w_ih) TRY(gemm_tn(tp->xg, 4 * H, tp->emb, E, T * B, 4 * H, E, g->lstm.w_ih, E, 1, st));
-        if (g->lstm.b_ih) TRY(colsum(tp->xg, 4 * H, T * B, 4 * H, g->lstm.b_ih, 1, st));
-        if (g->lstm.b_hh) TRY(colsum(tp->xg, 4 * H, T * B, 4 * H, g->lstm.b_hh, 1, st));
+        if (g->lstm.w_hh) TRY(gemm_tn(tp->xg, 4 * H, tp->hs, H, T * B, 4 * H, H, g->lstm.w_hh, H, 1, st, ar.rest(), ar.rest_n()));
+        if (g->lstm.w_ih) TRY(gemm_tn(tp->xg, 4 * H, tp->emb, E, T * B, 4 * H, E, g->lstm.w_ih, E, 1, st, ar.rest(), ar.rest_n()));
+        TRY(colsum_pair(tp->xg, 4 * H, T * B, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
     }
     return SF_OK;
 }
@@ -803,8 +804,8 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
     NEED(dht && dh1d && dh1m);
     // dlogit [B,ldv] has zeros in its padding columns
     TRY(gemm_nn_ws(dlogit, ldv, w->w_out, H, B, H, vocab, dht, H, 0, ar.rest(), ar.rest_n(), st));
-    if (g && g->w_out) TRY(gemm_tn(dlogit, ldv, tp->h_tilde, H, B, vocab, H, g->w_out, H, 1, st));
-    if (g && g->b_out) TRY(colsum(dlogit, ldv, B, vocab, g->b_out, 1, st));
+    if (g && g->w_out) TRY(gemm_tn(dlogit, ldv, tp->h_tilde, H, B, vocab, H, g->w_out, H, 1, st, ar.rest(), ar.rest_n()));
+    if (g && g->b_out) TRY(colsum(dlogit, ldv, B, vocab, g->b_out, 1, st, nullptr, ar.rest(), ar.rest_n()));
     TRY(softdot_bwd_i(&w->attn, g ? &g->attn : nullptr, B, Tp, H, ctx, tp->alpha, tp->cat2,
                       tp->t_text, tp->h_tilde, dht, dh1d, H, dctx, ar, st));
     TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));

@@ -48,10 +48,13 @@ int gemm_nn(const float* A, int lda, const float* W, int ldw, int M, int N, int 
             int ldy, int accumulate, hipStream_t st);
 
 // out[P,Q] (+)= Y[M,P]^T * X[M,Q]   (weight gradients; ldy % 4 == 0, ldx % 4 == 0, Q % 4 == 0)
+// ws (optional): scratch for splitting a deep reduction over M into up to 16 slabs of [P,Q]
 int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int Q, float* out,
-            int ldo, int accumulate, hipStream_t st);
+            int ldo, int accumulate, hipStream_t st, float* ws = nullptr, size_t ws_floats = 0);
 
 // out[N] (+)= sum_m Y[m, n]         (bias gradients)
-int colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, hipStream_t st);
+// out2 (optional) receives the same sums; ws (optional) lets a deep reduction be split over M
+int colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, hipStream_t st,
+           float* out2 = nullptr, float* ws = nullptr, size_t ws_floats = 0);
 
 }  // namespace sf

@@ -629,6 +629,7 @@ struct TnArgs {
     float* out;
     int ldo;
     int accumulate;
+    int msplit;            // > 1: block z reduces rows [z*M/msplit, (z+1)*M/msplit) into slab z of `out`
 };
 
 __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
@@ -637,6 +638,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     const int q0 = (blockIdx.x * 4 + wave) * 64;
     if (q0 >= a.Q) return;
     const int p0 = blockIdx.y * 64;
+    if (a.msplit > 1) {    // row range of this split; its slab is a dense [P, Q] matrix
+        const int z = blockIdx.z;
+        const int m_lo = (int)(((long)z * a.M) / a.msplit), m_hi = (int)(((long)(z + 1) * a.M) / a.msplit);
+        a.Y += (size_t)m_lo * a.ldy;
+        a.X += (size_t)m_lo * a.ldx;
+        a.M = m_hi - m_lo;
+        a.out += (size_t)z * a.P * a.ldo;
+    }
     const int li = lane & 15, kk = lane >> 4;
     const int pc = p0 + 4 * li;                 // Y columns pc..pc+3 (must be readable: ldy padded)
     const int qc = q0 + 4 * li;
@@ -735,23 +744,51 @@ __global__ __launch_bounds__(256) void reduce_slabs_kernel(RedArgs a) {
     }
 }
 
-// out[n] (+)= sum_m Y[m,n]: block = 64 columns x 16 row groups, coalesced 256-B row segments
+// out[n] (+)= sum_m Y[m,n]: block = 64 columns x 16 row groups, coalesced 256-B row segments.
+// grid (ceil(N/64), msplit): with msplit > 1 block (x, z) sums rows [z*M/msplit, ...) into
+// part[z][n] and a second tiny launch adds the parts (deterministic).  out2 (optional) receives
+// the same sums (LSTM: b_ih and b_hh have the same gradient).
 __global__ __launch_bounds__(1024) void colsum_kernel(const float* Y, int ldy, int M, int N,
-                                                      float* out, int accumulate) {
+                                                      float* out, float* out2, int accumulate,
+                                                      int msplit, float* part) {
     __shared__ float s_p[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (n < N)
-        for (int m = g; m < M; m += 16) s += Y[(size_t)m * ldy + n];
-    s_p[g][c] = s;
+    const int z = blockIdx.y;
+    const int m_lo = (int)(((long)z * M) / msplit), m_hi = (int)(((long)(z + 1) * M) / msplit);
+    const int nc = min(n, N - 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;      // 4 independent loads in flight per thread
+    int m = m_lo + g;
+    for (; m + 48 < m_hi; m += 64) {
+        s0 += Y[(size_t)m * ldy + nc];
+        s1 += Y[(size_t)(m + 16) * ldy + nc];
+        s2 += Y[(size_t)(m + 32) * ldy + nc];
+        s3 += Y[(size_t)(m + 48) * ldy + nc];
+    }
+    for (; m < m_hi; m += 16) s0 += Y[(size_t)m * ldy + nc];
+    s_p[g][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && n < N) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += s_p[k][c];
-        out[n] = accumulate ? out[n] + t : t;
+        if (msplit > 1) {
+            part[(size_t)z * N + n] = t;
+        } else {
+            out[n] = accumulate ? out[n] + t : t;
+            if (out2) out2[n] = accumulate ? out2[n] + t : t;
+        }
     }
+}
+
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, int msplit, int N,
+                                                            float* out, float* out2, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float t = 0.f;
+    for (int z = 0; z < msplit; ++z) t += part[(size_t)z * N + n];
+    out[n] = accumulate ? out[n] + t : t;
+    if (out2) out2[n] = accumulate ? out2[n] + t : t;
 }
 
 int pick_ksplit(int waves_per_split, int chunks) {
@@ -1091,19 +1128,44 @@ int gemm_nn(const float* A, int lda, const float* W, int ldw, int M, int N, int 
 }
 
 int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int Q, float* out,
-            int ldo, int accumulate, hipStream_t st) {
+            int ldo, int accumulate, hipStream_t st, float* ws, size_t ws_floats) {
     SF_CHECK_ARG(M > 0 && P > 0 && Q > 0 && Q % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 &&
                  ldo % 4 == 0);
-    TnArgs a{Y, ldy, X, ldx, M, P, Q, out, ldo, accumulate};
+    // A small weight matrix with a deep reduction (e.g. [256, 2176] over 2000 stacked rows) is a
+    // handful of waves each walking all M rows: split the rows over grid.z into slabs and add them
+    // up (deterministic order) until the chip is covered.
+    const int waves = ceil_div(Q, 64) * ceil_div(P, 64);
+    int ms = std::min(16, std::max(1, 1024 / waves));
+    ms = std::min(ms, std::max(1, M / 64));
+    if (ms > 1 && (!ws || ws_floats < (size_t)ms * P * Q)) ms = 1;
+    if (ms > 1) {
+        TnArgs a{Y, ldy, X, ldx, M, P, Q, ws, Q, 0, ms};
+        dim3 grid(ceil_div(Q, 256), ceil_div(P, 64), ms);
+        hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, a);
+        RedArgs r{};
+        r.slabs = ws; r.ks = ms; r.M = P; r.N = Q; r.y = out; r.ldy = ldo; r.epi = EPI_NONE;
+        r.accumulate = accumulate;
+        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
+        return launch_status();
+    }
+    TnArgs a{Y, ldy, X, ldx, M, P, Q, out, ldo, accumulate, 1};
     dim3 grid(ceil_div(Q, 256), ceil_div(P, 64));
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, a);
     return launch_status();
 }
 
-int colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, hipStream_t st) {
+int colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, hipStream_t st,
+           float* out2, float* ws, size_t ws_floats) {
     SF_CHECK_ARG(M > 0 && N > 0);
-    hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, Y, ldy, M, N, out,
-                       accumulate);
+    const int nb = ceil_div(N, 64);
+    int ms = std::min(32, std::max(1, 256 / nb));
+    ms = std::min(ms, std::max(1, M / 64));
+    if (ms > 1 && (!ws || ws_floats < (size_t)ms * N)) ms = 1;
+    hipLaunchKernelGGL(colsum_kernel, dim3(nb, ms), dim3(1024), 0, st, Y, ldy, M, N, out, out2,
+                       accumulate, ms, ws);
+    if (ms > 1)
+        hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, ws, ms, N,
+                           out, out2, accumulate);
     return launch_status();
 }
 

@@ -43,6 +43,9 @@ struct LstmPwBwd {
     float* dc0;                  // [B,H]
     const int* lengths; int t;   // encoder: dead rows pass dh1/dc1 through untouched, dgates = 0
     float* dh0_pass;             // encoder: for dead rows dh0 = dh1 (written here), live rows 0
+                                 // (may alias dh1: element-wise in place)
+    const float* dctx; int T;    // encoder: + dropout-masked dctx[b, t, :] (row stride T*H), or null
+    Dropout ctx_drop;
 };
 int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st);
 

@@ -57,28 +57,37 @@ __global__ __launch_bounds__(TPB) void lstm_pw_bwd_kernel(LstmPwBwd a) {
     const int H = a.H, B = a.B;
     for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
         const int b = idx / H, j = idx - b * H;
-        float dh = 0.f;
-        if (a.dh1) dh += a.dh1[idx];
-        if (a.dh1_b) dh += a.dh1_b[idx];
-        float dc = a.dc1 ? a.dc1[idx] : 0.f;
-        float* dg = a.dgates + (size_t)b * 4 * H + j;
-        if (a.lengths && a.t >= a.lengths[b]) {      // packed sequence: step did not happen
-            dg[0] = 0.f; dg[H] = 0.f; dg[2 * H] = 0.f; dg[3 * H] = 0.f;
-            a.dc0[idx] = dc;
-            if (a.dh0_pass) a.dh0_pass[idx] = dh;
-            continue;
-        }
+        // all operands first (block-uniform branches around optional ones), then the arithmetic
         const float* gp = a.gates + (size_t)b * 4 * H + j;
         const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
-        const float tc = tanhf(a.c1[idx]);
+        const float c1 = a.c1[idx], c0 = a.c0[idx];
+        float dh = 0.f, dc = 0.f;
+        if (a.dh1) dh = a.dh1[idx];
+        if (a.dh1_b) dh += a.dh1_b[idx];
+        if (a.dc1) dc = a.dc1[idx];
+        bool dead = false;
+        if (a.lengths) dead = a.t >= a.lengths[b];
+        if (a.dctx) {                                     // encoder: gradient of ctx[b, t, :]
+            float v = a.dctx[((size_t)b * a.T + a.t) * H + j];
+            if (a.ctx_drop.on()) {
+                const uint32_t rk = dropout_row_key(a.ctx_drop.seed, a.ctx_drop.stream,
+                                                    (uint32_t)(a.ctx_drop.row0 + b));
+                v = dropout_keep(rk, (uint32_t)(a.t * H + j), a.ctx_drop.thresh)
+                        ? v * a.ctx_drop.scale : 0.f;
+            }
+            dh += v;
+        }
+        float* dg = a.dgates + (size_t)b * 4 * H + j;
+        const float tc = tanhf(c1);
         const float dout = dh * tc;
-        dc += dh * og * (1.f - tc * tc);
-        dg[0] = dc * gg * ig * (1.f - ig);
-        dg[H] = dc * a.c0[idx] * fg * (1.f - fg);
-        dg[2 * H] = dc * ig * (1.f - gg * gg);
-        dg[3 * H] = dout * og * (1.f - og);
-        a.dc0[idx] = dc * fg;
-        if (a.dh0_pass) a.dh0_pass[idx] = 0.f;
+        const float dcl = dc + dh * og * (1.f - tc * tc);
+        // packed sequence: a step that did not happen passes dh / dc through, dgates = 0
+        dg[0] = dead ? 0.f : dcl * gg * ig * (1.f - ig);
+        dg[H] = dead ? 0.f : dcl * c0 * fg * (1.f - fg);
+        dg[2 * H] = dead ? 0.f : dcl * ig * (1.f - gg * gg);
+        dg[3 * H] = dead ? 0.f : dout * og * (1.f - og);
+        a.dc0[idx] = dead ? dc : dcl * fg;
+        if (a.dh0_pass) a.dh0_pass[idx] = dead ? dh : 0.f;
     }
 }
 

@@ -337,7 +337,7 @@ class FollowerEngine:
         tp0 = _lib.DecoderTape(*(st.tape[k].data_ptr() for k in _TAPE_KEYS))
         gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys))
         call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
-             byref(gt0), ws[2])
+             byref(gt0), *ws)
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
         ew, eg = _encoder_structs(enc), _encoder_structs(enc, grad=True)
         call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
