@@ -488,7 +488,7 @@ int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, in
                    tp->cat2 + H, 2 * H, d_h, ar, st));
     const sf_softdot_w* tw = &w->text;
     const sf_visual_w* vw = &w->visual;
-    bool paired = X_next && !w->fold && vw->w_v_t;
+    bool paired = X_next && vw->w_v_t;     // (a scoring fold, if any, is applied by scoring_fwd_i)
     if (paired) {
         const PanoSrc xn = pano(X_next);
         const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1));

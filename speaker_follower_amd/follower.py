@@ -197,7 +197,7 @@ class FollowerEngine:
         ws = ws_args(dev)
         d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
-        pipelined = self.pipelined and fold is None
+        pipelined = self.pipelined
         tapes = [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS)) for t in range(S)]
         panos = [store.pano(batch.vp[t], batch.view[t]) for t in range(S)]
         if pipelined:

@@ -287,3 +287,64 @@ def test_pipelined_rollout_is_identical_to_step_by_step():
                          st.tape['alpha'].clone(), st.hs.clone(), st.loss.clone()))
         for a, b in zip(*outs):
             assert torch.equal(a, b)
+
+
+def _rollout_vs_oracle(fb, table, enc, dec, enc_w, dec_w, steps, feedback='argmax'):
+    from speaker_follower_amd import features, follower, synth
+    from oracle import np_env, np_model
+    engine = follower.FollowerEngine(enc, dec, features.FeatureStore(table))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    with torch.no_grad():
+        st = engine.rollout(batch, steps, feedback, train=False)
+    seq, mask, lens = np_env.batch_instructions_from_encoded(fb.instr, 80, reverse=True)
+    loc = np_env.static_loc_embeddings()
+    ref = np_model.follower_rollout(enc_w, dec_w, seq, lens, mask, steps,
+                                    lambda t: np_env.dense_follower_step(table, loc, fb, t),
+                                    fb.target, feedback, synth.FULL.feat, early_exit=False)
+    n = len(ref['logits'])
+    assert np.array_equal(st.actions.cpu().numpy()[:n], ref['actions'])
+    lg = st.logits.cpu().numpy()
+    for t in range(n):
+        a = ref['logits'][t].shape[1]
+        fin = np.isfinite(ref['logits'][t])
+        assert np.array_equal(np.isfinite(lg[t][:, :a]), fin)
+        np.testing.assert_allclose(lg[t][:, :a][fin], ref['logits'][t][fin], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(float(st.loss), float(ref['loss']), rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize('case', ['single_sample', 'stop_only_and_len1', 'max_candidates', 'above_split_batch'])
+def test_engine_edge_cases_against_oracle(case):
+    """Ragged / degenerate inputs: one sample, one-token instructions next to 80-token ones, rows
+    whose only candidate is `stop`, rows that have ended before the first step, 16 candidates, and a
+    batch above 256 (the un-split attention / un-paired launch paths)."""
+    from speaker_follower_amd import synth, model
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights(21)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    nvp = 24
+    table = synth.feature_table(21, nvp)
+    if case == 'single_sample':
+        fb = synth.follower_batch(seed=1, batch=1, steps=3, n_viewpoints=nvp, min_len=5, max_len=5, a_max=4)
+        _rollout_vs_oracle(fb, table, enc, dec, enc_w, dec_w, 3)
+    elif case == 'stop_only_and_len1':
+        fb = synth.follower_batch(seed=2, batch=6, steps=4, n_viewpoints=nvp, min_len=1, max_len=80, a_max=5)
+        fb.instr[-1] = fb.instr[-1][:1]                      # a one-token instruction (+EOS)
+        fb.instr[0] = np.arange(4, 4 + 79, dtype=np.int64)   # and the longest one that fits
+        fb.a_num[:, 2] = 1                                   # row 2 can only stop
+        fb.target[:, 2] = np.where(fb.target[:, 2] >= 0, 0, -1)
+        fb.target[:, 4] = -1                                 # row 4: ended before the first step
+        for fbk in ('teacher', 'argmax'):
+            _rollout_vs_oracle(fb, table, enc, dec, enc_w, dec_w, 4, fbk)
+    elif case == 'max_candidates':
+        fb = synth.follower_batch(seed=3, batch=5, steps=3, n_viewpoints=nvp, min_len=3, max_len=30, a_max=16)
+        fb.a_num[:] = 16
+        fb.target[:] = np.where(fb.target >= 0, 15, -1)
+        _rollout_vs_oracle(fb, table, enc, dec, enc_w, dec_w, 3, 'teacher')
+    else:
+        fb = synth.follower_batch(seed=4, batch=260, steps=2, n_viewpoints=nvp, min_len=2, max_len=12, a_max=6)
+        _rollout_vs_oracle(fb, table, enc, dec, enc_w, dec_w, 2)
