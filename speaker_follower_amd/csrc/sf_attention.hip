@@ -133,10 +133,16 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
 // monotonic per-sample counter; partials are published write-through and read back with sc1
 // loads, so no cache-wide fence is needed) merges: no spinning, no extra launch.
 // -------------------------------------------------------------------------------------------------
-constexpr int VSP_NW = 6, VSP_RPG = VSP_NW * VIS_RPW, VSP_SLOTS = 3;
+constexpr int VSP_MAXG = 4;
+#ifndef SF_VIS_GROUPS
+#define SF_VIS_GROUPS 2
+#endif
+constexpr int VSP_G = SF_VIS_GROUPS;                   // workgroups per sample (2 or 4)
+constexpr int VSP_NW = VIS_NW / VSP_G, VSP_RPG = VSP_NW * VIS_RPW, VSP_SLOTS = VSP_NW < 3 ? VSP_NW : 3;
+static_assert(VSP_G == 2 || VSP_G == 4, "ticket arithmetic assumes a power of two");
 
 struct VisSplit {
-    float* part;          // [B][2][F + 64]: P | scores[32] | m, l
+    float* part;          // [B][G][F + 64]: P | scores[32] | m, l
     unsigned* counter;    // [B] monotonic tickets (zero before the first launch)
 };
 
@@ -148,7 +154,7 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
     const int V = a.src.V;
     const int F = a.src.IMG + a.src.LOC, n4 = F >> 2;
     const int pstride = F + 64;
-    float* rec = sp.part + ((size_t)b * 2 + g) * pstride;
+    float* rec = sp.part + ((size_t)b * VSP_G + g) * pstride;
     LAB_VSTAMP(0);
 
     const PanoRow prow = pano_row(a.src, b);
@@ -217,34 +223,54 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
     LAB_VSTAMP(4);
     __syncthreads();
     if (tid == 0)
-        s_last = (__hip_atomic_fetch_add(sp.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u) == 1u;
+        s_last = (__hip_atomic_fetch_add(sp.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                  (unsigned)(VSP_G - 1)) == (unsigned)(VSP_G - 1);
     __syncthreads();
     LAB_VSTAMP(5);
     if (!s_last) return;
 
-    float* r0 = sp.part + (size_t)b * 2 * pstride;
-    float* r1 = r0 + pstride;
+    float* r0 = sp.part + (size_t)b * VSP_G * pstride;
     auto ldf = [&](float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
-    const float m0 = ldf(r0 + F + 32), l0 = ldf(r0 + F + 33), m1 = ldf(r1 + F + 32), l1 = ldf(r1 + F + 33);
-    const float M = fmaxf(m0, m1);
-    const float c0 = expf(m0 - M), c1 = expf(m1 - M);          // m = -inf (empty group): c = 0, l = 0
-    const float inv = 1.0f / (l0 * c0 + l1 * c1);
+    float mg[VSP_G], lg[VSP_G];
+#pragma unroll
+    for (int k = 0; k < VSP_G; ++k) {
+        mg[k] = ldf(r0 + (size_t)k * pstride + F + 32);
+        lg[k] = ldf(r0 + (size_t)k * pstride + F + 33);
+    }
+    float M = mg[0];
+#pragma unroll
+    for (int k = 1; k < VSP_G; ++k) M = fmaxf(M, mg[k]);
+    float kk[VSP_G], L = 0.f;                                    // m = -inf (empty group): c = 0, l = 0
+#pragma unroll
+    for (int k = 0; k < VSP_G; ++k) {
+        kk[k] = expf(mg[k] - M);
+        L += lg[k] * kk[k];
+    }
+    const float inv = 1.0f / L;
     if (tid < V) {
-        const float sc = ldf((tid < VSP_RPG ? r0 : r1) + F + (tid < VSP_RPG ? tid : tid - VSP_RPG));
+        const int gk = tid / VSP_RPG;
+        const float sc = ldf(r0 + (size_t)gk * pstride + F + (tid - gk * VSP_RPG));
         a.alpha[(size_t)b * V + tid] = expf(sc - M) * inv;
     }
-    const float k0 = c0 * inv, k1 = c1 * inv;
+#pragma unroll
+    for (int k = 0; k < VSP_G; ++k) kk[k] *= inv;
     float* orow = a.out + (size_t)b * a.ldo;
     const Dropout dr = a.drop;
     const uint32_t rkey = dropout_row_key(dr.seed, dr.stream, (uint32_t)(dr.row0 + b));
-    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(r0, 0, 2 * pstride * 4, 0x00020000);
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(r0, 0, VSP_G * pstride * 4, 0x00020000);
     for (int c = tid; c < n4; c += VSP_NW * 64) {
-        const v4u uu = __builtin_amdgcn_raw_buffer_load_b128(rs0, c * 16, 0, 16);
-        const v4u ww = __builtin_amdgcn_raw_buffer_load_b128(rs0, pstride * 4 + c * 16, 0, 16);
-        const float4 u = make_float4(__uint_as_float(uu.x), __uint_as_float(uu.y), __uint_as_float(uu.z), __uint_as_float(uu.w));
-        const float4 w = make_float4(__uint_as_float(ww.x), __uint_as_float(ww.y), __uint_as_float(ww.z), __uint_as_float(ww.w));
-        float4 t = make_float4(k0 * u.x + k1 * w.x, k0 * u.y + k1 * w.y, k0 * u.z + k1 * w.z,
-                               k0 * u.w + k1 * w.w);
+        v4u pk[VSP_G];
+#pragma unroll
+        for (int k = 0; k < VSP_G; ++k)
+            pk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs0, k * pstride * 4 + c * 16, 0, 16);
+        float4 t = f4zero();
+#pragma unroll
+        for (int k = 0; k < VSP_G; ++k) {
+            t.x += kk[k] * __uint_as_float(pk[k].x);
+            t.y += kk[k] * __uint_as_float(pk[k].y);
+            t.z += kk[k] * __uint_as_float(pk[k].z);
+            t.w += kk[k] * __uint_as_float(pk[k].w);
+        }
         if (dr.on()) {
             const uint32_t col = (uint32_t)(a.drop_col0 + 4 * c);
             t.x = dropout_keep(rkey, col + 0, dr.thresh) ? t.x * dr.scale : 0.f;
@@ -592,7 +618,7 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArg
     const int bid = blockIdx.x;
     if (bid < nv) {
         if (threadIdx.x >= VSP_NW * 64) return;
-        visual_split_body(v, sp, bid & 1, bid >> 1);
+        visual_split_body(v, sp, bid % VSP_G, bid / VSP_G);
     } else {
         small_gemm_body<MT, CPW>(b, (bid - nv) % gxb, (bid - nv) / gxb);
     }
@@ -600,7 +626,7 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArg
 
 }  // namespace
 
-size_t visual_attn_split_floats(int B, int F) { return (size_t)B * 2 * (F + 64); }
+size_t visual_attn_split_floats(int B, int F) { return (size_t)B * VSP_G * (F + 64); }
 
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
                 float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st,
@@ -611,9 +637,9 @@ int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec
         return SF_ERR_UNSUPPORTED;
     VisArgs a{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
     // small batches: two workgroups per sample (see visual_attn_split_kernel)
-    if (mode == 0 && split_part && split_counter && src.V > VSP_RPG && src.V <= 2 * VSP_RPG &&
-        B <= 256) {
-        hipLaunchKernelGGL(visual_attn_split_kernel, dim3(2, B), dim3(VSP_NW * 64), 0, st, a,
+    if (mode == 0 && split_part && split_counter && src.V > (VSP_G - 1) * VSP_RPG &&
+        src.V <= VSP_G * VSP_RPG && B <= 256) {
+        hipLaunchKernelGGL(visual_attn_split_kernel, dim3(VSP_G, B), dim3(VSP_NW * 64), 0, st, a,
                            VisSplit{split_part, split_counter});
         return launch_status();
     }
@@ -723,12 +749,13 @@ int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float
                    unsigned* split_counter, const SmallPlan& b, hipStream_t st) {
     const int F = src.IMG + src.LOC;
     if (!(b.mt == 1 && b.cpw == 8)) return SF_ERR_UNSUPPORTED;
-    if (!split_part || !split_counter || src.V <= VSP_RPG || src.V > 2 * VSP_RPG || B > 256 ||
+    if (!split_part || !split_counter || src.V <= (VSP_G - 1) * VSP_RPG || src.V > VSP_G * VSP_RPG ||
+        B > 256 ||
         F > VIS_CPL * 256 || (F & 3) || (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) ||
         (ldvec & 3) || (ldo & 3))
         return SF_ERR_UNSUPPORTED;
     VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
-    const int nv = 2 * B, nb = b.gx * b.gy;
+    const int nv = VSP_G * B, nb = b.gx * b.gy;
     hipLaunchKernelGGL((pair_vis_small_kernel<1, 8>), dim3(nv + nb), dim3(SMALL_WAVES * 64), 0, st, va,
                        VisSplit{split_part, split_counter}, nv, b.args, b.gx);
     return launch_status();

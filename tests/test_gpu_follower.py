@@ -259,10 +259,11 @@ def test_engine_train_mode_dropout_matches_oracle_with_same_masks(follower_modul
         m.zero_grad(set_to_none=True)
 
 
-def test_pipelined_rollout_is_identical_to_step_by_step():
-    """The software-pipelined schedule (head(t+1) beside tail(t) in paired launches) runs the same
-    kernels on the same data as S calls of sf_attn_decoder_fwd: every output is bit-identical,
-    in eval mode and with dropout."""
+def test_pipelined_rollout_equals_step_by_step():
+    """The software-pipelined schedule (head(t+1) beside tail(t) in paired launches, the visual
+    attention in three partial passes) computes the same function as S calls of
+    sf_attn_decoder_fwd: identical actions, everything else to fp32 re-association (1e-5), in eval
+    mode and with dropout."""
     from speaker_follower_amd import synth, model, features, follower
     d = synth.FULL
     enc_w, dec_w = synth.follower_weights(9)
@@ -283,10 +284,13 @@ def test_pipelined_rollout_is_identical_to_step_by_step():
             eng.dropout_seed = 1234
             with torch.no_grad():
                 st = eng.rollout(batch, 5, 'argmax', train=train)
-            outs.append((st.logits.clone(), st.actions.clone(), st.tape['alpha_v'].clone(),
-                         st.tape['alpha'].clone(), st.hs.clone(), st.loss.clone()))
-        for a, b in zip(*outs):
-            assert torch.equal(a, b)
+            lg = st.logits.clone()
+            outs.append((st.actions.clone(), torch.isfinite(lg), torch.nan_to_num(lg, neginf=0.0),
+                         st.tape['alpha_v'].clone(), st.tape['alpha'].clone(), st.hs.clone(),
+                         st.loss.clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        for a, b in zip(outs[0][2:], outs[1][2:]):
+            torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-6)
 
 
 def _rollout_vs_oracle(fb, table, enc, dec, enc_w, dec_w, steps, feedback='argmax'):

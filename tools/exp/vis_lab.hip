@@ -1,29 +1,31 @@
 // Lab harness for the visual-attention kernels (not part of the product).
 #ifdef SF_LAB_STAMP
-#define LAB_VSTAMP(i) do { if (threadIdx.x == 0) g_vstamps[blockIdx.y * 2 + blockIdx.x][i] = wall_clock64(); } while (0)
-__device__ long long g_vstamps[512][8];
+#define LAB_VSTAMP(i) do { if (threadIdx.x == 0) g_vstamps[blockIdx.y * 4 + blockIdx.x][i] = wall_clock64(); } while (0)
+__device__ long long g_vstamps[1024][8];
 #else
 #define LAB_VSTAMP(i) do {} while (0)
 #endif
 #include "../../speaker_follower_amd/csrc/sf_attention.hip"
 #include <cstdio>
 #include <vector>
+#include <algorithm>
 namespace sf { thread_local hipError_t g_last_hip_error = hipSuccess; }
 int main(int argc, char** argv) {
-    const int B = argc > 1 ? atoi(argv[1]) : 100, NVP = 512, V = 36, IMG = 2048, LOC = 128, F = IMG + LOC;
+    const int B = argc > 1 ? atoi(argv[1]) : 100, NVP = argc > 3 ? atoi(argv[3]) : 512, V = 36, IMG = 2048, LOC = 128, F = IMG + LOC;
     const int split = argc > 2 ? atoi(argv[2]) : 1, reps = 300;
     float *table, *loc, *q, *alpha, *out, *part; int *vp, *view; unsigned* cnt;
     hipMalloc(&table, (size_t)NVP * V * IMG * 4); hipMalloc(&loc, V * V * LOC * 4); hipMalloc(&q, B * F * 4);
     hipMalloc(&alpha, B * V * 4); hipMalloc(&out, B * F * 4); hipMalloc(&part, sf::visual_attn_split_floats(B, F) * 4);
     hipMalloc(&vp, B * 4); hipMalloc(&view, B * 4); hipMalloc(&cnt, 4096); hipMemset(cnt, 0, 4096);
-    std::vector<float> h((size_t)NVP * V * IMG); unsigned s = 1;
+    std::vector<float> h((size_t)512 * V * IMG); unsigned s = 1;
     for (auto& x : h) { s = s * 1664525u + 1013904223u; x = (s >> 8) * (1.f / 16777216.f); }
-    hipMemcpy(table, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+    for (int r0 = 0; r0 < NVP; r0 += 512)      // replicate 512 random viewpoints over the table
+        hipMemcpy(table + (size_t)r0 * V * IMG, h.data(), (size_t)std::min(512, NVP - r0) * V * IMG * 4, hipMemcpyHostToDevice);
     hipMemcpy(loc, h.data(), V * V * LOC * 4, hipMemcpyHostToDevice);
     for (int i = 0; i < B * F; ++i) h[i] = 0.01f * ((i * 7919) % 101 - 50);
     hipMemcpy(q, h.data(), B * F * 4, hipMemcpyHostToDevice);
     std::vector<int> iv(B), vw(B);
-    for (int b = 0; b < B; ++b) { iv[b] = (b * 37) % NVP; vw[b] = b % 36; }
+    for (int b = 0; b < B; ++b) { iv[b] = (int)(((long)b * 7919 * 131) % NVP); vw[b] = b % 36; }
     hipMemcpy(vp, iv.data(), B * 4, hipMemcpyHostToDevice); hipMemcpy(view, vw.data(), B * 4, hipMemcpyHostToDevice);
     sf::PanoSrc src{nullptr, table, loc, vp, view, V, IMG, LOC};
     sf::Dropout dr{}; 
