@@ -392,6 +392,10 @@ typedef struct sf_spk_decoder_w {
     sf_lstm_w lstm;         /* LSTMCell(E -> H) */
     sf_softdot_w attn;
     const float *w_out, *b_out; /* decoder2action [vocab,H],[vocab] */
+    /* optional [vocab,4H] = embedding W_ih^T, refreshed by the host whenever either changes: the
+     * input half of the LSTM gates becomes a row lookup by the previous word (model.py:497 + :515)
+     * and the recurrent step is as short as the encoder's.  NULL = multiply every step. */
+    const float* xw_table;
 } sf_spk_decoder_w;
 typedef struct sf_spk_decoder_g { sf_lstm_g lstm; sf_softdot_g attn; float *w_out, *b_out; } sf_spk_decoder_g;
 typedef struct sf_spk_decoder_tape {

@@ -85,7 +85,7 @@ EncoderTape = _ptr_struct('EncoderTape', ['emb', 'xg', 'gates', 'hs', 'cs'])
 
 class SpkDecoderW(C.Structure):
     _fields_ = [('embedding', c_p), ('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p),
-                ('b_out', c_p)]
+                ('b_out', c_p), ('xw_table', c_p)]
 
 
 class SpkDecoderG(C.Structure):

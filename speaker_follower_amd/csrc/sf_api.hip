@@ -776,12 +776,24 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
     hipStream_t st = S(stream);
     const int ldv = (vocab + 3) & ~3;
     const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
-    TRY(embedding_rows(w->embedding, E, prev_word, B, tp->emb, st));             // :497-498
-    TRY(lstm_fwd_i(&w->lstm, B, E, H, tp->emb, E, h0, c0, tp->h1, tp->c1, tp->gates, tp->cat2 + H,
-                   2 * H, d_h, ar, st));                                          // :515-516
+    if (tp->emb) TRY(embedding_rows(w->embedding, E, prev_word, B, tp->emb, st));   // :497-498
+    if (w->xw_table && H % 16 == 0 && H <= 1024) {
+        // x W_ih^T is a row of the precomputed [vocab,4H] table: recurrent half only
+        LstmStepArgs f{};
+        f.h0 = h0; f.w_hh = w->lstm.w_hh; f.x = nullptr; f.xg = w->xw_table; f.xg_index = prev_word;
+        f.b_ih = w->lstm.b_ih; f.b_hh = w->lstm.b_hh; f.B = B; f.H = H;
+        LstmPwFwd& p = f.pw;
+        p.c0 = c0; p.h0 = h0; p.B = B; p.H = H; p.gates = tp->gates; p.h1 = tp->h1; p.c1 = tp->c1;
+        p.h1_drop = tp->cat2 + H; p.ld_h1_drop = 2 * H; p.drop = d_h; p.lengths = nullptr;
+        TRY(lstm_step_fused(f, st));                                              // :515-516
+    } else {
+        SF_CHECK_ARG(tp->emb);
+        TRY(lstm_fwd_i(&w->lstm, B, E, H, tp->emb, E, h0, c0, tp->h1, tp->c1, tp->gates,
+                       tp->cat2 + H, 2 * H, d_h, ar, st));                        // :515-516
+    }
     TRY(softdot_fwd_i(&w->attn, B, Tp, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2,
                       tp->t_text, ar, st, ctx_row));                              // :517
-    if (ldv != vocab) TRY(fill(tp->logit, (size_t)B * ldv, 0.f, st));
+    // (columns vocab..ldv-1 of tape->logit are padding: never read by the glue; callers slice)
     return linear_plain(tp->h_tilde, H, w->w_out, H, w->b_out, B, vocab, H, EPI_NONE, tp->logit, ldv,
                         ar, st);                                                  // :518
 }

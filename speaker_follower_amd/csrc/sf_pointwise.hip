@@ -433,11 +433,24 @@ __global__ __launch_bounds__(TPB) void speaker_glue_kernel(SGlue g) {
     const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (b >= g.B) return;
     const float* row = g.logit + (size_t)b * g.ldv;
+    // the whole row in registers with straight-line loads (vocab <= 1024 on this path), the target
+    // and its logit fetched alongside: one memory round trip instead of ~35 dependent ones
+    constexpr int NV = 16;
+    float v[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) v[i] = row[min(lane + 64 * i, g.vocab - 1)];
+    const int64_t tgt = g.target[b];
+    const float ltgt = row[min(max((int)tgt, 0), g.vocab - 1)];
     float m = -INFINITY;
     int am = 0;
-    for (int n = lane; n < g.vocab; n += 64) {
-        const float v = row[n];
-        if (v > m) { m = v; am = n; }                  // strict > keeps the lowest index per lane
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int n = lane + 64 * i;
+        if (n < g.vocab && v[i] > m) { m = v[i]; am = n; }      // strict > keeps the lowest index per lane
+    }
+    for (int n = lane + 64 * NV; n < g.vocab; n += 64) {       // (larger vocabularies: the slow way)
+        const float x = row[n];
+        if (x > m) { m = x; am = n; }
     }
     // wave arg-max with lowest-index tie break (torch.max semantics, speaker.py:169)
 #pragma unroll
@@ -447,15 +460,17 @@ __global__ __launch_bounds__(TPB) void speaker_glue_kernel(SGlue g) {
         if (om > m || (om == m && oa < am)) { m = om; am = oa; }
     }
     float s = 0.f;
-    for (int n = lane; n < g.vocab; n += 64) s += expf(row[n] - m);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) s += (lane + 64 * i < g.vocab) ? expf(v[i] - m) : 0.f;
+    for (int n = lane + 64 * NV; n < g.vocab; n += 64) s += expf(row[n] - m);
     const float lse = m + logf(wave_sum(s));
     if (lane == 0) {
-        const int64_t tgt = g.target[b];
         const int64_t w = g.feedback == 0 ? tgt : (int64_t)am;
+        const float lw = g.feedback == 0 ? ltgt : m;            // logit of the chosen word
         g.w_t[b] = w;
-        g.score[b] = (w != g.pad_idx) ? row[w] - lse : 0.f;      // speaker.py:179-180 (per-step term)
+        g.score[b] = (w != g.pad_idx) ? lw - lse : 0.f;          // speaker.py:179-180 (per-step term)
         const bool lv = tgt != g.pad_idx;
-        g.nll_term[b] = lv ? lse - row[tgt] : 0.f;               // speaker.py:182
+        g.nll_term[b] = lv ? lse - ltgt : 0.f;                   // speaker.py:182
         g.live[b] = lv ? 1.f : 0.f;
         if (w == g.eos_idx) g.ended[b] = 1;                      // speaker.py:190-191
     }

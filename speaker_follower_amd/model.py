@@ -653,7 +653,19 @@ class SpeakerDecoderLSTM(nn.Module):
             v = _grads(ps[1:])
             return _lib.SpkDecoderG(_lib.LstmW(*v[0:4]), _lib.SoftdotW(*v[4:6]), v[6], v[7])
         v = [p.data_ptr() for p in ps]
-        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5]), _lib.SoftdotW(*v[5:7]), v[7], v[8])
+        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5]), _lib.SoftdotW(*v[5:7]), v[7], v[8],
+                                self._xw_table().data_ptr())
+
+    def _xw_table(self):
+        """[vocab, 4H] = embedding W_ih^T, rebuilt when either tensor changes (optimizer steps bump
+        `_version`): the LSTM's input product becomes a row lookup by the previous word."""
+        emb, w_ih = self.embedding.weight, self.lstm.weight_ih
+        key = (emb.data_ptr(), emb._version, w_ih.data_ptr(), w_ih._version)
+        if getattr(self, '_xw_key', None) != key:
+            with torch.no_grad():
+                self._xw = ops.linear_fwd(emb.detach().contiguous(), w_ih.detach().contiguous())
+            self._xw_key = key
+        return self._xw
 
     def forward(self, previous_word, h_0, c_0, ctx, ctx_mask=None):
         require_gpu(previous_word, h_0, c_0, ctx)

@@ -83,6 +83,21 @@ class SpeakerEngine:
         self.iteration = 0
         self.dropout_seed = None
 
+    def capture(self, batch, steps, feedback='teacher'):
+        """hipGraph of one inference scoring / decoding pass: returns (replay, state); the state's
+        tensors are overwritten by every replay (same contract as FollowerEngine.capture)."""
+        with torch.no_grad():
+            self.score(batch, steps, feedback, train=False)
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                with torch.cuda.graph(graph, stream=side):
+                    st = self.score(batch, steps, feedback, train=False)
+            torch.cuda.current_stream().wait_stream(side)
+        return graph.replay, st
+
     def score(self, batch, steps, feedback='teacher', train=None):
         """Returns a SpeakerState: .words [S,B], .logits [S,B,vocab], .step_scores [S,B],
         .loss (differentiable), .ctx [B,Tp,H]."""
@@ -150,8 +165,13 @@ class SpeakerEngine:
         dw = dec._w_struct()
         d_dec = dropout_arg(*st.drop_dec)
         st.targets = batch.instr_seq[:, :S].t().contiguous()              # [S,B] (speaker.py:163)
+        params = list(ep) + [enc.encoder2decoder.weight, enc.encoder2decoder.bias] + list(dec._params9())
+        differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         for t in range(S):
-            tp = _lib.SpkDecoderTape(*(st.tape[k][t].data_ptr() for k in _DEC_TAPE))
+            # the embedded words are only kept for the backward (dW_ih); the forward looks the
+            # input product up in the [vocab,4H] table (sf_spk_decoder_w.xw_table)
+            tp = _lib.SpkDecoderTape(*(st.tape[k][t].data_ptr() if (k != 'emb' or differentiable)
+                                       else None for k in _DEC_TAPE))
             h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
             c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
             call('sf_speaker_decoder_fwd', byref(dw), B, E, H, Tp, vocab, ptr(st.words[t]), ptr(h0),
@@ -167,8 +187,7 @@ class SpeakerEngine:
         call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
         st.logits = st.tape['logit'][:, :, :vocab]
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
-        params = list(ep) + [e2d.weight, e2d.bias] + list(dec._params9())
-        if torch.is_grad_enabled() and any(p.requires_grad for p in params):
+        if differentiable:
             st.loss = _SpeakerLossFn.apply(self, st, *params)
         else:
             st.loss = st.loss_buf.clone().reshape(())
