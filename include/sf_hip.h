@@ -363,6 +363,10 @@ typedef struct sf_encoder_w {
     sf_lstm_w lstm;         /* weight_ih_l0 [4H,E] ... */
     const float *w_e2d, *b_e2d; /* encoder2decoder [H,H],[H] */
     const float *w_e2d_t;       /* optional [H,H] transposed */
+    /* optional [vocab,4H] = embedding weight_ih_l0^T (refreshed by the host when either changes):
+     * the input half of the gates of step t is then the table row of token seq[b,t] -- no
+     * [T*B,E]x[E,4H] product, no [T,B,4H] intermediate.  NULL = the product is formed every call. */
+    const float* xw_table;
 } sf_encoder_w;
 typedef struct sf_encoder_g { sf_lstm_g lstm; float *w_e2d, *b_e2d; } sf_encoder_g;
 typedef struct sf_encoder_tape { float *emb, *xg, *gates, *hs, *cs; } sf_encoder_tape;

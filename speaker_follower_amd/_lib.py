@@ -73,7 +73,8 @@ class FollowerGlue(C.Structure):
 
 
 class EncoderW(C.Structure):
-    _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p), ('w_e2d_t', c_p)]
+    _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p), ('w_e2d_t', c_p),
+                ('xw_table', c_p)]
 
 
 class EncoderG(C.Structure):

@@ -657,9 +657,11 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     const size_t BH = (size_t)B * H;
     // model.py:85  embedding, time-major so each step reads one contiguous [B,E] block
     TRY(embedding_tm(w->embedding, E, seq, B, Lpad, T, tp->emb, st));
-    // hoisted input product for all steps at once: [T*B,E] x [E,4H]
-    TRY(linear_plain(tp->emb, E, w->lstm.w_ih, E, nullptr, T * B, 4 * H, E, EPI_NONE, tp->xg, 4 * H,
-                     ar, st));
+    // input product: a row of the host's [vocab,4H] table per token, or hoisted for all steps at
+    // once ([T*B,E] x [E,4H])
+    if (!w->xw_table)
+        TRY(linear_plain(tp->emb, E, w->lstm.w_ih, E, nullptr, T * B, 4 * H, E, EPI_NONE, tp->xg,
+                         4 * H, ar, st));
     TRY(fill(tp->hs, BH, 0.f, st));   // model.py:67-79 init_state
     TRY(fill(tp->cs, BH, 0.f, st));
     const Dropout dctx = make_dropout(drop, drop_stream);
@@ -667,6 +669,11 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
         // one fused launch per time step: h_t W_hh^T on the matrix cores + gates + cell update
         LstmStepArgs f{};
         f.h0 = tp->hs + t * BH; f.w_hh = w->lstm.w_hh; f.x = nullptr; f.xg = tp->xg + (size_t)t * B * 4 * H;
+        if (w->xw_table) {                       // token lookup: seq is [B, Lpad], step t = column t
+            f.xg = w->xw_table;
+            f.xg_index = seq + t;
+            f.xg_index_ld = Lpad;
+        }
         f.b_ih = w->lstm.b_ih; f.b_hh = w->lstm.b_hh; f.B = B; f.H = H;
         LstmPwFwd& p = f.pw;
         p.c0 = tp->cs + t * BH; p.h0 = tp->hs + t * BH; p.B = B; p.H = H;

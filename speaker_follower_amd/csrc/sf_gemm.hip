@@ -499,7 +499,7 @@ __global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmS
             bh[g] = p.b_hh[g * H + pj];
         }
         if (p.xg) {                                              // block-uniform
-            const size_t xr = p.xg_index ? (size_t)p.xg_index[qb] : (size_t)qb;
+            const size_t xr = p.xg_index ? (size_t)p.xg_index[(size_t)qb * max(p.xg_index_ld, 1)] : (size_t)qb;
 #pragma unroll
             for (int g = 0; g < 4; ++g) xv[g] = p.xg[xr * 4 * H + g * H + pj];
         }

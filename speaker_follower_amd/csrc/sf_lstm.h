@@ -24,7 +24,8 @@ struct LstmStepArgs {            // fused recurrent step (sf_gemm.hip: lstm_step
     const float* h0; const float* w_hh;             // [B,H], [4H,H]
     const float* x; int ldx; const float* w_ih; int I;   // optional input segment (null if xg)
     const float* xg;                                // [B,4H] hoisted x*W_ih^T or null
-    const int64_t* xg_index;                        // optional: row b reads xg[xg_index[b]] (word lookup)
+    const int64_t* xg_index;                        // optional: row b reads xg[xg_index[b * xg_index_ld]]
+    int xg_index_ld;                                // (word lookup; 0 is read as 1)
     const float* b_ih; const float* b_hh;
     int B, H;
     LstmPwFwd pw;                                   // outputs / state (slabs, xg, biases unused)

@@ -245,7 +245,18 @@ def _encoder_structs(mod, grad=False):
         return _lib.EncoderG(_lib.LstmW(*_grads(l4)), *_grads(e2d))
     lw = _lib.LstmW(*(p.data_ptr() for p in l4), None, transposed(l4[1]).data_ptr())
     return _lib.EncoderW(mod.embedding.weight.data_ptr(), lw, *(p.data_ptr() for p in e2d),
-                         transposed(e2d[0]).data_ptr())
+                         transposed(e2d[0]).data_ptr(), _xw_table(mod, mod.embedding.weight, l4[0]).data_ptr())
+
+
+def _xw_table(mod, emb, w_ih):
+    """[vocab, 4H] = embedding W_ih^T, cached on the module and rebuilt when either tensor changes
+    (optimizer steps bump `_version`): the LSTM's input product becomes a row lookup by token."""
+    key = (emb.data_ptr(), emb._version, w_ih.data_ptr(), w_ih._version)
+    if getattr(mod, '_xw_key', None) != key:
+        with torch.no_grad():
+            mod._xw = ops.linear_fwd(emb.detach().contiguous(), w_ih.detach().contiguous())
+        mod._xw_key = key
+    return mod._xw
 
 
 class _EncoderFn(torch.autograd.Function):
