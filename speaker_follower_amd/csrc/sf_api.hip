@@ -129,14 +129,28 @@ int lstm_fwd_i(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx,
 int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, const float* x, int ldx,
                const float* h0, const float* c0, const float* c1, const float* gates,
                const float* dh1, const float* dh1_b, const float* dc1, float* dx, int lddx,
-               float* dh0, float* dc0, Arena ar, hipStream_t st, float* dgates_out = nullptr) {
+               float* dh0, float* dc0, Arena ar, hipStream_t st, float* dgates_out = nullptr,
+               int dx_col0 = 0) {          // dx is only formed for input columns >= dx_col0
     float* dgates = dgates_out ? dgates_out : ar.take((size_t)B * 4 * H);
     NEED(dgates);
     LstmPwBwd p{};
     p.gates = gates; p.c0 = c0; p.c1 = c1; p.dh1 = dh1; p.dh1_b = dh1_b; p.dc1 = dc1;
     p.B = B; p.H = H; p.dgates = dgates; p.dc0 = dc0; p.lengths = nullptr; p.dh0_pass = nullptr;
     TRY(lstm_pointwise_bwd(p, st));
-    if (dx) TRY(data_grad(dgates, 4 * H, w->w_ih, w->w_ih_t, B, 4 * H, I, dx, lddx, 0, ar, st));
+    if (dx && dx_col0 == 0) {
+        TRY(data_grad(dgates, 4 * H, w->w_ih, w->w_ih_t, B, 4 * H, I, dx, lddx, 0, ar, st));
+    } else if (dx) {
+        const int I2 = I - dx_col0;
+        if (w->w_ih_t) {
+            Seg sg{dgates, 4 * H, w->w_ih_t + (size_t)dx_col0 * 4 * H, 4 * H, 4 * H};
+            LinearOut o{};
+            o.y = dx + dx_col0; o.ldy = lddx; o.epi = EPI_NONE;
+            TRY(linear_nt(&sg, 1, B, I2, o, ar.rest(), ar.rest_n(), st));
+        } else {
+            TRY(gemm_nn_ws(dgates, 4 * H, w->w_ih + dx_col0, I, B, I2, 4 * H, dx + dx_col0, lddx, 0,
+                           ar.rest(), ar.rest_n(), st));
+        }
+    }
     if (dh0) TRY(data_grad(dgates, 4 * H, w->w_hh, w->w_hh_t, B, 4 * H, H, dh0, H, 0, ar, st));
     if (g) {
         if (g->w_ih) TRY(gemm_tn(dgates, 4 * H, x, ldx, B, 4 * H, I, g->w_ih, I, 1, st, ar.rest(), ar.rest_n()));
@@ -582,7 +596,8 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
     TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
     TRY(lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->c1,
                    tp->gates, dh1, dh1m, dc1, dxin, 2 * F, dh0, dc0, ar, st,
-                   gt ? gt->dgates : nullptr));
+                   gt ? gt->dgates : nullptr, F));      // u_prev is detached (follower.py:502): only
+                                                        // the feature half of d(LSTM input) is needed
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                         dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
                         gt ? gt->dt_v : nullptr);
