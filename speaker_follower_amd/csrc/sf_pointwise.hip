@@ -156,10 +156,17 @@ __global__ __launch_bounds__(1024) void colsum_prod_kernel(const float* a, int l
     __shared__ float s_p[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (n < N)
-        for (int m = g; m < M; m += 16) s += a[(size_t)m * lda + n] * b[(size_t)m * ldb + n];
-    s_p[g][c] = s;
+    const int nc = min(n, N - 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;          // 8 independent loads in flight per thread
+    int m = g;
+    for (; m + 48 < M; m += 64) {
+        s0 += a[(size_t)m * lda + nc] * b[(size_t)m * ldb + nc];
+        s1 += a[(size_t)(m + 16) * lda + nc] * b[(size_t)(m + 16) * ldb + nc];
+        s2 += a[(size_t)(m + 32) * lda + nc] * b[(size_t)(m + 32) * ldb + nc];
+        s3 += a[(size_t)(m + 48) * lda + nc] * b[(size_t)(m + 48) * ldb + nc];
+    }
+    for (; m < M; m += 16) s0 += a[(size_t)m * lda + nc] * b[(size_t)m * ldb + nc];
+    s_p[g][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && n < N) {
         float t = 0.f;
@@ -173,10 +180,17 @@ __global__ __launch_bounds__(1024) void dot_rows_kernel(const float* sv, const f
     __shared__ float s_p[16][64];
     const int c = threadIdx.x & 63, g = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
-    float s = 0.f;
-    if (n < N)
-        for (int m = g; m < M; m += 16) s += sv[m] * x[(size_t)m * ldx + n];
-    s_p[g][c] = s;
+    const int nc = min(n, N - 1);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int m = g;
+    for (; m + 48 < M; m += 64) {
+        s0 += sv[m] * x[(size_t)m * ldx + nc];
+        s1 += sv[m + 16] * x[(size_t)(m + 16) * ldx + nc];
+        s2 += sv[m + 32] * x[(size_t)(m + 32) * ldx + nc];
+        s3 += sv[m + 48] * x[(size_t)(m + 48) * ldx + nc];
+    }
+    for (; m < M; m += 16) s0 += sv[m] * x[(size_t)m * ldx + nc];
+    s_p[g][c] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (g == 0 && n < N) {
         float t = 0.f;
@@ -185,12 +199,16 @@ __global__ __launch_bounds__(1024) void dot_rows_kernel(const float* sv, const f
         out[n] += t;
     }
 }
-__global__ void sum_accum_kernel(const float* s, int M, float* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float acc = 0.f;
-        for (int m = 0; m < M; ++m) acc += s[m];
-        out[0] += acc;
+__global__ void sum_accum_kernel(const float* s, int M, float* out) {     // one wave, fixed order
+    const int lane = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int m = lane;
+    for (; m + 192 < M; m += 256) {
+        a0 += s[m]; a1 += s[m + 64]; a2 += s[m + 128]; a3 += s[m + 192];
     }
+    for (; m < M; m += 64) a0 += s[m];
+    const float t = wave_sum((a0 + a1) + (a2 + a3));
+    if (lane == 0) out[0] += t;
 }
 // 32x32 LDS-tiled transpose (both sides coalesced)
 __global__ __launch_bounds__(256) void transpose_kernel(const float* src, int R, int C, float* dst) {
