@@ -733,6 +733,23 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
     TRY(add2(d_ct, H, nullptr, 0, B, H, dc, H, st));
     const Dropout dd = make_dropout(drop, drop_stream);
     // dgates for step t overwrite tp->xg[t] (the hoisted product is dead after the forward)
+    if (w->lstm.w_hh_t && H % 16 == 0 && H <= 512) {
+        // ONE launch per step: dh_{t+1} = pass + dgates_{t+1} W_hh on the matrix cores and the cell
+        // backward of step t on the same tile (lstm_bwd_step_fused_kernel)
+        float* dh_b = dpass;                              // ping-pong partners of dh / dc
+        for (int t = T - 1; t >= 0; --t) {
+            LstmBwdStepArgs f{};
+            f.dgates_next = t + 1 < T ? tp->xg + (size_t)(t + 1) * BG : nullptr;
+            f.w_hh_t = w->lstm.w_hh_t;
+            f.dh_in = dh; f.dc_in = dc;
+            f.gates = tp->gates + t * BG; f.c0 = tp->cs + t * BH; f.c1 = tp->cs + (t + 1) * BH;
+            f.dctx = dctx; f.T = T; f.t = t; f.ctx_drop = dd; f.lengths = lengths; f.B = B; f.H = H;
+            f.dgates = tp->xg + t * BG; f.dc_out = dcn; f.dh_out = dh_b;
+            TRY(lstm_bwd_step_fused(f, st));
+            std::swap(dc, dcn);
+            std::swap(dh, dh_b);
+        }
+    } else
     for (int t = T - 1; t >= 0; --t) {
         // two dependent launches per step: the cell backward reads dctx[:, t, :] itself and leaves
         // the pass-through of dead rows IN dh (element-wise in place), then dh += dgates W_hh

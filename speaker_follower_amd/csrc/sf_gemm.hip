@@ -537,6 +537,78 @@ __global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmS
     lstm_cell_update(p.pw, pb, pj, g4, c0v, lv);
 }
 
+// Fused BACKWARD time step of the encoder LSTM: block = 16 rows x 16 hidden units, 8 waves = 8
+// K-slices of dh_{t+1}[tile] = dgates_{t+1}[16 rows, 4H] . W_hh^T[16 units, 4H] (all loads up front,
+// partial tiles meet in LDS), then the cell backward of step t for the tile's 256 elements in the
+// same launch: one dependent launch per time step instead of two.  grid (H/16, ceil(B/16)).
+constexpr int BWS_WAVES = 8;
+
+template <int CPW>
+__global__ __launch_bounds__(BWS_WAVES * 64) void lstm_bwd_step_fused_kernel(LstmBwdStepArgs p) {
+    __shared__ float s_part[BWS_WAVES][256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int H = p.H, B = p.B;
+    const int j0 = blockIdx.x * 16, m0 = blockIdx.y * 16;
+
+    // operands of the cell backward, fetched with the fragments (threads 0..255 own one element)
+    const int prow = threadIdx.x >> 4, pcol = threadIdx.x & 15;
+    const int pb = m0 + prow, pj = j0 + pcol;
+    const bool ptail = threadIdx.x < 256 && pb < B;
+    const int qb = min(pb, B - 1);
+    const size_t idx = (size_t)qb * H + pj;
+    const float* gp = p.gates + (size_t)qb * 4 * H + pj;
+    const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
+    const float c1 = p.c1[idx], c0 = p.c0[idx];
+    const float dc = p.dc_in[idx];
+    float dh = p.dh_in[idx];
+    const bool dead = p.t >= p.lengths[qb];
+    if (p.dctx) {                                                // block-uniform
+        float v = p.dctx[((size_t)qb * p.T + p.t) * H + pj];
+        if (p.ctx_drop.on()) {
+            const uint32_t rk = dropout_row_key(p.ctx_drop.seed, p.ctx_drop.stream,
+                                                (uint32_t)(p.ctx_drop.row0 + qb));
+            v = dropout_keep(rk, (uint32_t)(p.t * H + pj), p.ctx_drop.thresh) ? v * p.ctx_drop.scale : 0.f;
+        }
+        dh += v;
+    }
+
+    f32x4 acc[1] = {f32x4{0.f, 0.f, 0.f, 0.f}};
+    if (p.dgates_next) {                                         // block-uniform (absent at t = T-1)
+        Seg2 sg;
+        sg.s0 = Seg{p.dgates_next, 4 * H, p.w_hh_t, 4 * H, 4 * H};
+        sg.n0 = (4 * H) >> 4;
+        sg.s1 = sg.s0;
+        sg.total = sg.n0;
+        const int n = j0 + li;
+        int mrow[1] = {min(m0 + li, B - 1)};
+        const int c_lo = (wave * sg.total) / BWS_WAVES, c_hi = ((wave + 1) * sg.total) / BWS_WAVES;
+        if (c_hi > c_lo) {
+            Frags<1, CPW> f;
+            upfront_load<1, CPW>(f, sg, c_lo, c_hi, n, mrow, kk);
+            upfront_mma<1, CPW>(f, c_hi - c_lo, acc);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) s_part[wave][(kk * 4 + r) * 16 + li] = acc[0][r];
+    __syncthreads();
+    if (!ptail) return;
+#pragma unroll
+    for (int w = 0; w < BWS_WAVES; ++w) dh += s_part[w][threadIdx.x];
+
+    float* dg = p.dgates + (size_t)pb * 4 * H + pj;
+    const float tc = tanhf(c1);
+    const float dout = dh * tc;
+    const float dcl = dc + dh * og * (1.f - tc * tc);
+    // packed sequence: a step that did not happen passes dh / dc through, dgates = 0
+    dg[0] = dead ? 0.f : dcl * gg * ig * (1.f - ig);
+    dg[H] = dead ? 0.f : dcl * c0 * fg * (1.f - fg);
+    dg[2 * H] = dead ? 0.f : dcl * ig * (1.f - gg * gg);
+    dg[3 * H] = dead ? 0.f : dout * og * (1.f - og);
+    p.dc_out[(size_t)pb * H + pj] = dead ? dc : dcl * fg;
+    p.dh_out[(size_t)pb * H + pj] = dead ? dh : 0.f;
+}
+
 // ------------------------------------------------------------------------------------------------
 // NN: C[M,N] = A[M,K] * W[K,N]     (dX = dY * W; A K-contiguous, W N-contiguous)
 // grid (ceil(N/256), ksplit, mblocks); wave = MT m-tiles x 64 columns (4 virtual tiles).
@@ -1075,6 +1147,19 @@ int lstm_step_fused(const LstmStepArgs& p, hipStream_t st) {
         hipLaunchKernelGGL(lstm_step_fused_kernel<8>, grid, block, 0, st, p);
     else if (c <= 16)
         hipLaunchKernelGGL(lstm_step_fused_kernel<16>, grid, block, 0, st, p);
+    else
+        return SF_ERR_UNSUPPORTED;
+    return launch_status();
+}
+
+int lstm_bwd_step_fused(const LstmBwdStepArgs& p, hipStream_t st) {
+    if (p.H % 16 || (4 * p.H) % 16) return SF_ERR_UNSUPPORTED;
+    const int c = ceil_div((4 * p.H) >> 4, BWS_WAVES);
+    dim3 grid(p.H / 16, ceil_div(p.B, 16)), block(BWS_WAVES * 64);
+    if (c <= 8)
+        hipLaunchKernelGGL(lstm_bwd_step_fused_kernel<8>, grid, block, 0, st, p);
+    else if (c <= 16)
+        hipLaunchKernelGGL(lstm_bwd_step_fused_kernel<16>, grid, block, 0, st, p);
     else
         return SF_ERR_UNSUPPORTED;
     return launch_status();

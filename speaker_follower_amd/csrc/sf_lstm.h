@@ -85,4 +85,24 @@ __device__ __forceinline__ void lstm_cell_update(const LstmPwFwd& a, int b, int 
     }
 }
 
+// Fused backward time step of the encoder LSTM (sf_gemm.hip: lstm_bwd_step_fused_kernel):
+// dh_{t+1} = pass_{t+1} + dgates_{t+1} W_hh (skipped for the last step) and, in the same launch, the
+// cell backward of step t on that tile -> dgates_t, dc_t, pass_t.
+struct LstmBwdStepArgs {
+    const float* dgates_next;    // [B,4H] pre-activation gate gradients of step t+1, or null (t = T-1)
+    const float* w_hh_t;         // [H,4H] transposed recurrent weight (K-contiguous rows)
+    const float* dh_in;          // [B,H] pass-through part of dh_{t+1} (dead rows) / the incoming dh_T
+    const float* dc_in;          // [B,H] dc_{t+1}
+    const float* gates;          // [B,4H] activated gates of step t
+    const float* c0; const float* c1;   // [B,H] cell state before / after step t
+    const float* dctx; int T; int t;    // dctx[b, t, :] (row stride T*H) or null
+    Dropout ctx_drop;
+    const int* lengths;
+    int B, H;
+    float* dgates;               // [B,4H] out
+    float* dc_out;               // [B,H] out
+    float* dh_out;               // [B,H] out: pass-through of dead rows (0 for live rows)
+};
+int lstm_bwd_step_fused(const LstmBwdStepArgs& p, hipStream_t st);
+
 }  // namespace sf
