@@ -37,6 +37,7 @@ def parse():
     ap.add_argument('--decode-steps', type=int, default=20)
     ap.add_argument('--n-viewpoints', type=int, default=10567)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-train-extra', action='store_true', help='skip the extra training-iteration measurement')
     ap.add_argument('--no-graph', action='store_true', help='issue the rollout eagerly instead of replaying a hipGraph')
     ap.add_argument('--row-shards', type=int, default=1,
                     help='rollout only: run the batch as this many concurrent row shards (measured: no gain, '
@@ -98,6 +99,42 @@ def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps):
     return dict(value=best, unit='agent-steps/s', cores=1, kind='port',
                 sample='%d full rollouts of the same batch (B=%d, %d decode steps, encoder included), '
                        'numpy oracle, 1 thread, best of %d' % (reps, B, n, reps)), res
+
+
+def measure_train(enc, dec, store, batch, S, iters, warmup):
+    """follower.py:1001-1020 + train.py:263-268 per iteration: zero_grad, student-forcing rollout with
+    loss, backward, Adam(lr 1e-4, weight_decay 5e-4) on encoder and decoder."""
+    from speaker_follower_amd import follower, dp
+    enc.train()
+    dec.train()
+    params_e = [p for p in enc.parameters() if p.requires_grad]
+    params_d = [p for p in dec.parameters() if p.requires_grad]
+    opt_e = torch.optim.Adam(params_e, lr=1e-4, weight_decay=5e-4)
+    opt_d = torch.optim.Adam(params_d, lr=1e-4, weight_decay=5e-4)
+    flat = dp.FlatGrads(params_e + params_d)
+    engine = follower.FollowerEngine(enc, dec, store)
+    B = batch.batch_size
+
+    def it():
+        flat.zero()
+        st = engine.rollout(batch, S, 'argmax', train=True)
+        st.loss.backward()
+        opt_e.step()
+        opt_d.step()
+        return st
+    for _ in range(warmup):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        st = it()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    enc.eval()
+    dec.eval()
+    return dict(value=B * S / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
+                what='student-forcing rollout (dropout 0.5) + BPTT + 2x Adam, batch %d, %d decode steps, '
+                     'eager issue' % (B, S), loss=float(st.loss.detach()))
 
 
 def main():
@@ -291,6 +328,11 @@ def main():
             same = bool(np.array_equal(st.actions.cpu().numpy()[:n], ref['actions']))
             out['parity_vs_cpu_port'] = dict(actions_bit_exact=same,
                                              loss_abs_diff=abs(float(st.loss_buf) - float(ref['loss'])))
+    # ---- extra (not `value`): the full training iteration of BASELINE configs[1] -- student-forcing
+    # rollout (dropout on), BPTT through the C ABI, two Adam steps -- on the same batch, N = 1 only
+    # (it updates the weights, so it runs after every inference measurement and parity check)
+    if not train and world == 1 and not args.no_train_extra:
+        out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2)
     print(json.dumps(out))
     if world > 1:
         torch.distributed.destroy_process_group()
