@@ -264,9 +264,43 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
         for (int p = 0; p < 2; ++p)
             *reinterpret_cast<float4*>(Ws + (p * 32 + ldrow) * TLD + 4 * ldc4) = r.w[p];
     };
-    auto compute = [&](int buf) {
+    // one global load of the staging set (piece 0..APASS+1), issued between groups of 7 MFMAs: six
+    // back-to-back loads from all 8 waves right after the barrier stall every wave on the address
+    // path with the matrix pipe idle (timestamped: ~0.4 us per stage)
+    struct StageSrc {
+        const float* A;
+        const float* W;
+        int lda, ldw;
+    };
+    auto stage_src = [&](int s) {
+        const float* A;
+        const float* W;
+        int lda, ldw, k0;
+        if (s < st0n) {
+            A = a.seg[0].A; W = a.seg[0].W; lda = a.seg[0].lda; ldw = a.seg[0].ldw; k0 = s * TBK;
+        } else if (s < st0n + st1n) {
+            A = a.seg[1].A; W = a.seg[1].W; lda = a.seg[1].lda; ldw = a.seg[1].ldw; k0 = (s - st0n) * TBK;
+        } else {
+            A = a.seg[2].A; W = a.seg[2].W; lda = a.seg[2].lda; ldw = a.seg[2].ldw;
+            k0 = (s - st0n - st1n) * TBK;
+        }
+        return StageSrc{A + k0 + 4 * ldc4, W + k0 + 4 * ldc4, lda, ldw};
+    };
+    auto gpiece = [&](Regs& r, const StageSrc& ss, int piece) {
+        if (piece < APASS) {
+            const int row = min(piece * 32 + ldrow, a.M - 1);
+            r.a[piece < APASS ? piece : 0] = ld4(ss.A + (size_t)row * ss.lda);
+        } else if (piece < APASS + 2) {
+            const int p = piece - APASS;
+            const int row = min(n0 + p * 32 + ldrow, a.N - 1);
+            r.w[p & 1] = ld4(ss.W + (size_t)row * ss.ldw);
+        }
+    };
+    auto compute = [&](int buf, Regs* nx, int s_next) {
         const float* As = smem + buf * BUF;
         const float* Ws = As + AROWS * TLD + (wave * 16 + li) * TLD;
+        StageSrc ss{};
+        if (nx) ss = stage_src(s_next);
 #pragma unroll
         for (int cc = 0; cc < TBK / 32; ++cc) {
             const int c = khalf * (TBK / 32) + cc;
@@ -276,16 +310,18 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
             for (int t = 0; t < MT; ++t)
                 av[t] = *reinterpret_cast<const float4*>(As + (t * 16 + li) * TLD + 16 * c + 4 * kk);
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
+            for (int j = 0; j < 4; ++j) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(av[t], j), comp(b, j), acc[t]);
+                if (nx) gpiece(*nx, ss, cc * 4 + j);             // 8 slots >= APASS + 2 pieces
+            }
         }
     };
 
-    // Two stages of global loads stay in flight (register sets ra / rb alternate) behind the stage
-    // being computed from LDS: one stage of look-ahead measured ~2.9 us of exposed HBM latency per
-    // stage.  Prefetch indices are clamped, not predicated, so the loop body has no branches and the
-    // compiler can use counted vmcnt waits.
+    // Two register sets alternate over two LDS buffers; the refill of a set (its six loads) is
+    // interleaved with the MFMAs of the stage that follows its store.  Look-ahead: rb is loaded
+    // during stage s and stored after stage s+1, ra during stage s+1 and stored after stage s+2.
+    // Prefetch indices are clamped, not predicated.
     if (s_lo < s_hi) {
         const int last = s_hi - 1;
         Regs ra, rb;
@@ -294,16 +330,16 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
         gload(ra, min(s_lo + 1, last));
         gload(rb, min(s_lo + 2, last));
         __syncthreads();
+        bool first = true;
         for (int s = s_lo; s < s_hi; s += 2) {
-            compute(0);                       // stage s     (ra: s+1, rb: s+2 in flight)
+            compute(0, first ? nullptr : &rb, min(s + 2, last));   // stage s; rb <- s+2 (after the 1st)
+            first = false;
             lstore(ra, 1);
             __syncthreads();
-            gload(ra, min(s + 3, last));
             if (s + 1 >= s_hi) break;
-            compute(1);                       // stage s+1   (rb: s+2, ra: s+3 in flight)
+            compute(1, &ra, min(s + 3, last));                     // stage s+1; ra <- s+3
             lstore(rb, 0);
             __syncthreads();
-            gload(rb, min(s + 4, last));
         }
     }
     __syncthreads();
