@@ -375,119 +375,6 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// "A-resident" NT GEMM: the decoder LSTM gates again, without per-stage barriers.  PMC on the
-// tiled kernel above showed waves parked 29 % of their life at the per-stage block barrier with
-// the MFMA pipe ~50 % busy.  Here a block (8 waves = 8 n-tiles = 128 columns, 2 waves per SIMD)
-// first stages its WHOLE K-slice of A (MT*16 rows x 304 k = 138 KB of the 160 KB LDS) with
-// full-line loads -- one barrier -- and then every wave runs free: it streams its own 16 weight
-// rows HBM -> registers through a 4-deep clamped prefetch ring and reads A fragments from LDS
-// (row stride 308 dwords = 52 mod 64: conflict-free ds_read_b128).  ksplit = K / 304.
-// grid (N/128, ksplit), block 512.
-// ------------------------------------------------------------------------------------------------
-constexpr int AR_KS_CHUNKS = 19;                       // 304 k per split
-constexpr int AR_LD = AR_KS_CHUNKS * 16 + 4;           // LDS row stride in floats (308)
-
-template <int MT>
-__global__ __launch_bounds__(512) void gemm_nt_aresident_kernel(NtArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int li = lane & 15, kk = lane >> 4;
-    const int n0 = blockIdx.x * 128 + wave * 16;
-    const int split = blockIdx.y;
-    const int c_lo = split * AR_KS_CHUNKS;
-    const int c_hi = min(c_lo + AR_KS_CHUNKS, a.chunks_total);
-    const int n_s0 = a.seg[0].K >> 4;                   // chunks in segment 0 (K_s % 16 == 0)
-    const int n_s1 = a.nseg > 1 ? (a.seg[1].K >> 4) : 0;
-
-    // ---- stage the A slice: 16 lanes cover one 64-float unit of a row (256 B).  All loads are
-    // issued before the first LDS store (one L2 round trip for the whole 138 KB slice).
-    {
-        constexpr int QUADS = (AR_KS_CHUNKS + 3) / 4;    // 64-float units per row
-        constexpr int RP = (MT * 16 + 31) / 32;          // row passes of 32 rows
-        const int r0 = tid >> 4, q4 = tid & 15;
-        float4 v[QUADS][RP];
-#pragma unroll
-        for (int q = 0; q < QUADS; ++q) {
-            const int c = c_lo + 4 * q + (q4 >> 2);      // chunk this float4 belongs to
-            const int cc = c < c_hi ? c : c_lo;
-            const bool s1 = cc >= n_s0, s2 = cc >= n_s0 + n_s1;
-            const Seg& sg = s2 ? a.seg[2] : (s1 ? a.seg[1] : a.seg[0]);
-            const int kc = (cc - (s2 ? n_s0 + n_s1 : (s1 ? n_s0 : 0))) * 16 + 4 * (q4 & 3);
-#pragma unroll
-            for (int p = 0; p < RP; ++p) {
-                const int row = min(r0 + 32 * p, a.M - 1);
-                v[q][p] = ld4(sg.A + (size_t)row * sg.lda + kc);
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < QUADS; ++q) {
-            const int c = c_lo + 4 * q + (q4 >> 2);
-#pragma unroll
-            for (int p = 0; p < RP; ++p) {
-                const int r = r0 + 32 * p;
-                if (c < c_hi && r < MT * 16)
-                    *reinterpret_cast<float4*>(smem + r * AR_LD + (c - c_lo) * 16 + 4 * (q4 & 3)) = v[q][p];
-            }
-        }
-    }
-
-    f32x4 acc[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    const int n = min(n0 + li, a.N - 1);
-    auto wload = [&](int c) -> float4 {                 // weight fragment of global chunk c
-        const bool s1 = c >= n_s0, s2 = c >= n_s0 + n_s1;
-        const Seg& sg = s2 ? a.seg[2] : (s1 ? a.seg[1] : a.seg[0]);
-        const int k = (c - (s2 ? n_s0 + n_s1 : (s1 ? n_s0 : 0))) * 16 + 4 * kk;
-        return ld4(sg.W + (size_t)n * sg.ldw + k);
-    };
-    auto mma = [&](const float4& b, int lc) {           // lc = chunk index inside the slice
-        float4 av[MT];
-#pragma unroll
-        for (int t = 0; t < MT; ++t)
-            av[t] = *reinterpret_cast<const float4*>(smem + (t * 16 + li) * AR_LD + lc * 16 + 4 * kk);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int t = 0; t < MT; ++t) acc[t] = mfma16(comp(av[t], j), comp(b, j), acc[t]);
-    };
-
-    const int last = c_hi - 1;
-    float4 b0 = wload(min(c_lo, last)), b1 = wload(min(c_lo + 1, last)),
-           b2 = wload(min(c_lo + 2, last)), b3 = wload(min(c_lo + 3, last));
-    __syncthreads();                                    // A slice visible; W ring already in flight
-    int c = c_lo;
-    for (; c + 4 <= c_hi; c += 4) {
-        mma(b0, c - c_lo);     b0 = wload(min(c + 4, last));
-        mma(b1, c - c_lo + 1); b1 = wload(min(c + 5, last));
-        mma(b2, c - c_lo + 2); b2 = wload(min(c + 6, last));
-        mma(b3, c - c_lo + 3); b3 = wload(min(c + 7, last));
-    }
-    if (c < c_hi) mma(b0, c - c_lo);
-    if (c + 1 < c_hi) mma(b1, c - c_lo + 1);
-    if (c + 2 < c_hi) mma(b2, c - c_lo + 2);
-
-    const int col = n0 + li;
-    if (col >= a.N) return;
-    float* out = a.out + (a.ksplit > 1 ? (size_t)split * a.M * a.N : 0);
-    float bsum = 0.f;
-    if (a.bias) bsum += a.bias[col];
-    if (a.bias2) bsum += a.bias2[col];
-#pragma unroll
-    for (int t = 0; t < MT; ++t)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * t + kk * 4 + r;
-            if (row < a.M) {
-                float* o = out + (size_t)row * a.ldo + col;
-                const float v = acc[t][r] + bsum;
-                *o = (a.accumulate && a.ksplit == 1) ? *o + v : v;
-            }
-        }
-}
-
-// ------------------------------------------------------------------------------------------------
 // Short reductions (K <= 1024: every Linear of the decode step except the LSTM gates, and the
 // recurrent h*W_hh^T of the encoder / speaker decoder).  These are LATENCY bound: a wave that walks
 // its K range chunk by chunk pays one HBM round trip per chunk (measured 13 us for K = 512).  So the
@@ -1059,56 +946,9 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         a.y_pre = out.y_pre;
         a.ldy_pre = out.ldy_pre;
     }
-    static const int variant = [] {          // development switch: SF_GEMM_VARIANT=tiled|ares|stream
-        const char* e = getenv("SF_GEMM_VARIANT");
-        return !e ? 0 : (e[0] == 't' ? 1 : (e[0] == 'a' ? 2 : 3));
-    }();
-    bool ares = mblocks == 1 && chunks >= 128 && N >= 1024 && N % 128 == 0 && out.epi != EPI_MUL &&
-                variant == 2;   // measured equal to the tiled kernel (27.9 vs 28.1 us) but 2x the slabs
-    for (int s = 0; s < nseg; ++s) ares = ares && segs[s].K % 16 == 0;
     bool launched = false;
-    if (ares) {
-        const int aks = ceil_div(chunks, AR_KS_CHUNKS);
-        if (aks > 1 && aks <= 16 && ws && ws_floats >= (size_t)aks * M * N) {
-            a.ksplit = aks;
-            a.out = ws;
-            a.ldo = N;
-            a.bias = nullptr;
-            a.bias2 = nullptr;
-            a.epi = EPI_NONE;
-            const size_t lds = (size_t)mt * 16 * AR_LD * sizeof(float);
-            dim3 agrid(N / 128, aks);
-#define SF_ARES(MTV)                                                                                  \
-    case MTV: {                                                                                       \
-        static bool attr_set = false;                                                                 \
-        if (!attr_set) {                                                                              \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_aresident_kernel<MTV>),   \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
-            attr_set = true;                                                                          \
-        }                                                                                             \
-        hipLaunchKernelGGL(gemm_nt_aresident_kernel<MTV>, agrid, dim3(512), lds, st, a);              \
-    } break;
-            switch (mt) {
-                SF_ARES(1) SF_ARES(2) SF_ARES(3) SF_ARES(4) SF_ARES(5) SF_ARES(6) SF_ARES(7)
-                default: {
-                    static bool attr8 = false;
-                    if (!attr8) {
-                        (void)hipFuncSetAttribute(
-                            reinterpret_cast<const void*>(&gemm_nt_aresident_kernel<8>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-                        attr8 = true;
-                    }
-                    hipLaunchKernelGGL(gemm_nt_aresident_kernel<8>, agrid, dim3(512), lds, st, a);
-                }
-            }
-#undef SF_ARES
-            ks = aks;
-            launched = true;
-        }
-    }
     const NtArgs& k = a;   // raw slabs with ks == 1: slab 0 is written without bias
-    bool tiled = !launched && mblocks == 1 && chunks >= 128 && N % 64 == 0 && a.epi == EPI_NONE &&
-                 variant != 3;
+    bool tiled = !launched && mblocks == 1 && chunks >= 128 && N % 64 == 0 && a.epi == EPI_NONE;
     for (int s = 0; s < nseg; ++s) tiled = tiled && segs[s].K % TBK == 0;
     if (tiled) {
         dim3 tgrid(N / 64, ks);
