@@ -4,9 +4,6 @@
 #include "sf_rows.h"
 #include "sf_glue.h"
 #include "sf_gemm_small.h"
-#ifndef LAB_VSTAMP
-#define LAB_VSTAMP(i) do {} while (0)
-#endif
 
 namespace sf {
 
@@ -155,7 +152,6 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
     const int F = a.src.IMG + a.src.LOC, n4 = F >> 2;
     const int pstride = F + 64;
     float* rec = sp.part + ((size_t)b * VSP_G + g) * pstride;
-    LAB_VSTAMP(0);
 
     const PanoRow prow = pano_row(a.src, b);
     float4 x[VIS_RPW][VIS_CPL];
@@ -168,7 +164,6 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
             x[r][i] = pano_load(prow, v, c, v < V && c < n4, V, n4);
         }
     }
-    LAB_VSTAMP(1);
     float dot[VIS_RPW];
 #pragma unroll
     for (int r = 0; r < VIS_RPW; ++r) dot[r] = 0.f;
@@ -187,7 +182,6 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
         if (lane == 0) s_score[vl] = (g * VSP_RPG + vl < V) ? s : -INFINITY;
     }
     __syncthreads();
-    LAB_VSTAMP(2);
     const float s = lane < VSP_RPG ? s_score[lane] : -INFINITY;
     const float m = wave_max(s);
     const float e = s > -INFINITY ? expf(s - m) : 0.f;
@@ -218,15 +212,12 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
             __hip_atomic_store(rec + F + 33, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    LAB_VSTAMP(3);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains
-    LAB_VSTAMP(4);
     __syncthreads();
     if (tid == 0)
         s_last = (__hip_atomic_fetch_add(sp.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
                   (unsigned)(VSP_G - 1)) == (unsigned)(VSP_G - 1);
     __syncthreads();
-    LAB_VSTAMP(5);
     if (!s_last) return;
 
     float* r0 = sp.part + (size_t)b * VSP_G * pstride;
@@ -280,7 +271,6 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
         }
         reinterpret_cast<float4*>(orow)[c] = t;
     }
-    LAB_VSTAMP(6);
 }
 
 __global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_kernel(VisArgs a, VisSplit sp) {

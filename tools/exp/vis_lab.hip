@@ -1,4 +1,5 @@
-// Lab harness for the visual-attention kernels (not part of the product).
+// Lab harness for the visual-attention kernels (not part of the product).  The timestamp hooks
+// (LAB_VSTAMP) were removed from the product source; re-insert them locally to use SF_LAB_STAMP.
 #ifdef SF_LAB_STAMP
 #define LAB_VSTAMP(i) do { if (threadIdx.x == 0) g_vstamps[blockIdx.y * 4 + blockIdx.x][i] = wall_clock64(); } while (0)
 __device__ long long g_vstamps[1024][8];
