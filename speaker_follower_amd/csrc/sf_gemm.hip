@@ -687,19 +687,28 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     if (s4 + 2 < steps) mma(s4 + 2, y2, x2);
 
     if (!qok) return;
+    // read-modify-write of the gradient tile: all 16 reads first (straight-line, clamped rows), then
+    // the adds and stores -- one memory round trip instead of sixteen
+    float4 w[4][4];
+    if (a.accumulate) {                                  // block-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = min(p0 + 4 * (kk * 4 + r) + i, a.P - 1);
+                w[i][r] = ld4(a.out + (size_t)p * a.ldo + qc);
+            }
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int p = p0 + 4 * (kk * 4 + r) + i;     // tile row (kk*4+r) is virtual: stride-4 rows
-            if (p >= a.P) continue;
             float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
-            float4* o = reinterpret_cast<float4*>(a.out + (size_t)p * a.ldo + qc);
             if (a.accumulate) {
-                const float4 w = *o;
-                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+                v.x += w[i][r].x; v.y += w[i][r].y; v.z += w[i][r].z; v.w += w[i][r].w;
             }
-            *o = v;
+            if (p < a.P) *reinterpret_cast<float4*>(a.out + (size_t)p * a.ldo + qc) = v;
         }
 }
 
