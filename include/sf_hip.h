@@ -343,6 +343,36 @@ int sf_attn_decoder_wgrad(const sf_decoder_w* w, const sf_decoder_g* g, int M, i
                           const sf_decoder_gtape* gtape, void* ws, size_t ws_bytes,
                           sf_stream stream);
 
+/* ---- a whole follower episode in one call (follower.py:430-539 forward, :1014-1016 backward) ----
+ * All per-step tensors of an index-form (or dense) episode are stacked [S][...] arrays: `X`, `U`,
+ * `tape`, `glue` hold the pointers of STEP 0 and step t lives t * (per-step size) further on (sizes
+ * follow from S, B, H, D, L, A and the feature dims; tape.xin has S+1 steps, glue.ended is [B]).
+ * glue.u_next / ld_u_next / u_drop / u_drop_stream / sample_stream are ignored: u_next of step t
+ * always goes, through the next step's input dropout, into tape.xin of step t+1.
+ * fwd  = sf_attn_decoder_head_fwd(0) then S x sf_attn_decoder_tail_fwd, with no host work between.
+ * bwd  = per step t = S-1..0: sf_follower_glue_bwd (gscale[t]) + sf_attn_decoder_bwd (g = NULL, dY
+ *        operands into the stacked gtape), ping-ponging (dh, dc) between the two buffer pairs;
+ *        *result_in_b tells which pair holds d h_init / d c_init; dctx [B,L,H] is ADDED to.
+ *        Follow with sf_attn_decoder_wgrad. */
+typedef struct sf_follower_episode {
+    int32_t S, B, H, D, L, A;
+    sf_pano X;
+    sf_cands U;
+    const float *h_init, *c_init; /* [B,H] */
+    const float* ctx;             /* [B,L,H] */
+    const uint8_t* ctx_mask;      /* [B,L] */
+    sf_decoder_tape tape;
+    sf_follower_glue glue;
+    sf_dropout drop;              /* p == 0: no dropout */
+    uint32_t step0;               /* dropout / sampling site of step 0 */
+} sf_follower_episode;
+int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e, void* ws,
+                            size_t ws_bytes, sf_stream stream);
+int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
+                            const sf_decoder_gtape* gtape, const float* gscale, float* dlogit,
+                            float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
+                            int* result_in_b, void* ws, size_t ws_bytes, sf_stream stream);
+
 /* Loss bookkeeping without host syncs or atomics (deterministic order):
  * sum_cnt[t] = (sum_b term[t,b], sum_b live[t,b]) for t < T;  then, optionally after a
  * data-parallel all-reduce of sum_cnt, loss[0] = sum_t sum/cnt (0 where cnt == 0) which is the

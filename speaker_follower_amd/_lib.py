@@ -72,6 +72,13 @@ class FollowerGlue(C.Structure):
                 ('sample_stream', C.c_uint32), ('row0', C.c_int32)]
 
 
+class FollowerEpisode(C.Structure):
+    _fields_ = [('S', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('D', C.c_int32),
+                ('L', C.c_int32), ('A', C.c_int32), ('X', Pano), ('U', Cands), ('h_init', c_p),
+                ('c_init', c_p), ('ctx', c_p), ('ctx_mask', c_p), ('tape', DecoderTape),
+                ('glue', FollowerGlue), ('drop', Dropout), ('step0', C.c_uint32)]
+
+
 class EncoderW(C.Structure):
     _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p), ('w_e2d_t', c_p),
                 ('xw_table', c_p)]
@@ -133,6 +140,9 @@ _SIGNATURES = {
     'sf_attn_decoder_tail_fwd': (C.c_int, [P(DecoderW), P(Cands), i32, i32, i32, i32, c_f, c_f, c_f,
                                            c_f, c_p, c_p, P(DecoderTape), P(FollowerGlue), P(Dropout),
                                            u32, P(Pano), P(DecoderTape)] + WS),
+    'sf_follower_episode_fwd': (C.c_int, [P(DecoderW), P(FollowerEpisode)] + WS),
+    'sf_follower_episode_bwd': (C.c_int, [P(DecoderW), P(FollowerEpisode), P(DecoderGTape), c_f, c_f,
+                                          c_f, c_f, c_f, c_f, c_f, P(C.c_int)] + WS),
     'sf_attn_decoder_bwd': (C.c_int, [P(DecoderW), P(DecoderW), P(Pano), P(Cands), i32, i32, i32,
                                       i32, c_f, c_f, c_f, P(DecoderTape), P(DecoderGTape), c_f, c_f,
                                       c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),

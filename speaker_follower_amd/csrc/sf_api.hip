@@ -463,15 +463,21 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
 // tail(t)   = LSTM cell, text attention, scoring (+ glue) of step t, and -- when X_next is given --
 //             head(t+1) on h1 of step t, run SIDE BY SIDE with the text / scoring half in paired
 //             launches (sf_attention.hip): the two halves are independent given h1.
-int sf_attn_decoder_head_fwd(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
-                             const float* h0, const sf_decoder_tape* tp, const sf_dropout* drop,
-                             uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream) {
-    SF_ENTER();
+static int decoder_head_i(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
+                          const float* h0, const sf_decoder_tape* tp, const sf_dropout* drop,
+                          uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream) {
     SF_CHECK_ARG(w && X && h0 && tp && B > 0);
     const PanoSrc xs = pano(X);
     const int F = xs.IMG + xs.LOC;
     return visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
                         make_dropout(drop, 2 * step_id), F, arena(ws, ws_bytes), S(stream), w->fold);
+}
+
+int sf_attn_decoder_head_fwd(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
+                             const float* h0, const sf_decoder_tape* tp, const sf_dropout* drop,
+                             uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    return decoder_head_i(w, X, B, H, D, h0, tp, drop, step_id, ws, ws_bytes, stream);
 }
 
 static int plan_linear(const float* x, int ldx, const float* wgt, int ldw, const float* b, int M,
@@ -482,14 +488,12 @@ static int plan_linear(const float* x, int ldx, const float* wgt, int ldw, const
     return linear_small_plan(&sg, 1, M, N, o, p) ? SF_OK : SF_ERR_UNSUPPORTED;
 }
 
-int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
-                             const float* u_prev, const float* h0, const float* c0,
-                             const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
-                             const sf_decoder_tape* tp, const sf_follower_glue* glue,
-                             const sf_dropout* drop, uint32_t step_id, const sf_pano* X_next,
-                             const sf_decoder_tape* tn, void* ws, size_t ws_bytes,
-                             sf_stream stream) {
-    SF_ENTER();
+static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
+                          const float* u_prev, const float* h0, const float* c0, const float* ctx,
+                          const uint8_t* ctx_mask, const int32_t* ctx_row, const sf_decoder_tape* tp,
+                          const sf_follower_glue* glue, const sf_dropout* drop, uint32_t step_id,
+                          const sf_pano* X_next, const sf_decoder_tape* tn, void* ws, size_t ws_bytes,
+                          sf_stream stream) {
     SF_CHECK_ARG(w && U && h0 && c0 && ctx && tp && B > 0 && L > 0 && (!glue || glue_ok(U, glue)) &&
                  (!X_next || tn));
     Arena ar = arena(ws, ws_bytes);
@@ -543,6 +547,18 @@ int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, in
                          st, glue, w->fold);
 }
 
+int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
+                             const float* u_prev, const float* h0, const float* c0,
+                             const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
+                             const sf_decoder_tape* tp, const sf_follower_glue* glue,
+                             const sf_dropout* drop, uint32_t step_id, const sf_pano* X_next,
+                             const sf_decoder_tape* tn, void* ws, size_t ws_bytes,
+                             sf_stream stream) {
+    SF_ENTER();
+    return decoder_tail_i(w, U, B, H, D, L, u_prev, h0, c0, ctx, ctx_mask, ctx_row, tp, glue, drop,
+                          step_id, X_next, tn, ws, ws_bytes, stream);
+}
+
 int sf_decoder_fold_build(const sf_decoder_w* w, int H, int D, int F, float* m_v, float* c_v,
                           float* m_a, float* c_a, void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
@@ -569,14 +585,13 @@ int sf_decoder_fold_build(const sf_decoder_w* w, int H, int D, int F, float* m_v
     return linear_plain(wo_bh, D, w->action.b_a, D, w->action.b_out, 1, 1, D, EPI_NONE, c_a + F, 4, ar, st);
 }
 
-int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
-                        const sf_cands* U, int B, int H, int D, int L, const float* h0,
-                        const float* c0, const float* ctx, const sf_decoder_tape* tp,
-                        const sf_decoder_gtape* gt, const float* dlogit, const float* dh1,
-                        const float* dc1, float* dh0, float* dc0, float* dctx,
-                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
-                        sf_stream stream) {
-    SF_ENTER();
+static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
+                         const sf_cands* U, int B, int H, int D, int L, const float* h0,
+                         const float* c0, const float* ctx, const sf_decoder_tape* tp,
+                         const sf_decoder_gtape* gt, const float* dlogit, const float* dh1,
+                         const float* dc1, float* dh0, float* dc0, float* dctx,
+                         const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                         sf_stream stream) {
     SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0 && L > 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -601,6 +616,149 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                         dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
                         gt ? gt->dt_v : nullptr);
+}
+
+int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
+                        const sf_cands* U, int B, int H, int D, int L, const float* h0,
+                        const float* c0, const float* ctx, const sf_decoder_tape* tp,
+                        const sf_decoder_gtape* gt, const float* dlogit, const float* dh1,
+                        const float* dc1, float* dh0, float* dc0, float* dctx,
+                        const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                        sf_stream stream) {
+    SF_ENTER();
+    return decoder_bwd_i(w, g, X, U, B, H, D, L, h0, c0, ctx, tp, gt, dlogit, dh1, dc1, dh0, dc0, dctx,
+                         drop, step_id, ws, ws_bytes, stream);
+}
+
+// ---- a whole follower episode (follower.py:430-539 / 1001-1020) in one call ----------------------------
+// Every per-step tensor of an index-form episode is a stacked [S][...] array, so the decode loop and
+// its backward need no host work between steps: the host mirror makes ONE call instead of 2 S (its
+// Python + ctypes cost per step was exposed as idle gaps between the short kernels of the backward).
+extern "C++" {
+namespace {
+struct StepView {
+    sf_pano X;
+    sf_cands U;
+    sf_decoder_tape tp;
+    sf_follower_glue glue;
+};
+
+template <class T>
+inline T* adv(T* p, size_t n) { return p ? p + n : nullptr; }
+
+StepView step_view(const sf_follower_episode* e, int t) {
+    const size_t B = e->B, H = e->H, D = e->D, L = e->L, A = e->A;
+    const size_t F = e->X.IMG + e->X.LOC, V = e->X.V;
+    StepView v;
+    v.X = e->X;
+    v.X.vp = adv(e->X.vp, t * B);
+    v.X.view = adv(e->X.view, t * B);
+    v.X.dense = adv(e->X.dense, t * B * V * F);
+    v.U = e->U;
+    v.U.vp = adv(e->U.vp, t * B);
+    v.U.cand_view = adv(e->U.cand_view, t * B * A);
+    v.U.cand_sincos = adv(e->U.cand_sincos, t * B * A * 4);
+    v.U.a_num = adv(e->U.a_num, t * B);
+    v.U.dense = adv(e->U.dense, t * B * A * F);
+    const sf_decoder_tape& p = e->tape;
+    v.tp.t_v = adv(p.t_v, t * B * D);
+    v.tp.q = adv(p.q, t * B * F);
+    v.tp.alpha_v = adv(p.alpha_v, t * B * V);
+    v.tp.xin = adv(p.xin, t * B * 2 * F);
+    v.tp.gates = adv(p.gates, t * B * 4 * H);
+    v.tp.c1 = adv(p.c1, t * B * H);
+    v.tp.h1 = adv(p.h1, t * B * H);
+    v.tp.cat2 = adv(p.cat2, t * B * 2 * H);
+    v.tp.t_text = adv(p.t_text, t * B * H);
+    v.tp.alpha = adv(p.alpha, t * B * L);
+    v.tp.h_tilde = adv(p.h_tilde, t * B * H);
+    v.tp.t_a = adv(p.t_a, t * B * D);
+    v.tp.wt = adv(p.wt, t * B * D);
+    v.tp.r = adv(p.r, t * B * F);
+    v.tp.logit = adv(p.logit, t * B * A);
+    v.glue = e->glue;
+    v.glue.is_valid = adv(e->glue.is_valid, t * B * A);
+    v.glue.target = adv(e->glue.target, t * B);
+    v.glue.a_t = adv(e->glue.a_t, t * B);
+    v.glue.target_used = adv(e->glue.target_used, t * B);
+    v.glue.score = adv(e->glue.score, t * B);
+    v.glue.ce_term = adv(e->glue.ce_term, t * B);
+    v.glue.live = adv(e->glue.live, t * B);
+    v.glue.u_next = adv(p.xin, (t + 1) * B * 2 * F);        // straight into the next step's LSTM input
+    v.glue.ld_u_next = (int32_t)(2 * F);
+    v.glue.u_drop = e->drop.p > 0.f ? &e->drop : nullptr;
+    v.glue.u_drop_stream = 2 * (e->step0 + t + 1);
+    v.glue.sample_stream = e->step0 + t;
+    return v;
+}
+
+sf_decoder_gtape gtape_view(const sf_decoder_gtape* g, const sf_follower_episode* e, int t) {
+    const size_t B = e->B, H = e->H, D = e->D, F = e->X.IMG + e->X.LOC;
+    sf_decoder_gtape v;
+    v.dgates = adv(g->dgates, t * B * 4 * H);
+    v.dpre = adv(g->dpre, t * B * H);
+    v.dt_text = adv(g->dt_text, t * B * H);
+    v.dt_v = adv(g->dt_v, t * B * D);
+    v.dq = adv(g->dq, t * B * F);
+    v.dwt = adv(g->dwt, t * B * D);
+    v.dta = adv(g->dta, t * B * D);
+    v.dr = adv(g->dr, t * B * F);
+    v.dc = adv(g->dc, t * B);
+    return v;
+}
+}  // namespace
+}  // extern "C++"
+
+int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e, void* ws,
+                            size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && e && e->S > 0 && e->B > 0 && e->h_init && e->c_init && e->ctx && e->tape.xin &&
+                 e->tape.h1 && e->tape.c1 && e->glue.target && e->glue.ended);
+    const sf_dropout* drop = e->drop.p > 0.f ? &e->drop : nullptr;
+    const size_t BH = (size_t)e->B * e->H;
+    StepView cur = step_view(e, 0);
+    TRY(decoder_head_i(w, &cur.X, e->B, e->H, e->D, e->h_init, &cur.tp, drop, e->step0, ws, ws_bytes,
+                       stream));
+    for (int t = 0; t < e->S; ++t) {
+        const bool more = t + 1 < e->S;
+        StepView nxt = more ? step_view(e, t + 1) : cur;
+        const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
+        const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
+        TRY(decoder_tail_i(w, &cur.U, e->B, e->H, e->D, e->L, nullptr, h0, c0, e->ctx, e->ctx_mask,
+                           nullptr, &cur.tp, &cur.glue, drop, e->step0 + t, more ? &nxt.X : nullptr,
+                           more ? &nxt.tp : nullptr, ws, ws_bytes, stream));
+        cur = nxt;
+    }
+    return SF_OK;
+}
+
+int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
+                            const sf_decoder_gtape* gtape, const float* gscale, float* dlogit,
+                            float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
+                            int* result_in_b, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && e && gtape && gscale && dlogit && dh_a && dc_a && dh_b && dc_b && result_in_b &&
+                 e->S > 0 && e->B > 0);
+    const sf_dropout* drop = e->drop.p > 0.f ? &e->drop : nullptr;
+    const size_t BH = (size_t)e->B * e->H;
+    const float *dh1 = nullptr, *dc1 = nullptr;
+    float *dho = dh_a, *dco = dc_a, *dhn = dh_b, *dcn = dc_b;
+    for (int t = e->S - 1; t >= 0; --t) {
+        StepView v = step_view(e, t);
+        const sf_decoder_gtape g = gtape_view(gtape, e, t);
+        const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
+        const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
+        TRY(softmax_ce_bwd(e->B, e->A, e->A, v.tp.logit, v.glue.target_used, -1, gscale + t, dlogit,
+                           S(stream)));
+        TRY(decoder_bwd_i(w, nullptr, &v.X, &v.U, e->B, e->H, e->D, e->L, h0, c0, e->ctx, &v.tp, &g,
+                          dlogit, dh1, dc1, dho, dco, dctx, drop, e->step0 + t, ws, ws_bytes, stream));
+        dh1 = dho;
+        dc1 = dco;
+        std::swap(dho, dhn);
+        std::swap(dco, dcn);
+    }
+    *result_in_b = (dh1 == dh_b) ? 1 : 0;
+    return SF_OK;
 }
 
 // All weight gradients of S stacked decoder steps, each as ONE product of reduction depth M = S*B.

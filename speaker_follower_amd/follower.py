@@ -126,6 +126,7 @@ class FollowerEngine:
         self.dropout_seed = None
         self.fold_inference = False     # model.decoder_fold: correct, but measured no faster (590K vs 596K)
         self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
+        self.episode_call = True        # the whole decode loop (and its backward) as ONE C call
 
     # ------------------------------------------------------------------------------ forward
     def rollout(self, batch, steps, feedback='argmax', train=None, finalize=True):
@@ -198,12 +199,32 @@ class FollowerEngine:
         d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
         pipelined = self.pipelined
-        tapes = [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS)) for t in range(S)]
-        panos = [store.pano(batch.vp[t], batch.view[t]) for t in range(S)]
-        if pipelined:
+        st.episode = None
+        if pipelined and self.episode_call and fold is None:
+            # every per-step tensor is a stacked [S][...] array: hand step 0 to the library once
+            ep = _lib.FollowerEpisode()
+            ep.S, ep.B, ep.H, ep.D, ep.L, ep.A = S, B, H, D, T, A
+            ep.X = store.pano(batch.vp[0], batch.view[0])
+            ep.U = store.cands(batch.vp[0], batch.cand_view[0], batch.sincos[0], batch.a_num[0], A)
+            ep.h_init, ep.c_init = st.h_init.data_ptr(), st.c_init.data_ptr()
+            ep.ctx, ep.ctx_mask = st.ctx.data_ptr(), batch.mask.data_ptr()
+            ep.tape = _lib.DecoderTape(*(st.tape[k][0].data_ptr() for k in _TAPE_KEYS))
+            ep.glue = _lib.FollowerGlue(
+                None, batch.target[0].data_ptr(), st.feedback, st.ended.data_ptr(),
+                st.actions[0].data_ptr(), st.target_used[0].data_ptr(), st.step_scores[0].data_ptr(),
+                None, 0, None, 0, st.ce_term[0].data_ptr(), st.live[0].data_ptr(),
+                int(st.drop_dec[1]) ^ 0x1B873593, 0, batch.row0)
+            ep.drop = d_dec
+            ep.step0 = st.site0
+            call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
+            st.episode = (ep, dw)
+        tapes = [] if st.episode else [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
+                                       for t in range(S)]
+        panos = [] if st.episode else [store.pano(batch.vp[t], batch.view[t]) for t in range(S)]
+        if pipelined and not st.episode:
             call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
                  byref(tapes[0]), d_ptr, st.site0, *ws)
-        for t in range(S):
+        for t in range(0 if not st.episode else S, S):
             pano = panos[t]
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
             tp = tapes[t]
@@ -322,7 +343,14 @@ class FollowerEngine:
         d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
         dh1 = dc1 = None
-        for t in range(S - 1, -1, -1):
+        if st.episode is not None:
+            ep, _ = st.episode
+            gt0e = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys))
+            which = C.c_int(0)
+            call('sf_follower_episode_bwd', byref(dw), byref(ep), byref(gt0e), ptr(gscale), ptr(dlogit),
+                 ptr(dh_a), ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(which), *ws)
+            dh1, dc1 = (dh_b, dc_b) if which.value else (dh_a, dc_a)
+        for t in range(S - 1 if st.episode is None else -1, -1, -1):
             pano = store.pano(batch.vp[t], batch.view[t])
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
             tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
