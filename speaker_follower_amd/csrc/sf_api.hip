@@ -237,7 +237,8 @@ int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, in
 // ---- a4 EltwiseProdScoring --------------------------------------------------------------------------
 int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, const float* h,
                   float* logit, float* t_a, float* wt, float* r, Arena ar, hipStream_t st,
-                  const sf_follower_glue* glue = nullptr, const sf_decoder_fold* fold = nullptr) {
+                  const sf_follower_glue* glue = nullptr, const sf_decoder_fold* fold = nullptr,
+                  bool t_a_done = false) {     // t_a / wt already formed by the caller (paired launch)
     const int F = U.IMG + U.LOC;
     if (fold) {      // inference: [r | c] = M_a h~ + c_a in one product ([B, F+4] scratch)
         float* rext = ar.take((size_t)B * (F + 4));
@@ -252,7 +253,7 @@ int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, 
     LinearOut o{};
     o.y = wt; o.ldy = D; o.bias = w->b_h; o.mul = w->w_out; o.y_pre = t_a; o.ldy_pre = D;
     o.epi = EPI_MUL;
-    TRY(linear_nt(&sg, 1, B, D, o, ar.rest(), ar.rest_n(), st));
+    if (!t_a_done) TRY(linear_nt(&sg, 1, B, D, o, ar.rest(), ar.rest_n(), st));
     if (w->w_a_t)
         TRY(linear_plain(wt, D, w->w_a_t, D, nullptr, B, F, D, EPI_NONE, r, F, ar, st));
     else
@@ -526,10 +527,29 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
             TRY(text_attn_fwd(ctx, ctx_mask, B, L, H, tp->t_text, H, tp->alpha, tp->cat2, 2 * H, st, ctx_row));
             TRY(linear_plain(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, ar, st));
         }
-        // (3) h~ = tanh(W_out [wc ; h1])   ||   visual attention of step t+1
+        // (3) h~ = tanh(W_out [wc ; h1])   ||   visual attention of step t+1, per-group partials
+        // (4) t_a = W_h h~ + b_h, wt = t_a * w_out   ||   ... merge of the partials
+        // (the attention is not needed before the next gate product: its two halves ride with two
+        // stages of the text / scoring chain instead of stretching one of them)
         float* part = B <= (int)SYNC_WORDS ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
         const bool ok3 = part && plan_linear(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H,
                                              EPI_TANH, tp->h_tilde, H, &pb) == SF_OK;
+        SmallPlan pc;
+        bool ok4 = false;
+        if (ok3 && !w->fold) {
+            Seg sg{tp->h_tilde, H, w->action.w_h, H, H};
+            LinearOut o{};
+            o.y = tp->wt; o.ldy = D; o.bias = w->action.b_h; o.mul = w->action.w_out; o.y_pre = tp->t_a;
+            o.ldy_pre = D; o.epi = EPI_MUL;
+            ok4 = linear_small_plan(&sg, 1, B, D, o, &pc) && pc.mt == 1 && (pc.cpw == 4 || pc.cpw == 8);
+        }
+        if (ok4 && pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part,
+                                  nullptr, pb, st, 1) == SF_OK) {
+            TRY(pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, nullptr,
+                               pc, st, 2));
+            return scoring_fwd_i(&w->action, us, B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt, tp->r,
+                                 ar, st, glue, nullptr, true);
+        }
         if (!ok3 || pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part,
                                    ar.tickets(), pb, st) != SF_OK) {
             TRY(linear_plain(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H, EPI_TANH, tp->h_tilde, H, ar, st));

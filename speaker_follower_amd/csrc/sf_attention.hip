@@ -141,18 +141,33 @@ static_assert(VSP_G == 2 || VSP_G == 4, "ticket arithmetic assumes a power of tw
 struct VisSplit {
     float* part;          // [B][G][F + 64]: P | scores[32] | m, l
     unsigned* counter;    // [B] monotonic tickets (zero before the first launch)
+    unsigned long long* trace;   // development aid (sf_debug_trace): [blocks][8] wall-clock stamps
 };
+__device__ __forceinline__ void vis_stamp(const VisSplit& sp, int block, int slot) {
+    if (sp.trace && threadIdx.x == 0) sp.trace[(size_t)block * 8 + slot] = wall_clock64();
+}
+static unsigned long long* g_trace = nullptr;
 
+// PHASE 0: partials + ticket + merge by the last arriver, in one launch (hand-off inside the launch:
+//          write-through stores, sc1 loads).
+// PHASE 1: partials only, PHASE 2: merge only -- the same two halves as two consecutive launches
+//          (plain stores / loads: the kernel boundary is the hand-off).  The pipelined decode step
+//          runs them beside two different small products, so the visual attention of step t+1 never
+//          holds up the text / scoring chain of step t.
+template <int PHASE>
 __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSplit& sp, int g, int b) {
     __shared__ float4 slots[VSP_SLOTS][VIS_CPL * 64];
     __shared__ float s_score[64];
     __shared__ int s_last;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int V = a.src.V;
     const int F = a.src.IMG + a.src.LOC, n4 = F >> 2;
     const int pstride = F + 64;
     float* rec = sp.part + ((size_t)b * VSP_G + g) * pstride;
 
+    if (PHASE != 2) {
+    vis_stamp(sp, b * VSP_G + g, 0);
     const PanoRow prow = pano_row(a.src, b);
     float4 x[VIS_RPW][VIS_CPL];
 #pragma unroll
@@ -182,6 +197,7 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
         if (lane == 0) s_score[vl] = (g * VSP_RPG + vl < V) ? s : -INFINITY;
     }
     __syncthreads();
+    vis_stamp(sp, b * VSP_G + g, 1);
     const float s = lane < VSP_RPG ? s_score[lane] : -INFINITY;
     const float m = wave_max(s);
     const float e = s > -INFINITY ? expf(s - m) : 0.f;
@@ -199,7 +215,20 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
     // publish the partials WRITE-THROUGH (sc1: straight to the memory side, visible to every XCD),
     // drain, then draw a ticket: no release fence (a buffer_wbl2 of the whole L2 costs far more
     // than this kernel), and the merging block reads them back with sc1 loads: no acquire fence.
-    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    if (PHASE == 1) {                                            // next launch reads them
+        block_row_sum<VIS_CPL, VSP_NW, VSP_SLOTS>(p, slots, n4, [&](int c, float4 t) {
+            reinterpret_cast<float4*>(rec)[c] = t;
+        });
+        if (wave == 0) {
+            if (lane < 32) rec[F + lane] = s;
+            if (lane == 0) {
+                rec[F + 32] = m;
+                rec[F + 33] = l;
+            }
+        }
+        vis_stamp(sp, b * VSP_G + g, 2);
+        return;
+    }
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, pstride * 4, 0x00020000);
     block_row_sum<VIS_CPL, VSP_NW, VSP_SLOTS>(p, slots, n4, [&](int c, float4 t) {
         const v4u v{__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)};
@@ -219,9 +248,12 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
                   (unsigned)(VSP_G - 1)) == (unsigned)(VSP_G - 1);
     __syncthreads();
     if (!s_last) return;
+    }   // PHASE != 2
 
     float* r0 = sp.part + (size_t)b * VSP_G * pstride;
-    auto ldf = [&](float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto ldf = [&](float* q) {
+        return PHASE == 0 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+    };
     float mg[VSP_G], lg[VSP_G];
 #pragma unroll
     for (int k = 0; k < VSP_G; ++k) {
@@ -253,7 +285,7 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
         v4u pk[VSP_G];
 #pragma unroll
         for (int k = 0; k < VSP_G; ++k)
-            pk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs0, k * pstride * 4 + c * 16, 0, 16);
+            pk[k] = __builtin_amdgcn_raw_buffer_load_b128(rs0, k * pstride * 4 + c * 16, 0, PHASE == 0 ? 16 : 0);
         float4 t = f4zero();
 #pragma unroll
         for (int k = 0; k < VSP_G; ++k) {
@@ -274,7 +306,7 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
 }
 
 __global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_kernel(VisArgs a, VisSplit sp) {
-    visual_split_body(a, sp, blockIdx.x, blockIdx.y);
+    visual_split_body<0>(a, sp, blockIdx.x, blockIdx.y);
 }
 
 // =================================================================================================
@@ -601,14 +633,17 @@ __global__ __launch_bounds__(TXT_NW * 64) void pair_small_text_kernel(SmallArgs 
     }
 }
 
-template <int MT, int CPW>
+template <int MT, int CPW, int PHASE>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArgs v, VisSplit sp,
                                                                          int nv, SmallArgs b,
                                                                          int gxb) {
     const int bid = blockIdx.x;
     if (bid < nv) {
         if (threadIdx.x >= VSP_NW * 64) return;
-        visual_split_body(v, sp, bid % VSP_G, bid / VSP_G);
+        if (PHASE == 2)
+            visual_split_body<2>(v, sp, 0, bid);
+        else
+            visual_split_body<PHASE>(v, sp, bid % VSP_G, bid / VSP_G);
     } else {
         small_gemm_body<MT, CPW>(b, (bid - nv) % gxb, (bid - nv) / gxb);
     }
@@ -630,7 +665,7 @@ int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec
     if (mode == 0 && split_part && split_counter && src.V > (VSP_G - 1) * VSP_RPG &&
         src.V <= VSP_G * VSP_RPG && B <= 256) {
         hipLaunchKernelGGL(visual_attn_split_kernel, dim3(VSP_G, B), dim3(VSP_NW * 64), 0, st, a,
-                           VisSplit{split_part, split_counter});
+                           VisSplit{split_part, split_counter, nullptr});
         return launch_status();
     }
     if (mode == 0)
@@ -734,20 +769,30 @@ int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, i
     return launch_status();
 }
 
+extern "C" void sf_debug_trace(unsigned long long* buf) { g_trace = buf; }
+
 int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
                    int ldo, const Dropout& drop, int drop_col0, float* split_part,
-                   unsigned* split_counter, const SmallPlan& b, hipStream_t st) {
+                   unsigned* split_counter, const SmallPlan& b, hipStream_t st, int phase) {
     const int F = src.IMG + src.LOC;
-    if (!(b.mt == 1 && b.cpw == 8)) return SF_ERR_UNSUPPORTED;
-    if (!split_part || !split_counter || src.V <= (VSP_G - 1) * VSP_RPG || src.V > VSP_G * VSP_RPG ||
+    if (!(b.mt == 1 && (b.cpw == 8 || (phase == 2 && b.cpw == 4)))) return SF_ERR_UNSUPPORTED;
+    if (!split_part || (phase == 0 && !split_counter) || src.V <= (VSP_G - 1) * VSP_RPG || src.V > VSP_G * VSP_RPG ||
         B > 256 ||
         F > VIS_CPL * 256 || (F & 3) || (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) ||
         (ldvec & 3) || (ldo & 3))
         return SF_ERR_UNSUPPORTED;
     VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
-    const int nv = VSP_G * B, nb = b.gx * b.gy;
-    hipLaunchKernelGGL((pair_vis_small_kernel<1, 8>), dim3(nv + nb), dim3(SMALL_WAVES * 64), 0, st, va,
-                       VisSplit{split_part, split_counter}, nv, b.args, b.gx);
+    const int nv = (phase == 2 ? 1 : VSP_G) * B, nb = b.gx * b.gy;
+    const dim3 grid(nv + nb), block(SMALL_WAVES * 64);
+    const VisSplit sp{split_part, split_counter, g_trace};
+    if (phase == 0)
+        hipLaunchKernelGGL((pair_vis_small_kernel<1, 8, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (phase == 1)
+        hipLaunchKernelGGL((pair_vis_small_kernel<1, 8, 1>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (b.cpw == 8)
+        hipLaunchKernelGGL((pair_vis_small_kernel<1, 8, 2>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else
+        hipLaunchKernelGGL((pair_vis_small_kernel<1, 4, 2>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     return launch_status();
 }
 

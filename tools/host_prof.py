@@ -25,3 +25,8 @@ with torch.no_grad():
     for _ in range(10): eng.rollout(batch, 20, 'argmax', train=False)
     pr.disable(); torch.cuda.synchronize()
     pstats.Stats(pr).sort_stats('cumulative').print_stats(14)
+    for n in (5, 20, 40):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(n): st = eng.rollout(batch, 20, 'argmax', train=False)
+        torch.cuda.synchronize()
+        print('%d rollouts: %.3f ms each' % (n, (time.perf_counter() - t0) * 1e3 / n))
