@@ -483,6 +483,12 @@ int sf_transpose(const float* src, int R, int Ccols, float* dst, sf_stream strea
 int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float* out,
                      sf_stream stream);
 
+/* Development aid (no reference counterpart): while `buf` is non-null, the visual-attention body of
+ * the pipelined decode step stamps wall_clock64() (100 MHz) per workgroup into buf[block * 8 + k]
+ * (k = 0 start, 1 rows loaded and scored, 2 partials stored); buf = device memory of >= 512 * 8
+ * uint64, NULL switches it off.  Used by tools/vis_trace.py to read a kernel's inner timeline. */
+void sf_debug_trace(unsigned long long* buf);
+
 #ifdef __cplusplus
 }
 #endif

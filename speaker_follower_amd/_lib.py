@@ -110,6 +110,7 @@ WS = [c_p, C.c_size_t, c_p]          # ws, ws_bytes, stream
 _SIGNATURES = {
     'sf_workspace_bytes': (C.c_size_t, []),
     'sf_abi_version': (C.c_int, []),
+    'sf_debug_trace': (None, [C.c_void_p]),
     'sf_status_string': (C.c_char_p, [C.c_int]),
     'sf_last_error_string': (C.c_char_p, []),
     'sf_linear_fwd': (C.c_int, [c_f, i32, c_f, c_f, i32, i32, i32, i32, c_f, i32] + WS),

@@ -19,8 +19,6 @@ eng = follower.FollowerEngine(enc, dec, store)
 nblk = 512
 trace = torch.zeros(nblk * 8, dtype=torch.int64, device=device)
 lib = _lib.lib
-lib.sf_debug_trace.argtypes = [ctypes.c_void_p]
-lib.sf_debug_trace.restype = None
 with torch.no_grad():
     for _ in range(3):
         eng.rollout(batch, 20, 'argmax', train=False)
