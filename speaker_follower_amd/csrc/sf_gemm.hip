@@ -460,6 +460,134 @@ __global__ __launch_bounds__(4 * LSTM_KS * 64) void lstm_step_fused_kernel(LstmS
     lstm_cell_update(p.pw, pb, pj, g4, c0v, lv);
 }
 
+// The same step with a 32-row x 8-hidden-unit patch per block (B > 16).  A recurrent step is bound by
+// the bytes ONE block pulls through its CU (timestamped: the loads of the 16 x 16 patch -- 128 KB of
+// W_hh, the 32 KB of h fetched once per gate wave = 256 KB issued -- keep landing for ~6 us of an
+// 11.5 us step; the MFMAs take 1.7 us).  Per block the bytes are (4 hu + rows) x 2 KB, smallest at
+// rows = 4 hu: 8 units x 32 rows = 128 KB, and with the 16 waves as 16 K-slices that each hold both
+// m-tiles and both n-tiles nothing is fetched twice.  grid (H/8, ceil(B/32)).
+//   n-tile q = gates (2q, 2q+1) x 8 units: column li -> W_hh row (2q + li/8) H + 8 slice + li%8.
+constexpr int LSTMW_WAVES = 16;
+
+template <int CPW>
+__global__ __launch_bounds__(LSTMW_WAVES * 64) void lstm_step_wide_kernel(LstmStepArgs p) {
+    __shared__ float s_red[LSTMW_WAVES / 2][4][256];     // 32 KB: partial tiles (t, q) of 8 waves
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slice = blockIdx.x, m0 = blockIdx.y * 32;
+    const int li = lane & 15, kk = lane >> 4;
+    const int H = p.H;
+
+    // tail operands of the (row, unit) this thread updates (threads 0..255), fetched FIRST
+    const int prow = threadIdx.x >> 3, pcol = threadIdx.x & 7;
+    const int pb = m0 + prow, pj = slice * 8 + pcol;
+    const bool ptail = threadIdx.x < 256 && pb < p.B;
+    float pre[4] = {0.f, 0.f, 0.f, 0.f};
+    float c0v = 0.f;
+    LstmLive lv{true, 0.f};
+    {   // straight-line: rows / threads outside the tail read a clamped (valid) address
+        const int qb = min(pb, p.B - 1);
+        c0v = p.pw.c0[qb * H + pj];
+        lv = lstm_live_load(p.pw, qb, pj);
+        float bi[4], bh[4], xv[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            bi[g] = p.b_ih[g * H + pj];
+            bh[g] = p.b_hh[g * H + pj];
+        }
+        if (p.xg) {                                              // block-uniform
+            const size_t xr = p.xg_index ? (size_t)p.xg_index[(size_t)qb * max(p.xg_index_ld, 1)] : (size_t)qb;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) xv[g] = p.xg[xr * 4 * H + g * H + pj];
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) pre[g] = bi[g] + bh[g] + xv[g];
+    }
+
+    // this wave's K-slice of all four tiles: every fragment is loaded before the first MFMA
+    const int n0c = H >> 4;
+    const int total = n0c + (p.x ? ((p.I + 15) >> 4) : 0);
+    const int c_lo = (wave * total) / LSTMW_WAVES, c_hi = ((wave + 1) * total) / LSTMW_WAVES;
+    const int nrow[2] = {(li >> 3) * H + slice * 8 + (li & 7), (2 + (li >> 3)) * H + slice * 8 + (li & 7)};
+    const int mrow[2] = {min(m0 + li, p.B - 1), min(m0 + 16 + li, p.B - 1)};
+    float4 fa[CPW][2], fb[CPW][2];
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = min(min(c_lo + i, max(c_hi - 1, c_lo)), total - 1);   // clamped: surplus slots re-load a valid chunk
+        const bool second = c >= n0c;                            // wave-uniform
+        const int lc = second ? c - n0c : c;
+        const float* W = second ? p.w_ih : p.w_hh;
+        const float* A = second ? p.x : p.h0;
+        const int ldw = second ? p.I : H;
+        const int lda = second ? p.ldx : H;
+        const int K = second ? p.I : H;
+        const int k = lc * 16 + 4 * kk;
+        const bool ok = k < K && c_lo + i < c_hi;                // partial last chunk / surplus slot
+        const int kc = k < K ? k : 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const float4 bv = ld4(W + (size_t)nrow[q] * ldw + kc);
+            fb[i][q] = ok ? bv : z;
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const float4 av = ld4(A + (size_t)mrow[t] * lda + kc);
+            fa[i][t] = ok ? av : z;
+        }
+    }
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) acc[t][q] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < CPW; ++i)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    acc[t][q] = mfma16(comp(fa[i][t], c), comp(fb[i][q], c), acc[t][q]);
+
+    // 16 partial tile sets -> 8 (through LDS) -> the cell update sums the 8
+    if (wave >= LSTMW_WAVES / 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    s_red[wave - LSTMW_WAVES / 2][t * 2 + q][(kk * 4 + r) * 16 + li] = acc[t][q][r];
+    }
+    __syncthreads();
+    if (wave < LSTMW_WAVES / 2) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    float* sp = &s_red[wave][t * 2 + q][(kk * 4 + r) * 16 + li];
+                    *sp += acc[t][q][r];                          // (same thread wrote / reads this slot)
+                }
+    }
+    __syncthreads();
+
+    if (!ptail) return;
+    float g4[4];
+    const int tt = prow >> 4, rr = prow & 15;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        float v = pre[g];
+        const int e = rr * 16 + (g & 1) * 8 + pcol;
+#pragma unroll
+        for (int k = 0; k < LSTMW_WAVES / 2; ++k) v += s_red[k][tt * 2 + (g >> 1)][e];
+        g4[g] = v;
+    }
+    lstm_cell_update(p.pw, pb, pj, g4, c0v, lv);
+}
+
 // Fused BACKWARD time step of the encoder LSTM: block = 16 rows x 16 hidden units, 8 waves = 8
 // K-slices of dh_{t+1}[tile] = dgates_{t+1}[16 rows, 4H] . W_hh^T[16 units, 4H] (all loads up front,
 // partial tiles meet in LDS), then the cell backward of step t for the tile's 256 elements in the
@@ -1026,6 +1154,18 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
 int lstm_step_fused(const LstmStepArgs& p, hipStream_t st) {
     if (p.H % 16 || (p.x && (p.I % 4 || p.ldx % 4))) return SF_ERR_UNSUPPORTED;
     const int total = ceil_div(p.H, 16) + (p.x ? ceil_div(p.I, 16) : 0);
+    if (p.B > 16 && p.H % 8 == 0) {          // 32 x 8 patches: fewer bytes per block (see the kernel)
+        const int cw = ceil_div(total, LSTMW_WAVES);
+        dim3 wgrid(p.H / 8, ceil_div(p.B, 32)), wblock(LSTMW_WAVES * 64);
+        if (cw <= 2) {
+            hipLaunchKernelGGL(lstm_step_wide_kernel<2>, wgrid, wblock, 0, st, p);
+            return launch_status();
+        }
+        if (cw <= 4) {
+            hipLaunchKernelGGL(lstm_step_wide_kernel<4>, wgrid, wblock, 0, st, p);
+            return launch_status();
+        }
+    }
     const int c = ceil_div(total, LSTM_KS);
     dim3 grid(p.H / 16, ceil_div(p.B, 16)), block(4 * LSTM_KS * 64);
     if (c <= 8)
