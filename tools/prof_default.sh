@@ -8,5 +8,5 @@ rocprofv3 --kernel-trace --stats -d $O/prof_default -- python3 $R/bench.py "$@" 
 f=$(find $O/prof_default -name "*.db" | head -1)
 python3 $R/tools/rocpd_stats.py $f > $O/prof_default_stats.txt 2>&1
 rm -rf $O/prof_default
-tail -1 $O/prof_default.log > $O/prof_default_bench.json
+grep "\"metric\"" $O/prof_default.log | tail -1 > $O/prof_default_bench.json
 head -30 $O/prof_default_stats.txt | cut -c1-160
