@@ -130,12 +130,14 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
                const float* h0, const float* c0, const float* c1, const float* gates,
                const float* dh1, const float* dh1_b, const float* dc1, float* dx, int lddx,
                float* dh0, float* dc0, Arena ar, hipStream_t st, float* dgates_out = nullptr,
-               int dx_col0 = 0) {          // dx is only formed for input columns >= dx_col0
+               int dx_col0 = 0,            // dx is only formed for input columns >= dx_col0
+               const Dropout* dh1b_drop = nullptr) {   // mask still to be applied to dh1_b
     float* dgates = dgates_out ? dgates_out : ar.take((size_t)B * 4 * H);
     NEED(dgates);
     LstmPwBwd p{};
     p.gates = gates; p.c0 = c0; p.c1 = c1; p.dh1 = dh1; p.dh1_b = dh1_b; p.dc1 = dc1;
     p.B = B; p.H = H; p.dgates = dgates; p.dc0 = dc0; p.lengths = nullptr; p.dh0_pass = nullptr;
+    if (dh1b_drop) p.dh1b_drop = *dh1b_drop;
     TRY(lstm_pointwise_bwd(p, st));
     if (dx && dx_col0 == 0) {
         TRY(data_grad(dgates, 4 * H, w->w_ih, w->w_ih_t, B, 4 * H, I, dx, lddx, 0, ar, st));
@@ -219,17 +221,31 @@ int softdot_fwd_i(const sf_softdot_w* w, int B, int L, int H, const float* copy_
 int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, int H,
                   const float* ctx, const float* alpha, const float* cat2, const float* t_text,
                   const float* h_tilde, const float* dh_tilde, float* dh, int lddh, float* dctx,
-                  Arena ar, hipStream_t st, float* dpre_out = nullptr, float* dt_out = nullptr) {
+                  Arena ar, hipStream_t st, float* dpre_out = nullptr, float* dt_out = nullptr,
+                  bool dpre_ready = false) {   // dh_tilde already IS dpre (written to dpre_out)
     float* dpre = dpre_out ? dpre_out : ar.take((size_t)B * H);
     float* dt = dt_out ? dt_out : ar.take((size_t)B * H);
     float* dcat2 = ar.take((size_t)B * 2 * H);
     NEED(dpre && dcat2 && dt);
-    TRY(tanh_bwd(h_tilde, H, dh_tilde, H, B, H, dpre, H, st));
+    if (dpre_ready) dpre = const_cast<float*>(dh_tilde);
+    else TRY(tanh_bwd(h_tilde, H, dh_tilde, H, B, H, dpre, H, st));
     TRY(data_grad(dpre, H, w->w_out, w->w_out_t, B, H, 2 * H, dcat2, 2 * H, 0, ar, st));
     if (g && g->w_out) TRY(gemm_tn(dpre, H, cat2, 2 * H, B, H, 2 * H, g->w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
     TRY(text_attn_bwd(ctx, B, L, H, dcat2, 2 * H, t_text, H, alpha, dt, H, dctx, st));
-    TRY(add2(dcat2 + H, 2 * H, nullptr, 0, B, H, dh, lddh, st));
-    TRY(data_grad(dt, H, w->w_in, w->w_in_t, B, H, H, dh, lddh, 1, ar, st));
+    // dh = dcat2[:, H:] + dt W_in: the addend rides in the epilogue of the product
+    bool dh_done = false;
+    if (w->w_in_t) {
+        Seg sg{dt, H, w->w_in_t, H, H};
+        LinearOut o{};
+        o.y = dh; o.ldy = lddh; o.epi = EPI_NONE; o.addend = dcat2 + H; o.ld_addend = 2 * H;
+        const int rc = linear_nt(&sg, 1, B, H, o, ar.rest(), ar.rest_n(), st);
+        if (rc == SF_OK) dh_done = true;
+        else if (rc != SF_ERR_UNSUPPORTED) return rc;
+    }
+    if (!dh_done) {
+        TRY(add2(dcat2 + H, 2 * H, nullptr, 0, B, H, dh, lddh, st));
+        TRY(data_grad(dt, H, w->w_in, w->w_in_t, B, H, H, dh, lddh, 1, ar, st));
+    }
     if (g && g->w_in) TRY(gemm_tn(dt, H, cat2 + H, 2 * H, B, H, H, g->w_in, H, 1, st, ar.rest(), ar.rest_n()));
     return SF_OK;
 }
@@ -264,7 +280,10 @@ int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, 
 
 int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U, int B, int H,
                   int D, const float* h, const float* t_a, const float* wt, const float* dlogit,
-                  float* dh, Arena ar, hipStream_t st, const sf_decoder_gtape* gt = nullptr) {
+                  float* dh, Arena ar, hipStream_t st, const sf_decoder_gtape* gt = nullptr,
+                  const float* tanh_of = nullptr, bool* tanh_done = nullptr) {
+    // tanh_of (= h, the tanh output that fed the scoring): when given and the shape allows, dh is
+    // returned already multiplied by (1 - tanh_of^2) and *tanh_done is set
     const int F = U.IMG + U.LOC;
     float* dr = gt ? gt->dr : ar.take((size_t)B * F);
     float* dc = gt ? gt->dc : ar.take((size_t)B);
@@ -272,16 +291,41 @@ int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U
     float* dta = gt ? gt->dta : ar.take((size_t)B * D);
     NEED(dr && dc && dwt && dta);
     TRY(score_bwd(U, B, dlogit, dr, dc, st));
-    TRY(linear_plain(dr, F, w->w_a, F, nullptr, B, D, F, EPI_NONE, dwt, D, ar, st));
-    TRY(rank1_add(dc, w->b_a, B, D, dwt, D, st));
+    // dwt = dr W_a^T + dc (x) b_a,  dta = dwt * w_out: one launch (rank-1 term and column scale in
+    // the epilogue of the product) where the short-reduction kernel covers the shape
+    bool dta_done = false;
+    {
+        Seg sg{dr, F, w->w_a, F, F};
+        LinearOut o{};
+        o.y = dta; o.ldy = D; o.y_pre = dwt; o.ldy_pre = D; o.epi = EPI_MUL; o.mul = w->w_out;
+        o.r1_s = dc; o.r1_v = w->b_a;
+        const int rc = linear_nt(&sg, 1, B, D, o, ar.rest(), ar.rest_n(), st);
+        if (rc == SF_OK) dta_done = true;
+        else if (rc != SF_ERR_UNSUPPORTED) return rc;
+    }
+    if (!dta_done) {
+        TRY(linear_plain(dr, F, w->w_a, F, nullptr, B, D, F, EPI_NONE, dwt, D, ar, st));
+        TRY(rank1_add(dc, w->b_a, B, D, dwt, D, st));
+    }
     if (g) {
         if (g->w_a) TRY(gemm_tn(wt, D, dr, F, B, D, F, g->w_a, F, 1, st, ar.rest(), ar.rest_n()));
         if (g->b_a) TRY(dot_rows_accum(dc, wt, D, B, D, g->b_a, st));
         if (g->b_out) TRY(sum_accum(dc, B, g->b_out, st));
         if (g->w_out) TRY(colsum_prod(dwt, D, t_a, D, B, D, g->w_out, st));
     }
-    TRY(scale_cols(dwt, D, w->w_out, B, D, dta, D, st));
-    if (dh) TRY(data_grad(dta, D, w->w_h, w->w_h_t, B, D, H, dh, H, 0, ar, st));
+    if (!dta_done) TRY(scale_cols(dwt, D, w->w_out, B, D, dta, D, st));
+    if (dh && tanh_of && w->w_h_t) {
+        // dh <- (dta W_h) * (1 - tanh_of^2): the backward through h~ = tanh(.) rides in the epilogue
+        Seg sg{dta, D, w->w_h_t, D, D};
+        LinearOut o{};
+        o.y = dh; o.ldy = H; o.epi = EPI_TANHBWD; o.aux = tanh_of; o.ld_aux = H;
+        const int rc = linear_nt(&sg, 1, B, H, o, ar.rest(), ar.rest_n(), st);
+        if (rc == SF_OK) { if (tanh_done) *tanh_done = true; }
+        else if (rc != SF_ERR_UNSUPPORTED) return rc;
+        else TRY(data_grad(dta, D, w->w_h, w->w_h_t, B, D, H, dh, H, 0, ar, st));
+    } else if (dh) {
+        TRY(data_grad(dta, D, w->w_h, w->w_h_t, B, D, H, dh, H, 0, ar, st));
+    }
     if (g && g->w_h) TRY(gemm_tn(dta, D, h, H, B, D, H, g->w_h, H, 1, st, ar.rest(), ar.rest_n()));
     if (g && g->b_h) TRY(colsum(dta, D, B, D, g->b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
     return SF_OK;
@@ -620,18 +664,24 @@ static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_
     const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
     float* dht = ar.take((size_t)B * H);       // d h_tilde
     float* dh1d = ar.take((size_t)B * H);      // d dropout(h1)
-    float* dh1m = ar.take((size_t)B * H);      // the same through the dropout mask
     float* dxin = ar.take((size_t)B * 2 * F);  // d LSTM input
-    NEED(dht && dh1d && dh1m && dxin);
+    NEED(dht && dh1d && dxin);
+    // with a gradient tape the scoring backward writes d(pre-tanh) straight into gt->dpre
+    bool dpre_ready = false;
+    float* dht_out = gt ? gt->dpre : dht;
     TRY(scoring_bwd_i(&w->action, g ? &g->action : nullptr, cands(U), B, H, D, tp->h_tilde, tp->t_a,
-                      tp->wt, dlogit, dht, ar, st, gt));
+                      tp->wt, dlogit, dht_out, ar, st, gt, gt ? tp->h_tilde : nullptr, &dpre_ready));
+    if (gt && !dpre_ready) {      // not fused: dht_out holds d h~; keep it apart from gt->dpre
+        TRY(add2(dht_out, H, nullptr, 0, B, H, dht, H, st));
+        dht_out = dht;
+    }
     TRY(softdot_bwd_i(&w->text, g ? &g->text : nullptr, B, L, H, ctx, tp->alpha, tp->cat2,
-                      tp->t_text, tp->h_tilde, dht, dh1d, H, dctx, ar, st, gt ? gt->dpre : nullptr,
-                      gt ? gt->dt_text : nullptr));
-    TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
+                      tp->t_text, tp->h_tilde, dht_out, dh1d, H, dctx, ar, st, gt ? gt->dpre : nullptr,
+                      gt ? gt->dt_text : nullptr, dpre_ready));
+    // (the dropout between h1 and the text attention is undone inside the LSTM pointwise backward)
     TRY(lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->c1,
-                   tp->gates, dh1, dh1m, dc1, dxin, 2 * F, dh0, dc0, ar, st,
-                   gt ? gt->dgates : nullptr, F));      // u_prev is detached (follower.py:502): only
+                   tp->gates, dh1, dh1d, dc1, dxin, 2 * F, dh0, dc0, ar, st,
+                   gt ? gt->dgates : nullptr, F, &d_h)); // u_prev is detached (follower.py:502): only
                                                         // the feature half of d(LSTM input) is needed
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                         dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,

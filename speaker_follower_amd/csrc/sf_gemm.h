@@ -18,6 +18,7 @@ enum Epi : int {
     EPI_NONE = 0,    // y = acc + bias
     EPI_TANH = 1,    // y = tanh(acc + bias)
     EPI_MUL = 2,     // y = (acc + bias) * mul[n]         (EltwiseProdScoring fold)
+    EPI_TANHBWD = 3, // y = (acc + bias) * (1 - aux[m,n]^2)   (backward through h~ = tanh(.))
 };
 
 struct LinearOut {
@@ -30,6 +31,15 @@ struct LinearOut {
     int ldy_pre;
     Epi epi;
     int accumulate;      // y += result (EPI_NONE only)
+    // Fused element-wise neighbours of the backward pass (short-reduction kernel only; linear_nt
+    // returns SF_ERR_UNSUPPORTED when the shape needs another kernel and the caller launches the
+    // element-wise kernels separately):
+    const float* aux;    // EPI_TANHBWD operand [M, ld_aux]
+    int ld_aux;
+    const float* addend; // v += addend[m, n] (row stride ld_addend) before the epilogue
+    int ld_addend;
+    const float* r1_s;   // v += r1_s[m] * r1_v[n] before the epilogue (rank-1 term)
+    const float* r1_v;
 };
 
 // Workspace needed (in floats) for sf::linear_nt on an [M,N] output with total depth K.

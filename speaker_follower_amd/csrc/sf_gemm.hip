@@ -388,6 +388,10 @@ template <int MT, int CPW>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_kernel(SmallArgs a) {
     small_gemm_body<MT, CPW>(a, blockIdx.x, blockIdx.y);
 }
+template <int MT, int CPW>     // with the fused backward epilogues (see small_gemm_body)
+__global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_x_kernel(SmallArgs a) {
+    small_gemm_body<MT, CPW, true>(a, blockIdx.x, blockIdx.y);
+}
 
 // Fused recurrent LSTM step (nn.LSTMCell / one nn.LSTM time step): block = 16 waves = the 4 gate
 // tiles (i,f,g,o) of one 16-row x 16-hidden-unit patch x 4 K-slices; gates meet in LDS and the cell
@@ -950,9 +954,10 @@ inline int red_grid(size_t total) { return (int)std::min<size_t>((total + 255) /
 // streaming kernel should be used instead.
 static bool small_shape(int M, int N, int chunks, int* mt, int* cpw) {
     const int mtiles = ceil_div(M, 16), ntiles = ceil_div(N, 16);
-    if (chunks > 128 || (long)mtiles * ntiles > (chunks > 64 ? 512 : 2048)) return false;
-    const int c = ceil_div(chunks, SMALL_WAVES);          // chunks per wave: 1..16
-    *cpw = c <= 2 ? 2 : (c <= 4 ? 4 : (c <= 8 ? 8 : 16));
+    if (chunks > 144 || (long)mtiles * ntiles > (chunks > 64 ? 512 : 2048)) return false;
+    if (chunks > 128 && (long)mtiles * ntiles > 128) return false;   // (K = 2176 -> 256: the dq / dr products)
+    const int c = ceil_div(chunks, SMALL_WAVES);          // chunks per wave: 1..18
+    *cpw = c <= 2 ? 2 : (c <= 4 ? 4 : (c <= 8 ? 8 : (c <= 16 ? 16 : 18)));
     int m = std::max(1, std::min(mtiles, 32 / *cpw - 1)); // <= 32 float4 of loads per lane
     m = m >= 4 ? 4 : (m >= 2 ? 2 : 1);
     // a CU sustains only ~20-35 GB/s of loads, so what matters is the bytes ONE block pulls
@@ -965,7 +970,10 @@ static bool small_shape(int M, int N, int chunks, int* mt, int* cpw) {
 template <int MT, int CPW>
 static void launch_small(const SmallArgs& a, hipStream_t st) {
     dim3 grid(ceil_div(a.N, 16), ceil_div(ceil_div(a.M, 16), MT));
-    hipLaunchKernelGGL((gemm_nt_small_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
+    if (a.addend || a.r1_s || a.epi == EPI_TANHBWD)
+        hipLaunchKernelGGL((gemm_nt_small_x_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
+    else
+        hipLaunchKernelGGL((gemm_nt_small_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
 }
 
 static void nt_shape(int M, int N, int Ktot_chunks, int* mt, int* mblocks, int* ks) {
@@ -1014,6 +1022,8 @@ bool linear_small_plan(const Seg* segs, int nseg, int M, int N, const LinearOut&
     sa.M = M; sa.N = N; sa.y = out.y; sa.ldy = out.ldy; sa.bias = out.bias; sa.bias2 = out.bias2;
     sa.epi = out.epi; sa.mul = out.mul; sa.y_pre = out.y_pre; sa.ldy_pre = out.ldy_pre;
     sa.accumulate = out.accumulate;
+    sa.aux = out.aux; sa.ld_aux = out.ld_aux; sa.addend = out.addend; sa.ld_addend = out.ld_addend;
+    sa.r1_s = out.r1_s; sa.r1_v = out.r1_v;
     plan->mt = mt;
     plan->cpw = cpw;
     plan->gx = ceil_div(N, 16);
@@ -1028,6 +1038,7 @@ static int launch_small_plan(const SmallPlan& p, hipStream_t st) {
         case 1 * 32 + 4: launch_small<1, 4>(sa, st); break;
         case 1 * 32 + 8: launch_small<1, 8>(sa, st); break;
         case 1 * 32 + 16: launch_small<1, 16>(sa, st); break;
+        case 1 * 32 + 18: launch_small<1, 18>(sa, st); break;
         case 2 * 32 + 2: launch_small<2, 2>(sa, st); break;
         case 2 * 32 + 4: launch_small<2, 4>(sa, st); break;
         case 2 * 32 + 8: launch_small<2, 8>(sa, st); break;
@@ -1057,6 +1068,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         if (ksplit_out) *ksplit_out = 1;
         return rc;
     }
+    if (out.addend || out.r1_s || out.epi == EPI_TANHBWD) return SF_ERR_UNSUPPORTED;   // small kernel only
     nt_shape(M, N, chunks, &mt, &mblocks, &ks);
     const bool slabs = ks > 1 || raw_slabs;
     if (slabs) {

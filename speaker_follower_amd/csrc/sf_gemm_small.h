@@ -81,11 +81,16 @@ struct SmallArgs {
     float* y_pre;
     int ldy_pre;
     int accumulate;
+    const float* aux; int ld_aux;          // see LinearOut
+    const float* addend; int ld_addend;
+    const float* r1_s; const float* r1_v;
 };
 
 // Block (bx, by) of the grid (ceil(N/16), ceil(mtiles/MT)); 512 threads = 8 waves = 8 K-slices of one
 // 16-col n-tile x MT m-tiles.  Threads >= 512 of a larger (paired) block must not enter.
-template <int MT, int CPW>
+// EXTRA: the fused backward epilogues (aux / addend / rank-1 operands); a separate instantiation so
+// that the forward products carry none of their registers or branches.
+template <int MT, int CPW, bool EXTRA = false>
 __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int by) {
     __shared__ float s_part[SMALL_WAVES][MT][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -102,6 +107,20 @@ __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int 
     if (a.bias) e_bias = a.bias[ecol];                 // block-uniform branches, one load each
     if (a.bias2) e_bias += a.bias2[ecol];
     if (a.epi == EPI_MUL) e_mul = a.mul[ecol];
+    // element-wise operands of the fused backward epilogues: this thread's elements are known now,
+    // so their loads travel with the fragments instead of sitting behind the MFMAs
+    constexpr int EPT = (MT * 256 + SMALL_WAVES * 64 - 1) / (SMALL_WAVES * 64);
+    float e_add[EPT], e_aux[EPT], e_r1[EPT];
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = min((int)threadIdx.x + i * SMALL_WAVES * 64, MT * 256 - 1);
+        const int row = min(m0 + 16 * (e >> 8) + ((e & 255) >> 4), a.M - 1);
+        e_add[i] = e_aux[i] = e_r1[i] = 0.f;
+        if (!EXTRA) continue;
+        if (a.addend) e_add[i] = a.addend[(size_t)row * a.ld_addend + ecol];     // block-uniform
+        if (a.epi == EPI_TANHBWD) e_aux[i] = a.aux[(size_t)row * a.ld_aux + ecol];
+        if (a.r1_s) e_r1[i] = a.r1_s[row] * a.r1_v[ecol];
+    }
 
     const int c_lo = (wave * a.sg.total) / SMALL_WAVES;
     const int c_hi = ((wave + 1) * a.sg.total) / SMALL_WAVES;
@@ -119,7 +138,10 @@ __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int 
         for (int r = 0; r < 4; ++r) s_part[wave][t][(kk * 4 + r) * 16 + li] = acc[t][r];
     __syncthreads();
 
-    for (int e = threadIdx.x; e < MT * 256; e += SMALL_WAVES * 64) {
+#pragma unroll
+    for (int i = 0; i < EPT; ++i) {
+        const int e = threadIdx.x + i * SMALL_WAVES * 64;
+        if (e >= MT * 256) break;
         const int t = e >> 8, rc = e & 255;
         const int row = m0 + 16 * t + (rc >> 4), col = n0 + (rc & 15);
         if (row >= a.M || col >= a.N) continue;
@@ -127,7 +149,9 @@ __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int 
 #pragma unroll
         for (int w = 0; w < SMALL_WAVES; ++w) v += s_part[w][t][rc];
         v += e_bias;                                   // (col == ecol: 512 % 16 == 0)
+        if (EXTRA) v += e_add[i] + e_r1[i];
         if (a.epi == EPI_TANH) v = tanhf(v);
+        if (EXTRA && a.epi == EPI_TANHBWD) v *= 1.f - e_aux[i] * e_aux[i];
         if (a.epi == EPI_MUL) {
             if (a.y_pre) a.y_pre[(size_t)row * a.ldy_pre + col] = v;
             v *= e_mul;

@@ -46,6 +46,8 @@ struct LstmPwBwd {
                                  // (may alias dh1: element-wise in place)
     const float* dctx; int T;    // encoder: + dropout-masked dctx[b, t, :] (row stride T*H), or null
     Dropout ctx_drop;
+    Dropout dh1b_drop;           // mask applied to dh1_b on load (column = j): the backward of the
+                                 // dropout between h1 and the text attention (model.py:394)
 };
 int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st);
 

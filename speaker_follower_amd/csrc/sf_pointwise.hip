@@ -63,7 +63,15 @@ __global__ __launch_bounds__(TPB) void lstm_pw_bwd_kernel(LstmPwBwd a) {
         const float c1 = a.c1[idx], c0 = a.c0[idx];
         float dh = 0.f, dc = 0.f;
         if (a.dh1) dh = a.dh1[idx];
-        if (a.dh1_b) dh += a.dh1_b[idx];
+        if (a.dh1_b) {
+            float v = a.dh1_b[idx];
+            if (a.dh1b_drop.on()) {
+                const uint32_t rk = dropout_row_key(a.dh1b_drop.seed, a.dh1b_drop.stream,
+                                                    (uint32_t)(a.dh1b_drop.row0 + b));
+                v = dropout_keep(rk, (uint32_t)j, a.dh1b_drop.thresh) ? v * a.dh1b_drop.scale : 0.f;
+            }
+            dh += v;
+        }
         if (a.dc1) dc = a.dc1[idx];
         bool dead = false;
         if (a.lengths) dead = a.t >= a.lengths[b];
