@@ -787,7 +787,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // 4-deep clamped prefetch ring over the batch rows (4 rows per step): loads of steps s+1..s+3
+    // 8-deep clamped prefetch ring over the batch rows (4 rows per step): loads of steps s+1..s+7
     // are in flight while step s feeds 16 MFMAs; clamped (not predicated) addresses keep the loop
     // body branch-free, rows >= M contribute through a zero multiplier.
     const int steps = (a.M + 3) >> 2;
@@ -805,18 +805,21 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(comp(y, i), comp(xv, j), acc[i][j]);
     };
-    float4 y0, x0, y1, x1, y2, x2, y3, x3;
-    ld(0, y0, x0); ld(1, y1, x1); ld(2, y2, x2); ld(3, y3, x3);
+    constexpr int RING = 8;
+    float4 yr[RING], xr[RING];
+#pragma unroll
+    for (int i = 0; i < RING; ++i) ld(i, yr[i], xr[i]);
     int s4 = 0;
-    for (; s4 + 4 <= steps; s4 += 4) {
-        mma(s4, y0, x0);     ld(s4 + 4, y0, x0);
-        mma(s4 + 1, y1, x1); ld(s4 + 5, y1, x1);
-        mma(s4 + 2, y2, x2); ld(s4 + 6, y2, x2);
-        mma(s4 + 3, y3, x3); ld(s4 + 7, y3, x3);
+    for (; s4 + RING <= steps; s4 += RING) {
+#pragma unroll
+        for (int i = 0; i < RING; ++i) {
+            mma(s4 + i, yr[i], xr[i]);
+            ld(s4 + RING + i, yr[i], xr[i]);
+        }
     }
-    if (s4 < steps) mma(s4, y0, x0);
-    if (s4 + 1 < steps) mma(s4 + 1, y1, x1);
-    if (s4 + 2 < steps) mma(s4 + 2, y2, x2);
+#pragma unroll
+    for (int i = 0; i < RING - 1; ++i)
+        if (s4 + i < steps) mma(s4 + i, yr[i], xr[i]);
 
     if (!qok) return;
     // read-modify-write of the gradient tile: all 16 reads first (straight-line, clamped rows), then
@@ -928,6 +931,101 @@ __global__ __launch_bounds__(256) void colsum_finish_kernel(const float* part, i
     if (out2) out2[n] = accumulate ? out2[n] + t : t;
 }
 
+// The same product with the operands shared through LDS: block = 4 waves = 2 x 2 tiles of 64 x 64,
+// i.e. 128 P-rows x 128 Q-cols; every 16 batch rows are staged once ([16][128] of Y and of X, 16 KB,
+// double buffered) and read back as fragments by the two waves that need them.  The register-
+// streaming kernel above pulls 2 KB per wave and 16 MFMAs -- at the matrix-pipe rate that is the
+// ~40 GB/s one CU sustains; this one pulls half of that.  A fragment row is 256 contiguous bytes
+// per 16 lanes: conflict-free without padding.
+constexpr int TNT_BM = 16, TNT_B = 128;
+
+__global__ __launch_bounds__(256) void gemm_tn_tiled_kernel(TnArgs a) {
+    __shared__ float4 Ys[2][TNT_BM][TNT_B / 4];
+    __shared__ float4 Xs[2][TNT_BM][TNT_B / 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int p0b = blockIdx.y * TNT_B, q0b = blockIdx.x * TNT_B;
+    if (a.msplit > 1) {    // row range of this split; its slab is a dense [P, Q] matrix
+        const int z = blockIdx.z;
+        const int m_lo = (int)(((long)z * a.M) / a.msplit), m_hi = (int)(((long)(z + 1) * a.M) / a.msplit);
+        a.Y += (size_t)m_lo * a.ldy;
+        a.X += (size_t)m_lo * a.ldx;
+        a.M = m_hi - m_lo;
+        a.out += (size_t)z * a.P * a.ldo;
+    }
+    const int li = lane & 15, kk = lane >> 4;
+    const int srow = tid >> 5, sc4 = tid & 31;          // staging: 8 rows x 32 float4 per pass, 2 passes
+    const int pcl = min(p0b + 4 * sc4, a.ldy - 4);      // clamped: columns beyond P / Q are never stored
+    const int qcl = min(q0b + 4 * sc4, a.Q - 4);
+    const int stages = (a.M + TNT_BM - 1) / TNT_BM;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ry[2], rx[2];
+    auto gload = [&](int st) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = min(st * TNT_BM + srow + 8 * h, a.M - 1);
+            ry[h] = ld4(a.Y + (size_t)m * a.ldy + pcl);
+            rx[h] = ld4(a.X + (size_t)m * a.ldx + qcl);
+        }
+    };
+    auto lstore = [&](int st, int buf) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const bool ok = st * TNT_BM + srow + 8 * h < a.M;    // rows beyond M contribute zeros
+            Ys[buf][srow + 8 * h][sc4] = ok ? ry[h] : make_float4(0.f, 0.f, 0.f, 0.f);
+            Xs[buf][srow + 8 * h][sc4] = rx[h];
+        }
+    };
+    gload(0);
+    lstore(0, 0);
+    __syncthreads();
+    for (int st = 0; st < stages; ++st) {
+        const int buf = st & 1;
+        gload(min(st + 1, stages - 1));                          // clamped, not predicated
+#pragma unroll
+        for (int s = 0; s < TNT_BM / 4; ++s) {
+            const float4 y = Ys[buf][4 * s + kk][wp * 16 + li];
+            const float4 x = Xs[buf][4 * s + kk][wq * 16 + li];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(comp(y, i), comp(x, j), acc[i][j]);
+        }
+        lstore(st + 1, buf ^ 1);                                 // (st + 1 == stages: all rows >= M -> zeros)
+        __syncthreads();
+    }
+
+    const int p0 = p0b + wp * 64, qc = q0b + wq * 64 + 4 * li;
+    if (qc >= a.Q) return;
+    float4 w[4][4];
+    if (a.accumulate) {                                  // block-uniform
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int p = min(p0 + 4 * (kk * 4 + r) + i, a.P - 1);
+                w[i][r] = ld4(a.out + (size_t)p * a.ldo + qc);
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int p = p0 + 4 * (kk * 4 + r) + i;     // tile row (kk*4+r) is virtual: stride-4 rows
+            float4 v = make_float4(acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]);
+            if (a.accumulate) {
+                v.x += w[i][r].x; v.y += w[i][r].y; v.z += w[i][r].z; v.w += w[i][r].w;
+            }
+            if (p < a.P) *reinterpret_cast<float4*>(a.out + (size_t)p * a.ldo + qc) = v;
+        }
+}
+
 int pick_ksplit(int waves_per_split, int chunks) {
     // aim for ~2 waves per SIMD over the chip (1024 SIMDs), at least 4 16-deep chunks per split,
     // and at most 8 partial slabs (each split costs one extra write + read of the output)
@@ -990,6 +1088,10 @@ static void nt_shape(int M, int N, int Ktot_chunks, int* mt, int* mblocks, int* 
     *mt = mtiles <= 8 ? mtiles : 8;
     *mblocks = ceil_div(mtiles, *mt);
     *ks = pick_ksplit(ntiles * *mblocks, Ktot_chunks);
+    // the LDS-tiled kernel runs one workgroup per CU: a grid of more than 256 of them (34 n-tiles x 8
+    // splits for the [100,2048] x [2048,2176] input gradient) pays a second, nearly empty round
+    if (*mblocks == 1 && Ktot_chunks >= 128)
+        while (*ks > 1 && ceil_div(N, 64) * *ks > 256) --*ks;
 }
 
 int linear_ksplit(int M, int N, int Ktot) {
@@ -1257,6 +1359,26 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
     // A small weight matrix with a deep reduction (e.g. [256, 2176] over 2000 stacked rows) is a
     // handful of waves each walking all M rows: split the rows over grid.z into slabs and add them
     // up (deterministic order) until the chip is covered.
+    if (P >= 128 && Q >= 128 && ldy >= 128 && M >= 4096) {   // (measured: pays for the deep encoder reductions)
+        // LDS-tiled kernel: 128 x 128 per block; small outputs split the batch rows into slabs
+        const int blocks = ceil_div(Q, TNT_B) * ceil_div(P, TNT_B);
+        int ms = std::min(16, std::max(1, 768 / blocks));
+        ms = std::min(ms, std::max(1, M / 64));
+        if (ms > 1 && (!ws || ws_floats < (size_t)ms * P * Q)) ms = 1;
+        dim3 grid(ceil_div(Q, TNT_B), ceil_div(P, TNT_B), ms);
+        if (ms > 1) {
+            TnArgs a{Y, ldy, X, ldx, M, P, Q, ws, Q, 0, ms};
+            hipLaunchKernelGGL(gemm_tn_tiled_kernel, grid, dim3(256), 0, st, a);
+            RedArgs r{};
+            r.slabs = ws; r.ks = ms; r.M = P; r.N = Q; r.y = out; r.ldy = ldo; r.epi = EPI_NONE;
+            r.accumulate = accumulate;
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
+            return launch_status();
+        }
+        TnArgs a{Y, ldy, X, ldx, M, P, Q, out, ldo, accumulate, 1};
+        hipLaunchKernelGGL(gemm_tn_tiled_kernel, grid, dim3(256), 0, st, a);
+        return launch_status();
+    }
     const int waves = ceil_div(Q, 64) * ceil_div(P, 64);
     int ms = std::min(16, std::max(1, 1024 / waves));
     ms = std::min(ms, std::max(1, M / 64));
