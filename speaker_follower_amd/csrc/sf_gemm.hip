@@ -481,30 +481,26 @@ __global__ __launch_bounds__(LSTMW_WAVES * 64) void lstm_step_wide_kernel(LstmSt
     const int li = lane & 15, kk = lane >> 4;
     const int H = p.H;
 
-    // tail operands of the (row, unit) this thread updates (threads 0..255), fetched FIRST
-    const int prow = threadIdx.x >> 3, pcol = threadIdx.x & 7;
+    // Tail operands.  The block updates 256 (row, unit) elements (threads 0..255 do it); their gate
+    // biases and hoisted input rows are 12 scattered dword loads per element -- issued by all 1024
+    // threads for their own element they were more vector-memory instructions than the fragments
+    // (and ahead of them in the queue).  Instead thread (g, e) fetches gate g of element e: 4 loads,
+    // the sums meet in LDS with the partial tiles.
+    __shared__ float s_pre[4][256];
+    const int pe = threadIdx.x & 255, pg = threadIdx.x >> 8;
+    const int prow = pe >> 3, pcol = pe & 7;
     const int pb = m0 + prow, pj = slice * 8 + pcol;
     const bool ptail = threadIdx.x < 256 && pb < p.B;
-    float pre[4] = {0.f, 0.f, 0.f, 0.f};
-    float c0v = 0.f;
-    LstmLive lv{true, 0.f};
-    {   // straight-line: rows / threads outside the tail read a clamped (valid) address
-        const int qb = min(pb, p.B - 1);
-        c0v = p.pw.c0[qb * H + pj];
-        lv = lstm_live_load(p.pw, qb, pj);
-        float bi[4], bh[4], xv[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            bi[g] = p.b_ih[g * H + pj];
-            bh[g] = p.b_hh[g * H + pj];
-        }
+    const int qb = min(pb, p.B - 1);
+    float pre_g;
+    {   // straight-line: rows outside the batch read a clamped (valid) address
+        const float bi = p.b_ih[pg * H + pj], bh = p.b_hh[pg * H + pj];
+        float xv = 0.f;
         if (p.xg) {                                              // block-uniform
             const size_t xr = p.xg_index ? (size_t)p.xg_index[(size_t)qb * max(p.xg_index_ld, 1)] : (size_t)qb;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) xv[g] = p.xg[xr * 4 * H + g * H + pj];
+            xv = p.xg[xr * 4 * H + pg * H + pj];
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) pre[g] = bi[g] + bh[g] + xv[g];
+        pre_g = bi + bh + xv;
     }
 
     // this wave's K-slice of all four tiles: every fragment is loaded before the first MFMA
@@ -539,6 +535,13 @@ __global__ __launch_bounds__(LSTMW_WAVES * 64) void lstm_step_wide_kernel(LstmSt
             fa[i][t] = ok ? av : z;
         }
     }
+    // state operands of the tail threads (waves 0-3), behind the fragment loads in the queue
+    float c0v = 0.f;
+    LstmLive lv{true, 0.f};
+    if (threadIdx.x < 256) {                                     // wave-uniform
+        c0v = p.pw.c0[qb * H + pj];
+        lv = lstm_live_load(p.pw, qb, pj);
+    }
     f32x4 acc[2][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -554,6 +557,7 @@ __global__ __launch_bounds__(LSTMW_WAVES * 64) void lstm_step_wide_kernel(LstmSt
                 for (int q = 0; q < 2; ++q)
                     acc[t][q] = mfma16(comp(fa[i][t], c), comp(fb[i][q], c), acc[t][q]);
 
+    s_pre[pg][pe] = pre_g;
     // 16 partial tile sets -> 8 (through LDS) -> the cell update sums the 8
     if (wave >= LSTMW_WAVES / 2) {
 #pragma unroll
@@ -583,7 +587,7 @@ __global__ __launch_bounds__(LSTMW_WAVES * 64) void lstm_step_wide_kernel(LstmSt
     const int tt = prow >> 4, rr = prow & 15;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        float v = pre[g];
+        float v = s_pre[g][pe];
         const int e = rr * 16 + (g & 1) * 8 + pcol;
 #pragma unroll
         for (int k = 0; k < LSTMW_WAVES / 2; ++k) v += s_red[k][tt * 2 + (g >> 1)][e];
