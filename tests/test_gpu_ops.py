@@ -43,7 +43,10 @@ def rnd(rng, *shape, scale=1.0):
 # ------------------------------------------------------------------------------------ GEMMs
 @pytest.mark.parametrize('M,N,K', [(100, 2048, 4864), (8, 256, 2176), (128, 2048, 4352), (33, 64, 2048),
                                    (100, 2048, 512), (8, 256, 512), (3, 512, 1024), (100, 991, 512),
-                                   (7, 2048, 300), (128, 64, 16), (250, 2048, 300), (1, 16, 4)])
+                                   (7, 2048, 300), (128, 64, 16), (250, 2048, 300), (1, 16, 4),
+                                   # deep reductions: the LDS-tiled weight-gradient kernel (M >= 4096),
+                                   # with a ragged last column tile
+                                   (4500, 512, 256), (4100, 256, 304)])
 @pytest.mark.parametrize('act', [0, 1])
 def test_linear_fwd_bwd(sf, M, N, K, act):
     rng = np.random.default_rng(M * 7 + N + K)
@@ -75,7 +78,9 @@ def test_gemm_is_transpose_safe(sf):
 
 
 # ------------------------------------------------------------------------------------ LSTMCell
-@pytest.mark.parametrize('B,I,H', [(8, 4352, 512), (100, 4352, 512), (5, 300, 512), (3, 48, 16)])
+@pytest.mark.parametrize('B,I,H', [(8, 4352, 512), (100, 4352, 512), (5, 300, 512), (3, 48, 16),
+                                   # B > 16: the 32-row x 8-unit recurrent step, with an input segment
+                                   (100, 300, 512), (33, 300, 512), (17, 48, 16)])
 def test_lstm_cell(sf, B, I, H):
     rng = np.random.default_rng(B + I)
     k = H ** -0.5
