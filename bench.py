@@ -317,7 +317,7 @@ def main():
                roofline=roofline, concurrent=concurrent, loss=float(st.loss_buf), launch=('hipGraph replay, %d concurrent row shards' % args.row_shards if shard_states
                        else 'hipGraph replay') if replay else 'eager')
 
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
         used = np.unique(fb.vp)
         rows = table[torch.from_numpy(used).to(device)].cpu().numpy()
         row_of = {int(v): i for i, v in enumerate(used)}
