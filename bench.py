@@ -109,9 +109,10 @@ def measure_train(enc, dec, store, batch, S, iters, warmup):
     dec.train()
     params_e = [p for p in enc.parameters() if p.requires_grad]
     params_d = [p for p in dec.parameters() if p.requires_grad]
-    opt_e = torch.optim.Adam(params_e, lr=1e-4, weight_decay=5e-4)
-    opt_d = torch.optim.Adam(params_d, lr=1e-4, weight_decay=5e-4)
-    flat = dp.FlatGrads(params_e + params_d)
+    from speaker_follower_amd import optim
+    flat = dp.FlatGrads(params_e + params_d)      # gradients: one buffer (what the all-reduce wants)
+    opt_e = optim.FusedAdam(params_e, lr=1e-4, weight_decay=5e-4)      # one launch per step each
+    opt_d = optim.FusedAdam(params_d, lr=1e-4, weight_decay=5e-4)
     engine = follower.FollowerEngine(enc, dec, store)
     B = batch.batch_size
 
@@ -133,7 +134,7 @@ def measure_train(enc, dec, store, batch, S, iters, warmup):
     enc.eval()
     dec.eval()
     return dict(value=B * S / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
-                what='student-forcing rollout (dropout 0.5) + BPTT + 2x Adam, batch %d, %d decode steps, '
+                what='student-forcing rollout (dropout 0.5) + BPTT + 2x Adam (one HIP launch each), batch %d, %d decode steps, '
                      'eager issue' % (B, S), loss=float(st.loss.detach()))
 
 
@@ -165,10 +166,10 @@ def main():
         dec.train()
         params_e = [p for p in enc.parameters() if p.requires_grad]
         params_d = [p for p in dec.parameters() if p.requires_grad]
-        opt_e = torch.optim.Adam(params_e, lr=1e-4, weight_decay=5e-4)     # train.py:263-268
-        opt_d = torch.optim.Adam(params_d, lr=1e-4, weight_decay=5e-4)
-        from speaker_follower_amd import dp
+        from speaker_follower_amd import dp, optim
         flat = dp.FlatGrads(params_e + params_d)       # kernels accumulate straight into this buffer
+        opt_e = optim.FusedAdam(params_e, lr=1e-4, weight_decay=5e-4)      # train.py:263-268
+        opt_d = optim.FusedAdam(params_d, lr=1e-4, weight_decay=5e-4)
     else:
         enc.eval()
         dec.eval()

@@ -483,6 +483,16 @@ int sf_transpose(const float* src, int R, int Ccols, float* dst, sf_stream strea
 int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float* out,
                      sf_stream stream);
 
+/* ---- a13 the optimizer step (train.py:263-268: optim.Adam(lr=1e-4, weight_decay=5e-4) for the
+ * encoder and for the decoder; follower.py:1014-1020 / speaker.py:389-395 call .step() after
+ * loss.backward()).  torch.optim.Adam semantics (L2 weight decay added to the gradient, bias
+ * correction with the 1-based `step`, no amsgrad) over ONE flat range of n fp32 parameters:
+ * p, m (exp_avg), v (exp_avg_sq) are updated in place, g is read.  Hyper-parameters are doubles (as
+ * in Python): 1 - beta and the bias corrections are formed in double and rounded to float once.  One launch for a whole
+ * optimizer when its parameters, gradients and moments are laid out flat (optim.FusedAdam). */
+int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int step, sf_stream stream);
+
 /* Development aid (no reference counterpart): while `buf` is non-null, the visual-attention body of
  * the pipelined decode step stamps wall_clock64() (100 MHz) per workgroup into buf[block * 8 + k]
  * (k = 0 start, 1 rows loaded and scored, 2 partials stored); buf = device memory of >= 512 * 8

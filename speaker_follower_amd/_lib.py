@@ -173,6 +173,8 @@ _SIGNATURES = {
     'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),
     'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
     'sf_add_f32': (C.c_int, [c_f, c_f, C.c_size_t, c_p]),
+    'sf_adam_step': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
+                              C.c_double, C.c_int, c_p]),
     'sf_dropout_copy': (C.c_int, [c_f, i32, i32, i32, c_f, i32, P(Dropout), u32, i32, c_p]),
     'sf_embedding_fwd': (C.c_int, [c_f, i32, i64p, i32, c_f, c_p]),
     'sf_transpose': (C.c_int, [c_f, i32, i32, c_f, c_p]),

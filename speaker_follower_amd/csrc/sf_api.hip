@@ -1123,6 +1123,15 @@ int sf_add_f32(float* dst, const float* src, size_t n, sf_stream stream) {
     return add2(dst, 0, src, 0, 1, (int)n, dst, 0, S(stream));
 }
 
+int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+                 double beta2, double eps, double weight_decay, int step, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG((p && g && m && v) || n == 0);
+    SF_CHECK_ARG(step >= 1 && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1.);
+    if (n == 0) return SF_OK;
+    return adam_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
+
 int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,
                     const sf_dropout* drop, uint32_t drop_stream, int col0, sf_stream stream) {
     SF_ENTER();

@@ -1,6 +1,9 @@
 // Streaming (HBM-bound) kernels of the path: LSTM gate math, dropout, gathers from the feature
 // table, the follower/speaker per-step glue, and the small vector helpers the backward needs.
 #include "sf_kernels.h"
+
+#include <algorithm>
+#include <cmath>
 #include "sf_glue.h"
 
 namespace sf {
@@ -530,6 +533,41 @@ __global__ void loss_finalize_kernel(const float* sum_cnt, int T, float* loss, f
     }
 }
 
+// torch.optim.Adam.step() (train.py:263-268: lr 1e-4, weight_decay 5e-4 as L2-in-gradient, default
+// betas / eps, no amsgrad) over one flat parameter range, in the operation order of torch's own
+// implementation (lerp for exp_avg, mul + addcmul for exp_avg_sq, sqrt / sqrt(bc2) + eps, addcdiv).
+struct AdamArgs {
+    float* p; const float* g; float* m; float* v; size_t n;
+    float beta2, om_beta1, om_beta2, eps, wd, step_size, inv_sqrt_bc2;   // om = 1 - beta, rounded from double
+};
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
+    if (a.wd != 0.f) g = g + a.wd * p;
+    m = m + a.om_beta1 * (g - m);
+    v = v * a.beta2 + (a.om_beta2 * g) * g;
+    const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
+    p = p - a.step_size * (m / denom);
+}
+__global__ __launch_bounds__(TPB) void adam_kernel(AdamArgs a) {
+    const size_t n4 = a.n >> 2;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (size_t)gridDim.x * TPB) {
+        float4 p = reinterpret_cast<float4*>(a.p)[i];
+        const float4 g = reinterpret_cast<const float4*>(a.g)[i];
+        float4 m = reinterpret_cast<float4*>(a.m)[i];
+        float4 v = reinterpret_cast<float4*>(a.v)[i];
+        adam_one(p.x, g.x, m.x, v.x, a);
+        adam_one(p.y, g.y, m.y, v.y, a);
+        adam_one(p.z, g.z, m.z, v.z, a);
+        adam_one(p.w, g.w, m.w, v.w, a);
+        reinterpret_cast<float4*>(a.p)[i] = p;
+        reinterpret_cast<float4*>(a.m)[i] = m;
+        reinterpret_cast<float4*>(a.v)[i] = v;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (a.n & 3)) {            // tail (n % 4 elements)
+        const size_t i = (n4 << 2) + threadIdx.x;
+        adam_one(a.p[i], a.g[i], a.m[i], a.v[i], a);
+    }
+}
+
 }  // namespace
 
 int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st) {
@@ -591,6 +629,19 @@ int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float*
                    hipStream_t st) {
     hipLaunchKernelGGL(dot_rows_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, s, x, ldx, M, N,
                        out);
+    return launch_status();
+}
+int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
+              double beta2, double eps, double wd, int step, hipStream_t st) {
+    // every derived constant in double, rounded to float once -- what torch does with its Python
+    // floats (1 - 0.999 evaluated in float would be off by 5e-5 relative)
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    AdamArgs a{p, g, m, v, n, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+               (float)wd, (float)(lr / bc1), (float)(1.0 / sqrt(bc2))};
+    const size_t n4 = (n + 3) >> 2;
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<size_t>((n4 + TPB - 1) / TPB, 4096)), dim3(TPB), 0,
+                       st, a);
     return launch_status();
 }
 int sum_accum(const float* s, int M, float* out, hipStream_t st) {
