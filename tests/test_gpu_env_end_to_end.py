@@ -89,3 +89,32 @@ def test_teacher_forced_training_on_real_graphs_reduces_loss(world):
         opt.step()
         losses.append(float(st.loss.detach()))
     assert losses[-1] < 0.7 * losses[0], losses
+
+
+def test_training_with_fused_adam_follows_torch_adam(world):
+    """The same six teacher-forced iterations with optim.FusedAdam and with torch.optim.Adam: equal
+    losses.  (FusedAdam updates the weights behind torch's back; if the caches keyed on
+    `param._version` -- transposed weights, the token table of the encoder -- were not refreshed the
+    second iteration would already run on stale copies and the curves would part.)"""
+    e, enc, dec, store, follower, agents = world
+    import copy
+    from speaker_follower_amd import optim
+    e.reset_epoch()
+    fb, _, _ = e.gold_index_batch(10)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    curves = []
+    for make in (lambda ps: torch.optim.Adam(ps, lr=1e-3, weight_decay=5e-4),
+                 lambda ps: optim.FusedAdam(ps, lr=1e-3, weight_decay=5e-4)):
+        enc2, dec2 = copy.deepcopy(enc), copy.deepcopy(dec)
+        engine = follower.FollowerEngine(enc2, dec2, store)
+        opt = make([p for m in (enc2, dec2) for p in m.parameters() if p.requires_grad])
+        losses = []
+        for _ in range(6):
+            opt.zero_grad(set_to_none=False)
+            st = engine.rollout(batch, fb.vp.shape[0], 'teacher', train=False)
+            st.loss.backward()
+            opt.step()
+            losses.append(float(st.loss.detach()))
+        curves.append(losses)
+    assert curves[1][-1] < 0.7 * curves[1][0], curves
+    np.testing.assert_allclose(curves[1], curves[0], rtol=2e-4)
