@@ -281,7 +281,8 @@ int scoring_fwd_i(const sf_scoring_w* w, const CandSrc& U, int B, int H, int D, 
 int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U, int B, int H,
                   int D, const float* h, const float* t_a, const float* wt, const float* dlogit,
                   float* dh, Arena ar, hipStream_t st, const sf_decoder_gtape* gt = nullptr,
-                  const float* tanh_of = nullptr, bool* tanh_done = nullptr) {
+                  const float* tanh_of = nullptr, bool* tanh_done = nullptr,
+                  const CeSrc* ce = nullptr) {
     // tanh_of (= h, the tanh output that fed the scoring): when given and the shape allows, dh is
     // returned already multiplied by (1 - tanh_of^2) and *tanh_done is set
     const int F = U.IMG + U.LOC;
@@ -290,7 +291,7 @@ int scoring_bwd_i(const sf_scoring_w* w, const sf_scoring_g* g, const CandSrc& U
     float* dwt = gt ? gt->dwt : ar.take((size_t)B * D);
     float* dta = gt ? gt->dta : ar.take((size_t)B * D);
     NEED(dr && dc && dwt && dta);
-    TRY(score_bwd(U, B, dlogit, dr, dc, st));
+    TRY(score_bwd(U, B, dlogit, dr, dc, st, ce));
     // dwt = dr W_a^T + dc (x) b_a,  dta = dwt * w_out: one launch (rank-1 term and column scale in
     // the epilogue of the product) where the short-reduction kernel covers the shape
     bool dta_done = false;
@@ -655,7 +656,7 @@ static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_
                          const sf_decoder_gtape* gt, const float* dlogit, const float* dh1,
                          const float* dc1, float* dh0, float* dc0, float* dctx,
                          const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
-                         sf_stream stream) {
+                         sf_stream stream, const CeSrc* ce = nullptr) {
     SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0 && L > 0);
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -670,7 +671,7 @@ static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_
     bool dpre_ready = false;
     float* dht_out = gt ? gt->dpre : dht;
     TRY(scoring_bwd_i(&w->action, g ? &g->action : nullptr, cands(U), B, H, D, tp->h_tilde, tp->t_a,
-                      tp->wt, dlogit, dht_out, ar, st, gt, gt ? tp->h_tilde : nullptr, &dpre_ready));
+                      tp->wt, dlogit, dht_out, ar, st, gt, gt ? tp->h_tilde : nullptr, &dpre_ready, ce));
     if (gt && !dpre_ready) {      // not fused: dht_out holds d h~; keep it apart from gt->dpre
         TRY(add2(dht_out, H, nullptr, 0, B, H, dht, H, st));
         dht_out = dht;
@@ -818,10 +819,11 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
         const sf_decoder_gtape g = gtape_view(gtape, e, t);
         const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
         const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
-        TRY(softmax_ce_bwd(e->B, e->A, e->A, v.tp.logit, v.glue.target_used, -1, gscale + t, dlogit,
-                           S(stream)));
+        // the cross-entropy backward (softmax - onehot, scaled by 1 / live rows of the step) is formed
+        // inside the scoring backward: one dependent launch less per step
+        const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
         TRY(decoder_bwd_i(w, nullptr, &v.X, &v.U, e->B, e->H, e->D, e->L, h0, c0, e->ctx, &v.tp, &g,
-                          dlogit, dh1, dc1, dho, dco, dctx, drop, e->step0 + t, ws, ws_bytes, stream));
+                          dlogit, dh1, dc1, dho, dco, dctx, drop, e->step0 + t, ws, ws_bytes, stream, &ce));
         dh1 = dho;
         dc1 = dco;
         std::swap(dho, dhn);

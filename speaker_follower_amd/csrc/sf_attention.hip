@@ -480,6 +480,7 @@ struct ScoreArgs {
     float* logit;          // fwd out [B,A]; bwd: dlogit in
     float* dr;             // bwd out [B,F]
     float* dc;             // bwd out [B]
+    CeSrc ce;              // bwd: ce.logit != null -> d(logit) is formed here (and stored to `logit`)
 };
 
 // wt[b] . b_a + b_out (or the precomputed per-row constant): straight-line loads for D <= 256
@@ -579,7 +580,22 @@ __global__ __launch_bounds__(SC_NW * 64) void score_bwd_kernel(ScoreArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int A = a.src.A;
     const int n4 = (a.src.IMG + a.src.LOC) >> 2;
-    const float w = a.logit[(size_t)b * A + min(wave, A - 1)];
+    float w, dlv;
+    if (a.ce.logit) {                                            // block-uniform: fused CE backward
+        const int64_t tgt = a.ce.target[b];
+        const float lg = a.ce.logit[(size_t)b * a.ce.ld + min(lane, A - 1)];
+        const float l = lane < A ? lg : -INFINITY;
+        const float m = wave_max(l);
+        const float e = l > -INFINITY ? expf(l - m) : 0.f;
+        const float ssum = wave_sum(e);
+        const float gs = a.ce.gscale[0];
+        dlv = (tgt == a.ce.ignore || lane >= A) ? 0.f : gs * (e / ssum - (lane == (int)tgt ? 1.f : 0.f));
+        if (wave == 0 && lane < A) a.logit[(size_t)b * A + lane] = dlv;
+        w = __shfl(dlv, min(wave, A - 1), WAVE);
+    } else {
+        w = a.logit[(size_t)b * A + min(wave, A - 1)];
+        dlv = a.logit[(size_t)b * A + min(lane, A - 1)];
+    }
     const CandRow row = cand_row(a.src, b, wave);
     float4 p[SC_CPL];
 #pragma unroll
@@ -592,7 +608,6 @@ __global__ __launch_bounds__(SC_NW * 64) void score_bwd_kernel(ScoreArgs a) {
         }
     }
     if (wave == 0) {
-        const float dlv = a.logit[(size_t)b * A + min(lane, A - 1)];
         const float tot = wave_sum(lane < A ? dlv : 0.f);
         if (lane == 0) a.dc[b] = tot;
     }
@@ -712,7 +727,7 @@ int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
     if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
-    ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, logit, nullptr, nullptr};
+    ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, logit, nullptr, nullptr, CeSrc{}};
     hipLaunchKernelGGL(score_fwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
     return launch_status();
 }
@@ -725,18 +740,20 @@ int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float
     if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
-    ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr};
+    ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr, CeSrc{}};
     hipLaunchKernelGGL(score_glue_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a, g);
     return launch_status();
 }
 
 int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* dc,
-              hipStream_t st) {
+              hipStream_t st, const CeSrc* ce) {
     const int F = src.IMG + src.LOC;
     if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
-    ScoreArgs a{src, F, nullptr, nullptr, nullptr, nullptr, nullptr, 0, const_cast<float*>(dlogit), dr, dc};
+    ScoreArgs a{src, F, nullptr, nullptr, nullptr, nullptr, nullptr, 0, const_cast<float*>(dlogit), dr, dc,
+                ce ? *ce : CeSrc{}};
+    if (ce && ce->ld < src.A) return SF_ERR_ARG;
     hipLaunchKernelGGL(score_bwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
     return launch_status();
 }

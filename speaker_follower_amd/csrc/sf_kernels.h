@@ -22,7 +22,10 @@ int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int l
                   hipStream_t st);
 int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
               const float* b_out, float* logit, hipStream_t st, int ldr = 0, const float* cst = nullptr);
-int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* dc, hipStream_t st);
+// ce (optional): d(logit) = gscale (softmax(ce.logit) - onehot(ce.target)) is formed inside the
+// kernel (and written to dlogit) instead of being read from dlogit
+int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* dc, hipStream_t st,
+              const CeSrc* ce = nullptr);
 
 // ---- sf_gemm.hip (workspace-aware NN) -------------------------------------------------------------
 int gemm_nn_ws(const float* A, int lda, const float* W, int ldw, int M, int N, int K, float* y,

@@ -153,6 +153,16 @@ __device__ __forceinline__ float4 cand_chunk(const CandSrc& s, int b, int a, int
     return cand_load(r, chunk, a >= 0 && a < s.A && !r.zero, (s.IMG + s.LOC) >> 2);
 }
 
+// Where the scoring backward takes d(logit) from when it forms it itself: softmax(logit) - onehot
+// (CrossEntropyLoss(ignore_index) backward, follower.py:278, 481), scaled by gscale[0].
+struct CeSrc {
+    const float* logit;      // [B, ld] masked logits of the step (-inf on padding candidates)
+    const int64_t* target;   // [B]
+    const float* gscale;     // [1] 1 / (live rows of the step)
+    int ignore;              // target value of rows that do not count
+    int ld;
+};
+
 // Sum per-wave partial rows (CPL float4 per lane) over the NW waves of the block.  Waves fold
 // into waves [0, SLOTS) through SLOTS LDS slots, then thread `c` gets chunk c's total via
 // `emit(c, total)`.  Every thread of the block must call this (it synchronises).
