@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 2
+#define SF_ABI_VERSION 3
 
 enum {
     SF_OK = 0,
@@ -319,6 +319,12 @@ typedef struct sf_decoder_gtape {
     float* dta;     /* [B,D]  gradient of t_a */
     float* dr;      /* [B,F]  gradient of the folded scoring vector */
     float* dc;      /* [B]    gradient of the per-row scoring constant */
+    /* optional (NULL = dctx is updated by every step's text-attention backward): with both given,
+     * sf_follower_episode_bwd keeps each step's d[wc ; h1_drop] and d(score) here and adds
+     * dctx += sum_t (alpha_t (x) dwc_t + ds_t (x) t_text_t) ONCE after the loop, instead of a
+     * read-modify-write of the [B,L,H] gradient per step */
+    float* dcat2;   /* [B,2H] gradient of [weighted context ; dropout(h1)] */
+    float* ds;      /* [B,L]  gradient of the text-attention scores */
 } sf_decoder_gtape;
 /* Builds the sf_decoder_fold matrices from the (transposed copies of the) decoder weights:
  * m_v [F,H], c_v [F], m_a [F+4,H], c_a [F+4] are caller-allocated device buffers. */

@@ -59,7 +59,7 @@ class DecoderW(C.Structure):
 
 
 DecoderGTape = _ptr_struct('DecoderGTape', ['dgates', 'dpre', 'dt_text', 'dt_v', 'dq', 'dwt', 'dta', 'dr',
-                                            'dc'])
+                                            'dc', 'dcat2', 'ds'])
 DecoderTape = _ptr_struct('DecoderTape', ['t_v', 'q', 'alpha_v', 'xin', 'gates', 'c1', 'h1', 'cat2',
                                           't_text', 'alpha', 'h_tilde', 't_a', 'wt', 'r', 'logit'])
 
@@ -181,7 +181,7 @@ _SIGNATURES = {
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 
 def _load():

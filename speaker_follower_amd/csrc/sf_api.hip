@@ -222,16 +222,19 @@ int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, in
                   const float* ctx, const float* alpha, const float* cat2, const float* t_text,
                   const float* h_tilde, const float* dh_tilde, float* dh, int lddh, float* dctx,
                   Arena ar, hipStream_t st, float* dpre_out = nullptr, float* dt_out = nullptr,
-                  bool dpre_ready = false) {   // dh_tilde already IS dpre (written to dpre_out)
+                  bool dpre_ready = false,     // dh_tilde already IS dpre (written to dpre_out)
+                  float* dcat2_out = nullptr, float* ds_out = nullptr) {   // both: dctx is deferred
     float* dpre = dpre_out ? dpre_out : ar.take((size_t)B * H);
     float* dt = dt_out ? dt_out : ar.take((size_t)B * H);
-    float* dcat2 = ar.take((size_t)B * 2 * H);
+    float* dcat2 = dcat2_out ? dcat2_out : ar.take((size_t)B * 2 * H);
+    const bool defer = dcat2_out && ds_out;
     NEED(dpre && dcat2 && dt);
     if (dpre_ready) dpre = const_cast<float*>(dh_tilde);
     else TRY(tanh_bwd(h_tilde, H, dh_tilde, H, B, H, dpre, H, st));
     TRY(data_grad(dpre, H, w->w_out, w->w_out_t, B, H, 2 * H, dcat2, 2 * H, 0, ar, st));
     if (g && g->w_out) TRY(gemm_tn(dpre, H, cat2, 2 * H, B, H, 2 * H, g->w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
-    TRY(text_attn_bwd(ctx, B, L, H, dcat2, 2 * H, t_text, H, alpha, dt, H, dctx, st));
+    TRY(text_attn_bwd(ctx, B, L, H, dcat2, 2 * H, t_text, H, alpha, dt, H, defer ? nullptr : dctx, st,
+                      defer ? ds_out : nullptr));
     // dh = dcat2[:, H:] + dt W_in: the addend rides in the epilogue of the product
     bool dh_done = false;
     if (w->w_in_t) {
@@ -678,7 +681,8 @@ static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_
     }
     TRY(softdot_bwd_i(&w->text, g ? &g->text : nullptr, B, L, H, ctx, tp->alpha, tp->cat2,
                       tp->t_text, tp->h_tilde, dht_out, dh1d, H, dctx, ar, st, gt ? gt->dpre : nullptr,
-                      gt ? gt->dt_text : nullptr, dpre_ready));
+                      gt ? gt->dt_text : nullptr, dpre_ready, gt ? gt->dcat2 : nullptr,
+                      gt ? gt->ds : nullptr));
     // (the dropout between h1 and the text attention is undone inside the LSTM pointwise backward)
     TRY(lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->c1,
                    tp->gates, dh1, dh1d, dc1, dxin, 2 * F, dh0, dc0, ar, st,
@@ -775,6 +779,9 @@ sf_decoder_gtape gtape_view(const sf_decoder_gtape* g, const sf_follower_episode
     v.dta = adv(g->dta, t * B * D);
     v.dr = adv(g->dr, t * B * F);
     v.dc = adv(g->dc, t * B);
+    const bool defer = g->dcat2 && g->ds;
+    v.dcat2 = defer ? adv(g->dcat2, t * B * 2 * H) : nullptr;
+    v.ds = defer ? adv(g->ds, t * B * e->L) : nullptr;
     return v;
 }
 }  // namespace
@@ -812,6 +819,10 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
                  e->S > 0 && e->B > 0);
     const sf_dropout* drop = e->drop.p > 0.f ? &e->drop : nullptr;
     const size_t BH = (size_t)e->B * e->H;
+    sf_decoder_gtape gt_all = *gtape;          // the deferred context gradient only where it is covered
+    if (!(gt_all.dcat2 && gt_all.ds && dctx && ctx_grad_supported(e->S, e->L, e->H)))
+        gt_all.dcat2 = gt_all.ds = nullptr;
+    gtape = &gt_all;
     const float *dh1 = nullptr, *dc1 = nullptr;
     float *dho = dh_a, *dco = dc_a, *dhn = dh_b, *dcn = dc_b;
     for (int t = e->S - 1; t >= 0; --t) {
@@ -830,6 +841,9 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
         std::swap(dco, dcn);
     }
     *result_in_b = (dh1 == dh_b) ? 1 : 0;
+    if (gtape->dcat2 && gtape->ds && dctx)     // the deferred context gradient, once for the episode
+        TRY(ctx_grad_accum(e->tape.alpha, gtape->ds, gtape->dcat2, 2 * e->H, e->tape.t_text, e->S, e->B,
+                           e->L, e->H, dctx, S(stream)));
     return SF_OK;
 }
 

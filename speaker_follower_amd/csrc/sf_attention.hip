@@ -330,6 +330,7 @@ struct TxtArgs {
     int ldo;
     float* dctx;           // bwd, accumulated; may be null
     const int32_t* ctx_row;  // fwd: sample b attends over ctx / mask row ctx_row[b] (null = b)
+    float* ds_out;         // bwd, optional [B, L]: the score gradients (for a deferred dctx update)
 };
 
 template <int RPW, int MODE>
@@ -408,6 +409,10 @@ __device__ __forceinline__ void text_attn_body(const TxtArgs& a, int b) {
         const float tot = wave_sum(a0 * d0 + a1 * d1);
         w0 = a0 * (d0 - tot);
         w1 = a1 * (d1 - tot);
+        if (a.ds_out && wave == 0) {                             // block-uniform
+            if (l0 < L) a.ds_out[(size_t)b * L + l0] = w0;
+            if (l1 < L) a.ds_out[(size_t)b * L + l1] = w1;
+        }
     }
 
     float4 p[TXT_CPL];
@@ -664,6 +669,55 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArg
     }
 }
 
+
+// Deferred gradient of the instruction context (model.py:129-139 backward, summed over an episode):
+// dctx[b,l,:] += sum_t ( alpha[t,b,l] dwc[t,b,:] + ds[t,b,l] tt[t,b,:] ).  The per-step form reads and
+// writes the whole [B,L,H] gradient S times (2 x 16 MB per step at the headline shape); this reads each
+// step's two H-vectors once.  One block per sample; thread = one float4 column x every 8th row.
+constexpr int CG_ROWS = 10;        // rows per thread: L <= 8 * CG_ROWS
+
+__global__ __launch_bounds__(1024) void ctx_grad_kernel(const float* alpha, const float* ds,
+                                                        const float* dcat2, int lddc, const float* tt,
+                                                        int S, int B, int L, int H, float* dctx) {
+    extern __shared__ float s_w[];                       // [S][2][L]: alpha, ds of this sample
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < S * L; i += 1024) {
+        const int t = i / L, l = i - t * L;
+        s_w[(t * 2 + 0) * L + l] = alpha[((size_t)t * B + b) * L + l];
+        s_w[(t * 2 + 1) * L + l] = ds[((size_t)t * B + b) * L + l];
+    }
+    __syncthreads();
+    const int n4 = H >> 2;
+    const int c = tid % n4, lg = tid / n4;               // n4 = 128: 8 row groups
+    const int ngroups = 1024 / n4;
+    if (lg >= ngroups) return;
+    float4 acc[CG_ROWS];
+#pragma unroll
+    for (int r = 0; r < CG_ROWS; ++r) acc[r] = f4zero();
+    for (int t = 0; t < S; ++t) {
+        const float4 d = reinterpret_cast<const float4*>(dcat2 + ((size_t)t * B + b) * lddc)[c];
+        const float4 x = reinterpret_cast<const float4*>(tt + ((size_t)t * B + b) * H)[c];
+#pragma unroll
+        for (int r = 0; r < CG_ROWS; ++r) {
+            const int l = lg + ngroups * r;
+            if (l < L) {
+                f4fma(acc[r], s_w[(t * 2 + 0) * L + l], d);
+                f4fma(acc[r], s_w[(t * 2 + 1) * L + l], x);
+            }
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < CG_ROWS; ++r) {
+        const int l = lg + ngroups * r;
+        if (l < L) {
+            float4* o = reinterpret_cast<float4*>(dctx + ((size_t)b * L + l) * H) + c;
+            float4 v = *o;
+            f4add(v, acc[r]);
+            *o = v;
+        }
+    }
+}
+
 }  // namespace
 
 size_t visual_attn_split_floats(int B, int F) { return (size_t)B * VSP_G * (F + 64); }
@@ -707,17 +761,31 @@ int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, co
                   int ldt, float* alpha, float* wc, int ldwc, hipStream_t st,
                   const int32_t* ctx_row) {
     if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (ldwc & 3) || L < 1) return SF_ERR_UNSUPPORTED;
-    TxtArgs a{ctx, mask, L, H, t, ldt, nullptr, 0, alpha, wc, ldwc, nullptr, ctx_row};
+    TxtArgs a{ctx, mask, L, H, t, ldt, nullptr, 0, alpha, wc, ldwc, nullptr, ctx_row, nullptr};
     return text_attn_launch<0>(a, B, st);
 }
 
 int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc,
                   const float* t, int ldt, const float* alpha, float* dt, int lddt, float* dctx,
-                  hipStream_t st) {
+                  hipStream_t st, float* ds_out) {
     if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (lddwc & 3) || (lddt & 3) || L < 1)
         return SF_ERR_UNSUPPORTED;
-    TxtArgs a{ctx, nullptr, L, H, dwc, lddwc, t, ldt, const_cast<float*>(alpha), dt, lddt, dctx, nullptr};
+    TxtArgs a{ctx, nullptr, L, H, dwc, lddwc, t, ldt, const_cast<float*>(alpha), dt, lddt, dctx, nullptr, ds_out};
     return text_attn_launch<1>(a, B, st);
+}
+
+bool ctx_grad_supported(int S, int L, int H) {
+    const int n4 = H >> 2;
+    return !(H & 3) && n4 >= 1 && n4 <= 1024 && 1024 % n4 == 0 && L <= (1024 / n4) * CG_ROWS &&
+           (size_t)S * 2 * L * sizeof(float) <= 64 * 1024;
+}
+
+int ctx_grad_accum(const float* alpha, const float* ds, const float* dcat2, int lddc, const float* tt,
+                   int S, int B, int L, int H, float* dctx, hipStream_t st) {
+    if (!ctx_grad_supported(S, L, H) || (lddc & 3)) return SF_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(ctx_grad_kernel, dim3(B), dim3(1024), (size_t)S * 2 * L * sizeof(float), st, alpha,
+                       ds, dcat2, lddc, tt, S, B, L, H, dctx);
+    return launch_status();
 }
 
 int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
@@ -774,7 +842,7 @@ int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, i
     if (!(a.mt == 4 && a.cpw == 2)) return SF_ERR_UNSUPPORTED;
     if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (ldwc & 3) || L < 1 || L > TXT_NW * 8)
         return SF_ERR_UNSUPPORTED;
-    TxtArgs ta{ctx, mask, L, H, t, ldt, nullptr, 0, alpha, wc, ldwc, nullptr, ctx_row};
+    TxtArgs ta{ctx, mask, L, H, t, ldt, nullptr, 0, alpha, wc, ldwc, nullptr, ctx_row, nullptr};
     const int na = a.gx * a.gy;
     const dim3 grid(na + B), block(TXT_NW * 64);
     if (L <= TXT_NW)

@@ -19,7 +19,11 @@ int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, co
                   const int32_t* ctx_row = nullptr);
 int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc,
                   const float* t, int ldt, const float* alpha, float* dt, int lddt, float* dctx,
-                  hipStream_t st);
+                  hipStream_t st, float* ds_out = nullptr);   // dctx null + ds_out: deferred update
+// dctx[b,l,:] += sum_t (alpha[t,b,l] dcat2[t,b,:H] + ds[t,b,l] tt[t,b,:]) over S stacked steps
+bool ctx_grad_supported(int S, int L, int H);
+int ctx_grad_accum(const float* alpha, const float* ds, const float* dcat2, int lddc, const float* tt,
+                   int S, int B, int L, int H, float* dctx, hipStream_t st);
 int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
               const float* b_out, float* logit, hipStream_t st, int ldr = 0, const float* cst = nullptr);
 // ce (optional): d(logit) = gscale (softmax(ce.logit) - onehot(ce.target)) is formed inside the

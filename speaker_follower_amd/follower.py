@@ -345,7 +345,10 @@ class FollowerEngine:
         dh1 = dc1 = None
         if st.episode is not None:
             ep, _ = st.episode
-            gt0e = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys))
+            # d[wc ; h1_drop] and d(score) of every step: the context gradient is formed once after
+            # the loop instead of a read-modify-write of [B,T,H] per step
+            gt_dcat2, gt_ds = new(S, B, 2 * H), new(S, B, T)
+            gt0e = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), gt_dcat2.data_ptr(), gt_ds.data_ptr())
             which = C.c_int(0)
             call('sf_follower_episode_bwd', byref(dw), byref(ep), byref(gt0e), ptr(gscale), ptr(dlogit),
                  ptr(dh_a), ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(which), *ws)
@@ -354,7 +357,7 @@ class FollowerEngine:
             pano = store.pano(batch.vp[t], batch.view[t])
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
             tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
-            gtp = _lib.DecoderGTape(*(gt[k][t].data_ptr() for k in gkeys))
+            gtp = _lib.DecoderGTape(*(gt[k][t].data_ptr() for k in gkeys), None, None)
             call('sf_follower_glue_bwd', B, A, ptr(st.tape['logit'][t]), ptr(st.target_used[t]),
                  ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
             call('sf_attn_decoder_bwd', byref(dw), None, byref(pano), byref(cnd), B, H, D, T,
@@ -363,7 +366,7 @@ class FollowerEngine:
             dh1, dc1 = dh_a, dc_a
             dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
         tp0 = _lib.DecoderTape(*(st.tape[k].data_ptr() for k in _TAPE_KEYS))
-        gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys))
+        gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), None, None)
         call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
              byref(gt0), *ws)
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
