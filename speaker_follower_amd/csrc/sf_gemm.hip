@@ -1384,6 +1384,27 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
         return launch_status();
     }
     const int waves = ceil_div(Q, 64) * ceil_div(P, 64);
+    {
+        // Wave quantisation: a large output whose 64 x 64 wave tiles are a little more than a whole
+        // number of rounds over the chip's 1024 SIMDs (dW_ih of the decoder LSTM: 2176 tiles = 2.125
+        // per SIMD, so some SIMDs run 3) is cut into the columns that fill whole rounds and a
+        // narrow remainder, which the row split below spreads over the chip on its own.
+        const int pb = ceil_div(P, 64), qb = ceil_div(Q, 256);
+        const int rem = waves % 1024;
+        if (waves > 1024 && rem > 0 && rem <= 384 && rem % (4 * pb) == 0) {
+            const int r = rem / (4 * pb);                       // column blocks of 256 in the remainder
+            const int q_main = (qb - r) * 256, q_tail = Q - q_main;
+            const int tail_waves = ceil_div(q_tail, 64) * pb;
+            const int tail_ms = std::min(16, std::max(1, 1024 / tail_waves));
+            if (r < qb && q_tail > 0 && tail_ms > 1 && ws && ws_floats >= (size_t)tail_ms * P * q_tail &&
+                M / 64 >= tail_ms) {
+                const int rc = gemm_tn(Y, ldy, X, ldx, M, P, q_main, out, ldo, accumulate, st, ws, ws_floats);
+                if (rc != SF_OK) return rc;
+                return gemm_tn(Y, ldy, X + q_main, ldx, M, P, q_tail, out + q_main, ldo, accumulate, st, ws,
+                               ws_floats);
+            }
+        }
+    }
     int ms = std::min(16, std::max(1, 1024 / waves));
     ms = std::min(ms, std::max(1, M / 64));
     if (ms > 1 && (!ws || ws_floats < (size_t)ms * P * Q)) ms = 1;
