@@ -131,7 +131,10 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
                const float* dh1, const float* dh1_b, const float* dc1, float* dx, int lddx,
                float* dh0, float* dc0, Arena ar, hipStream_t st, float* dgates_out = nullptr,
                int dx_col0 = 0,            // dx is only formed for input columns >= dx_col0
-               const Dropout* dh1b_drop = nullptr) {   // mask still to be applied to dh1_b
+               const Dropout* dh1b_drop = nullptr,     // mask still to be applied to dh1_b
+               SmallPlan* dh0_plan = nullptr, bool* dh0_deferred = nullptr) {
+    // dh0_plan: do not launch dh0 = dgates W_hh; hand its launch plan to the caller (who pairs it with
+    // an independent kernel) when the short-reduction kernel covers the shape
     float* dgates = dgates_out ? dgates_out : ar.take((size_t)B * 4 * H);
     NEED(dgates);
     LstmPwBwd p{};
@@ -153,7 +156,15 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
                            ar.rest(), ar.rest_n(), st));
         }
     }
-    if (dh0) TRY(data_grad(dgates, 4 * H, w->w_hh, w->w_hh_t, B, 4 * H, H, dh0, H, 0, ar, st));
+    if (dh0_deferred) *dh0_deferred = false;
+    if (dh0 && dh0_plan && dh0_deferred && w->w_hh_t) {
+        Seg sg{dgates, 4 * H, w->w_hh_t, 4 * H, 4 * H};
+        LinearOut o{};
+        o.y = dh0; o.ldy = H; o.epi = EPI_NONE;
+        *dh0_deferred = linear_small_plan(&sg, 1, B, H, o, dh0_plan);
+    }
+    if (dh0 && !(dh0_deferred && *dh0_deferred))
+        TRY(data_grad(dgates, 4 * H, w->w_hh, w->w_hh_t, B, 4 * H, H, dh0, H, 0, ar, st));
     if (g) {
         if (g->w_ih) TRY(gemm_tn(dgates, 4 * H, x, ldx, B, 4 * H, I, g->w_ih, I, 1, st, ar.rest(), ar.rest_n()));
         if (g->w_hh) TRY(gemm_tn(dgates, 4 * H, h0, H, B, 4 * H, H, g->w_hh, H, 1, st, ar.rest(), ar.rest_n()));
@@ -188,12 +199,21 @@ int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, co
 int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, int B, int H, int D,
                  const float* h, const float* alpha, const float* t_v, const float* dout, int lddo,
                  const Dropout& drop, int col0, float* dh, Arena ar, hipStream_t st,
-                 float* dq_out = nullptr, float* dt_out = nullptr) {
-    const int F = X.IMG + X.LOC;
+                 float* dq_out = nullptr, float* dt_out = nullptr,
+                 const SmallPlan* beside = nullptr) {   // an independent small product to launch with
+    const int F = X.IMG + X.LOC;                        // the attention backward (must run either way)
     float* dq = dq_out ? dq_out : ar.take((size_t)B * F);
     float* dt = dt_out ? dt_out : ar.take((size_t)B * D);
     NEED(dq && dt);
-    TRY(visual_attn(1, X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0, st));
+    bool paired = false;
+    if (beside) {
+        const int rc = pair_visbwd_small(X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0,
+                                         *beside, st);
+        if (rc == SF_OK) paired = true;
+        else if (rc != SF_ERR_UNSUPPORTED) return rc;
+        else TRY(launch_small_plan_x(*beside, st));
+    }
+    if (!paired) TRY(visual_attn(1, X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0, st));
     TRY(linear_plain(dq, F, w->w_v, F, nullptr, B, D, F, EPI_NONE, dt, D, ar, st));
     if (g && g->w_v) TRY(gemm_tn(t_v, D, dq, F, B, D, F, g->w_v, F, 1, st, ar.rest(), ar.rest_n()));
     // g->b_v: the bias shifts all V scores of a row equally; its gradient is identically zero.
@@ -683,14 +703,17 @@ static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_
                       tp->t_text, tp->h_tilde, dht_out, dh1d, H, dctx, ar, st, gt ? gt->dpre : nullptr,
                       gt ? gt->dt_text : nullptr, dpre_ready, gt ? gt->dcat2 : nullptr,
                       gt ? gt->ds : nullptr));
+    SmallPlan dh0_plan;
+    bool dh0_deferred = false;
     // (the dropout between h1 and the text attention is undone inside the LSTM pointwise backward)
     TRY(lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->c1,
                    tp->gates, dh1, dh1d, dc1, dxin, 2 * F, dh0, dc0, ar, st,
-                   gt ? gt->dgates : nullptr, F, &d_h)); // u_prev is detached (follower.py:502): only
-                                                        // the feature half of d(LSTM input) is needed
+                   gt ? gt->dgates : nullptr, F, &d_h,   // u_prev is detached (follower.py:502): only
+                   &dh0_plan, &dh0_deferred));          // the feature half of d(LSTM input) is needed
+    // dh0 = dgates W_hh rides beside the visual-attention backward (both only need the LSTM backward)
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                         dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
-                        gt ? gt->dt_v : nullptr);
+                        gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr);
 }
 
 int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,

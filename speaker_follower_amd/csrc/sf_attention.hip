@@ -29,10 +29,9 @@ struct VisArgs {
 };
 
 template <int MODE>
-__global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
+__device__ __forceinline__ void visual_attn_body(const VisArgs& a, int b) {
     __shared__ float4 slots[VIS_SLOTS][VIS_CPL * 64];
     __shared__ float s_score[64];
-    const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int V = a.src.V;
     const int n4 = (a.src.IMG + a.src.LOC) >> 2;
@@ -119,6 +118,11 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
         }
         reinterpret_cast<float4*>(orow)[c] = t;
     });
+}
+
+template <int MODE>
+__global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
+    visual_attn_body<MODE>(a, blockIdx.x);
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -718,6 +722,22 @@ __global__ __launch_bounds__(1024) void ctx_grad_kernel(const float* alpha, cons
     }
 }
 
+
+// Backward: the visual-attention backward of a step (needs the input gradient of the LSTM) beside the
+// recurrent data gradient dh0 = dgates W_hh (needs only dgates): independent, one launch.
+// Blocks [0, nv): attention backward (12 waves); the rest: the small product (threads >= 512 leave).
+template <int MT, int CPW>
+__global__ __launch_bounds__(VIS_NW * 64) void pair_visbwd_small_kernel(VisArgs v, int nv, SmallArgs b,
+                                                                       int gxb) {
+    const int bid = blockIdx.x;
+    if (bid < nv) {
+        visual_attn_body<1>(v, bid);
+    } else {
+        if (threadIdx.x >= SMALL_WAVES * 64) return;
+        small_gemm_body<MT, CPW>(b, (bid - nv) % gxb, (bid - nv) / gxb);
+    }
+}
+
 }  // namespace
 
 size_t visual_attn_split_floats(int B, int F) { return (size_t)B * VSP_G * (F + 64); }
@@ -851,6 +871,22 @@ int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, i
         hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 5>), grid, block, 0, st, a.args, a.gx, na, ta);
     else
         hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 8>), grid, block, 0, st, a.args, a.gx, na, ta);
+    return launch_status();
+}
+
+// visual-attention backward (mode 1 of visual_attn) paired with a small product (mt 1, cpw 16: the
+// K = 4H recurrent data gradient); SF_ERR_UNSUPPORTED = not pairable, launch separately
+int pair_visbwd_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
+                      int ldo, const Dropout& drop, int drop_col0, const SmallPlan& b, hipStream_t st) {
+    const int F = src.IMG + src.LOC;
+    if (!(b.mt == 1 && b.cpw == 16)) return SF_ERR_UNSUPPORTED;
+    if (src.V > VIS_RPW * VIS_NW || src.V > 64 || F > VIS_CPL * 256 || (F & 3) ||
+        (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) || (ldvec & 3) || (ldo & 3))
+        return SF_ERR_UNSUPPORTED;
+    VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
+    const int nb = b.gx * b.gy;
+    hipLaunchKernelGGL((pair_visbwd_small_kernel<1, 16>), dim3(B + nb), dim3(VIS_NW * 64), 0, st, va, B,
+                       b.args, b.gx);
     return launch_status();
 }
 

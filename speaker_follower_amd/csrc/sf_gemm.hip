@@ -1155,6 +1155,8 @@ static int launch_small_plan(const SmallPlan& p, hipStream_t st) {
     return launch_status();
 }
 
+int launch_small_plan_x(const SmallPlan& p, hipStream_t st) { return launch_small_plan(p, st); }
+
 int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, float* ws,
               size_t ws_floats, hipStream_t st, float** raw_slabs, int* ksplit_out) {
     SF_CHECK_ARG(nseg >= 1 && nseg <= 3 && M > 0 && N > 0);

@@ -168,5 +168,6 @@ struct SmallPlan {
     int gx, gy;           // grid
 };
 bool linear_small_plan(const Seg* segs, int nseg, int M, int N, const LinearOut& out, SmallPlan* plan);
+int launch_small_plan_x(const SmallPlan& p, hipStream_t st);      // launch a plan on its own
 
 }  // namespace sf

@@ -102,6 +102,8 @@ int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st);
 int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, int B, int L, int H,
                     const float* t, int ldt, float* alpha, float* wc, int ldwc,
                     const int32_t* ctx_row, hipStream_t st);
+int pair_visbwd_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
+                      int ldo, const Dropout& drop, int drop_col0, const SmallPlan& b, hipStream_t st);
 int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
                    int ldo, const Dropout& drop, int drop_col0, float* split_part,
                    unsigned* split_counter, const SmallPlan& b, hipStream_t st, int phase = 0);
