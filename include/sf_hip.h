@@ -325,6 +325,8 @@ typedef struct sf_decoder_gtape {
      * read-modify-write of the [B,L,H] gradient per step */
     float* dcat2;   /* [B,2H] gradient of [weighted context ; dropout(h1)] */
     float* ds;      /* [B,L]  gradient of the text-attention scores */
+    /* optional (episode backward with a side stream): the attention path's share of d h1, per step */
+    float* dh1d;    /* [B,H] */
 } sf_decoder_gtape;
 /* Builds the sf_decoder_fold matrices from the (transposed copies of the) decoder weights:
  * m_v [F,H], c_v [F], m_a [F+4,H], c_a [F+4] are caller-allocated device buffers. */
@@ -371,6 +373,11 @@ typedef struct sf_follower_episode {
     sf_follower_glue glue;
     sf_dropout drop;              /* p == 0: no dropout */
     uint32_t step0;               /* dropout / sampling site of step 0 */
+    /* optional, backward only: a second stream.  With it (and gtape.dcat2 / ds / dh1d) the scoring and
+     * text-attention backward of step t-1 run on it while the LSTM / visual backward of step t runs on
+     * `stream` (they only meet at the LSTM pointwise backward); the two are ordered with events and the
+     * call leaves `stream` behind all of the side stream's work. */
+    sf_stream side_stream;
 } sf_follower_episode;
 int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e, void* ws,
                             size_t ws_bytes, sf_stream stream);

@@ -59,7 +59,7 @@ class DecoderW(C.Structure):
 
 
 DecoderGTape = _ptr_struct('DecoderGTape', ['dgates', 'dpre', 'dt_text', 'dt_v', 'dq', 'dwt', 'dta', 'dr',
-                                            'dc', 'dcat2', 'ds'])
+                                            'dc', 'dcat2', 'ds', 'dh1d'])
 DecoderTape = _ptr_struct('DecoderTape', ['t_v', 'q', 'alpha_v', 'xin', 'gates', 'c1', 'h1', 'cat2',
                                           't_text', 'alpha', 'h_tilde', 't_a', 'wt', 'r', 'logit'])
 
@@ -76,7 +76,8 @@ class FollowerEpisode(C.Structure):
     _fields_ = [('S', C.c_int32), ('B', C.c_int32), ('H', C.c_int32), ('D', C.c_int32),
                 ('L', C.c_int32), ('A', C.c_int32), ('X', Pano), ('U', Cands), ('h_init', c_p),
                 ('c_init', c_p), ('ctx', c_p), ('ctx_mask', c_p), ('tape', DecoderTape),
-                ('glue', FollowerGlue), ('drop', Dropout), ('step0', C.c_uint32)]
+                ('glue', FollowerGlue), ('drop', Dropout), ('step0', C.c_uint32),
+                ('side_stream', C.c_void_p)]
 
 
 class EncoderW(C.Structure):

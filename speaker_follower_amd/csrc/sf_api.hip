@@ -673,23 +673,17 @@ int sf_decoder_fold_build(const sf_decoder_w* w, int H, int D, int F, float* m_v
     return linear_plain(wo_bh, D, w->action.b_a, D, w->action.b_out, 1, 1, D, EPI_NONE, c_a + F, 4, ar, st);
 }
 
-static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
-                         const sf_cands* U, int B, int H, int D, int L, const float* h0,
-                         const float* c0, const float* ctx, const sf_decoder_tape* tp,
-                         const sf_decoder_gtape* gt, const float* dlogit, const float* dh1,
-                         const float* dc1, float* dh0, float* dc0, float* dctx,
-                         const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
-                         sf_stream stream, const CeSrc* ce = nullptr) {
-    SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0 && L > 0);
-    Arena ar = arena(ws, ws_bytes);
-    hipStream_t st = S(stream);
-    const PanoSrc xs = pano(X);
-    const int F = xs.IMG + xs.LOC;
-    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+// The backward of one decode step is two chains that only meet at the LSTM pointwise backward:
+//   head: scoring -> h~ -> text attention  =>  dh1d (the attention path's share of d h1), and the dY
+//         operands of that half; needs only the forward tape and d(logit) of ITS step;
+//   tail: LSTM cell -> input gradient -> visual attention  =>  dh0, dc0; needs dh1 / dc1 of step t+1.
+// So head(t-1) can run while tail(t) does (sf_follower_episode_bwd puts the heads on a side stream).
+static int decoder_bwd_head_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_cands* U, int B,
+                              int H, int D, int L, const float* ctx, const sf_decoder_tape* tp,
+                              const sf_decoder_gtape* gt, const float* dlogit, float* dh1d, float* dctx,
+                              Arena ar, hipStream_t st, const CeSrc* ce) {
     float* dht = ar.take((size_t)B * H);       // d h_tilde
-    float* dh1d = ar.take((size_t)B * H);      // d dropout(h1)
-    float* dxin = ar.take((size_t)B * 2 * F);  // d LSTM input
-    NEED(dht && dh1d && dxin);
+    NEED(dht && dh1d);
     // with a gradient tape the scoring backward writes d(pre-tanh) straight into gt->dpre
     bool dpre_ready = false;
     float* dht_out = gt ? gt->dpre : dht;
@@ -699,10 +693,22 @@ static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_
         TRY(add2(dht_out, H, nullptr, 0, B, H, dht, H, st));
         dht_out = dht;
     }
-    TRY(softdot_bwd_i(&w->text, g ? &g->text : nullptr, B, L, H, ctx, tp->alpha, tp->cat2,
-                      tp->t_text, tp->h_tilde, dht_out, dh1d, H, dctx, ar, st, gt ? gt->dpre : nullptr,
-                      gt ? gt->dt_text : nullptr, dpre_ready, gt ? gt->dcat2 : nullptr,
-                      gt ? gt->ds : nullptr));
+    return softdot_bwd_i(&w->text, g ? &g->text : nullptr, B, L, H, ctx, tp->alpha, tp->cat2, tp->t_text,
+                         tp->h_tilde, dht_out, dh1d, H, dctx, ar, st, gt ? gt->dpre : nullptr,
+                         gt ? gt->dt_text : nullptr, dpre_ready, gt ? gt->dcat2 : nullptr,
+                         gt ? gt->ds : nullptr);
+}
+
+static int decoder_bwd_tail_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X, int B,
+                              int H, int D, const float* h0, const float* c0,
+                              const sf_decoder_tape* tp, const sf_decoder_gtape* gt, const float* dh1,
+                              const float* dh1d, const float* dc1, float* dh0, float* dc0,
+                              const sf_dropout* drop, uint32_t step_id, Arena ar, hipStream_t st) {
+    const PanoSrc xs = pano(X);
+    const int F = xs.IMG + xs.LOC;
+    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+    float* dxin = ar.take((size_t)B * 2 * F);  // d LSTM input
+    NEED(dxin);
     SmallPlan dh0_plan;
     bool dh0_deferred = false;
     // (the dropout between h1 and the text attention is undone inside the LSTM pointwise backward)
@@ -714,6 +720,22 @@ static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                         dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
                         gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr);
+}
+
+static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
+                         const sf_cands* U, int B, int H, int D, int L, const float* h0,
+                         const float* c0, const float* ctx, const sf_decoder_tape* tp,
+                         const sf_decoder_gtape* gt, const float* dlogit, const float* dh1,
+                         const float* dc1, float* dh0, float* dc0, float* dctx,
+                         const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
+                         sf_stream stream, const CeSrc* ce = nullptr) {
+    SF_CHECK_ARG(w && X && U && h0 && c0 && ctx && tp && dlogit && dh0 && dc0 && B > 0 && L > 0);
+    Arena ar = arena(ws, ws_bytes);
+    float* dh1d = ar.take((size_t)B * H);      // d dropout(h1)
+    NEED(dh1d);
+    TRY(decoder_bwd_head_i(w, g, U, B, H, D, L, ctx, tp, gt, dlogit, dh1d, dctx, ar, S(stream), ce));
+    return decoder_bwd_tail_i(w, g, X, B, H, D, h0, c0, tp, gt, dh1, dh1d, dc1, dh0, dc0, drop, step_id,
+                              ar, S(stream));
 }
 
 int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
@@ -734,6 +756,17 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
 // Python + ctypes cost per step was exposed as idle gaps between the short kernels of the backward).
 extern "C++" {
 namespace {
+// events of the two-stream episode backward (created once per host thread, timing disabled)
+std::vector<hipEvent_t>& event_pool(size_t n) {
+    static thread_local std::vector<hipEvent_t> pool;
+    while (pool.size() < n) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
+        pool.push_back(e);
+    }
+    return pool;
+}
+
 struct StepView {
     sf_pano X;
     sf_cands U;
@@ -805,6 +838,7 @@ sf_decoder_gtape gtape_view(const sf_decoder_gtape* g, const sf_follower_episode
     const bool defer = g->dcat2 && g->ds;
     v.dcat2 = defer ? adv(g->dcat2, t * B * 2 * H) : nullptr;
     v.ds = defer ? adv(g->ds, t * B * e->L) : nullptr;
+    v.dh1d = adv(g->dh1d, t * B * H);
     return v;
 }
 }  // namespace
@@ -848,20 +882,57 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
     gtape = &gt_all;
     const float *dh1 = nullptr, *dc1 = nullptr;
     float *dho = dh_a, *dco = dc_a, *dhn = dh_b, *dcn = dc_b;
-    for (int t = e->S - 1; t >= 0; --t) {
-        StepView v = step_view(e, t);
-        const sf_decoder_gtape g = gtape_view(gtape, e, t);
-        const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
-        const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
-        // the cross-entropy backward (softmax - onehot, scaled by 1 / live rows of the step) is formed
-        // inside the scoring backward: one dependent launch less per step
-        const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
-        TRY(decoder_bwd_i(w, nullptr, &v.X, &v.U, e->B, e->H, e->D, e->L, h0, c0, e->ctx, &v.tp, &g,
-                          dlogit, dh1, dc1, dho, dco, dctx, drop, e->step0 + t, ws, ws_bytes, stream, &ce));
-        dh1 = dho;
-        dc1 = dco;
-        std::swap(dho, dhn);
-        std::swap(dco, dcn);
+    // Software-pipelined over two streams when the caller gives a side stream and per-step dh1d
+    // storage: the heads (scoring / text-attention backward, ~45 us of small dependent launches per
+    // step) run ahead on the side stream, the tails (LSTM / visual backward, ~65 us) follow on the main
+    // stream, each behind the event of its own head.  The heads write only per-step tape slots and
+    // their own arena region, so nothing is shared but the events.
+    hipStream_t main_st = S(stream), side_st = S(e->side_stream);
+    const bool two = side_st && side_st != main_st && gtape->dh1d && gtape->dcat2 && gtape->ds;
+    if (two) {
+        SF_CHECK_ARG(e->ctx && dctx);
+        std::vector<hipEvent_t>& ev = event_pool(e->S + 1);
+        const size_t nfl = ws ? ws_bytes / 4 : 0;
+        const size_t usable = nfl > SYNC_WORDS ? nfl - SYNC_WORDS : 0;
+        const size_t head_n = std::min<size_t>(usable / 4, (size_t)4 << 20);
+        Arena tail_ar{(float*)ws, usable - head_n, 0};
+        Arena head_ar{(float*)ws + (usable - head_n), head_n, 0};
+        if (hipEventRecord(ev[e->S], main_st) != hipSuccess || hipStreamWaitEvent(side_st, ev[e->S], 0) != hipSuccess)
+            return SF_ERR_LAUNCH;
+        for (int t = e->S - 1; t >= 0; --t) {
+            StepView v = step_view(e, t);
+            const sf_decoder_gtape g = gtape_view(gtape, e, t);
+            const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
+            const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
+            const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
+            TRY(decoder_bwd_head_i(w, nullptr, &v.U, e->B, e->H, e->D, e->L, e->ctx, &v.tp, &g, dlogit,
+                                   g.dh1d, dctx, head_ar, side_st, &ce));
+            if (hipEventRecord(ev[t], side_st) != hipSuccess || hipStreamWaitEvent(main_st, ev[t], 0) != hipSuccess)
+                return SF_ERR_LAUNCH;
+            TRY(decoder_bwd_tail_i(w, nullptr, &v.X, e->B, e->H, e->D, h0, c0, &v.tp, &g, dh1, g.dh1d, dc1,
+                                   dho, dco, drop, e->step0 + t, tail_ar, main_st));
+            dh1 = dho;
+            dc1 = dco;
+            std::swap(dho, dhn);
+            std::swap(dco, dcn);
+        }
+    } else {
+        for (int t = e->S - 1; t >= 0; --t) {
+            StepView v = step_view(e, t);
+            const sf_decoder_gtape g = gtape_view(gtape, e, t);
+            const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
+            const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
+            // the cross-entropy backward (softmax - onehot, scaled by 1 / live rows of the step) is
+            // formed inside the scoring backward: one dependent launch less per step
+            const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
+            TRY(decoder_bwd_i(w, nullptr, &v.X, &v.U, e->B, e->H, e->D, e->L, h0, c0, e->ctx, &v.tp, &g,
+                              dlogit, dh1, dc1, dho, dco, dctx, drop, e->step0 + t, ws, ws_bytes, stream,
+                              &ce));
+            dh1 = dho;
+            dc1 = dco;
+            std::swap(dho, dhn);
+            std::swap(dco, dcn);
+        }
     }
     *result_in_b = (dh1 == dh_b) ? 1 : 0;
     if (gtape->dcat2 && gtape->ds && dctx)     // the deferred context gradient, once for the episode

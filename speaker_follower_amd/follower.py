@@ -124,6 +124,8 @@ class FollowerEngine:
         self.group = group              # torch.distributed process group for data parallelism
         self.iteration = 0
         self.dropout_seed = None
+        self.two_stream_backward = True  # heads of the backward on a side stream (see sf_follower_episode_bwd)
+        self._side_stream = None
         self.fold_inference = False     # model.decoder_fold: correct, but measured no faster (590K vs 596K)
         self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
         self.episode_call = True        # the whole decode loop (and its backward) as ONE C call
@@ -347,8 +349,17 @@ class FollowerEngine:
             ep, _ = st.episode
             # d[wc ; h1_drop] and d(score) of every step: the context gradient is formed once after
             # the loop instead of a read-modify-write of [B,T,H] per step
-            gt_dcat2, gt_ds = new(S, B, 2 * H), new(S, B, T)
-            gt0e = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), gt_dcat2.data_ptr(), gt_ds.data_ptr())
+            gt_dcat2, gt_ds, gt_dh1d = new(S, B, 2 * H), new(S, B, T), new(S, B, H)
+            gt0e = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), gt_dcat2.data_ptr(), gt_ds.data_ptr(),
+                                     gt_dh1d.data_ptr())
+            # second stream: the scoring / text-attention backward of step t-1 runs beside the LSTM /
+            # visual backward of step t (not under stream capture: eager issue only)
+            if self.two_stream_backward and not torch.cuda.is_current_stream_capturing():
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=dev)
+                ep.side_stream = self._side_stream.cuda_stream
+            else:
+                ep.side_stream = None
             which = C.c_int(0)
             call('sf_follower_episode_bwd', byref(dw), byref(ep), byref(gt0e), ptr(gscale), ptr(dlogit),
                  ptr(dh_a), ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(which), *ws)
@@ -357,7 +368,7 @@ class FollowerEngine:
             pano = store.pano(batch.vp[t], batch.view[t])
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
             tp = _lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
-            gtp = _lib.DecoderGTape(*(gt[k][t].data_ptr() for k in gkeys), None, None)
+            gtp = _lib.DecoderGTape(*(gt[k][t].data_ptr() for k in gkeys), None, None, None)
             call('sf_follower_glue_bwd', B, A, ptr(st.tape['logit'][t]), ptr(st.target_used[t]),
                  ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
             call('sf_attn_decoder_bwd', byref(dw), None, byref(pano), byref(cnd), B, H, D, T,
@@ -366,7 +377,7 @@ class FollowerEngine:
             dh1, dc1 = dh_a, dc_a
             dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
         tp0 = _lib.DecoderTape(*(st.tape[k].data_ptr() for k in _TAPE_KEYS))
-        gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), None, None)
+        gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), None, None, None)
         call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
              byref(gt0), *ws)
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
