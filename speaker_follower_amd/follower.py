@@ -285,9 +285,10 @@ class FollowerEngine:
         shard, replayed on its own stream.  Samples never interact in the forward pass, and at batch
         100 every stage of the chain is latency-bound with most of the 256 CUs idle, so two
         half-batch chains overlap; the per-step (CE sum, live count) tables are added before the loss
-        is finalised, exactly like the data-parallel path does across GPUs.  (Fork/join branches
-        inside a single hipGraph were measured to execute serially on ROCm 7.2, hence one graph per
-        stream.)  Returns (replay, states, loss_buf)."""
+        is finalised, exactly like the data-parallel path does across GPUs.  (One graph per stream:
+        branches of a single hipGraph do run concurrently on ROCm 7.2 -- tools/graph_branch_test.py --
+        but every fork / join between them costs several microseconds.)  Returns (replay, states,
+        loss_buf)."""
         dev = self.store.device
         streams = [torch.cuda.Stream() for _ in shards]
         graphs, states = [], []
