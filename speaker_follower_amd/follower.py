@@ -379,10 +379,25 @@ class FollowerEngine:
             dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
         tp0 = _lib.DecoderTape(*(st.tape[k].data_ptr() for k in _TAPE_KEYS))
         gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), None, None, None)
-        call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
-             byref(gt0), *ws)
+        # the decoder's weight gradients (a few large products over the S*B stacked rows: matrix-core
+        # work) and the encoder's backward through time (80 dependent, latency-bound steps) are
+        # independent: issued on two streams they overlap
+        overlap = self.two_stream_backward and not torch.cuda.is_current_stream_capturing()
+        if overlap:
+            if self._side_stream is None:
+                self._side_stream = torch.cuda.Stream(device=dev)
+            side = self._side_stream
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
+                     byref(gt0), *ws_args(dev))
+        else:
+            call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
+                 byref(gt0), *ws)
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
         ew, eg = _encoder_structs(enc), _encoder_structs(enc, grad=True)
         call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
              ptr(st.h_init), ptr(dctx), ptr(dh1), ptr(dc1), byref(etp), dropout_arg(*st.drop_enc),
              st.site0, *ws)
+        if overlap:
+            torch.cuda.current_stream().wait_stream(side)
