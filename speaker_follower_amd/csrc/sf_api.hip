@@ -899,16 +899,26 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
         Arena head_ar{(float*)ws + (usable - head_n), head_n, 0};
         if (hipEventRecord(ev[e->S], main_st) != hipSuccess || hipStreamWaitEvent(side_st, ev[e->S], 0) != hipSuccess)
             return SF_ERR_LAUNCH;
+        // ALL heads are issued first (they depend on nothing the tails produce), each followed by
+        // its event; then the tails, each behind the event of its head.  (Measured on MI355X: work of
+        // two queues overlaps only where a kernel leaves CUs unoccupied -- tools/overlap_test.py: an
+        // 0.73 ms chain of recurrent steps beside 0.87 ms of gate products takes 1.35 ms, beside
+        // chip-filling library GEMMs the plain sum, stream priority changes nothing -- so the gain of
+        // the second stream is the small kernels of the heads filling the gaps of the tails.)
+        for (int t = e->S - 1; t >= 0; --t) {
+            StepView v = step_view(e, t);
+            const sf_decoder_gtape g = gtape_view(gtape, e, t);
+            const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
+            TRY(decoder_bwd_head_i(w, nullptr, &v.U, e->B, e->H, e->D, e->L, e->ctx, &v.tp, &g, dlogit,
+                                   g.dh1d, dctx, head_ar, side_st, &ce));
+            if (hipEventRecord(ev[t], side_st) != hipSuccess) return SF_ERR_LAUNCH;
+        }
         for (int t = e->S - 1; t >= 0; --t) {
             StepView v = step_view(e, t);
             const sf_decoder_gtape g = gtape_view(gtape, e, t);
             const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
             const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
-            const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
-            TRY(decoder_bwd_head_i(w, nullptr, &v.U, e->B, e->H, e->D, e->L, e->ctx, &v.tp, &g, dlogit,
-                                   g.dh1d, dctx, head_ar, side_st, &ce));
-            if (hipEventRecord(ev[t], side_st) != hipSuccess || hipStreamWaitEvent(main_st, ev[t], 0) != hipSuccess)
-                return SF_ERR_LAUNCH;
+            if (hipStreamWaitEvent(main_st, ev[t], 0) != hipSuccess) return SF_ERR_LAUNCH;
             TRY(decoder_bwd_tail_i(w, nullptr, &v.X, e->B, e->H, e->D, h0, c0, &v.tp, &g, dh1, g.dh1d, dc1,
                                    dho, dco, drop, e->step0 + t, tail_ar, main_st));
             dh1 = dho;
