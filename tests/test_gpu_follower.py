@@ -146,9 +146,11 @@ def _check_grads(named, g, prefix, rtol=3e-3):
     assert seen > 0
 
 
+@pytest.mark.parametrize('two_stream', [True, False])
 @pytest.mark.parametrize('case', ['b8', 'b100'])
-def test_engine_teacher_gradients_golden(follower_modules, batch8, golden, case):
-    """Full BPTT through the C-ABI backward vs the reference's autograd gradients."""
+def test_engine_teacher_gradients_golden(follower_modules, batch8, golden, case, two_stream):
+    """Full BPTT through the C-ABI backward vs the reference's autograd gradients, with the backward
+    through time on two streams (the default) and on one."""
     enc, dec, _, _ = follower_modules
     if case == 'b8':
         fb, table = batch8
@@ -159,6 +161,7 @@ def test_engine_teacher_gradients_golden(follower_modules, batch8, golden, case)
         steps = 20
     g = golden('g4_rollout_%s_teacher' % case)
     engine, follower = _engine(follower_modules, table)
+    engine.two_stream_backward = two_stream
     batch = follower.DeviceFollowerBatch.from_synth(fb)
     for m in (enc, dec):
         m.zero_grad(set_to_none=True)
