@@ -134,7 +134,6 @@ __global__ __launch_bounds__(VIS_NW * 64) void visual_attn_kernel(VisArgs a) {
 // monotonic per-sample counter; partials are published write-through and read back with sc1
 // loads, so no cache-wide fence is needed) merges: no spinning, no extra launch.
 // -------------------------------------------------------------------------------------------------
-constexpr int VSP_MAXG = 4;
 #ifndef SF_VIS_GROUPS
 #define SF_VIS_GROUPS 2
 #endif

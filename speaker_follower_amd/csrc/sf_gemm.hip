@@ -783,7 +783,6 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(TnArgs a) {
     const int qc = q0 + 4 * li;
     const bool pok = pc < a.ldy;                // stay inside the row (caller pads P to %4 via ldy)
     const bool qok = qc < a.Q;
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 
     f32x4 acc[4][4];
 #pragma unroll
