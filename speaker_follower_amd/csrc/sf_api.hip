@@ -901,7 +901,7 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
             return SF_ERR_LAUNCH;
         // ALL heads are issued first (they depend on nothing the tails produce), each followed by
         // its event; then the tails, each behind the event of its head.  (Measured on MI355X: work of
-        // two queues overlaps only where a kernel leaves CUs unoccupied -- tools/overlap_test.py: an
+        // two queues overlaps only where a kernel leaves CUs unoccupied -- tools/overlap_probe.py: an
         // 0.73 ms chain of recurrent steps beside 0.87 ms of gate products takes 1.35 ms, beside
         // chip-filling library GEMMs the plain sum, stream priority changes nothing -- so the gain of
         // the second stream is the small kernels of the heads filling the gaps of the tails.)

@@ -286,7 +286,7 @@ class FollowerEngine:
         100 every stage of the chain is latency-bound with most of the 256 CUs idle, so two
         half-batch chains overlap; the per-step (CE sum, live count) tables are added before the loss
         is finalised, exactly like the data-parallel path does across GPUs.  (One graph per stream:
-        branches of a single hipGraph do run concurrently on ROCm 7.2 -- tools/graph_branch_test.py --
+        branches of a single hipGraph do run concurrently on ROCm 7.2 -- tools/graph_branch_probe.py --
         but every fork / join between them costs several microseconds.)  Returns (replay, states,
         loss_buf)."""
         dev = self.store.device

@@ -48,9 +48,6 @@ SpeakerInferenceState = namedtuple(
     'SpeakerInferenceState',
     'prev_inference_state, flat_index, last_word, word_count, score, last_alpha')   # speaker.py:18
 
-Cons = namedtuple('Cons', 'first, rest')
-
-
 def _add_f32(score, step_score):
     """The reference accumulates hypothesis scores as `score + action_score` with action_score a
     float32 tensor element (follower.py:629, 826; speaker.py:277): every partial sum is rounded to
@@ -66,54 +63,41 @@ def path_element_from_observation(ob):
     return (ob['viewpoint'], ob['heading'], ob['elevation'])
 
 
-def cons_to_list(cons):
-    out = []
-    while cons is not None:
-        out.append(cons.first)
-        cons = cons.rest
-    return out
+def _lineage(inf_state):
+    """The state and its ancestors, newest first (back-pointer chain of InferenceState)."""
+    chain = []
+    while inf_state is not None:
+        chain.append(inf_state)
+        inf_state = inf_state.prev_inference_state
+    return chain
 
 
 def backchain_inference_states(last_inference_state):
-    """follower.py:33-50: walk the back-pointers; returns (states, observations, actions, scores,
-    attention rows) from the start, the start pseudo-action excluded."""
-    states, observations, actions, scores, attentions = [], [], [], [], []
-    inf_state, last_score = last_inference_state, None
-    while inf_state is not None:
-        states.append(inf_state.world_state)
-        observations.append(inf_state.observation)
-        actions.append(inf_state.last_action)
-        attentions.append(inf_state.last_alpha)
-        if last_score is not None:
-            scores.append(last_score - inf_state.score)
-        last_score = inf_state.score
-        inf_state = inf_state.prev_inference_state
-    scores.append(last_score)
-    return (states[::-1], observations[::-1], actions[::-1][1:], scores[::-1][1:],
-            attentions[::-1][1:])
+    """What follower.py:33-50 returns for a hypothesis: (world states, observations, actions,
+    per-action scores, attention rows), oldest first; the start pseudo-action (and its attention
+    row) is left out, and the score of action i is the difference of the cumulative scores on
+    either side of it."""
+    chain = _lineage(last_inference_state)[::-1]
+    taken = chain[1:]
+    return ([s.world_state for s in chain], [s.observation for s in chain],
+            [s.last_action for s in taken],
+            [s.score - p.score for p, s in zip(chain, taken)],
+            [s.last_alpha for s in taken])
 
 
 def least_common_viewpoint_path(inf_state_a, inf_state_b):
-    """follower.py:52-73: A -> X, Y -> B where X, Y are the closest ancestors of A and B that share
-    a viewpoint (the physical walk between two frontier states)."""
-    path_to_b_by_viewpoint = {}
-    b = inf_state_b
-    b_stack = Cons(b, None)
-    while b is not None:
-        path_to_b_by_viewpoint[b.world_state.viewpointId] = b_stack
-        b = b.prev_inference_state
-        b_stack = Cons(b, b_stack)
-    a = inf_state_a
-    path_from_a = [a]
-    while a is not None:
-        vp = a.world_state.viewpointId
-        if vp in path_to_b_by_viewpoint:
-            path_to_b = cons_to_list(path_to_b_by_viewpoint[vp])
-            assert path_from_a[-1].world_state.viewpointId == path_to_b[0].world_state.viewpointId
-            return path_from_a + path_to_b[1:]
-        a = a.prev_inference_state
-        path_from_a.append(a)
-    raise AssertionError('no common ancestor found')
+    """The physical walk between two frontier states (follower.py:52-73): up from A to its nearest
+    ancestor standing on a viewpoint that B's lineage also visits, then down B's lineage from the
+    OLDEST state on that viewpoint to B.  The meeting viewpoint appears once."""
+    down = _lineage(inf_state_b)                       # B, parent(B), ..., root
+    oldest_at = {s.world_state.viewpointId: i for i, s in enumerate(down)}   # later (older) index wins
+    up = []
+    for s in _lineage(inf_state_a):
+        up.append(s)
+        i = oldest_at.get(s.world_state.viewpointId)
+        if i is not None:
+            return up + down[:i][::-1]
+    raise AssertionError('the two states share no viewpoint on their lineages')
 
 
 class _Pool:
