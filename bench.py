@@ -8,26 +8,35 @@ from the HBM-resident 36x2048 feature table.  With --workload train the step als
 BPTT, the (data-parallel) gradient all-reduce and two Adam updates (train.py:263-268).
 
     python bench.py --gpus 1 --steps 20 --warmup 5
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --gpus 8 ...          # spawns 8 ranks itself (one process per GPU, RCCL)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...   # or be launched
 
 Prints ONE JSON line on rank 0.  value = B * decode_steps * world * K / max-over-ranks time.
+
+Process model: when WORLD_SIZE is not in the environment and --gpus N > 1, this process is only a
+launcher -- it starts N children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, rendezvous on
+127.0.0.1) BEFORE anything touches the GPU, waits for them and exits with their status.  It never
+re-execs itself.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FLOPS_LSTM = lambda B, I, H: 2.0 * B * (I + H) * 4 * H      # noqa: E731  gate GEMM of one LSTMCell step
+# SURVEY.md section 8(d): algorithmic work of ONE agent-step (forward, fp32, A = 8, L = 80, B = 100)
+AGENT_STEP_FLOPS = 71386112.0
+AGENT_STEP_BYTES = 1049469.0
+PEAK_TFLOPS_F32_MFMA = 157.3        # MI355X_MICROARCH.md: dense fp32 MFMA at 2.4 GHz
+PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s measured achievable)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -37,6 +46,8 @@ def parse():
     ap.add_argument('--decode-steps', type=int, default=20)
     ap.add_argument('--n-viewpoints', type=int, default=10567)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip every measurement that is not `value`, `roofline` or `cpu_baseline`')
     ap.add_argument('--no-train-extra', action='store_true', help='skip the extra training-iteration measurement')
     ap.add_argument('--no-graph', action='store_true', help='issue the rollout eagerly instead of replaying a hipGraph')
     ap.add_argument('--row-shards', type=int, default=1,
@@ -45,10 +56,63 @@ def parse():
     ap.add_argument('--in-flight', type=int, default=2,
                     help='extra measurement: this many independent batch-100 rollouts in flight on separate streams')
     ap.add_argument('--cpu-reps', type=int, default=2)
-    return ap.parse_args()
+    # test-only switches: exercise the N > 1 code path (launcher, rendezvous, collectives, JSON) on a
+    # box with ONE GPU.  Ranks share cuda:0 and reduce through gloo; the line is marked oversubscribed.
+    ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
+    ap.add_argument('--share-gpu', action='store_true', help='(test) every rank uses cuda:0')
+    return ap.parse_args(argv)
 
 
+# ------------------------------------------------------------------------------------------ launcher
+def free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_plan(n, argv, env=None, port=None):
+    """The N child processes of `bench.py --gpus N`: [(command, environment)], one per GPU."""
+    env = dict(os.environ if env is None else env)
+    port = port or free_port()
+    plan = []
+    for r in range(n):
+        e = dict(env)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        e.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC (RCCL needs it on this stack)
+        plan.append(([sys.executable, os.path.join(ROOT, 'bench.py')] + list(argv), e))
+    return plan
+
+
+def run_launcher(args, argv):
+    """Parent of an N-GPU run.  Touches no GPU; children inherit stdout/stderr (only rank 0 prints)."""
+    procs = [subprocess.Popen(cmd, env=env) for cmd, env in launch_plan(args.gpus, argv)]
+    rc = 0
+    try:
+        pending = set(range(len(procs)))
+        while pending:
+            for i in sorted(pending):
+                code = procs[i].poll()
+                if code is None:
+                    continue
+                pending.discard(i)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for j in pending:                 # one rank failed: stop the others (exact PIDs)
+                        procs[j].terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+# ------------------------------------------------------------------------------------------- workload
 def build_models(seed, device):
+    import torch
     from speaker_follower_amd import synth, model
     d = synth.FULL
     enc_w, dec_w = synth.follower_weights(seed)
@@ -62,6 +126,7 @@ def build_models(seed, device):
 def device_table(n_vp, seed, device):
     """ResNet-pool5-like table generated on the device (0.5*N(0,1) clipped at 0), 3.1 GB at
     the full 10 567 viewpoints."""
+    import torch
     g = torch.Generator(device=device)
     g.manual_seed(seed)
     t = torch.empty(n_vp, 36, 2048, device=device, dtype=torch.float32)
@@ -73,19 +138,20 @@ def device_table(n_vp, seed, device):
     return t
 
 
-def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps):
-    """The numpy oracle (a port of the reference modules, oracle/np_model.py) on ONE host thread,
-    on the same batch the GPU ran: full rollout, `reps` repetitions."""
+def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps, threads):
+    """The numpy oracle (a port of the reference modules, oracle/np_model.py) on `threads` host
+    threads (None = every core the BLAS pool takes), on the same batch the GPU ran."""
+    import copy
+    import numpy as np
     from threadpoolctl import threadpool_limits
     from oracle import np_env, np_model
-    import copy
     fbc = copy.copy(fb)
     fbc.vp = np.vectorize(row_of.get)(fb.vp).astype(np.int32)
     loc = np_env.static_loc_embeddings()
     seq, mask, lens = np_env.batch_instructions_from_encoded(fb.instr, 80, reverse=True)
     B = len(lens)
-    best = None
-    with threadpool_limits(limits=1):
+    best, res = None, None
+    with threadpool_limits(limits=threads):
         for _ in range(reps):
             t0 = time.perf_counter()
             res = np_model.follower_rollout(
@@ -96,63 +162,152 @@ def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps):
             n = len(res['logits'])
             rate = B * n / dt
             best = rate if best is None else max(best, rate)
-    return dict(value=best, unit='agent-steps/s', cores=1, kind='port',
+    cores = threads if threads else os.cpu_count()
+    return dict(value=best, unit='agent-steps/s', cores=cores, kind='port',
                 sample='%d full rollouts of the same batch (B=%d, %d decode steps, encoder included), '
-                       'numpy oracle, 1 thread, best of %d' % (reps, B, n, reps)), res
+                       'numpy oracle, %d thread%s, best of %d'
+                       % (reps, B, n, cores, '' if cores == 1 else 's (BLAS pool)', reps)), res
 
 
-def measure_train(enc, dec, store, batch, S, iters, warmup):
+def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1):
     """follower.py:1001-1020 + train.py:263-268 per iteration: zero_grad, student-forcing rollout with
-    loss, backward, Adam(lr 1e-4, weight_decay 5e-4) on encoder and decoder."""
-    from speaker_follower_amd import follower, dp
+    loss, backward, [gradient all-reduce,] Adam(lr 1e-4, weight_decay 5e-4) on encoder and decoder."""
+    import torch
+    from speaker_follower_amd import follower, dp, optim
     enc.train()
     dec.train()
     params_e = [p for p in enc.parameters() if p.requires_grad]
     params_d = [p for p in dec.parameters() if p.requires_grad]
-    from speaker_follower_amd import optim
     flat = dp.FlatGrads(params_e + params_d)      # gradients: one buffer (what the all-reduce wants)
     opt_e = optim.FusedAdam(params_e, lr=1e-4, weight_decay=5e-4)      # one launch per step each
     opt_d = optim.FusedAdam(params_d, lr=1e-4, weight_decay=5e-4)
-    engine = follower.FollowerEngine(enc, dec, store)
+    engine = follower.FollowerEngine(enc, dec, store, group=group)
     B = batch.batch_size
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
 
-    def it():
+    def it(k=None):
         flat.zero()
         st = engine.rollout(batch, S, 'argmax', train=True)
         st.loss.backward()
+        if k is not None:
+            ev[k][0].record()
+        flat.allreduce(group)
+        if k is not None:
+            ev[k][1].record()
         opt_e.step()
         opt_d.step()
         return st
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
     for _ in range(warmup):
         it()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
-    for _ in range(iters):
-        st = it()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / iters
+    for k in range(iters):
+        st = it(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=store.device, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt)
+    dt /= iters
+    ar_ms = sum(a.elapsed_time(b) for a, b in ev) / iters
     enc.eval()
     dec.eval()
-    return dict(value=B * S / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
-                what='student-forcing rollout (dropout 0.5) + BPTT + 2x Adam (one HIP launch each), batch %d, %d decode steps, '
-                     'eager issue' % (B, S), loss=float(st.loss.detach()))
+    return dict(value=B * S * world / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
+                allreduce_ms=ar_ms if world > 1 else 0.0, allreduce_bytes=flat.flat.numel() * 4,
+                what='student-forcing rollout (dropout 0.5) + BPTT + %s2x Adam (one HIP launch each), batch %d per GPU, '
+                     '%d decode steps, eager issue' % ('one flat sum all-reduce over %d ranks + ' % world
+                                                       if world > 1 else '', B, S),
+                loss=float(st.loss.detach()))
 
 
-def main():
-    args = parse()
+# --------------------------------------------------------------------------- per-kernel roofline table
+def kernel_work(name, B, S, T, A_mean, dims):
+    """Algorithmic (flops, bytes, what) of ONE launch of a forward-rollout kernel, from the shapes
+    alone (fp32).  Bytes = every operand and result once, weights included (SURVEY 8d convention)."""
+    H, F, D, V = dims
+    f4 = 4.0
+    small = lambda M, N, K: (2.0 * M * N * K, f4 * (N * K + M * K + M * N))     # noqa: E731  y = x W^T
+    if 'lstm_step' in name or 'lstm_persist' in name:
+        return (2.0 * B * H * 4 * H, f4 * (4 * H * H + B * (H + 4 * H + 4 * H)),
+                'encoder recurrent step: gates = h W_hh^T + table row, cell update')
+    if 'gemm_nt_tiled' in name:
+        return (2.0 * B * (2 * F + H) * 4 * H, f4 * (4 * H * (2 * F + H) + B * (2 * F + H) + B * 4 * H),
+                'decoder LSTMCell gate product [B,2F+H] x [4H,2F+H]^T')
+    if 'pair_vis_small_kernel<1, 8' in name:
+        fl, by = small(B, H, 2 * H)
+        return (fl + 4.0 * B * V * F, by + f4 * B * V * F,
+                'visual-attention partials of step t+1 (panorama rows read once) || h~ = tanh(W_out [wc;h])')
+    if 'pair_vis_small_kernel<1, 4' in name:
+        fl, by = small(B, D, H)
+        return (fl + 2.0 * B * F, by + f4 * 2 * B * F, 'merge of the attention partials || t_a = W_h h~ + b')
+    if 'pair_small_text' in name:
+        fl, by = small(B, F, D)
+        return (fl + 4.0 * B * T * H, by + f4 * B * T * H, 'text attention over ctx [B,L,H] || q = W_v^T t_v')
+    if 'pair_small_small' in name:
+        fl, by = small(B, H, H)
+        fl2, by2 = small(B, D, H)
+        return (fl + fl2, by + by2, 't_text = W_in h1 || t_v = W_h h1 + b')
+    if 'score_glue' in name:
+        return (2.0 * B * A_mean * F, f4 * B * (A_mean + 1) * F + f4 * B * F,
+                'candidate rows . r, mask, CE, argmax, u_next gather')
+    if 'lstm_pw_fwd' in name:
+        return (10.0 * B * 4 * H, f4 * B * (8 * 4 * H + 4 * H + 4 * H), 'split-K slab sum + LSTM cell update')
+    if 'gemm_nt_small_kernel<4, 2>' in name:
+        fl, by = small(B, F, D)
+        return (fl, by, 'r = W_a^T wt')
+    return (None, None, '')
+
+
+def roofline_table(prof_rows, n_rollouts, B, S, T, A_mean, dims, pmc):
+    """Top kernels of the profiled eager rollouts, each priced against both ceilings."""
+    total = sum(r['total_us'] for r in prof_rows.values())
+    out = []
+    for name, r in sorted(prof_rows.items(), key=lambda kv: -kv[1]['total_us']):
+        fl, by, what = kernel_work(name, B, S, T, A_mean, dims)
+        row = dict(kernel=name, calls_per_rollout=r['calls'] / n_rollouts, avg_us=r['avg_us'],
+                   share=r['total_us'] / total, what=what)
+        if fl is not None:
+            tf = fl / (r['avg_us'] * 1e-6) / 1e12
+            gbs = by / (r['avg_us'] * 1e-6) / 1e9
+            row.update(flops_per_launch=fl, bytes_per_launch=by, tflops=tf, mfma_frac=tf / PEAK_TFLOPS_F32_MFMA,
+                       hbm_gbs=gbs, hbm_frac=gbs / PEAK_HBM_GBS)
+        for key, v in pmc.items():
+            if key in name:
+                row['traffic_offline_pmc'] = v
+        out.append(row)
+    return out, total
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(run_launcher(args, argv))
+
+    import numpy as np
+    import torch
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    local = int(os.environ.get('LOCAL_RANK', '0'))
+    local = 0 if args.share_gpu else int(os.environ.get('LOCAL_RANK', '0'))
     assert torch.cuda.is_available(), 'bench.py needs a GPU'
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     group = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=device)
+        if args.backend == 'nccl':
+            dist.init_process_group('nccl', device_id=device)
+        else:
+            dist.init_process_group('gloo')
         group = dist.group.WORLD
 
-    from speaker_follower_amd import synth, features, follower
+    from speaker_follower_amd import synth, features, follower, _lib
     enc, dec, enc_w, dec_w = build_models(101, device)
     B, S = args.batch, args.decode_steps
     table = device_table(args.n_viewpoints, 1234, device)
@@ -175,8 +330,7 @@ def main():
         dec.eval()
     replay = graph_state = shard_states = None
     if not train and not args.no_graph:
-        # the whole episode (encoder + S decode steps + glue + loss) as ONE hipGraph: ~330 kernels,
-        # no host work per step
+        # the whole episode (encoder + S decode steps + glue + loss) as ONE hipGraph: no host work per step
         if args.row_shards > 1:
             from speaker_follower_amd import dp
             shards = [follower.DeviceFollowerBatch.from_synth(
@@ -229,12 +383,17 @@ def main():
     value = agent_steps / elapsed
     if shard_states is not None:                # outside the timed region: stitch shard results
         graph_state.actions = torch.cat([x.actions for x in shard_states], dim=1)
+    extras = not args.no_extras
+
+    # ---- extra (not `value`), N > 1: the data-parallel TRAINING iteration (BASELINE configs[3]) on the
+    # same per-GPU batch, with the gradient all-reduce timed on its own.  Every rank takes part.
+    train_dp = None
+    if extras and world > 1 and not train and not args.no_train_extra:
+        train_dp = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2, group=group, world=world)
 
     # ---- extra (not `value`): serving-style throughput with several independent rollouts in flight.
-    # Every stage of one batch-100 chain is latency-bound and leaves most CUs idle, so independent
-    # episodes overlap on separate streams (validation / data-augmentation decode over many batches).
     concurrent = None
-    if not train and replay is not None and args.in_flight > 1 and rank == 0:
+    if extras and not train and replay is not None and args.in_flight > 1 and rank == 0 and world == 1:
         streams = [torch.cuda.Stream() for _ in range(args.in_flight)]
         reps = []
         for i, s in enumerate(streams):
@@ -261,48 +420,56 @@ def main():
             torch.distributed.destroy_process_group()
         return
 
-    # ---- roofline of the dominant kernel: the decoder LSTMCell gate GEMM [B,4864]x[4864,2048]
-    from speaker_follower_amd import ops
-    H, I = 512, 4352
-    x = torch.randn(B, I, device=device)
-    h0 = torch.randn(B, H, device=device)
-    c0 = torch.randn(B, H, device=device)
-    w4 = [dec.lstm.weight_ih.detach(), dec.lstm.weight_hh.detach(), dec.lstm.bias_ih.detach(),
-          dec.lstm.bias_hh.detach()]
-    from speaker_follower_amd.runtime import ptr, ws_args, struct_of
-    from speaker_follower_amd import _lib
-    import ctypes as C
-    # exactly what the rollout launches for the gates: x W_ih^T + h W_hh^T as split-K slabs (the
-    # LSTM pointwise kernel adds slabs + biases); ONE kernel per call, timed with HIP events on the
-    # stream it is launched on, over `reps` back-to-back launches
-    ks = C.c_int(0)
-    reps = 100
-    for _ in range(10):
-        _lib.call('sf_linear_slabs_fwd', ptr(x), I, ptr(w4[0]), I, ptr(h0), H, ptr(w4[1]), H, B, 4 * H,
-                  C.byref(ks), *ws_args(device))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    torch.cuda.synchronize()
-    e0.record()
-    for _ in range(reps):
-        _lib.call('sf_linear_slabs_fwd', ptr(x), I, ptr(w4[0]), I, ptr(h0), H, ptr(w4[1]), H, B, 4 * H,
-                  C.byref(ks), *ws_args(device))
-    e1.record()
-    torch.cuda.synchronize()
-    gemm_ms = e0.elapsed_time(e1) / reps
-    flops = FLOPS_LSTM(B, I, H)
-    achieved = flops / (gemm_ms * 1e-3) / 1e12
-    traffic = None          # HBM bytes per launch from the committed rocprofv3 PMC passes (offline)
-    pmc = os.path.join(ROOT, 'profiles', 'r01_lstm_gemm_pmc.json')
-    if os.path.exists(pmc) and B == 100:
-        traffic = json.load(open(pmc))['hbm_bytes_per_launch']
-    roofline = dict(bound='mfma', achieved=achieved, peak=157.3, unit='TFLOP/s',
-                    frac=achieved / 157.3, traffic=traffic,
-                    kernel='gemm_nt_tiled_kernel<7> (decoder LSTMCell gate product '
-                           '[%d,%d]x[%d,%d]^T fp32 -> %d split-K slabs, summed by lstm_pw_fwd_kernel)'
-                           % (B, I + H, 4 * H, I + H, ks.value),
-                    launch_ms=gemm_ms, flops_per_launch=flops,
-                    note='peak = 2.4 GHz fp32 MFMA; the same MFMA stream alone sustains ~145 TFLOP/s on '
-                         'random operands (tools/exp/mfma_power.hip)')
+    # ---- roofline: every kernel of the rollout timed IN THIS RUN.  Three eager rollouts are issued
+    # with a start/stop event pair on each dispatch (sf_profile_begin/end: the kernel's own execution
+    # time on its launch stream, what rocprofv3 --kernel-trace reports); the table prices each kernel's
+    # algorithmic FLOPs and bytes per launch against the fp32-MFMA and HBM peaks, `roofline` is the
+    # kernel with the largest share of the rollout.
+    d = synth.FULL
+    H, F = d.hidden, d.feat
+    D = dec.visual_attention_layer.linear_in_h.weight.shape[0]
+    T = max(batch.lengths)
+    A_mean = float(np.mean(fb.a_num))
+    n_prof = 3
+    enc.eval()
+    dec.eval()
+    prof_engine = follower.FollowerEngine(enc, dec, store)
+    with torch.no_grad():
+        prof_engine.rollout(batch, S, 'argmax', train=False)
+        torch.cuda.synchronize()
+        with _lib.kernel_profile() as prof:
+            for _ in range(n_prof):
+                prof_engine.rollout(batch, S, 'argmax', train=False)
+    pmc = {}
+    pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(pmc_path) and B == 100:
+        pmc = json.load(open(pmc_path))['hbm_bytes_per_launch']
+    kernels, kernel_us = roofline_table(prof.rows, n_prof, B, S, T, A_mean, (H, F, D, 36), pmc)
+    priced = [k for k in kernels if 'tflops' in k]
+    top = priced[0]
+    bound = 'mfma' if top['mfma_frac'] >= top['hbm_frac'] else 'hbm'
+    ms_rollout = 1e3 * elapsed / args.steps
+    roofline = dict(
+        bound=bound,
+        achieved=top['tflops'] if bound == 'mfma' else top['hbm_gbs'],
+        peak=PEAK_TFLOPS_F32_MFMA if bound == 'mfma' else PEAK_HBM_GBS,
+        unit='TFLOP/s' if bound == 'mfma' else 'GB/s',
+        frac=top['mfma_frac'] if bound == 'mfma' else top['hbm_frac'],
+        traffic=top.get('traffic_offline_pmc'),
+        kernel='%s (%s): top kernel by time of the profiled rollout, %.1f%% of its kernel time'
+               % (top['kernel'], top['what'], 100 * top['share']),
+        launch_us=top['avg_us'], flops_per_launch=top['flops_per_launch'],
+        bytes_per_launch=top['bytes_per_launch'],
+        mfma_frac=top['mfma_frac'], hbm_frac=top['hbm_frac'],
+        kernels=kernels[:8],
+        kernel_time_ms_per_rollout=1e-3 * kernel_us / n_prof,
+        rollout=dict(flops_frac=AGENT_STEP_FLOPS * B * S / (ms_rollout * 1e-3) / 1e12 / PEAK_TFLOPS_F32_MFMA,
+                     hbm_frac=AGENT_STEP_BYTES * B * S / (ms_rollout * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                     note='SURVEY 8(d) per-agent-step work (71.39 MFLOP, 1.049 MB at B=100; the unfolded '
+                          'reference arithmetic, decode steps only) x agent-steps / ms_per_step'),
+        method='launch times: HIP start/stop events on each dispatch of %d eager rollouts in this run; '
+               'traffic_offline_pmc: HBM bytes per launch from committed rocprofv3 --pmc passes '
+               '(profiles/pmc_traffic.json), NOT measured in this run' % n_prof)
 
     out = dict(metric='agent-steps/sec (follower rollout, batch %d)' % B, value=value,
                unit='agent-steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
@@ -315,26 +482,38 @@ def main():
                                        ', batch run as %d concurrent row shards' % args.row_shards
                                        if shard_states else ''),
                            global_batch=B * world, parallelism='dp%d' % world),
-               roofline=roofline, concurrent=concurrent, loss=float(st.loss_buf), launch=('hipGraph replay, %d concurrent row shards' % args.row_shards if shard_states
+               roofline=roofline, concurrent=concurrent, loss=float(st.loss_buf),
+               launch=('hipGraph replay, %d concurrent row shards' % args.row_shards if shard_states
                        else 'hipGraph replay') if replay else 'eager')
+    if args.share_gpu:
+        out['oversubscribed'] = 'TEST RUN: %d ranks share one GPU, %s collectives' % (world, args.backend)
+    if train_dp is not None:
+        out['train_dp'] = train_dp
 
     if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only
         used = np.unique(fb.vp)
         rows = table[torch.from_numpy(used).to(device)].cpu().numpy()
         row_of = {int(v): i for i, v in enumerate(used)}
-        cb, ref = cpu_baseline(enc_w, dec_w, fb, rows, row_of, S, args.cpu_reps)
+        cb, ref = cpu_baseline(enc_w, dec_w, fb, rows, row_of, S, args.cpu_reps, 1)
         out['cpu_baseline'] = cb
+        if extras:
+            out['cpu_baseline_all_cores'] = cpu_baseline(enc_w, dec_w, fb, rows, row_of, S, args.cpu_reps, None)[0]
         if not train:
             n = len(ref['logits'])
             same = bool(np.array_equal(st.actions.cpu().numpy()[:n], ref['actions']))
             out['parity_vs_cpu_port'] = dict(actions_bit_exact=same,
                                              loss_abs_diff=abs(float(st.loss_buf) - float(ref['loss'])))
-    # ---- extra (not `value`): the full training iteration of BASELINE configs[1] -- student-forcing
-    # rollout (dropout on), BPTT through the C ABI, two Adam steps -- on the same batch, N = 1 only
-    # (it updates the weights, so it runs after every inference measurement and parity check)
-    if not train and world == 1 and not args.no_train_extra:
-        out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2)
+    # ---- extras (not `value`), N = 1: the other BASELINE configs on this GPU
+    if extras and not train and world == 1:
+        from speaker_follower_amd import bench_extras
+        out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2]
+        out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
+        # the full training iteration of configs[1] -- student-forcing rollout (dropout on), BPTT, two
+        # Adam steps -- on the same batch (it updates the weights, so it runs last)
+        if not args.no_train_extra:
+            out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2)
     print(json.dumps(out))
+    sys.stdout.flush()
     if world > 1:
         torch.distributed.destroy_process_group()
 

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 3
+#define SF_ABI_VERSION 4
 
 enum {
     SF_OK = 0,
@@ -511,6 +511,16 @@ int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double 
  * (k = 0 start, 1 rows loaded and scored, 2 partials stored); buf = device memory of >= 512 * 8
  * uint64, NULL switches it off.  Used by tools/vis_trace.py to read a kernel's inner timeline. */
 void sf_debug_trace(unsigned long long* buf);
+
+/* In-process kernel timing (no reference counterpart; what bench.py's `roofline.kernels` table is
+ * measured with).  Between sf_profile_begin() and sf_profile_end() every kernel the CALLING host
+ * thread launches through this library carries a start and a stop event on its own dispatch, so a
+ * pair's elapsed time is that kernel's execution time on the stream it ran on (the figure rocprofv3
+ * --kernel-trace reports).  Not usable during hipGraph stream capture.  sf_profile_end waits for the
+ * recorded kernels, writes one text line per kernel name -- "name\tcalls\ttotal_us\tmin_us\tmax_us\n"
+ * -- into buf (NUL-terminated, truncated to cap) and returns the bytes the full text needs, or -1. */
+int sf_profile_begin(void);
+long sf_profile_end(char* buf, size_t cap);
 
 #ifdef __cplusplus
 }

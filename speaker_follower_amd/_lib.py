@@ -179,10 +179,12 @@ _SIGNATURES = {
     'sf_dropout_copy': (C.c_int, [c_f, i32, i32, i32, c_f, i32, P(Dropout), u32, i32, c_p]),
     'sf_embedding_fwd': (C.c_int, [c_f, i32, i64p, i32, c_f, c_p]),
     'sf_transpose': (C.c_int, [c_f, i32, i32, c_f, c_p]),
+    'sf_profile_begin': (C.c_int, []),
+    'sf_profile_end': (C.c_long, [C.c_char_p, C.c_size_t]),
 }
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 
 def _load():
@@ -213,3 +215,26 @@ def check(status, what=''):
 
 def call(name, *args):
     check(getattr(lib, name)(*args), name)
+
+
+class kernel_profile:
+    """`with kernel_profile() as prof: ...` times every kernel this thread launches through the
+    library (sf_profile_begin / sf_profile_end); afterwards prof.rows maps the kernel name to
+    dict(calls, total_us, avg_us, min_us, max_us).  Eager issue only (not under graph capture)."""
+
+    def __enter__(self):
+        call('sf_profile_begin')
+        self.rows = {}
+        return self
+
+    def __exit__(self, *exc):
+        buf = C.create_string_buffer(1 << 16)
+        n = lib.sf_profile_end(buf, len(buf))
+        if n < 0:
+            raise SfError('sf_profile_end failed')
+        for line in buf.value.decode().splitlines():
+            name, calls, total, mn, mx = line.split('\t')
+            name = name.strip('()')
+            self.rows[name] = dict(calls=int(calls), total_us=float(total), avg_us=float(total) / int(calls),
+                                   min_us=float(mn), max_us=float(mx))
+        return False

@@ -1,0 +1,126 @@
+"""Extra measurements of bench.py (never its `value`): the other BASELINE.json configs on one GPU.
+
+* `speaker_decode`  -- configs[2]: SpeakerEncoderLSTM over 100 paths of 4-7 steps + 80 greedy
+  SpeakerDecoderLSTM word steps (data_augmentation_from_speaker.py -> speaker.py:158-197), and the
+  teacher-forced scoring of the same batch (what pragmatic re-ranking runs per candidate).
+* `search_step`     -- configs[4]: one expansion step of the follower search over a flat list of
+  states (follower.py:575-603 / 785-803: gather h/c rows, one AttnDecoderLSTM step with per-state
+  instruction rows, log-softmax + sorted top-k) at 64 states (state-factored search, one state per
+  instance) and at 64 x 40 states (beam form), plus speaker scoring of 64 x 40 candidate paths
+  (rational_follower.py:60-95).
+
+Every measurement is wrapped: a failure is reported as {"error": ...} instead of losing the line.
+"""
+import time
+import traceback
+
+import numpy as np
+import torch
+
+
+def _guard(fn):
+    def run(*a, **k):
+        try:
+            return fn(*a, **k)
+        except Exception as e:                                    # noqa: BLE001
+            return dict(error='%s: %s' % (type(e).__name__, e), where=traceback.format_exc(limit=2))
+    return run
+
+
+def _timed(fn, warm, reps):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps
+
+
+def _speaker_models(device, seed=5):
+    from . import synth, model
+    d = synth.FULL
+    enc_w, dec_w = synth.speaker_weights(seed)
+    enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=dec_w['embedding.weight'])
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    return enc.to(device).eval(), dec.to(device).eval()
+
+
+@_guard
+def speaker_decode(store, device, batch=100, words=80):
+    from . import synth, speaker
+    enc, dec = _speaker_models(device)
+    n_vp = store.table.shape[0]
+    sb = synth.speaker_batch(seed=0, batch=batch, n_viewpoints=n_vp, min_path=4, max_path=7,
+                             min_len=10, max_len=79)
+    b = speaker.DeviceSpeakerBatch.from_synth(sb, device=device)
+    eng = speaker.SpeakerEngine(enc, dec, store)
+    out = dict(what='speaker: %d paths of 4-7 steps (encoder: visual attention + LSTMCell per path step) + %d word '
+                    'steps, hipGraph replay' % (batch, words), unit='word-steps/s')
+    for fb in ('argmax', 'teacher'):
+        replay, _ = eng.capture(b, words, fb)
+        dt = _timed(replay, 3, 10)
+        out['greedy_decode' if fb == 'argmax' else 'teacher_scoring'] = dict(
+            value=batch * words / dt, ms_per_batch=1e3 * dt)
+    return out
+
+
+def _synthetic_states(rng, n, n_vp, a_max=14):
+    """Index-form observations of `n` search states (env.R2RIndexEnv layout) with random candidates."""
+    obs, udesc = [], []
+    for _ in range(n):
+        a_num = int(1 + np.clip(rng.poisson(4), 1, a_max - 1))
+        adj = [dict(absViewIndex=-1, rel_heading=0.0, rel_elevation=0.0)]
+        for _a in range(1, a_num):
+            adj.append(dict(absViewIndex=int(rng.integers(0, 36)),
+                            rel_heading=float(rng.uniform(-np.pi, np.pi)),
+                            rel_elevation=float(rng.uniform(-np.pi / 6, np.pi / 6))))
+        obs.append(dict(vp_row=int(rng.integers(0, n_vp)), viewIndex=int(rng.integers(0, 36)),
+                        adj_loc_list=adj))
+        udesc.append((int(rng.integers(0, n_vp)), int(rng.integers(0, 36)),
+                      float(rng.uniform(-np.pi, np.pi)), float(rng.uniform(-np.pi / 6, np.pi / 6))))
+    return obs, udesc
+
+
+@_guard
+def search_step(enc, dec, store, device, instances=64, k=40, words=80):
+    from . import synth, search, speaker
+    from .follower import batch_instructions_from_encoded
+    rng = np.random.default_rng(7)
+    n_vp = store.table.shape[0]
+    instr = synth.instructions(3, instances, 10, 79, synth.FULL, sort=True)
+    seq, mask, lengths = batch_instructions_from_encoded(instr, 80, reverse=True, device=device)
+    with torch.no_grad():
+        ctx, h_t, c_t = enc(seq, lengths)
+    out = dict(what='one expansion step of the follower search over a flat state list: h/c row gather, '
+                    'AttnDecoderLSTM step with per-state instruction rows, log-softmax + sorted top-k, '
+                    'host packing of the index-form observations and D2H of the top-k included',
+               unit='states/s')
+    for label, n in (('state_factored_64', instances), ('beam_64x40', instances * k)):
+        obs, udesc = _synthetic_states(rng, n, n_vp)
+        rows = [int(i) for i in rng.integers(0, instances, size=n)]
+        inst = [i % instances for i in range(n)]
+
+        def step():
+            fd = search.FlatDecoder(dec, store, ctx, mask)
+            fd.seed(h_t, c_t)
+            with torch.no_grad():
+                fd.step(obs, udesc, rows, inst, k)
+        dt = _timed(step, 2, 5)
+        out[label] = dict(value=n / dt, ms_per_step=1e3 * dt, states=n)
+    # speaker rescoring of instances x k candidate paths (teacher-forced NLL of the instruction)
+    senc, sdec = _speaker_models(device)
+    n = instances * k
+    chunk = 128
+    sb = synth.speaker_batch(seed=1, batch=chunk, n_viewpoints=n_vp, min_path=4, max_path=7, min_len=10,
+                             max_len=79)
+    b = speaker.DeviceSpeakerBatch.from_synth(sb, device=device)
+    eng = speaker.SpeakerEngine(senc, sdec, store)
+    replay, _ = eng.capture(b, words, 'teacher')
+    dt = _timed(replay, 2, 5) * (n / chunk)
+    out['speaker_rescoring_64x40'] = dict(value=n / dt, unit='candidates/s', ms_total=1e3 * dt,
+                                          how='%d teacher-forced batches of %d paths x %d words' % (n // chunk, chunk, words))
+    return out

@@ -6,9 +6,37 @@
 
 using namespace sf;
 
+#include <map>
+#include <string>
+#include <vector>
+
 namespace sf {
 thread_local hipError_t g_last_hip_error = hipSuccess;
+
+// ---- in-process kernel timing (SF_LAUNCH, sf_common.h) ----
+namespace {
+struct ProfRec { const char* name; hipEvent_t e0, e1; };
+struct Prof {
+    bool active = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;      // events are created once and reused by later sessions
+    size_t used = 0;
+};
+thread_local Prof g_prof;
+}  // namespace
+bool prof_active() { return g_prof.active; }
+void prof_events(const char* name, hipEvent_t* e0, hipEvent_t* e1) {
+    Prof& p = g_prof;
+    while (p.pool.size() < p.used + 2) {
+        hipEvent_t e = nullptr;
+        if (hipEventCreate(&e) != hipSuccess) { e = nullptr; }
+        p.pool.push_back(e);
+    }
+    *e0 = p.pool[p.used++];
+    *e1 = p.pool[p.used++];
+    p.recs.push_back(ProfRec{name, *e0, *e1});
 }
+}  // namespace sf
 
 namespace {
 
@@ -19,6 +47,7 @@ constexpr size_t WORKSPACE_BYTES = 64u << 20;
 struct Arena {
     float* base;
     size_t cap, off;
+    unsigned* tk = nullptr;   // the workspace's ticket region (set by arena(); sub-arenas carry it along)
     float* take(size_t n) {
         n = (n + 63) & ~(size_t)63;
         if (off + n > cap) return nullptr;
@@ -30,13 +59,14 @@ struct Arena {
     size_t rest_n() const { return cap - off; }
     // the last SYNC_WORDS dwords of the workspace: monotonic ticket counters (zero-initialised by
     // the caller once, see sf_workspace_bytes); never handed out by take()
-    unsigned* tickets() const { return base ? reinterpret_cast<unsigned*>(base + cap) : nullptr; }
+    unsigned* tickets() const { return tk; }
 };
 constexpr size_t SYNC_WORDS = 1024;
 
 inline Arena arena(void* ws, size_t bytes) {
     const size_t n = ws ? bytes / 4 : 0;
-    return Arena{(float*)ws, n > SYNC_WORDS ? n - SYNC_WORDS : 0, 0};
+    const size_t usable = n > SYNC_WORDS ? n - SYNC_WORDS : 0;
+    return Arena{(float*)ws, usable, 0, usable ? reinterpret_cast<unsigned*>((float*)ws + usable) : nullptr};
 }
 inline hipStream_t S(sf_stream s) { return (hipStream_t)s; }
 
@@ -757,8 +787,12 @@ int sf_attn_decoder_bwd(const sf_decoder_w* w, const sf_decoder_g* g, const sf_p
 extern "C++" {
 namespace {
 // events of the two-stream episode backward (created once per host thread, timing disabled)
+// (keyed by device: an event belongs to the device that was current when it was created)
 std::vector<hipEvent_t>& event_pool(size_t n) {
-    static thread_local std::vector<hipEvent_t> pool;
+    static thread_local std::map<int, std::vector<hipEvent_t>> pools;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::vector<hipEvent_t>& pool = pools[dev];
     while (pool.size() < n) {
         hipEvent_t e;
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) break;
@@ -892,11 +926,13 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
     if (two) {
         SF_CHECK_ARG(e->ctx && dctx);
         std::vector<hipEvent_t>& ev = event_pool(e->S + 1);
-        const size_t nfl = ws ? ws_bytes / 4 : 0;
-        const size_t usable = nfl > SYNC_WORDS ? nfl - SYNC_WORDS : 0;
+        if (ev.size() < (size_t)e->S + 1) return SF_ERR_LAUNCH;      // event creation failed
+        const Arena whole = arena(ws, ws_bytes);
+        const size_t usable = whole.cap;
         const size_t head_n = std::min<size_t>(usable / 4, (size_t)4 << 20);
-        Arena tail_ar{(float*)ws, usable - head_n, 0};
-        Arena head_ar{(float*)ws + (usable - head_n), head_n, 0};
+        // two disjoint regions of the one workspace; both keep the real ticket region
+        Arena tail_ar{(float*)ws, usable - head_n, 0, whole.tk};
+        Arena head_ar{(float*)ws + (usable - head_n), head_n, 0, whole.tk};
         if (hipEventRecord(ev[e->S], main_st) != hipSuccess || hipStreamWaitEvent(side_st, ev[e->S], 0) != hipSuccess)
             return SF_ERR_LAUNCH;
         // ALL heads are issued first (they depend on nothing the tails produce), each followed by
@@ -1273,3 +1309,45 @@ int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float
 }
 
 }  // extern "C"
+
+// ---- in-process kernel timing ---------------------------------------------------------------------
+int sf_profile_begin(void) {
+    SF_ENTER();
+    if (g_prof.active) return SF_ERR_ARG;
+    g_prof.recs.clear();
+    g_prof.used = 0;
+    g_prof.active = true;
+    return SF_OK;
+}
+
+long sf_profile_end(char* buf, size_t cap) {
+    SF_ENTER();
+    if (!g_prof.active) return -1;
+    g_prof.active = false;
+    struct Row { long calls = 0; double total = 0, mn = 1e30, mx = 0; };
+    std::map<std::string, Row> rows;
+    for (const ProfRec& r : g_prof.recs) {
+        if (!r.e0 || !r.e1) return -1;
+        if (hipEventSynchronize(r.e1) != hipSuccess) return -1;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return -1;
+        Row& w = rows[r.name];
+        const double us = 1e3 * (double)ms;
+        w.calls += 1; w.total += us; w.mn = std::min(w.mn, us); w.mx = std::max(w.mx, us);
+    }
+    g_prof.recs.clear();
+    g_prof.used = 0;
+    std::string out;
+    char line[512];
+    for (const auto& kv : rows) {
+        snprintf(line, sizeof line, "%s\t%ld\t%.3f\t%.3f\t%.3f\n", kv.first.c_str(), kv.second.calls,
+                 kv.second.total, kv.second.mn, kv.second.mx);
+        out += line;
+    }
+    if (buf && cap) {
+        const size_t n = std::min(cap - 1, out.size());
+        std::copy(out.begin(), out.begin() + (long)n, buf);
+        buf[n] = 0;
+    }
+    return (long)out.size() + 1;
+}

@@ -753,25 +753,25 @@ int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec
     // small batches: two workgroups per sample (see visual_attn_split_kernel)
     if (mode == 0 && split_part && split_counter && src.V > (VSP_G - 1) * VSP_RPG &&
         src.V <= VSP_G * VSP_RPG && B <= 256) {
-        hipLaunchKernelGGL(visual_attn_split_kernel, dim3(VSP_G, B), dim3(VSP_NW * 64), 0, st, a,
+        SF_LAUNCH(visual_attn_split_kernel, dim3(VSP_G, B), dim3(VSP_NW * 64), 0, st, a,
                            VisSplit{split_part, split_counter, nullptr});
         return launch_status();
     }
     if (mode == 0)
-        hipLaunchKernelGGL(visual_attn_kernel<0>, dim3(B), dim3(VIS_NW * 64), 0, st, a);
+        SF_LAUNCH(visual_attn_kernel<0>, dim3(B), dim3(VIS_NW * 64), 0, st, a);
     else
-        hipLaunchKernelGGL(visual_attn_kernel<1>, dim3(B), dim3(VIS_NW * 64), 0, st, a);
+        SF_LAUNCH(visual_attn_kernel<1>, dim3(B), dim3(VIS_NW * 64), 0, st, a);
     return launch_status();
 }
 
 template <int MODE>
 static int text_attn_launch(const TxtArgs& a, int B, hipStream_t st) {
     if (a.L <= TXT_NW)
-        hipLaunchKernelGGL((text_attn_kernel<1, MODE>), dim3(B), dim3(TXT_NW * 64), 0, st, a);
+        SF_LAUNCH((text_attn_kernel<1, MODE>), dim3(B), dim3(TXT_NW * 64), 0, st, a);
     else if (a.L <= TXT_NW * 5)
-        hipLaunchKernelGGL((text_attn_kernel<5, MODE>), dim3(B), dim3(TXT_NW * 64), 0, st, a);
+        SF_LAUNCH((text_attn_kernel<5, MODE>), dim3(B), dim3(TXT_NW * 64), 0, st, a);
     else if (a.L <= TXT_NW * 8)
-        hipLaunchKernelGGL((text_attn_kernel<8, MODE>), dim3(B), dim3(TXT_NW * 64), 0, st, a);
+        SF_LAUNCH((text_attn_kernel<8, MODE>), dim3(B), dim3(TXT_NW * 64), 0, st, a);
     else
         return SF_ERR_UNSUPPORTED;
     return launch_status();
@@ -803,7 +803,7 @@ bool ctx_grad_supported(int S, int L, int H) {
 int ctx_grad_accum(const float* alpha, const float* ds, const float* dcat2, int lddc, const float* tt,
                    int S, int B, int L, int H, float* dctx, hipStream_t st) {
     if (!ctx_grad_supported(S, L, H) || (lddc & 3)) return SF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(ctx_grad_kernel, dim3(B), dim3(1024), (size_t)S * 2 * L * sizeof(float), st, alpha,
+    SF_LAUNCH(ctx_grad_kernel, dim3(B), dim3(1024), (size_t)S * 2 * L * sizeof(float), st, alpha,
                        ds, dcat2, lddc, tt, S, B, L, H, dctx);
     return launch_status();
 }
@@ -816,7 +816,7 @@ int score_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
     ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, logit, nullptr, nullptr, CeSrc{}};
-    hipLaunchKernelGGL(score_fwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
+    SF_LAUNCH(score_fwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
     return launch_status();
 }
 
@@ -829,7 +829,7 @@ int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float
         (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
     ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr, CeSrc{}};
-    hipLaunchKernelGGL(score_glue_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a, g);
+    SF_LAUNCH(score_glue_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a, g);
     return launch_status();
 }
 
@@ -842,7 +842,7 @@ int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* 
     ScoreArgs a{src, F, nullptr, nullptr, nullptr, nullptr, nullptr, 0, const_cast<float*>(dlogit), dr, dc,
                 ce ? *ce : CeSrc{}};
     if (ce && ce->ld < src.A) return SF_ERR_ARG;
-    hipLaunchKernelGGL(score_bwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
+    SF_LAUNCH(score_bwd_kernel, dim3(B), dim3(SC_NW * 64), 0, st, a);
     return launch_status();
 }
 
@@ -851,7 +851,7 @@ int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* 
 int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
     if (!(a.mt == 1 && a.cpw == 4 && b.mt == 1 && b.cpw == 4)) return SF_ERR_UNSUPPORTED;
     const int na = a.gx * a.gy, nb = b.gx * b.gy;
-    hipLaunchKernelGGL((pair_small_small_kernel<1, 4, 1, 4>), dim3(na + nb), dim3(SMALL_WAVES * 64), 0,
+    SF_LAUNCH((pair_small_small_kernel<1, 4, 1, 4>), dim3(na + nb), dim3(SMALL_WAVES * 64), 0,
                        st, a.args, a.gx, na, b.args, b.gx);
     return launch_status();
 }
@@ -866,11 +866,11 @@ int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, i
     const int na = a.gx * a.gy;
     const dim3 grid(na + B), block(TXT_NW * 64);
     if (L <= TXT_NW)
-        hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 1>), grid, block, 0, st, a.args, a.gx, na, ta);
+        SF_LAUNCH((pair_small_text_kernel<4, 2, 1>), grid, block, 0, st, a.args, a.gx, na, ta);
     else if (L <= TXT_NW * 5)
-        hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 5>), grid, block, 0, st, a.args, a.gx, na, ta);
+        SF_LAUNCH((pair_small_text_kernel<4, 2, 5>), grid, block, 0, st, a.args, a.gx, na, ta);
     else
-        hipLaunchKernelGGL((pair_small_text_kernel<4, 2, 8>), grid, block, 0, st, a.args, a.gx, na, ta);
+        SF_LAUNCH((pair_small_text_kernel<4, 2, 8>), grid, block, 0, st, a.args, a.gx, na, ta);
     return launch_status();
 }
 
@@ -885,7 +885,7 @@ int pair_visbwd_small(const PanoSrc& src, int B, const float* vec, int ldvec, fl
         return SF_ERR_UNSUPPORTED;
     VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
     const int nb = b.gx * b.gy;
-    hipLaunchKernelGGL((pair_visbwd_small_kernel<1, 16>), dim3(B + nb), dim3(VIS_NW * 64), 0, st, va, B,
+    SF_LAUNCH((pair_visbwd_small_kernel<1, 16>), dim3(B + nb), dim3(VIS_NW * 64), 0, st, va, B,
                        b.args, b.gx);
     return launch_status();
 }
@@ -907,13 +907,13 @@ int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float
     const dim3 grid(nv + nb), block(SMALL_WAVES * 64);
     const VisSplit sp{split_part, split_counter, g_trace};
     if (phase == 0)
-        hipLaunchKernelGGL((pair_vis_small_kernel<1, 8, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+        SF_LAUNCH((pair_vis_small_kernel<1, 8, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     else if (phase == 1)
-        hipLaunchKernelGGL((pair_vis_small_kernel<1, 8, 1>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+        SF_LAUNCH((pair_vis_small_kernel<1, 8, 1>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     else if (b.cpw == 8)
-        hipLaunchKernelGGL((pair_vis_small_kernel<1, 8, 2>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+        SF_LAUNCH((pair_vis_small_kernel<1, 8, 2>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     else
-        hipLaunchKernelGGL((pair_vis_small_kernel<1, 4, 2>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+        SF_LAUNCH((pair_vis_small_kernel<1, 4, 2>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     return launch_status();
 }
 

@@ -1,6 +1,7 @@
 // Shared device/host helpers for the speaker/follower HIP hot path (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <algorithm>
@@ -32,6 +33,26 @@ static inline int launch_status() {
     return SF_ERR_LAUNCH;
 }
 #define SF_ENTER() sf::clear_stale_error()
+
+// ---------------------------------------------------------------------------------------------
+// In-process kernel timing (sf_profile_begin / sf_profile_end, include/sf_hip.h).  While a host
+// thread has it switched on, every launch it makes through SF_LAUNCH carries a start and a stop
+// event on the dispatch itself (hipExtLaunchKernelGGL), so the elapsed time of a pair is that
+// kernel's execution time on the stream it was launched on -- what rocprofv3 --kernel-trace
+// reports, without a second process.  Off (the default) SF_LAUNCH is a plain launch.
+// ---------------------------------------------------------------------------------------------
+bool prof_active();
+void prof_events(const char* name, hipEvent_t* e0, hipEvent_t* e1);
+#define SF_LAUNCH(kernel, grid, block, shmem, st, ...)                                          \
+    do {                                                                                         \
+        if (sf::prof_active()) {                                                                 \
+            hipEvent_t _e0, _e1;                                                                 \
+            sf::prof_events(#kernel, &_e0, &_e1);                                                \
+            hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, _e0, _e1, 0, __VA_ARGS__);     \
+        } else {                                                                                 \
+            hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                     \
+        }                                                                                        \
+    } while (0)
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 

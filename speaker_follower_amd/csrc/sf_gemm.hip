@@ -1039,12 +1039,12 @@ int pick_ksplit(int waves_per_split, int chunks) {
 
 template <int MT>
 void launch_nt(const NtArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_nt_kernel<MT>, grid, dim3(256), 0, st, a);
+    SF_LAUNCH(gemm_nt_kernel<MT>, grid, dim3(256), 0, st, a);
 }
 
 template <int MT>
 void launch_nn(const NnArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL(gemm_nn_kernel<MT>, grid, dim3(256), 0, st, a);
+    SF_LAUNCH(gemm_nn_kernel<MT>, grid, dim3(256), 0, st, a);
 }
 
 inline int red_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 2048); }
@@ -1072,9 +1072,9 @@ template <int MT, int CPW>
 static void launch_small(const SmallArgs& a, hipStream_t st) {
     dim3 grid(ceil_div(a.N, 16), ceil_div(ceil_div(a.M, 16), MT));
     if (a.addend || a.r1_s || a.epi == EPI_TANHBWD)
-        hipLaunchKernelGGL((gemm_nt_small_x_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
+        SF_LAUNCH((gemm_nt_small_x_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
     else
-        hipLaunchKernelGGL((gemm_nt_small_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
+        SF_LAUNCH((gemm_nt_small_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
 }
 
 static void nt_shape(int M, int N, int Ktot_chunks, int* mt, int* mblocks, int* ks) {
@@ -1217,7 +1217,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
                                       hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
             attr_set = true;                                                                       \
         }                                                                                          \
-        hipLaunchKernelGGL(gemm_nt_tiled_kernel<MTV>, tgrid, dim3(512), lds, st, k);               \
+        SF_LAUNCH(gemm_nt_tiled_kernel<MTV>, tgrid, dim3(512), lds, st, k);               \
     } break;
         switch (mt) {
             SF_TILED(1) SF_TILED(2) SF_TILED(3) SF_TILED(4) SF_TILED(5) SF_TILED(6) SF_TILED(7)
@@ -1228,7 +1228,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
                     attr8 = true;
                 }
-                hipLaunchKernelGGL(gemm_nt_tiled_kernel<8>, tgrid, dim3(512), lds, st, k);
+                SF_LAUNCH(gemm_nt_tiled_kernel<8>, tgrid, dim3(512), lds, st, k);
             }
         }
 #undef SF_TILED
@@ -1265,7 +1265,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         r.ks = ks;
         r.bias = out.bias;
         r.bias2 = out.bias2;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid((size_t)M * N)), dim3(256), 0, st, r);
+        SF_LAUNCH(reduce_slabs_kernel, dim3(red_grid((size_t)M * N)), dim3(256), 0, st, r);
     }
     return launch_status();
 }
@@ -1277,20 +1277,20 @@ int lstm_step_fused(const LstmStepArgs& p, hipStream_t st) {
         const int cw = ceil_div(total, LSTMW_WAVES);
         dim3 wgrid(p.H / 8, ceil_div(p.B, 32)), wblock(LSTMW_WAVES * 64);
         if (cw <= 2) {
-            hipLaunchKernelGGL(lstm_step_wide_kernel<2>, wgrid, wblock, 0, st, p);
+            SF_LAUNCH(lstm_step_wide_kernel<2>, wgrid, wblock, 0, st, p);
             return launch_status();
         }
         if (cw <= 4) {
-            hipLaunchKernelGGL(lstm_step_wide_kernel<4>, wgrid, wblock, 0, st, p);
+            SF_LAUNCH(lstm_step_wide_kernel<4>, wgrid, wblock, 0, st, p);
             return launch_status();
         }
     }
     const int c = ceil_div(total, LSTM_KS);
     dim3 grid(p.H / 16, ceil_div(p.B, 16)), block(4 * LSTM_KS * 64);
     if (c <= 8)
-        hipLaunchKernelGGL(lstm_step_fused_kernel<8>, grid, block, 0, st, p);
+        SF_LAUNCH(lstm_step_fused_kernel<8>, grid, block, 0, st, p);
     else if (c <= 16)
-        hipLaunchKernelGGL(lstm_step_fused_kernel<16>, grid, block, 0, st, p);
+        SF_LAUNCH(lstm_step_fused_kernel<16>, grid, block, 0, st, p);
     else
         return SF_ERR_UNSUPPORTED;
     return launch_status();
@@ -1301,9 +1301,9 @@ int lstm_bwd_step_fused(const LstmBwdStepArgs& p, hipStream_t st) {
     const int c = ceil_div((4 * p.H) >> 4, BWS_WAVES);
     dim3 grid(p.H / 16, ceil_div(p.B, 16)), block(BWS_WAVES * 64);
     if (c <= 8)
-        hipLaunchKernelGGL(lstm_bwd_step_fused_kernel<8>, grid, block, 0, st, p);
+        SF_LAUNCH(lstm_bwd_step_fused_kernel<8>, grid, block, 0, st, p);
     else if (c <= 16)
-        hipLaunchKernelGGL(lstm_bwd_step_fused_kernel<16>, grid, block, 0, st, p);
+        SF_LAUNCH(lstm_bwd_step_fused_kernel<16>, grid, block, 0, st, p);
     else
         return SF_ERR_UNSUPPORTED;
     return launch_status();
@@ -1339,7 +1339,7 @@ int gemm_nn_ws(const float* A, int lda, const float* W, int ldw, int M, int N, i
         r.ldy = ldy;
         r.epi = EPI_NONE;
         r.accumulate = accumulate;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid((size_t)M * N)), dim3(256), 0, st, r);
+        SF_LAUNCH(reduce_slabs_kernel, dim3(red_grid((size_t)M * N)), dim3(256), 0, st, r);
     }
     return launch_status();
 }
@@ -1373,15 +1373,15 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
         dim3 grid(ceil_div(Q, TNT_B), ceil_div(P, TNT_B), ms);
         if (ms > 1) {
             TnArgs a{Y, ldy, X, ldx, M, P, Q, ws, Q, 0, ms};
-            hipLaunchKernelGGL(gemm_tn_tiled_kernel, grid, dim3(256), 0, st, a);
+            SF_LAUNCH(gemm_tn_tiled_kernel, grid, dim3(256), 0, st, a);
             RedArgs r{};
             r.slabs = ws; r.ks = ms; r.M = P; r.N = Q; r.y = out; r.ldy = ldo; r.epi = EPI_NONE;
             r.accumulate = accumulate;
-            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
+            SF_LAUNCH(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
             return launch_status();
         }
         TnArgs a{Y, ldy, X, ldx, M, P, Q, out, ldo, accumulate, 1};
-        hipLaunchKernelGGL(gemm_tn_tiled_kernel, grid, dim3(256), 0, st, a);
+        SF_LAUNCH(gemm_tn_tiled_kernel, grid, dim3(256), 0, st, a);
         return launch_status();
     }
     const int waves = ceil_div(Q, 64) * ceil_div(P, 64);
@@ -1412,16 +1412,16 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
     if (ms > 1) {
         TnArgs a{Y, ldy, X, ldx, M, P, Q, ws, Q, 0, ms};
         dim3 grid(ceil_div(Q, 256), ceil_div(P, 64), ms);
-        hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, a);
+        SF_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, st, a);
         RedArgs r{};
         r.slabs = ws; r.ks = ms; r.M = P; r.N = Q; r.y = out; r.ldy = ldo; r.epi = EPI_NONE;
         r.accumulate = accumulate;
-        hipLaunchKernelGGL(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
+        SF_LAUNCH(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
         return launch_status();
     }
     TnArgs a{Y, ldy, X, ldx, M, P, Q, out, ldo, accumulate, 1};
     dim3 grid(ceil_div(Q, 256), ceil_div(P, 64));
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, st, a);
+    SF_LAUNCH(gemm_tn_kernel, grid, dim3(256), 0, st, a);
     return launch_status();
 }
 
@@ -1432,10 +1432,10 @@ int colsum(const float* Y, int ldy, int M, int N, float* out, int accumulate, hi
     int ms = std::min(32, std::max(1, 256 / nb));
     ms = std::min(ms, std::max(1, M / 64));
     if (ms > 1 && (!ws || ws_floats < (size_t)ms * N)) ms = 1;
-    hipLaunchKernelGGL(colsum_kernel, dim3(nb, ms), dim3(1024), 0, st, Y, ldy, M, N, out, out2,
+    SF_LAUNCH(colsum_kernel, dim3(nb, ms), dim3(1024), 0, st, Y, ldy, M, N, out, out2,
                        accumulate, ms, ws);
     if (ms > 1)
-        hipLaunchKernelGGL(colsum_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, ws, ms, N,
+        SF_LAUNCH(colsum_finish_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, ws, ms, N,
                            out, out2, accumulate);
     return launch_status();
 }

@@ -573,7 +573,7 @@ __global__ __launch_bounds__(TPB) void adam_kernel(AdamArgs a) {
 int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st) {
     const dim3 grid(grid1d((size_t)a.B * a.H));
     switch (a.ks) {
-#define SF_PW(KS) case KS: hipLaunchKernelGGL(lstm_pw_fwd_kernel<KS>, grid, dim3(TPB), 0, st, a); break;
+#define SF_PW(KS) case KS: SF_LAUNCH(lstm_pw_fwd_kernel<KS>, grid, dim3(TPB), 0, st, a); break;
         SF_PW(0) SF_PW(1) SF_PW(2) SF_PW(3) SF_PW(4) SF_PW(5) SF_PW(6) SF_PW(7) SF_PW(8)
         SF_PW(9) SF_PW(10) SF_PW(11) SF_PW(12) SF_PW(13) SF_PW(14) SF_PW(15) SF_PW(16)
 #undef SF_PW
@@ -582,18 +582,18 @@ int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st) {
     return launch_status();
 }
 int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st) {
-    hipLaunchKernelGGL(lstm_pw_bwd_kernel, dim3(grid1d((size_t)a.B * a.H)), dim3(TPB), 0, st, a);
+    SF_LAUNCH(lstm_pw_bwd_kernel, dim3(grid1d((size_t)a.B * a.H)), dim3(TPB), 0, st, a);
     return launch_status();
 }
 int dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd, const Dropout& d,
                  int col0, hipStream_t st) {
-    hipLaunchKernelGGL(dropout_copy_kernel, dim3(grid1d((size_t)B * N)), dim3(TPB), 0, st, src, lds,
+    SF_LAUNCH(dropout_copy_kernel, dim3(grid1d((size_t)B * N)), dim3(TPB), 0, st, src, lds,
                        B, N, dst, ldd, d, col0);
     return launch_status();
 }
 int ctx_grad_slice(const float* dctx, int T, int H, int B, int t, const Dropout& d, float* out,
                    hipStream_t st) {
-    hipLaunchKernelGGL(ctx_grad_slice_kernel, dim3(grid1d((size_t)B * H)), dim3(TPB), 0, st, dctx, T,
+    SF_LAUNCH(ctx_grad_slice_kernel, dim3(grid1d((size_t)B * H)), dim3(TPB), 0, st, dctx, T,
                        H, B, t, d, out);
     return launch_status();
 }
@@ -601,7 +601,7 @@ template <int OP>
 static int ew(const float* a, int lda, const float* b, int ldb, int M, int N, float* dst, int ldd,
               hipStream_t st) {
     EwArgs e{a, lda, b, ldb, M, N, dst, ldd};
-    hipLaunchKernelGGL(ew_kernel<OP>, dim3(grid1d((size_t)M * N)), dim3(TPB), 0, st, e);
+    SF_LAUNCH(ew_kernel<OP>, dim3(grid1d((size_t)M * N)), dim3(TPB), 0, st, e);
     return launch_status();
 }
 int add2(const float* a, int lda, const float* b, int ldb, int M, int N, float* dst, int ldd,
@@ -621,13 +621,13 @@ int rank1_add(const float* s, const float* v, int M, int N, float* dst, int ldd,
 }
 int colsum_prod(const float* a, int lda, const float* b, int ldb, int M, int N, float* out,
                 hipStream_t st) {
-    hipLaunchKernelGGL(colsum_prod_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, a, lda, b, ldb,
+    SF_LAUNCH(colsum_prod_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, a, lda, b, ldb,
                        M, N, out);
     return launch_status();
 }
 int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float* out,
                    hipStream_t st) {
-    hipLaunchKernelGGL(dot_rows_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, s, x, ldx, M, N,
+    SF_LAUNCH(dot_rows_kernel, dim3(ceil_div(N, 64)), dim3(1024), 0, st, s, x, ldx, M, N,
                        out);
     return launch_status();
 }
@@ -640,77 +640,77 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr,
     AdamArgs a{p, g, m, v, n, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                (float)wd, (float)(lr / bc1), (float)(1.0 / sqrt(bc2))};
     const size_t n4 = (n + 3) >> 2;
-    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)std::min<size_t>((n4 + TPB - 1) / TPB, 4096)), dim3(TPB), 0,
+    SF_LAUNCH(adam_kernel, dim3((unsigned)std::min<size_t>((n4 + TPB - 1) / TPB, 4096)), dim3(TPB), 0,
                        st, a);
     return launch_status();
 }
 int sum_accum(const float* s, int M, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(sum_accum_kernel, dim3(1), dim3(64), 0, st, s, M, out);
+    SF_LAUNCH(sum_accum_kernel, dim3(1), dim3(64), 0, st, s, M, out);
     return launch_status();
 }
 int fill(float* p, size_t n, float v, hipStream_t st) {
     if (n == 0) return SF_OK;
-    hipLaunchKernelGGL(fill_kernel, dim3(grid1d(n)), dim3(TPB), 0, st, p, n, v);
+    SF_LAUNCH(fill_kernel, dim3(grid1d(n)), dim3(TPB), 0, st, p, n, v);
     return launch_status();
 }
 int transpose(const float* src, int R, int C, float* dst, hipStream_t st) {
-    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, st, src,
+    SF_LAUNCH(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, st, src,
                        R, C, dst);
     return launch_status();
 }
 int embedding_tm(const float* table, int E, const int64_t* seq, int B, int Lpad, int T, float* out,
                  hipStream_t st) {
     if (E & 3) return SF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(embedding_tm_kernel, dim3(grid1d((size_t)T * B * (E >> 2))), dim3(TPB), 0, st,
+    SF_LAUNCH(embedding_tm_kernel, dim3(grid1d((size_t)T * B * (E >> 2))), dim3(TPB), 0, st,
                        table, E, seq, B, Lpad, T, out);
     return launch_status();
 }
 int embedding_rows(const float* table, int E, const int64_t* idx, int B, float* out,
                    hipStream_t st) {
     if (E & 3) return SF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(embedding_rows_kernel, dim3(grid1d((size_t)B * (E >> 2))), dim3(TPB), 0, st,
+    SF_LAUNCH(embedding_rows_kernel, dim3(grid1d((size_t)B * (E >> 2))), dim3(TPB), 0, st,
                        table, E, idx, B, out);
     return launch_status();
 }
 int gather_panorama(const PanoSrc& s, int B, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(gather_pano_kernel,
+    SF_LAUNCH(gather_pano_kernel,
                        dim3(grid1d((size_t)B * s.V * ((s.IMG + s.LOC) >> 2))), dim3(TPB), 0, st, s, B,
                        out);
     return launch_status();
 }
 int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hipStream_t st) {
-    hipLaunchKernelGGL(gather_cand_kernel,
+    SF_LAUNCH(gather_cand_kernel,
                        dim3(grid1d((size_t)B * s.A * ((s.IMG + s.LOC) >> 2))), dim3(TPB), 0, st, s, B,
                        all_u, is_valid);
     return launch_status();
 }
 int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st) {
-    hipLaunchKernelGGL(gather_action_kernel, dim3(grid1d((size_t)B * ((s.IMG + s.LOC) >> 2))),
+    SF_LAUNCH(gather_action_kernel, dim3(grid1d((size_t)B * ((s.IMG + s.LOC) >> 2))),
                        dim3(TPB), 0, st, s, B, a, out);
     return launch_status();
 }
 int gather_rows(const float* src, int lds, const int* idx, int n, int w, float* dst, int ldd,
                 hipStream_t st) {
     if ((w & 3) || (lds & 3) || (ldd & 3)) return SF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid1d((size_t)n * (w >> 2))), dim3(TPB), 0, st, src,
+    SF_LAUNCH(gather_rows_kernel, dim3(grid1d((size_t)n * (w >> 2))), dim3(TPB), 0, st, src,
                        lds, idx, n, w, dst, ldd);
     return launch_status();
 }
 int logprob_topk(float* logit, int ld, int N, int n, const int* n_valid, int k, int* idx,
                  float* logp, hipStream_t st) {
     if (n > TOPK_E * TPB || k < 1 || k > n) return SF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(logprob_topk_kernel, dim3(N), dim3(TPB), 0, st, logit, ld, n, n_valid, k, idx,
+    SF_LAUNCH(logprob_topk_kernel, dim3(N), dim3(TPB), 0, st, logit, ld, n, n_valid, k, idx,
                        logp);
     return launch_status();
 }
 int follower_glue_fwd(const FGlue& g, hipStream_t st) {
     if (g.src.A > 64) return SF_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(follower_glue_kernel, dim3(ceil_div(g.B, TPB / 64)), dim3(TPB), 0, st, g);
+    SF_LAUNCH(follower_glue_kernel, dim3(ceil_div(g.B, TPB / 64)), dim3(TPB), 0, st, g);
     return launch_status();
 }
 int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,
                    const float* gscale, float* dlogit, hipStream_t st) {
-    hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, B, N,
+    SF_LAUNCH(softmax_ce_bwd_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, B, N,
                        ld, logit, target, ignore, gscale, dlogit);
     return launch_status();
 }
@@ -719,16 +719,16 @@ int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_
                      float* score, float* nll_term, float* live, hipStream_t st) {
     SGlue g{B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t, score, nll_term,
             live};
-    hipLaunchKernelGGL(speaker_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
+    SF_LAUNCH(speaker_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
     return launch_status();
 }
 int reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
                  hipStream_t st) {
-    hipLaunchKernelGGL(reduce_terms_kernel, dim3(T), dim3(64), 0, st, term, live, B, sum_cnt);
+    SF_LAUNCH(reduce_terms_kernel, dim3(T), dim3(64), 0, st, term, live, B, sum_cnt);
     return launch_status();
 }
 int loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, hipStream_t st) {
-    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sum_cnt, T, loss, gscale);
+    SF_LAUNCH(loss_finalize_kernel, dim3(1), dim3(64), 0, st, sum_cnt, T, loss, gscale);
     return launch_status();
 }
 

@@ -20,7 +20,7 @@ from . import _lib
 from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
-                    grad_ptr)
+                    grad_ptr, require_frozen_embedding)
 from .runtime import ptr, stream, ws_args, dropout_arg
 
 byref = C.byref
@@ -122,7 +122,8 @@ class FollowerEngine:
     def __init__(self, encoder, decoder, store, group=None):
         self.encoder, self.decoder, self.store = encoder, decoder, store
         self.group = group              # torch.distributed process group for data parallelism
-        self.iteration = 0
+        self.iteration = 0              # rollouts issued so far
+        self.site_next = 0              # first unused dropout / sampling site (see rollout)
         self.dropout_seed = None
         self.two_stream_backward = True  # heads of the backward on a side stream (see sf_follower_episode_bwd)
         self._side_stream = None
@@ -144,6 +145,7 @@ class FollowerEngine:
         T = max(batch.lengths)
         Lpad = batch.seq.shape[1]
         training = dec.training if train is None else train
+        require_frozen_embedding(enc, training)          # same refusal as EncoderLSTM.forward
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         st = RolloutState()
         st.batch, st.steps, st.dims = batch, S, (B, A, H, E, F, V, D, T)
@@ -156,7 +158,11 @@ class FollowerEngine:
             self.dropout_seed = torch.initial_seed() & 0xFFFFFFFF
         st.drop_dec = (p_dec, self.dropout_seed, batch.row0)
         st.drop_enc = (p_enc, self.dropout_seed ^ 0x5BD1E995, batch.row0)
-        st.site0 = self.iteration * 64
+        # A rollout of S steps uses sites site0 .. site0 + S + 1 (x2 for the two masks of a step): the
+        # next rollout starts behind them, at least 64 further on (so that S <= 62 keeps the
+        # `iteration * 64` numbering the oracle tests mirror).  Identical on every data-parallel rank.
+        st.site0 = self.site_next
+        self.site_next += max(64, S + 2)
         self.iteration += 1
 
         # ---- encoder (model.py:81-104)
@@ -251,23 +257,62 @@ class FollowerEngine:
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         st.logits = st.tape['logit']
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
+        st.all_params = all_params
         if not finalize:            # a row shard of a larger batch: the caller combines sum_cnt tables
-            return st
+            return st               # and calls finish(st, total)
         if self.group is not None:
             # global per-step normaliser so that the sharded loss equals the reference's batch mean
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
-        call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
+        return self.finish(st)
 
+    def finish(self, st, total=None):
+        """Second half of `rollout(..., finalize=False)`: turns the per-step (CE sum, live count) table
+        into the loss.  `total` = the table summed over every row shard of the batch (what the
+        data-parallel all-reduce produces across GPUs); with it the shard's loss IS the whole batch's
+        loss (follower.py:481: per-step mean over the non-ignored rows of the full batch) and its
+        backward() contributes exactly this shard's share of the batch gradient."""
+        if total is not None:
+            st.sum_cnt = total
+        call('sf_loss_finalize', ptr(st.sum_cnt), st.steps, ptr(st.loss_buf), ptr(st.gscale), stream())
         if st.differentiable:
-            st.loss = _RolloutLossFn.apply(self, st, *all_params)
+            st.loss = _RolloutLossFn.apply(self, st, *st.all_params)
         else:
             st.loss = st.loss_buf.clone().reshape(())
         return st
 
+    def _baked_pointers(self):
+        """Every weight-side device pointer a captured rollout bakes into its hipGraph: the parameters
+        and their derived copies (transposed layouts, the encoder's [vocab,4H] table).  Building the
+        structs also refreshes stale derived copies IN PLACE, on the current stream."""
+        ew = _encoder_structs(self.encoder)
+        dw = decoder_w_struct(decoder_params(self.decoder))
+        return bytes(ew) + bytes(dw)
+
+    def _guarded(self, graph_replay):
+        baked = self._baked_pointers()
+
+        def replay():
+            # weights updated since capture (optimizer.step, load_state_dict)?  Their derived copies are
+            # rebuilt in place here, ahead of the replay on the same stream, so the graph reads current
+            # data everywhere.  A MOVED tensor cannot be patched into the graph: refuse.
+            if self._baked_pointers() != baked:
+                raise RuntimeError('a weight (or one of its cached layouts) moved since this rollout was '
+                                   'captured; capture() again')
+            graph_replay()
+        return replay
+
     def capture(self, batch, steps, feedback='argmax'):
         """hipGraph of one inference rollout (eval mode, no autograd): returns (replay, state).
         `replay()` re-runs encoder + `steps` decode steps on the captured buffers; the state's
-        tensors (.actions, .logits, .loss_buf, ...) are overwritten by every replay."""
+        tensors (.actions, .logits, .loss_buf, ...) are overwritten by every replay.
+
+        The graph holds raw device pointers of the weights AND of their cached derived copies
+        (`runtime.transposed`, the encoder's embedding x W_ih^T table).  Those copies live in
+        persistent buffers that are refreshed in place, and `replay()` refreshes them first when a
+        weight's version changed, so replays after `optimizer.step()` / `load_state_dict` use the new
+        weights; if a weight tensor itself was re-allocated, `replay()` raises and the rollout must be
+        captured again.  Dropout sites are fixed at capture time: a captured TRAINING rollout would
+        replay one mask forever, which is why only inference is captured here."""
         with torch.no_grad():
             self.rollout(batch, steps, feedback, train=False)          # warm-up: allocations, caches
             torch.cuda.synchronize()
@@ -278,7 +323,7 @@ class FollowerEngine:
                 with torch.cuda.graph(graph, stream=side):
                     st = self.rollout(batch, steps, feedback, train=False)
             torch.cuda.current_stream().wait_stream(side)
-        return graph.replay, st
+        return self._guarded(graph.replay), st
 
     def capture_sharded(self, shards, steps, feedback='argmax'):
         """Runs the row shards of ONE batch as concurrent chains (inference): one hipGraph per
@@ -307,7 +352,7 @@ class FollowerEngine:
         loss_buf = torch.empty(1, device=dev)
         gscale = torch.empty(steps, device=dev)
 
-        def replay():
+        def replay_all():
             cur = torch.cuda.current_stream()
             for s, g in zip(streams, graphs):
                 s.wait_stream(cur)
@@ -320,7 +365,7 @@ class FollowerEngine:
                 call('sf_add_f32', ptr(total), ptr(st.sum_cnt), total.numel(), stream())
             call('sf_loss_finalize', ptr(total), steps, ptr(loss_buf), ptr(gscale), stream())
 
-        return replay, states, loss_buf
+        return self._guarded(replay_all), states, loss_buf
 
     # ------------------------------------------------------------------------------ backward
     def _backward(self, st, dloss):
@@ -328,6 +373,7 @@ class FollowerEngine:
         weight gradient is one product over all S*B stacked rows at the end (sf_attn_decoder_wgrad),
         accumulated in place into param.grad."""
         enc, dec, store = self.encoder, self.decoder, self.store
+        require_frozen_embedding(enc, True)              # no embedding gradient is formed on this path
         batch, S = st.batch, st.steps
         B, A, H, E, F, V, D, T = st.dims
         dev = store.device

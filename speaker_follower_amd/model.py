@@ -25,7 +25,7 @@ import torch.nn as nn
 from . import _lib, ops
 from ._lib import call
 from .runtime import (require_gpu, ptr, f32, stream, ws_args, dropout_arg, struct_of, grad_ptr,
-                      pano_dense, cands_dense, transposed, _v)
+                      pano_dense, cands_dense, transposed, xw_table, weight_key, _v)
 
 byref = C.byref
 
@@ -249,14 +249,17 @@ def _encoder_structs(mod, grad=False):
 
 
 def _xw_table(mod, emb, w_ih):
-    """[vocab, 4H] = embedding W_ih^T, cached on the module and rebuilt when either tensor changes
-    (optimizer steps bump `_version`): the LSTM's input product becomes a row lookup by token."""
-    key = (emb.data_ptr(), emb._version, w_ih.data_ptr(), w_ih._version)
-    if getattr(mod, '_xw_key', None) != key:
-        with torch.no_grad():
-            mod._xw = ops.linear_fwd(emb.detach().contiguous(), w_ih.detach().contiguous())
-        mod._xw_key = key
-    return mod._xw
+    """[vocab, 4H] = embedding W_ih^T (runtime.xw_table: cached on the module, rebuilt in place)."""
+    return xw_table(mod, emb, w_ih)
+
+
+def require_frozen_embedding(mod, training):
+    """The HIP encoder / speaker decoder read `W_ih . embedding[token]` as a table row and form no
+    embedding gradient; the reference also applies dropout to a trainable (non-GloVe) embedding
+    (model.py:86-87).  That configuration is refused instead of silently training another model."""
+    if training and not mod.use_glove and mod.embedding.weight.requires_grad:
+        raise NotImplementedError('HIP %s: trainable (non-GloVe) embeddings are not supported in '
+                                  'training mode' % type(mod).__name__)
 
 
 class _EncoderFn(torch.autograd.Function):
@@ -321,9 +324,7 @@ class EncoderLSTM(nn.Module):
 
     def forward(self, inputs, lengths):
         require_gpu(inputs)
-        if self.training and not self.use_glove and self.embedding.weight.requires_grad:
-            raise NotImplementedError('HIP EncoderLSTM: trainable (non-GloVe) embeddings are not '
-                                      'supported in training mode')
+        require_frozen_embedding(self, self.training)
         lengths = [int(x) for x in lengths]
         T = max(lengths)
         lengths_dev = torch.tensor(lengths, dtype=torch.int32, device=inputs.device)
@@ -368,7 +369,7 @@ def decoder_fold(mod):
     tensors it is made of changed.  Kept on the module so that the pointers stay alive."""
     params = decoder_params(mod)
     src = [params[i] for i in (4, 5, 6, 10, 11, 12, 13, 14, 15)]
-    key = tuple((p.data_ptr(), p._version) for p in src)
+    key = weight_key(*src)
     cached = getattr(mod, '_sf_fold', None)
     if cached is not None and cached[0] == key:
         return cached[2]
@@ -668,21 +669,13 @@ class SpeakerDecoderLSTM(nn.Module):
                                 self._xw_table().data_ptr())
 
     def _xw_table(self):
-        """[vocab, 4H] = embedding W_ih^T, rebuilt when either tensor changes (optimizer steps bump
-        `_version`): the LSTM's input product becomes a row lookup by the previous word."""
-        emb, w_ih = self.embedding.weight, self.lstm.weight_ih
-        key = (emb.data_ptr(), emb._version, w_ih.data_ptr(), w_ih._version)
-        if getattr(self, '_xw_key', None) != key:
-            with torch.no_grad():
-                self._xw = ops.linear_fwd(emb.detach().contiguous(), w_ih.detach().contiguous())
-            self._xw_key = key
-        return self._xw
+        """[vocab, 4H] = embedding W_ih^T (runtime.xw_table): the LSTM's input product becomes a
+        row lookup by the previous word."""
+        return xw_table(self, self.embedding.weight, self.lstm.weight_ih)
 
     def forward(self, previous_word, h_0, c_0, ctx, ctx_mask=None):
         require_gpu(previous_word, h_0, c_0, ctx)
-        if self.training and not self.use_glove and self.embedding.weight.requires_grad:
-            raise NotImplementedError('HIP SpeakerDecoderLSTM: trainable (non-GloVe) embeddings '
-                                      'are not supported in training mode')
+        require_frozen_embedding(self, self.training)
         cfg = self._drop_state.next(self, self.drop.p)
         words = previous_word.reshape(-1).contiguous()                 # model.py:497-498
         return _SpeakerDecoderFn.apply(self, cfg, words, h_0.contiguous(), c_0.contiguous(),

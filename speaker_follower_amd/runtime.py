@@ -105,16 +105,57 @@ def cands_dense(U):
 
 
 _transposed = {}
+_cache_epoch = 0
+
+
+def invalidate_caches():
+    """Forces every derived copy of the weights (transposed layouts, the [vocab,4H] input-product
+    tables, the folded inference matrices) to be rebuilt on next use.
+
+    The caches are keyed on `(param.data_ptr(), param._version)`: every in-place update torch knows
+    about (optimizer.step(), `load_state_dict`, `p.add_()` under no_grad, FusedAdam) bumps `_version`
+    and is noticed by itself.  A write through `param.data` (or a raw pointer) is NOT -- `.data`
+    carries its own version counter -- so code that does that must call this afterwards."""
+    global _cache_epoch
+    _cache_epoch += 1
+
+
+def cache_epoch():
+    return _cache_epoch
+
+
+def weight_key(*tensors):
+    """Cache key of a set of weights: storage, torch version counter and the invalidation epoch."""
+    return tuple((t.data_ptr(), t._version) for t in tensors) + (_cache_epoch,)
+
+
+def xw_table(owner, emb, w_ih):
+    """[vocab, 4H] = embedding W_ih^T kept on `owner` (a module) and rebuilt IN PLACE when either
+    tensor changes: an LSTM whose input is an embedding lookup reads its input product as a row of
+    this table.  In place, so that a captured hipGraph keeps pointing at live memory (see
+    FollowerEngine.capture)."""
+    key = weight_key(emb, w_ih)
+    if getattr(owner, '_xw_key', None) != key:
+        V, N = emb.shape[0], w_ih.shape[0]
+        buf = getattr(owner, '_xw', None)
+        if buf is None or buf.shape != (V, N) or buf.device != emb.device:
+            buf = torch.empty(V, N, device=emb.device, dtype=torch.float32)
+        e, w = emb.detach().contiguous(), w_ih.detach().contiguous()
+        _lib.call('sf_linear_fwd', ptr(e), e.shape[1], ptr(w), None, V, N, e.shape[1], 0, ptr(buf), N,
+                  *ws_args(emb.device))
+        owner._xw, owner._xw_key = buf, key
+    return owner._xw
 
 
 def transposed(w):
-    """Device copy of w^T for a 2-D weight, rebuilt only when the weight changed (torch bumps
-    `_version` on every in-place update, e.g. optimizer.step()).  288 GB of HBM make keeping every
-    hot weight in both layouts free; it turns y = x W into a K-contiguous product."""
+    """Device copy of w^T for a 2-D weight, rebuilt (in place) only when the weight changed (torch
+    bumps `_version` on every in-place update, e.g. optimizer.step(); see invalidate_caches for
+    the one case it cannot see).  288 GB of HBM make keeping every hot weight in both layouts free;
+    it turns y = x W into a K-contiguous product."""
     import weakref
     key = w.data_ptr()
     hit = _transposed.get(key)
-    if hit is not None and hit[0]() is w and hit[1] == w._version:
+    if hit is not None and hit[0]() is w and hit[1] == (w._version, _cache_epoch):
         return hit[2]
     R, Cc = w.shape
     out = hit[2] if (hit is not None and hit[2].shape == (Cc, R) and hit[2].device == w.device) \
@@ -123,5 +164,5 @@ def transposed(w):
     if len(_transposed) > 256:                      # dead entries of freed modules
         for k in [k for k, v in _transposed.items() if v[0]() is None]:
             del _transposed[k]
-    _transposed[key] = (weakref.ref(w), w._version, out)
+    _transposed[key] = (weakref.ref(w), (w._version, _cache_epoch), out)
     return out

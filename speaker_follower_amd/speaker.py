@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
-from .model import _grads
+from .model import _grads, require_frozen_embedding
 from .runtime import ptr, stream, ws_args, dropout_arg, struct_of
 
 byref = C.byref
@@ -81,6 +81,7 @@ class SpeakerEngine:
         self.encoder, self.decoder, self.store = encoder, decoder, store
         self.group = group
         self.iteration = 0
+        self.site_next = 0              # first unused dropout site (see score)
         self.dropout_seed = None
 
     def capture(self, batch, steps, feedback='teacher'):
@@ -96,7 +97,15 @@ class SpeakerEngine:
                 with torch.cuda.graph(graph, stream=side):
                     st = self.score(batch, steps, feedback, train=False)
             torch.cuda.current_stream().wait_stream(side)
-        return graph.replay, st
+        baked = bytes(self.decoder._w_struct())
+
+        def replay():
+            # the [vocab,4H] input-product table is refreshed in place when the weights changed; a
+            # re-allocated weight cannot be patched into the graph (FollowerEngine.capture)
+            if bytes(self.decoder._w_struct()) != baked:
+                raise RuntimeError('a speaker weight moved since this pass was captured; capture() again')
+            graph.replay()
+        return replay, st
 
     def score(self, batch, steps, feedback='teacher', train=None):
         """Returns a SpeakerState: .words [S,B], .logits [S,B,vocab], .step_scores [S,B],
@@ -110,6 +119,7 @@ class SpeakerEngine:
         E, vocab = dec.vocab_embedding_size, dec.vocab_size
         ldv = (vocab + 3) & ~3
         training = dec.training if train is None else train
+        require_frozen_embedding(dec, training)          # same refusal as SpeakerDecoderLSTM.forward
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         st = SpeakerState()
         st.batch, st.steps, st.dims = batch, S, (B, Tp, H, F, V, D, E, vocab, ldv)
@@ -118,7 +128,9 @@ class SpeakerEngine:
             self.dropout_seed = torch.initial_seed() & 0xFFFFFFFF
         st.drop_enc = (enc.drop.p if training else 0.0, self.dropout_seed ^ 0x2545F491, batch.row0)
         st.drop_dec = (dec.drop.p if training else 0.0, self.dropout_seed, batch.row0)
-        st.site0 = self.iteration * 256
+        # sites site0 .. site0 + max(S, Tp) + 1 are used by this pass; the next one starts behind them
+        st.site0 = self.site_next
+        self.site_next += max(256, S + 2, Tp + 2)
         self.iteration += 1
         ws = ws_args(dev)
 
@@ -195,6 +207,7 @@ class SpeakerEngine:
 
     def _backward(self, st, dloss):
         enc, dec, store = self.encoder, self.decoder, self.store
+        require_frozen_embedding(dec, True)              # no embedding gradient is formed on this path
         batch, S = st.batch, st.steps
         B, Tp, H, F, V, D, E, vocab, ldv = st.dims
         dev = store.device

@@ -30,6 +30,21 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
     for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
         assert k in r, k
     assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9
+    # the roofline names the top kernel by time of the profiled rollout and carries the table
+    ks = r['kernels']
+    assert len(ks) >= 5 and ks[0]['kernel'] in r['kernel']
+    assert all(ks[i]['share'] >= ks[i + 1]['share'] for i in range(len(ks) - 1))
+    for k in ks[:5]:
+        assert k['avg_us'] > 0 and k['calls_per_rollout'] > 0
+    priced = [k for k in ks if 'mfma_frac' in k]
+    assert len(priced) >= 4 and all(0 < k['mfma_frac'] < 1 and 0 < k['hbm_frac'] < 1 for k in priced)
+    assert 0 < r['rollout']['flops_frac'] < 1 and 0 < r['rollout']['hbm_frac'] < 1
+    # kernel time of a rollout (sum of event pairs) cannot exceed its wall time by more than noise
+    assert r['kernel_time_ms_per_rollout'] < 1.5 * d['ms_per_step']
+    for extra in ('speaker_decode', 'search_step', 'train_iteration', 'cpu_baseline_all_cores'):
+        assert extra in d, extra
+    assert 'error' not in d['speaker_decode'], d['speaker_decode']
+    assert 'error' not in d['search_step'], d['search_step']
     c = d['cpu_baseline']
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k

@@ -1,0 +1,171 @@
+"""GPU: the data-parallel path proven on ONE GPU.
+
+The reference has no multi-GPU code; the exchange slots in between `loss.backward()` and
+`optimizer.step()` (follower.py:1014-1018).  Samples interact only through the per-step loss
+normaliser (CrossEntropyLoss averages over the non-ignored rows of the whole batch,
+follower.py:278, 481), so R row shards + a summed [steps,2] (CE sum, live count) table + summed
+gradients must reproduce the unsharded batch -- including dropout masks and sampled actions, which
+are functions of the GLOBAL row id."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+from speaker_follower_amd import synth                                # noqa: E402
+
+
+def fresh_modules(seed=101):
+    from speaker_follower_amd import model
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights(seed)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    return enc.cuda(), dec.cuda()
+
+
+@pytest.mark.parametrize('n_shards,feedback', [(2, 'argmax'), (3, 'argmax'), (3, 'sample'), (2, 'teacher')])
+def test_row_shards_reproduce_the_unsharded_batch(n_shards, feedback):
+    from speaker_follower_amd import follower, features, dp
+    B, S, NVP = 26, 7, 64
+    enc, dec = fresh_modules()
+    enc.train()
+    dec.train()                                            # dropout ON: masks must follow the global row
+    params = [p for p in list(enc.parameters()) + list(dec.parameters()) if p.requires_grad]
+    flat = dp.FlatGrads(params)
+    fb = synth.follower_batch(seed=3, batch=B, steps=S, n_viewpoints=NVP, min_len=4, max_len=30, a_max=9)
+    store = features.FeatureStore(synth.feature_table(3, NVP))
+
+    def engine():
+        e = follower.FollowerEngine(enc, dec, store)
+        e.dropout_seed = 0x1234ABCD
+        return e
+
+    whole = follower.DeviceFollowerBatch.from_synth(fb)
+    st = engine().rollout(whole, S, feedback, train=True)
+    st.loss.backward()
+    torch.cuda.synchronize()
+    ref_loss = float(st.loss.detach())
+    ref_grad = flat.flat.clone()
+    ref_actions = st.actions.cpu().numpy()
+    ref_cnt = st.sum_cnt.cpu().numpy()
+    assert np.isfinite(ref_loss) and float(ref_grad.abs().max()) > 0
+
+    flat.zero()
+    shards, states = [], []
+    for i in range(n_shards):
+        rows = dp.shard_rows(B, i, n_shards)
+        sh = follower.DeviceFollowerBatch.from_synth(fb, rows=rows, row0=rows.start)
+        shards.append(rows)
+        states.append((engine(), sh))
+    states = [(e, e.rollout(sh, S, feedback, train=True, finalize=False)) for e, sh in states]
+    total = sum(s.sum_cnt for _, s in states)              # what the [steps,2] all-reduce produces
+    np.testing.assert_allclose(total.cpu().numpy(), ref_cnt, rtol=1e-6, atol=1e-6)
+    for e, s in states:
+        e.finish(s, total.clone())
+        assert abs(float(s.loss.detach()) - ref_loss) <= 1e-6 * max(1.0, abs(ref_loss))
+        s.loss.backward()                                  # accumulates into the one flat buffer
+    torch.cuda.synchronize()
+    got_actions = np.concatenate([s.actions.cpu().numpy() for _, s in states], axis=1)
+    assert np.array_equal(got_actions, ref_actions)        # same masks, same samples, same argmax
+    got, want = flat.flat, ref_grad
+    off = 0
+    for p in params:                                       # per parameter: 1e-6 of its own scale
+        n = p.numel()
+        g, w = got[off:off + n], want[off:off + n]
+        scale = float(w.abs().max())
+        assert float((g - w).abs().max()) <= 2e-6 * scale + 1e-12, (tuple(p.shape), scale)
+        off += n
+
+
+def test_captured_rollout_follows_weight_updates():
+    """A hipGraph replay after optimizer.step() must use the NEW weights everywhere -- also through
+    the cached transposed copies and the encoder's embedding x W_ih^T table (rebuilt in place)."""
+    from speaker_follower_amd import follower, features, runtime
+    B, S, NVP = 10, 4, 32
+    enc, dec = fresh_modules(7)
+    enc.eval()
+    dec.eval()
+    fb = synth.follower_batch(seed=5, batch=B, steps=S, n_viewpoints=NVP, min_len=4, max_len=20, a_max=8)
+    store = features.FeatureStore(synth.feature_table(5, NVP))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    eng = follower.FollowerEngine(enc, dec, store)
+    replay, gst = eng.capture(batch, S, 'argmax')
+
+    def eager():
+        with torch.no_grad():
+            return follower.FollowerEngine(enc, dec, store).rollout(batch, S, 'argmax', train=False)
+
+    replay()
+    torch.cuda.synchronize()
+    before = gst.logits.clone()
+    assert torch.equal(before, eager().logits)
+    with torch.no_grad():                                   # an update torch knows about (bumps _version)
+        for p in list(enc.parameters()) + list(dec.parameters()):
+            if p.requires_grad:
+                p.mul_(1.25)
+    replay()
+    torch.cuda.synchronize()
+    after = gst.logits.clone()
+    fin = torch.isfinite(before)
+    assert not torch.allclose(after[fin], before[fin])
+    assert torch.equal(after, eager().logits)
+    # an update torch does NOT see (`.data` has its own version counter) needs the explicit call
+    for p in dec.parameters():
+        p.data.mul_(0.8)
+    for p in enc.parameters():
+        if p.requires_grad:
+            p.data.mul_(0.8)
+    runtime.invalidate_caches()
+    replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gst.logits, eager().logits)
+    assert not torch.allclose(gst.logits[fin], after[fin])
+    # a re-allocated weight cannot be patched into the graph: loud failure, not stale memory
+    dec.lstm.weight_hh.data = dec.lstm.weight_hh.data.clone()
+    with pytest.raises(RuntimeError, match='capture'):
+        replay()
+
+
+def test_dropout_sites_do_not_collide_for_long_rollouts():
+    """Sites advance by at least S + 2 per rollout (they were `iteration * 64`: a rollout with more
+    than 62 steps reused the masks of the next iteration)."""
+    from speaker_follower_amd import follower, features
+    enc, dec = fresh_modules(9)
+    store = features.FeatureStore(synth.feature_table(1, 16))
+    eng = follower.FollowerEngine(enc, dec, store)
+    fb = synth.follower_batch(seed=1, batch=4, steps=70, n_viewpoints=16, min_len=3, max_len=8, a_max=5)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    with torch.no_grad():
+        a = eng.rollout(batch, 70, 'argmax', train=True)
+        b = eng.rollout(batch, 5, 'argmax', train=True)
+        c = eng.rollout(batch, 5, 'argmax', train=True)
+    assert a.site0 == 0 and b.site0 == 72 and c.site0 == 72 + 64
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """The N > 1 code path of bench.py end to end -- self-launch, rendezvous, weak-scaling rollout,
+    data-parallel training iteration with the flat gradient all-reduce, one JSON line from rank 0 --
+    with both ranks sharing this box's single GPU and gloo standing in for RCCL."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-gpu',
+                          '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--n-viewpoints', '96',
+                          '--batch', '16', '--decode-steps', '5'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
+    assert d['scaling'] == 'weak' and 'oversubscribed' in d
+    assert abs(d['value'] - 2 * 16 * 5 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+    t = d['train_dp']
+    assert t['allreduce_ms'] > 0 and t['allreduce_bytes'] == 4 * 14059265 and np.isfinite(t['loss'])
