@@ -410,7 +410,14 @@ typedef struct sf_encoder_w {
      * the input half of the gates of step t is then the table row of token seq[b,t] -- no
      * [T*B,E]x[E,4H] product, no [T,B,4H] intermediate.  NULL = the product is formed every call. */
     const float* xw_table;
+    /* SF_ENC_* bits.  By default, when xw_table is given, H == 512, B <= 128, T <= 128 and the device
+     * has >= 256 CUs, the T recurrent steps run as ONE persistent launch (csrc/sf_persist.hip: W_hh in
+     * registers, the batch partitioned across the XCDs, h exchanged inside a partition); results are
+     * bit-identical to the one-launch-per-step path for B > 16 (same summation order as its
+     * 32-row kernel; within 2e-6 of its 16-row kernel below that).  SF_ENC_PER_STEP forces per-step. */
+    int32_t flags;
 } sf_encoder_w;
+#define SF_ENC_PER_STEP 1
 typedef struct sf_encoder_g { sf_lstm_g lstm; float *w_e2d, *b_e2d; } sf_encoder_g;
 typedef struct sf_encoder_tape { float *emb, *xg, *gates, *hs, *cs; } sf_encoder_tape;
 int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, int H,

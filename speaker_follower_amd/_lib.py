@@ -82,7 +82,7 @@ class FollowerEpisode(C.Structure):
 
 class EncoderW(C.Structure):
     _fields_ = [('embedding', c_p), ('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p), ('w_e2d_t', c_p),
-                ('xw_table', c_p)]
+                ('xw_table', c_p), ('flags', C.c_int32)]
 
 
 class EncoderG(C.Structure):
@@ -182,6 +182,8 @@ _SIGNATURES = {
     'sf_profile_begin': (C.c_int, []),
     'sf_profile_end': (C.c_long, [C.c_char_p, C.c_size_t]),
 }
+
+SF_ENC_PER_STEP = 1           # sf_encoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)
 ABI_VERSION = 4

@@ -62,6 +62,7 @@ struct Arena {
     unsigned* tickets() const { return tk; }
 };
 constexpr size_t SYNC_WORDS = 1024;
+constexpr size_t PERSIST_TICKET = 1000;   // arrival counter of the persistent encoder launch
 
 inline Arena arena(void* ws, size_t bytes) {
     const size_t n = ws ? bytes / 4 : 0;
@@ -1061,10 +1062,24 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     if (!w->xw_table)
         TRY(linear_plain(tp->emb, E, w->lstm.w_ih, E, nullptr, T * B, 4 * H, E, EPI_NONE, tp->xg,
                          4 * H, ar, st));
-    TRY(fill(tp->hs, BH, 0.f, st));   // model.py:67-79 init_state
-    TRY(fill(tp->cs, BH, 0.f, st));
     const Dropout dctx = make_dropout(drop, drop_stream);
-    for (int t = 0; t < T; ++t) {
+    // all T steps as ONE persistent launch (sf_persist.hip) where it applies; bit-identical results
+    bool persistent = false;
+    if (w->xw_table && !(w->flags & SF_ENC_PER_STEP) && encoder_persistent_supported(B, H, T)) {
+        Arena pa = ar;
+        float* xchg = pa.take(encoder_persistent_xchg_floats(H));
+        if (xchg && ar.tickets()) {
+            TRY(encoder_persistent(w->lstm.w_hh, w->lstm.b_ih, w->lstm.b_hh, w->xw_table, seq, Lpad, lengths, B,
+                                   H, T, tp->gates, tp->hs, tp->cs, ctx, dctx, xchg,
+                                   ar.tickets() + PERSIST_TICKET, st));
+            persistent = true;
+        }
+    }
+    if (!persistent) {
+        TRY(fill(tp->hs, BH, 0.f, st));   // model.py:67-79 init_state
+        TRY(fill(tp->cs, BH, 0.f, st));
+    }
+    for (int t = 0; t < T && !persistent; ++t) {
         // one fused launch per time step: h_t W_hh^T on the matrix cores + gates + cell update
         LstmStepArgs f{};
         f.h0 = tp->hs + t * BH; f.w_hh = w->lstm.w_hh; f.x = nullptr; f.xg = tp->xg + (size_t)t * B * 4 * H;

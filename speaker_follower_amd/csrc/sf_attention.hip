@@ -149,7 +149,6 @@ struct VisSplit {
 __device__ __forceinline__ void vis_stamp(const VisSplit& sp, int block, int slot) {
     if (sp.trace && threadIdx.x == 0) sp.trace[(size_t)block * 8 + slot] = wall_clock64();
 }
-static unsigned long long* g_trace = nullptr;
 
 // PHASE 0: partials + ticket + merge by the last arriver, in one launch (hand-off inside the launch:
 //          write-through stores, sc1 loads).

@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <string>
 
 #include "../../include/sf_hip.h"
 
@@ -43,11 +44,14 @@ static inline int launch_status() {
 // ---------------------------------------------------------------------------------------------
 bool prof_active();
 void prof_events(const char* name, hipEvent_t* e0, hipEvent_t* e1);
-#define SF_LAUNCH(kernel, grid, block, shmem, st, ...)                                          \
+// SF_LAUNCH_AS: the same with an explicit name (a launch inside a template only sees "<MT, CPW>").
+#define SF_LAUNCH(kernel, grid, block, shmem, st, ...) \
+    SF_LAUNCH_AS(#kernel, kernel, grid, block, shmem, st, __VA_ARGS__)
+#define SF_LAUNCH_AS(name, kernel, grid, block, shmem, st, ...)                                 \
     do {                                                                                         \
         if (sf::prof_active()) {                                                                 \
             hipEvent_t _e0, _e1;                                                                 \
-            sf::prof_events(#kernel, &_e0, &_e1);                                                \
+            sf::prof_events(name, &_e0, &_e1);                                                   \
             hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, _e0, _e1, 0, __VA_ARGS__);     \
         } else {                                                                                 \
             hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                     \

@@ -1039,12 +1039,14 @@ int pick_ksplit(int waves_per_split, int chunks) {
 
 template <int MT>
 void launch_nt(const NtArgs& a, dim3 grid, hipStream_t st) {
-    SF_LAUNCH(gemm_nt_kernel<MT>, grid, dim3(256), 0, st, a);
+    static const std::string nm = "gemm_nt_kernel<" + std::to_string(MT) + ">";
+    SF_LAUNCH_AS(nm.c_str(), gemm_nt_kernel<MT>, grid, dim3(256), 0, st, a);
 }
 
 template <int MT>
 void launch_nn(const NnArgs& a, dim3 grid, hipStream_t st) {
-    SF_LAUNCH(gemm_nn_kernel<MT>, grid, dim3(256), 0, st, a);
+    static const std::string nm = "gemm_nn_kernel<" + std::to_string(MT) + ">";
+    SF_LAUNCH_AS(nm.c_str(), gemm_nn_kernel<MT>, grid, dim3(256), 0, st, a);
 }
 
 inline int red_grid(size_t total) { return (int)std::min<size_t>((total + 255) / 256, 2048); }
@@ -1071,10 +1073,12 @@ static bool small_shape(int M, int N, int chunks, int* mt, int* cpw) {
 template <int MT, int CPW>
 static void launch_small(const SmallArgs& a, hipStream_t st) {
     dim3 grid(ceil_div(a.N, 16), ceil_div(ceil_div(a.M, 16), MT));
+    static const std::string tp = "<" + std::to_string(MT) + ", " + std::to_string(CPW) + ">";
+    static const std::string nx = "gemm_nt_small_x_kernel" + tp, nn = "gemm_nt_small_kernel" + tp;
     if (a.addend || a.r1_s || a.epi == EPI_TANHBWD)
-        SF_LAUNCH((gemm_nt_small_x_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
+        SF_LAUNCH_AS(nx.c_str(), (gemm_nt_small_x_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
     else
-        SF_LAUNCH((gemm_nt_small_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
+        SF_LAUNCH_AS(nn.c_str(), (gemm_nt_small_kernel<MT, CPW>), grid, dim3(SMALL_WAVES * 64), 0, st, a);
 }
 
 static void nt_shape(int M, int N, int Ktot_chunks, int* mt, int* mblocks, int* ks) {

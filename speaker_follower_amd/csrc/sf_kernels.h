@@ -41,6 +41,18 @@ size_t gemm_nn_ws_floats(int M, int N, int K);
 int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st);
 int lstm_step_fused(const LstmStepArgs& p, hipStream_t st);      // sf_gemm.hip
 
+extern unsigned long long* g_trace;   // sf_debug_trace buffer (development aid), null = off
+
+// ---- sf_persist.hip: the T recurrent steps of a table-input LSTM as one persistent launch ---------
+size_t encoder_persistent_xchg_floats(int H);
+bool encoder_persistent_supported(int B, int H, int T);
+// hs / cs: [T+1,B,H] tapes (slot 0 is zeroed here); xchg: scratch of encoder_persistent_xchg_floats
+// floats; done: one zero-initialised ticket word.  SF_ERR_UNSUPPORTED = use the per-step path.
+int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
+                       const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
+                       float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
+                       hipStream_t st);
+
 struct LstmPwBwd {
     const float* gates; const float* c0; const float* c1;
     const float* dh1; const float* dh1_b;   // two optional contributions to dh1 (either may be null)

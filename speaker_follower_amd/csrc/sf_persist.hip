@@ -1,0 +1,314 @@
+// Persistent recurrent kernels: the T dependent time steps of an LSTM whose input is a table lookup
+// (EncoderLSTM, model.py:81-104) in ONE launch, with the batch partitioned across the XCDs.
+//
+// A per-step launch (lstm_step_wide_kernel) is bound by the bytes one workgroup pulls: its 128 KB
+// slice of W_hh is re-fetched through the fabric by every launch (an XCD's L2 does not survive a
+// kernel boundary) and lands over ~6 us of an 8.4 us step whose MFMAs take 1.7 us.  Here:
+//   * grid = 256 workgroups of 4 waves, one per CU; workgroup b belongs to row group b % 8 (the
+//     XCD it is dispatched to -- a placement that is observed, used for speed only and never relied
+//     on for correctness) and owns hidden units [16 (b / 8), +16) of that group's <= 16 batch rows;
+//   * its [64 gate rows x 512] slice of W_hh lives in REGISTERS for all T steps (128 VGPRs: wave w
+//     holds K-slices {w, w+8, w+4, w+12} of 32 for all four gates), the cell state too;
+//   * only h_t travels, and only inside a row group: 32 KB per workgroup per step, through the
+//     group's own L2 when the placement holds.  The exchange needs no flag, counter or fence: every
+//     dword of h IS its own flag.  Three buffers rotate; a producer resets its 1 KB patch of the
+//     buffer two steps ahead to a sentinel (0xFFFFFFFF, a NaN no cell can produce) and consumers
+//     re-read with L1-bypassing (sc1) loads until no sentinel is left.  Stores are write-through
+//     (sc1), so the protocol is correct for ANY workgroup placement.
+//   * summation order is that of lstm_step_wide_kernel (16 K-slices of 32, paired (k, k+8), then
+//     added in order to bias + table row): the two paths give bit-identical h, c, ctx.
+// Every wait is bounded (wall clock): on a timeout the workgroup stops waiting and poisons its
+// outputs with NaN, so a starved launch (co-residency lost to another process) ends instead of
+// hanging, and the loss shows it.  Launches of one process are serialised by a device-wide lock
+// taken in the prologue kernel and released by the last workgroup.
+#include "sf_kernels.h"
+#include "sf_gemm_small.h"
+
+namespace sf {
+unsigned long long* g_trace = nullptr;     // sf_debug_trace buffer (set in sf_attention.hip)
+namespace {
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+
+constexpr int EP_GROUPS = 8;               // row groups (= XCDs)
+constexpr int EP_SLOTS = 32;               // workgroups per group: 16 hidden units each (H = 512)
+constexpr int EP_ROWS = 16;                // rows per group (one MFMA m-tile)
+constexpr int EP_TMAX = 128;
+constexpr unsigned EP_SENTINEL = 0xFFFFFFFFu;
+constexpr long long EP_TIMEOUT_TICKS = 25000000LL;   // 0.25 s of the 100 MHz wall clock
+constexpr int AUX_SC1 = 16;                // cache-policy bit 4: agent scope (bypass L1 / write through)
+
+__device__ unsigned g_persist_lock = 0;
+
+__global__ __launch_bounds__(256) void enc_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, float* h0,
+                                                                   float* c0, size_t n_state) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_xchg; i += stride) xchg[i] = EP_SENTINEL;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_state; i += stride) {
+        h0[i] = 0.f;                       // model.py:67-79 init_state
+        c0[i] = 0.f;
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (atomicCAS(&g_persist_lock, 0u, 1u) != 0u) {
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > 8 * EP_TIMEOUT_TICKS) break;   // a lost unlock must not hang the stream
+        }
+    }
+}
+
+struct EncPersistArgs {
+    const float* w_hh; const float* b_ih; const float* b_hh;   // [4H,H], [4H], [4H]
+    const float* xw_table;                                     // [vocab,4H] = embedding W_ih^T
+    const int64_t* seq; int Lpad;                              // [B,Lpad] tokens
+    const int* lengths;                                        // [B]
+    int B, H, T, rpg;                                          // rpg = rows per group
+    float* gates; float* hs; float* cs;                        // tapes [T,B,4H], [T+1,B,H] x2
+    float* ctx; int ld_ctx; Dropout ctx_drop;                  // ctx[b, t, :], row stride T*H
+    unsigned* xchg;                                            // [8][3][16][H] dwords, sentinel-filled
+    unsigned* done;                                            // arrival counter (0 before and after)
+    unsigned long long* trace;                                 // sf_debug_trace: [blocks][8] tick sums, or null
+};
+
+__global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
+    __shared__ float s_red[8][4][256];                  // paired K-slice partials R_k of the 4 gates
+    __shared__ int s_tok[EP_ROWS][EP_TMAX];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int grp = blockIdx.x & (EP_GROUPS - 1), slot = blockIdx.x >> 3;
+    const int H = p.H, T = p.T, B = p.B;
+    const int row0 = grp * p.rpg;
+    const int nrows = max(0, min(p.rpg, B - row0));
+
+    // ---- resident operands --------------------------------------------------------------------
+    // wave w: K-slices sj = {w, w+8 | w+4, w+12} (32 k each = chunks 2s, 2s+1), all four gates
+    const int sj[4] = {w, w + 8, w + 4, w + 12};
+    float4 wf[4][4][2];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int cc = 0; cc < 2; ++cc)
+                wf[g][j][cc] = ld4(p.w_hh + (size_t)(g * H + 16 * slot + li) * H + 16 * (2 * sj[j] + cc) + 4 * kk);
+    for (int i = tid; i < EP_ROWS * T; i += 256) {
+        const int r = i / T, t = i - r * T;
+        s_tok[r][t] = r < nrows ? (int)p.seq[(size_t)(row0 + r) * p.Lpad + t] : 0;
+    }
+    // the (row, unit) this thread updates; rows beyond the group's share compute on row B-1's
+    // operands (clamped, as the per-step kernel does) and store nothing
+    const int er = tid >> 4, eu = tid & 15;
+    const bool evalid = er < nrows;
+    const int eb = evalid ? row0 + er : B - 1;
+    const int ej = 16 * slot + eu;
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = p.b_ih[g * H + ej] + p.b_hh[g * H + ej];
+    const int len_b = p.lengths[eb];
+    const uint32_t rk = dropout_row_key(p.ctx_drop.seed, p.ctx_drop.stream, (uint32_t)(p.ctx_drop.row0 + eb));
+    float c_state = 0.f, h_state = 0.f;
+    const size_t BH = (size_t)B * H;
+
+    unsigned* xg = p.xchg + (size_t)grp * 3 * EP_ROWS * H;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(xg, 0, 3 * EP_ROWS * H * 4, 0x00020000);
+    // packed 16-byte access of this workgroup's own [16 x 16] patch: thread with (tid & 3) == 0
+    // covers units eu .. eu+3 of row er
+    const unsigned patch_off = (unsigned)((er * H + ej) * 4);
+    bool dead = false;
+
+    __syncthreads();
+    float xv[4];
+    {
+        const int tok = s_tok[er][0];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xv[g] = p.xw_table[(size_t)tok * 4 * H + g * H + ej];
+    }
+
+    long long tk[5] = {0, 0, 0, 0, 0}, tprev = wall_clock64();    // development aid (p.trace)
+#define EP_STAMP(k)                                 \
+    if (p.trace) {                                  \
+        const long long now_ = wall_clock64();      \
+        tk[k] += now_ - tprev;                      \
+        tprev = now_;                               \
+    }
+    for (int t = 0; t < T; ++t) {
+        EP_STAMP(4)                                      // tapes + loop back
+        float xn[4] = {0.f, 0.f, 0.f, 0.f};
+        if (t > 0) {                                     // h_0 = 0: the first step has no product
+            v4u a[4][2];
+            const unsigned base = (unsigned)((((t % 3) * EP_ROWS + li) * H) * 4);
+            const long long t0 = wall_clock64();
+            for (;;) {
+                asm volatile("" ::: "memory");           // the loads below are re-issued every pass
+                bool ok = true;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+                        a[j][cc] = __builtin_amdgcn_raw_buffer_load_b128(
+                            rs, base + (unsigned)((16 * (2 * sj[j] + cc) + 4 * kk) * 4), 0, AUX_SC1);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc)
+                        ok = ok && a[j][cc].x != EP_SENTINEL && a[j][cc].y != EP_SENTINEL &&
+                             a[j][cc].z != EP_SENTINEL && a[j][cc].w != EP_SENTINEL;
+                if (__all(ok) || dead) break;
+                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) {
+                    dead = true;
+                    break;
+                }
+            }
+            EP_STAMP(0)                                  // waiting for h_t
+            // every workgroup of the group has consumed h_{t-1}: its buffer becomes the buffer of
+            // h_{t+2}; reset the own patch there (same lanes, same addresses as the later publish)
+            if ((tid & 3) == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
+                                                       (unsigned)((((t + 2) % 3) * EP_ROWS) * H * 4) + patch_off, 0,
+                                                       AUX_SC1);
+            // input row of the NEXT step (table lookup by token): lands behind the MFMAs
+            if (t + 1 < T) {
+                const int tok = s_tok[er][t + 1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xn[g] = p.xw_table[(size_t)tok * 4 * H + g * H + ej];
+            }
+            __syncthreads();                             // s_red of the previous step fully consumed
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                f32x4 acc[4][2];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * h2 + jj;
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const float4 af = make_float4(__uint_as_float(a[j][cc].x), __uint_as_float(a[j][cc].y),
+                                                      __uint_as_float(a[j][cc].z), __uint_as_float(a[j][cc].w));
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+                                acc[g][jj] = mfma16(comp(af, c), comp(wf[g][j][cc], c), acc[g][jj]);
+                    }
+                }
+                // R_k = P_{k+8} + P_k goes to LDS at once (the stores of the first half ride under
+                // the MFMAs of the second)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 Rk = acc[g][1] + acc[g][0];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_red[w + 4 * h2][g][(kk * 4 + r) * 16 + li] = Rk[r];
+                }
+            }
+        } else {
+            if (T > 1) {
+                const int tok = s_tok[er][1];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) xn[g] = p.xw_table[(size_t)tok * 4 * H + g * H + ej];
+            }
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) s_red[w + 4 * h2][g][(kk * 4 + r) * 16 + li] = 0.f;
+        }
+        __syncthreads();
+        EP_STAMP(1)                                      // MFMAs + partials to LDS + barrier
+        float g4[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float v = bias[g] + xv[g];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v += s_red[k][g][tid];
+            g4[g] = v;
+        }
+        const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
+        float c1 = fg * c_state + ig * gg;
+        float h1 = og * tanhf(c1);
+        const bool live = t < len_b;                     // packed sequence (model.py:88-95)
+        if (!live) { c1 = c_state; h1 = h_state; }
+        if (dead) h1 = __uint_as_float(0x7FC00000u);     // starved launch: poison, do not hang
+        // publish h_{t+1} first (it is the critical path), the tapes at leisure
+        if (t + 1 < T) {
+            const float hp = evalid ? h1 : 0.f;
+            const float h_1 = __shfl_down(hp, 1), h_2 = __shfl_down(hp, 2), h_3 = __shfl_down(hp, 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sentinel reset is behind us
+            if ((tid & 3) == 0)
+                __builtin_amdgcn_raw_buffer_store_b128(
+                    v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)}, rs,
+                    (unsigned)((((t + 1) % 3) * EP_ROWS) * H * 4) + patch_off, 0, AUX_SC1);
+        }
+        EP_STAMP(2)                                      // reduce + cell + publish
+        if (evalid) {
+            if (p.gates) {
+                float* gp = p.gates + ((size_t)t * B + eb) * 4 * H + ej;
+                gp[0] = ig; gp[H] = fg; gp[2 * H] = gg; gp[3 * H] = og;
+            }
+            float cv = live ? h1 : 0.f;
+            if (live && p.ctx_drop.on())
+                cv = dropout_keep(rk, (uint32_t)(t * H + ej), p.ctx_drop.thresh) ? cv * p.ctx_drop.scale : 0.f;
+            p.ctx[(size_t)eb * p.ld_ctx + (size_t)t * H + ej] = cv;
+            p.cs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = c1;
+            p.hs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = h1;
+        }
+        c_state = c1;
+        h_state = h1;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xv[g] = xn[g];
+    }
+    if (p.trace && lane == 0 && w == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p.trace[blockIdx.x * 8 + k] = (unsigned long long)tk[k];
+    }
+    // last workgroup out releases the device-wide lock and re-arms the counter
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned n = atomicAdd(p.done, 1u);
+        if (n == gridDim.x - 1) {
+            atomicExch(p.done, 0u);
+            atomicExch(&g_persist_lock, 0u);
+        }
+    }
+}
+
+int device_cus() {
+    static thread_local int cached_dev = -1, cached = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+        cached_dev = dev;
+        cached = n;
+    }
+    return cached;
+}
+
+}  // namespace
+
+size_t encoder_persistent_xchg_floats(int H) { return (size_t)EP_GROUPS * 3 * EP_ROWS * H; }
+
+bool encoder_persistent_supported(int B, int H, int T) {
+    return H == 16 * EP_SLOTS && B >= 1 && B <= EP_GROUPS * EP_ROWS && T >= 1 && T <= EP_TMAX &&
+           device_cus() >= EP_GROUPS * EP_SLOTS;
+}
+
+int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
+                       const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
+                       float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
+                       hipStream_t st) {
+    if (!encoder_persistent_supported(B, H, T) || !xw_table || !xchg || !done) return SF_ERR_UNSUPPORTED;
+    EncPersistArgs a{};
+    a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.xw_table = xw_table; a.seq = seq; a.Lpad = Lpad;
+    a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
+    a.gates = gates; a.hs = hs; a.cs = cs; a.ctx = ctx; a.ld_ctx = T * H; a.ctx_drop = ctx_drop;
+    a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.trace = g_trace;
+    SF_LAUNCH(enc_persist_prologue_kernel, dim3(96), dim3(256), 0, st, a.xchg, encoder_persistent_xchg_floats(H),
+              hs, cs, (size_t)B * H);
+    SF_LAUNCH(enc_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
+    return launch_status();
+}
+
+}  // namespace sf

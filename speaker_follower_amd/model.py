@@ -245,7 +245,8 @@ def _encoder_structs(mod, grad=False):
         return _lib.EncoderG(_lib.LstmW(*_grads(l4)), *_grads(e2d))
     lw = _lib.LstmW(*(p.data_ptr() for p in l4), None, transposed(l4[1]).data_ptr())
     return _lib.EncoderW(mod.embedding.weight.data_ptr(), lw, *(p.data_ptr() for p in e2d),
-                         transposed(e2d[0]).data_ptr(), _xw_table(mod, mod.embedding.weight, l4[0]).data_ptr())
+                         transposed(e2d[0]).data_ptr(), _xw_table(mod, mod.embedding.weight, l4[0]).data_ptr(),
+                         0 if getattr(mod, 'persistent', True) else _lib.SF_ENC_PER_STEP)
 
 
 def _xw_table(mod, emb, w_ih):

@@ -77,12 +77,13 @@ def test_row_shards_reproduce_the_unsharded_batch(n_shards, feedback):
     got_actions = np.concatenate([s.actions.cpu().numpy() for _, s in states], axis=1)
     assert np.array_equal(got_actions, ref_actions)        # same masks, same samples, same argmax
     got, want = flat.flat, ref_grad
+    gmax = float(want.abs().max())
     off = 0
-    for p in params:                                       # per parameter: 1e-6 of its own scale
-        n = p.numel()
+    for p in params:         # per parameter: 2e-6 of its own scale (+ 1e-7 of the largest gradient: the
+        n = p.numel()        # visual linear_in_v.bias and scoring linear_out.bias gradients are exactly 0 in exact arithmetic)
         g, w = got[off:off + n], want[off:off + n]
         scale = float(w.abs().max())
-        assert float((g - w).abs().max()) <= 2e-6 * scale + 1e-12, (tuple(p.shape), scale)
+        assert float((g - w).abs().max()) <= 2e-6 * scale + 1e-7 * gmax, (tuple(p.shape), scale, gmax)
         off += n
 
 

@@ -1,0 +1,111 @@
+"""GPU: the persistent encoder launch (csrc/sf_persist.hip; EncoderLSTM.forward, model.py:81-104)
+against the one-launch-per-step path: same summation order, so ctx / h / c and every tape must be
+BIT-identical -- for ragged lengths, batch sizes that leave row groups partly or wholly empty,
+train-mode dropout on ctx, repeated launches and launches racing on two streams."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from speaker_follower_amd import synth                                # noqa: E402
+
+
+def encoder(seed=101):
+    from speaker_follower_amd import model
+    d = synth.FULL
+    enc_w, _ = synth.follower_weights(seed)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    return enc.cuda()
+
+
+def batch(seed, B, min_len, max_len):
+    from speaker_follower_amd.follower import batch_instructions_from_encoded
+    instr = synth.instructions(seed, B, min_len, max_len, synth.FULL, sort=True)
+    return batch_instructions_from_encoded(instr, 80, reverse=True)
+
+
+def run(enc, seq, lens, persistent, train=False):
+    from speaker_follower_amd import _lib
+    from speaker_follower_amd.model import _encoder_structs
+    from speaker_follower_amd.runtime import ptr, ws_args, dropout_arg
+    import ctypes as C
+    enc.persistent = persistent
+    B, Lpad = seq.shape
+    T, E, H = max(lens), enc.embedding_size, enc.hidden_size
+    new = lambda *s: torch.full(s, float('nan'), device='cuda', dtype=torch.float32)   # noqa: E731
+    out = dict(ctx=new(B, T, H), h=new(B, H), c=new(B, H), emb=new(T, B, E), xg=new(T, B, 4 * H),
+               gates=new(T, B, 4 * H), hs=new(T + 1, B, H), cs=new(T + 1, B, H))
+    tp = _lib.EncoderTape(*(out[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
+    w = _encoder_structs(enc)
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    _lib.call('sf_encoder_lstm_fwd', C.byref(w), B, Lpad, T, E, H, ptr(seq), ptr(lens_dev), ptr(out['ctx']),
+              ptr(out['h']), ptr(out['c']), C.byref(tp), dropout_arg(0.5 if train else 0.0, 0xBEEF, 3), 7,
+              *ws_args(seq.device))
+    out.pop('xg')            # the per-step path with a table never writes it either
+    return out
+
+
+@pytest.mark.parametrize('B,min_len,max_len,train', [(100, 10, 79, False), (100, 10, 79, True), (8, 3, 19, False),
+                                                     (13, 1, 5, False), (128, 2, 79, False), (97, 79, 79, True),
+                                                     (1, 4, 4, False)])
+def test_persistent_encoder_is_bit_identical_to_per_step(B, min_len, max_len, train):
+    enc = encoder()
+    seq, mask, lens = batch(B + 1, B, min_len, max_len)
+    ref = run(enc, seq, lens, persistent=False, train=train)
+    got = run(enc, seq, lens, persistent=True, train=train)
+    torch.cuda.synchronize()
+    for k in ref:
+        assert not torch.isnan(ref[k]).any(), k
+        if B > 16:           # the per-step path runs lstm_step_wide_kernel: same summation order
+            assert torch.equal(got[k], ref[k]), (k, float((got[k] - ref[k]).abs().max()))
+        else:                # <= 16 rows: its 16 x 16-patch kernel splits K four ways, not sixteen
+            torch.testing.assert_close(got[k], ref[k], rtol=2e-6, atol=2e-6)
+
+
+def test_persistent_encoder_kernel_is_the_one_that_runs():
+    """The default path at the headline shape is the persistent launch (not a silent fallback)."""
+    from speaker_follower_amd import _lib
+    enc = encoder()
+    seq, mask, lens = batch(5, 100, 10, 79)
+    run(enc, seq, lens, persistent=True)
+    torch.cuda.synchronize()
+    with _lib.kernel_profile() as prof:
+        run(enc, seq, lens, persistent=True)
+    names = ' '.join(prof.rows)
+    assert 'enc_persist_kernel' in names and 'lstm_step' not in names, names
+    with _lib.kernel_profile() as prof:
+        run(enc, seq, lens, persistent=False)
+    assert 'enc_persist_kernel' not in ' '.join(prof.rows)
+
+
+def test_persistent_encoder_soak_and_two_streams():
+    """200 back-to-back launches and two streams racing for the device-wide lock give the same bits
+    every time (an exchange that trusted stale data or a torn reset would not)."""
+    enc = encoder(3)
+    seq, mask, lens = batch(9, 100, 10, 79)
+    ref = run(enc, seq, lens, persistent=False)
+    torch.cuda.synchronize()
+    for _ in range(100):
+        got = run(enc, seq, lens, persistent=True)
+    torch.cuda.synchronize()
+    assert torch.equal(got['ctx'], ref['ctx']) and torch.equal(got['c'], ref['c'])
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for i in range(50):
+        for s in (s1, s2):
+            with torch.cuda.stream(s):
+                outs.append(run(enc, seq, lens, persistent=True))
+    torch.cuda.synchronize()
+    for o in outs:
+        assert torch.equal(o['ctx'], ref['ctx']) and torch.equal(o['h'], ref['h'])
+
+
+def test_larger_batches_fall_back_to_the_per_step_path():
+    enc = encoder()
+    seq, mask, lens = batch(2, 160, 5, 40)
+    a = run(enc, seq, lens, persistent=True)
+    b = run(enc, seq, lens, persistent=False)
+    torch.cuda.synchronize()
+    assert torch.equal(a['ctx'], b['ctx'])
