@@ -521,6 +521,9 @@ def main(argv=None):
         from speaker_follower_amd import bench_extras
         out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2]
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
+        conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
+        if os.path.isdir(conn):
+            out['search_full'] = bench_extras.search_full(conn, device)
         # the full training iteration of configs[1] -- student-forcing rollout (dropout on), BPTT, two
         # Adam steps -- on the same batch (it updates the weights, so it runs last)
         if not args.no_train_extra:

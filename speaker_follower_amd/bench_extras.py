@@ -68,6 +68,53 @@ def speaker_decode(store, device, batch=100, words=80):
     return out
 
 
+@_guard
+def search_full(conn_dir, device, scans=('YmJkqBEsHnH', 'gZ6f7yhEvPG', 'GdvgFV5R1Z5'), instances=64, k=40,
+                episode_len=8):
+    """configs[4] end to end on real connectivity graphs: Seq2SeqAgent.state_factored_search(K = 40, 1)
+    over one minibatch of 64 instructions (follower.py:720-980), host bookkeeping and the navigation-only
+    simulator included.  The same search is pinned against the reference's own output in
+    tests/test_gpu_search.py (there the reference took 17.8 s on 4 CPU threads)."""
+    import os
+    from . import env, synth, model, features, agents
+    from .build import build_sim
+    build_sim(verbose=False)
+    graphs = {s: env.NavGraph(os.path.join(conn_dir, s + '_connectivity.json')) for s in scans}
+    items = env.random_items(graphs, instances, np.random.default_rng(15), min_len=4, max_len=20)
+    row_of, n = {}, 0
+    for s, g in graphs.items():
+        for v in g.ids:
+            row_of[s + '_' + v] = n
+            n += 1
+    table = synth.feature_table(11, n)
+    e = env.R2RIndexEnv(items, row_of, conn_dir, batch_size=instances, host_table=None)
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(303)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({kk: torch.tensor(v) for kk, v in enc_w.items()})
+    dec.load_state_dict({kk: torch.tensor(v) for kk, v in dec_w.items()})
+    enc.to(device).eval()
+    dec.to(device).eval()
+    agent = agents.Seq2SeqAgent(e, '/tmp/sf_bench_search.json', enc, dec, episode_len=episode_len)
+    agent.store = features.FeatureStore(table, device=device)
+    e.set_beam_size(k)
+    best, n_c, n_steps = None, 0, 0
+    for _ in range(3):
+        e.reset_epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            trajs, completed, traversed = agent.state_factored_search(k, 1)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+        n_c = sum(len(t) for t in trajs)
+    return dict(what='state_factored_search(K=%d, 1), %d instructions, %d-viewpoint fixture graphs, episode_len %d'
+                     % (k, instances, n, episode_len), value=instances / best, unit='instructions/s',
+                seconds=best, candidates=n_c)
+
+
 def _synthetic_states(rng, n, n_vp, a_max=14):
     """Index-form observations of `n` search states (env.R2RIndexEnv layout) with random candidates."""
     obs, udesc = [], []

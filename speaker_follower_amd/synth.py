@@ -83,6 +83,44 @@ def follower_weights(seed, dims=FULL):
     return enc, dec
 
 
+# Gains that turn the torch-default initialisation above (logit spread ~5e-3, near-uniform
+# attention) into a regime like a trained model's: visual attention max ~0.8, text attention max
+# ~0.8, action logits with O(1) spread.  Parity on these weights has teeth: an error in an
+# attention or scoring kernel moves logits by far more than the tolerance.
+PEAKY_GAINS = {
+    'enc': {'lstm.weight_ih_l0': 3.0, 'lstm.weight_hh_l0': 2.0},
+    'dec': {'visual_attention_layer.linear_in_h.weight': 4.0,
+            'visual_attention_layer.linear_in_v.weight': 4.0,
+            'text_attention_layer.linear_in.weight': 40.0,
+            'decoder2action.linear_in_h.weight': 6.0,
+            'decoder2action.linear_in_a.weight': 6.0,
+            'decoder2action.linear_out.weight': 8.0},
+}
+
+
+def follower_weights_peaky(seed, dims=FULL):
+    """`follower_weights(seed)` with PEAKY_GAINS applied (same keys, same shapes)."""
+    enc, dec = follower_weights(seed, dims)
+    for k, g in PEAKY_GAINS['enc'].items():
+        enc[k] = (enc[k] * np.float32(g)).astype(np.float32)
+    for k, g in PEAKY_GAINS['dec'].items():
+        dec[k] = (dec[k] * np.float32(g)).astype(np.float32)
+    return enc, dec
+
+
+def speaker_weights_peaky(seed, dims=FULL):
+    """`speaker_weights(seed)` with attention and output gains (path attention max ~0.7, word
+    distribution with a clear mode)."""
+    enc, dec = speaker_weights(seed, dims)
+    for k, g in (('visual_attention_layer.linear_in_h.weight', 8.0),
+                 ('visual_attention_layer.linear_in_v.weight', 8.0)):
+        enc[k] = (enc[k] * np.float32(g)).astype(np.float32)
+    for k, g in (('attention_layer.linear_in.weight', 25.0), ('decoder2action.weight', 60.0),
+                 ('lstm.weight_ih', 3.0), ('lstm.weight_hh', 2.0)):
+        dec[k] = (dec[k] * np.float32(g)).astype(np.float32)
+    return enc, dec
+
+
 def speaker_weights(seed, dims=FULL):
     """(encoder_state, decoder_state) keyed like SpeakerEncoderLSTM / SpeakerDecoderLSTM
     (model.py:415-419 and :467-485)."""

@@ -108,9 +108,40 @@ def main():
                 for ol in outs]
 
     path = os.path.join(HERE, 'g7_search.json')
-    with open(path, 'w') as f:
-        json.dump(out, f)
-    print('wrote', path, os.path.getsize(path), 'bytes')
+    if '--big-only' not in sys.argv:
+        with open(path, 'w') as f:
+            json.dump(out, f)
+        print('wrote', path, os.path.getsize(path), 'bytes')
+
+    # ---- BASELINE configs[4] at its size: state-factored search, K = 40, batch 64, "peaky" weights
+    # (with the default initialisation every hypothesis scores within 1e-3 of the next one and the
+    # ORDER of completions is decided by roundoff)
+    import time
+    env, table = W.build_world(dense=True, n_items=W.BIG_ITEMS, batch=W.BIG_BATCH, item_seed=W.BIG_ITEM_SEED)
+    env.image_features_list = [_Featurizer()]
+    enc_w, dec_w = synth.follower_weights_peaky(W.BIG_FOLLOWER_SEED)
+    enc = load(ref_model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight']), enc_w)
+    dec = load(ref_model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat), dec_w)
+    agent = ref_follower.Seq2SeqAgent(env, '', enc, dec, episode_len=W.BIG_EPISODE_LEN)
+    env.set_beam_size(W.BIG_K)
+    env.reset_epoch()
+    t0 = time.time()
+    with torch.no_grad():
+        trajs, completed, traversed = agent.state_factored_search(W.BIG_K, 1)
+    dt = time.time() - t0
+    big = dict(config=dict(scans=W.SCANS, n_items=W.BIG_ITEMS, batch=W.BIG_BATCH, K=W.BIG_K,
+                           episode_len=W.BIG_EPISODE_LEN, follower_seed=W.BIG_FOLLOWER_SEED,
+                           reference_cpu_seconds=dt, reference_threads=torch.get_num_threads()),
+               results=[dict(cands=[cand_summary(c) for c in tl],
+                             traversed=[s.world_state.viewpointId for s in tr])
+                        for tl, tr in zip(trajs, traversed)])
+    import gzip
+    path = os.path.join(HERE, 'g7_search_b64_k40.json.gz')
+    with gzip.open(path, 'wt') as f:
+        json.dump(big, f)
+    n_c = [len(r['cands']) for r in big['results']]
+    print('wrote', path, os.path.getsize(path), 'bytes; %.1f s; candidates per instance min %d mean %.1f max %d'
+          % (dt, min(n_c), np.mean(n_c), max(n_c)))
 
 
 if __name__ == '__main__':

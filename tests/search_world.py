@@ -26,18 +26,23 @@ class ListTokenizer:
         return ' '.join(out) if join else out
 
 
-def build_world(dense=True):
+# BASELINE.json configs[4]: state-factored search, K = 40 completions, batch 64 (rational_follower.py:42-47)
+BIG_ITEMS = BIG_BATCH = 64
+BIG_K, BIG_EPISODE_LEN, BIG_ITEM_SEED, BIG_FOLLOWER_SEED = 40, 8, 15, 303
+
+
+def build_world(dense=True, n_items=N_ITEMS, batch=BATCH, item_seed=ITEM_SEED):
     from speaker_follower_amd.build import build_sim
     build_sim()
     from speaker_follower_amd import env, synth
     graphs = {s: env.NavGraph(os.path.join(CONN, s + '_connectivity.json')) for s in SCANS}
-    items = env.random_items(graphs, N_ITEMS, np.random.default_rng(ITEM_SEED), min_len=4, max_len=20)
+    items = env.random_items(graphs, n_items, np.random.default_rng(item_seed), min_len=4, max_len=20)
     row_of, n = {}, 0
     for s, g in graphs.items():
         for v in g.ids:
             row_of[s + '_' + v] = n
             n += 1
     table = synth.feature_table(TABLE_SEED, n)
-    e = env.R2RIndexEnv(items, row_of, CONN, batch_size=BATCH, host_table=table if dense else None)
+    e = env.R2RIndexEnv(items, row_of, CONN, batch_size=batch, host_table=table if dense else None)
     e.tokenizer = ListTokenizer()
     return e, table

@@ -96,7 +96,10 @@ def _check_rollout(st, g, steps):
     A = min(ref.shape[2], logits.shape[2])
     fin = np.isfinite(ref[:, :, :A])
     assert np.array_equal(np.isfinite(logits[:n, :, :A]), fin)
-    np.testing.assert_allclose(logits[:n, :, :A][fin], ref[:, :, :A][fin], **TOL)
+    # 1e-4 of the LOGIT SCALE (these default-initialised weights give |logit| <= 0.045, so a fixed
+    # 1e-4 would be 2 % of their spread; tests/test_gpu_hard_parity.py pins O(1) logits)
+    scale = float(np.abs(ref[:, :, :A][fin]).max())
+    assert float(np.abs(logits[:n, :, :A][fin] - ref[:, :, :A][fin]).max()) <= 1e-4 * scale
     np.testing.assert_allclose(float(st.loss), g['loss'], rtol=1e-4)
     np.testing.assert_allclose(st.step_scores.cpu().numpy()[:n].sum(0), g['scores'], **TOL)
     if n == steps:

@@ -101,6 +101,47 @@ def test_state_factored_search_matches_reference(world, golden, sizes):
         assert len(set(keys)) == len(keys), ends
 
 
+def test_state_factored_search_batch64_k40_matches_reference():
+    """BASELINE.json configs[4] at its size (rational_follower.py:42-47: state_factored_search(K = 40, 1)
+    over a minibatch of 64) on the fixture graphs with "peaky" weights: the same completions in the
+    same order, the same physical traversal, scores within 3e-4."""
+    import gzip
+    import time
+    from speaker_follower_amd import model, features, agents, synth
+    with gzip.open(os.path.join(HERE, 'golden', 'g7_search_b64_k40.json.gz'), 'rt') as f:
+        gold = json.load(f)
+    cfg = gold['config']
+    assert cfg['batch'] == 64 and cfg['K'] == 40
+    env, table = W.build_world(dense=True, n_items=W.BIG_ITEMS, batch=W.BIG_BATCH, item_seed=W.BIG_ITEM_SEED)
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(W.BIG_FOLLOWER_SEED)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    agent = agents.Seq2SeqAgent(env, '/tmp/sf_search_big.json', enc, dec, episode_len=W.BIG_EPISODE_LEN)
+    agent.store = features.FeatureStore(table)
+    env.set_beam_size(W.BIG_K)
+    env.reset_epoch()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    trajs, completed, traversed = agent.state_factored_search(W.BIG_K, 1)
+    torch.cuda.synchronize()
+    dt = time.time() - t0
+    want = gold['results']
+    assert len(trajs) == len(want) == 64
+    n_cands = 0
+    for g, tr, w in zip(trajs, traversed, want):
+        check_candidates(g, w['cands'])
+        assert [s.world_state.viewpointId for s in tr] == w['traversed']
+        n_cands += len(g)
+    assert n_cands == sum(len(w['cands']) for w in want) and n_cands > 64 * 20
+    print('state-factored search, batch 64, K = 40: %.2f s here; the reference took %.1f s on %d CPU threads'
+          % (dt, cfg['reference_cpu_seconds'], cfg['reference_threads']))
+
+
 def test_beam_one_equals_greedy_rollout(world):
     """follower.py:150-156 (the reference's own commented sanity check): beam_search(1) reproduces
     the argmax rollout's trajectory and score."""

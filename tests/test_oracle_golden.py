@@ -263,3 +263,92 @@ def test_speaker_teacher_gradients(golden, speaker_setup):
     res['loss'].backward()
     _check_grads({k: v.grad for k, v in enc.items() if v.grad is not None}, g, 'enc/')
     _check_grads({k: v.grad for k, v in dec.items() if v.grad is not None}, g, 'dec/')
+
+
+# ----------------------------------------------------------------------------- G8 / G9 (round 2)
+# The hard cases of tests/golden/make_golden_hard.py: "peaky" weights (O(1) logits), all 20 steps
+# of the headline batch, train mode with explicit dropout masks, speaker at B = 100.
+def _scaled_close(got, want, scale_tol=1e-4):
+    fin = np.isfinite(want)
+    assert np.array_equal(np.isfinite(got), fin)
+    scale = float(np.abs(want[fin]).max())
+    assert float(np.abs(got[fin] - want[fin]).max()) <= scale_tol * scale, scale
+
+
+def test_peaky_rollout_b100_all_twenty_steps(golden):
+    g = golden('g8_follower_peaky_b100_argmax')
+    enc_w, dec_w = synth.follower_weights_peaky(int(g['weight_seed']))
+    fb = synth.follower_batch(seed=int(g['batch_seed']), batch=100, steps=20, n_viewpoints=256)
+    table = synth.feature_table(int(g['table_seed']), 256)
+    res = _np_rollout(enc_w, dec_w, fb, table, np_env.static_loc_embeddings(), 20, 'argmax')
+    assert int(g['n_steps']) == 20 and len(res['logits']) == 20
+    np.testing.assert_array_equal(res['actions'], g['actions'])
+    for t in range(20):
+        a = res['logits'][t].shape[1]
+        _scaled_close(res['logits'][t], g['logits'][t][:, :a])
+    np.testing.assert_allclose(res['loss'], g['loss'], rtol=1e-4)
+    np.testing.assert_allclose(res['h'], g['h'], rtol=1e-4, atol=1e-4)
+
+
+def test_peaky_train_mode_b100_loss_and_gradients(golden):
+    """torch_ref with the SAME counter-based dropout masks (oracle/rng.py) against the reference
+    modules run with those masks in place of nn.Dropout."""
+    from oracle import rng as orng
+    g = golden('g8_follower_peaky_b100_train')
+    enc_w, dec_w = synth.follower_weights_peaky(int(g['weight_seed']))
+    fb = synth.follower_batch(seed=int(g['batch_seed']), batch=100, steps=20, n_viewpoints=256,
+                              stop_prob=1.0 / 40.0)
+    table = synth.feature_table(int(g['table_seed']), 256)
+    loc = np_env.static_loc_embeddings()
+    seq, mask, lens = np_env.batch_instructions_from_encoded(fb.instr, 80, reverse=True)
+    B, T, H, F = 100, max(lens), 512, 2176
+    seed, site0, rows = int(g['dropout_seed']), int(g['site0']), np.arange(100)
+
+    def masks(t):
+        if t == 'ctx':
+            return torch.tensor(orng.dropout_mask(seed ^ 0x5BD1E995, site0, rows, T * H, 0.5).reshape(B, T, H))
+        return (torch.tensor(orng.dropout_mask(seed, 2 * (site0 + t), rows, 2 * F, 0.5)),
+                torch.tensor(orng.dropout_mask(seed, 2 * (site0 + t) + 1, rows, H, 0.5)))
+
+    enc = torch_ref.to_torch(enc_w, True, frozen=('embedding.weight',))
+    dec = torch_ref.to_torch(dec_w, True)
+    res = torch_ref.follower_rollout(enc, dec, torch.tensor(seq), lens, torch.tensor(mask), 20,
+                                     lambda t: np_env.dense_follower_step(table, loc, fb, t),
+                                     torch.tensor(fb.target), 'teacher', F, drop_masks=masks)
+    np.testing.assert_allclose(res['loss'].item(), g['loss'], rtol=1e-5)
+    res['loss'].backward()
+    gmax = max(float(v) for k, v in g.items() if 'gnorm/' in k)
+    for prefix, named in (('enc/', enc), ('dec/', dec)):
+        seen = 0
+        for name, p in named.items():
+            key = prefix + 'gnorm/' + name
+            if p.grad is None or key not in g:
+                continue
+            seen += 1
+            flat = p.grad.numpy().ravel()
+            norm = np.sqrt(np.sum(flat.astype(np.float64) ** 2))
+            if g[key] < 1e-6 * gmax:
+                assert norm < 1e-5 * gmax, name
+                continue
+            np.testing.assert_allclose(norm, g[key], rtol=2e-3, err_msg=name)
+            np.testing.assert_allclose(flat[g[prefix + 'gidx/' + name]], g[prefix + 'gval/' + name], rtol=2e-3,
+                                       atol=2e-3 * g[key] / np.sqrt(flat.size) + 1e-7, err_msg=name)
+        assert seen > 0
+
+
+@pytest.mark.parametrize('feedback', ['teacher', 'argmax'])
+def test_speaker_b100(golden, feedback):
+    g = golden('g9_speaker_b100_' + feedback)
+    senc_w, sdec_w = synth.speaker_weights_peaky(int(g['weight_seed']))
+    sb = synth.speaker_batch(seed=int(g['batch_seed']), batch=100, n_viewpoints=256, min_len=10, max_len=79)
+    table = synth.feature_table(int(g['table_seed']), 256)
+    acts, feats, path_mask = np_env.dense_speaker_inputs(sb, table, np_env.static_loc_embeddings())
+    instr_seq, _, _ = np_env.batch_instructions_from_encoded(sb.instr, 80)
+    n = int(g['n_steps'])
+    res = np_model.speaker_score(senc_w, sdec_w, acts, feats, path_mask, instr_seq, n, feedback)
+    assert len(res['logits']) == n
+    np.testing.assert_array_equal(res['words'], g['words'])
+    _scaled_close(res['logits'][0], g['logits_first'][0])
+    _scaled_close(res['logits'][-1], g['logit_last'])
+    np.testing.assert_allclose(res['loss'], g['loss'], rtol=1e-4)
+    np.testing.assert_allclose(res['scores'], g['scores'], rtol=1e-4, atol=2e-3)
