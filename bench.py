@@ -524,6 +524,7 @@ def main(argv=None):
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):
             out['search_full'] = bench_extras.search_full(conn, device)
+            out['real_env_rollout'] = bench_extras.real_env_rollout(conn, device)     # configs[1], inference
         # the full training iteration of configs[1] -- student-forcing rollout (dropout on), BPTT, two
         # Adam steps -- on the same batch (it updates the weights, so it runs last)
         if not args.no_train_extra:

@@ -519,6 +519,33 @@ int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double 
  * uint64, NULL switches it off.  Used by tools/vis_trace.py to read a kernel's inner timeline. */
 void sf_debug_trace(unsigned long long* buf);
 
+/* ---- device-resident navigation (env.py:126-146 step, :149-224 panorama sweep, :742-761 teacher,
+ * :763-804 observe) ---------------------------------------------------------------------------------
+ * The candidate list of a state is a pure function of (viewpoint, view index): the host tabulates it
+ * once per connectivity graph (speaker_follower_amd/nav.py) over its own contiguous "nav rows" (one
+ * per viewpoint, scans back to back).  State s = nav_row * V + view; candidate a of state s leads to
+ * nav row next_row[s,a] facing view cand_view[s,a] (a = 0: stop, next_row = the state's own row). */
+typedef struct sf_nav_table {
+    const int32_t* a_num;       /* [n_rows*V]      1 + number of neighbours */
+    const int32_t* next_row;    /* [n_rows*V, A] */
+    const int32_t* cand_view;   /* [n_rows*V, A]   absViewIndex of the candidate = the view after the move */
+    const float* cand_sincos;   /* [n_rows*V, A,4] sin/cos of rel_heading, rel_elevation */
+    const int32_t* feat_row;    /* [n_rows]        feature-table row of a nav row */
+    int32_t A, V;
+} sf_nav_table;
+/* One env.step + env.observe (+ teacher) for a batch: from state (row[b], view[b]) and the chosen
+ * candidate a_t[b] (NULL = no move: the initial observation) to the next state, written as the NEXT
+ * decode step's index-form observation (what sf_pano / sf_cands / sf_follower_glue read): row_next,
+ * vp_next (feature rows), view_next, a_num_next [B], cand_view_next [B,A], sincos_next [B,A,4] and,
+ * when target_next != NULL, the shortest-path teacher action (-1 for rows with ended[b] != 0): the
+ * candidate whose next_row equals goal_hop[b, row - hop_base[b]] (the next nav row on the shortest
+ * path to the sample's goal, tabulated per sample over its scan's rows), 0 at the goal. */
+int sf_nav_step(const sf_nav_table* nav, int B, const int32_t* row, const int32_t* view,
+                const int64_t* a_t, const uint8_t* ended, const int32_t* goal_hop, int ld_hop,
+                const int32_t* hop_base, int32_t* row_next, int32_t* vp_next, int32_t* view_next,
+                int32_t* a_num_next, int32_t* cand_view_next, float* sincos_next,
+                int64_t* target_next, sf_stream stream);
+
 /* In-process kernel timing (no reference counterpart; what bench.py's `roofline.kernels` table is
  * measured with).  Between sf_profile_begin() and sf_profile_end() every kernel the CALLING host
  * thread launches through this library carries a start and a stop event on its own dispatch, so a

@@ -101,6 +101,11 @@ class SpkDecoderG(C.Structure):
     _fields_ = [('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p), ('b_out', c_p)]
 
 
+class NavTableS(C.Structure):
+    _fields_ = [('a_num', c_p), ('next_row', c_p), ('cand_view', c_p), ('cand_sincos', c_p),
+                ('feat_row', c_p), ('A', C.c_int32), ('V', C.c_int32)]
+
+
 SpkDecoderTape = _ptr_struct('SpkDecoderTape', ['emb', 'gates', 'c1', 'h1', 'cat2', 't_text',
                                                 'alpha', 'h_tilde', 'logit'])
 
@@ -179,6 +184,7 @@ _SIGNATURES = {
     'sf_dropout_copy': (C.c_int, [c_f, i32, i32, i32, c_f, i32, P(Dropout), u32, i32, c_p]),
     'sf_embedding_fwd': (C.c_int, [c_f, i32, i64p, i32, c_f, c_p]),
     'sf_transpose': (C.c_int, [c_f, i32, i32, c_f, c_p]),
+    'sf_nav_step': (C.c_int, [P(NavTableS), i32] + [c_p] * 5 + [i32] + [c_p] * 8 + [c_p]),
     'sf_profile_begin': (C.c_int, []),
     'sf_profile_end': (C.c_long, [C.c_char_p, C.c_size_t]),
 }

@@ -115,6 +115,34 @@ class Seq2SeqAgent(BaseAgent):
         self._sample_seed = torch.initial_seed() & 0xFFFFFFFF
         self._sample_count = 0
         self.store = None          # features.FeatureStore: enables the index-form search procedures
+        self.nav_table = None      # nav.NavTable: rollouts step the environment ON THE DEVICE
+        self._engine = None
+
+    def use_device_env(self, nav_table):
+        """Opt in to device-resident navigation (nav.py): `_rollout_with_loss` -- and with it `train`,
+        `test` and `rollout` -- then runs the whole episode with one host sync instead of a D2H copy
+        plus Python env.step / observe per step.  Needs `self.store`; the env must be the
+        R2RIndexEnv the table was built from.  The result dictionaries carry instr_id / trajectory /
+        actions / scores (no per-step 'observations': nothing observes on the host any more)."""
+        from .follower import FollowerEngine
+        if self.store is None:
+            raise RuntimeError('use_device_env needs a features.FeatureStore (agent.store)')
+        self.nav_table = nav_table
+        self._engine = FollowerEngine(self.encoder, self.decoder, self.store)
+        self._engine.dropout_seed = self._sample_seed ^ 0x1B873593
+
+    def _rollout_on_device(self):
+        from .nav import DeviceNavBatch
+        self.env.reset(sort=True)
+        batch = DeviceNavBatch(self.nav_table, list(self.env.batch), self.episode_len,
+                               max_length=self.max_instruction_length, reverse=self.reverse_instruction)
+        st = self._engine.rollout(batch, self.episode_len, self.feedback, train=self.decoder.training)
+        self.loss = st.loss
+        traj = batch.trajectories(st)                   # the one host sync of the rollout
+        for tr, it in zip(traj, self.env.batch):
+            tr['instr_encoding'] = it['instr_encoding']
+        self.losses.append(float(st.loss.detach()))
+        return traj
 
     # ---- tensor assembly (follower.py:291-332): numpy stacks -> device tensors
     def _device(self):
@@ -186,6 +214,8 @@ class Seq2SeqAgent(BaseAgent):
 
     def _rollout_with_loss(self):
         """follower.py:430-539."""
+        if self.nav_table is not None:
+            return self._rollout_on_device()
         world_states = self.env.reset(sort=True)
         obs = np.array(self.env.observe(world_states))
         B = len(obs)

@@ -115,6 +115,65 @@ def search_full(conn_dir, device, scans=('YmJkqBEsHnH', 'gZ6f7yhEvPG', 'GdvgFV5R
                 seconds=best, candidates=n_c)
 
 
+@_guard
+def real_env_rollout(conn_dir, device, batch=100, steps=20, scans=('YmJkqBEsHnH', 'gZ6f7yhEvPG', 'GdvgFV5R1Z5')):
+    """configs[1] inference half on REAL connectivity graphs: a student-forced (argmax) follower rollout
+    whose every next observation depends on the action just chosen -- env.step / observe / teacher run
+    on the device (nav.py, sf_nav_step), so head(t+1) cannot be pipelined beside tail(t) -- next to the
+    SAME rollout driven the reference's way (agents._rollout_with_loss: D2H of the actions and Python
+    env.step / observe every step, follower.py:507-514)."""
+    import os
+    from . import env, synth, model, features, agents, nav, follower
+    from .build import build_sim
+    build_sim(verbose=False)
+    graphs = {s: env.NavGraph(os.path.join(conn_dir, s + '_connectivity.json')) for s in scans}
+    items = env.random_items(graphs, batch, np.random.default_rng(21), min_len=10, max_len=79)
+    row_of, n = {}, 0
+    for s, g in graphs.items():
+        for v in g.ids:
+            row_of[s + '_' + v] = n
+            n += 1
+    table = synth.feature_table(11, n)
+    e = env.R2RIndexEnv(items, row_of, conn_dir, batch_size=batch, host_table=table)
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(303)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({kk: torch.tensor(v) for kk, v in enc_w.items()})
+    dec.load_state_dict({kk: torch.tensor(v) for kk, v in dec_w.items()})
+    enc.to(device).eval()
+    dec.to(device).eval()
+    store = features.FeatureStore(table, device=device)
+    nt = nav.NavTable(e, store)
+    e.reset_epoch()
+    e._next_minibatch(True)
+    navb = nav.DeviceNavBatch(nt, list(e.batch), steps)
+    eng = follower.FollowerEngine(enc, dec, store)
+    replay, gst = eng.capture(navb, steps, 'argmax')
+    dt = _timed(replay, 3, 10)
+    out = dict(what='student-forced argmax rollout on real connectivity graphs (%d viewpoints), batch %d, %d decode '
+                    'steps, encoder included; every step executed for every row' % (n, batch, steps),
+               unit='agent-steps/s', device_env=dict(value=batch * steps / dt, ms_per_rollout=1e3 * dt,
+                                                     launch='hipGraph replay, one host sync per rollout'))
+    agent = agents.Seq2SeqAgent(e, '/tmp/sf_bench_nav.json', enc, dec, episode_len=steps)
+    agent.feedback = 'argmax'
+
+    def host():
+        e.reset_epoch()
+        with torch.no_grad():
+            agent._rollout_with_loss()
+    host()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host()
+    torch.cuda.synchronize()
+    dth = time.perf_counter() - t0
+    out['host_env_per_step'] = dict(ms_per_rollout=1e3 * dth,
+                                    note='reference-style loop: dense observations, D2H + Python env every step; '
+                                         'exits early once every row has stopped')
+    return out
+
+
 def _synthetic_states(rng, n, n_vp, a_max=14):
     """Index-form observations of `n` search states (env.R2RIndexEnv layout) with random candidates."""
     obs, udesc = [], []

@@ -206,7 +206,13 @@ class FollowerEngine:
         ws = ws_args(dev)
         d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
-        pipelined = self.pipelined
+        # A nav.DeviceNavBatch produces its observations ON THE DEVICE, one step ahead of the decoder,
+        # from the action the glue kernel has just chosen (real student forcing: the next panorama
+        # depends on a_t).  head(t+1) therefore cannot ride beside tail(t): plain step order.
+        on_device_env = hasattr(batch, 'advance')
+        if on_device_env:
+            batch.advance(-1)                           # slot 0 = the initial observation
+        pipelined = self.pipelined and not on_device_env
         st.episode = None
         if pipelined and self.episode_call and fold is None:
             # every per-step tensor is a stacked [S][...] array: hand step 0 to the library once
@@ -254,6 +260,8 @@ class FollowerEngine:
                 call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T, None,
                      ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue),
                      d_ptr, st.site0 + t, *ws)
+            if on_device_env:                           # env.step + observe + teacher for step t + 1
+                batch.advance(t, st.actions[t], st.ended)
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         st.logits = st.tape['logit']
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]

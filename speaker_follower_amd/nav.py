@@ -1,0 +1,187 @@
+"""Device-resident navigation (BASELINE configs[1]: student-forced rollouts on real
+R2R items without a host round trip per step).
+
+The reference walks the simulator from Python every step (`R2RBatch.step` / `observe`,
+tasks/R2R/env.py:628-641, 763-804; the 36-view sweep :149-224; the teacher :742-761) and syncs the
+chosen actions to the host to do so (follower.py:507-514).  Everything that walk computes is a pure
+function of the state (scan, viewpoint, view index):
+
+  * `NavTable`        -- built ONCE per set of connectivity graphs with this repo's navigation-only
+                         simulator: per state the candidate list (next viewpoint, absViewIndex, relative
+                         angles) exactly as `env.panorama_sweep` orders it, over contiguous "nav rows";
+  * `DeviceNavBatch`  -- one R2R minibatch: instructions, start states, and per sample the next hop of
+                         the shortest path to ITS goal from every viewpoint of its scan (the teacher);
+  * `sf_nav_step`     -- the per-step kernel (csrc/sf_nav.hip): state + a_t -> next state, written as
+                         the next decode step's index-form observation.
+
+`FollowerEngine.rollout(DeviceNavBatch, ...)` then runs encoder + S decode steps with ONE host sync at
+the end; `trajectories()` turns the recorded states into the reference's result format.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import call
+from .env import ANGLE_INC, WorldState
+from .features import cand_sincos
+from .follower import batch_instructions_from_encoded
+from .runtime import ptr, stream
+
+V = 36
+
+
+class NavTable:
+    """Candidate lists of every (viewpoint, view) state of the env's graphs, on the device."""
+
+    def __init__(self, env, store, a_max=None):
+        self.scans = sorted(env.graphs)
+        self.row_of = {}                 # (scan, viewpoint) -> nav row
+        self.vp_of = []                  # nav row -> (scan, viewpoint)
+        self.base = {}                   # scan -> first nav row
+        for s in self.scans:
+            self.base[s] = len(self.vp_of)
+            for v in env.graphs[s].nodes():
+                self.row_of[(s, v)] = len(self.vp_of)
+                self.vp_of.append((s, v))
+        n = len(self.vp_of)
+        sweeps = {}
+        A = 1
+        for r, (s, v) in enumerate(self.vp_of):
+            for view in range(V):
+                ws = WorldState(s, v, (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC)
+                got_view, adj = env.panorama(ws)
+                assert got_view == view
+                sweeps[(r, view)] = adj
+                A = max(A, len(adj))
+        self.A = A = max(A, a_max or 0)
+        a_num = np.zeros(n * V, np.int32)
+        next_row = np.zeros((n * V, A), np.int32)
+        cand_view = np.zeros((n * V, A), np.int32)
+        head = np.zeros((n * V, A), np.float64)
+        elev = np.zeros((n * V, A), np.float64)
+        for (r, view), adj in sweeps.items():
+            s = r * V + view
+            a_num[s] = len(adj)
+            next_row[s, 0] = r
+            for a, d in enumerate(adj[1:], 1):
+                next_row[s, a] = self.row_of[(self.vp_of[r][0], d['nextViewpointId'])]
+                cand_view[s, a] = d['absViewIndex']
+                head[s, a], elev[s, a] = d['rel_heading'], d['rel_elevation']
+        feat_row = np.array([env.row_of[s + '_' + v] for s, v in self.vp_of], np.int32)
+        dev = store.device
+        up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)   # noqa: E731
+        self.a_num, self.next_row, self.cand_view = up(a_num, torch.int32), up(next_row, torch.int32), up(cand_view, torch.int32)
+        self.sincos = up(cand_sincos(head, elev), torch.float32)          # the same host sin/cos the env batches use
+        self.feat_row = up(feat_row, torch.int32)
+        self.n_rows, self.device, self.env = n, dev, env
+        self.scan_rows = {s: len(env.graphs[s].nodes()) for s in self.scans}
+        self._hops = {}
+
+    def struct(self):
+        return _lib.NavTableS(self.a_num.data_ptr(), self.next_row.data_ptr(), self.cand_view.data_ptr(),
+                              self.sincos.data_ptr(), self.feat_row.data_ptr(), self.A, V)
+
+    def hops(self, scan, goal):
+        """[rows of `scan`] int32: next nav row on the shortest path to `goal` (itself at the goal),
+        the table behind env.py:742-761."""
+        key = (scan, goal)
+        if key not in self._hops:
+            g = self.env.graphs[scan]
+            out = np.zeros(self.scan_rows[scan], np.int32)
+            for i, v in enumerate(g.nodes()):
+                r = self.base[scan] + i
+                out[i] = r if v == goal else self.row_of[(scan, g.path(v, goal)[1])]
+            self._hops[key] = out
+        return self._hops[key]
+
+
+class DeviceNavBatch:
+    """The current minibatch of an R2RIndexEnv as device state for `FollowerEngine.rollout`:
+    `vp/view/a_num/cand_view/sincos/target` are [S+1, B, ...] buffers that `advance` fills one step
+    ahead of the decoder (slot 0 = the initial observation)."""
+
+    def __init__(self, nav, items, steps, max_length=80, reverse=True, row0=0):
+        env, dev = nav.env, nav.device
+        self.nav, self.items, self.steps = nav, items, steps
+        B, A, S = len(items), nav.A, steps
+        self.seq, mask, self.lengths = batch_instructions_from_encoded(
+            [it['instr_encoding'] for it in items], max_length, reverse=reverse, device=dev)
+        self.mask = mask.to(torch.uint8).contiguous()
+        self.lengths_dev = torch.tensor(self.lengths, dtype=torch.int32, device=dev)
+        self.a_max, self.row0 = A, row0
+        z = lambda *s, dt=torch.int32: torch.zeros(*s, dtype=dt, device=dev)             # noqa: E731
+        self.row = z(S + 1, B)
+        self.vp, self.view, self.a_num = z(S + 1, B), z(S + 1, B), z(S + 1, B)
+        self.cand_view = z(S + 1, B, A)
+        self.sincos = z(S + 1, B, A, 4, dt=torch.float32)
+        self.target = z(S + 1, B, dt=torch.int64)
+        # start states: newEpisode snaps the item's heading to the discrete view (env.py:814-819)
+        rows, views = [], []
+        ld = max(nav.scan_rows[it['scan']] for it in items)
+        hop = np.zeros((B, ld), np.int32)
+        base = np.zeros(B, np.int32)
+        for b, it in enumerate(items):
+            view, _ = env.panorama(WorldState(it['scan'], it['path'][0], it['heading'], 0))
+            rows.append(nav.row_of[(it['scan'], it['path'][0])])
+            views.append(view)
+            h = nav.hops(it['scan'], it['path'][-1])
+            hop[b, :len(h)] = h
+            base[b] = nav.base[it['scan']]
+        self.row0_state = torch.tensor(rows, dtype=torch.int32, device=dev)
+        self.view0_state = torch.tensor(views, dtype=torch.int32, device=dev)
+        self.goal_hop = torch.from_numpy(hop).to(dev)
+        self.hop_base = torch.from_numpy(base).to(dev)
+        self.ld_hop = ld
+        self._nav_struct = nav.struct()
+
+    @property
+    def batch_size(self):
+        return self.seq.shape[0]
+
+    def advance(self, t, a_t=None, ended=None):
+        """Fills slot t + 1 from slot t and the actions of step t (t = -1: the initial observation)."""
+        src_row = self.row0_state if t < 0 else self.row[t]
+        src_view = self.view0_state if t < 0 else self.view[t]
+        n = t + 1
+        call('sf_nav_step', C.byref(self._nav_struct), self.batch_size, ptr(src_row), ptr(src_view),
+             ptr(a_t) if a_t is not None else None, ptr(ended) if ended is not None else None,
+             ptr(self.goal_hop), self.ld_hop, ptr(self.hop_base), ptr(self.row[n]), ptr(self.vp[n]),
+             ptr(self.view[n]), ptr(self.a_num[n]), ptr(self.cand_view[n]), ptr(self.sincos[n]),
+             ptr(self.target[n]), stream())
+
+    def trajectories(self, st):
+        """The rollout's result dictionaries (follower.py:446-456, 517-524): per sample instr_id,
+        trajectory [(viewpointId, heading, elevation)], actions, scores -- the stop action and the
+        duplicated final state included, nothing after it.  One D2H copy."""
+        S = st.steps
+        rows = self.row[:S + 1].cpu().numpy()
+        views = self.view[:S + 1].cpu().numpy()
+        acts = st.actions.cpu().numpy()
+        sc = st.step_scores.cpu().numpy()
+        out = []
+        for b, it in enumerate(self.items):
+            def elem(t, first=False):
+                vp = self.nav.vp_of[rows[t, b]][1]
+                if first:
+                    return (vp, it['heading'], 0)
+                v = int(views[t, b])
+                moved = any(int(rows[k, b]) != int(rows[0, b]) or int(views[k, b]) != int(views[0, b])
+                            for k in range(1, t + 1))
+                if not moved:                      # still in the start pose: its heading is the item's
+                    return (vp, it['heading'], 0)
+                return (vp, (v % 12) * ANGLE_INC, (v // 12 - 1) * ANGLE_INC)
+            tr = dict(instr_id=it['instr_id'], trajectory=[elem(0, True)], actions=[], scores=[], score=0.0)
+            total = np.float32(0)
+            for t in range(S):
+                tr['trajectory'].append(elem(t + 1))
+                tr['actions'].append(int(acts[t, b]))
+                tr['scores'].append(float(sc[t, b]))
+                total = np.float32(total + sc[t, b])
+                tr['score'] = float(total)
+                if acts[t, b] == 0:
+                    break
+            out.append(tr)
+        return out

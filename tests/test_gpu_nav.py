@@ -1,0 +1,174 @@
+"""GPU: device-resident navigation (speaker_follower_amd/nav.py, csrc/sf_nav.hip) -- a student-forced
+rollout on REAL connectivity graphs with one host sync -- against `agents._rollout_with_loss`, which
+mirrors the reference loop (follower.py:430-539: decoder step, D2H of the actions, env.step,
+env.observe in Python every step): identical trajectories, actions, teacher targets and loss for
+argmax, teacher and sample feedback; replayable as a hipGraph."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import search_world as W          # noqa: E402
+
+EPISODE = 7
+
+
+@pytest.fixture(scope='module')
+def world():
+    from speaker_follower_amd import model, features, agents, synth, nav, follower
+    env, table = W.build_world(dense=True, n_items=24, batch=12, item_seed=77)
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(303)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    agent = agents.Seq2SeqAgent(env, '/tmp/sf_nav.json', enc, dec, episode_len=EPISODE)
+    store = features.FeatureStore(table)
+    agent.store = store
+    table_nav = nav.NavTable(env, store)
+    return env, agent, store, table_nav, enc, dec
+
+
+def test_nav_table_reproduces_the_panorama_sweep(world):
+    """Every (viewpoint, view) state: the tabulated candidates equal env.panorama (env.py:149-224)."""
+    from speaker_follower_amd.env import WorldState, ANGLE_INC
+    env, agent, store, nt, enc, dec = world
+    a_num = nt.a_num.cpu().numpy()
+    nxt, cv = nt.next_row.cpu().numpy(), nt.cand_view.cpu().numpy()
+    sc = nt.sincos.cpu().numpy()
+    assert nt.n_rows == sum(len(g.nodes()) for g in env.graphs.values())
+    for r, (scan, vp) in enumerate(nt.vp_of):
+        for view in (0, 13, 35):
+            _, adj = env.panorama(WorldState(scan, vp, (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC))
+            s = r * 36 + view
+            assert a_num[s] == len(adj) and nxt[s, 0] == r
+            for a, d in enumerate(adj[1:], 1):
+                assert nt.vp_of[nxt[s, a]] == (scan, d['nextViewpointId']) and cv[s, a] == d['absViewIndex']
+                np.testing.assert_allclose(sc[s, a], [np.sin(d['rel_heading']), np.cos(d['rel_heading']),
+                                                      np.sin(d['rel_elevation']), np.cos(d['rel_elevation'])],
+                                           rtol=1e-6, atol=1e-6)
+
+
+def _host_rollout(env, agent, feedback):
+    env.reset_epoch()
+    agent.feedback = feedback
+    agent._sample_count = 0
+    with torch.no_grad():
+        traj = agent._rollout_with_loss()
+    return traj, float(agent.loss), list(env.batch)
+
+
+@pytest.mark.parametrize('feedback', ['argmax', 'teacher', 'sample'])
+def test_device_rollout_equals_the_per_step_host_loop(world, feedback):
+    from speaker_follower_amd import follower, nav
+    env, agent, store, nt, enc, dec = world
+    want, want_loss, items = _host_rollout(env, agent, feedback)
+    eng = follower.FollowerEngine(enc, dec, store)
+    # same counter-based sampling streams as the agent's glue calls (seed, 1-based step counter)
+    eng.dropout_seed = agent._sample_seed ^ 0x1B873593
+    eng.site_next = 1
+    navb = nav.DeviceNavBatch(nt, items, EPISODE)
+    with torch.no_grad():
+        st = eng.rollout(navb, EPISODE, feedback, train=False)
+    got = navb.trajectories(st)
+    assert [g['instr_id'] for g in got] == [w['instr_id'] for w in want]
+    moved = 0
+    for g, w in zip(got, want):
+        assert g['actions'] == [int(a) for a in w['actions']], (g['instr_id'], feedback)
+        assert len(g['trajectory']) == len(w['trajectory'])
+        for pg, pw in zip(g['trajectory'], w['trajectory']):
+            assert pg[0] == pw[0] and pg[1] == pytest.approx(pw[1], abs=1e-12) and pg[2] == pytest.approx(pw[2], abs=1e-12)
+        np.testing.assert_allclose(g['scores'], w['scores'], rtol=2e-4, atol=2e-4)
+        moved += len({p[0] for p in g['trajectory']}) > 1
+    assert moved >= len(got) // 2                      # the agents really walk the graph
+    np.testing.assert_allclose(float(st.loss), want_loss, rtol=1e-4)
+    # the teacher the device derived (shortest-path next hop) is the env's (env.py:742-761)
+    tgt = navb.target[:EPISODE].cpu().numpy()
+    ws = env.reset(sort=True, load_next_minibatch=False)
+    obs = env.observe(ws)
+    assert [int(x) for x in tgt[0]] == [ob['teacher'] for ob in obs]
+
+
+def test_device_rollout_trains_and_replays_as_a_graph(world):
+    """BPTT through a device-env rollout gives the gradients of the same rollout fed from the host
+    (its recorded index-form observations), and the whole thing is hipGraph-capturable."""
+    from speaker_follower_amd import follower, nav, synth
+    env, agent, store, nt, enc, dec = world
+    env.reset_epoch()
+    env._next_minibatch(True)
+    items = list(env.batch)
+    navb = nav.DeviceNavBatch(nt, items, EPISODE)
+    eng = follower.FollowerEngine(enc, dec, store)
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+    st = eng.rollout(navb, EPISODE, 'argmax', train=False)
+    st.loss.backward()
+    torch.cuda.synchronize()
+    g_nav = {k: p.grad.clone() for k, p in dec.named_parameters() if p.grad is not None}
+    # the same observations as a plain host-fed batch (pipelined episode path)
+    fb = synth.FollowerBatch(instr=[it['instr_encoding'] for it in items],
+                             vp=navb.vp[:EPISODE].cpu().numpy(), view=navb.view[:EPISODE].cpu().numpy(),
+                             a_num=navb.a_num[:EPISODE].cpu().numpy(),
+                             cand_view=navb.cand_view[:EPISODE].cpu().numpy(),
+                             cand_heading=np.zeros((EPISODE, len(items), nt.A), np.float32),
+                             cand_elevation=np.zeros((EPISODE, len(items), nt.A), np.float32),
+                             target=navb.target[:EPISODE].cpu().numpy(), a_max=nt.A)
+    hb = follower.DeviceFollowerBatch.from_synth(fb)
+    hb.sincos = navb.sincos[:EPISODE].clone()
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+    st2 = follower.FollowerEngine(enc, dec, store).rollout(hb, EPISODE, 'argmax', train=False)
+    st2.loss.backward()
+    assert torch.equal(st2.actions, st.actions)
+    np.testing.assert_allclose(float(st2.loss), float(st.loss), rtol=1e-5)
+    for k, p in dec.named_parameters():
+        if p.grad is not None and float(g_nav[k].abs().max()) > 1e-6:
+            np.testing.assert_allclose(p.grad.cpu().numpy(), g_nav[k].cpu().numpy(), rtol=2e-3,
+                                       atol=1e-5 * float(g_nav[k].abs().max()), err_msg=k)
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+    # hipGraph: capture once, replay: same walk
+    replay, gst = eng.capture(navb, EPISODE, 'argmax')
+    navb.row.zero_()
+    replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gst.actions, st.actions)
+    assert [t['trajectory'] for t in navb.trajectories(gst)] == [t['trajectory'] for t in navb.trajectories(st)]
+
+
+def test_agent_api_with_device_env_trains_and_tests(world, tmp_path):
+    """Seq2SeqAgent.train / test (follower.py:987-1020) over the device-resident env: same walk as the
+    host loop in eval mode, finite falling loss over a few Adam iterations in train mode."""
+    from speaker_follower_amd import agents, optim, synth, model
+    env, agent0, store, nt, _, _ = world
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(303)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda()
+    dec.cuda()
+    want, _, _ = _host_rollout(env, agent0, 'argmax')
+    agent = agents.Seq2SeqAgent(env, str(tmp_path / 'r.json'), enc, dec, episode_len=EPISODE)
+    agent.store = store
+    agent.use_device_env(nt)
+    env.reset_epoch()
+    res = agent.test(use_dropout=False, feedback='argmax')
+    for w in want:
+        assert [p[0] for p in res[w['instr_id']]['trajectory']] == [p[0] for p in w['trajectory']]
+    env.reset_epoch()
+    oe = optim.FusedAdam([p for p in enc.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4)
+    od = optim.FusedAdam([p for p in dec.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4)
+    agent.train(oe, od, 6, feedback='teacher')
+    assert len(agent.losses) == 6 and all(np.isfinite(agent.losses))
+    assert min(agent.losses[3:]) < agent.losses[0]
