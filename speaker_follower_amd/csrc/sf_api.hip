@@ -61,8 +61,8 @@ struct Arena {
     // the caller once, see sf_workspace_bytes); never handed out by take()
     unsigned* tickets() const { return tk; }
 };
-constexpr size_t SYNC_WORDS = 1024;
-constexpr size_t PERSIST_TICKET = 1000;   // arrival counter of the persistent encoder launch
+constexpr size_t SYNC_WORDS = 2048;        // [0, 1024): per-sample tickets of the split attention kernels
+constexpr size_t PERSIST_TICKET = 1100;   // [1100, 1140): arrival counter + placement record of the persistent launches
 
 inline Arena arena(void* ws, size_t bytes) {
     const size_t n = ws ? bytes / 4 : 0;
@@ -211,7 +211,7 @@ int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, co
     const int F = X.IMG + X.LOC;
     if (fold) {      // inference: q = M_v h + c_v in one product
         TRY(linear_plain(h, H, fold->m_v, H, fold->c_v, B, F, H, EPI_NONE, q, F, ar, st));
-        float* part = B <= (int)SYNC_WORDS ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+        float* part = B <= 1024 ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
         return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st, part,
                            part ? ar.tickets() : nullptr);
     }
@@ -222,7 +222,7 @@ int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, co
         TRY(gemm_nn_ws(t_v, D, w->w_v, F, B, F, D, q, F, 0, ar.rest(), ar.rest_n(), st));
     // (the products above are done with their slabs by the time the attention kernel runs: the
     // partials may reuse that part of the workspace)
-    float* part = B <= (int)SYNC_WORDS ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+    float* part = B <= 1024 ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
     return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st, part,
                        part ? ar.tickets() : nullptr);
 }
@@ -630,7 +630,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         // (4) t_a = W_h h~ + b_h, wt = t_a * w_out   ||   ... merge of the partials
         // (the attention is not needed before the next gate product: its two halves ride with two
         // stages of the text / scoring chain instead of stretching one of them)
-        float* part = B <= (int)SYNC_WORDS ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+        float* part = B <= 1024 ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
         const bool ok3 = part && plan_linear(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H,
                                              EPI_TANH, tp->h_tilde, H, &pb) == SF_OK;
         SmallPlan pc;
@@ -1132,7 +1132,19 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
     TRY(add2(d_ct, H, nullptr, 0, B, H, dc, H, st));
     const Dropout dd = make_dropout(drop, drop_stream);
     // dgates for step t overwrite tp->xg[t] (the hoisted product is dead after the forward)
-    if (w->lstm.w_hh_t && H % 16 == 0 && H <= 512) {
+    bool persistent = false;
+    if (!(w->flags & SF_ENC_PER_STEP) && encoder_persistent_supported(B, H, T) && ar.tickets()) {
+        // ALL T backward steps as one persistent launch (sf_persist.hip)
+        Arena pa = ar;
+        float* xchg = pa.take(encoder_bwd_persistent_xchg_floats());
+        if (xchg) {
+            TRY(encoder_bwd_persistent(w->lstm.w_hh, lengths, B, H, T, tp->gates, tp->cs, dctx, dd, dh, dc, tp->xg,
+                                       xchg, ar.tickets() + PERSIST_TICKET, st));
+            persistent = true;
+        }
+    }
+    if (persistent) {
+    } else if (w->lstm.w_hh_t && H % 16 == 0 && H <= 512) {
         // ONE launch per step: dh_{t+1} = pass + dgates_{t+1} W_hh on the matrix cores and the cell
         // backward of step t on the same tile (lstm_bwd_step_fused_kernel)
         float* dh_b = dpass;                              // ping-pong partners of dh / dc

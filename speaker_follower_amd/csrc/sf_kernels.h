@@ -52,6 +52,11 @@ int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
                        const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
                        float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
                        hipStream_t st);
+// the backward recurrence (all T steps of lstm_bwd_step_fused): dgates [T,B,4H] out
+size_t encoder_bwd_persistent_xchg_floats();
+int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, int T, const float* gates,
+                           const float* cs, const float* dctx, const Dropout& ctx_drop, const float* dh_in,
+                           const float* dc_in, float* dgates, float* xchg, unsigned* done, hipStream_t st);
 
 struct LstmPwBwd {
     const float* gates; const float* c0; const float* c1;

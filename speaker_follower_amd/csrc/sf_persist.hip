@@ -40,9 +40,43 @@ constexpr int AUX_SC1 = 16;                // cache-policy bit 4: agent scope (b
 
 __device__ unsigned g_persist_lock = 0;
 
+// Per-launch placement record of one row group: [0] arrivals, [1] min XCC id, [2] max XCC id
+// (initialised by the prologue kernel).  EP_PLACE_WORDS dwords per group.
+constexpr int EP_PLACE_WORDS = 4;
+__device__ __forceinline__ void place_init(unsigned* place, size_t i) {
+    if (i < (size_t)EP_GROUPS * EP_PLACE_WORDS) place[i] = (i % EP_PLACE_WORDS) == 1 ? 0xFFFFFFFFu : 0u;
+}
+// True iff all EP_SLOTS workgroups of `grp` run on ONE XCD (read from the hardware id register, agreed
+// on through agent-scope atomics once per launch).  Then their exchange can stay inside that XCD's
+// L2: plain stores (L1 is write-through, the line stays in L2) + L1-bypassing loads -- no write-through
+// to the fabric.  Any doubt (timeout, mixed ids) => false => the placement-independent sc1 protocol.
+__device__ __forceinline__ bool group_on_one_xcd(unsigned* place, int grp) {
+    __shared__ int s_fast;
+    if (threadIdx.x == 0) {
+        unsigned* p = place + grp * EP_PLACE_WORDS;
+        const unsigned xcc = __builtin_amdgcn_s_getreg(63508) & 0xFu;      // hwreg(HW_REG_XCC_ID)
+        atomicMin(p + 1, xcc);
+        atomicMax(p + 2, xcc);
+        __threadfence();
+        atomicAdd(p, 1u);
+        const long long t0 = wall_clock64();
+        bool all = false;
+        while (!(all = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= (unsigned)EP_SLOTS)) {
+            __builtin_amdgcn_s_sleep(2);
+            if (wall_clock64() - t0 > 2000) break;                         // 20 us: decide without the others
+        }
+        __threadfence();
+        s_fast = all && __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                            __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    return s_fast != 0;
+}
+
 __global__ __launch_bounds__(256) void enc_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, float* h0,
-                                                                   float* c0, size_t n_state) {
+                                                                   float* c0, size_t n_state, unsigned* place) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
+    place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_xchg; i += stride) xchg[i] = EP_SENTINEL;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_state; i += stride) {
         h0[i] = 0.f;                       // model.py:67-79 init_state
@@ -57,6 +91,16 @@ __global__ __launch_bounds__(256) void enc_persist_prologue_kernel(unsigned* xch
     }
 }
 
+// 16-byte store into an exchange buffer: plain (stays in the XCD's L2) when the group shares an XCD,
+// write-through (sc1) otherwise.
+template <class RS>
+__device__ __forceinline__ void xstore(bool local, v4u v, RS rs, unsigned off) {
+    if (local)
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b128(v, rs, off, 0, AUX_SC1);
+}
+
 struct EncPersistArgs {
     const float* w_hh; const float* b_ih; const float* b_hh;   // [4H,H], [4H], [4H]
     const float* xw_table;                                     // [vocab,4H] = embedding W_ih^T
@@ -67,6 +111,7 @@ struct EncPersistArgs {
     float* ctx; int ld_ctx; Dropout ctx_drop;                  // ctx[b, t, :], row stride T*H
     unsigned* xchg;                                            // [8][3][16][H] dwords, sentinel-filled
     unsigned* done;                                            // arrival counter (0 before and after)
+    unsigned* place;                                           // placement record (group_on_one_xcd)
     unsigned long long* trace;                                 // sf_debug_trace: [blocks][8] tick sums, or null
 };
 
@@ -115,6 +160,7 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
     // covers units eu .. eu+3 of row er
     const unsigned patch_off = (unsigned)((er * H + ej) * 4);
     bool dead = false;
+    const bool local = group_on_one_xcd(p.place, grp);
 
     __syncthreads();
     float xv[4];
@@ -163,9 +209,8 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
             // every workgroup of the group has consumed h_{t-1}: its buffer becomes the buffer of
             // h_{t+2}; reset the own patch there (same lanes, same addresses as the later publish)
             if ((tid & 3) == 0)
-                __builtin_amdgcn_raw_buffer_store_b128(v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
-                                                       (unsigned)((((t + 2) % 3) * EP_ROWS) * H * 4) + patch_off, 0,
-                                                       AUX_SC1);
+                xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
+                       (unsigned)((((t + 2) % 3) * EP_ROWS) * H * 4) + patch_off);
             // input row of the NEXT step (table lookup by token): lands behind the MFMAs
             if (t + 1 < T) {
                 const int tok = s_tok[er][t + 1];
@@ -236,9 +281,8 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
             const float h_1 = __shfl_down(hp, 1), h_2 = __shfl_down(hp, 2), h_3 = __shfl_down(hp, 3);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the sentinel reset is behind us
             if ((tid & 3) == 0)
-                __builtin_amdgcn_raw_buffer_store_b128(
-                    v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)}, rs,
-                    (unsigned)((((t + 1) % 3) * EP_ROWS) * H * 4) + patch_off, 0, AUX_SC1);
+                xstore(local, v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)},
+                       rs, (unsigned)((((t + 1) % 3) * EP_ROWS) * H * 4) + patch_off);
         }
         EP_STAMP(2)                                      // reduce + cell + publish
         if (evalid) {
@@ -261,6 +305,7 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
     if (p.trace && lane == 0 && w == 0) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) p.trace[blockIdx.x * 8 + k] = (unsigned long long)tk[k];
+        p.trace[blockIdx.x * 8 + 5] = local ? 1u : 0u;
     }
     // last workgroup out releases the device-wide lock and re-arms the counter
     __syncthreads();
@@ -269,6 +314,199 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
         if (n == gridDim.x - 1) {
             atomicExch(p.done, 0u);
             atomicExch(&g_persist_lock, 0u);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The BACKWARD recurrence of the same LSTM (sf_encoder_lstm_bwd; per-step form:
+// lstm_bwd_step_fused_kernel) as one persistent launch.  Same partition: workgroup (group, slot)
+// owns hidden units [16 slot, +16) of the group's <= 16 rows, keeps dc and the pass-through part of
+// dh in registers and the SAME 64 rows of W_hh as the forward kernel -- now used as the K = 64 slice
+// (its own four gates x 16 units) of dh_{t+1} = dgates_{t+1} W_hh.  Per step it
+//   1. gathers, for its 16 x 16 patch, the 32 partial sums the group's workgroups published (32 KB,
+//      its OWN contiguous region: after reading it resets it to the sentinel, so two buffers suffice),
+//   2. runs the cell backward of step t  -> dgates_t (tape, and [16 x 64] into LDS),
+//   3. multiplies: partial[16 rows x 512 units] = dgates_t[16 x 64] . W_hh[its 64 rows, :]
+//      (128 MFMAs per wave, no K split inside the workgroup),
+//   4. publishes the partial as 32 blocks of 1 KB, one per destination workgroup, in the MFMA output
+//      layout (one coalesced 16-byte store per lane and block).
+// ------------------------------------------------------------------------------------------------
+struct EncBwdPersistArgs {
+    const float* w_hh;                            // [4H,H]
+    const int* lengths;
+    int B, H, T, rpg;
+    const float* gates; const float* cs;          // tapes [T,B,4H] (activated gates), [T+1,B,H]
+    const float* dctx; Dropout ctx_drop;          // [B,T,H] gradient wrt the dropped ctx, or null
+    const float* dh_in; const float* dc_in;       // [B,H] incoming dh_T, dc_T
+    float* dgates;                                // [T,B,4H] out (pre-activation gate gradients)
+    unsigned* xchg;                               // [8][2][32 dest][32 src][256] dwords, sentinel-filled
+    unsigned* done;
+    unsigned* place;
+    unsigned long long* trace;
+};
+constexpr int EB_LDA = 68;                        // LDS row stride of the [16 x 64] dgates tile
+
+__global__ __launch_bounds__(256, 2) void enc_bwd_persist_kernel(EncBwdPersistArgs p) {
+    __shared__ float sA[2][EP_ROWS][EB_LDA];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int grp = blockIdx.x & (EP_GROUPS - 1), slot = blockIdx.x >> 3;
+    const int H = p.H, T = p.T, B = p.B;
+    const int row0 = grp * p.rpg;
+    const int nrows = max(0, min(p.rpg, B - row0));
+    // resident: wave w covers units [128 w, +128) = 8 n-tiles; k = 16 kk + c  <->  gate kk, unit c
+    float wf[8][16];
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt)
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+            wf[nt][c] = p.w_hh[(size_t)(kk * H + 16 * slot + c) * H + 16 * (8 * w + nt) + li];
+    // this thread's element in the MFMA output layout: index e = (kk*16 + col)*4 + r
+    const int er = 4 * (tid >> 6) + (tid & 3), eu = (tid >> 2) & 15;
+    const bool evalid = er < nrows;
+    const int eb = evalid ? row0 + er : B - 1;
+    const int ej = 16 * slot + eu;
+    const int len_b = p.lengths[eb];
+    const uint32_t rk = dropout_row_key(p.ctx_drop.seed, p.ctx_drop.stream, (uint32_t)(p.ctx_drop.row0 + eb));
+    const size_t BH = (size_t)B * H;
+    float dc = p.dc_in ? p.dc_in[(size_t)eb * H + ej] : 0.f;
+    float dh_pass = p.dh_in ? p.dh_in[(size_t)eb * H + ej] : 0.f;
+
+    unsigned* xg = p.xchg + (size_t)grp * 2 * EP_SLOTS * EP_SLOTS * 256;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(xg, 0, 2 * EP_SLOTS * EP_SLOTS * 256 * 4, 0x00020000);
+    bool dead_wg = false;
+    const bool local = group_on_one_xcd(p.place, grp);
+    long long tk[5] = {0, 0, 0, 0, 0}, tprev = wall_clock64();
+
+    // operands of step t (activated gates, cell states, dctx), fetched one step ahead
+    float g_i, g_f, g_g, g_o, c0v, c1v, dcx;
+    auto fetch = [&](int t) {
+        const float* gp = p.gates + ((size_t)t * B + eb) * 4 * H + ej;
+        g_i = gp[0]; g_f = gp[H]; g_g = gp[2 * H]; g_o = gp[3 * H];
+        c0v = p.cs[(size_t)t * BH + (size_t)eb * H + ej];
+        c1v = p.cs[(size_t)(t + 1) * BH + (size_t)eb * H + ej];
+        dcx = p.dctx ? p.dctx[((size_t)eb * T + t) * H + ej] : 0.f;
+    };
+    fetch(T - 1);
+
+    for (int t = T - 1; t >= 0; --t) {
+        EP_STAMP(4)
+        float dh = dh_pass;
+        if (t < T - 1) {
+            // ---- 1. gather the 32 partials of dgates_{t+1} W_hh for this patch
+            unsigned v[EP_SLOTS];
+            const unsigned base = (unsigned)(((((t + 1) & 1) * EP_SLOTS + slot) * EP_SLOTS) * 256 + tid) * 4u;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                asm volatile("" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int c = 0; c < EP_SLOTS; ++c)
+                    v[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, base + (unsigned)(c * 256 * 4), 0, AUX_SC1);
+#pragma unroll
+                for (int c = 0; c < EP_SLOTS; ++c) ok = ok && v[c] != EP_SENTINEL;
+                if (__all(ok) || dead_wg) break;
+                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) {
+                    dead_wg = true;
+                    break;
+                }
+            }
+            EP_STAMP(0)                                  // waiting for the partials
+#pragma unroll
+            for (int c = 0; c < EP_SLOTS; ++c) dh += __uint_as_float(v[c]);
+        }
+        // ---- 2. cell backward of step t (lstm_bwd_step_fused_kernel's arithmetic)
+        {
+            float vctx = dcx;
+            if (p.dctx && p.ctx_drop.on())
+                vctx = dropout_keep(rk, (uint32_t)(t * H + ej), p.ctx_drop.thresh) ? vctx * p.ctx_drop.scale : 0.f;
+            dh += vctx;
+        }
+        if (dead_wg) dh = __uint_as_float(0x7FC00000u);
+        const bool dead = t >= len_b;                    // packed sequence: the step did not happen
+        const float tc = tanhf(c1v);
+        const float dout = dh * tc;
+        const float dcl = dc + dh * g_o * (1.f - tc * tc);
+        const float dgi = dead ? 0.f : dcl * g_g * g_i * (1.f - g_i);
+        const float dgf = dead ? 0.f : dcl * c0v * g_f * (1.f - g_f);
+        const float dgg = dead ? 0.f : dcl * g_i * (1.f - g_g * g_g);
+        const float dgo = dead ? 0.f : dout * g_o * (1.f - g_o);
+        dc = dead ? dc : dcl * g_f;
+        dh_pass = dead ? dh : 0.f;
+        float* sa = &sA[t & 1][er][0];
+        const float z = evalid ? 1.f : 0.f;              // rows beyond the group's share contribute nothing
+        sa[eu] = dgi * z; sa[16 + eu] = dgf * z; sa[32 + eu] = dgg * z; sa[48 + eu] = dgo * z;
+        if (evalid) {
+            float* dg = p.dgates + ((size_t)t * B + eb) * 4 * H + ej;
+            dg[0] = dgi; dg[H] = dgf; dg[2 * H] = dgg; dg[3 * H] = dgo;
+        }
+        __syncthreads();                                 // tile complete; every wave has finished its gather
+        if (t < T - 1) {                                 // the region just read becomes the region of step t-1
+            const unsigned rb = (unsigned)(((((t + 1) & 1) * EP_SLOTS + slot) * EP_SLOTS) * 256) * 4u;
+#pragma unroll
+            for (int i = 0; i < 8; ++i)
+                xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
+                       rb + (unsigned)((tid + 256 * i) * 16));
+        }
+        EP_STAMP(1)                                      // cell backward + tile + barrier + reset issue
+        if (t == 0) break;                               // h_0 = 0 carries no gradient: nothing to publish
+        fetch(t - 1);
+        // ---- 3. partial[16 x 512] = dgates_t[16 x 64] . W_hh[own 64 rows, :]
+        float a[16];
+        {
+            const float4* ap = reinterpret_cast<const float4*>(&sA[t & 1][li][16 * kk]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 x = ap[q];
+                a[4 * q] = x.x; a[4 * q + 1] = x.y; a[4 * q + 2] = x.z; a[4 * q + 3] = x.w;
+            }
+        }
+        f32x4 acc[8];
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[nt] = mfma16(a[c], wf[nt][c], acc[nt]);
+        // ---- 4. publish: block (dest = 8 w + nt, src = slot), lane's four rows contiguous
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the resets above are behind us
+        const unsigned pb = (unsigned)((t & 1) * EP_SLOTS * EP_SLOTS * 256) * 4u;
+        EP_STAMP(2)                                      // MFMAs + drain
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt)
+            xstore(local, v4u{__float_as_uint(acc[nt][0]), __float_as_uint(acc[nt][1]), __float_as_uint(acc[nt][2]),
+                              __float_as_uint(acc[nt][3])},
+                   rs, pb + (unsigned)((((8 * w + nt) * EP_SLOTS + slot) * 256 + (kk * 16 + li) * 4) * 4));
+        EP_STAMP(3)                                      // publish issue
+    }
+    if (p.trace && lane == 0 && w == 0) {
+#pragma unroll
+        for (int k = 0; k < 5; ++k) p.trace[blockIdx.x * 8 + k] = (unsigned long long)tk[k];
+        p.trace[blockIdx.x * 8 + 5] = local ? 1u : 0u;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned n = atomicAdd(p.done, 1u);
+        if (n == gridDim.x - 1) {
+            atomicExch(p.done, 0u);
+            atomicExch(&g_persist_lock, 0u);
+        }
+    }
+}
+
+// sentinel fill + device-wide lock of the backward launch (no state to zero)
+__global__ __launch_bounds__(256) void enc_bwd_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, unsigned* place) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    v4u* x4 = reinterpret_cast<v4u*>(xchg);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_xchg / 4; i += stride)
+        x4[i] = v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL};
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        const long long t0 = wall_clock64();
+        while (atomicCAS(&g_persist_lock, 0u, 1u) != 0u) {
+            __builtin_amdgcn_s_sleep(32);
+            if (wall_clock64() - t0 > 8 * EP_TIMEOUT_TICKS) break;
         }
     }
 }
@@ -304,10 +542,26 @@ int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
     a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.xw_table = xw_table; a.seq = seq; a.Lpad = Lpad;
     a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
     a.gates = gates; a.hs = hs; a.cs = cs; a.ctx = ctx; a.ld_ctx = T * H; a.ctx_drop = ctx_drop;
-    a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.trace = g_trace;
+    a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
     SF_LAUNCH(enc_persist_prologue_kernel, dim3(96), dim3(256), 0, st, a.xchg, encoder_persistent_xchg_floats(H),
-              hs, cs, (size_t)B * H);
+              hs, cs, (size_t)B * H, a.place);
     SF_LAUNCH(enc_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
+    return launch_status();
+}
+
+size_t encoder_bwd_persistent_xchg_floats() { return (size_t)EP_GROUPS * 2 * EP_SLOTS * EP_SLOTS * 256; }
+
+int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, int T, const float* gates,
+                           const float* cs, const float* dctx, const Dropout& ctx_drop, const float* dh_in,
+                           const float* dc_in, float* dgates, float* xchg, unsigned* done, hipStream_t st) {
+    if (!encoder_persistent_supported(B, H, T) || !xchg || !done) return SF_ERR_UNSUPPORTED;
+    EncBwdPersistArgs a{};
+    a.w_hh = w_hh; a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
+    a.gates = gates; a.cs = cs; a.dctx = dctx; a.ctx_drop = ctx_drop; a.dh_in = dh_in; a.dc_in = dc_in;
+    a.dgates = dgates; a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
+    SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(512), dim3(256), 0, st, a.xchg, encoder_bwd_persistent_xchg_floats(),
+              a.place);
+    SF_LAUNCH(enc_bwd_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }
 

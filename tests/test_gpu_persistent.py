@@ -109,3 +109,68 @@ def test_larger_batches_fall_back_to_the_per_step_path():
     b = run(enc, seq, lens, persistent=False)
     torch.cuda.synchronize()
     assert torch.equal(a['ctx'], b['ctx'])
+
+
+def run_bwd(enc, seq, lens, fwd, persistent, train, dctx, d_init, d_ct):
+    """sf_encoder_lstm_bwd on a copy of the forward tape `fwd`; returns (dgates tape, weight grads)."""
+    from speaker_follower_amd import _lib
+    from speaker_follower_amd.model import _encoder_structs
+    from speaker_follower_amd.runtime import ptr, ws_args, dropout_arg
+    import ctypes as C
+    enc.persistent = persistent
+    B, Lpad = seq.shape
+    T, E, H = max(lens), enc.embedding_size, enc.hidden_size
+    tape = {k: fwd[k].clone() for k in ('emb', 'gates', 'hs', 'cs')}
+    tape['xg'] = torch.zeros(T, B, 4 * H, device='cuda')
+    tp = _lib.EncoderTape(*(tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
+    for p in enc.parameters():
+        p.grad = None
+    w, g = _encoder_structs(enc), _encoder_structs(enc, grad=True)
+    lens_dev = torch.tensor(lens, dtype=torch.int32, device='cuda')
+    _lib.call('sf_encoder_lstm_bwd', C.byref(w), C.byref(g), B, T, E, H, ptr(lens_dev), ptr(fwd['h']), ptr(dctx),
+              ptr(d_init), ptr(d_ct), C.byref(tp), dropout_arg(0.5 if train else 0.0, 0xBEEF, 3), 7,
+              *ws_args(seq.device))
+    torch.cuda.synchronize()
+    return tape['xg'], {k: p.grad.clone() for k, p in enc.named_parameters() if p.grad is not None}
+
+
+@pytest.mark.parametrize('B,min_len,max_len,train', [(100, 10, 79, True), (100, 79, 79, False), (13, 1, 5, False),
+                                                     (128, 2, 60, True), (40, 3, 33, False)])
+def test_persistent_encoder_backward_matches_per_step(B, min_len, max_len, train):
+    """The backward recurrence as one launch (enc_bwd_persist_kernel) against lstm_bwd_step_fused per
+    step: the same dgates tape and weight gradients (different summation order: 1e-5 of the scale)."""
+    enc = encoder(11)
+    seq, mask, lens = batch(B + 7, B, min_len, max_len)
+    fwd = run(enc, seq, lens, persistent=True, train=train)
+    fwd['xg'] = None
+    T, H = max(lens), enc.hidden_size
+    g = torch.Generator(device='cuda').manual_seed(B)
+    dctx = torch.randn(B, T, H, device='cuda', generator=g)
+    d_init = torch.randn(B, H, device='cuda', generator=g)
+    d_ct = torch.randn(B, H, device='cuda', generator=g)
+    ref_dg, ref_gr = run_bwd(enc, seq, lens, fwd, False, train, dctx, d_init, d_ct)
+    for _ in range(3):                                   # repeated launches reuse the self-resetting buffers
+        got_dg, got_gr = run_bwd(enc, seq, lens, fwd, True, train, dctx, d_init, d_ct)
+    assert not torch.isnan(got_dg).any()
+    scale = float(ref_dg.abs().max())
+    assert float((got_dg - ref_dg).abs().max()) <= 1e-5 * scale
+    assert set(got_gr) == set(ref_gr) and len(ref_gr) >= 5
+    for k in ref_gr:
+        s = float(ref_gr[k].abs().max())
+        assert float((got_gr[k] - ref_gr[k]).abs().max()) <= 2e-5 * s, k
+
+
+def test_persistent_backward_is_the_kernel_that_runs():
+    from speaker_follower_amd import _lib
+    enc = encoder()
+    seq, mask, lens = batch(5, 100, 10, 79)
+    fwd = run(enc, seq, lens, persistent=True)
+    T, H = max(lens), enc.hidden_size
+    dctx = torch.randn(100, T, H, device='cuda')
+    z = torch.zeros(100, H, device='cuda')
+    run_bwd(enc, seq, lens, fwd, True, False, dctx, z, z)
+    with _lib.kernel_profile() as prof:
+        run_bwd(enc, seq, lens, fwd, True, False, dctx, z, z)
+    names = ' '.join(prof.rows)
+    assert 'enc_bwd_persist_kernel' in names and 'lstm_bwd_step' not in names, names
+    print({k: round(v['avg_us'], 1) for k, v in prof.rows.items() if 'persist' in k}, 'T =', T)
