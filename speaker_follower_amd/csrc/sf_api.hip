@@ -607,7 +607,44 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     const sf_softdot_w* tw = &w->text;
     const sf_visual_w* vw = &w->visual;
     bool paired = X_next && vw->w_v_t;     // (a scoring fold, if any, is applied by scoring_fwd_i)
-    if (paired) {
+    if (paired && w->fold) {
+        // Folded inference step (sf_decoder_fold): two dependent stages fewer, and the attention
+        // partials of step t+1 ride beside the text attention (the longest small stage) instead of
+        // stretching the h~ product:
+        //   (1) t_text = W_in h1                  ||  q' = M_v h1 + c_v
+        //   (2) text attention                    ||  visual-attention partials of step t+1
+        //   (3) h~ = tanh(W_out [wc ; h1])        ||  merge of the partials
+        //   (4) [r | c] = M_a h~ + c_a            (5) scoring + glue
+        const PanoSrc xn = pano(X_next);
+        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1));
+        SmallPlan pa, pb;
+        const bool ok1 =
+            plan_linear(tp->cat2 + H, 2 * H, tw->w_in, H, nullptr, B, H, H, EPI_NONE, tp->t_text, H, &pa) == SF_OK &&
+            plan_linear(tp->h1, H, w->fold->m_v, H, w->fold->c_v, B, F, H, EPI_NONE, tn->q, F, &pb) == SF_OK;
+        if (!ok1 || pair_small_small(pa, pb, st) != SF_OK) {
+            TRY(linear_plain(tp->cat2 + H, 2 * H, tw->w_in, H, nullptr, B, H, H, EPI_NONE, tp->t_text, H, ar, st));
+            TRY(linear_plain(tp->h1, H, w->fold->m_v, H, w->fold->c_v, B, F, H, EPI_NONE, tn->q, F, ar, st));
+        }
+        float* part = B <= 1024 ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+        const bool ok3 = part && plan_linear(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H, EPI_TANH,
+                                             tp->h_tilde, H, &pb) == SF_OK;
+        bool split = false;
+        if (ok3) {
+            const int rc = pair_vis_text(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, ctx,
+                                         ctx_mask, L, H, tp->t_text, H, tp->alpha, tp->cat2, 2 * H, ctx_row, st);
+            if (rc == SF_OK) split = true;
+            else if (rc != SF_ERR_UNSUPPORTED) return rc;
+        }
+        if (split && pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, nullptr, pb,
+                                    st, 2) != SF_OK)
+            return SF_ERR_LAUNCH;            // the partials exist: the merge must not be skipped
+        if (!split) {
+            TRY(text_attn_fwd(ctx, ctx_mask, B, L, H, tp->t_text, H, tp->alpha, tp->cat2, 2 * H, st, ctx_row));
+            TRY(linear_plain(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H, EPI_TANH, tp->h_tilde, H, ar, st));
+            TRY(visual_attn(0, xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, st, part,
+                            part ? ar.tickets() : nullptr));
+        }
+    } else if (paired) {
         const PanoSrc xn = pano(X_next);
         const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1));
         SmallPlan pa, pb;

@@ -335,10 +335,10 @@ struct TxtArgs {
     float* ds_out;         // bwd, optional [B, L]: the score gradients (for a deferred dctx update)
 };
 
-template <int RPW, int MODE>
+template <int RPW, int MODE, int NW = TXT_NW>
 __device__ __forceinline__ void text_attn_body(const TxtArgs& a, int b) {
     __shared__ float4 slots[TXT_SLOTS][TXT_CPL * 64];
-    __shared__ float s_score[TXT_NW * RPW];
+    __shared__ float s_score[NW * RPW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int L = a.L, n4 = a.H >> 2;
     const int bc = a.ctx_row ? a.ctx_row[b] : b;
@@ -458,7 +458,7 @@ __device__ __forceinline__ void text_attn_body(const TxtArgs& a, int b) {
         }
     }
     float* orow = a.out + (size_t)b * a.ldo;
-    block_row_sum<TXT_CPL, TXT_NW, TXT_SLOTS>(p, slots, n4, [&](int c, float4 t) {
+    block_row_sum<TXT_CPL, NW, TXT_SLOTS>(p, slots, n4, [&](int c, float4 t) {
         reinterpret_cast<float4*>(orow)[c] = t;
     });
 }
@@ -656,6 +656,21 @@ __global__ __launch_bounds__(TXT_NW * 64) void pair_small_text_kernel(SmallArgs 
     }
 }
 
+// Folded inference step (sf_decoder_fold): the attention partials of step t+1 ride beside the TEXT
+// attention of step t.  512-thread blocks: the attention body needs its 163 registers per lane, so the
+// text body runs with 8 waves x RPW context rows (L <= 8 RPW) instead of 16 x RPW/2.
+template <int RPW>
+__global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_text_kernel(VisArgs v, VisSplit sp, int nv,
+                                                                        TxtArgs t) {
+    const int bid = blockIdx.x;
+    if (bid < nv) {
+        if (threadIdx.x >= VSP_NW * 64) return;
+        visual_split_body<1>(v, sp, bid % VSP_G, bid / VSP_G);
+    } else {
+        text_attn_body<RPW, 0, SMALL_WAVES>(t, bid - nv);
+    }
+}
+
 template <int MT, int CPW, int PHASE>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArgs v, VisSplit sp,
                                                                          int nv, SmallArgs b,
@@ -848,10 +863,40 @@ int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* 
 // ---- paired launches (host side).  SF_ERR_UNSUPPORTED = "not pairable": the caller launches the
 // two kernels one after the other instead.
 int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
-    if (!(a.mt == 1 && a.cpw == 4 && b.mt == 1 && b.cpw == 4)) return SF_ERR_UNSUPPORTED;
+    if (!(a.mt == 1 && a.cpw == 4 && b.cpw == 4 && (b.mt == 1 || b.mt == 2 || b.mt == 4))) return SF_ERR_UNSUPPORTED;
     const int na = a.gx * a.gy, nb = b.gx * b.gy;
-    SF_LAUNCH((pair_small_small_kernel<1, 4, 1, 4>), dim3(na + nb), dim3(SMALL_WAVES * 64), 0,
-                       st, a.args, a.gx, na, b.args, b.gx);
+    const dim3 grid(na + nb), block(SMALL_WAVES * 64);
+    if (b.mt == 1)
+        SF_LAUNCH((pair_small_small_kernel<1, 4, 1, 4>), grid, block, 0, st, a.args, a.gx, na, b.args, b.gx);
+    else if (b.mt == 2)
+        SF_LAUNCH((pair_small_small_kernel<1, 4, 2, 4>), grid, block, 0, st, a.args, a.gx, na, b.args, b.gx);
+    else
+        SF_LAUNCH((pair_small_small_kernel<1, 4, 4, 4>), grid, block, 0, st, a.args, a.gx, na, b.args, b.gx);
+    return launch_status();
+}
+
+// visual-attention partials (phase 1 of the split attention) beside the text attention
+int pair_vis_text(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out, int ldo,
+                  const Dropout& drop, int drop_col0, float* split_part, const float* ctx, const uint8_t* mask,
+                  int L, int H, const float* t, int ldt, float* talpha, float* wc, int ldwc,
+                  const int32_t* ctx_row, hipStream_t st) {
+    const int F = src.IMG + src.LOC;
+    if (!split_part || src.V <= (VSP_G - 1) * VSP_RPG || src.V > VSP_G * VSP_RPG || B > 256 || F > VIS_CPL * 256 ||
+        (F & 3) || (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) || (ldvec & 3) || (ldo & 3))
+        return SF_ERR_UNSUPPORTED;
+    if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (ldwc & 3) || L < 1 || L > SMALL_WAVES * 10)
+        return SF_ERR_UNSUPPORTED;
+    VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
+    const VisSplit sp{split_part, nullptr, g_trace};
+    TxtArgs ta{ctx, mask, L, H, t, ldt, nullptr, 0, talpha, wc, ldwc, nullptr, ctx_row, nullptr};
+    const int nv = VSP_G * B;
+    const dim3 grid(nv + B), block(SMALL_WAVES * 64);
+    if (L <= SMALL_WAVES * 2)
+        SF_LAUNCH((pair_vis_text_kernel<2>), grid, block, 0, st, va, sp, nv, ta);
+    else if (L <= SMALL_WAVES * 5)
+        SF_LAUNCH((pair_vis_text_kernel<5>), grid, block, 0, st, va, sp, nv, ta);
+    else
+        SF_LAUNCH((pair_vis_text_kernel<10>), grid, block, 0, st, va, sp, nv, ta);
     return launch_status();
 }
 

@@ -126,6 +126,11 @@ int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float
                    unsigned* split_counter, const SmallPlan& b, hipStream_t st, int phase = 0);
 // phase 0: the whole split attention (ticket inside the launch); 1: per-group partials only;
 // 2: merge of the partials written by a phase-1 launch (alpha, out)
+// phase-1 partials beside the text attention (folded inference step)
+int pair_vis_text(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out, int ldo,
+                  const Dropout& drop, int drop_col0, float* split_part, const float* ctx, const uint8_t* mask,
+                  int L, int H, const float* t, int ldt, float* talpha, float* wc, int ldwc,
+                  const int32_t* ctx_row, hipStream_t st);
 
 struct FGlue;
 int follower_glue_fwd(const FGlue& g, hipStream_t st);

@@ -127,7 +127,11 @@ class FollowerEngine:
         self.dropout_seed = None
         self.two_stream_backward = True  # heads of the backward on a side stream (see sf_follower_episode_bwd)
         self._side_stream = None
-        self.fold_inference = False     # model.decoder_fold: correct, but measured no faster (590K vs 596K)
+        # model.decoder_fold for no-grad eval rollouts (folded Linears + the folded paired schedule of
+        # sf_attn_decoder_tail_fwd).  Correct (tests/test_gpu_follower.py) but SLOWER on MI355X: the two
+        # folded [2176 x 512] products read 4.4 MB of weights each and take 11.6 us, the four unfolded
+        # ones 5-6 us each in paired stages: 2.20 vs 2.09 ms per rollout.  Off.
+        self.fold_inference = False
         self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
         self.episode_call = True        # the whole decode loop (and its backward) as ONE C call
 
@@ -214,7 +218,7 @@ class FollowerEngine:
             batch.advance(-1)                           # slot 0 = the initial observation
         pipelined = self.pipelined and not on_device_env
         st.episode = None
-        if pipelined and self.episode_call and fold is None:
+        if pipelined and self.episode_call:
             # every per-step tensor is a stacked [S][...] array: hand step 0 to the library once
             ep = _lib.FollowerEpisode()
             ep.S, ep.B, ep.H, ep.D, ep.L, ep.A = S, B, H, D, T, A
@@ -294,7 +298,8 @@ class FollowerEngine:
         structs also refreshes stale derived copies IN PLACE, on the current stream."""
         ew = _encoder_structs(self.encoder)
         dw = decoder_w_struct(decoder_params(self.decoder))
-        return bytes(ew) + bytes(dw)
+        fold = bytes(decoder_fold(self.decoder)) if self.fold_inference else b''
+        return bytes(ew) + bytes(dw) + fold
 
     def _guarded(self, graph_replay):
         baked = self._baked_pointers()

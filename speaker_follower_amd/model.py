@@ -377,7 +377,9 @@ def decoder_fold(mod):
     H, F, D = mod.hidden_size, mod.feature_size, params[4].shape[0]
     dev = params[0].device
     new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
-    bufs = (new(F, H), new(F), new(F + 4, H), new(F + 4))
+    # rebuilt IN PLACE (a captured hipGraph keeps pointing at these buffers: FollowerEngine.capture)
+    bufs = cached[1] if cached is not None and cached[1][0].device == dev else \
+        (new(F, H), new(F), new(F + 4, H), new(F + 4))
     w = decoder_w_struct(params)
     call('sf_decoder_fold_build', byref(w), H, D, F, *(ptr(b) for b in bufs), *ws_args(dev))
     fold = _lib.DecoderFold(*(b.data_ptr() for b in bufs))

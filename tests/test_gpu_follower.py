@@ -358,3 +358,34 @@ def test_engine_edge_cases_against_oracle(case):
     else:
         fb = synth.follower_batch(seed=4, batch=260, steps=2, n_viewpoints=nvp, min_len=2, max_len=12, a_max=6)
         _rollout_vs_oracle(fb, table, enc, dec, enc_w, dec_w, 2)
+
+
+def test_folded_inference_schedule_matches_unfolded():
+    """sf_decoder_fold + the folded paired schedule (q' = M_v h + c_v beside t_text, attention partials
+    beside the text attention, [r | c] = M_a h~ + c_a): same actions, logits within 1e-4 of their scale.
+    (Kept off by default: slower on MI355X, see FollowerEngine.fold_inference.)"""
+    from speaker_follower_amd import model, features, follower
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(303)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    fb = synth.follower_batch(seed=47, batch=100, steps=12, n_viewpoints=256)
+    store = features.FeatureStore(synth.feature_table(8, 256))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    out = []
+    for fold in (False, True):
+        eng = follower.FollowerEngine(enc, dec, store)
+        eng.fold_inference = fold
+        with torch.no_grad():
+            out.append(eng.rollout(batch, 12, 'argmax', train=False))
+    a, b = out
+    assert torch.equal(a.actions, b.actions)
+    la, lb = a.logits.cpu().numpy(), b.logits.cpu().numpy()
+    fin = np.isfinite(la)
+    assert np.array_equal(fin, np.isfinite(lb))
+    assert float(np.abs(la[fin] - lb[fin]).max()) <= 1e-4 * float(np.abs(la[fin]).max())
+    np.testing.assert_allclose(float(b.loss), float(a.loss), rtol=1e-5)
