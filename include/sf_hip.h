@@ -463,6 +463,21 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
                            const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
                            const sf_spk_decoder_tape* tape, const sf_dropout* drop,
                            uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream);
+/* The WHOLE word loop of an inference pass (speaker.py:158-197: S times SpeakerDecoderLSTM.forward +
+ * sf_speaker_glue_fwd, eval mode, no tapes for a backward) as one persistent launch
+ * (csrc/sf_persist.hip: weights register-resident, rows partitioned across XCDs, three in-kernel
+ * exchanges per word).  targets [S,B] int64; words [S+1,B] with words[0] = the start tokens;
+ * feedback 0 = teacher, 1 = argmax; step_scores / nll_term / live [S,B] as sf_speaker_glue_fwd;
+ * optional outputs (NULL = skip): logits [S,B,ldv], alpha [S,B,Tp], h1_tape / c1_tape [S,B,H].
+ * Needs w->xw_table and w->attn.w_in_t.  The attention is evaluated in the folded form
+ * cq = ctx W_in, cw = ctx W_c^T (same function, fp32 re-association).  SF_ERR_UNSUPPORTED (H != 512,
+ * B > 128, Tp > 12, vocab > 1024, fewer than 256 CUs): run the per-step entry points instead. */
+int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab, int S, int feedback,
+                      int pad_idx, int eos_idx, const int64_t* targets, const float* h_init,
+                      const float* c_init, const float* ctx, const uint8_t* ctx_mask, int64_t* words,
+                      uint8_t* ended, float* step_scores, float* nll_term, float* live, float* logits,
+                      float* alpha, float* h1_tape, float* c1_tape, void* ws, size_t ws_bytes,
+                      sf_stream stream);
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E,
                            int H, int Tp, int vocab, const float* h0, const float* c0,
                            const float* ctx, const sf_spk_decoder_tape* tape, const float* dlogit,

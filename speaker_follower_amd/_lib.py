@@ -174,6 +174,8 @@ _SIGNATURES = {
     'sf_speaker_decoder_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32,
                                          c_f, c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, c_f,
                                          c_f, P(Dropout), u32] + WS),
+    'sf_speaker_decode': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i32, i32, i32, i64p, c_f, c_f, c_f, c_p,
+                                   i64p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f] + WS),
     'sf_speaker_glue_fwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, i32, i32, c_p, i64p, c_f, c_f,
                                       c_f, c_p]),
     'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),

@@ -1285,6 +1285,33 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
                         ar, st);                                                  // :518
 }
 
+// The whole word loop of an inference pass in one persistent launch (sf_persist.hip)
+int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab, int n_steps, int feedback,
+                      int pad_idx, int eos_idx, const int64_t* targets, const float* h_init,
+                      const float* c_init, const float* ctx, const uint8_t* ctx_mask, int64_t* words,
+                      uint8_t* ended, float* step_scores, float* nll_term, float* live, float* logits,
+                      float* alpha, float* h1_tape, float* c1_tape, void* ws, size_t ws_bytes,
+                      sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && targets && h_init && c_init && ctx && words && ended && step_scores && nll_term && live &&
+                 B > 0 && n_steps > 0 && Tp > 0 && (feedback == 0 || feedback == 1) && (!h1_tape == !c1_tape));
+    if (!w->xw_table || !w->attn.w_in_t || !speaker_persistent_supported(B, H, Tp, vocab)) return SF_ERR_UNSUPPORTED;
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = S(stream);
+    float* cq = ar.take((size_t)B * Tp * H);
+    float* cw = ar.take((size_t)B * Tp * H);
+    float* xchg = ar.take(speaker_persistent_xchg_floats());
+    NEED(cq && cw && xchg && ar.tickets());
+    // cq = ctx W_in (so that ctx_l . (W_in h) = cq_l . h), cw = ctx W_c^T with W_c = linear_out[:, :H]
+    TRY(linear_plain(ctx, H, w->attn.w_in_t, H, nullptr, B * Tp, H, H, EPI_NONE, cq, H, ar, st));
+    TRY(linear_plain(ctx, H, w->attn.w_out, 2 * H, nullptr, B * Tp, H, H, EPI_NONE, cw, H, ar, st));
+    const int ldv = (vocab + 3) & ~3;
+    return speaker_persistent(w->lstm.w_hh, w->lstm.b_ih, w->lstm.b_hh, w->xw_table, w->attn.w_out, 2 * H, w->w_out,
+                              w->b_out, vocab, ldv, cq, cw, ctx_mask, h_init, c_init, targets, feedback, pad_idx,
+                              eos_idx, B, H, Tp, n_steps, words, step_scores, nll_term, live, logits, alpha, h1_tape,
+                              c1_tape, ended, xchg, ar.tickets() + PERSIST_TICKET, st);
+}
+
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H,
                            int Tp, int vocab, const float* h0, const float* c0, const float* ctx,
                            const sf_spk_decoder_tape* tp, const float* dlogit, const float* dh1,

@@ -52,6 +52,16 @@ int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
                        const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
                        float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
                        hipStream_t st);
+// the speaker's S word steps (inference) as one persistent launch; cq = ctx W_in, cw = ctx W_c^T [B,Tp,H]
+size_t speaker_persistent_xchg_floats();
+bool speaker_persistent_supported(int B, int H, int Tp, int vocab);
+int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
+                       const float* w_out, int ld_wout, const float* w_d2a, const float* b_d2a, int vocab, int ldv,
+                       const float* cq, const float* cw, const uint8_t* mask, const float* h_init,
+                       const float* c_init, const int64_t* targets, int feedback, int pad, int eos, int B, int H,
+                       int Tp, int S, int64_t* words, float* step_scores, float* nll_term, float* live,
+                       float* logits, float* alpha, float* h1_tape, float* c1_tape, uint8_t* ended, float* xchg,
+                       unsigned* done, hipStream_t st);
 // the backward recurrence (all T steps of lstm_bwd_step_fused): dgates [T,B,4H] out
 size_t encoder_bwd_persistent_xchg_floats();
 int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, int T, const float* gates,

@@ -511,6 +511,396 @@ __global__ __launch_bounds__(256) void enc_bwd_persist_prologue_kernel(unsigned*
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The speaker's word loop (Seq2SeqSpeaker._score_obs_actions_and_instructions, speaker.py:158-197 over
+// SpeakerDecoderLSTM.forward, model.py:487-519) for INFERENCE as one persistent launch: S word steps of
+//   LSTMCell -> attention over the path context -> tanh(linear_out) -> vocabulary projection ->
+//   log-softmax / next word (teacher or argmax) / score / NLL term / EOS flag
+// with the same partition as the encoder kernels (row group = XCD, 16 hidden units per workgroup)
+// and every weight slice register-resident.  Two identities keep the attention inside a workgroup:
+//   s_l = ctx_l . (W_in h1) = (ctx_l W_in) . h1            -> cq = ctx W_in     [B,Tp,H], once per call
+//   W_out [wc ; h1] = sum_l alpha_l (W_c ctx_l) + W_h h1   -> cw = ctx W_c^T    [B,Tp,H], once per call
+// so a workgroup needs only ITS 16 columns of cq / cw (registers) and the step has three exchanges
+// inside the row group: (1) h1 + the 16-column partial scores, (2) h~, (3) per-workgroup softmax
+// statistics of its 31-32 vocabulary columns (max, arg max, sum exp, target logit).
+// ------------------------------------------------------------------------------------------------
+constexpr int SP_TPMAX = 12;
+constexpr int SPX_H1 = 0;                                     // [16][512]
+constexpr int SPX_PS = EP_ROWS * 512;                         // [32 src][16][SP_TPMAX]
+constexpr int SPX_HT = SPX_PS + EP_SLOTS * EP_ROWS * SP_TPMAX;   // [16][512]
+constexpr int SPX_ST = SPX_HT + EP_ROWS * 512;                // [32 src][16][4]
+constexpr int SPX_BUF = SPX_ST + EP_SLOTS * EP_ROWS * 4;      // dwords per (group, buffer)
+
+struct SpkPersistArgs {
+    const float* w_hh; const float* b_ih; const float* b_hh; const float* xw_table;
+    const float* w_out; int ld_wout;                          // attention linear_out [H,2H]; W_h = columns H..2H
+    const float* w_d2a; const float* b_d2a; int vocab, ldv;
+    const float* cq; const float* cw;                         // [B,Tp,H]
+    const uint8_t* mask;                                      // [B,Tp], 1 = padded path step
+    const float* h_init; const float* c_init;
+    const int64_t* targets;                                   // [S,B]
+    int feedback, pad, eos;
+    int B, H, Tp, S, rpg;
+    int64_t* words;                                           // [S+1,B], row 0 given
+    float* step_scores; float* nll_term; float* live;         // [S,B]
+    float* logits; float* alpha; float* h1_tape; float* c1_tape;   // optional tapes
+    uint8_t* ended;
+    unsigned* xchg; unsigned* done; unsigned* place;
+    unsigned long long* trace;
+};
+
+template <class RS>
+__device__ __forceinline__ void xstore32(bool local, unsigned v, RS rs, unsigned off) {
+    if (local)
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, 0);
+    else
+        __builtin_amdgcn_raw_buffer_store_b32(v, rs, off, 0, AUX_SC1);
+}
+__device__ __forceinline__ float row16_sum(float v) {          // over the 16 lanes of a row
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
+    return v;
+}
+__device__ __forceinline__ float wexp(float m, float mm) { return m == -INFINITY ? 0.f : expf(m - mm); }
+__device__ __forceinline__ float row16_max(float v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 16));
+    return v;
+}
+
+__global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
+    __shared__ float s_part[4][5][256];
+    __shared__ float s_voc[4][2][256];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int grp = blockIdx.x & (EP_GROUPS - 1), slot = blockIdx.x >> 3;
+    const int H = p.H, B = p.B, Tp = p.Tp, S = p.S, vocab = p.vocab;
+    const int row0 = grp * p.rpg;
+    const int nrows = max(0, min(p.rpg, B - row0));
+    // ---- resident weights
+    float4 wf[5][8];                                    // K-quarter w of: 4 gate tiles, W_h tile
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int k = 16 * (8 * w + i) + 4 * kk;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) wf[g][i] = ld4(p.w_hh + (size_t)(g * H + 16 * slot + li) * H + k);
+        wf[4][i] = ld4(p.w_out + (size_t)(16 * slot + li) * p.ld_wout + H + k);
+    }
+    float4 wv[2][8];                                    // both vocabulary tiles, this wave's K-quarter
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int vrow = min(32 * slot + 16 * nt + li, vocab - 1);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) wv[nt][i] = ld4(p.w_d2a + (size_t)vrow * H + 16 * (8 * w + i) + 4 * kk);
+    }
+    const int er = tid >> 4, eu = tid & 15;
+    const bool evalid = er < nrows;
+    const int eb = evalid ? row0 + er : B - 1;
+    const int ej = 16 * slot + eu;
+    float bias[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) bias[g] = p.b_ih[g * H + ej] + p.b_hh[g * H + ej];
+    float cqr[SP_TPMAX], cwr[SP_TPMAX];
+#pragma unroll
+    for (int l = 0; l < SP_TPMAX; ++l) {
+        const int lc = min(l, Tp - 1);
+        const float q = p.cq[((size_t)eb * Tp + lc) * H + ej], c = p.cw[((size_t)eb * Tp + lc) * H + ej];
+        cqr[l] = l < Tp ? q : 0.f;
+        cwr[l] = l < Tp ? c : 0.f;
+    }
+    const bool masked = eu < Tp ? (p.mask && p.mask[(size_t)eb * Tp + eu] != 0) : true;   // lane eu <-> path step eu
+    const int col0 = 32 * slot + eu, col1 = col0 + 16;
+    const float bv0 = col0 < vocab ? p.b_d2a[col0] : 0.f, bv1 = col1 < vocab ? p.b_d2a[col1] : 0.f;
+    float c_state = p.c_init[(size_t)eb * H + ej];
+    long long wprev = p.words[eb];
+    const size_t BH = (size_t)B * H;
+
+    unsigned* xg = p.xchg + (size_t)grp * 3 * SPX_BUF;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(xg, 0, 3 * SPX_BUF * 4, 0x00020000);
+    const bool local = group_on_one_xcd(p.place, grp);
+    bool dead = false;
+    const unsigned patch = (unsigned)(er * H + ej);      // own [16 x 16] patch inside a [16][512] block
+    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();
+
+    // recurrent part of step 0: h_init W_hh^T (plain loads: h_init is complete before the launch)
+    float R[4];
+    {
+        const int arow = li < nrows ? row0 + li : B - 1;
+        f32x4 acc[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 af = ld4(p.h_init + (size_t)arow * H + 16 * (8 * w + i) + 4 * kk);
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) acc[g] = mfma16(comp(af, c), comp(wf[g][i], c), acc[g]);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) s_part[w][g][(kk * 4 + r) * 16 + li] = acc[g][r];
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < 4; ++g) R[g] = (s_part[0][g][tid] + s_part[1][g][tid]) + (s_part[2][g][tid] + s_part[3][g][tid]);
+    }
+    float xv[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) xv[g] = p.xw_table[(size_t)wprev * 4 * H + g * H + ej];
+
+    for (int t = 0; t < S; ++t) {
+        const unsigned bo = (unsigned)((t % 3) * SPX_BUF);               // this step's buffer (dwords)
+        const unsigned bn = (unsigned)(((t + 2) % 3) * SPX_BUF);         // the one two steps ahead
+        EP_STAMP(7)
+        // ---- A. LSTM cell (model.py:515)
+        const float ig = sigmoidf_(bias[0] + xv[0] + R[0]), fg = sigmoidf_(bias[1] + xv[1] + R[1]);
+        const float gg = tanhf(bias[2] + xv[2] + R[2]), og = sigmoidf_(bias[3] + xv[3] + R[3]);
+        c_state = fg * c_state + ig * gg;
+        float h1 = og * tanhf(c_state);
+        if (dead) h1 = __uint_as_float(0x7FC00000u);
+        // ---- B. publish h1 and this workgroup's share of the attention scores
+        {
+            const float hp = evalid ? h1 : 0.f;
+            float ps = 0.f;
+#pragma unroll
+            for (int l = 0; l < SP_TPMAX; ++l) {
+                const float v = row16_sum(cqr[l] * hp);
+                ps = eu == l ? v : ps;
+            }
+            const float h_1 = __shfl_down(hp, 1), h_2 = __shfl_down(hp, 2), h_3 = __shfl_down(hp, 3);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if ((tid & 3) == 0)
+                xstore(local, v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)},
+                       rs, (bo + SPX_H1 + patch) * 4u);
+            if (eu < SP_TPMAX)
+                xstore32(local, __float_as_uint(ps), rs, (bo + SPX_PS + (unsigned)((slot * EP_ROWS + er) * SP_TPMAX + eu)) * 4u);
+        }
+        if (evalid && p.h1_tape) {                       // tapes AFTER the publish: nothing waits on them for a step
+            p.h1_tape[(size_t)t * BH + (size_t)eb * H + ej] = h1;
+            p.c1_tape[(size_t)t * BH + (size_t)eb * H + ej] = c_state;
+        }
+        EP_STAMP(0)                                      // cell + partial scores + publish
+        // ---- C. gather h1 (this wave's K-quarter) and the 32 partial scores of (row er, path step eu)
+        v4u a[8];
+        unsigned sc[EP_SLOTS];
+        {
+            const unsigned ab = (bo + SPX_H1 + (unsigned)(li * H)) * 4u;
+            const unsigned sb = (bo + SPX_PS + (unsigned)(er * SP_TPMAX + min(eu, SP_TPMAX - 1))) * 4u;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                asm volatile("" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    a[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, ab + (unsigned)((16 * (8 * w + i) + 4 * kk) * 4), 0, AUX_SC1);
+#pragma unroll
+                for (int c = 0; c < EP_SLOTS; ++c)
+                    sc[c] = __builtin_amdgcn_raw_buffer_load_b32(rs, sb + (unsigned)(c * EP_ROWS * SP_TPMAX * 4), 0, AUX_SC1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    ok = ok && a[i].x != EP_SENTINEL && a[i].y != EP_SENTINEL && a[i].z != EP_SENTINEL && a[i].w != EP_SENTINEL;
+#pragma unroll
+                for (int c = 0; c < EP_SLOTS; ++c) ok = ok && sc[c] != EP_SENTINEL;
+                if (__all(ok) || dead) break;
+                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) { dead = true; break; }
+            }
+        }
+        EP_STAMP(1)                                      // wait for h1 + scores
+        // everyone in the group has finished step t-1: reset the own regions of the buffer of step t+2
+        if ((tid & 3) == 0) {
+            xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs, (bn + SPX_H1 + patch) * 4u);
+            xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs, (bn + SPX_HT + patch) * 4u);
+        }
+        if (eu < SP_TPMAX)
+            xstore32(local, EP_SENTINEL, rs, (bn + SPX_PS + (unsigned)((slot * EP_ROWS + er) * SP_TPMAX + eu)) * 4u);
+        if (tid < EP_ROWS)
+            xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
+                   (bn + SPX_ST + (unsigned)((slot * EP_ROWS + tid) * 4)) * 4u);
+        // attention weights of row er: lane eu holds path step eu (model.py:131-137)
+        float alpha_l;
+        {
+            float sl = 0.f;
+#pragma unroll
+            for (int c = 0; c < EP_SLOTS; ++c) sl += __uint_as_float(sc[c]);
+            sl = masked ? -INFINITY : sl;
+            const float m = row16_max(sl);
+            const float e = masked ? 0.f : expf(sl - m);
+            alpha_l = e / row16_sum(e);
+            if (slot == 0 && evalid && eu < Tp && p.alpha) p.alpha[((size_t)t * B + eb) * Tp + eu] = alpha_l;
+        }
+        // ---- D. [next step's recurrent gates | W_h h1] = h1 . [W_hh ; W_h]^T over this wave's K-quarter
+        {
+            f32x4 acc[5];
+#pragma unroll
+            for (int g = 0; g < 5; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 af = make_float4(__uint_as_float(a[i].x), __uint_as_float(a[i].y),
+                                              __uint_as_float(a[i].z), __uint_as_float(a[i].w));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 5; ++g) acc[g] = mfma16(comp(af, c), comp(wf[g][i], c), acc[g]);
+            }
+            __syncthreads();                             // s_part of the previous use fully consumed
+#pragma unroll
+            for (int g = 0; g < 5; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_part[w][g][(kk * 4 + r) * 16 + li] = acc[g][r];
+            __syncthreads();
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) R[g] = (s_part[0][g][tid] + s_part[1][g][tid]) + (s_part[2][g][tid] + s_part[3][g][tid]);
+        EP_STAMP(2)                                      // softmax + MFMA (5 tiles) + LDS reduce
+        // ---- E. h~ = tanh(sum_l alpha_l cw_l + W_h h1)   (model.py:139-141, folded)
+        float ht = (s_part[0][4][tid] + s_part[1][4][tid]) + (s_part[2][4][tid] + s_part[3][4][tid]);
+#pragma unroll
+        for (int l = 0; l < SP_TPMAX; ++l) ht += __shfl(alpha_l, (lane & 48) + l, 64) * cwr[l];
+        ht = tanhf(ht);
+        {
+            const float hp = evalid ? ht : 0.f;
+            const float h_1 = __shfl_down(hp, 1), h_2 = __shfl_down(hp, 2), h_3 = __shfl_down(hp, 3);
+            if ((tid & 3) == 0)      // (its region was reset two steps ago, behind the drain of step t-1's publish)
+                xstore(local, v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)},
+                       rs, (bo + SPX_HT + patch) * 4u);
+        }
+        EP_STAMP(3)                                      // h~ + publish
+        // ---- F. vocabulary projection of this workgroup's 32 columns (model.py:518)
+        {
+            v4u av[8];
+            const unsigned hb = (bo + SPX_HT + (unsigned)(li * H)) * 4u;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                asm volatile("" ::: "memory");
+                bool ok = true;
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    av[i] = __builtin_amdgcn_raw_buffer_load_b128(rs, hb + (unsigned)((16 * (8 * w + i) + 4 * kk) * 4), 0, AUX_SC1);
+#pragma unroll
+                for (int i = 0; i < 8; ++i)
+                    ok = ok && av[i].x != EP_SENTINEL && av[i].y != EP_SENTINEL && av[i].z != EP_SENTINEL && av[i].w != EP_SENTINEL;
+                if (__all(ok) || dead) break;
+                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) { dead = true; break; }
+            }
+            EP_STAMP(4)                                  // wait for h~
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 af = make_float4(__uint_as_float(av[i].x), __uint_as_float(av[i].y),
+                                              __uint_as_float(av[i].z), __uint_as_float(av[i].w));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) acc[nt] = mfma16(comp(af, c), comp(wv[nt][i], c), acc[nt]);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_voc[w][nt][(kk * 4 + r) * 16 + li] = acc[nt][r];
+            __syncthreads();
+        }
+        const float l0 = (s_voc[0][0][tid] + s_voc[1][0][tid]) + (s_voc[2][0][tid] + s_voc[3][0][tid]) + bv0;
+        const float l1 = (s_voc[0][1][tid] + s_voc[1][1][tid]) + (s_voc[2][1][tid] + s_voc[3][1][tid]) + bv1;
+        if (evalid && p.logits) {
+            float* lp = p.logits + ((size_t)t * B + eb) * p.ldv;
+            if (col0 < vocab) lp[col0] = l0;
+            if (col1 < vocab) lp[col1] = l1;
+        }
+        // ---- G. softmax statistics of these 32 columns for row er (speaker.py:163-182)
+        const long long tgt = p.targets[(size_t)t * B + eb];
+        {
+            const float x0 = col0 < vocab ? l0 : -INFINITY, x1 = col1 < vocab ? l1 : -INFINITY;
+            float m = x0;
+            int am = col0;
+            if (x1 > m) { m = x1; am = col1; }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const float om = __shfl_xor(m, off, 16);
+                const int oa = __shfl_xor(am, off, 16);
+                if (om > m || (om == m && oa < am)) { m = om; am = oa; }
+            }
+            const float se = row16_sum((col0 < vocab ? expf(l0 - m) : 0.f) + (col1 < vocab ? expf(l1 - m) : 0.f));
+            const float tl = row16_sum((col0 == tgt ? l0 : 0.f) + (col1 == tgt ? l1 : 0.f));
+            if (eu == 0)
+                xstore(local, v4u{__float_as_uint(m), (unsigned)am, __float_as_uint(se), __float_as_uint(tl)}, rs,
+                       (bo + SPX_ST + (unsigned)((slot * EP_ROWS + er) * 4)) * 4u);
+        }
+        EP_STAMP(5)                                      // vocabulary MFMA + statistics + publish
+        // ---- H. combine the 32 workgroups' statistics: every lane of row er learns the word
+        float M, Z, tlog;
+        int arg;
+        {
+            v4u s0, s1;
+            const unsigned sb0 = (bo + SPX_ST + (unsigned)((eu * EP_ROWS + er) * 4)) * 4u;
+            const unsigned sb1 = (bo + SPX_ST + (unsigned)(((eu + 16) * EP_ROWS + er) * 4)) * 4u;
+            const long long t0 = wall_clock64();
+            for (;;) {
+                asm volatile("" ::: "memory");
+                s0 = __builtin_amdgcn_raw_buffer_load_b128(rs, sb0, 0, AUX_SC1);
+                s1 = __builtin_amdgcn_raw_buffer_load_b128(rs, sb1, 0, AUX_SC1);
+                const bool ok = s0.x != EP_SENTINEL && s0.z != EP_SENTINEL && s1.x != EP_SENTINEL && s1.z != EP_SENTINEL &&
+                                s0.w != EP_SENTINEL && s1.w != EP_SENTINEL && s0.y != EP_SENTINEL && s1.y != EP_SENTINEL;
+                if (__all(ok) || dead) break;
+                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) { dead = true; break; }
+            }
+            float m0 = __uint_as_float(s0.x), m1 = __uint_as_float(s1.x);
+            int a0 = (int)s0.y, a1 = (int)s1.y;
+            float z0 = __uint_as_float(s0.z), z1 = __uint_as_float(s1.z);
+            M = m0; arg = a0; Z = z0;
+            if (m1 > M || (m1 == M && a1 < arg)) { arg = a1; }
+            {
+                const float mm = fmaxf(m0, m1);
+                Z = z0 * wexp(m0, mm) + z1 * wexp(m1, mm);
+                M = mm;
+            }
+#pragma unroll
+            for (int off = 8; off > 0; off >>= 1) {
+                const float om = __shfl_xor(M, off, 16), oz = __shfl_xor(Z, off, 16);
+                const int oa = __shfl_xor(arg, off, 16);
+                const float mm = fmaxf(M, om);
+                Z = Z * wexp(M, mm) + oz * wexp(om, mm);
+                if (om > M || (om == M && oa < arg)) arg = oa;
+                M = mm;
+            }
+            const int ts = (int)min(max(tgt, 0LL), (long long)vocab - 1) >> 5;        // workgroup that owns the target column
+            const float mine = (ts & 16) ? __uint_as_float(s1.w) : __uint_as_float(s0.w);
+            tlog = __shfl(mine, (lane & 48) + (ts & 15), 64);
+        }
+        EP_STAMP(6)                                      // wait for the statistics + combine
+        const float lse = M + logf(Z);
+        const long long wt = p.feedback == 0 ? tgt : (long long)arg;
+        const float lw = p.feedback == 0 ? tlog : M;
+        if (slot == 0 && eu == 0 && evalid) {
+            const size_t o = (size_t)t * B + eb;
+            p.words[(size_t)(t + 1) * B + eb] = wt;
+            float scv = wt != p.pad ? lw - lse : 0.f;
+            float nl = tgt != p.pad ? lse - tlog : 0.f;
+            if (dead) scv = nl = __uint_as_float(0x7FC00000u);
+            p.step_scores[o] = scv;
+            p.nll_term[o] = nl;
+            p.live[o] = tgt != p.pad ? 1.f : 0.f;
+            if (wt == p.eos) p.ended[eb] = 1;
+        }
+        wprev = wt;
+        // ---- I. input row of the next step (model.py:497 + the hoisted W_ih product)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) xv[g] = p.xw_table[(size_t)wprev * 4 * H + g * H + ej];
+    }
+    if (p.trace && lane == 0 && w == 0) {
+#pragma unroll
+        for (int kx = 0; kx < 8; ++kx) p.trace[blockIdx.x * 8 + kx] = (unsigned long long)tk[kx];
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned n = atomicAdd(p.done, 1u);
+        if (n == gridDim.x - 1) {
+            atomicExch(p.done, 0u);
+            atomicExch(&g_persist_lock, 0u);
+        }
+    }
+}
+
 int device_cus() {
     static thread_local int cached_dev = -1, cached = 0;
     int dev = 0;
@@ -546,6 +936,34 @@ int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
     SF_LAUNCH(enc_persist_prologue_kernel, dim3(96), dim3(256), 0, st, a.xchg, encoder_persistent_xchg_floats(H),
               hs, cs, (size_t)B * H, a.place);
     SF_LAUNCH(enc_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
+    return launch_status();
+}
+
+size_t speaker_persistent_xchg_floats() { return (size_t)EP_GROUPS * 3 * SPX_BUF; }
+bool speaker_persistent_supported(int B, int H, int Tp, int vocab) {
+    return H == 16 * EP_SLOTS && B >= 1 && B <= EP_GROUPS * EP_ROWS && Tp >= 1 && Tp <= SP_TPMAX && vocab >= 32 &&
+           vocab <= 32 * EP_SLOTS && device_cus() >= EP_GROUPS * EP_SLOTS;
+}
+
+int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
+                       const float* w_out, int ld_wout, const float* w_d2a, const float* b_d2a, int vocab, int ldv,
+                       const float* cq, const float* cw, const uint8_t* mask, const float* h_init,
+                       const float* c_init, const int64_t* targets, int feedback, int pad, int eos, int B, int H,
+                       int Tp, int S, int64_t* words, float* step_scores, float* nll_term, float* live,
+                       float* logits, float* alpha, float* h1_tape, float* c1_tape, uint8_t* ended, float* xchg,
+                       unsigned* done, hipStream_t st) {
+    if (!speaker_persistent_supported(B, H, Tp, vocab) || !xchg || !done || !xw_table) return SF_ERR_UNSUPPORTED;
+    SpkPersistArgs a{};
+    a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.xw_table = xw_table; a.w_out = w_out; a.ld_wout = ld_wout;
+    a.w_d2a = w_d2a; a.b_d2a = b_d2a; a.vocab = vocab; a.ldv = ldv; a.cq = cq; a.cw = cw; a.mask = mask;
+    a.h_init = h_init; a.c_init = c_init; a.targets = targets; a.feedback = feedback; a.pad = pad; a.eos = eos;
+    a.B = B; a.H = H; a.Tp = Tp; a.S = S; a.rpg = ceil_div(B, EP_GROUPS); a.words = words;
+    a.step_scores = step_scores; a.nll_term = nll_term; a.live = live; a.logits = logits; a.alpha = alpha;
+    a.h1_tape = h1_tape; a.c1_tape = c1_tape; a.ended = ended; a.xchg = reinterpret_cast<unsigned*>(xchg);
+    a.done = done; a.place = done + 4; a.trace = g_trace;
+    SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(256), dim3(256), 0, st, a.xchg, speaker_persistent_xchg_floats(),
+              a.place);
+    SF_LAUNCH(spk_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }
 

@@ -668,7 +668,8 @@ class SpeakerDecoderLSTM(nn.Module):
             v = _grads(ps[1:])
             return _lib.SpkDecoderG(_lib.LstmW(*v[0:4]), _lib.SoftdotW(*v[4:6]), v[6], v[7])
         v = [p.data_ptr() for p in ps]
-        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5]), _lib.SoftdotW(*v[5:7]), v[7], v[8],
+        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5]),
+                                _lib.SoftdotW(v[5], v[6], transposed(ps[5]).data_ptr(), None), v[7], v[8],
                                 self._xw_table().data_ptr())
 
     def _xw_table(self):

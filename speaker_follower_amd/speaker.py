@@ -83,6 +83,7 @@ class SpeakerEngine:
         self.iteration = 0
         self.site_next = 0              # first unused dropout site (see score)
         self.dropout_seed = None
+        self.persistent = True          # inference passes: the whole word loop as ONE launch (sf_speaker_decode)
 
     def capture(self, batch, steps, feedback='teacher'):
         """hipGraph of one inference scoring / decoding pass: returns (replay, state); the state's
@@ -179,7 +180,19 @@ class SpeakerEngine:
         st.targets = batch.instr_seq[:, :S].t().contiguous()              # [S,B] (speaker.py:163)
         params = list(ep) + [enc.encoder2decoder.weight, enc.encoder2decoder.bias] + list(dec._params9())
         differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        for t in range(S):
+        persistent = False
+        if self.persistent and not training and not differentiable:
+            # inference: all S word steps in one persistent launch (csrc/sf_persist.hip)
+            rc = _lib.lib.sf_speaker_decode(
+                byref(dw), B, H, Tp, vocab, S, st.feedback, PAD, EOS, ptr(st.targets), ptr(st.h_init),
+                ptr(st.c_init), ptr(st.ctx), ptr(batch.path_mask), ptr(st.words), ptr(st.ended),
+                ptr(st.step_scores), ptr(st.nll_term), ptr(st.live), ptr(st.tape['logit']),
+                ptr(st.tape['alpha']), ptr(st.tape['h1']), ptr(st.tape['c1']), *ws)
+            if rc != 2:                                   # SF_ERR_UNSUPPORTED: shapes outside the kernel
+                _lib.check(rc, 'sf_speaker_decode')
+                persistent = True
+        st.persistent = persistent
+        for t in range(0 if not persistent else S, S):
             # the embedded words are only kept for the backward (dW_ih); the forward looks the
             # input product up in the [vocab,4H] table (sf_spk_decoder_w.xw_table)
             tp = _lib.SpkDecoderTape(*(st.tape[k][t].data_ptr() if (k != 'emb' or differentiable)

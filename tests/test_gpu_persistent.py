@@ -174,3 +174,78 @@ def test_persistent_backward_is_the_kernel_that_runs():
     names = ' '.join(prof.rows)
     assert 'enc_bwd_persist_kernel' in names and 'lstm_bwd_step' not in names, names
     print({k: round(v['avg_us'], 1) for k, v in prof.rows.items() if 'persist' in k}, 'T =', T)
+
+
+# ---------------------------------------------------------------------------------- speaker word loop
+def speaker_setup(B, seed=404, peaky=True):
+    from speaker_follower_amd import model, features, speaker
+    d = synth.FULL
+    senc_w, sdec_w = (synth.speaker_weights_peaky if peaky else synth.speaker_weights)(seed)
+    enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'])
+    enc.load_state_dict({k: torch.tensor(v) for k, v in senc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in sdec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    sb = synth.speaker_batch(seed=B + 1, batch=B, n_viewpoints=128, min_len=5, max_len=60)
+    store = features.FeatureStore(synth.feature_table(8, 128))
+    return enc, dec, store, speaker.DeviceSpeakerBatch.from_synth(sb)
+
+
+@pytest.mark.parametrize('B,feedback,peaky', [(100, 'argmax', True), (100, 'teacher', True), (37, 'argmax', False),
+                                              (128, 'teacher', False), (5, 'argmax', True)])
+def test_persistent_speaker_decode_matches_per_step(B, feedback, peaky):
+    """sf_speaker_decode (one launch for S word steps, folded attention) against S x
+    (sf_speaker_decoder_fwd + sf_speaker_glue_fwd): identical words, logits within 1e-4 of their
+    scale, scores / NLL terms / attention / final state to 1e-4."""
+    from speaker_follower_amd import speaker
+    enc, dec, store, batch = speaker_setup(B, peaky=peaky)
+    S = 40
+    out = []
+    for persistent in (False, True):
+        eng = speaker.SpeakerEngine(enc, dec, store)
+        eng.persistent = persistent
+        with torch.no_grad():
+            st = eng.score(batch, S, feedback, train=False)
+        assert st.persistent == persistent
+        out.append(st)
+    a, b = out
+    torch.cuda.synchronize()
+    assert torch.equal(a.words, b.words)
+    la, lb = a.logits.cpu().numpy(), b.logits.cpu().numpy()
+    assert float(np.abs(la - lb).max()) <= 1e-4 * float(np.abs(la).max())
+    np.testing.assert_allclose(b.step_scores.cpu().numpy(), a.step_scores.cpu().numpy(), rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(b.nll_term.cpu().numpy(), a.nll_term.cpu().numpy(), rtol=1e-4, atol=2e-4)
+    assert torch.equal(a.live, b.live) and torch.equal(a.ended, b.ended)
+    np.testing.assert_allclose(b.tape['alpha'].cpu().numpy(), a.tape['alpha'].cpu().numpy(), rtol=1e-3, atol=2e-5)
+    np.testing.assert_allclose(b.h.cpu().numpy(), a.h.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(b.c.cpu().numpy(), a.c.cpu().numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(float(b.loss), float(a.loss), rtol=1e-5)
+
+
+def test_persistent_speaker_decode_timing_and_graph():
+    from speaker_follower_amd import speaker, _lib
+    enc, dec, store, batch = speaker_setup(100)
+    res = {}
+    for persistent in (False, True):
+        eng = speaker.SpeakerEngine(enc, dec, store)
+        eng.persistent = persistent
+        replay, gst = eng.capture(batch, 80, 'argmax')
+        for _ in range(3):
+            replay()
+        torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        for _ in range(10):
+            replay()
+        torch.cuda.synchronize()
+        res[persistent] = ((time.perf_counter() - t0) / 10, gst.words.clone())
+    assert torch.equal(res[True][1], res[False][1])
+    print('speaker 100 x 80 greedy words: per-step %.2f ms, persistent %.2f ms' % (1e3 * res[False][0], 1e3 * res[True][0]))
+    with torch.no_grad():
+        eng = speaker.SpeakerEngine(enc, dec, store)
+        eng.score(batch, 80, 'argmax', train=False)
+        with _lib.kernel_profile() as prof:
+            eng.score(batch, 80, 'argmax', train=False)
+    print({k: round(v['avg_us'], 1) for k, v in prof.rows.items() if 'persist' in k})
+    assert res[True][0] < res[False][0]
