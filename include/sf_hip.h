@@ -400,7 +400,9 @@ int sf_loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, sf
  * Packed-sequence semantics: row b advances for t < lengths[b]; ctx [B,T,H] is zero beyond.
  * Writes ctx (dropout site `drop_stream` when training), decoder_init = tanh(W h_T + b), c_T.
  * tape: emb_t [T,B,E], xg [T,B,4H] (hoisted input product), gates [T,B,4H], hs [T+1,B,H],
- * cs [T+1,B,H] (state before/after every step). */
+ * cs [T+1,B,H] (state before/after every step).  An INFERENCE call (no backward to follow) with
+ * w->xw_table may pass emb = NULL and gates = NULL: the embedded tokens and the gate tape are then not
+ * written (hs / cs are still needed as working storage). */
 typedef struct sf_encoder_w {
     const float* embedding; /* [vocab,E] */
     sf_lstm_w lstm;         /* weight_ih_l0 [4H,E] ... */
@@ -562,8 +564,8 @@ int sf_nav_step(const sf_nav_table* nav, int B, const int32_t* row, const int32_
                 int64_t* target_next, sf_stream stream);
 
 /* In-process kernel timing (no reference counterpart; what bench.py's `roofline.kernels` table is
- * measured with).  Between sf_profile_begin() and sf_profile_end() every kernel the CALLING host
- * thread launches through this library carries a start and a stop event on its own dispatch, so a
+ * measured with).  Between sf_profile_begin() and sf_profile_end() every kernel ANY host thread of the
+ * process launches through this library (torch runs backward() on its own thread) carries a start and a stop event on its own dispatch, so a
  * pair's elapsed time is that kernel's execution time on the stream it ran on (the figure rocprofv3
  * --kernel-trace reports).  Not usable during hipGraph stream capture.  sf_profile_end waits for the
  * recorded kernels, writes one text line per kernel name -- "name\tcalls\ttotal_us\tmin_us\tmax_us\n"

@@ -7,6 +7,7 @@
 using namespace sf;
 
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -22,10 +23,12 @@ struct Prof {
     std::vector<hipEvent_t> pool;      // events are created once and reused by later sessions
     size_t used = 0;
 };
-thread_local Prof g_prof;
+Prof g_prof;                 // process-wide: torch runs backward() on its own host thread
+std::mutex g_prof_mutex;
 }  // namespace
 bool prof_active() { return g_prof.active; }
 void prof_events(const char* name, hipEvent_t* e0, hipEvent_t* e1) {
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     Prof& p = g_prof;
     while (p.pool.size() < p.used + 2) {
         hipEvent_t e = nullptr;
@@ -1092,10 +1095,13 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
     const size_t BH = (size_t)B * H;
-    // model.py:85  embedding, time-major so each step reads one contiguous [B,E] block
-    TRY(embedding_tm(w->embedding, E, seq, B, Lpad, T, tp->emb, st));
+    // model.py:85  embedding, time-major so each step reads one contiguous [B,E] block (kept for the
+    // backward's dW_ih; an inference call with the input-product table passes tape->emb = NULL)
+    SF_CHECK_ARG(tp->emb || w->xw_table);
+    if (tp->emb) TRY(embedding_tm(w->embedding, E, seq, B, Lpad, T, tp->emb, st));
     // input product: a row of the host's [vocab,4H] table per token, or hoisted for all steps at
     // once ([T*B,E] x [E,4H])
+    if (!w->xw_table) SF_CHECK_ARG(tp->emb && tp->xg);
     if (!w->xw_table)
         TRY(linear_plain(tp->emb, E, w->lstm.w_ih, E, nullptr, T * B, 4 * H, E, EPI_NONE, tp->xg,
                          4 * H, ar, st));
@@ -1108,7 +1114,7 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
         if (xchg && ar.tickets()) {
             TRY(encoder_persistent(w->lstm.w_hh, w->lstm.b_ih, w->lstm.b_hh, w->xw_table, seq, Lpad, lengths, B,
                                    H, T, tp->gates, tp->hs, tp->cs, ctx, dctx, xchg,
-                                   ar.tickets() + PERSIST_TICKET, st));
+                                   ar.tickets() + PERSIST_TICKET, st, c_t));
             persistent = true;
         }
     }
@@ -1128,7 +1134,7 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
         f.b_ih = w->lstm.b_ih; f.b_hh = w->lstm.b_hh; f.B = B; f.H = H;
         LstmPwFwd& p = f.pw;
         p.c0 = tp->cs + t * BH; p.h0 = tp->hs + t * BH; p.B = B; p.H = H;
-        p.gates = tp->gates + (size_t)t * B * 4 * H;
+        p.gates = tp->gates ? tp->gates + (size_t)t * B * 4 * H : nullptr;
         p.h1 = tp->hs + (t + 1) * BH; p.c1 = tp->cs + (t + 1) * BH;
         p.h1_drop = nullptr; p.drop = make_dropout(nullptr, 0);
         p.lengths = lengths; p.t = t; p.ctx_out = ctx; p.ld_ctx = T * H; p.ctx_drop = dctx;
@@ -1137,6 +1143,7 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     // model.py:96-99  decoder_init = tanh(encoder2decoder(h_T)); c_T raw
     TRY(linear_plain(tp->hs + T * BH, H, w->w_e2d, H, w->b_e2d, B, H, H, EPI_TANH, decoder_init, H,
                      ar, st));
+    if (persistent) return SF_OK;                 // (the persistent launch wrote c_T itself)
     return add2(tp->cs + T * BH, H, nullptr, 0, B, H, c_t, H, st);
 }
 
@@ -1404,6 +1411,7 @@ int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float
 // ---- in-process kernel timing ---------------------------------------------------------------------
 int sf_profile_begin(void) {
     SF_ENTER();
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     if (g_prof.active) return SF_ERR_ARG;
     g_prof.recs.clear();
     g_prof.used = 0;
@@ -1413,6 +1421,7 @@ int sf_profile_begin(void) {
 
 long sf_profile_end(char* buf, size_t cap) {
     SF_ENTER();
+    std::lock_guard<std::mutex> lock(g_prof_mutex);
     if (!g_prof.active) return -1;
     g_prof.active = false;
     struct Row { long calls = 0; double total = 0, mn = 1e30, mx = 0; };

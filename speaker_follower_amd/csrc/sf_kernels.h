@@ -51,7 +51,7 @@ bool encoder_persistent_supported(int B, int H, int T);
 int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
                        const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
                        float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
-                       hipStream_t st);
+                       hipStream_t st, float* c_out = nullptr);
 // the speaker's S word steps (inference) as one persistent launch; cq = ctx W_in, cw = ctx W_c^T [B,Tp,H]
 size_t speaker_persistent_xchg_floats();
 bool speaker_persistent_supported(int B, int H, int Tp, int vocab);

@@ -109,6 +109,7 @@ struct EncPersistArgs {
     int B, H, T, rpg;                                          // rpg = rows per group
     float* gates; float* hs; float* cs;                        // tapes [T,B,4H], [T+1,B,H] x2
     float* ctx; int ld_ctx; Dropout ctx_drop;                  // ctx[b, t, :], row stride T*H
+    float* c_out;                                              // [B,H] final cell state (c_T), or null
     unsigned* xchg;                                            // [8][3][16][H] dwords, sentinel-filled
     unsigned* done;                                            // arrival counter (0 before and after)
     unsigned* place;                                           // placement record (group_on_one_xcd)
@@ -116,7 +117,8 @@ struct EncPersistArgs {
 };
 
 __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
-    __shared__ float s_red[8][4][256];                  // paired K-slice partials R_k of the 4 gates
+    __shared__ float s_red[2][8][4][256];               // paired K-slice partials R_k of the 4 gates, double
+                                                        // buffered by step parity: ONE barrier per step
     __shared__ int s_tok[EP_ROWS][EP_TMAX];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -217,7 +219,6 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) xn[g] = p.xw_table[(size_t)tok * 4 * H + g * H + ej];
             }
-            __syncthreads();                             // s_red of the previous step fully consumed
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
                 f32x4 acc[4][2];
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
                 for (int g = 0; g < 4; ++g) {
                     const f32x4 Rk = acc[g][1] + acc[g][0];
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s_red[w + 4 * h2][g][(kk * 4 + r) * 16 + li] = Rk[r];
+                    for (int r = 0; r < 4; ++r) s_red[t & 1][w + 4 * h2][g][(kk * 4 + r) * 16 + li] = Rk[r];
                 }
             }
         } else {
@@ -257,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) s_red[w + 4 * h2][g][(kk * 4 + r) * 16 + li] = 0.f;
+                    for (int r = 0; r < 4; ++r) s_red[t & 1][w + 4 * h2][g][(kk * 4 + r) * 16 + li] = 0.f;
         }
         __syncthreads();
         EP_STAMP(1)                                      // MFMAs + partials to LDS + barrier
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
         for (int g = 0; g < 4; ++g) {
             float v = bias[g] + xv[g];
 #pragma unroll
-            for (int k = 0; k < 8; ++k) v += s_red[k][g][tid];
+            for (int k = 0; k < 8; ++k) v += s_red[t & 1][k][g][tid];
             g4[g] = v;
         }
         const float ig = sigmoidf_(g4[0]), fg = sigmoidf_(g4[1]), gg = tanhf(g4[2]), og = sigmoidf_(g4[3]);
@@ -294,8 +295,11 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
             if (live && p.ctx_drop.on())
                 cv = dropout_keep(rk, (uint32_t)(t * H + ej), p.ctx_drop.thresh) ? cv * p.ctx_drop.scale : 0.f;
             p.ctx[(size_t)eb * p.ld_ctx + (size_t)t * H + ej] = cv;
-            p.cs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = c1;
-            p.hs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = h1;
+            if (p.gates || t == T - 1) {                 // inference (no gates tape): only the final state
+                p.cs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = c1;
+                p.hs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = h1;
+            }
+            if (t == T - 1 && p.c_out) p.c_out[(size_t)eb * H + ej] = c1;
         }
         c_state = c1;
         h_state = h1;
@@ -926,12 +930,12 @@ bool encoder_persistent_supported(int B, int H, int T) {
 int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
                        const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
                        float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
-                       hipStream_t st) {
+                       hipStream_t st, float* c_out) {
     if (!encoder_persistent_supported(B, H, T) || !xw_table || !xchg || !done) return SF_ERR_UNSUPPORTED;
     EncPersistArgs a{};
     a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.xw_table = xw_table; a.seq = seq; a.Lpad = Lpad;
     a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
-    a.gates = gates; a.hs = hs; a.cs = cs; a.ctx = ctx; a.ld_ctx = T * H; a.ctx_drop = ctx_drop;
+    a.gates = gates; a.hs = hs; a.cs = cs; a.ctx = ctx; a.ld_ctx = T * H; a.ctx_drop = ctx_drop; a.c_out = c_out;
     a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
     SF_LAUNCH(enc_persist_prologue_kernel, dim3(96), dim3(256), 0, st, a.xchg, encoder_persistent_xchg_floats(H),
               hs, cs, (size_t)B * H, a.place);

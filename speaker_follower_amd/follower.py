@@ -174,9 +174,13 @@ class FollowerEngine:
         st.hs_all = new(steps + 1, B, H)
         st.cs_all = new(steps + 1, B, H)
         st.h_init, st.c_init = st.hs_all[0], st.cs_all[0]
-        st.enc_tape = dict(emb=new(T, B, E), xg=new(T, B, 4 * H), gates=new(T, B, 4 * H),
-                           hs=new(T + 1, B, H), cs=new(T + 1, B, H))
-        etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
+        # (an inference rollout keeps no embedded tokens / gate tape: nothing will run backward)
+        keep = training or (torch.is_grad_enabled() and any(
+            p.requires_grad for p in list(enc.parameters()) + list(dec.parameters())))
+        st.enc_tape = dict(emb=new(T, B, E) if keep else None, xg=new(T, B, 4 * H) if keep else None,
+                           gates=new(T, B, 4 * H) if keep else None, hs=new(T + 1, B, H), cs=new(T + 1, B, H))
+        etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() if st.enc_tape[k] is not None else None
+                                 for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
         ew = _encoder_structs(enc)
         call('sf_encoder_lstm_fwd', byref(ew), B, Lpad, T, E, H, ptr(batch.seq),
              ptr(batch.lengths_dev), ptr(st.ctx), ptr(st.h_init), ptr(st.c_init), byref(etp),
