@@ -135,3 +135,35 @@ def dense_speaker_inputs(sb, table, loc_table):
                     [0.0, sb.act_elevation[s, b]])
                 acts[s][b] = emb[1]
     return acts, feats, mask
+
+
+# ------------------------------------------------------------------------------------------------
+# tasks/R2R/eval.py:56-139 (Evaluation._get_nearest / _score_item / score_results): navigation error =
+# shortest-path distance from the LAST viewpoint of a trajectory to the goal, oracle error = from the
+# closest viewpoint on it, success = error < 3 m; the summary averages over all scored instructions.
+# `graphs`: scan -> object with .distance(a, b) (speaker_follower_amd.env.NavGraph); `gt`: path_id ->
+# item with 'scan' and 'path'.
+# ------------------------------------------------------------------------------------------------
+def score_results(gt, graphs, results, error_margin=3.0):
+    per_item, acc = {}, dict(nav_error=[], oracle_error=[], steps=[], lengths=[], success=[], oracle_success=[])
+    for instr_id, res in results.items():
+        path = res['trajectory']
+        item = gt[int(instr_id.split('_')[0])]
+        g = graphs[item['scan']]
+        assert item['path'][0] == path[0][0], 'Result trajectories should include the start position'
+        goal = item['path'][-1]
+        nav_error = g.distance(path[-1][0], goal)                                          # :66
+        oracle_error = min(g.distance(p[0], goal) for p in path)                           # :48-54, :67
+        length = sum(g.distance(a[0], b[0]) for a, b in zip(path[:-1], path[1:]))          # :69-73
+        per_item[instr_id] = dict(nav_error=nav_error, oracle_error=oracle_error, steps=len(path) - 1,
+                                  length=length, success=nav_error < error_margin,
+                                  oracle_success=oracle_error < error_margin)
+        for k, v in (('nav_error', nav_error), ('oracle_error', oracle_error), ('steps', len(path) - 1),
+                     ('lengths', length), ('success', nav_error < error_margin),
+                     ('oracle_success', oracle_error < error_margin)):
+            acc[k].append(v)
+    n = len(results)
+    summary = dict(nav_error=float(np.mean(acc['nav_error'])), oracle_error=float(np.mean(acc['oracle_error'])),
+                   steps=float(np.mean(acc['steps'])), lengths=float(np.mean(acc['lengths'])),
+                   success_rate=float(sum(acc['success'])) / n, oracle_rate=float(sum(acc['oracle_success'])) / n)
+    return summary, per_item

@@ -352,3 +352,27 @@ def test_speaker_b100(golden, feedback):
     _scaled_close(res['logits'][-1], g['logit_last'])
     np.testing.assert_allclose(res['loss'], g['loss'], rtol=1e-4)
     np.testing.assert_allclose(res['scores'], g['scores'], rtol=1e-4, atol=2e-3)
+
+
+# ----------------------------------------------------------------------------- G10: SR on real R2R items
+def test_eval_restatement_reproduces_the_reference_evaluation():
+    """oracle score_results (eval.py:56-139 restated over this repo's NavGraph distances) applied to the
+    REFERENCE agent's trajectories gives the reference Evaluation's per-item errors and its summary
+    (success rate, oracle rate, navigation error) on 156 real R2R instructions."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import r2r_world
+    items, gold = r2r_world.load()
+    _, _, graphs = r2r_world.build_env(items, gold['config'], dense=False)
+    results = {k: dict(trajectory=[(vp, 0.0, 0.0) for vp in v['viewpoints']]) for k, v in gold['items'].items()}
+    summary, per_item = np_env.score_results(r2r_world.gt_of(items), graphs, results)
+    assert len(per_item) == 156 == gold['config']['n_items']
+    for k, v in gold['items'].items():
+        assert per_item[k]['success'] == v['success'] and per_item[k]['oracle_success'] == v['oracle_success']
+        assert per_item[k]['steps'] == v['steps']
+        np.testing.assert_allclose(per_item[k]['nav_error'], v['nav_error'], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(per_item[k]['length'], v['length'], rtol=1e-9, atol=1e-9)
+    for k in ('success_rate', 'oracle_rate', 'nav_error', 'oracle_error', 'steps', 'lengths'):
+        np.testing.assert_allclose(summary[k], gold['summary'][k], rtol=1e-9)
+    assert summary['success_rate'] == 10 / 156
