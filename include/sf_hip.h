@@ -535,6 +535,11 @@ int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double 
  * (k = 0 start, 1 rows loaded and scored, 2 partials stored); buf = device memory of >= 512 * 8
  * uint64, NULL switches it off.  Used by tools/vis_trace.py to read a kernel's inner timeline. */
 void sf_debug_trace(unsigned long long* buf);
+/* Development aid: on != 0 makes the persistent launches (csrc/sf_persist.hip) use their
+ * placement-independent exchange -- write-through (sc1) stores -- even when a row group's workgroups
+ * share an XCD and would keep the exchange inside that XCD's L2.  Lets the tests exercise the protocol
+ * the kernels fall back to when the observed workgroup -> XCD placement does not hold. */
+void sf_debug_force_write_through(int on);
 
 /* ---- device-resident navigation (env.py:126-146 step, :149-224 panorama sweep, :742-761 teacher,
  * :763-804 observe) ---------------------------------------------------------------------------------

@@ -935,6 +935,7 @@ int pair_visbwd_small(const PanoSrc& src, int B, const float* vec, int ldvec, fl
 }
 
 extern "C" void sf_debug_trace(unsigned long long* buf) { g_trace = buf; }
+extern "C" void sf_debug_force_write_through(int on) { g_force_sc1 = on; }
 
 int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
                    int ldo, const Dropout& drop, int drop_col0, float* split_part,

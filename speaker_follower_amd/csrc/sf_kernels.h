@@ -42,6 +42,7 @@ int lstm_pointwise_fwd(const LstmPwFwd& a, hipStream_t st);
 int lstm_step_fused(const LstmStepArgs& p, hipStream_t st);      // sf_gemm.hip
 
 extern unsigned long long* g_trace;   // sf_debug_trace buffer (development aid), null = off
+extern int g_force_sc1;               // sf_debug_force_write_through
 
 // ---- sf_persist.hip: the T recurrent steps of a table-input LSTM as one persistent launch ---------
 size_t encoder_persistent_xchg_floats(int H);

@@ -26,6 +26,7 @@
 
 namespace sf {
 unsigned long long* g_trace = nullptr;     // sf_debug_trace buffer (set in sf_attention.hip)
+int g_force_sc1 = 0;                       // sf_debug_force_write_through: never take the one-XCD fast path
 namespace {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -43,8 +44,9 @@ __device__ unsigned g_persist_lock = 0;
 // Per-launch placement record of one row group: [0] arrivals, [1] min XCC id, [2] max XCC id
 // (initialised by the prologue kernel).  EP_PLACE_WORDS dwords per group.
 constexpr int EP_PLACE_WORDS = 4;
-__device__ __forceinline__ void place_init(unsigned* place, size_t i) {
-    if (i < (size_t)EP_GROUPS * EP_PLACE_WORDS) place[i] = (i % EP_PLACE_WORDS) == 1 ? 0xFFFFFFFFu : 0u;
+__device__ __forceinline__ void place_init(unsigned* place, size_t i, int force_sc1) {
+    if (i < (size_t)EP_GROUPS * EP_PLACE_WORDS)
+        place[i] = (i % EP_PLACE_WORDS) == 1 ? 0xFFFFFFFFu : ((i % EP_PLACE_WORDS) == 3 && force_sc1 ? 1u : 0u);
 }
 // True iff all EP_SLOTS workgroups of `grp` run on ONE XCD (read from the hardware id register, agreed
 // on through agent-scope atomics once per launch).  Then their exchange can stay inside that XCD's
@@ -66,17 +68,19 @@ __device__ __forceinline__ bool group_on_one_xcd(unsigned* place, int grp) {
             if (wall_clock64() - t0 > 2000) break;                         // 20 us: decide without the others
         }
         __threadfence();
-        s_fast = all && __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
-                            __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_fast = all && p[3] == 0u &&                                      // [3]: write-through forced (debug)
+                 __hip_atomic_load(p + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ==
+                     __hip_atomic_load(p + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     return s_fast != 0;
 }
 
 __global__ __launch_bounds__(256) void enc_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, float* h0,
-                                                                   float* c0, size_t n_state, unsigned* place) {
+                                                                   float* c0, size_t n_state, unsigned* place,
+                                                                   int force_sc1) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x, force_sc1);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_xchg; i += stride) xchg[i] = EP_SENTINEL;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_state; i += stride) {
         h0[i] = 0.f;                       // model.py:67-79 init_state
@@ -500,9 +504,10 @@ __global__ __launch_bounds__(256, 2) void enc_bwd_persist_kernel(EncBwdPersistAr
 }
 
 // sentinel fill + device-wide lock of the backward launch (no state to zero)
-__global__ __launch_bounds__(256) void enc_bwd_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, unsigned* place) {
+__global__ __launch_bounds__(256) void enc_bwd_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, unsigned* place,
+                                                                       int force_sc1) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
-    place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x);
+    place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x, force_sc1);
     v4u* x4 = reinterpret_cast<v4u*>(xchg);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_xchg / 4; i += stride)
         x4[i] = v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL};
@@ -938,7 +943,7 @@ int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
     a.gates = gates; a.hs = hs; a.cs = cs; a.ctx = ctx; a.ld_ctx = T * H; a.ctx_drop = ctx_drop; a.c_out = c_out;
     a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
     SF_LAUNCH(enc_persist_prologue_kernel, dim3(96), dim3(256), 0, st, a.xchg, encoder_persistent_xchg_floats(H),
-              hs, cs, (size_t)B * H, a.place);
+              hs, cs, (size_t)B * H, a.place, g_force_sc1);
     SF_LAUNCH(enc_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }
@@ -966,7 +971,7 @@ int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
     a.h1_tape = h1_tape; a.c1_tape = c1_tape; a.ended = ended; a.xchg = reinterpret_cast<unsigned*>(xchg);
     a.done = done; a.place = done + 4; a.trace = g_trace;
     SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(256), dim3(256), 0, st, a.xchg, speaker_persistent_xchg_floats(),
-              a.place);
+              a.place, g_force_sc1);
     SF_LAUNCH(spk_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }
@@ -982,7 +987,7 @@ int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, 
     a.gates = gates; a.cs = cs; a.dctx = dctx; a.ctx_drop = ctx_drop; a.dh_in = dh_in; a.dc_in = dc_in;
     a.dgates = dgates; a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
     SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(512), dim3(256), 0, st, a.xchg, encoder_bwd_persistent_xchg_floats(),
-              a.place);
+              a.place, g_force_sc1);
     SF_LAUNCH(enc_bwd_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }

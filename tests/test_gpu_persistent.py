@@ -249,3 +249,39 @@ def test_persistent_speaker_decode_timing_and_graph():
             eng.score(batch, 80, 'argmax', train=False)
     print({k: round(v['avg_us'], 1) for k, v in prof.rows.items() if 'persist' in k})
     assert res[True][0] < res[False][0]
+
+
+def test_placement_independent_exchange_gives_the_same_results():
+    """The persistent launches take a fast path (plain stores, exchange inside one XCD's L2) when the
+    hardware XCC ids of a row group agree; otherwise write-through stores make the protocol valid for
+    any placement.  Force the fallback: forward still bit-identical to the per-step kernel, backward
+    and the speaker word loop equal to the fast path."""
+    from speaker_follower_amd import _lib, speaker
+    enc = encoder(5)
+    seq, mask, lens = batch(21, 100, 10, 79)
+    T, H = max(lens), enc.hidden_size
+    ref = run(enc, seq, lens, persistent=False)
+    dctx = torch.randn(100, T, H, device='cuda')
+    z = torch.zeros(100, H, device='cuda')
+    fast_dg, _ = run_bwd(enc, seq, lens, ref, True, False, dctx, z, z)
+    senc, sdec, store, sbatch = speaker_setup(100)
+    with torch.no_grad():
+        fast_spk = speaker.SpeakerEngine(senc, sdec, store).score(sbatch, 30, 'argmax', train=False)
+    _lib.lib.sf_debug_force_write_through(1)
+    try:
+        trace = torch.zeros(256 * 8, dtype=torch.int64, device='cuda')
+        _lib.lib.sf_debug_trace(trace.data_ptr())
+        got = run(enc, seq, lens, persistent=True)
+        torch.cuda.synchronize()
+        _lib.lib.sf_debug_trace(None)
+        assert int(trace.view(256, 8)[:, 5].sum()) == 0          # no workgroup took the one-XCD path
+        for k in ref:
+            assert torch.equal(got[k], ref[k]), k
+        slow_dg, _ = run_bwd(enc, seq, lens, ref, True, False, dctx, z, z)
+        assert torch.equal(slow_dg, fast_dg)
+        with torch.no_grad():
+            slow_spk = speaker.SpeakerEngine(senc, sdec, store).score(sbatch, 30, 'argmax', train=False)
+        assert torch.equal(slow_spk.words, fast_spk.words) and torch.equal(slow_spk.logits, fast_spk.logits)
+    finally:
+        _lib.lib.sf_debug_trace(None)
+        _lib.lib.sf_debug_force_write_through(0)
