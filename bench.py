@@ -56,6 +56,7 @@ def parse(argv=None):
     ap.add_argument('--in-flight', type=int, default=2,
                     help='extra measurement: this many independent batch-100 rollouts in flight on separate streams')
     ap.add_argument('--cpu-reps', type=int, default=2)
+    ap.add_argument('--two-stream-forward', action='store_true', help='(experiment) visual half on a side stream, device-flag ordering')
     # test-only switches: exercise the N > 1 code path (launcher, rendezvous, collectives, JSON) on a
     # box with ONE GPU.  Ranks share cuda:0 and reduce through gloo; the line is marked oversubscribed.
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
@@ -320,6 +321,7 @@ def main(argv=None):
     batch = follower.DeviceFollowerBatch.from_synth(fb, device=device, row0=rank * B)
     train = args.workload == 'train'
     engine = follower.FollowerEngine(enc, dec, store, group=group if train else None)
+    engine.two_stream_forward = args.two_stream_forward
     if train:
         enc.train()
         dec.train()

@@ -706,6 +706,28 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
                          st, glue, w->fold);
 }
 
+// tail(t) WITHOUT the head of step t+1 (that runs on another stream): LSTM cell, then -- after
+// publishing "h1 of this step is complete" -- the text attention and scoring chain, unpaired.
+static int decoder_tail_split_i(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
+                                const float* h0, const float* c0, const float* ctx, const uint8_t* ctx_mask,
+                                const sf_decoder_tape* tp, const sf_follower_glue* glue, const sf_dropout* drop,
+                                uint32_t step_id, unsigned* flag_h1, unsigned flag_value, void* ws,
+                                size_t ws_bytes, unsigned* tickets, hipStream_t st) {
+    SF_CHECK_ARG(w && U && h0 && c0 && ctx && tp && glue && glue_ok(U, glue));
+    const size_t n = ws_bytes / 4;
+    Arena ar{(float*)ws, n, 0, tickets};
+    const CandSrc us = cands(U);
+    const int F = us.IMG + us.LOC;
+    const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
+    TRY(lstm_fwd_i(&w->lstm, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->h1, tp->c1, tp->gates, tp->cat2 + H, 2 * H,
+                   d_h, ar, st));
+    if (flag_h1) TRY(flag_set(flag_h1, flag_value, st));
+    TRY(softdot_fwd_i(&w->text, B, L, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2, tp->t_text,
+                      ar, st, nullptr));
+    return scoring_fwd_i(&w->action, us, B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt, tp->r, ar, st, glue,
+                         nullptr);
+}
+
 int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
                              const float* u_prev, const float* h0, const float* c0,
                              const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
@@ -929,6 +951,47 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
     StepView cur = step_view(e, 0);
     TRY(decoder_head_i(w, &cur.X, e->B, e->H, e->D, e->h_init, &cur.tp, drop, e->step0, ws, ws_bytes,
                        stream));
+    if (e->side_stream && e->side_stream != stream && !w->fold && e->S > 1) {
+        // Two chains, ONE fork and ONE join per episode, ordered per step by device flags
+        // (flag_wait / flag_set kernels) instead of events:
+        //   main:  [wait feat(t)] gate product, cell, [set h1(t)], t_text, text attention, h~, scoring + glue
+        //   side:  [wait h1(t)]  t_v', q', visual attention of step t+1, [set feat(t+1)]
+        hipStream_t ms = S(stream), ss = S(e->side_stream);
+        std::vector<hipEvent_t>& ev = event_pool(2);
+        if (ev.size() < 2) return SF_ERR_LAUNCH;
+        const Arena whole = arena(ws, ws_bytes);
+        if (!whole.tk) return SF_ERR_WORKSPACE;
+        const size_t side_n = std::min<size_t>(whole.cap / 4, (size_t)4 << 20);
+        unsigned* flag_h1 = whole.tk + PERSIST_TICKET + 48;
+        unsigned* flag_ft = whole.tk + PERSIST_TICKET + 49;
+        void* side_ws = (float*)ws + (whole.cap - side_n);
+        const size_t main_bytes = (whole.cap - side_n) * sizeof(float);
+        TRY(flag_set(flag_h1, 0u, ms));
+        TRY(flag_set(flag_ft, 0u, ms));
+        if (hipEventRecord(ev[0], ms) != hipSuccess || hipStreamWaitEvent(ss, ev[0], 0) != hipSuccess) return SF_ERR_LAUNCH;
+        for (int t = 0; t < e->S; ++t) {
+            const bool more = t + 1 < e->S;
+            StepView nxt = more ? step_view(e, t + 1) : cur;
+            const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
+            const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
+            if (t > 0) TRY(flag_wait(flag_ft, (unsigned)t, ms));
+            TRY(decoder_tail_split_i(w, &cur.U, e->B, e->H, e->D, e->L, h0, c0, e->ctx, e->ctx_mask, &cur.tp,
+                                     &cur.glue, drop, e->step0 + t, more ? flag_h1 : nullptr, (unsigned)(t + 1), ws,
+                                     main_bytes, whole.tk, ms));
+            if (more) {
+                TRY(flag_wait(flag_h1, (unsigned)(t + 1), ss));
+                Arena sar{(float*)side_ws, side_n, 0, whole.tk};
+                const PanoSrc xs = pano(&nxt.X);
+                const int F = xs.IMG + xs.LOC;
+                TRY(visual_fwd_i(&w->visual, xs, e->B, e->H, e->D, cur.tp.h1, nxt.tp.xin + F, 2 * F, nxt.tp.alpha_v,
+                                 nxt.tp.t_v, nxt.tp.q, make_dropout(drop, 2 * (e->step0 + t + 1)), F, sar, ss, nullptr));
+                TRY(flag_set(flag_ft, (unsigned)(t + 1), ss));
+            }
+            cur = nxt;
+        }
+        if (hipEventRecord(ev[1], ss) != hipSuccess || hipStreamWaitEvent(ms, ev[1], 0) != hipSuccess) return SF_ERR_LAUNCH;
+        return SF_OK;
+    }
     for (int t = 0; t < e->S; ++t) {
         const bool more = t + 1 < e->S;
         StepView nxt = more ? step_view(e, t + 1) : cur;

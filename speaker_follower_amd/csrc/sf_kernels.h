@@ -105,6 +105,9 @@ int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float*
                    hipStream_t st);        // out[n] += sum_m s[m] * x[m,n]
 int sum_accum(const float* s, int M, float* out, hipStream_t st);   // out[0] += sum_m s[m]
 int fill(float* p, size_t n, float v, hipStream_t st);
+// device-flag ordering between two streams (sf_pointwise.hip)
+int flag_wait(const unsigned* flag, unsigned target, hipStream_t st);
+int flag_set(unsigned* flag, unsigned value, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
               double beta2, double eps, double wd, int step, hipStream_t st);
 int transpose(const float* src, int R, int C, float* dst, hipStream_t st);   // dst[C,R] = src^T

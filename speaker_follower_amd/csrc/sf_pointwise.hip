@@ -648,6 +648,31 @@ int sum_accum(const float* s, int M, float* out, hipStream_t st) {
     SF_LAUNCH(sum_accum_kernel, dim3(1), dim3(64), 0, st, s, M, out);
     return launch_status();
 }
+// Cross-stream ordering without events: a one-wave kernel that spins on a device word until it
+// reaches `target` (bounded by the wall clock), and a one-thread kernel that publishes a value.  A
+// stream that launches flag_wait ahead of a consumer cannot start the consumer before another stream's
+// flag_set (launched behind the producer) has run; kernel boundaries do the release / acquire of the
+// data itself.  An event-based fork / join per decode step costs several times more on this stack.
+__global__ void flag_wait_kernel(const unsigned* flag, unsigned target) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 50000000LL) break;      // 0.5 s: never hang a stream
+    }
+}
+__global__ void flag_set_kernel(unsigned* flag, unsigned value) {
+    if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+int flag_wait(const unsigned* flag, unsigned target, hipStream_t st) {
+    SF_LAUNCH(flag_wait_kernel, dim3(1), dim3(64), 0, st, flag, target);
+    return launch_status();
+}
+int flag_set(unsigned* flag, unsigned value, hipStream_t st) {
+    SF_LAUNCH(flag_set_kernel, dim3(1), dim3(64), 0, st, flag, value);
+    return launch_status();
+}
+
 int fill(float* p, size_t n, float v, hipStream_t st) {
     if (n == 0) return SF_OK;
     SF_LAUNCH(fill_kernel, dim3(grid1d(n)), dim3(TPB), 0, st, p, n, v);

@@ -133,6 +133,7 @@ class FollowerEngine:
         # ones 5-6 us each in paired stages: 2.20 vs 2.09 ms per rollout.  Off.
         self.fold_inference = False
         self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
+        self.two_stream_forward = False  # experiment: visual half of step t+1 on a side stream, ordered by device flags
         self.episode_call = True        # the whole decode loop (and its backward) as ONE C call
 
     # ------------------------------------------------------------------------------ forward
@@ -238,6 +239,11 @@ class FollowerEngine:
                 int(st.drop_dec[1]) ^ 0x1B873593, 0, batch.row0)
             ep.drop = d_dec
             ep.step0 = st.site0
+            ep.side_stream = None
+            if self.two_stream_forward and fold is None:
+                if self._side_stream is None:
+                    self._side_stream = torch.cuda.Stream(device=dev)
+                ep.side_stream = self._side_stream.cuda_stream
             call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
             st.episode = (ep, dw)
         tapes = [] if st.episode else [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))

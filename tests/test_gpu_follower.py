@@ -389,3 +389,36 @@ def test_folded_inference_schedule_matches_unfolded():
     assert np.array_equal(fin, np.isfinite(lb))
     assert float(np.abs(la[fin] - lb[fin]).max()) <= 1e-4 * float(np.abs(la[fin]).max())
     np.testing.assert_allclose(float(b.loss), float(a.loss), rtol=1e-5)
+
+
+def test_two_stream_forward_equals_paired_schedule():
+    """FollowerEngine.two_stream_forward (visual half of step t+1 on a side stream, ordered by
+    device-flag kernels; off by default: the flag kernels cost what the overlap gains) computes the same
+    rollout as the paired single-stream schedule, eagerly and as a captured graph."""
+    from speaker_follower_amd import model, features, follower
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(303)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    fb = synth.follower_batch(seed=47, batch=60, steps=9, n_viewpoints=128)
+    store = features.FeatureStore(synth.feature_table(8, 128))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    with torch.no_grad():
+        ref = follower.FollowerEngine(enc, dec, store).rollout(batch, 9, 'argmax', train=False)
+    eng = follower.FollowerEngine(enc, dec, store)
+    eng.two_stream_forward = True
+    with torch.no_grad():
+        st = eng.rollout(batch, 9, 'argmax', train=False)
+    torch.cuda.synchronize()
+    assert torch.equal(st.actions, ref.actions)
+    fin = torch.isfinite(ref.logits)
+    torch.testing.assert_close(st.logits[fin], ref.logits[fin], rtol=1e-5, atol=1e-5)
+    replay, gst = eng.capture(batch, 9, 'argmax')
+    replay()
+    replay()
+    torch.cuda.synchronize()
+    assert torch.equal(gst.actions, ref.actions)
