@@ -540,6 +540,12 @@ void sf_debug_trace(unsigned long long* buf);
  * share an XCD and would keep the exchange inside that XCD's L2.  Lets the tests exercise the protocol
  * the kernels fall back to when the observed workgroup -> XCD placement does not hold. */
 void sf_debug_force_write_through(int on);
+/* Development entry (csrc/sf_mega.hip, milestone 1 of the persistent decode loop): the LSTMCell of n_steps
+ * decode steps in ONE launch -- gate product, cell update, h fed back -- with the (u_prev | feature) operand of
+ * every step read from xin_ref [n_steps+1, B, 2F] (a reference rollout's tape).  h1_tape / c1_tape [n_steps,B,H]. */
+int sf_debug_mega_lstm_loop(const sf_lstm_w* w, const float* h_init, const float* c_init, const float* xin_ref,
+                            int B, int n_steps, float* h1_tape, float* c1_tape, float* gates_tape,
+                            void* ws, size_t ws_bytes, sf_stream stream);
 
 /* ---- device-resident navigation (env.py:126-146 step, :149-224 panorama sweep, :742-761 teacher,
  * :763-804 observe) ---------------------------------------------------------------------------------

@@ -118,6 +118,7 @@ _SIGNATURES = {
     'sf_abi_version': (C.c_int, []),
     'sf_debug_trace': (None, [C.c_void_p]),
     'sf_debug_force_write_through': (None, [C.c_int]),
+    'sf_debug_mega_lstm_loop': (C.c_int, [P(LstmW), c_f, c_f, c_f, i32, i32, c_f, c_f, c_f] + WS),
     'sf_status_string': (C.c_char_p, [C.c_int]),
     'sf_last_error_string': (C.c_char_p, []),
     'sf_linear_fwd': (C.c_int, [c_f, i32, c_f, c_f, i32, i32, i32, i32, c_f, i32] + WS),

@@ -1471,6 +1471,20 @@ int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float
 
 }  // extern "C"
 
+// ---- development entry: milestone 1 of the persistent decode loop (sf_mega.hip) --------------------------------
+extern "C" int sf_debug_mega_lstm_loop(const sf_lstm_w* w, const float* h_init, const float* c_init, const float* xin_ref,
+                                       int B, int n_steps, float* h1_tape, float* c1_tape, float* gates_tape,
+                                       void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && h_init && c_init && xin_ref && h1_tape && c1_tape && B > 0 && n_steps > 0);
+    Arena ar = arena(ws, ws_bytes);
+    float* xin = ar.take(mega_xin_dwords());
+    float* slab = ar.take(mega_slab_dwords());
+    NEED(xin && slab && ar.tickets());
+    return mega_lstm_loop(w->w_ih, w->w_hh, w->b_ih, w->b_hh, h_init, c_init, xin_ref, B, n_steps, h1_tape, c1_tape,
+                          gates_tape, xin, slab, ar.tickets() + PERSIST_TICKET, S(stream));
+}
+
 // ---- in-process kernel timing ---------------------------------------------------------------------
 int sf_profile_begin(void) {
     SF_ENTER();

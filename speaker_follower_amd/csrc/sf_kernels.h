@@ -44,6 +44,15 @@ int lstm_step_fused(const LstmStepArgs& p, hipStream_t st);      // sf_gemm.hip
 extern unsigned long long* g_trace;   // sf_debug_trace buffer (development aid), null = off
 extern int g_force_sc1;               // sf_debug_force_write_through
 
+unsigned* persist_lock_addr();         // the device-wide lock of every persistent launch (sf_persist.hip)
+
+// ---- sf_mega.hip: the decode loop as one persistent launch (milestones; see the file header)
+size_t mega_xin_dwords();
+size_t mega_slab_dwords();
+int mega_lstm_loop(const float* w_ih, const float* w_hh, const float* b_ih, const float* b_hh, const float* h_init,
+                   const float* c_init, const float* xin_ref, int B, int S, float* h1_tape, float* c1_tape,
+                   float* gates_tape, float* ws_xin, float* ws_slab, unsigned* done, hipStream_t st);
+
 // ---- sf_persist.hip: the T recurrent steps of a table-input LSTM as one persistent launch ---------
 size_t encoder_persistent_xchg_floats(int H);
 bool encoder_persistent_supported(int B, int H, int T);

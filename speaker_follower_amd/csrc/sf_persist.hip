@@ -925,6 +925,22 @@ int device_cus() {
 
 }  // namespace
 
+// Device address of the ONE device-wide lock all persistent launches of this library take (a __device__
+// variable of this translation unit; other translation units pass the pointer to their kernels).
+unsigned* persist_lock_addr() {
+    static thread_local int cached_dev = -1;
+    static thread_local unsigned* cached = nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
+    if (dev != cached_dev) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(g_persist_lock)) != hipSuccess) return nullptr;
+        cached = static_cast<unsigned*>(ptr);
+        cached_dev = dev;
+    }
+    return cached;
+}
+
 size_t encoder_persistent_xchg_floats(int H) { return (size_t)EP_GROUPS * 3 * EP_ROWS * H; }
 
 bool encoder_persistent_supported(int B, int H, int T) {
