@@ -540,12 +540,15 @@ void sf_debug_trace(unsigned long long* buf);
  * share an XCD and would keep the exchange inside that XCD's L2.  Lets the tests exercise the protocol
  * the kernels fall back to when the observed workgroup -> XCD placement does not hold. */
 void sf_debug_force_write_through(int on);
-/* Development entry (csrc/sf_mega.hip, milestone 1 of the persistent decode loop): the LSTMCell of n_steps
- * decode steps in ONE launch -- gate product, cell update, h fed back -- with the (u_prev | feature) operand of
- * every step read from xin_ref [n_steps+1, B, 2F] (a reference rollout's tape).  h1_tape / c1_tape [n_steps,B,H]. */
-int sf_debug_mega_lstm_loop(const sf_lstm_w* w, const float* h_init, const float* c_init, const float* xin_ref,
-                            int B, int n_steps, float* h1_tape, float* c1_tape, float* gates_tape,
-                            void* ws, size_t ws_bytes, sf_stream stream);
+/* The S decode steps of an INFERENCE rollout (no dropout, no backward to follow) as ONE persistent launch
+ * (csrc/sf_mega.hip): same inputs and outputs as sf_follower_episode_fwd -- logits, actions, scores, CE
+ * terms, liveness, `ended`, the h1 / c1 tapes -- without the per-step tapes of the backward.  Needs
+ * w->fold (sf_decoder_fold_build), index-form panoramas / candidates (no dense tensors, no is_valid),
+ * B <= 128, H = 512, F = 2176, V = 36, L <= 80, A <= 16; anything else returns SF_ERR_UNSUPPORTED and
+ * the caller uses sf_follower_episode_fwd.  debug_tapes != 0 (tests): t_text, cat2[:, :H], h_tilde,
+ * q and xin of every step are also copied into e->tape. */
+int sf_follower_decode_persistent(const sf_decoder_w* w, const sf_follower_episode* e, int debug_tapes,
+                                  void* ws, size_t ws_bytes, sf_stream stream);
 
 /* ---- device-resident navigation (env.py:126-146 step, :149-224 panorama sweep, :742-761 teacher,
  * :763-804 observe) ---------------------------------------------------------------------------------

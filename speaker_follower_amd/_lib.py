@@ -118,7 +118,7 @@ _SIGNATURES = {
     'sf_abi_version': (C.c_int, []),
     'sf_debug_trace': (None, [C.c_void_p]),
     'sf_debug_force_write_through': (None, [C.c_int]),
-    'sf_debug_mega_lstm_loop': (C.c_int, [P(LstmW), c_f, c_f, c_f, i32, i32, c_f, c_f, c_f] + WS),
+    'sf_follower_decode_persistent': (C.c_int, [P(DecoderW), P(FollowerEpisode), i32] + WS),
     'sf_status_string': (C.c_char_p, [C.c_int]),
     'sf_last_error_string': (C.c_char_p, []),
     'sf_linear_fwd': (C.c_int, [c_f, i32, c_f, c_f, i32, i32, i32, i32, c_f, i32] + WS),
@@ -193,6 +193,7 @@ _SIGNATURES = {
     'sf_profile_end': (C.c_long, [C.c_char_p, C.c_size_t]),
 }
 
+SF_OK, SF_ERR_ARG, SF_ERR_UNSUPPORTED, SF_ERR_LAUNCH, SF_ERR_WORKSPACE = 0, 1, 2, 3, 4
 SF_ENC_PER_STEP = 1           # sf_encoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)

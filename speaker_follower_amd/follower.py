@@ -135,6 +135,10 @@ class FollowerEngine:
         self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
         self.two_stream_forward = False  # experiment: visual half of step t+1 on a side stream, ordered by device flags
         self.episode_call = True        # the whole decode loop (and its backward) as ONE C call
+        # inference rollouts: the S decode steps as ONE persistent launch (csrc/sf_mega.hip).  Falls back to
+        # the per-stage episode when the shape is outside what that kernel supports.
+        self.persistent_decode = False
+        self.persistent_debug_tapes = False   # tests: also copy t_text / cat2 / h_tilde / q / xin per step
 
     # ------------------------------------------------------------------------------ forward
     def rollout(self, batch, steps, feedback='argmax', train=None, finalize=True):
@@ -244,7 +248,17 @@ class FollowerEngine:
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(device=dev)
                 ep.side_stream = self._side_stream.cuda_stream
-            call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
+            st.persistent = False
+            if self.persistent_decode and not (st.differentiable or training) and ep.side_stream is None:
+                dwf = dw if fold is not None else decoder_w_struct(params, fold=decoder_fold(dec))
+                rc = _lib.lib.sf_follower_decode_persistent(byref(dwf), byref(ep), int(self.persistent_debug_tapes), *ws)
+                if rc == _lib.SF_ERR_UNSUPPORTED:
+                    rc = None
+                else:
+                    _lib.check(rc, 'sf_follower_decode_persistent')
+                    st.persistent = True
+            if not st.persistent:
+                call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
             st.episode = (ep, dw)
         tapes = [] if st.episode else [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
                                        for t in range(S)]

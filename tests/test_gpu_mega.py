@@ -1,7 +1,6 @@
-"""GPU: the persistent decode loop (csrc/sf_mega.hip), milestone by milestone, against the tapes of the
-per-stage engine (which is itself pinned to the reference's goldens)."""
-import ctypes as C
-
+"""GPU: the follower's decode loop as ONE persistent launch (csrc/sf_mega.hip, sf_follower_decode_persistent)
+against the per-stage engine, which is itself pinned to the reference's goldens (tests/test_gpu_follower.py,
+test_gpu_hard_parity.py)."""
 import numpy as np
 import pytest
 import torch
@@ -11,7 +10,7 @@ pytestmark = pytest.mark.gpu
 from speaker_follower_amd import synth                                # noqa: E402
 
 
-def reference_rollout(B, S, seed=47, peaky=True):
+def make_engine(peaky=True):
     from speaker_follower_amd import model, features, follower
     d = synth.FULL
     enc_w, dec_w = (synth.follower_weights_peaky if peaky else synth.follower_weights)(303)
@@ -21,56 +20,110 @@ def reference_rollout(B, S, seed=47, peaky=True):
     dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
     enc.cuda().eval()
     dec.cuda().eval()
-    fb = synth.follower_batch(seed=seed, batch=B, steps=S, n_viewpoints=256)
     store = features.FeatureStore(synth.feature_table(8, 256))
+    return follower.FollowerEngine(enc, dec, store)
+
+
+def rollouts(B, S, feedback='argmax', seed=47, debug=True):
+    from speaker_follower_amd import follower
+    eng = make_engine()
+    fb = synth.follower_batch(seed=seed, batch=B, steps=S, n_viewpoints=256)
     batch = follower.DeviceFollowerBatch.from_synth(fb)
     with torch.no_grad():
-        st = follower.FollowerEngine(enc, dec, store).rollout(batch, S, 'argmax', train=False)
-    torch.cuda.synchronize()
-    return enc, dec, store, batch, st
-
-
-@pytest.mark.parametrize('B,S', [(100, 20), (128, 5), (16, 6), (37, 9)])
-def test_milestone1_lstm_loop_matches_the_step_kernels(B, S):
-    """Gate product + cell + h feedback of all S decode steps in one launch, (u | feature) from the
-    reference tape: h1 / c1 of every step as the gemm_nt_tiled + lstm_pw pair computes them."""
-    from speaker_follower_amd import _lib
-    from speaker_follower_amd.model import decoder_params
-    from speaker_follower_amd.runtime import ptr, ws_args
-    enc, dec, store, batch, st = reference_rollout(B, S)
-    p = decoder_params(dec)
-    lw = _lib.LstmW(p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(), None, None)
-    H = 512
-    for rep in range(3):
-        h1 = torch.full((S, B, H), float('nan'), device='cuda')
-        c1 = torch.full((S, B, H), float('nan'), device='cuda')
-        _lib.call('sf_debug_mega_lstm_loop', C.byref(lw), ptr(st.h_init), ptr(st.c_init), ptr(st.tape['xin']), B, S,
-                  ptr(h1), ptr(c1), None, *ws_args(h1.device))
+        eng.fold_inference = True                  # same folded Linears as the persistent kernel
+        ref = eng.rollout(batch, S, feedback, train=False)
         torch.cuda.synchronize()
-        assert not torch.isnan(h1).any()
-        torch.testing.assert_close(h1, st.tape['h1'], rtol=2e-5, atol=2e-6)
-        torch.testing.assert_close(c1, st.tape['c1'], rtol=2e-5, atol=2e-6)
+        eng.persistent_decode, eng.persistent_debug_tapes = True, debug
+        eng.site_next, eng.iteration = 0, 0        # the same sampling sites as the first rollout
+        got = eng.rollout(batch, S, feedback, train=False)
+        torch.cuda.synchronize()
+    assert got.persistent, 'the persistent launch was refused for this shape'
+    return eng, batch, ref, got
 
 
-def test_milestone1_timing():
+def compare(ref, got, S, B, tapes=True):
+    F = 2176
+    if tapes:
+        # step by step, so that the first deviating quantity is the one reported
+        for t in range(S):
+            for name, a, b in (
+                    ('feat', got.tape['xin'][t][:, F:], ref.tape['xin'][t][:, F:]),
+                    ('u', got.tape['xin'][t][:, :F], ref.tape['xin'][t][:, :F]),
+                    ('h1', got.tape['h1'][t], ref.tape['h1'][t]),
+                    ('c1', got.tape['c1'][t], ref.tape['c1'][t]),
+                    ('t_text', got.tape['t_text'][t], ref.tape['t_text'][t]),
+                    ('wc', got.tape['cat2'][t][:, :512], ref.tape['cat2'][t][:, :512]),
+                    ('h_tilde', got.tape['h_tilde'][t], ref.tape['h_tilde'][t]),
+                    ('logit', got.logits[t], ref.logits[t])):
+                assert not torch.isnan(a).any(), 'step %d %s has NaN' % (t, name)
+                scale = max(float(b[torch.isfinite(b)].abs().max()), 1e-3)
+                fin = torch.isfinite(b)
+                assert (torch.isfinite(a) == fin).all(), 'step %d %s: mask pattern differs' % (t, name)
+                err = float((a[fin] - b[fin]).abs().max())
+                assert err <= 2e-5 * scale + 1e-6, 'step %d %s: max err %.3e (scale %.3e)' % (t, name, err, scale)
+            assert torch.equal(got.actions[t], ref.actions[t]), 'step %d actions differ' % t
+    assert torch.equal(got.actions, ref.actions)
+    assert torch.equal(got.target_used, ref.target_used)
+    assert torch.equal(got.ended, ref.ended)
+    torch.testing.assert_close(got.step_scores, ref.step_scores, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got.ce_term, ref.ce_term, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got.live, ref.live, rtol=0, atol=0)
+    torch.testing.assert_close(got.h, ref.h, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got.c, ref.c, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(got.loss, ref.loss, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('B,S', [(100, 20), (128, 5), (16, 6), (37, 9), (3, 4)])
+def test_persistent_decode_matches_the_per_stage_engine(B, S):
+    eng, batch, ref, got = rollouts(B, S)
+    compare(ref, got, S, B)
+
+
+@pytest.mark.parametrize('feedback', ['teacher', 'sample'])
+def test_persistent_decode_feedback_modes(feedback):
+    eng, batch, ref, got = rollouts(40, 8, feedback)
+    compare(ref, got, 8, 40, tapes=False)
+
+
+def test_persistent_decode_is_repeatable_and_leaves_no_state():
+    eng, batch, ref, got = rollouts(100, 12, debug=False)
+    with torch.no_grad():
+        again = eng.rollout(batch, 12, 'argmax', train=False)
+        torch.cuda.synchronize()
+    assert torch.equal(again.actions, got.actions)
+    assert torch.equal(again.logits, got.logits)
+    assert torch.equal(again.h, got.h)
+    compare(ref, again, 12, 100, tapes=False)
+
+
+def test_persistent_decode_timing():
     from speaker_follower_amd import _lib
-    from speaker_follower_amd.model import decoder_params
-    from speaker_follower_amd.runtime import ptr, ws_args
     B, S = 100, 20
-    enc, dec, store, batch, st = reference_rollout(B, S)
-    p = decoder_params(dec)
-    lw = _lib.LstmW(p[0].data_ptr(), p[1].data_ptr(), p[2].data_ptr(), p[3].data_ptr(), None, None)
-    h1 = torch.empty(S, B, 512, device='cuda')
-    c1 = torch.empty(S, B, 512, device='cuda')
-    run = lambda: _lib.call('sf_debug_mega_lstm_loop', C.byref(lw), ptr(st.h_init), ptr(st.c_init), ptr(st.tape['xin']),  # noqa: E731
-                            B, S, ptr(h1), ptr(c1), None, *ws_args(h1.device))
-    for _ in range(3):
-        run()
-    torch.cuda.synchronize()
-    with _lib.kernel_profile() as prof:
-        for _ in range(5):
+    eng, batch, ref, got = rollouts(B, S, debug=False)
+    run = lambda: eng.rollout(batch, S, 'argmax', train=False)       # noqa: E731
+    with torch.no_grad():
+        for _ in range(3):
             run()
-    print({k: round(v['avg_us'], 1) for k, v in prof.rows.items()})
-    mk = [v for k, v in prof.rows.items() if 'mega_kernel' in k][0]
-    print('gate product + cell, %d steps in one launch: %.1f us = %.2f us per step (per-stage kernels: 25.0 + 4.3)'
-          % (S, mk['avg_us'], mk['avg_us'] / S))
+        torch.cuda.synchronize()
+        with _lib.kernel_profile() as prof:
+            for _ in range(5):
+                run()
+        rows = sorted(prof.rows.items(), key=lambda kv: -kv[1]['total_us'])
+        for k, v in rows[:6]:
+            print('    %-50s calls %3d avg %9.1f us' % (k[:50], v['calls'] // 5, v['avg_us']))
+        mk = [v for k, v in prof.rows.items() if 'mega_kernel' in k][0]
+        print('decode loop, %d steps in one launch: %.1f us = %.2f us per step' % (S, mk['avg_us'], mk['avg_us'] / S))
+        trace = torch.zeros(256 * 8, dtype=torch.int64, device='cuda')
+        _lib.lib.sf_debug_trace(trace.data_ptr())
+        run()
+        torch.cuda.synchronize()
+        _lib.lib.sf_debug_trace(None)
+    tr = trace.cpu().numpy().reshape(256, 8).astype(np.float64) / 100.0 / S
+    blk = np.arange(256)
+    even = ((blk >> 3) & 1) == 0
+    act = (blk & 7) < 7
+    names = ['first product (t_text | q)', 'h stage', 'attn+h~+r | visual', 'scores + glue', 'u + feature stages',
+             'tile stores', 'wait partial tiles', 'cell + loop']
+    for k, n in enumerate(names):
+        print('    %-28s even %6.2f   odd %6.2f   idle group %6.2f' % (
+            n, tr[even & act, k].mean(), tr[~even & act, k].mean(), tr[~act, k].mean()))
