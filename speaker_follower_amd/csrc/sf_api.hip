@@ -1475,7 +1475,7 @@ int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float
 extern "C" int sf_follower_decode_persistent(const sf_decoder_w* w, const sf_follower_episode* e, int debug_tapes,
                                              void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
-    SF_CHECK_ARG(w && e && e->S > 0 && e->B > 0 && e->h_init && e->c_init && e->ctx && e->tape.xin && e->tape.h1 &&
+    SF_CHECK_ARG(w && e && e->S > 0 && e->B > 0 && e->h_init && e->c_init && e->ctx && e->ctx_mask && e->tape.xin && e->tape.h1 &&
                  e->tape.c1 && e->tape.logit && glue_ok(&e->U, &e->glue));
     const PanoSrc xs = pano(&e->X);
     const CandSrc us = cands(&e->U);

@@ -61,7 +61,7 @@ constexpr unsigned MG_TOTAL = MG_SLAB + MG_SLAB_N;
 struct MegaArgs {
     MegaHost h;
     unsigned* lock;                                     // persist_lock_addr()
-    unsigned long long* trace;                          // sf_debug_trace: [blocks][8] tick sums, or null
+    unsigned long long* trace;                          // sf_debug_trace: [blocks][32] (tick sums | stamps), or null
 };
 
 __global__ __launch_bounds__(256) void mega_prologue_kernel(unsigned* x, size_t n, unsigned* lock) {
@@ -137,7 +137,7 @@ struct TileJob {
     float* dbg; int ld_dbg;      // optional plain copy: pointer to row 0 of the group
     bool tanh_epi;
 };
-template <int NI, int TC>
+template <int NI, int TC, int MAXT>
 __device__ __forceinline__ void tile_gemm(__amdgpu_buffer_rsrc_t rs, const TileJob& j, float* smem, int rows_valid,
                                           bool& dead) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -147,35 +147,43 @@ __device__ __forceinline__ void tile_gemm(__amdgpu_buffer_rsrc_t rs, const TileJ
                            (unsigned)((NI == 16 ? (w & 1) * 256 : w * 128) + 4 * kk);
     const int kw = (NI == 16 ? w * 256 : w * 128) + 4 * kk;
     f32x4* red = reinterpret_cast<f32x4*>(smem);
+    // every load below is unconditional on a clamped index (a load inside a branch would be followed by a
+    // full vmcnt(0) wait): chunk c + 1 of the weights is in flight while chunk c is multiplied
+    constexpr int NCH = (MAXT + TC - 1) / TC;
+    float4 wf[2][TC][NI];
+    auto wload = [&](int ch, float4 (&dst)[TC][NI]) {
+#pragma unroll
+        for (int tc = 0; tc < TC; ++tc) {
+            const int tile = j.tile0 + min(ch * TC + tc, j.ntiles - 1) * j.tile_stride;
+            const float* wp = j.w + (size_t)min(16 * tile + li, j.w_rows - 1) * j.ldw + kw;
+#pragma unroll
+            for (int i = 0; i < NI; ++i) dst[tc][i] = ld4(wp + 16 * i);
+        }
+    };
+    wload(0, wf[0]);
     v4u a[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) a[i] = xload(rs, abase + 16 * i);
-    bool settled = false;
-    for (int c0 = 0; c0 < j.ntiles; c0 += TC) {
-        float4 wf[TC][NI];
 #pragma unroll
-        for (int tc = 0; tc < TC; ++tc) {
-            const int tile = j.tile0 + min(c0 + tc, j.ntiles - 1) * j.tile_stride;
-            const float* wp = j.w + (size_t)min(16 * tile + li, j.w_rows - 1) * j.ldw + kw;
+    for (int ch = 0; ch < NCH; ++ch) {
+        if (ch * TC < j.ntiles || ch == 0) {
+            if (ch + 1 < NCH) wload(ch + 1, wf[(ch + 1) & 1]);
+            if (ch == 0) {
 #pragma unroll
-            for (int i = 0; i < NI; ++i) wf[tc][i] = ld4(wp + 16 * i);
-        }
-        if (!settled) {
+                for (int i = 0; i < NI; ++i) settle(rs, abase + 16 * i, a[i], dead);
+            }
 #pragma unroll
-            for (int i = 0; i < NI; ++i) settle(rs, abase + 16 * i, a[i], dead);
-            settled = true;
-        }
+            for (int tc = 0; tc < TC; ++tc) {
+                if (ch * TC + tc < j.ntiles) {
+                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int tc = 0; tc < TC; ++tc) {
-            if (c0 + tc < j.ntiles) {
-                f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    for (int i = 0; i < NI; ++i) {
+                        const float4 af = as_f4(a[i]);
 #pragma unroll
-                for (int i = 0; i < NI; ++i) {
-                    const float4 af = as_f4(a[i]);
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = mfma16(comp(wf[tc][i], q), comp(af, q), acc);
+                        for (int q = 0; q < 4; ++q) acc = mfma16(comp(wf[ch & 1][tc][i], q), comp(af, q), acc);
+                    }
+                    red[(w * MG_MAXT + ch * TC + tc) * 64 + lane] = acc;
                 }
-                red[(w * MG_MAXT + c0 + tc) * 64 + lane] = acc;
             }
         }
     }
@@ -242,6 +250,9 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     const int row0 = xcd * 16;                            // first row of the group
     const int rows_valid = max(0, min(16, B - row0));
     bool ended_reg = p.ended[bsc] != 0;
+    // instruction mask of the sample (step-invariant): lane l holds positions l and l + 64
+    const bool mask0 = p.mask[(size_t)bsc * L + min(lane, L - 1)] != 0;
+    const bool mask1 = p.mask[(size_t)bsc * L + min(lane + 64, L - 1)] != 0;
 
     // ---- this workgroup's stages of the gate product: its h stage, its feature stages, its u stages
     // (computed, not tabulated: a register array filled through a running index compiles to movrel writes
@@ -251,16 +262,22 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     const int nu = (MG_NU - xcd + 7) >> 3;
     auto stage_of = [&](int i) { return i == 0 ? sh : (i <= nf ? f0 + 8 * (i - 1) : xcd + 8 * (i - 1 - nf)); };
 
-    long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = wall_clock64();    // development aid (pa.trace)
+    // development aid (pa.trace): per phase the ticks summed over the steps, and the absolute stamps of the
+    // middle step
+    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tabs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    long long tprev = wall_clock64();
+    int t_now = 0;
 #define MG_STAMP(k)                                 \
     if (pa.trace) {                                 \
         const long long now_ = wall_clock64();      \
         tk[k] += now_ - tprev;                      \
+        if (t_now == (S >> 1)) tabs[k] = now_;      \
         tprev = now_;                               \
     }
 
     f32x4 acc[MT];
     for (int t = 0; t <= S; ++t) {
+        t_now = t;
         const unsigned xb = MG_XIN + (unsigned)((t % 3) * 128 * MG_K);           // operand rows of step t
         const unsigned xn = MG_XIN + (unsigned)(((t + 1) % 3) * 128 * MG_K);     // ... of step t + 1
         const int cs = (t + 2) % 3, cn = t % 3;           // chain step t - 1: its slot, and the one it resets
@@ -334,7 +351,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
             }
         };
 
-        MG_STAMP(7)                                         // loop back
+        MG_STAMP(11)                                        // loop back
         // ============================ chain of step t - 1, first product ============================
         if (chain) {
             TileJob j{};
@@ -346,14 +363,14 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 j.out = MG_TT + (unsigned)((cs * 128 + row0) * MG_H); j.rst = MG_TT + (unsigned)((cn * 128 + row0) * MG_H);
                 j.ldo = MG_H;
                 j.dbg = p.dbg_t_text ? p.dbg_t_text + ((size_t)(t - 1) * B + row0) * MG_H : nullptr; j.ld_dbg = MG_H;
-                tile_gemm<8, 2>(rs, j, smem, rows_valid, dead);
+                tile_gemm<8, 2, 2>(rs, j, smem, rows_valid, dead);
             } else if (gates) {                             // q' = M_v h1 + c_v: the query of step t's panorama
                 j.w = p.m_v; j.ldw = MG_H; j.w_rows = MG_F; j.bias = p.c_v;
                 j.tile0 = e; j.tile_stride = 16; j.ntiles = (MG_TILES_Q - e + 15) >> 4;
                 j.out = MG_Q + (unsigned)((cs * 128 + row0) * MG_F); j.rst = MG_Q + (unsigned)((cn * 128 + row0) * MG_F);
                 j.ldo = MG_F;
                 j.dbg = p.dbg_q ? p.dbg_q + ((size_t)t * B + row0) * MG_F : nullptr; j.ld_dbg = MG_F;
-                tile_gemm<8, 3>(rs, j, smem, rows_valid, dead);
+                tile_gemm<8, 3, 9>(rs, j, smem, rows_valid, dead);
             }
         }
         MG_STAMP(0)
@@ -370,18 +387,12 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 float* s_score = smem + 4 * 2 * 64 * 4;
                 constexpr int RPW = MG_LMAX / 4;            // 20 context rows per wave
                 const float4* ctx = reinterpret_cast<const float4*>(p.ctx) + (size_t)bsc * L * (MG_H / 4);
-                float4 x[RPW][2];
-                uint8_t mk[RPW];
+                float4 x[RPW][2];                           // rows beyond L: a clamped (finite) row, weight 0 below
 #pragma unroll
                 for (int r = 0; r < RPW; ++r) {
-                    const int l = wave4 * RPW + r;
-                    const int lc = min(l, L - 1);
+                    const int lc = min(wave4 * RPW + r, L - 1);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const float4 v = ctx[(size_t)lc * (MG_H / 4) + lane + 64 * i];
-                        x[r][i] = l < L ? v : f4zero();
-                    }
-                    mk[r] = p.mask ? p.mask[(size_t)bsc * L + lc] : 0;
+                    for (int i = 0; i < 2; ++i) x[r][i] = ctx[(size_t)lc * (MG_H / 4) + lane + 64 * i];
                 }
                 const unsigned tb = MG_TT + (unsigned)((cs * 128 + bs) * MG_H);
                 v4u tv[2];
@@ -395,15 +406,15 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                     float d = dot4(x[r][0], v1[0]) + dot4(x[r][1], v1[1]);
                     d = wave_sum(d);
                     const int l = wave4 * RPW + r;
-                    if (lane == 0 && l < L) s_score[l] = mk[r] ? -INFINITY : d;
+                    if (lane == 0 && l < L) s_score[l] = d;
                 }
                 __syncthreads();
                 const int l0 = lane, l1 = lane + 64;
-                const float s0 = l0 < L ? s_score[l0] : -INFINITY;
-                const float s1 = l1 < L ? s_score[l1] : -INFINITY;
+                const float s0 = (l0 < L && !mask0) ? s_score[l0] : -INFINITY;
+                const float s1 = (l1 < L && !mask1) ? s_score[l1] : -INFINITY;
                 const float m = wave_max(fmaxf(s0, s1));
-                const float e0 = l0 < L ? expf(s0 - m) : 0.f;
-                const float e1 = l1 < L ? expf(s1 - m) : 0.f;
+                const float e0 = expf(s0 - m);
+                const float e1 = expf(s1 - m);
                 const float inv = 1.0f / wave_sum(e0 + e1);
                 const float w0 = e0 * inv, w1 = e1 * inv;
                 float4 pw[2] = {f4zero(), f4zero()};
@@ -428,6 +439,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 });
                 __syncthreads();
             }
+            MG_STAMP(2)
             // ---------------- h~ = tanh(W_out [wc ; h1]) (model.py:141-142) ----------------------
             {
                 TileJob j{};
@@ -438,8 +450,9 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 j.out = MG_HT + (unsigned)((cs * 128 + row0) * MG_H); j.rst = MG_HT + (unsigned)((cn * 128 + row0) * MG_H);
                 j.ldo = MG_H;
                 j.dbg = p.dbg_h_tilde ? p.dbg_h_tilde + ((size_t)(t - 1) * B + row0) * MG_H : nullptr; j.ld_dbg = MG_H;
-                tile_gemm<16, 1>(rs, j, smem, rows_valid, dead);
+                tile_gemm<16, 1, 2>(rs, j, smem, rows_valid, dead);
             }
+            MG_STAMP(3)
             // ---------------- [r | const] = M_a h~ + c_a (sf_decoder_fold) -----------------------
             {
                 TileJob j{};
@@ -449,9 +462,9 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 j.out = MG_R + (unsigned)((cs * 128 + row0) * MG_RLD); j.rst = MG_R + (unsigned)((cn * 128 + row0) * MG_RLD);
                 j.ldo = MG_RLD;
                 j.dbg = nullptr; j.ld_dbg = 0;
-                tile_gemm<8, 3>(rs, j, smem, rows_valid, dead);
+                tile_gemm<8, 3, 9>(rs, j, smem, rows_valid, dead);
             }
-            MG_STAMP(2)
+            MG_STAMP(4)
             // ---------------- candidate scores + glue of sample bs (model.py:342-352, follower.py:476-505)
             {
                 float* s_logit = smem;
@@ -460,20 +473,17 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 CandSrc us = p.U;
                 us.vp += (size_t)st * B; us.cand_view += (size_t)st * B * A; us.cand_sincos += (size_t)st * B * A * 4;
                 us.a_num += (size_t)st * B;
+                const int anum = us.a_num[bsc];
                 float4 x[4][9];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int ca = wave4 + 4 * k;
-                    const CandRow cr = cand_row(us, bsc, ca);
-                    const bool have = sample_ok && ca < A && !cr.zero;      // wave-uniform: stop / padding rows cost no traffic
+                    const bool real = sample_ok && ca > 0 && ca < anum;     // stop / padding candidates are zero rows:
+                    const CandRow cr = cand_row(us, bsc, real ? ca : 1);    // they re-load candidate 1 (cache hits) x 0
 #pragma unroll
-                    for (int i = 0; i < 9; ++i) x[k][i] = f4zero();
-                    if (have) {
-#pragma unroll
-                        for (int i = 0; i < 9; ++i) x[k][i] = cand_load(cr, lane + 64 * i, lane + 64 * i < MG_F4, MG_F4);
-                    }
+                    for (int i = 0; i < 9; ++i)
+                        x[k][i] = cand_load(cr, lane + 64 * i, real && !cr.zero && lane + 64 * i < MG_F4, MG_F4);
                 }
-                const int anum = us.a_num[bsc];
                 const int64_t tgt_in = p.target[(size_t)st * B + bsc];
                 const unsigned rb = MG_R + (unsigned)((cs * 128 + bs) * MG_RLD);
                 v4u rv[9];
@@ -564,7 +574,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 }
                 __syncthreads();
             }
-            MG_STAMP(3)
+            MG_STAMP(5)
         } else if (chain && gates) {
             // ---------------- visual attention of sample bs over the panorama of step t (model.py:310-326)
             float4(*slots)[9 * 64] = reinterpret_cast<float4(*)[9 * 64]>(smem);
@@ -647,8 +657,9 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
 
         // ============================ the rest of the gate product ==================================
         gate_group(1 + nf, 1 + nf + nu);                    // u stages (u of step t arrives before the feature)
+        MG_STAMP(6)
         gate_group(1, 1 + nf);                              // feature stages
-        MG_STAMP(4)
+        MG_STAMP(7)
         // the result goes out as [16 x 64] tiles in MFMA layout, one per row group, into the region of the
         // workgroup that owns that group's cell for these 16 units
         {
@@ -660,7 +671,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 xstore(rs, off, v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
             }
         }
-        MG_STAMP(5)
+        MG_STAMP(8)
         // ============================ cell update (owner of row group xcd, units 16 slot..) =========
         if (active) {
             float pre[4] = {bias[0], bias[1], bias[2], bias[3]};
@@ -691,7 +702,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                     for (int sp = 0; sp < 8; ++sp) pre[g] += __uint_as_float(v[g][sp]);
             }
             __syncthreads();                             // every wave has read the region: the owner resets it
-            MG_STAMP(6)
+            MG_STAMP(9)
 #pragma unroll
             for (int i = 0; i < 8; ++i) xreset(rs, base + (unsigned)((tid + 256 * i) * 4));
             {
@@ -715,10 +726,14 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
             }
         }
         __syncthreads();
+        MG_STAMP(10)
     }
     if (pa.trace && tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pa.trace[blockIdx.x * 8 + k] = (unsigned long long)tk[k];
+        for (int k = 0; k < 12; ++k) {
+            pa.trace[blockIdx.x * 32 + k] = (unsigned long long)tk[k];
+            pa.trace[blockIdx.x * 32 + 16 + k] = (unsigned long long)tabs[k];
+        }
     }
     if (tid == 0) {
         const unsigned n = atomicAdd(p.done, 1u);

@@ -113,17 +113,29 @@ def test_persistent_decode_timing():
             print('    %-50s calls %3d avg %9.1f us' % (k[:50], v['calls'] // 5, v['avg_us']))
         mk = [v for k, v in prof.rows.items() if 'mega_kernel' in k][0]
         print('decode loop, %d steps in one launch: %.1f us = %.2f us per step' % (S, mk['avg_us'], mk['avg_us'] / S))
-        trace = torch.zeros(256 * 8, dtype=torch.int64, device='cuda')
+        trace = torch.zeros(256 * 32, dtype=torch.int64, device='cuda')
         _lib.lib.sf_debug_trace(trace.data_ptr())
         run()
         torch.cuda.synchronize()
         _lib.lib.sf_debug_trace(None)
-    tr = trace.cpu().numpy().reshape(256, 8).astype(np.float64) / 100.0 / S
+    raw = trace.cpu().numpy().reshape(256, 32).astype(np.float64)
+    tr = raw[:, :12] / 100.0 / S
     blk = np.arange(256)
     even = ((blk >> 3) & 1) == 0
     act = (blk & 7) < 7
-    names = ['first product (t_text | q)', 'h stage', 'attn+h~+r | visual', 'scores + glue', 'u + feature stages',
-             'tile stores', 'wait partial tiles', 'cell + loop']
+    names = ['first product (t_text | q)', 'h stage', 'text attn | visual', 'h~', 'r', 'scores + glue', 'u stages',
+             'feature stages', 'tile stores', 'wait partial tiles', 'cell', 'loop back']
+    print('  mean us per step and phase')
     for k, n in enumerate(names):
         print('    %-28s even %6.2f   odd %6.2f   idle group %6.2f' % (
             n, tr[even & act, k].mean(), tr[~even & act, k].mean(), tr[~act, k].mean()))
+    ab = raw[:, 16:28] / 100.0
+    t0 = ab[ab > 0].min()
+    print('  step %d: phase END times (us after the earliest stamp), min / mean / max over workgroups' % (S // 2))
+    order = [11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
+    for k in order:
+        for lab, sel in (('even', even & act), ('odd', ~even & act), ('idle', ~act)):
+            v = ab[sel, k]
+            v = v[v > 0] - t0
+            if len(v):
+                print('    %-28s %-5s %7.2f %7.2f %7.2f' % (names[k], lab, v.min(), v.mean(), v.max()))
