@@ -348,6 +348,11 @@ __device__ __forceinline__ void text_attn_body(const TxtArgs& a, int b) {
     // memory round trip each (see sf_rows.h)
     float4 x[RPW][TXT_CPL];
     uint8_t mk[RPW];
+    // the mask bytes are loaded UNCONDITIONALLY (from the context itself when there is no mask): a load
+    // behind even a block-uniform branch is followed by a full `s_waitcnt vmcnt(0)`, which made every
+    // context row its own memory round trip
+    const bool use_mask = MODE == 0 && a.mask != nullptr;
+    const uint8_t* mrow = use_mask ? a.mask + (size_t)bc * L : reinterpret_cast<const uint8_t*>(ctx);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const int l = wave * RPW + r;
@@ -358,8 +363,7 @@ __device__ __forceinline__ void text_attn_body(const TxtArgs& a, int b) {
             const float4 t = ctx[(size_t)lc * n4 + min(c, n4 - 1)];
             x[r][i] = (l < L && c < n4) ? t : f4zero();
         }
-        mk[r] = 0;
-        if (MODE == 0 && a.mask) mk[r] = a.mask[(size_t)bc * L + lc];       // block-uniform branch
+        mk[r] = mrow[lc];
     }
     float4 v1[TXT_CPL], v2[TXT_CPL];
 #pragma unroll
@@ -381,7 +385,7 @@ __device__ __forceinline__ void text_attn_body(const TxtArgs& a, int b) {
         for (int i = 0; i < TXT_CPL; ++i) d += dot4(x[r][i], v1[i]);
         d = wave_sum(d);
         const int l = wave * RPW + r;
-        if (lane == 0 && l < L) s_score[l] = (MODE == 0 && mk[r]) ? -INFINITY : d;
+        if (lane == 0 && l < L) s_score[l] = (use_mask && mk[r]) ? -INFINITY : d;
     }
     __syncthreads();
 

@@ -6,22 +6,28 @@
 //
 //   gate product  (all 256 CUs)  [B, 2F+H] x [4H, 2F+H]^T of the LSTMCell (model.py:393): n-tile = hidden
 //                 units [16c, +16) x 4 gates, K split 8 ways by XCD (stage s of 64 k belongs to split
-//                 s % 8).  The operand row [u | attended feature | h] of step t lives in the exchange
-//                 buffer XIN[t % 3]; partial [16 x 64] tiles go to the SLAB region of the workgroup that
-//                 owns the cell of those rows and units, which sums its 8 partials, updates the cell and
-//                 publishes h.
-//   row group x   (XCD x < ceil(B/16) owns batch rows [16x, +16): the MFMA m-tile).  The chain between two
-//                 cells runs inside the group's XCD, sample r = c / 2 of the group:
-//        even c:  t_text = W_in h1 (tiles)  ->  text attention of sample r  ->  h~ = tanh(W_out [wc ; h1])
-//                 (tiles)  ->  [r | const] = M_a h~ + c_a (tiles, sf_decoder_fold)  ->  candidate scores,
-//                 masking, CE term, action, u of the next step (sample r)
-//        odd c:   q' = M_v h1 + c_v (tiles)  ->  visual attention of sample r over the NEXT step's panorama
-//                 -> attended feature of the next step
+//                 s % 8); the workgroup's weight block of every one of its stages stays in registers for
+//                 the whole episode, only the operand rows stream.  The operand row [u | attended feature |
+//                 h] of step t lives in the exchange buffer XIN[t % 3]; partial [16 x 64] tiles go to the
+//                 SLAB region of the workgroup (XCD = m-tile, slot = n-tile) that owns the cell of those
+//                 16 rows x 16 units, which sums its 8 partials, updates the cell and publishes h.
+//   chain groups  rows [32 g, +32), g = x & 3.  XCDs 0-3 run the text / scoring chain of group g, XCDs 4-7
+//                 the visual chain of the same rows; workgroup c owns sample 32 g + c and tile lane c:
+//        text:    t_text = W_in h1 (tile c)  ->  text attention of the sample  ->  h~ = tanh(W_out [wc ; h1])
+//                 (tile c)  ->  [r | const] = M_a h~ + c_a (tiles c, c+32, .., sf_decoder_fold)  ->
+//                 candidate scores, masking, CE term, action, u of the next step (the sample)
+//        visual:  q' = M_v h1 + c_v (tiles c, c+32, ..)  ->  visual attention of the sample over the NEXT
+//                 step's panorama  ->  attended feature of the next step
 //   Every hand-off is data tagged with a sentinel (0xFFFFFFFF, never a finite float): producers publish
 //   write-through (sc1), consumers re-read until no sentinel is left, and a producer resets the slot
 //   two versions ahead (three slots per buffer; every step is an all-to-all through the gate product, so
 //   all readers of a slot are done before it is reset).  Waits are bounded (0.25 s); a timed-out
 //   workgroup poisons its outputs with NaN instead of hanging.
+//
+// Addressing discipline: every bulk load is a buffer load whose address is (one per-lane VGPR offset) +
+// (a wave-uniform SGPR offset) + (an immediate).  Per-load 64-bit pointers would be hoisted out of the step
+// loop by the compiler (hundreds of them), spilled to scratch and re-read in front of every load.
+// No load sits inside a branch (the compiler ends such a block with a full vmcnt(0) wait).
 //
 // Only the inference forward exists in this form (no tapes for a backward, no dropout).
 #include "sf_kernels.h"
@@ -32,9 +38,10 @@ namespace sf {
 namespace {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
 
 constexpr int MG_SLOTS = 32, MG_XCD = 8;
-constexpr int MG_H = 512, MG_F = 2176, MG_V = 36, MG_AMAX = 16, MG_LMAX = 80;
+constexpr int MG_H = 512, MG_F = 2176, MG_IMG = 2048, MG_LOC = 128, MG_V = 36, MG_AMAX = 16, MG_LMAX = 80;
 constexpr int MG_K = 2 * MG_F + MG_H;                 // 4864 = [u | feat | h]
 constexpr int MG_OFF_F = MG_F, MG_OFF_H = 2 * MG_F;
 constexpr int MG_F4 = MG_F / 4;                       // 544 float4 per feature row
@@ -46,7 +53,7 @@ constexpr long long MG_TIMEOUT = 25000000LL;          // 0.25 s of the 100 MHz w
 constexpr int MG_SC1 = 16;
 constexpr int MG_TILES_R = (MG_F + 4 + 15) / 16;      // 137 tiles of [r | const]
 constexpr int MG_TILES_Q = MG_F / 16;                 // 136
-constexpr int MG_MAXT = 9;                            // tiles per workgroup and phase
+constexpr int MG_GM = 2;                              // MFMA m-tiles of a chain group (32 rows)
 
 // exchange workspace (dword offsets)
 constexpr unsigned MG_XIN = 0, MG_XIN_N = 3u * 128 * MG_K;
@@ -92,108 +99,152 @@ __global__ __launch_bounds__(256) void mega_seed_kernel(unsigned* xin, const flo
     reinterpret_cast<float4*>(xin)[(size_t)row * (MG_K / 4) + c4] = v;
 }
 
+__device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ rsrc_t make_rs(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, bytes, 0x00020000);
+}
 __device__ __forceinline__ bool has_sent(const v4u& v) {
     return v.x == MG_SENT || v.y == MG_SENT || v.z == MG_SENT || v.w == MG_SENT;
-}
-__device__ __forceinline__ v4u xload(__amdgpu_buffer_rsrc_t rs, unsigned dw) {
-    return __builtin_amdgcn_raw_buffer_load_b128(rs, dw * 4u, 0, MG_SC1);
-}
-__device__ __forceinline__ void xstore(__amdgpu_buffer_rsrc_t rs, unsigned dw, const v4u& v) {
-    __builtin_amdgcn_raw_buffer_store_b128(v, rs, dw * 4u, 0, MG_SC1);
-}
-__device__ __forceinline__ void xstore_f(__amdgpu_buffer_rsrc_t rs, unsigned dw, const float4& v) {
-    xstore(rs, dw, v4u{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)});
-}
-__device__ __forceinline__ void xreset(__amdgpu_buffer_rsrc_t rs, unsigned dw) {
-    xstore(rs, dw, v4u{MG_SENT, MG_SENT, MG_SENT, MG_SENT});
-}
-// re-read a published piece until it is complete (bounded)
-__device__ __forceinline__ void settle(__amdgpu_buffer_rsrc_t rs, unsigned dw, v4u& v, bool& dead) {
-    if (!has_sent(v) || dead) return;
-    const long long t0 = wall_clock64();
-    while (has_sent(v)) {
-        asm volatile("" ::: "memory");
-        v = xload(rs, dw);
-        if (wall_clock64() - t0 > MG_TIMEOUT) { dead = true; break; }
-    }
 }
 __device__ __forceinline__ float4 as_f4(const v4u& v) {
     return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
 }
+__device__ __forceinline__ v4u as_u4(const float4& v) {
+    return v4u{__float_as_uint(v.x), __float_as_uint(v.y), __float_as_uint(v.z), __float_as_uint(v.w)};
+}
 __device__ __forceinline__ float qnan() { return __uint_as_float(0x7FC00000u); }
+// all offsets below are BYTES: voff per lane (VGPR), soff wave-uniform (SGPR)
+__device__ __forceinline__ v4u xld(rsrc_t rs, unsigned voff, unsigned soff) {               // exchange data (sc1)
+    return __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, MG_SC1);
+}
+__device__ __forceinline__ void xst(rsrc_t rs, unsigned voff, unsigned soff, const v4u& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff, MG_SC1);
+}
+__device__ __forceinline__ void xrst(rsrc_t rs, unsigned voff, unsigned soff) {
+    xst(rs, voff, soff, v4u{MG_SENT, MG_SENT, MG_SENT, MG_SENT});
+}
+__device__ __forceinline__ float4 bld(rsrc_t rs, unsigned voff, unsigned soff) {             // weights / rows
+    return as_f4(__builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+}
+// re-read a published piece until it is complete (bounded)
+__device__ __forceinline__ void settle(rsrc_t rs, unsigned voff, unsigned soff, v4u& v, bool& dead) {
+    if (!has_sent(v) || dead) return;
+    const long long t0 = wall_clock64();
+    while (has_sent(v)) {
+        asm volatile("" ::: "memory");
+        v = xld(rs, voff, soff);
+        if (wall_clock64() - t0 > MG_TIMEOUT) { dead = true; break; }
+    }
+}
 
-// One chain product of a row group: Y[16 rows, tiles] = A[16, K] W[tile rows, K]^T (+ bias, tanh), the
+// Before a workgroup reads exchanged data it parks: ONE lane polls one representative piece (with a short
+// sleep between reads) and the rest wait at the barrier.  256 lanes per CU spinning on write-through lines
+// load the fabric enough to slow the producers they are waiting for.
+__device__ __forceinline__ void park(rsrc_t rs, unsigned voff, unsigned soff, bool& dead) {
+    if (threadIdx.x == 0 && !dead) {
+        const long long t0 = wall_clock64();
+        v4u v = xld(rs, voff, soff);
+        while (has_sent(v)) {
+            __builtin_amdgcn_s_sleep(4);
+            asm volatile("" ::: "memory");
+            v = xld(rs, voff, soff);
+            if (wall_clock64() - t0 > MG_TIMEOUT) break;       // the readers' own bounded waits report it
+        }
+    }
+    __syncthreads();
+}
+
+// One chain product of a chain group: Y[32 rows, tiles] = A[32, K] W[tile rows, K]^T (+ bias, tanh), the
 // operand A read from exchange buffers (one or two K segments of 512), the result published tile by tile.
-// The 4 waves split K; wave w keeps its K chunk of A in registers and walks the tiles, the partials meet
-// in LDS.  The product is formed TRANSPOSED (W as the MFMA row operand), so a lane ends up with 4
-// consecutive output columns of one batch row: one b128 store.
+// The 4 waves split K; wave w keeps its K chunk of A (both m-tiles) in registers and walks the tiles, the
+// partials meet in LDS.  The product is formed TRANSPOSED (W as the MFMA row operand), so a lane ends up
+// with 4 consecutive output columns of one batch row: one b128 store.  Weight rows beyond w_rows read as
+// zero (buffer bounds), an m-tile beyond `m_live` re-reads m-tile 0 and is not stored.
 struct TileJob {
-    unsigned a0, a1;            // dword offset of row 0 of the group in segment 0 / 1
-    int lda0, lda1;
+    unsigned a0, a1;            // BYTE offset of row 0 of the group in segment 0 / 1 (exchange workspace)
+    int lda0, lda1;             // row strides in floats
     const float* w; int ldw, w_rows;
     const float* bias;
     int tile0, tile_stride, ntiles;
-    unsigned out, rst; int ldo;  // publish / reset slot: dword offset of row 0 of the group
+    unsigned out, rst; int ldo;  // publish / reset slot: BYTE offset of row 0 of the group, row stride in floats
     float* dbg; int ld_dbg;      // optional plain copy: pointer to row 0 of the group
     bool tanh_epi;
+    int m_live;                  // m-tiles of the group that exist (rows < 16 MT)
 };
 template <int NI, int TC, int MAXT>
-__device__ __forceinline__ void tile_gemm(__amdgpu_buffer_rsrc_t rs, const TileJob& j, float* smem, int rows_valid,
-                                          bool& dead) {
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+__device__ __forceinline__ void tile_gemm(rsrc_t rs, const TileJob& j, float* smem, int wv, int rows_valid, bool& dead) {
+    const int lane = threadIdx.x & 63;
     const int li = lane & 15, kk = lane >> 4;
-    const bool second = NI == 16 && w >= 2;              // NI = 8: K = 512, NI = 16: two segments of 512
-    const unsigned abase = (second ? j.a1 : j.a0) + (unsigned)(li * (second ? j.lda1 : j.lda0)) +
-                           (unsigned)((NI == 16 ? (w & 1) * 256 : w * 128) + 4 * kk);
-    const int kw = (NI == 16 ? w * 256 : w * 128) + 4 * kk;
+    const bool second = NI == 16 && wv >= 2;             // NI = 8: K = 512, NI = 16: two segments of 512
+    const int lda = second ? j.lda1 : j.lda0;
+    const unsigned va = (unsigned)(li * lda + 4 * kk) * 4u;                         // per lane
+    const unsigned sa = (second ? j.a1 : j.a0) + (unsigned)(NI == 16 ? (wv & 1) * 256 : wv * 128) * 4u;   // uniform
+    const unsigned vw = (unsigned)(li * j.ldw + 4 * kk) * 4u;
+    const unsigned sw0 = (unsigned)(NI == 16 ? wv * 256 : wv * 128) * 4u;
+    const rsrc_t rw = make_rs(j.w, (unsigned)j.w_rows * (unsigned)j.ldw * 4u);
     f32x4* red = reinterpret_cast<f32x4*>(smem);
-    // every load below is unconditional on a clamped index (a load inside a branch would be followed by a
-    // full vmcnt(0) wait): chunk c + 1 of the weights is in flight while chunk c is multiplied
     constexpr int NCH = (MAXT + TC - 1) / TC;
     float4 wf[2][TC][NI];
     auto wload = [&](int ch, float4 (&dst)[TC][NI]) {
 #pragma unroll
         for (int tc = 0; tc < TC; ++tc) {
             const int tile = j.tile0 + min(ch * TC + tc, j.ntiles - 1) * j.tile_stride;
-            const float* wp = j.w + (size_t)min(16 * tile + li, j.w_rows - 1) * j.ldw + kw;
+            const unsigned sw = sw0 + (unsigned)(16 * tile * j.ldw) * 4u;
 #pragma unroll
-            for (int i = 0; i < NI; ++i) dst[tc][i] = ld4(wp + 16 * i);
+            for (int i = 0; i < NI; ++i) dst[tc][i] = bld(rw, vw + 64u * i, sw);
         }
     };
     wload(0, wf[0]);
-    v4u a[NI];
+    v4u a[MG_GM][NI];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) a[i] = xload(rs, abase + 16 * i);
+    for (int mm = 0; mm < MG_GM; ++mm) {
+        const unsigned sam = sa + (unsigned)((mm < j.m_live ? mm : 0) * 16 * lda) * 4u;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) a[mm][i] = xld(rs, va + 64u * i, sam);
+    }
+    park(rs, 0u, j.a0, dead);                            // (the loads above are in flight: a ready operand costs one trip)
 #pragma unroll
     for (int ch = 0; ch < NCH; ++ch) {
         if (ch * TC < j.ntiles || ch == 0) {
             if (ch + 1 < NCH) wload(ch + 1, wf[(ch + 1) & 1]);
             if (ch == 0) {
 #pragma unroll
-                for (int i = 0; i < NI; ++i) settle(rs, abase + 16 * i, a[i], dead);
+                for (int mm = 0; mm < MG_GM; ++mm) {
+                    const unsigned sam = sa + (unsigned)((mm < j.m_live ? mm : 0) * 16 * lda) * 4u;
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) settle(rs, va + 64u * i, sam, a[mm][i], dead);
+                }
             }
 #pragma unroll
             for (int tc = 0; tc < TC; ++tc) {
                 if (ch * TC + tc < j.ntiles) {
-                    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+                    f32x4 acc[MG_GM];
+#pragma unroll
+                    for (int mm = 0; mm < MG_GM; ++mm) acc[mm] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                     for (int i = 0; i < NI; ++i) {
-                        const float4 af = as_f4(a[i]);
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) acc = mfma16(comp(wf[ch & 1][tc][i], q), comp(af, q), acc);
+                        for (int q = 0; q < 4; ++q)
+#pragma unroll
+                            for (int mm = 0; mm < MG_GM; ++mm)
+                                acc[mm] = mfma16(comp(wf[ch & 1][tc][i], q), comp(as_f4(a[mm][i]), q), acc[mm]);
                     }
-                    red[(w * MG_MAXT + ch * TC + tc) * 64 + lane] = acc;
+#pragma unroll
+                    for (int mm = 0; mm < MG_GM; ++mm)
+                        red[((wv * MAXT + ch * TC + tc) * MG_GM + mm) * 64 + lane] = acc[mm];
                 }
             }
         }
     }
     __syncthreads();
-    for (int ti = w; ti < j.ntiles; ti += 4) {
-        f32x4 s = red[ti * 64 + lane];
+    for (int tj = wv; tj < j.ntiles * MG_GM; tj += 4) {
+        const int ti = tj / MG_GM, mm = tj - ti * MG_GM;
+        f32x4 s = red[(ti * MG_GM + mm) * 64 + lane];
 #pragma unroll
-        for (int ww = 1; ww < 4; ++ww) s += red[(ww * MG_MAXT + ti) * 64 + lane];
+        for (int ww = 1; ww < 4; ++ww) s += red[((ww * MAXT + ti) * MG_GM + mm) * 64 + lane];
         const int tile = j.tile0 + ti * j.tile_stride;
         const int col = 16 * tile + 4 * kk;
+        const int row = 16 * mm + li;
         if (j.bias) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) s[q] += j.bias[min(col + q, j.w_rows - 1)];
@@ -203,11 +254,14 @@ __device__ __forceinline__ void tile_gemm(__amdgpu_buffer_rsrc_t rs, const TileJ
             for (int q = 0; q < 4; ++q) s[q] = tanhf(s[q]);
         }
         if (dead) s = f32x4{qnan(), qnan(), qnan(), qnan()};
-        const unsigned o = (unsigned)(li * j.ldo + col);
-        xstore(rs, j.out + o, v4u{__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])});
-        xreset(rs, j.rst + o);
-        if (j.dbg && li < rows_valid && col + 3 < j.ld_dbg)
-            *reinterpret_cast<float4*>(j.dbg + (size_t)li * j.ld_dbg + col) = make_float4(s[0], s[1], s[2], s[3]);
+        if (mm < j.m_live) {
+            const unsigned vo = (unsigned)(li * j.ldo + 4 * kk) * 4u;
+            const unsigned so = (unsigned)(16 * mm * j.ldo + 16 * tile) * 4u;
+            xst(rs, vo, j.out + so, v4u{__float_as_uint(s[0]), __float_as_uint(s[1]), __float_as_uint(s[2]), __float_as_uint(s[3])});
+            xrst(rs, vo, j.rst + so);
+            if (j.dbg && row < rows_valid && col + 3 < j.ld_dbg)
+                *reinterpret_cast<float4*>(j.dbg + (size_t)row * j.ld_dbg + col) = make_float4(s[0], s[1], s[2], s[3]);
+        }
     }
     __syncthreads();
 }
@@ -219,17 +273,19 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     constexpr int AROWS = MT * 16, WROWS = 64;
     constexpr int BUF = (AROWS + WROWS) * MG_LD;
     constexpr int APASS = MT;                            // 16 rows x 16 float4 per staging pass
-    const int tid = threadIdx.x, lane = tid & 63, wave4 = tid >> 6;
-    const int gate = wave4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = uni(tid >> 6);                        // wave index as a wave-uniform (SGPR) value
+    const int gate = wv;
     const int li = lane & 15, kk = lane >> 4;
     const int xcd = blockIdx.x & (MG_XCD - 1), slot = blockIdx.x >> 3;
     const int B = p.B, S = p.S, L = p.L, A = p.U.A;
     const int ldrow = tid >> 4, ldc4 = tid & 15;
     const size_t BH = (size_t)B * MG_H;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(p.xchg, 0, MG_TOTAL * 4, 0x00020000);
+    const rsrc_t rs = make_rs(p.xchg, MG_TOTAL * 4u);
+    const unsigned vl16 = (unsigned)lane * 16u;          // this lane's float4 of a 1 KB row chunk
     bool dead = false;
 
-    // ---- cell ownership: (row group = xcd, units [16 slot, +16)); every thread owns one element
+    // ---- cell ownership: (m-tile = xcd, units [16 slot, +16)); every thread owns one element
     const bool active = xcd < MT;
     const int er = (tid >> 4) & 15, eu = tid & 15;
     const int eb = xcd * 16 + er;
@@ -241,14 +297,19 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     for (int g = 0; g < 4; ++g) bias[g] = p.b_ih[g * MG_H + ej] + p.b_hh[g * MG_H + ej];
     float c_state = p.c_init[(size_t)ebc * MG_H + ej];
 
-    // ---- per-sample role inside the row group
-    const bool even = (slot & 1) == 0;
-    const int e = slot >> 1;                              // sample of the group, and tile lane of the group
-    const int bs = xcd * 16 + e;
-    const bool sample_ok = active && bs < B;
+    // ---- chain role: XCDs 0-3 run the text / scoring chain of rows [32 (x & 3), +32), XCDs 4-7 the visual
+    // chain of the same rows; workgroup c of the XCD owns sample c of the group and tile lane c of its products
+    constexpr int NGRP = (MT + 1) / 2;
+    const int cg = xcd & 3;
+    const bool text_role = xcd < 4;
+    const bool chain_active = cg < NGRP;
+    const int e = slot;
+    const int bs = cg * 32 + e;
+    const bool sample_ok = chain_active && bs < B;
     const int bsc = min(bs, B - 1);
-    const int row0 = xcd * 16;                            // first row of the group
-    const int rows_valid = max(0, min(16, B - row0));
+    const int row0 = cg * 32;                             // first row of the chain group
+    const int rows_valid = max(0, min(32, B - row0));
+    const int m_live = min(MG_GM, MT - 2 * cg);           // m-tiles of the group inside the gate product's rows
     bool ended_reg = p.ended[bsc] != 0;
     // instruction mask of the sample (step-invariant): lane l holds positions l and l + 64
     const bool mask0 = p.mask[(size_t)bsc * L + min(lane, L - 1)] != 0;
@@ -260,61 +321,95 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     const int sh = 2 * MG_NU + ((xcd - 2 * MG_NU) & 7);
     const int f0 = MG_NU + ((xcd - MG_NU) & 7), nf = (2 * MG_NU - f0 + 7) >> 3;
     const int nu = (MG_NU - xcd + 7) >> 3;
-    auto stage_of = [&](int i) { return i == 0 ? sh : (i <= nf ? f0 + 8 * (i - 1) : xcd + 8 * (i - 1 - nf)); };
+    // The weights of those stages never change: this workgroup's [64 gate rows x 64 k] block of every stage
+    // stays in registers for the whole episode, in the staging layout (4 float4 per thread and stage), so
+    // the step loop streams only the operand rows.  (Indexed by unrolled loop counters only.)
+    constexpr int NKMAX = 5;
+    float4 wres_h[1][4], wres_f[NKMAX][4], wres_u[NKMAX][4];
+    {
+        auto wstage = [&](int s, float4 (&dst)[4]) {
+            const int k0 = s * MG_BK;
+            const bool is_h = s >= 2 * MG_NU;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp) {
+                const int wrow = pp * MG_H + 16 * slot + ldrow;                   // gate pp, unit 16 slot + ldrow
+                dst[pp] = is_h ? ld4(p.w_hh + (size_t)wrow * MG_H + (k0 - MG_OFF_H) + 4 * ldc4)
+                               : ld4(p.w_ih + (size_t)wrow * 2 * MG_F + k0 + 4 * ldc4);
+            }
+        };
+        wstage(sh, wres_h[0]);
+#pragma unroll
+        for (int k = 0; k < NKMAX; ++k) {
+            wstage(f0 + 8 * min(k, nf - 1), wres_f[k]);
+            wstage(xcd + 8 * min(k, nu - 1), wres_u[k]);
+        }
+    }
 
-    // development aid (pa.trace): per phase the ticks summed over the steps, and the absolute stamps of the
-    // middle step
-    long long tk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tabs[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    long long tprev = wall_clock64();
+    // development aid (pa.trace): per phase the ticks summed over the steps, and the stamps of the middle step
+    unsigned tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tabs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned tprev = (unsigned)wall_clock64();           // 32-bit ticks (10 ns): 42 s before they wrap
     int t_now = 0;
 #define MG_STAMP(k)                                 \
     if (pa.trace) {                                 \
-        const long long now_ = wall_clock64();      \
+        const unsigned now_ = (unsigned)wall_clock64(); \
         tk[k] += now_ - tprev;                      \
         if (t_now == (S >> 1)) tabs[k] = now_;      \
         tprev = now_;                               \
     }
 
+    // per-lane parts of the addresses used below
+    const unsigned v_stage = (unsigned)(ldrow * MG_K + 4 * ldc4) * 4u;               // gate operand staging
+    const unsigned v_slab = (unsigned)((((er >> 2)) * 16 + eu) * 4 + (er & 3)) * 4u;  // cell: element of a partial tile
+
+    // indices of the sample for its NEXT per-sample phase, requested one step ahead (a dependent round trip each
+    // otherwise): scoring of decode step st -> a_num, vp, target, per lane a the view and sin/cos of candidate a;
+    // visual attention over step t's panorama -> vp, view
+    int pf_anum = 0, pf_vp = -1, pf_view = 0;
+    int64_t pf_tgt = -1;
+    float4 pf_sc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int pv_vp = -1, pv_view = 0;
+    auto fetch_score_idx = [&](int st) {
+        const size_t sb = (size_t)min(st, S - 1) * B + bsc;
+        pf_anum = p.U.a_num[sb];
+        pf_vp = p.U.vp[sb];
+        pf_tgt = p.target[sb];
+        pf_view = p.U.cand_view[sb * A + min(lane, A - 1)];
+        pf_sc = reinterpret_cast<const float4*>(p.U.cand_sincos)[sb * A + min(lane, A - 1)];
+    };
+    auto fetch_pano_idx = [&](int tt) {
+        const size_t sb = (size_t)min(tt, S - 1) * B + bsc;
+        pv_vp = p.X.vp[sb];
+        pv_view = p.X.view[sb];
+    };
+    if (text_role) fetch_score_idx(0); else fetch_pano_idx(1);
+
     f32x4 acc[MT];
     for (int t = 0; t <= S; ++t) {
         t_now = t;
-        const unsigned xb = MG_XIN + (unsigned)((t % 3) * 128 * MG_K);           // operand rows of step t
-        const unsigned xn = MG_XIN + (unsigned)(((t + 1) % 3) * 128 * MG_K);     // ... of step t + 1
+        const unsigned xb = (MG_XIN + (unsigned)((t % 3) * 128 * MG_K)) * 4u;            // operand rows of step t (bytes)
+        const unsigned xn = (MG_XIN + (unsigned)(((t + 1) % 3) * 128 * MG_K)) * 4u;      // ... of step t + 1
         const int cs = (t + 2) % 3, cn = t % 3;           // chain step t - 1: its slot, and the one it resets
-        const bool chain = t > 0 && active;
+        const bool chain = t > 0 && chain_active;
         const bool gates = t < S;
 
-        // ============================ gate product: stages [i0, i1) of this workgroup ================
-        struct Regs { v4u a[APASS]; float4 w[4]; };
-        auto issue = [&](Regs& r, int s) {
-            const int k0 = s * MG_BK;                       // XIN columns are in stage order: u | feat | h
-            const bool is_h = s >= 2 * MG_NU;
+        // ============================ gate product ==================================================
+        auto issue = [&](v4u (&r)[APASS], int s) {          // operand rows of stage s (XIN columns are in stage order)
 #pragma unroll
-            for (int pp = 0; pp < APASS; ++pp)
-                r.a[pp] = xload(rs, xb + (unsigned)((pp * 16 + ldrow) * MG_K + k0 + 4 * ldc4));
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int nl = pp * 16 + ldrow;
-                const int wrow = (nl >> 4) * MG_H + 16 * slot + (nl & 15);
-                r.w[pp] = is_h ? ld4(p.w_hh + (size_t)wrow * MG_H + (k0 - MG_OFF_H) + 4 * ldc4)
-                               : ld4(p.w_ih + (size_t)wrow * 2 * MG_F + k0 + 4 * ldc4);
-            }
+            for (int pp = 0; pp < APASS; ++pp) r[pp] = xld(rs, v_stage, xb + (unsigned)(pp * 16 * MG_K + s * MG_BK) * 4u);
         };
-        auto settle_stage = [&](Regs& r, int s) {
-            const int k0 = s * MG_BK;
+        auto settle_stage = [&](v4u (&r)[APASS], int s) {
 #pragma unroll
-            for (int pp = 0; pp < APASS; ++pp)
-                settle(rs, xb + (unsigned)((pp * 16 + ldrow) * MG_K + k0 + 4 * ldc4), r.a[pp], dead);
+            for (int pp = 0; pp < APASS; ++pp) settle(rs, v_stage, xb + (unsigned)(pp * 16 * MG_K + s * MG_BK) * 4u, r[pp], dead);
         };
-        auto lstore = [&](const Regs& r, int buf) {
+        auto lstore = [&](const v4u (&r)[APASS], const float4 (&wr)[4], int buf) {
             float* As = smem + buf * BUF;
             float* Ws = As + AROWS * MG_LD;
 #pragma unroll
             for (int pp = 0; pp < APASS; ++pp)
-                *reinterpret_cast<v4u*>(As + (pp * 16 + ldrow) * MG_LD + 4 * ldc4) = r.a[pp];
+                *reinterpret_cast<v4u*>(As + (pp * 16 + ldrow) * MG_LD + 4 * ldc4) = r[pp];
 #pragma unroll
             for (int pp = 0; pp < 4; ++pp)
-                *reinterpret_cast<float4*>(Ws + (pp * 16 + ldrow) * MG_LD + 4 * ldc4) = r.w[pp];
+                *reinterpret_cast<float4*>(Ws + (pp * 16 + ldrow) * MG_LD + 4 * ldc4) = wr[pp];
         };
         auto compute = [&](int buf) {
             const float* As = smem + buf * BUF;
@@ -332,22 +427,28 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                     for (int m = 0; m < MT; ++m) acc[m] = mfma16(comp(av[m], j), comp(bq, j), acc[m]);
             }
         };
-        auto gate_group = [&](int i0, int i1) {
-            if (i0 >= i1) return;
-            Regs r0, r1;
-            issue(r0, stage_of(i0));
-            settle_stage(r0, stage_of(i0));
-            lstore(r0, 0);
+        // stages s0, s0 + 8, ... (n of them, n <= rows of wr): the operand rows of ALL of them are requested at
+        // once (a round trip of an exchange load is ~2.5 us under load, a stage's MFMAs 1.5 us)
+        auto gate_group = [&](const auto& wr, int s0, int n) {
+            constexpr int NK = (int)(sizeof(wr) / sizeof(wr[0]));
+            v4u ar[NK][APASS];
+#pragma unroll
+            for (int k = 0; k < NK; ++k) issue(ar[k], s0 + 8 * min(k, n - 1));
+            park(rs, 0u, xb + (unsigned)(s0 * MG_BK) * 4u, dead);
+            settle_stage(ar[0], s0);
+            lstore(ar[0], wr[0], 0);
             __syncthreads();
-            for (int i = i0; i < i1; ++i) {
-                const bool more = i + 1 < i1;
-                if (more) issue(r1, stage_of(i + 1));
-                compute((i - i0) & 1);
-                if (more) {
-                    settle_stage(r1, stage_of(i + 1));
-                    lstore(r1, (i + 1 - i0) & 1);
+#pragma unroll
+            for (int k = 0; k < NK; ++k) {
+                if (k < n) {
+                    const bool more = k + 1 < NK && k + 1 < n;
+                    compute(k & 1);
+                    if (more) {
+                        settle_stage(ar[k + 1 < NK ? k + 1 : NK - 1], s0 + 8 * (k + 1));
+                        lstore(ar[k + 1 < NK ? k + 1 : NK - 1], wr[k + 1 < NK ? k + 1 : NK - 1], (k + 1) & 1);
+                    }
+                    __syncthreads();
                 }
-                __syncthreads();
             }
         };
 
@@ -355,86 +456,88 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
         // ============================ chain of step t - 1, first product ============================
         if (chain) {
             TileJob j{};
-            j.a0 = xb + (unsigned)(row0 * MG_K + MG_OFF_H); j.lda0 = MG_K;          // h1 of step t - 1
-            j.tile_stride = 1; j.tanh_epi = false;
-            if (even) {                                     // t_text = W_in h1 (model.py:129)
+            j.a0 = xb + (unsigned)(row0 * MG_K + MG_OFF_H) * 4u; j.lda0 = MG_K;     // h1 of step t - 1
+            j.tile_stride = 1; j.tanh_epi = false; j.m_live = m_live;
+            if (text_role) {                                // t_text = W_in h1 (model.py:129)
                 j.w = p.w_in; j.ldw = MG_H; j.w_rows = MG_H; j.bias = nullptr;
-                j.tile0 = 2 * e; j.ntiles = 2;
-                j.out = MG_TT + (unsigned)((cs * 128 + row0) * MG_H); j.rst = MG_TT + (unsigned)((cn * 128 + row0) * MG_H);
+                j.tile0 = e; j.ntiles = 1;
+                j.out = (MG_TT + (unsigned)((cs * 128 + row0) * MG_H)) * 4u; j.rst = (MG_TT + (unsigned)((cn * 128 + row0) * MG_H)) * 4u;
                 j.ldo = MG_H;
                 j.dbg = p.dbg_t_text ? p.dbg_t_text + ((size_t)(t - 1) * B + row0) * MG_H : nullptr; j.ld_dbg = MG_H;
-                tile_gemm<8, 2, 2>(rs, j, smem, rows_valid, dead);
+                tile_gemm<8, 1, 1>(rs, j, smem, wv, rows_valid, dead);
             } else if (gates) {                             // q' = M_v h1 + c_v: the query of step t's panorama
                 j.w = p.m_v; j.ldw = MG_H; j.w_rows = MG_F; j.bias = p.c_v;
-                j.tile0 = e; j.tile_stride = 16; j.ntiles = (MG_TILES_Q - e + 15) >> 4;
-                j.out = MG_Q + (unsigned)((cs * 128 + row0) * MG_F); j.rst = MG_Q + (unsigned)((cn * 128 + row0) * MG_F);
+                j.tile0 = e; j.tile_stride = 32; j.ntiles = (MG_TILES_Q - e + 31) >> 5;
+                j.out = (MG_Q + (unsigned)((cs * 128 + row0) * MG_F)) * 4u; j.rst = (MG_Q + (unsigned)((cn * 128 + row0) * MG_F)) * 4u;
                 j.ldo = MG_F;
                 j.dbg = p.dbg_q ? p.dbg_q + ((size_t)t * B + row0) * MG_F : nullptr; j.ld_dbg = MG_F;
-                tile_gemm<8, 3, 9>(rs, j, smem, rows_valid, dead);
+                tile_gemm<8, 2, 5>(rs, j, smem, wv, rows_valid, dead);
             }
         }
         MG_STAMP(0)
         if (gates) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gate_group(0, 1);                               // the h stage
+            gate_group(wres_h, sh, 1);                      // the h stage
         }
         MG_STAMP(1)
-        if (chain && even) {
+        if (chain && text_role) {
             // ---------------- text attention of sample bs (model.py:129-139) --------------------
             {
                 float4(*slots)[2 * 64] = reinterpret_cast<float4(*)[2 * 64]>(smem);
                 float* s_score = smem + 4 * 2 * 64 * 4;
                 constexpr int RPW = MG_LMAX / 4;            // 20 context rows per wave
-                const float4* ctx = reinterpret_cast<const float4*>(p.ctx) + (size_t)bsc * L * (MG_H / 4);
-                float4 x[RPW][2];                           // rows beyond L: a clamped (finite) row, weight 0 below
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    const int lc = min(wave4 * RPW + r, L - 1);
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) x[r][i] = ctx[(size_t)lc * (MG_H / 4) + lane + 64 * i];
-                }
-                const unsigned tb = MG_TT + (unsigned)((cs * 128 + bs) * MG_H);
-                v4u tv[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) tv[i] = xload(rs, tb + 4 * (lane + 64 * i));
-#pragma unroll
-                for (int i = 0; i < 2; ++i) settle(rs, tb + 4 * (lane + 64 * i), tv[i], dead);
-                const float4 v1[2] = {as_f4(tv[0]), as_f4(tv[1])};
-#pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    float d = dot4(x[r][0], v1[0]) + dot4(x[r][1], v1[1]);
-                    d = wave_sum(d);
-                    const int l = wave4 * RPW + r;
-                    if (lane == 0 && l < L) s_score[l] = d;
-                }
-                __syncthreads();
-                const int l0 = lane, l1 = lane + 64;
-                const float s0 = (l0 < L && !mask0) ? s_score[l0] : -INFINITY;
-                const float s1 = (l1 < L && !mask1) ? s_score[l1] : -INFINITY;
-                const float m = wave_max(fmaxf(s0, s1));
-                const float e0 = expf(s0 - m);
-                const float e1 = expf(s1 - m);
-                const float inv = 1.0f / wave_sum(e0 + e1);
-                const float w0 = e0 * inv, w1 = e1 * inv;
+                const unsigned ob = (MG_WC + (unsigned)((cs * 128 + bs) * MG_H)) * 4u, rb = (MG_WC + (unsigned)((cn * 128 + bs) * MG_H)) * 4u;
                 float4 pw[2] = {f4zero(), f4zero()};
+                if (sample_ok) {                            // (workgroup-uniform; the loads inside are unconditional)
+                    const rsrc_t rc = make_rs(p.ctx + (size_t)bsc * L * MG_H, (unsigned)(L * MG_H) * 4u);
+                    float4 x[RPW][2];                       // rows beyond L: a clamped (finite) row, weight 0 below
 #pragma unroll
-                for (int r = 0; r < RPW; ++r) {
-                    const int l = wave4 * RPW + r;
-                    const int src = (l < L ? l : 0) & 63;
-                    const float lo = __shfl(w0, src, WAVE), hi = __shfl(w1, src, WAVE);
-                    const float wl = l < L ? (l < 64 ? lo : hi) : 0.f;
-                    f4fma(pw[0], wl, x[r][0]);
-                    f4fma(pw[1], wl, x[r][1]);
+                    for (int r = 0; r < RPW; ++r) {
+                        const unsigned so = (unsigned)(min(wv * RPW + r, L - 1) * MG_H) * 4u;
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) x[r][i] = bld(rc, vl16 + 1024u * i, so);
+                    }
+                    const unsigned tb = (MG_TT + (unsigned)((cs * 128 + bs) * MG_H)) * 4u;
+                    v4u tv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) tv[i] = xld(rs, vl16 + 1024u * i, tb);
+                    park(rs, 0u, tb, dead);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) settle(rs, vl16 + 1024u * i, tb, tv[i], dead);
+                    const float4 v1[2] = {as_f4(tv[0]), as_f4(tv[1])};
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        float d = dot4(x[r][0], v1[0]) + dot4(x[r][1], v1[1]);
+                        d = wave_sum(d);
+                        const int l = wv * RPW + r;
+                        if (lane == 0 && l < L) s_score[l] = d;
+                    }
+                    __syncthreads();
+                    const int l0 = lane, l1 = lane + 64;
+                    const float s0 = (l0 < L && !mask0) ? s_score[l0] : -INFINITY;
+                    const float s1 = (l1 < L && !mask1) ? s_score[l1] : -INFINITY;
+                    const float m = wave_max(fmaxf(s0, s1));
+                    const float e0 = expf(s0 - m);
+                    const float e1 = expf(s1 - m);
+                    const float inv = 1.0f / wave_sum(e0 + e1);
+                    const float w0 = e0 * inv, w1 = e1 * inv;
+#pragma unroll
+                    for (int r = 0; r < RPW; ++r) {
+                        const int l = wv * RPW + r;
+                        const int src = (l < L ? l : 0) & 63;
+                        const float lo = __shfl(w0, src, WAVE), hi = __shfl(w1, src, WAVE);
+                        const float wl = l < L ? (l < 64 ? lo : hi) : 0.f;
+                        f4fma(pw[0], wl, x[r][0]);
+                        f4fma(pw[1], wl, x[r][1]);
+                    }
                 }
-                const unsigned ob = MG_WC + (unsigned)((cs * 128 + bs) * MG_H), rb = MG_WC + (unsigned)((cn * 128 + bs) * MG_H);
                 float* dbg = (p.dbg_cat2 && sample_ok) ? p.dbg_cat2 + ((size_t)(t - 1) * B + bs) * 2 * MG_H : nullptr;
                 const bool poison = dead;
                 block_row_sum<2, 4, 4>(pw, slots, MG_H / 4, [&](int c, float4 v) {
-                    if (!sample_ok) v = f4zero();
                     if (poison) v.x = qnan();
-                    xstore_f(rs, ob + 4 * c, v);
-                    xreset(rs, rb + 4 * c);
+                    xst(rs, 16u * c, ob, as_u4(v));
+                    xrst(rs, 16u * c, rb);
                     if (dbg) reinterpret_cast<float4*>(dbg)[c] = v;
                 });
                 __syncthreads();
@@ -443,26 +546,26 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
             // ---------------- h~ = tanh(W_out [wc ; h1]) (model.py:141-142) ----------------------
             {
                 TileJob j{};
-                j.a0 = MG_WC + (unsigned)((cs * 128 + row0) * MG_H); j.lda0 = MG_H;
-                j.a1 = xb + (unsigned)(row0 * MG_K + MG_OFF_H); j.lda1 = MG_K;
+                j.a0 = (MG_WC + (unsigned)((cs * 128 + row0) * MG_H)) * 4u; j.lda0 = MG_H;
+                j.a1 = xb + (unsigned)(row0 * MG_K + MG_OFF_H) * 4u; j.lda1 = MG_K;
                 j.w = p.w_out; j.ldw = 2 * MG_H; j.w_rows = MG_H; j.bias = nullptr;
-                j.tile0 = 2 * e; j.tile_stride = 1; j.ntiles = 2; j.tanh_epi = true;
-                j.out = MG_HT + (unsigned)((cs * 128 + row0) * MG_H); j.rst = MG_HT + (unsigned)((cn * 128 + row0) * MG_H);
+                j.tile0 = e; j.tile_stride = 1; j.ntiles = 1; j.tanh_epi = true; j.m_live = m_live;
+                j.out = (MG_HT + (unsigned)((cs * 128 + row0) * MG_H)) * 4u; j.rst = (MG_HT + (unsigned)((cn * 128 + row0) * MG_H)) * 4u;
                 j.ldo = MG_H;
                 j.dbg = p.dbg_h_tilde ? p.dbg_h_tilde + ((size_t)(t - 1) * B + row0) * MG_H : nullptr; j.ld_dbg = MG_H;
-                tile_gemm<16, 1, 2>(rs, j, smem, rows_valid, dead);
+                tile_gemm<16, 1, 1>(rs, j, smem, wv, rows_valid, dead);
             }
             MG_STAMP(3)
             // ---------------- [r | const] = M_a h~ + c_a (sf_decoder_fold) -----------------------
             {
                 TileJob j{};
-                j.a0 = MG_HT + (unsigned)((cs * 128 + row0) * MG_H); j.lda0 = MG_H;
+                j.a0 = (MG_HT + (unsigned)((cs * 128 + row0) * MG_H)) * 4u; j.lda0 = MG_H;
                 j.w = p.m_a; j.ldw = MG_H; j.w_rows = MG_F + 4; j.bias = p.c_a;
-                j.tile0 = e; j.tile_stride = 16; j.ntiles = (MG_TILES_R - e + 15) >> 4; j.tanh_epi = false;
-                j.out = MG_R + (unsigned)((cs * 128 + row0) * MG_RLD); j.rst = MG_R + (unsigned)((cn * 128 + row0) * MG_RLD);
+                j.tile0 = e; j.tile_stride = 32; j.ntiles = (MG_TILES_R - e + 31) >> 5; j.tanh_epi = false; j.m_live = m_live;
+                j.out = (MG_R + (unsigned)((cs * 128 + row0) * MG_RLD)) * 4u; j.rst = (MG_R + (unsigned)((cn * 128 + row0) * MG_RLD)) * 4u;
                 j.ldo = MG_RLD;
                 j.dbg = nullptr; j.ld_dbg = 0;
-                tile_gemm<8, 3, 9>(rs, j, smem, rows_valid, dead);
+                tile_gemm<8, 2, 5>(rs, j, smem, wv, rows_valid, dead);
             }
             MG_STAMP(4)
             // ---------------- candidate scores + glue of sample bs (model.py:342-352, follower.py:476-505)
@@ -470,43 +573,71 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 float* s_logit = smem;
                 int* s_at = reinterpret_cast<int*>(smem + 64);
                 const int st = t - 1;                       // decode step of this chain
-                CandSrc us = p.U;
-                us.vp += (size_t)st * B; us.cand_view += (size_t)st * B * A; us.cand_sincos += (size_t)st * B * A * 4;
-                us.a_num += (size_t)st * B;
-                const int anum = us.a_num[bsc];
                 float4 x[4][9];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const int ca = wave4 + 4 * k;
-                    const bool real = sample_ok && ca > 0 && ca < anum;     // stop / padding candidates are zero rows:
-                    const CandRow cr = cand_row(us, bsc, real ? ca : 1);    // they re-load candidate 1 (cache hits) x 0
+                for (int k = 0; k < 4; ++k)
 #pragma unroll
-                    for (int i = 0; i < 9; ++i)
-                        x[k][i] = cand_load(cr, lane + 64 * i, real && !cr.zero && lane + 64 * i < MG_F4, MG_F4);
-                }
-                const int64_t tgt_in = p.target[(size_t)st * B + bsc];
-                const unsigned rb = MG_R + (unsigned)((cs * 128 + bs) * MG_RLD);
-                v4u rv[9];
-#pragma unroll
-                for (int i = 0; i < 9; ++i) rv[i] = xload(rs, rb + 4 * min(lane + 64 * i, MG_F4));   // chunk 544 = [const | ..]
-#pragma unroll
-                for (int i = 0; i < 9; ++i) settle(rs, rb + 4 * min(lane + 64 * i, MG_F4), rv[i], dead);
+                    for (int i = 0; i < 9; ++i) x[k][i] = f4zero();
+                int anum = 0;
+                int64_t tgt_in = -1;
                 float d[4] = {0.f, 0.f, 0.f, 0.f};
+                float cst = 0.f;
+                if (sample_ok) {                            // (workgroup-uniform; the loads inside are unconditional)
+                    // the sample's indices (requested a step ago) are wave-uniform: scalar registers
+                    anum = uni(pf_anum);
+                    const int vp = uni(pf_vp);
+                    tgt_in = pf_tgt;
+                    const rsrc_t rt = make_rs(p.U.table + (size_t)max(vp, 0) * MG_V * MG_IMG, (unsigned)(MG_V * MG_IMG) * 4u);
 #pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    const float4 r4 = as_f4(rv[i]);
+                    for (int k = 0; k < 4; ++k) {
+                        const int ca = wv + 4 * k;
+                        const bool real = ca > 0 && ca < anum && vp >= 0;   // stop / padding candidates are zero rows:
+                        const int cl = real ? ca : 1;                        // they re-read candidate 1 (cache hits) x 0
+                        const int view = __builtin_amdgcn_readlane(pf_view, cl);
+                        const float4 sc = make_float4(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf_sc.x), cl)),
+                                                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf_sc.y), cl)),
+                                                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf_sc.z), cl)),
+                                                      __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf_sc.w), cl)));
+                        const unsigned so = (unsigned)(min(max(view, 0), MG_V - 1) * MG_IMG) * 4u;
+                        const float on = real ? 1.f : 0.f;
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) d[k] += dot4(x[k][i], r4);   // x is zero beyond the row: the constant chunk adds 0
+                        for (int i = 0; i < 8; ++i) {       // image features: 8 chunks of 1 KB
+                            const float4 v = bld(rt, vl16 + 1024u * (i & 3), so + 4096u * (i >> 2));
+                            x[k][i] = make_float4(v.x * on, v.y * on, v.z * on, v.w * on);
+                        }
+                        // location features (env.py:60-75): sin h, cos h, sin e, cos e, each repeated LOC/4 times
+                        const int grp = (lane >> 3) & 3;
+                        const float lv = (grp == 0 ? sc.x : (grp == 1 ? sc.y : (grp == 2 ? sc.z : sc.w))) * (lane < 32 ? on : 0.f);
+                        x[k][8] = make_float4(lv, lv, lv, lv);
+                    }
+                    const unsigned rb = (MG_R + (unsigned)((cs * 128 + bs) * MG_RLD)) * 4u;
+                    v4u rv[9];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) rv[i] = xld(rs, vl16 + 1024u * (i & 3), rb + 4096u * (i >> 2));
+                    const unsigned v8 = (unsigned)min(lane, 32) * 16u;      // lanes >= 32: chunk 544 = [const | ..]
+                    rv[8] = xld(rs, v8, rb + 8192u);
+                    MG_STAMP(12)
+                    park(rs, 0u, rb + 8192u, dead);         // (the last tile of r)
+                    MG_STAMP(13)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) settle(rs, vl16 + 1024u * (i & 3), rb + 4096u * (i >> 2), rv[i], dead);
+                    settle(rs, v8, rb + 8192u, rv[8], dead);
+#pragma unroll
+                    for (int i = 0; i < 9; ++i) {
+                        const float4 r4 = as_f4(rv[i]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) d[k] += dot4(x[k][i], r4);   // x is zero beyond the row: the constant chunk adds 0
+                    }
+                    cst = __shfl(__uint_as_float(rv[8].x), 63, WAVE);           // the constant sits at column F
                 }
-                // the constant sits at column F: chunk 544, held by lanes >= 32 of i = 8
-                const float cst = __shfl(__uint_as_float(rv[8].x), 63, WAVE);
+                MG_STAMP(14)
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const float dk = wave_sum(d[k]) + cst;
-                    if (lane == 0) s_logit[wave4 + 4 * k] = dk;
+                    if (lane == 0) s_logit[wv + 4 * k] = dk;
                 }
                 __syncthreads();
-                if (wave4 == 0) {
+                if (wv == 0) {
                     const bool valid = lane < A && lane < anum;
                     const float raw = s_logit[min(lane, MG_AMAX - 1)];
                     float l = valid ? raw : -INFINITY;
@@ -556,22 +687,25 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                     }
                 }
                 __syncthreads();
-                const int at = *s_at;
-                if (gates && (at & 3) == wave4) {           // the wave that holds the chosen row publishes u of step t
+                const int at = uni(*s_at);
+                MG_STAMP(15)
+                if (gates && (at & 3) == wv) {              // the wave that holds the chosen row publishes u of step t
                     const int ak = at >> 2;
-                    const unsigned ub = xb + (unsigned)(bs * MG_K), un = xn + (unsigned)(bs * MG_K);
+                    const unsigned ub = xb + (unsigned)(bs * MG_K) * 4u, un = xn + (unsigned)(bs * MG_K) * 4u;
                     float* dbg = (p.dbg_xin && sample_ok) ? p.dbg_xin + ((size_t)t * B + bs) * 2 * MG_F : nullptr;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) {
                         const int c = lane + 64 * i;
                         if (c < MG_F4) {
-                            const float4 v = ak == 0 ? x[0][i] : (ak == 1 ? x[1][i] : (ak == 2 ? x[2][i] : x[3][i]));
-                            xstore_f(rs, ub + 4 * c, v);
-                            xreset(rs, un + 4 * c);
+                            float4 v = ak == 0 ? x[0][i] : (ak == 1 ? x[1][i] : (ak == 2 ? x[2][i] : x[3][i]));
+                            if (dead) v.x = qnan();
+                            xst(rs, 16u * c, ub, as_u4(v));
+                            xrst(rs, 16u * c, un);
                             if (dbg) reinterpret_cast<float4*>(dbg)[c] = v;
                         }
                     }
                 }
+                fetch_score_idx(st + 1);
                 __syncthreads();
             }
             MG_STAMP(5)
@@ -579,104 +713,131 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
             // ---------------- visual attention of sample bs over the panorama of step t (model.py:310-326)
             float4(*slots)[9 * 64] = reinterpret_cast<float4(*)[9 * 64]>(smem);
             float* s_ml = smem + 4 * 9 * 64 * 4;            // [4] running maxima, [4] sums
-            PanoSrc xs = p.X;
-            xs.vp += (size_t)t * B; xs.view += (size_t)t * B;
-            const PanoRow prow = pano_row(xs, bsc);
             float4 P[9];
 #pragma unroll
             for (int i = 0; i < 9; ++i) P[i] = f4zero();
             float m_run = -INFINITY, l_run = 0.f;
-            float4 q[9];
-            const unsigned qb = MG_Q + (unsigned)((cs * 128 + bs) * MG_F);
-            for (int pass = 0; pass < 3; ++pass) {
-                float4 x[3][9];
+            if (sample_ok) {                                // (workgroup-uniform; the loads inside are unconditional)
+                const int vp = uni(pv_vp), view = uni(pv_view);
+                const float on = vp >= 0 ? 1.f : 0.f;       // vp < 0: an all-zero panorama (padded speaker step)
+                const rsrc_t rt = make_rs(p.X.table + (size_t)max(vp, 0) * MG_V * MG_IMG, (unsigned)(MG_V * MG_IMG) * 4u);
+                const rsrc_t rl = make_rs(p.X.loc_table + (size_t)view * MG_V * MG_LOC, (unsigned)(MG_V * MG_LOC) * 4u);
+                const unsigned v8 = (unsigned)min(lane, 31) * 16u;
+                const float on8 = lane < 32 ? on : 0.f;
+                float4 q[9];
+                const unsigned qb = (MG_Q + (unsigned)((cs * 128 + bs) * MG_F)) * 4u;
+                for (int pass = 0; pass < 3; ++pass) {
+                    float4 x[3][9];
 #pragma unroll
-                for (int jj = 0; jj < 3; ++jj) {
-                    const int v = wave4 + 4 * (3 * pass + jj);               // < 36 always
+                    for (int jj = 0; jj < 3; ++jj) {
+                        const int v = wv + 4 * (3 * pass + jj);                  // < 36 always
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) x[jj][i] = bld(rt, vl16 + 1024u * (i & 3), (unsigned)(v * MG_IMG) * 4u + 4096u * (i >> 2));
+                        x[jj][8] = bld(rl, v8, (unsigned)(v * MG_LOC) * 4u);
+                    }
+                    if (pass == 0) {
+                        v4u qv[9];
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) qv[i] = xld(rs, vl16 + 1024u * (i & 3), qb + 4096u * (i >> 2));
+                        qv[8] = xld(rs, v8, qb + 8192u);
+                        park(rs, 0u, qb + 8192u, dead);
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            settle(rs, vl16 + 1024u * (i & 3), qb + 4096u * (i >> 2), qv[i], dead);
+                            q[i] = as_f4(qv[i]);
+                        }
+                        settle(rs, v8, qb + 8192u, qv[8], dead);
+                        q[8] = as_f4(qv[8]);
+                    }
+                    float d[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            x[jj][i].x *= on; x[jj][i].y *= on; x[jj][i].z *= on; x[jj][i].w *= on;
+                            d[jj] += dot4(x[jj][i], q[i]);
+                        }
+                        x[jj][8].x *= on8; x[jj][8].y *= on8; x[jj][8].z *= on8; x[jj][8].w *= on8;
+                        d[jj] += dot4(x[jj][8], q[8]);
+                    }
+#pragma unroll
+                    for (int jj = 0; jj < 3; ++jj) d[jj] = wave_sum(d[jj]);
+                    const float mn = fmaxf(fmaxf(m_run, d[0]), fmaxf(d[1], d[2]));
+                    const float sc = expf(m_run - mn), e0 = expf(d[0] - mn), e1 = expf(d[1] - mn), e2 = expf(d[2] - mn);
+                    l_run = l_run * sc + e0 + e1 + e2;
 #pragma unroll
                     for (int i = 0; i < 9; ++i) {
-                        const int c = lane + 64 * i;
-                        x[jj][i] = pano_load(prow, v, c, c < MG_F4, MG_V, MG_F4);
+                        P[i].x = P[i].x * sc + e0 * x[0][i].x + e1 * x[1][i].x + e2 * x[2][i].x;
+                        P[i].y = P[i].y * sc + e0 * x[0][i].y + e1 * x[1][i].y + e2 * x[2][i].y;
+                        P[i].z = P[i].z * sc + e0 * x[0][i].z + e1 * x[1][i].z + e2 * x[2][i].z;
+                        P[i].w = P[i].w * sc + e0 * x[0][i].w + e1 * x[1][i].w + e2 * x[2][i].w;
                     }
+                    m_run = mn;
                 }
-                if (pass == 0) {
-                    v4u qv[9];
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) qv[i] = xload(rs, qb + 4 * min(lane + 64 * i, MG_F4 - 1));
-#pragma unroll
-                    for (int i = 0; i < 9; ++i) {
-                        settle(rs, qb + 4 * min(lane + 64 * i, MG_F4 - 1), qv[i], dead);
-                        q[i] = lane + 64 * i < MG_F4 ? as_f4(qv[i]) : f4zero();
-                    }
-                }
-                float d[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-                for (int i = 0; i < 9; ++i)
-#pragma unroll
-                    for (int jj = 0; jj < 3; ++jj) d[jj] += dot4(x[jj][i], q[i]);
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) d[jj] = wave_sum(d[jj]);
-                const float mn = fmaxf(fmaxf(m_run, d[0]), fmaxf(d[1], d[2]));
-                const float sc = expf(m_run - mn), e0 = expf(d[0] - mn), e1 = expf(d[1] - mn), e2 = expf(d[2] - mn);
-                l_run = l_run * sc + e0 + e1 + e2;
-#pragma unroll
-                for (int i = 0; i < 9; ++i) {
-                    P[i].x = P[i].x * sc + e0 * x[0][i].x + e1 * x[1][i].x + e2 * x[2][i].x;
-                    P[i].y = P[i].y * sc + e0 * x[0][i].y + e1 * x[1][i].y + e2 * x[2][i].y;
-                    P[i].z = P[i].z * sc + e0 * x[0][i].z + e1 * x[1][i].z + e2 * x[2][i].z;
-                    P[i].w = P[i].w * sc + e0 * x[0][i].w + e1 * x[1][i].w + e2 * x[2][i].w;
-                }
-                m_run = mn;
             }
-            if (lane == 0) { s_ml[wave4] = m_run; s_ml[4 + wave4] = l_run; }
+            if (lane == 0) { s_ml[wv] = m_run; s_ml[4 + wv] = l_run; }
             __syncthreads();
-            float mm = s_ml[0];
+            float sc = 0.f;
+            if (sample_ok) {
+                float mm = s_ml[0];
 #pragma unroll
-            for (int w = 1; w < 4; ++w) mm = fmaxf(mm, s_ml[w]);
-            float lt = 0.f;
+                for (int w = 1; w < 4; ++w) mm = fmaxf(mm, s_ml[w]);
+                float lt = 0.f;
 #pragma unroll
-            for (int w = 0; w < 4; ++w) lt += s_ml[4 + w] * expf(s_ml[w] - mm);
-            const float sc = expf(m_run - mm) / lt;
+                for (int w = 0; w < 4; ++w) lt += s_ml[4 + w] * expf(s_ml[w] - mm);
+                sc = expf(m_run - mm) / lt;
+            }
 #pragma unroll
             for (int i = 0; i < 9; ++i) { P[i].x *= sc; P[i].y *= sc; P[i].z *= sc; P[i].w *= sc; }
             __syncthreads();
-            const unsigned fb = xb + (unsigned)(bs * MG_K + MG_OFF_F), fn = xn + (unsigned)(bs * MG_K + MG_OFF_F);
+            const unsigned fb = xb + (unsigned)(bs * MG_K + MG_OFF_F) * 4u, fn = xn + (unsigned)(bs * MG_K + MG_OFF_F) * 4u;
             float* dbg = (p.dbg_xin && sample_ok) ? p.dbg_xin + ((size_t)t * B + bs) * 2 * MG_F + MG_F : nullptr;
             const bool poison = dead;
             block_row_sum<9, 4, 4>(P, slots, MG_F4, [&](int c, float4 v) {
-                if (!sample_ok) v = f4zero();
                 if (poison) v.x = qnan();
-                xstore_f(rs, fb + 4 * c, v);
-                xreset(rs, fn + 4 * c);
+                xst(rs, 16u * c, fb, as_u4(v));
+                xrst(rs, 16u * c, fn);
                 if (dbg) reinterpret_cast<float4*>(dbg)[c] = v;
             });
+            fetch_pano_idx(t + 1);
             __syncthreads();
             MG_STAMP(2)
         }
         if (!gates) break;
 
         // ============================ the rest of the gate product ==================================
-        gate_group(1 + nf, 1 + nf + nu);                    // u stages (u of step t arrives before the feature)
-        MG_STAMP(6)
-        gate_group(1, 1 + nf);                              // feature stages
-        MG_STAMP(7)
-        // the result goes out as [16 x 64] tiles in MFMA layout, one per row group, into the region of the
-        // workgroup that owns that group's cell for these 16 units
+        // the text chain ends with u of step t (the feature of step t is long there); everybody else has been
+        // waiting since the feature arrived
+        if (text_role && chain_active) {
+            gate_group(wres_u, xcd, nu);
+            MG_STAMP(6)
+            gate_group(wres_f, f0, nf);
+            MG_STAMP(7)
+        } else {
+            gate_group(wres_f, f0, nf);
+            MG_STAMP(7)
+            gate_group(wres_u, xcd, nu);
+            MG_STAMP(6)
+        }
+        // the result goes out as [16 x 64] tiles in MFMA layout, one per m-tile, into the region of the
+        // workgroup that owns that m-tile's cell for these 16 units
         {
-            const unsigned sbuf = MG_SLAB + (unsigned)((t & 1) * MG_XCD * MG_SLOTS * 8 * 1024);
+            const unsigned sbuf = (MG_SLAB + (unsigned)((t & 1) * MG_XCD * MG_SLOTS * 8 * 1024)) * 4u;
+            const unsigned vs = (unsigned)((kk * 16 + li) * 4) * 4u;
 #pragma unroll
             for (int m = 0; m < MT; ++m) {
                 const f32x4 v = acc[m];
-                const unsigned off = sbuf + (unsigned)(((m * MG_SLOTS + slot) * 8 + xcd) * 1024 + ((gate * 4 + kk) * 16 + li) * 4);
-                xstore(rs, off, v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
+                const unsigned so = sbuf + (unsigned)(((m * MG_SLOTS + slot) * 8 + xcd) * 1024 + gate * 256) * 4u;
+                xst(rs, vs, so, v4u{__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])});
             }
         }
         MG_STAMP(8)
-        // ============================ cell update (owner of row group xcd, units 16 slot..) =========
+        // ============================ cell update (owner of m-tile xcd, units 16 slot..) ============
         if (active) {
             float pre[4] = {bias[0], bias[1], bias[2], bias[3]};
-            const unsigned base = MG_SLAB + (unsigned)((t & 1) * MG_XCD * MG_SLOTS * 8 * 1024) +
-                                  (unsigned)((xcd * MG_SLOTS + slot) * 8 * 1024);
+            const unsigned base = (MG_SLAB + (unsigned)((t & 1) * MG_XCD * MG_SLOTS * 8 * 1024) +
+                                   (unsigned)((xcd * MG_SLOTS + slot) * 8 * 1024)) * 4u;
+            park(rs, 0u, base + 7u * 4096u, dead);
             {
                 unsigned v[4][8];
                 const long long t0 = wall_clock64();
@@ -687,8 +848,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
                         for (int sp = 0; sp < 8; ++sp)
-                            v[g][sp] = __builtin_amdgcn_raw_buffer_load_b32(
-                                rs, (base + (unsigned)(sp * 1024 + ((g * 4 + (er >> 2)) * 16 + eu) * 4 + (er & 3))) * 4u, 0, MG_SC1);
+                            v[g][sp] = __builtin_amdgcn_raw_buffer_load_b32(rs, v_slab, base + (unsigned)(sp * 1024 + g * 256) * 4u, MG_SC1);
 #pragma unroll
                     for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -704,7 +864,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
             __syncthreads();                             // every wave has read the region: the owner resets it
             MG_STAMP(9)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) xreset(rs, base + (unsigned)((tid + 256 * i) * 4));
+            for (int i = 0; i < 8; ++i) xrst(rs, (unsigned)tid * 16u, base + 4096u * i);
             {
                 const float ig = sigmoidf_(pre[0]), fg = sigmoidf_(pre[1]), gg = tanhf(pre[2]), og = sigmoidf_(pre[3]);
                 c_state = fg * c_state + ig * gg;
@@ -715,9 +875,10 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 const float h_1 = __shfl_down(hp, 1), h_2 = __shfl_down(hp, 2), h_3 = __shfl_down(hp, 3);
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 if ((tid & 3) == 0) {
-                    const unsigned po = (unsigned)(eb * MG_K + MG_OFF_H + ej);
-                    xstore(rs, xn + po, v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)});
-                    xreset(rs, MG_XIN + (unsigned)(((t + 2) % 3) * 128 * MG_K) + po);
+                    const unsigned vo = (unsigned)(er * MG_K + eu) * 4u;
+                    const unsigned so = (unsigned)(xcd * 16 * MG_K + MG_OFF_H + 16 * slot) * 4u;
+                    xst(rs, vo, xn + so, v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)});
+                    xrst(rs, vo, (MG_XIN + (unsigned)(((t + 2) % 3) * 128 * MG_K)) * 4u + so);
                 }
                 if (evalid) {
                     p.h1_tape[(size_t)t * BH + (size_t)eb * MG_H + ej] = h1;
@@ -730,7 +891,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     }
     if (pa.trace && tid == 0) {
 #pragma unroll
-        for (int k = 0; k < 12; ++k) {
+        for (int k = 0; k < 16; ++k) {
             pa.trace[blockIdx.x * 32 + k] = (unsigned long long)tk[k];
             pa.trace[blockIdx.x * 32 + 16 + k] = (unsigned long long)tabs[k];
         }
@@ -749,8 +910,8 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
 size_t mega_xchg_dwords() { return MG_TOTAL; }
 
 bool mega_supported(int B, int H, int L, int A, const PanoSrc& X, const CandSrc& U) {
-    return B >= 1 && B <= 128 && H == MG_H && L >= 1 && L <= MG_LMAX && A >= 1 && A <= MG_AMAX && !X.dense && !U.dense &&
-           X.IMG + X.LOC == MG_F && X.V == MG_V && U.IMG + U.LOC == MG_F && U.V == MG_V && (X.LOC % 16) == 0;
+    return B >= 1 && B <= 128 && H == MG_H && L >= 1 && L <= MG_LMAX && A >= 2 && A <= MG_AMAX && !X.dense && !U.dense &&
+           X.IMG == MG_IMG && X.LOC == MG_LOC && X.V == MG_V && U.IMG == MG_IMG && U.LOC == MG_LOC && U.V == MG_V;
 }
 
 int mega_decode(const MegaHost& h, hipStream_t st) {
@@ -777,11 +938,14 @@ int mega_decode(const MegaHost& h, hipStream_t st) {
         }                                                                                                     \
         SF_LAUNCH(mega_kernel<MTV>, grid, block, lds, st, a);                                                 \
     }
+#ifdef SF_MEGA_ONLY7                                     /* development builds: one instantiation */
+    if (need <= 7) SF_MEGA(7) else return SF_ERR_UNSUPPORTED;
+#else
     if (need <= 2) SF_MEGA(2)
     else if (need <= 4) SF_MEGA(4)
     else if (need <= 7) SF_MEGA(7)
     else SF_MEGA(8)
-#undef SF_MEGA
+#endif
     return launch_status();
 }
 

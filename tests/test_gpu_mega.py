@@ -119,22 +119,21 @@ def test_persistent_decode_timing():
         torch.cuda.synchronize()
         _lib.lib.sf_debug_trace(None)
     raw = trace.cpu().numpy().reshape(256, 32).astype(np.float64)
-    tr = raw[:, :12] / 100.0 / S
+    tr = raw[:, :16] / 100.0 / S
     blk = np.arange(256)
-    even = ((blk >> 3) & 1) == 0
-    act = (blk & 7) < 7
+    text = (blk & 7) < 4
     names = ['first product (t_text | q)', 'h stage', 'text attn | visual', 'h~', 'r', 'scores + glue', 'u stages',
-             'feature stages', 'tile stores', 'wait partial tiles', 'cell', 'loop back']
+             'feature stages', 'tile stores', 'wait partial tiles', 'cell', 'loop back',
+             'scores: loads issued', 'scores: parked on r', 'scores: rows + r landed, dots', 'scores: glue']
     print('  mean us per step and phase')
     for k, n in enumerate(names):
-        print('    %-28s even %6.2f   odd %6.2f   idle group %6.2f' % (
-            n, tr[even & act, k].mean(), tr[~even & act, k].mean(), tr[~act, k].mean()))
-    ab = raw[:, 16:28] / 100.0
+        print('    %-28s text %6.2f   visual %6.2f' % (n, tr[text, k].mean(), tr[~text, k].mean()))
+    ab = raw[:, 16:32] / 100.0
     t0 = ab[ab > 0].min()
     print('  step %d: phase END times (us after the earliest stamp), min / mean / max over workgroups' % (S // 2))
-    order = [11, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10]
+    order = [11, 0, 1, 2, 3, 4, 12, 13, 14, 15, 5, 6, 7, 8, 9, 10]
     for k in order:
-        for lab, sel in (('even', even & act), ('odd', ~even & act), ('idle', ~act)):
+        for lab, sel in (('text', text), ('visual', ~text)):
             v = ab[sel, k]
             v = v[v > 0] - t0
             if len(v):
