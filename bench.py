@@ -523,6 +523,7 @@ def main(argv=None):
         from speaker_follower_amd import bench_extras
         out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2]
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
+        out['persistent_decode_experiment'] = bench_extras.persistent_decode(enc, dec, store, batch, S)
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):
             out['search_full'] = bench_extras.search_full(conn, device)

@@ -63,7 +63,9 @@ constexpr unsigned MG_HT = MG_WC + MG_HN;
 constexpr unsigned MG_Q = MG_HT + MG_HN, MG_Q_N = 3u * 128 * MG_F;
 constexpr unsigned MG_R = MG_Q + MG_Q_N, MG_R_N = 3u * 128 * MG_RLD;
 constexpr unsigned MG_SLAB = MG_R + MG_R_N, MG_SLAB_N = 2u * MG_XCD * MG_SLOTS * 8 * 1024;
-constexpr unsigned MG_TOTAL = MG_SLAB + MG_SLAB_N;
+constexpr unsigned MG_CNT = MG_SLAB + MG_SLAB_N, MG_CNT_N = 64;   // arrival counters (monotonic within a launch)
+constexpr unsigned MG_CNT_H = 0, MG_CNT_U = 16, MG_CNT_F = 32;    // (one 64-byte line each)
+constexpr unsigned MG_TOTAL = MG_CNT + MG_CNT_N;
 
 struct MegaArgs {
     MegaHost h;
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(256) void mega_prologue_kernel(unsigned* x, size_t 
 __global__ __launch_bounds__(256) void mega_seed_kernel(unsigned* xin, const float* h_init, const float* feat0,
                                                         int ld_feat, int B) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < (int)MG_CNT_N) xin[MG_CNT - MG_XIN + i] = 0u;          // arrival counters (xin = base of the workspace)
     if (i >= 128 * (MG_K / 4)) return;
     const int row = i / (MG_K / 4), c4 = i - row * (MG_K / 4);
     const int col = 4 * c4;
@@ -148,6 +151,25 @@ __device__ __forceinline__ void park(rsrc_t rs, unsigned voff, unsigned soff, bo
             __builtin_amdgcn_s_sleep(4);
             asm volatile("" ::: "memory");
             v = xld(rs, voff, soff);
+            if (wall_clock64() - t0 > MG_TIMEOUT) break;       // the readers' own bounded waits report it
+        }
+    }
+    __syncthreads();
+}
+
+// Arrival counters for the all-to-all hand-offs (h, u, attended feature of a step): every producer workgroup
+// drains its write-through stores, then ONE lane adds 1; a consumer parks one lane on the counter and only
+// then requests the data, so its loads find everything in place (one round trip) instead of sentinels.
+__device__ __forceinline__ void arrive(unsigned* cnt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's publishes are acknowledged
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void wait_count(const unsigned* cnt, unsigned target, bool& dead) {
+    if (threadIdx.x == 0 && !dead) {
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(4);
             if (wall_clock64() - t0 > MG_TIMEOUT) break;       // the readers' own bounded waits report it
         }
     }
@@ -285,6 +307,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     const unsigned vl16 = (unsigned)lane * 16u;          // this lane's float4 of a 1 KB row chunk
     bool dead = false;
 
+    constexpr int NGRP = (MT + 1) / 2;                   // chain groups
     // ---- cell ownership: (m-tile = xcd, units [16 slot, +16)); every thread owns one element
     const bool active = xcd < MT;
     const int er = (tid >> 4) & 15, eu = tid & 15;
@@ -299,7 +322,6 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
 
     // ---- chain role: XCDs 0-3 run the text / scoring chain of rows [32 (x & 3), +32), XCDs 4-7 the visual
     // chain of the same rows; workgroup c of the XCD owns sample c of the group and tile lane c of its products
-    constexpr int NGRP = (MT + 1) / 2;
     const int cg = xcd & 3;
     const bool text_role = xcd < 4;
     const bool chain_active = cg < NGRP;
@@ -315,35 +337,32 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
     const bool mask0 = p.mask[(size_t)bsc * L + min(lane, L - 1)] != 0;
     const bool mask1 = p.mask[(size_t)bsc * L + min(lane + 64, L - 1)] != 0;
 
-    // ---- this workgroup's stages of the gate product: its h stage, its feature stages, its u stages
-    // (computed, not tabulated: a register array filled through a running index compiles to movrel writes
-    //  that the compiler also issues speculatively one past the end)
-    const int sh = 2 * MG_NU + ((xcd - 2 * MG_NU) & 7);
-    const int f0 = MG_NU + ((xcd - MG_NU) & 7), nf = (2 * MG_NU - f0 + 7) >> 3;
-    const int nu = (MG_NU - xcd + 7) >> 3;
-    // The weights of those stages never change: this workgroup's [64 gate rows x 64 k] block of every stage
-    // stays in registers for the whole episode, in the staging layout (4 float4 per thread and stage), so
-    // the step loop streams only the operand rows.  (Indexed by unrolled loop counters only.)
+    // ---- this workgroup's stages of the gate product.  u stages (s < 34): split s % 8, on every XCD -- they
+    // are the tail of the critical path (u of step t is the last thing the text chain produces).  Feature and
+    // h stages (s = 34 + j): split j % 4 on the VISUAL XCDs only, which are idle once their attention is done;
+    // the text XCDs go from u straight to the next step's chain.
+    const int nu = (MG_NU - xcd + 7) >> 3;                // u stages xcd + 8k
+    const int jx = xcd - 4;                               // visual XCDs: stages 34 + jx + 4k
+    const int nfh = xcd >= 4 ? (MG_NU + MG_NH - jx + 3) >> 2 : 0;
+    const int nfeat = xcd >= 4 ? (MG_NU - jx + 3) >> 2 : 0;   // of which the first nfeat are feature stages, the rest h
+    // The u-stage weights never change: this workgroup's [64 gate rows x 64 k] block of each stays in registers
+    // for the whole episode, in the staging layout (4 float4 per thread and stage).  (Indexed by unrolled loop
+    // counters only.)  The feature / h stages stream theirs: those workgroups have slack.
     constexpr int NKMAX = 5;
-    float4 wres_h[1][4], wres_f[NKMAX][4], wres_u[NKMAX][4];
+    float4 wres_u[NKMAX][4];
     {
-        auto wstage = [&](int s, float4 (&dst)[4]) {
-            const int k0 = s * MG_BK;
-            const bool is_h = s >= 2 * MG_NU;
-#pragma unroll
-            for (int pp = 0; pp < 4; ++pp) {
-                const int wrow = pp * MG_H + 16 * slot + ldrow;                   // gate pp, unit 16 slot + ldrow
-                dst[pp] = is_h ? ld4(p.w_hh + (size_t)wrow * MG_H + (k0 - MG_OFF_H) + 4 * ldc4)
-                               : ld4(p.w_ih + (size_t)wrow * 2 * MG_F + k0 + 4 * ldc4);
-            }
-        };
-        wstage(sh, wres_h[0]);
 #pragma unroll
         for (int k = 0; k < NKMAX; ++k) {
-            wstage(f0 + 8 * min(k, nf - 1), wres_f[k]);
-            wstage(xcd + 8 * min(k, nu - 1), wres_u[k]);
+            const int k0 = (xcd + 8 * min(k, nu - 1)) * MG_BK;
+#pragma unroll
+            for (int pp = 0; pp < 4; ++pp)
+                wres_u[k][pp] = ld4(p.w_ih + (size_t)(pp * MG_H + 16 * slot + ldrow) * 2 * MG_F + k0 + 4 * ldc4);
         }
     }
+    unsigned* const cnt_h = p.xchg + MG_CNT + MG_CNT_H;
+    unsigned* const cnt_u = p.xchg + MG_CNT + MG_CNT_U;
+    unsigned* const cnt_f = p.xchg + MG_CNT + MG_CNT_F;
+    const unsigned n_cells = 32u * MT, n_chain = 32u * NGRP;   // publishers of h / of u and of the feature per step
 
     // development aid (pa.trace): per phase the ticks summed over the steps, and the stamps of the middle step
     unsigned tk[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tabs[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -427,34 +446,69 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                     for (int m = 0; m < MT; ++m) acc[m] = mfma16(comp(av[m], j), comp(bq, j), acc[m]);
             }
         };
-        // stages s0, s0 + 8, ... (n of them, n <= rows of wr): the operand rows of ALL of them are requested at
-        // once (a round trip of an exchange load is ~2.5 us under load, a stage's MFMAs 1.5 us)
-        auto gate_group = [&](const auto& wr, int s0, int n) {
-            constexpr int NK = (int)(sizeof(wr) / sizeof(wr[0]));
-            v4u ar[NK][APASS];
+        // u stages xcd, xcd + 8, ... (nu of them): the caller has waited for the arrival counter, so the operand
+        // rows of ALL stages are requested at once (a round trip is ~2.5 us, a stage's MFMAs 1.5 us)
+        auto gate_group_u = [&]() {
+            v4u ar[NKMAX][APASS];
 #pragma unroll
-            for (int k = 0; k < NK; ++k) issue(ar[k], s0 + 8 * min(k, n - 1));
-            park(rs, 0u, xb + (unsigned)(s0 * MG_BK) * 4u, dead);
-            settle_stage(ar[0], s0);
-            lstore(ar[0], wr[0], 0);
+            for (int k = 0; k < NKMAX; ++k) issue(ar[k], xcd + 8 * min(k, nu - 1));
+            settle_stage(ar[0], xcd);
+            lstore(ar[0], wres_u[0], 0);
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < NK; ++k) {
-                if (k < n) {
-                    const bool more = k + 1 < NK && k + 1 < n;
+            for (int k = 0; k < NKMAX; ++k) {
+                if (k < nu) {
+                    const bool more = k + 1 < NKMAX && k + 1 < nu;
                     compute(k & 1);
                     if (more) {
-                        settle_stage(ar[k + 1 < NK ? k + 1 : NK - 1], s0 + 8 * (k + 1));
-                        lstore(ar[k + 1 < NK ? k + 1 : NK - 1], wr[k + 1 < NK ? k + 1 : NK - 1], (k + 1) & 1);
+                        settle_stage(ar[k + 1 < NKMAX ? k + 1 : NKMAX - 1], xcd + 8 * (k + 1));
+                        lstore(ar[k + 1 < NKMAX ? k + 1 : NKMAX - 1], wres_u[k + 1 < NKMAX ? k + 1 : NKMAX - 1], (k + 1) & 1);
                     }
                     __syncthreads();
                 }
+            }
+        };
+        // feature / h stages 34 + jx + 4k, k in [k0, k1): weights streamed with the operand rows, one stage ahead
+        auto gate_group_stream = [&](int k0, int k1) {
+            if (k0 >= k1) return;
+            const rsrc_t rwi = make_rs(p.w_ih, (unsigned)(4 * MG_H) * (unsigned)(2 * MG_F) * 4u);
+            const rsrc_t rwh = make_rs(p.w_hh, (unsigned)(4 * MG_H) * (unsigned)MG_H * 4u);
+            const unsigned vwi = (unsigned)(ldrow * 2 * MG_F + 4 * ldc4) * 4u, vwh = (unsigned)(ldrow * MG_H + 4 * ldc4) * 4u;
+            v4u ar[APASS];
+            float4 wr[4];
+            auto issue_w = [&](int s) {
+                const bool is_h = s >= 2 * MG_NU;
+#pragma unroll
+                for (int pp = 0; pp < 4; ++pp) {
+                    const float4 a = bld(rwi, vwi, (unsigned)((pp * MG_H + 16 * slot) * 2 * MG_F + min(s, 2 * MG_NU - 1) * MG_BK) * 4u);
+                    const float4 b = bld(rwh, vwh, (unsigned)((pp * MG_H + 16 * slot) * MG_H + max(s - 2 * MG_NU, 0) * MG_BK) * 4u);
+                    wr[pp] = is_h ? b : a;
+                }
+            };
+            int s = MG_NU + jx + 4 * k0;
+            issue(ar, s);
+            issue_w(s);
+            settle_stage(ar, s);
+            lstore(ar, wr, 0);
+            __syncthreads();
+            for (int k = k0; k < k1; ++k) {
+                const bool more = k + 1 < k1;
+                const int sn = MG_NU + jx + 4 * min(k + 1, k1 - 1);
+                issue(ar, sn);                              // (re-reads the last stage when there is no next one)
+                issue_w(sn);
+                compute((k - k0) & 1);
+                if (more) {
+                    settle_stage(ar, sn);
+                    lstore(ar, wr, (k + 1 - k0) & 1);
+                }
+                __syncthreads();
             }
         };
 
         MG_STAMP(11)                                        // loop back
         // ============================ chain of step t - 1, first product ============================
         if (chain) {
+            wait_count(cnt_h, (unsigned)t * n_cells, dead);
             TileJob j{};
             j.a0 = xb + (unsigned)(row0 * MG_K + MG_OFF_H) * 4u; j.lda0 = MG_K;     // h1 of step t - 1
             j.tile_stride = 1; j.tanh_epi = false; j.m_live = m_live;
@@ -478,7 +532,10 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
         if (gates) {
 #pragma unroll
             for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            gate_group(wres_h, sh, 1);                      // the h stage
+            if (xcd >= 4) {                                 // the h stages (h of step t - 1 is complete: counted above)
+                if (!chain) wait_count(cnt_h, (unsigned)t * n_cells, dead);
+                gate_group_stream(nfeat, nfh);
+            }
         }
         MG_STAMP(1)
         if (chain && text_role) {
@@ -600,9 +657,10 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                                                       __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pf_sc.w), cl)));
                         const unsigned so = (unsigned)(min(max(view, 0), MG_V - 1) * MG_IMG) * 4u;
                         const float on = real ? 1.f : 0.f;
+                        const unsigned vrow = real ? vl16 : 0u;    // (a padding candidate re-reads one 16-byte piece)
 #pragma unroll
                         for (int i = 0; i < 8; ++i) {       // image features: 8 chunks of 1 KB
-                            const float4 v = bld(rt, vl16 + 1024u * (i & 3), so + 4096u * (i >> 2));
+                            const float4 v = bld(rt, vrow + (real ? 1024u * (i & 3) : 0u), so + (real ? 4096u * (i >> 2) : 0u));
                             x[k][i] = make_float4(v.x * on, v.y * on, v.z * on, v.w * on);
                         }
                         // location features (env.py:60-75): sin h, cos h, sin e, cos e, each repeated LOC/4 times
@@ -706,7 +764,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                     }
                 }
                 fetch_score_idx(st + 1);
-                __syncthreads();
+                if (gates) arrive(cnt_u); else __syncthreads();
             }
             MG_STAMP(5)
         } else if (chain && gates) {
@@ -800,25 +858,20 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 if (dbg) reinterpret_cast<float4*>(dbg)[c] = v;
             });
             fetch_pano_idx(t + 1);
-            __syncthreads();
+            arrive(cnt_f);
             MG_STAMP(2)
         }
         if (!gates) break;
 
         // ============================ the rest of the gate product ==================================
-        // the text chain ends with u of step t (the feature of step t is long there); everybody else has been
-        // waiting since the feature arrived
-        if (text_role && chain_active) {
-            gate_group(wres_u, xcd, nu);
-            MG_STAMP(6)
-            gate_group(wres_f, f0, nf);
-            MG_STAMP(7)
-        } else {
-            gate_group(wres_f, f0, nf);
-            MG_STAMP(7)
-            gate_group(wres_u, xcd, nu);
-            MG_STAMP(6)
+        if (xcd >= 4) {                                     // feature stages (visual XCDs), as soon as all of it is there
+            wait_count(cnt_f, (unsigned)t * n_chain, dead);
+            gate_group_stream(0, nfeat);
         }
+        MG_STAMP(7)
+        wait_count(cnt_u, (unsigned)t * n_chain, dead);     // u of step t: the end of the text chain
+        gate_group_u();
+        MG_STAMP(6)
         // the result goes out as [16 x 64] tiles in MFMA layout, one per m-tile, into the region of the
         // workgroup that owns that m-tile's cell for these 16 units
         {
@@ -886,7 +939,7 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 }
             }
         }
-        __syncthreads();
+        if (active) arrive(cnt_h); else __syncthreads();
         MG_STAMP(10)
     }
     if (pa.trace && tid == 0) {
