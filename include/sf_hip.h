@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 4
+#define SF_ABI_VERSION 5
 
 enum {
     SF_OK = 0,
@@ -264,6 +264,9 @@ typedef struct sf_follower_glue {
     float* live;              /* [B] out */
     uint32_t sample_seed, sample_stream; /* feedback 2 only */
     int32_t row0;                        /* global id of row 0 (sampling stream) */
+    /* optional (scoring + glue launch only): env.step + env.observe + teacher of a device-resident
+     * environment right behind the action choice, instead of a separate sf_nav_step launch */
+    const struct sf_nav_io* nav;
 } sf_follower_glue;
 int sf_follower_glue_fwd(const sf_cands* U, int B, float* logit, const sf_follower_glue* glue,
                          sf_stream stream);
@@ -298,6 +301,12 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
 int sf_attn_decoder_head_fwd(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
                              const float* h0, const sf_decoder_tape* tape, const sf_dropout* drop,
                              uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream);
+/* When the next panorama depends on this step's action (a device-resident environment: nav.py), call the
+ * tail with X_next = NULL and tape_next != NULL: only the QUERY of step t+1's visual attention (t_v', q':
+ * functions of h1) is formed beside the text stages; after the environment step, sf_attn_decoder_attend_fwd
+ * runs the attention of step t+1 from tape->q into tape->xin[:, F:2F] / tape->alpha_v (model.py:310-326). */
+int sf_attn_decoder_attend_fwd(const sf_pano* X, int B, const sf_decoder_tape* tape, const sf_dropout* drop,
+                               uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream);
 int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
                              const float* u_prev, const float* h0, const float* c0,
                              const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
@@ -571,6 +580,19 @@ typedef struct sf_nav_table {
  * when target_next != NULL, the shortest-path teacher action (-1 for rows with ended[b] != 0): the
  * candidate whose next_row equals goal_hop[b, row - hop_base[b]] (the next nav row on the shortest
  * path to the sample's goal, tabulated per sample over its scan's rows), 0 at the goal. */
+/* The same step as the tail of the scoring + glue launch (sf_follower_glue.nav): state and outputs as in
+ * sf_nav_step; the action and the `ended` flag are the ones the glue has just produced. */
+typedef struct sf_nav_io {
+    sf_nav_table nav;
+    const int32_t *row, *view;   /* [B] current state */
+    const int32_t* goal_hop;     /* [B, ld_hop] or NULL with target_next == NULL */
+    int32_t ld_hop;
+    const int32_t* hop_base;     /* [B] */
+    int32_t *row_next, *vp_next, *view_next, *a_num_next; /* [B] */
+    int32_t* cand_view_next;     /* [B,A] */
+    float* sincos_next;          /* [B,A,4] */
+    int64_t* target_next;        /* [B] or NULL */
+} sf_nav_io;
 int sf_nav_step(const sf_nav_table* nav, int B, const int32_t* row, const int32_t* view,
                 const int64_t* a_t, const uint8_t* ended, const int32_t* goal_hop, int ld_hop,
                 const int32_t* hop_base, int32_t* row_next, int32_t* vp_next, int32_t* view_next,

@@ -69,7 +69,7 @@ class FollowerGlue(C.Structure):
                 ('a_t', c_p), ('target_used', c_p), ('score', c_p), ('u_next', c_p),
                 ('ld_u_next', C.c_int32), ('u_drop', C.POINTER(Dropout)), ('u_drop_stream', C.c_uint32),
                 ('ce_term', c_p), ('live', c_p), ('sample_seed', C.c_uint32),
-                ('sample_stream', C.c_uint32), ('row0', C.c_int32)]
+                ('sample_stream', C.c_uint32), ('row0', C.c_int32), ('nav', c_p)]
 
 
 class FollowerEpisode(C.Structure):
@@ -104,6 +104,12 @@ class SpkDecoderG(C.Structure):
 class NavTableS(C.Structure):
     _fields_ = [('a_num', c_p), ('next_row', c_p), ('cand_view', c_p), ('cand_sincos', c_p),
                 ('feat_row', c_p), ('A', C.c_int32), ('V', C.c_int32)]
+
+
+class NavIO(C.Structure):
+    _fields_ = [('nav', NavTableS), ('row', c_p), ('view', c_p), ('goal_hop', c_p), ('ld_hop', C.c_int32),
+                ('hop_base', c_p), ('row_next', c_p), ('vp_next', c_p), ('view_next', c_p),
+                ('a_num_next', c_p), ('cand_view_next', c_p), ('sincos_next', c_p), ('target_next', c_p)]
 
 
 SpkDecoderTape = _ptr_struct('SpkDecoderTape', ['emb', 'gates', 'c1', 'h1', 'cat2', 't_text',
@@ -149,6 +155,7 @@ _SIGNATURES = {
     'sf_attn_decoder_tail_fwd': (C.c_int, [P(DecoderW), P(Cands), i32, i32, i32, i32, c_f, c_f, c_f,
                                            c_f, c_p, c_p, P(DecoderTape), P(FollowerGlue), P(Dropout),
                                            u32, P(Pano), P(DecoderTape)] + WS),
+    'sf_attn_decoder_attend_fwd': (C.c_int, [P(Pano), i32, P(DecoderTape), P(Dropout), u32] + WS),
     'sf_follower_episode_fwd': (C.c_int, [P(DecoderW), P(FollowerEpisode)] + WS),
     'sf_follower_episode_bwd': (C.c_int, [P(DecoderW), P(FollowerEpisode), P(DecoderGTape), c_f, c_f,
                                           c_f, c_f, c_f, c_f, c_f, P(C.c_int)] + WS),
@@ -197,7 +204,7 @@ SF_OK, SF_ERR_ARG, SF_ERR_UNSUPPORTED, SF_ERR_LAUNCH, SF_ERR_WORKSPACE = 0, 1, 2
 SF_ENC_PER_STEP = 1           # sf_encoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 def _load():

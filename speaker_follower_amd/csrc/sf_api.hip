@@ -90,12 +90,22 @@ inline FGlue make_glue(const CandSrc& src, int B, float* logit, const sf_followe
     f.u_drop = make_dropout(g->u_drop, g->u_drop_stream);
     f.ce_term = g->ce_term; f.live = g->live; f.sample_seed = g->sample_seed;
     f.sample_stream = g->sample_stream; f.row0 = g->row0;
+    if (g->nav) {
+        const sf_nav_io& n = *g->nav;
+        f.nav = NavIO{n.nav, n.row, n.view, n.goal_hop, n.ld_hop, n.hop_base, n.row_next, n.vp_next, n.view_next,
+                      n.a_num_next, n.cand_view_next, n.sincos_next, n.target_next, true};
+    }
     return f;
 }
 inline bool glue_ok(const sf_cands* U, const sf_follower_glue* g) {
     return g->target && g->ended && g->a_t && g->target_used && g->score && g->ce_term && g->live &&
            g->feedback >= 0 && g->feedback <= 2 && (g->is_valid || U->a_num) &&
-           (!g->u_next || g->ld_u_next % 4 == 0);
+           (!g->u_next || g->ld_u_next % 4 == 0) &&
+           (!g->nav || (g->nav->nav.A == U->A && g->nav->nav.a_num && g->nav->nav.next_row && g->nav->nav.cand_view &&
+                        g->nav->nav.cand_sincos && g->nav->nav.feat_row && g->nav->row && g->nav->view &&
+                        g->nav->row_next && g->nav->vp_next && g->nav->view_next && g->nav->a_num_next &&
+                        g->nav->cand_view_next && g->nav->sincos_next &&
+                        (!g->nav->target_next || (g->nav->goal_hop && g->nav->hop_base && g->nav->ld_hop > 0))));
 }
 
 #define TRY(expr)                     \
@@ -602,6 +612,11 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
     const CandSrc us = cands(U);
+    // tape_next WITHOUT X_next: the next panorama is not known yet (it depends on this step's action: a
+    // device-resident environment).  Only the query of the next step's visual attention (t_v', q': they need
+    // nothing but h1) rides beside the text stages; the attention itself follows the environment step
+    // (sf_attn_decoder_attend_fwd).
+    const bool query_only = !X_next && tn && w->visual.w_v_t && !w->fold;
     const int F = us.IMG + us.LOC;
     const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
     if (u_prev) TRY(dropout_copy(u_prev, F, B, F, tp->xin, 2 * F, d_in, 0, st));
@@ -695,6 +710,22 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
             TRY(visual_attn(0, xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, st, part,
                             part ? ar.tickets() : nullptr));
         }
+    } else if (query_only) {
+        SmallPlan pa, pb;
+        const bool ok1 =
+            plan_linear(tp->cat2 + H, 2 * H, tw->w_in, H, nullptr, B, H, H, EPI_NONE, tp->t_text, H, &pa) == SF_OK &&
+            plan_linear(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, &pb) == SF_OK;
+        if (!ok1 || pair_small_small(pa, pb, st) != SF_OK) {
+            TRY(linear_plain(tp->cat2 + H, 2 * H, tw->w_in, H, nullptr, B, H, H, EPI_NONE, tp->t_text, H, ar, st));
+            TRY(linear_plain(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, ar, st));
+        }
+        const bool ok2 = plan_linear(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, &pa) == SF_OK;
+        if (!ok2 || pair_small_text(pa, ctx, ctx_mask, B, L, H, tp->t_text, H, tp->alpha, tp->cat2,
+                                    2 * H, ctx_row, st) != SF_OK) {
+            TRY(text_attn_fwd(ctx, ctx_mask, B, L, H, tp->t_text, H, tp->alpha, tp->cat2, 2 * H, st, ctx_row));
+            TRY(linear_plain(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, ar, st));
+        }
+        TRY(linear_plain(tp->cat2, 2 * H, tw->w_out, 2 * H, nullptr, B, H, 2 * H, EPI_TANH, tp->h_tilde, H, ar, st));
     } else {
         TRY(softdot_fwd_i(tw, B, L, H, nullptr, 0, ctx, ctx_mask, tp->h_tilde, tp->alpha, tp->cat2,
                           tp->t_text, ar, st, ctx_row));
@@ -726,6 +757,18 @@ static int decoder_tail_split_i(const sf_decoder_w* w, const sf_cands* U, int B,
                       ar, st, nullptr));
     return scoring_fwd_i(&w->action, us, B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt, tp->r, ar, st, glue,
                          nullptr);
+}
+
+int sf_attn_decoder_attend_fwd(const sf_pano* X, int B, const sf_decoder_tape* tp, const sf_dropout* drop,
+                               uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(X && tp && tp->q && tp->xin && tp->alpha_v && B > 0);
+    Arena ar = arena(ws, ws_bytes);
+    const PanoSrc xs = pano(X);
+    const int F = xs.IMG + xs.LOC;
+    float* part = B <= 1024 ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
+    return visual_attn(0, xs, B, tp->q, F, tp->alpha_v, tp->xin + F, 2 * F, make_dropout(drop, 2 * step_id), F,
+                       S(stream), part, part ? ar.tickets() : nullptr);
 }
 
 int sf_attn_decoder_tail_fwd(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,

@@ -574,6 +574,7 @@ __global__ __launch_bounds__(SC_NW * 64) void score_glue_kernel(ScoreArgs a, FGl
     if (wave == 0) {
         const int at = follower_glue_row(g, b, lane < A ? s_logit[lane] : 0.f, gin);
         if (lane == 0) s_at = at;
+        if (g.nav.on && lane < A) nav_advance_slot(g.nav, b, lane, at, gin.was_ended || at == 0);
     }
     __syncthreads();
     if (g.u_next && wave == s_at) {

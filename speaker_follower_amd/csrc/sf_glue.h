@@ -5,6 +5,56 @@
 
 namespace sf {
 
+// env.step + env.observe + shortest-path teacher of one (sample, candidate slot) of a device-resident
+// environment (env.py:126-146, 628-641, 742-761, 763-804 over the tabulated panorama sweep): the body of
+// sf_nav_step, also run by the scoring + glue kernel right behind the action choice.
+struct NavIO {
+    sf_nav_table nav;
+    const int32_t* row; const int32_t* view;      // [B] current state
+    const int32_t* goal_hop; int ld_hop;          // [B, ld_hop] next nav row towards the goal, by LOCAL row
+    const int32_t* hop_base;                      // [B] first nav row of the sample's scan
+    int32_t* row_next; int32_t* vp_next; int32_t* view_next; int32_t* a_num_next;
+    int32_t* cand_view_next; float* sincos_next;  // [B,A], [B,A,4]
+    int64_t* target_next;                         // [B] or null
+    bool on;
+};
+// act < 0: no move (the initial observation); ended: the row's flag AFTER this step
+__device__ __forceinline__ void nav_advance_slot(const NavIO& p, int b, int a, int act, bool ended) {
+    const int A = p.nav.A, V = p.nav.V;
+    int row = p.row[b], view = p.view[b];
+    if (act >= 0) {                               // env.py:126-146: stop, or a candidate that is the
+        const int s0 = row * V + view;            // current viewpoint itself, leaves the state alone
+        act = act >= p.nav.a_num[s0] ? 0 : act;
+        const int nr = p.nav.next_row[(size_t)s0 * A + act];
+        if (act != 0 && nr != row) {
+            view = p.nav.cand_view[(size_t)s0 * A + act];
+            row = nr;
+        }
+    }
+    const size_t s = (size_t)row * V + view;
+    const int n = p.nav.a_num[s];
+    p.cand_view_next[(size_t)b * A + a] = a < n ? p.nav.cand_view[s * A + a] : 0;
+    const float4 sc = a < n ? reinterpret_cast<const float4*>(p.nav.cand_sincos)[s * A + a]
+                            : make_float4(0.f, 1.f, 0.f, 1.f);
+    reinterpret_cast<float4*>(p.sincos_next)[(size_t)b * A + a] = sc;
+    if (a != 0) return;
+    p.row_next[b] = row;
+    p.vp_next[b] = p.nav.feat_row[row];
+    p.view_next[b] = view;
+    p.a_num_next[b] = n;
+    if (p.target_next) {
+        long tgt = -1;                            // follower.py:322-328: -1 once ended
+        if (!ended) {
+            const int hop = p.goal_hop[(size_t)b * p.ld_hop + (row - p.hop_base[b])];
+            tgt = 0;                              // at the goal: stop (env.py:744-745)
+            if (hop != row)
+                for (int c = 1; c < n; ++c)
+                    if (p.nav.next_row[s * A + c] == hop) { tgt = c; break; }
+        }
+        p.target_next[b] = tgt;
+    }
+}
+
 struct FGlue {
     CandSrc src;
     int B;
@@ -24,6 +74,7 @@ struct FGlue {
     uint32_t sample_seed;    // feedback 2: counter-based uniform per (seed, stream, row)
     uint32_t sample_stream;
     int row0;
+    NavIO nav;               // nav.on: env step of a device-resident environment behind the action choice
 };
 
 // The glue's inputs, loaded up front with straight-line code (callers issue this BEFORE they wait

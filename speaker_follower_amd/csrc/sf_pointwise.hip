@@ -400,6 +400,7 @@ __global__ __launch_bounds__(TPB) void follower_glue_kernel(FGlue g) {
     const FGlueIn gin = follower_glue_load(g, b);
     const float raw = g.logit[(size_t)b * A + min(lane, A - 1)];
     const int at = follower_glue_row(g, b, raw, gin);
+    if (g.nav.on && lane < A) nav_advance_slot(g.nav, b, lane, at, gin.was_ended || at == 0);
     if (g.u_next) {                                              // follower.py:502
         const int n4 = (g.src.IMG + g.src.LOC) >> 2;
         const CandRow row = cand_row(g.src, b, at);

@@ -138,6 +138,7 @@ class FollowerEngine:
         # inference rollouts: the S decode steps as ONE persistent launch (csrc/sf_mega.hip).  Falls back to
         # the per-stage episode when the shape is outside what that kernel supports.
         self.persistent_decode = False
+        self.fused_env_step = True      # nav.DeviceNavBatch: the env step inside the scoring + glue launch
         self.persistent_debug_tapes = False   # tests: also copy t_text / cat2 / h_tilde / q / xin per step
 
     # ------------------------------------------------------------------------------ forward
@@ -221,7 +222,8 @@ class FollowerEngine:
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
         # A nav.DeviceNavBatch produces its observations ON THE DEVICE, one step ahead of the decoder,
         # from the action the glue kernel has just chosen (real student forcing: the next panorama
-        # depends on a_t).  head(t+1) therefore cannot ride beside tail(t): plain step order.
+        # depends on a_t).  The attention of step t+1 therefore cannot ride beside tail(t); its QUERY can
+        # (t_v', q' need only h1): tail(t) with tape_next but no X_next, env step, then the attention alone.
         on_device_env = hasattr(batch, 'advance')
         if on_device_env:
             batch.advance(-1)                           # slot 0 = the initial observation
@@ -266,6 +268,10 @@ class FollowerEngine:
         if pipelined and not st.episode:
             call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
                  byref(tapes[0]), d_ptr, st.site0, *ws)
+        deferred = on_device_env and self.pipelined and fold is None and dw.visual.w_v_t
+        if deferred:
+            call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
+                 byref(tapes[0]), d_ptr, st.site0, *ws)
         for t in range(0 if not st.episode else S, S):
             pano = panos[t]
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
@@ -278,18 +284,26 @@ class FollowerEngine:
                 st.tape['xin'][t + 1].data_ptr(), 2 * F, d_ptr, 2 * (st.site0 + t + 1),
                 st.ce_term[t].data_ptr(), st.live[t].data_ptr(),
                 int(st.drop_dec[1]) ^ 0x1B873593, st.site0 + t, batch.row0)
-            if pipelined:
+            navio = None
+            if deferred and self.fused_env_step:        # env.step + observe in the scoring + glue launch
+                navio = batch.fused_step(t)
+                glue.nav = C.cast(C.pointer(navio), C.c_void_p)
+            if pipelined or deferred:
                 nxt = t + 1 < S
                 call('sf_attn_decoder_tail_fwd', byref(dw), byref(cnd), B, H, D, T, None, ptr(h0),
                      ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue), d_ptr,
-                     st.site0 + t, byref(panos[t + 1]) if nxt else None,
+                     st.site0 + t, byref(panos[t + 1]) if nxt and not deferred else None,
                      byref(tapes[t + 1]) if nxt else None, *ws)
             else:
                 call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T, None,
                      ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue),
                      d_ptr, st.site0 + t, *ws)
             if on_device_env:                           # env.step + observe + teacher for step t + 1
-                batch.advance(t, st.actions[t], st.ended)
+                if navio is None:
+                    batch.advance(t, st.actions[t], st.ended)
+                if deferred and t + 1 < S:              # the attention of step t + 1 over the panorama just chosen
+                    call('sf_attn_decoder_attend_fwd', byref(panos[t + 1]), B, byref(tapes[t + 1]), d_ptr,
+                         st.site0 + t + 1, *ws)
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         st.logits = st.tape['logit']
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]

@@ -152,6 +152,16 @@ class DeviceNavBatch:
              ptr(self.view[n]), ptr(self.a_num[n]), ptr(self.cand_view[n]), ptr(self.sincos[n]),
              ptr(self.target[n]), stream())
 
+    def fused_step(self, t):
+        """sf_nav_io of decode step t (slot t -> slot t + 1) for sf_follower_glue.nav: the env step runs in
+        the scoring + glue launch, right behind the action choice, instead of `advance(t, ...)`."""
+        n = t + 1
+        return _lib.NavIO(self._nav_struct, self.row[t].data_ptr(), self.view[t].data_ptr(),
+                          self.goal_hop.data_ptr(), self.ld_hop, self.hop_base.data_ptr(),
+                          self.row[n].data_ptr(), self.vp[n].data_ptr(), self.view[n].data_ptr(),
+                          self.a_num[n].data_ptr(), self.cand_view[n].data_ptr(), self.sincos[n].data_ptr(),
+                          self.target[n].data_ptr())
+
     def trajectories(self, st):
         """The rollout's result dictionaries (follower.py:446-456, 517-524): per sample instr_id,
         trajectory [(viewpointId, heading, elevation)], actions, scores -- the stop action and the

@@ -98,6 +98,31 @@ def test_device_rollout_equals_the_per_step_host_loop(world, feedback):
     assert [int(x) for x in tgt[0]] == [ob['teacher'] for ob in obs]
 
 
+@pytest.mark.parametrize('feedback', ['argmax', 'sample'])
+def test_env_step_schedules_agree_bit_for_bit(world, feedback):
+    """The three schedules of a device-environment rollout -- attention of step t+1 deferred behind the env step
+    with the env step inside the scoring + glue launch (default), the same with a separate sf_nav_step launch,
+    and the plain per-step order -- produce identical states, actions and logits."""
+    from speaker_follower_amd import follower, nav
+    env, agent, store, nt, enc, dec = world
+    env.reset_epoch()
+    items = list(env.batch)
+    outs = []
+    for fused, pipelined in ((True, True), (False, True), (False, False)):
+        eng = follower.FollowerEngine(enc, dec, store)
+        eng.dropout_seed, eng.site_next = 12345, 1
+        eng.fused_env_step, eng.pipelined = fused, pipelined
+        navb = nav.DeviceNavBatch(nt, items, EPISODE)
+        with torch.no_grad():
+            st = eng.rollout(navb, EPISODE, feedback, train=False)
+        torch.cuda.synchronize()
+        outs.append((st.actions.clone(), st.logits.clone(), navb.row.clone(), navb.view.clone(), navb.target.clone(),
+                     navb.cand_view.clone(), navb.sincos.clone(), st.loss.clone()))
+    for other in outs[1:]:
+        for a, b in zip(outs[0], other):
+            assert torch.equal(a, b)
+
+
 def test_device_rollout_trains_and_replays_as_a_graph(world):
     """BPTT through a device-env rollout gives the gradients of the same rollout fed from the host
     (its recorded index-form observations), and the whole thing is hipGraph-capturable."""
