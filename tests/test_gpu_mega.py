@@ -73,7 +73,7 @@ def compare(ref, got, S, B, tapes=True):
     torch.testing.assert_close(got.loss, ref.loss, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.parametrize('B,S', [(100, 20), (128, 5), (16, 6), (37, 9), (3, 4)])
+@pytest.mark.parametrize('B,S', [(100, 20), (128, 5), (16, 6), (37, 9), (3, 4), (1, 3)])
 def test_persistent_decode_matches_the_per_stage_engine(B, S):
     eng, batch, ref, got = rollouts(B, S)
     compare(ref, got, S, B)
@@ -83,6 +83,23 @@ def test_persistent_decode_matches_the_per_stage_engine(B, S):
 def test_persistent_decode_feedback_modes(feedback):
     eng, batch, ref, got = rollouts(40, 8, feedback)
     compare(ref, got, 8, 40, tapes=False)
+
+
+def test_persistent_decode_falls_back_outside_its_envelope():
+    """B > 128: sf_follower_decode_persistent answers SF_ERR_UNSUPPORTED and the engine runs the per-stage
+    episode instead (same results as an engine that never asked)."""
+    from speaker_follower_amd import follower
+    eng = make_engine()
+    fb = synth.follower_batch(seed=5, batch=130, steps=3, n_viewpoints=256)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    with torch.no_grad():
+        ref = eng.rollout(batch, 3, 'argmax', train=False)
+        eng.persistent_decode = True
+        eng.site_next, eng.iteration = 0, 0
+        got = eng.rollout(batch, 3, 'argmax', train=False)
+        torch.cuda.synchronize()
+    assert got.persistent is False
+    assert torch.equal(got.actions, ref.actions) and torch.equal(got.logits, ref.logits)
 
 
 def test_persistent_decode_is_repeatable_and_leaves_no_state():
