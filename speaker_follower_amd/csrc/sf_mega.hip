@@ -4,13 +4,16 @@
 //
 // Workgroup b: XCD x = b % 8, slot c = b / 8.  Three kinds of work share the launch:
 //
-//   gate product  (all 256 CUs)  [B, 2F+H] x [4H, 2F+H]^T of the LSTMCell (model.py:393): n-tile = hidden
-//                 units [16c, +16) x 4 gates, K split 8 ways by XCD (stage s of 64 k belongs to split
-//                 s % 8); the workgroup's weight block of every one of its stages stays in registers for
-//                 the whole episode, only the operand rows stream.  The operand row [u | attended feature |
-//                 h] of step t lives in the exchange buffer XIN[t % 3]; partial [16 x 64] tiles go to the
-//                 SLAB region of the workgroup (XCD = m-tile, slot = n-tile) that owns the cell of those
-//                 16 rows x 16 units, which sums its 8 partials, updates the cell and publishes h.
+//   gate product  [B, 2F+H] x [4H, 2F+H]^T of the LSTMCell (model.py:393): n-tile = hidden units [16c, +16) x 4
+//                 gates per slot; the K range is cut into 76 stages of 64.  The u stages (the tail of the
+//                 critical path) are split s % 8 over ALL XCDs and keep their weight blocks in registers for
+//                 the whole episode (only operand rows stream); the feature / h stages are split over the
+//                 visual XCDs 4-7, which are idle once their attention is done, and stream their weights.
+//                 The operand row [u | attended feature | h] of step t lives in the exchange buffer
+//                 XIN[t % 3]; partial [16 x 64] tiles go to the SLAB region of the workgroup (XCD = m-tile,
+//                 slot = n-tile) that owns the cell of those 16 rows x 16 units, which sums its 8 partials,
+//                 updates the cell and publishes h.  The three all-to-all edges (h, u, feature) carry an
+//                 arrival counter: consumers request data only once all of it has been published.
 //   chain groups  rows [32 g, +32), g = x & 3.  XCDs 0-3 run the text / scoring chain of group g, XCDs 4-7
 //                 the visual chain of the same rows; workgroup c owns sample 32 g + c and tile lane c:
 //        text:    t_text = W_in h1 (tile c)  ->  text attention of the sample  ->  h~ = tanh(W_out [wc ; h1])
@@ -29,7 +32,9 @@
 // loop by the compiler (hundreds of them), spilled to scratch and re-read in front of every load.
 // No load sits inside a branch (the compiler ends such a block with a full vmcnt(0) wait).
 //
-// Only the inference forward exists in this form (no tapes for a backward, no dropout).
+// Only the inference forward exists in this form (no tapes for a backward, no dropout).  Status: correct
+// (tests/test_gpu_mega.py) and ~20 % SLOWER than the per-stage path -- opt-in; DESIGN.md section 8 has the
+// measured timeline and the reasons (an in-kernel hop costs 3.5-4 us, a CU pulls ~35 GB/s of L2 misses).
 #include "sf_kernels.h"
 #include "sf_gemm_small.h"
 #include "sf_rows.h"
