@@ -511,20 +511,19 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
         };
 
         MG_STAMP(11)                                        // loop back
-        // ============================ chain of step t - 1, first product ============================
-        if (chain) {
+        // ============================ chain of step t - 1 ============================================
+        if (gates) {
+#pragma unroll
+            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        constexpr int RPW = MG_LMAX / 4;                    // 20 context rows per wave
+        float4 xctx[RPW][2];                                // text role: the sample's context rows
+        if (chain && !text_role) {
             wait_count(cnt_h, (unsigned)t * n_cells, dead);
-            TileJob j{};
-            j.a0 = xb + (unsigned)(row0 * MG_K + MG_OFF_H) * 4u; j.lda0 = MG_K;     // h1 of step t - 1
-            j.tile_stride = 1; j.tanh_epi = false; j.m_live = m_live;
-            if (text_role) {                                // t_text = W_in h1 (model.py:129)
-                j.w = p.w_in; j.ldw = MG_H; j.w_rows = MG_H; j.bias = nullptr;
-                j.tile0 = e; j.ntiles = 1;
-                j.out = (MG_TT + (unsigned)((cs * 128 + row0) * MG_H)) * 4u; j.rst = (MG_TT + (unsigned)((cn * 128 + row0) * MG_H)) * 4u;
-                j.ldo = MG_H;
-                j.dbg = p.dbg_t_text ? p.dbg_t_text + ((size_t)(t - 1) * B + row0) * MG_H : nullptr; j.ld_dbg = MG_H;
-                tile_gemm<8, 1, 1>(rs, j, smem, wv, rows_valid, dead);
-            } else if (gates) {                             // q' = M_v h1 + c_v: the query of step t's panorama
+            if (gates) {                                    // q' = M_v h1 + c_v: the query of step t's panorama
+                TileJob j{};
+                j.a0 = xb + (unsigned)(row0 * MG_K + MG_OFF_H) * 4u; j.lda0 = MG_K;     // h1 of step t - 1
+                j.tanh_epi = false; j.m_live = m_live;
                 j.w = p.m_v; j.ldw = MG_H; j.w_rows = MG_F; j.bias = p.c_v;
                 j.tile0 = e; j.tile_stride = 32; j.ntiles = (MG_TILES_Q - e + 31) >> 5;
                 j.out = (MG_Q + (unsigned)((cs * 128 + row0) * MG_F)) * 4u; j.rst = (MG_Q + (unsigned)((cn * 128 + row0) * MG_F)) * 4u;
@@ -533,33 +532,48 @@ __global__ __launch_bounds__(256, 1) void mega_kernel(MegaArgs pa) {
                 tile_gemm<8, 2, 5>(rs, j, smem, wv, rows_valid, dead);
             }
         }
-        MG_STAMP(0)
-        if (gates) {
-#pragma unroll
-            for (int m = 0; m < MT; ++m) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (xcd >= 4) {                                 // the h stages (h of step t - 1 is complete: counted above)
+        if (!(chain && text_role)) {
+            MG_STAMP(0)
+            if (gates && xcd >= 4) {                        // the h stages (h of step t - 1 is complete: counted)
                 if (!chain) wait_count(cnt_h, (unsigned)t * n_cells, dead);
                 gate_group_stream(nfeat, nfh);
             }
+            MG_STAMP(1)
         }
-        MG_STAMP(1)
         if (chain && text_role) {
+            // the context rows of the sample depend on nothing: requested before the wait for h so that their
+            // ~160 KB land during the first hop (rows beyond L: a clamped, finite row; an invalid sample reads
+            // the last valid sample's rows and discards them)
+            {
+                const rsrc_t rc = make_rs(p.ctx + (size_t)bsc * L * MG_H, (unsigned)(L * MG_H) * 4u);
+#pragma unroll
+                for (int r = 0; r < RPW; ++r) {
+                    const unsigned so = (unsigned)(min(wv * RPW + r, L - 1) * MG_H) * 4u;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) xctx[r][i] = bld(rc, vl16 + 1024u * i, so);
+                }
+            }
+            wait_count(cnt_h, (unsigned)t * n_cells, dead);
+            {                                               // t_text = W_in h1 (model.py:129)
+                TileJob j{};
+                j.a0 = xb + (unsigned)(row0 * MG_K + MG_OFF_H) * 4u; j.lda0 = MG_K;     // h1 of step t - 1
+                j.tile_stride = 1; j.tanh_epi = false; j.m_live = m_live;
+                j.w = p.w_in; j.ldw = MG_H; j.w_rows = MG_H; j.bias = nullptr;
+                j.tile0 = e; j.ntiles = 1;
+                j.out = (MG_TT + (unsigned)((cs * 128 + row0) * MG_H)) * 4u; j.rst = (MG_TT + (unsigned)((cn * 128 + row0) * MG_H)) * 4u;
+                j.ldo = MG_H;
+                j.dbg = p.dbg_t_text ? p.dbg_t_text + ((size_t)(t - 1) * B + row0) * MG_H : nullptr; j.ld_dbg = MG_H;
+                tile_gemm<8, 1, 1>(rs, j, smem, wv, rows_valid, dead);
+            }
+            MG_STAMP(0)
             // ---------------- text attention of sample bs (model.py:129-139) --------------------
             {
                 float4(*slots)[2 * 64] = reinterpret_cast<float4(*)[2 * 64]>(smem);
                 float* s_score = smem + 4 * 2 * 64 * 4;
-                constexpr int RPW = MG_LMAX / 4;            // 20 context rows per wave
                 const unsigned ob = (MG_WC + (unsigned)((cs * 128 + bs) * MG_H)) * 4u, rb = (MG_WC + (unsigned)((cn * 128 + bs) * MG_H)) * 4u;
                 float4 pw[2] = {f4zero(), f4zero()};
                 if (sample_ok) {                            // (workgroup-uniform; the loads inside are unconditional)
-                    const rsrc_t rc = make_rs(p.ctx + (size_t)bsc * L * MG_H, (unsigned)(L * MG_H) * 4u);
-                    float4 x[RPW][2];                       // rows beyond L: a clamped (finite) row, weight 0 below
-#pragma unroll
-                    for (int r = 0; r < RPW; ++r) {
-                        const unsigned so = (unsigned)(min(wv * RPW + r, L - 1) * MG_H) * 4u;
-#pragma unroll
-                        for (int i = 0; i < 2; ++i) x[r][i] = bld(rc, vl16 + 1024u * i, so);
-                    }
+                    float4 (&x)[RPW][2] = xctx;
                     const unsigned tb = (MG_TT + (unsigned)((cs * 128 + bs) * MG_H)) * 4u;
                     v4u tv[2];
 #pragma unroll
