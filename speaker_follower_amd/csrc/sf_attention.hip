@@ -52,10 +52,16 @@ __device__ __forceinline__ void visual_attn_body(const VisArgs& a, int b) {
     float dot[VIS_RPW];
 #pragma unroll
     for (int r = 0; r < VIS_RPW; ++r) dot[r] = 0.f;
+    // (all chunks of the vector requested before the first use: behind the dropout branch below each load
+    //  would otherwise be its own memory round trip)
+    float4 qv[VIS_CPL];
+#pragma unroll
+    for (int i = 0; i < VIS_CPL; ++i)
+        qv[i] = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[min(lane + 64 * i, n4 - 1)];
 #pragma unroll
     for (int i = 0; i < VIS_CPL; ++i) {
         const int c = lane + 64 * i;
-        float4 q = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[min(c, n4 - 1)];
+        float4 q = qv[i];
         if (c >= n4) q = f4zero();
         {
             if (MODE == 1 && a.drop.on()) {

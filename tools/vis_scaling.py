@@ -13,11 +13,15 @@ rng = np.random.default_rng(0)
 enc, dec, _, _ = bench.build_models(101, dev)
 va = dec.visual_attention_layer
 wv = (va.linear_in_h.weight, va.linear_in_h.bias, va.linear_in_v.weight, va.linear_in_v.bias)
+MODE = os.environ.get('MODE', 'random')
 for B in (16, 32, 64, 100, 128, 200, 256, 400):
     h = torch.randn(B, 512, device=dev)
     outs = []
-    for rep in range(12):       # fresh random viewpoints every call: cold rows
-        vp = torch.from_numpy(rng.integers(0, 10567, size=B).astype(np.int32)).to(dev)
+    for rep in range(12):       # fresh viewpoints every call: cold rows (random, or one contiguous run of rows)
+        if MODE == 'random':
+            vp = torch.from_numpy(rng.integers(0, 10567, size=B).astype(np.int32)).to(dev)
+        else:
+            vp = torch.from_numpy(((rng.integers(0, 10567) + np.arange(B)) % 10567).astype(np.int32)).to(dev)
         view = torch.from_numpy(rng.integers(0, 36, size=B).astype(np.int32)).to(dev)
         outs.append((vp, view))
     torch.cuda.synchronize()
