@@ -32,6 +32,13 @@ sys.path.insert(0, ROOT)
 # algorithmic work of ONE agent-step (forward, fp32, A = 8, L = 80, B = 100)
 AGENT_STEP_FLOPS = 71386112.0
 AGENT_STEP_BYTES = 1049469.0
+# what the kernels EXECUTE per agent-step after the folds of DESIGN.md section 3 (the [36 x 2176] x [2176 x 256] key
+# projection and the per-candidate action projection are re-associated away): gate product 19.92 M + t_v 0.26 +
+# q 1.11 + visual attention 0.31 + t_text 0.52 + text attention 0.16 + h~ 1.05 + t_a 0.26 + r 1.11 + scores 0.03
+def executed_agent_step_flops(H=512, F=2176, D=256, V=36, L=80, A=8):
+    return 2.0 * ((2 * F + H) * 4 * H + H * D + D * F + 2 * V * F + H * H + 2 * L * H + 2 * H * H + H * D + D * F + A * F)
+
+
 PEAK_TFLOPS_F32_MFMA = 157.3        # MI355X_MICROARCH.md: dense fp32 MFMA at 2.4 GHz
 PEAK_HBM_GBS = 8000.0               # MI355X_MICROARCH.md: HBM3E spec (6.3 TB/s measured achievable)
 
@@ -116,7 +123,9 @@ def build_models(seed, device):
     import torch
     from speaker_follower_amd import synth, model
     d = synth.FULL
-    enc_w, dec_w = synth.follower_weights(seed)
+    # 'peaky' gains: logit std ~1.4, attention maxima 0.6-0.8 -- with the flat initialisation every logit is ~0,
+    # the loss is sum log(a_num) and a parity check against the CPU port says nothing (round-2 verdict)
+    enc_w, dec_w = synth.follower_weights_peaky(seed)
     enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
     dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
     enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
@@ -470,9 +479,14 @@ def main(argv=None):
         kernels=kernels[:8],
         kernel_time_ms_per_rollout=1e-3 * kernel_us / n_prof,
         rollout=dict(flops_frac=AGENT_STEP_FLOPS * B * S / (ms_rollout * 1e-3) / 1e12 / PEAK_TFLOPS_F32_MFMA,
+                     executed_flops_frac=executed_agent_step_flops(H, F, D, 36, T, A_mean) * B * S / (ms_rollout * 1e-3)
+                     / 1e12 / PEAK_TFLOPS_F32_MFMA,
+                     executed_mflop_per_agent_step=1e-6 * executed_agent_step_flops(H, F, D, 36, T, A_mean),
                      hbm_frac=AGENT_STEP_BYTES * B * S / (ms_rollout * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                     note='SURVEY 8(d) per-agent-step work (71.39 MFLOP, 1.049 MB at B=100; the unfolded '
-                          'reference arithmetic, decode steps only) x agent-steps / ms_per_step'),
+                     note='flops_frac prices SURVEY 8(d)\'s per-agent-step work (71.39 MFLOP, 1.049 MB at B=100: the '
+                          'UNFOLDED reference arithmetic, decode steps only) x agent-steps / ms_per_step; '
+                          'executed_flops_frac prices what the kernels actually execute after the key-projection and '
+                          'action-projection folds (the honest matrix-core utilisation of the whole rollout)'),
         method='launch times: HIP start/stop events on each dispatch of %d eager rollouts in this run; '
                'traffic_offline_pmc: HBM bytes per launch from committed rocprofv3 --pmc passes '
                '(profiles/pmc_traffic.json), NOT measured in this run' % n_prof)
@@ -523,7 +537,8 @@ def main(argv=None):
         from speaker_follower_amd import bench_extras
         out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2]
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
-        out['persistent_decode_experiment'] = bench_extras.persistent_decode(enc, dec, store, batch, S)
+        if os.path.exists(_lib.EXP_LIB_PATH):      # frozen experiment, only when its library was built on demand
+            out['persistent_decode_experiment'] = bench_extras.persistent_decode(enc, dec, store, batch, S)
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):
             out['search_full'] = bench_extras.search_full(conn, device)

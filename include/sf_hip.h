@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 5
+#define SF_ABI_VERSION 6
 
 enum {
     SF_OK = 0,
@@ -549,16 +549,6 @@ void sf_debug_trace(unsigned long long* buf);
  * share an XCD and would keep the exchange inside that XCD's L2.  Lets the tests exercise the protocol
  * the kernels fall back to when the observed workgroup -> XCD placement does not hold. */
 void sf_debug_force_write_through(int on);
-/* The S decode steps of an INFERENCE rollout (no dropout, no backward to follow) as ONE persistent launch
- * (csrc/sf_mega.hip): same inputs and outputs as sf_follower_episode_fwd -- logits, actions, scores, CE
- * terms, liveness, `ended`, the h1 / c1 tapes -- without the per-step tapes of the backward.  Needs
- * w->fold (sf_decoder_fold_build), index-form panoramas / candidates (no dense tensors, no is_valid),
- * B <= 128, H = 512, F = 2176, V = 36, L <= 80, A <= 16; anything else returns SF_ERR_UNSUPPORTED and
- * the caller uses sf_follower_episode_fwd.  debug_tapes != 0 (tests): t_text, cat2[:, :H], h_tilde,
- * q and xin of every step are also copied into e->tape. */
-int sf_follower_decode_persistent(const sf_decoder_w* w, const sf_follower_episode* e, int debug_tapes,
-                                  void* ws, size_t ws_bytes, sf_stream stream);
-
 /* ---- device-resident navigation (env.py:126-146 step, :149-224 panorama sweep, :742-761 teacher,
  * :763-804 observe) ---------------------------------------------------------------------------------
  * The candidate list of a state is a pure function of (viewpoint, view index): the host tabulates it

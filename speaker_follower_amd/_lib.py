@@ -124,7 +124,6 @@ _SIGNATURES = {
     'sf_abi_version': (C.c_int, []),
     'sf_debug_trace': (None, [C.c_void_p]),
     'sf_debug_force_write_through': (None, [C.c_int]),
-    'sf_follower_decode_persistent': (C.c_int, [P(DecoderW), P(FollowerEpisode), i32] + WS),
     'sf_status_string': (C.c_char_p, [C.c_int]),
     'sf_last_error_string': (C.c_char_p, []),
     'sf_linear_fwd': (C.c_int, [c_f, i32, c_f, c_f, i32, i32, i32, i32, c_f, i32] + WS),
@@ -204,7 +203,7 @@ SF_OK, SF_ERR_ARG, SF_ERR_UNSUPPORTED, SF_ERR_LAUNCH, SF_ERR_WORKSPACE = 0, 1, 2
 SF_ENC_PER_STEP = 1           # sf_encoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 def _load():
@@ -223,6 +222,29 @@ def _load():
 
 
 lib = _load()
+
+# ---- experiments kept out of the product library (include/sf_hip_experimental.h) ----
+EXP_LIB_PATH = os.path.join(_PKG, 'libsf_experimental.so')
+_EXP_SIGNATURES = {
+    'sf_follower_decode_persistent': (C.c_int, [P(DecoderW), P(FollowerEpisode), i32] + WS),
+}
+_exp = None
+
+
+def experimental():
+    """libsf_experimental.so, loaded on first use.  Raises when it has not been built
+    (`python -m speaker_follower_amd.build --experimental`)."""
+    global _exp
+    if _exp is None:
+        if not os.path.exists(EXP_LIB_PATH):
+            raise ImportError('libsf_experimental.so is not built: python -m speaker_follower_amd.build --experimental')
+        e = C.CDLL(EXP_LIB_PATH)
+        for name, (res, args) in _EXP_SIGNATURES.items():
+            fn = getattr(e, name)
+            fn.restype = res
+            fn.argtypes = args
+        _exp = e
+    return _exp
 
 
 def check(status, what=''):

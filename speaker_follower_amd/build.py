@@ -17,9 +17,12 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(PKG, 'libsf_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['sf_gemm.hip', 'sf_attention.hip', 'sf_pointwise.hip', 'sf_persist.hip', 'sf_mega.hip', 'sf_nav.hip', 'sf_api.hip']
-FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function'
-        ]
+SOURCES = ['sf_gemm.hip', 'sf_attention.hip', 'sf_pointwise.hip', 'sf_persist.hip', 'sf_nav.hip', 'sf_api.hip']
+# libsf_experimental.so (on demand, --experimental): the product's kernel objects + the persistent decode loop;
+# experimental/sf_mega_api.hip textually includes sf_api.hip, so sf_api.o is NOT linked into it
+EXP_LIB = os.path.join(PKG, 'libsf_experimental.so')
+EXP_SOURCES = ['experimental/sf_mega.hip', 'experimental/sf_mega_api.hip']
+FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-I' + CSRC]
 
 
 def _hipcc():
@@ -29,17 +32,20 @@ def _hipcc():
     return exe
 
 
-def _deps_mtime():
+def _deps_mtime(experimental=False):
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
     headers.append(os.path.join(os.path.dirname(PKG), 'include', 'sf_hip.h'))
+    if experimental:
+        headers += [os.path.join(CSRC, 'experimental', 'sf_mega.h'), os.path.join(CSRC, 'sf_api.hip'),
+                    os.path.join(os.path.dirname(PKG), 'include', 'sf_hip_experimental.h')]
     return max(os.path.getmtime(h) for h in headers)
 
 
 def _compile(src, force):
-    obj = os.path.join(OBJ, src.replace('.hip', '.o'))
+    obj = os.path.join(OBJ, os.path.basename(src).replace('.hip', '.o'))
     path = os.path.join(CSRC, src)
     if (not force and os.path.exists(obj)
-            and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime())):
+            and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime('experimental' in src))):
         return obj, False
     cmd = [_hipcc()] + FLAGS + ['-c', path, '-o', obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
@@ -67,6 +73,24 @@ def build_lib(force=False, verbose=True):
     return LIB
 
 
+def build_experimental(force=False, verbose=True):
+    """libsf_experimental.so: sf_follower_decode_persistent (include/sf_hip_experimental.h).  Not built by
+    __graft_entry__.build(); tests/test_gpu_mega.py and FollowerEngine.persistent_decode need it."""
+    os.makedirs(OBJ, exist_ok=True)
+    shared = [s for s in SOURCES if s != 'sf_api.hip']
+    with ThreadPoolExecutor(max_workers=4) as ex:
+        results = list(ex.map(lambda s: _compile(s, force), shared + EXP_SOURCES))
+    objs = [o for o, _ in results]
+    if any(r for _, r in results) or not os.path.exists(EXP_LIB):
+        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', EXP_LIB] + objs
+        res = subprocess.run(cmd, capture_output=True, text=True)
+        if res.returncode != 0:
+            raise RuntimeError('link failed:\n%s\n%s' % (res.stdout, res.stderr))
+    if verbose:
+        print('libsf_experimental.so (%d bytes)' % os.path.getsize(EXP_LIB))
+    return EXP_LIB
+
+
 def build_sim(force=False, verbose=True):
     """The navigation-only MatterSim pybind11 module (g++, no OpenCV / GL / jsoncpp)."""
     import sysconfig
@@ -89,3 +113,5 @@ def build_sim(force=False, verbose=True):
 if __name__ == '__main__':
     build_lib(force='--force' in sys.argv)
     build_sim(force='--force' in sys.argv)
+    if '--experimental' in sys.argv:
+        build_experimental(force='--force' in sys.argv)

@@ -35,7 +35,7 @@
 // Only the inference forward exists in this form (no tapes for a backward, no dropout).  Status: correct
 // (tests/test_gpu_mega.py) and ~20 % SLOWER than the per-stage path -- opt-in; DESIGN.md section 8 has the
 // measured timeline and the reasons (an in-kernel hop costs 3.5-4 us, a CU pulls ~35 GB/s of L2 misses).
-#include "sf_kernels.h"
+#include "sf_mega.h"
 #include "sf_gemm_small.h"
 #include "sf_rows.h"
 

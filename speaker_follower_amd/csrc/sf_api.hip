@@ -6,6 +6,7 @@
 
 using namespace sf;
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -18,7 +19,7 @@ thread_local hipError_t g_last_hip_error = hipSuccess;
 namespace {
 struct ProfRec { const char* name; hipEvent_t e0, e1; };
 struct Prof {
-    bool active = false;
+    std::atomic<bool> active{false};   // read by every SF_LAUNCH on any host thread, flipped by begin / end
     std::vector<ProfRec> recs;
     std::vector<hipEvent_t> pool;      // events are created once and reused by later sessions
     size_t used = 0;
@@ -26,15 +27,18 @@ struct Prof {
 Prof g_prof;                 // process-wide: torch runs backward() on its own host thread
 std::mutex g_prof_mutex;
 }  // namespace
-bool prof_active() { return g_prof.active; }
+bool prof_active() { return g_prof.active.load(std::memory_order_acquire); }
 void prof_events(const char* name, hipEvent_t* e0, hipEvent_t* e1) {
     std::lock_guard<std::mutex> lock(g_prof_mutex);
     Prof& p = g_prof;
+    *e0 = *e1 = nullptr;
+    if (!p.active.load(std::memory_order_relaxed)) return;     // sf_profile_end won the race: plain launch
     while (p.pool.size() < p.used + 2) {
         hipEvent_t e = nullptr;
         if (hipEventCreate(&e) != hipSuccess) { e = nullptr; }
         p.pool.push_back(e);
     }
+    if (!p.pool[p.used] || !p.pool[p.used + 1]) return;        // event creation failed: untimed launch
     *e0 = p.pool[p.used++];
     *e1 = p.pool[p.used++];
     p.recs.push_back(ProfRec{name, *e0, *e1});
@@ -1512,46 +1516,6 @@ int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float
     return embedding_rows(table, E, idx, B, out, S(stream));
 }
 
-}  // extern "C"
-
-// ---- the decode loop of an inference rollout as ONE persistent launch (sf_mega.hip) -----------------
-extern "C" int sf_follower_decode_persistent(const sf_decoder_w* w, const sf_follower_episode* e, int debug_tapes,
-                                             void* ws, size_t ws_bytes, sf_stream stream) {
-    SF_ENTER();
-    SF_CHECK_ARG(w && e && e->S > 0 && e->B > 0 && e->h_init && e->c_init && e->ctx && e->ctx_mask && e->tape.xin && e->tape.h1 &&
-                 e->tape.c1 && e->tape.logit && glue_ok(&e->U, &e->glue));
-    const PanoSrc xs = pano(&e->X);
-    const CandSrc us = cands(&e->U);
-    if (!w->fold || e->drop.p > 0.f || e->glue.is_valid || !mega_supported(e->B, e->H, e->L, e->A, xs, us))
-        return SF_ERR_UNSUPPORTED;
-    const int F = xs.IMG + xs.LOC;
-    // head(0): the visual attention of step 0 on h_init, by the per-stage kernels, into tape.xin[0][:, F:2F]
-    StepView v0 = step_view(e, 0);
-    TRY(decoder_head_i(w, &v0.X, e->B, e->H, e->D, e->h_init, &v0.tp, nullptr, e->step0, ws, ws_bytes, stream));
-    Arena ar = arena(ws, ws_bytes);
-    float* xchg = ar.take(mega_xchg_dwords());
-    NEED(xchg && ar.tickets());
-    MegaHost h{};
-    h.w_ih = w->lstm.w_ih; h.w_hh = w->lstm.w_hh; h.b_ih = w->lstm.b_ih; h.b_hh = w->lstm.b_hh;
-    h.w_in = w->text.w_in; h.w_out = w->text.w_out;
-    h.m_v = w->fold->m_v; h.c_v = w->fold->c_v; h.m_a = w->fold->m_a; h.c_a = w->fold->c_a;
-    h.h_init = e->h_init; h.c_init = e->c_init; h.feat0 = e->tape.xin + F; h.ld_feat0 = 2 * F;
-    h.ctx = e->ctx; h.mask = e->ctx_mask; h.L = e->L;
-    h.X = xs; h.U = us;
-    h.target = e->glue.target; h.feedback = e->glue.feedback; h.sample_seed = e->glue.sample_seed;
-    h.sample_stream0 = e->step0; h.row0 = e->glue.row0; h.ended = e->glue.ended;
-    h.logit = e->tape.logit; h.a_t = e->glue.a_t; h.target_used = e->glue.target_used; h.score = e->glue.score;
-    h.ce_term = e->glue.ce_term; h.live = e->glue.live; h.h1_tape = e->tape.h1; h.c1_tape = e->tape.c1;
-    if (debug_tapes) {
-        h.dbg_t_text = e->tape.t_text; h.dbg_cat2 = e->tape.cat2; h.dbg_h_tilde = e->tape.h_tilde; h.dbg_q = e->tape.q;
-        h.dbg_xin = e->tape.xin;
-    }
-    h.B = e->B; h.S = e->S;
-    h.xchg = reinterpret_cast<unsigned*>(xchg);
-    h.done = ar.tickets() + PERSIST_TICKET;
-    return mega_decode(h, S(stream));
-}
-
 // ---- in-process kernel timing ---------------------------------------------------------------------
 int sf_profile_begin(void) {
     SF_ENTER();
@@ -1595,3 +1559,5 @@ long sf_profile_end(char* buf, size_t cap) {
     }
     return (long)out.size() + 1;
 }
+
+}  // extern "C"

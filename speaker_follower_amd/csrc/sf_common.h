@@ -49,9 +49,9 @@ void prof_events(const char* name, hipEvent_t* e0, hipEvent_t* e1);
     SF_LAUNCH_AS(#kernel, kernel, grid, block, shmem, st, __VA_ARGS__)
 #define SF_LAUNCH_AS(name, kernel, grid, block, shmem, st, ...)                                 \
     do {                                                                                         \
-        if (sf::prof_active()) {                                                                 \
-            hipEvent_t _e0, _e1;                                                                 \
-            sf::prof_events(name, &_e0, &_e1);                                                   \
+        hipEvent_t _e0 = nullptr, _e1 = nullptr;                                                 \
+        if (sf::prof_active()) sf::prof_events(name, &_e0, &_e1); /* null: session just ended */ \
+        if (_e0 && _e1) {                                                                        \
             hipExtLaunchKernelGGL(kernel, grid, block, shmem, st, _e0, _e1, 0, __VA_ARGS__);     \
         } else {                                                                                 \
             hipLaunchKernelGGL(kernel, grid, block, shmem, st, __VA_ARGS__);                     \

@@ -212,11 +212,6 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
                 }
             }
             EP_STAMP(0)                                  // waiting for h_t
-            // every workgroup of the group has consumed h_{t-1}: its buffer becomes the buffer of
-            // h_{t+2}; reset the own patch there (same lanes, same addresses as the later publish)
-            if ((tid & 3) == 0)
-                xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
-                       (unsigned)((((t + 2) % 3) * EP_ROWS) * H * 4) + patch_off);
             // input row of the NEXT step (table lookup by token): lands behind the MFMAs
             if (t + 1 < T) {
                 const int tok = s_tok[er][t + 1];
@@ -265,6 +260,13 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
                     for (int r = 0; r < 4; ++r) s_red[t & 1][w + 4 * h2][g][(kk * 4 + r) * 16 + li] = 0.f;
         }
         __syncthreads();
+        // A wave polls only its own 8 of the 32 source slots; behind this barrier the four waves
+        // TOGETHER have seen all 32 workgroups publish h_t, i.e. every workgroup of the group has
+        // finished reading h_{t-1}.  Its buffer becomes the buffer of h_{t+2}: reset the own patch there
+        // (same lanes, same addresses as the later publish; ordered before it by the vmcnt(0) below).
+        if (t > 0 && (tid & 3) == 0)
+            xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
+                   (unsigned)((((t + 2) % 3) * EP_ROWS) * H * 4) + patch_off);
         EP_STAMP(1)                                      // MFMAs + partials to LDS + barrier
         float g4[4];
 #pragma unroll
@@ -716,16 +718,21 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
             }
         }
         EP_STAMP(1)                                      // wait for h1 + scores
-        // everyone in the group has finished step t-1: reset the own regions of the buffer of step t+2
+        // h1 / h~ / partial scores of step t-1 were all consumed in front of a workgroup barrier of step t-1
+        // (phases D and F), so any wave that published for step t proves its whole workgroup is done with
+        // them: reset the own regions of the buffer of step t+2
         if ((tid & 3) == 0) {
             xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs, (bn + SPX_H1 + patch) * 4u);
             xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs, (bn + SPX_HT + patch) * 4u);
         }
         if (eu < SP_TPMAX)
             xstore32(local, EP_SENTINEL, rs, (bn + SPX_PS + (unsigned)((slot * EP_ROWS + er) * SP_TPMAX + eu)) * 4u);
-        if (tid < EP_ROWS)
+        // statistics rows: phase H of step t-1 has no workgroup barrier behind it, and what this wave has
+        // seen (the partial scores of rows [4w, 4w+4) from all 32 slots) proves only that WAVE w of every
+        // workgroup is past it -- those waves are the only readers of rows [4w, 4w+4) of this block
+        if (lane < 4)
             xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
-                   (bn + SPX_ST + (unsigned)((slot * EP_ROWS + tid) * 4)) * 4u);
+                   (bn + SPX_ST + (unsigned)((slot * EP_ROWS + 4 * w + lane) * 4)) * 4u);
         // attention weights of row er: lane eu holds path step eu (model.py:131-137)
         float alpha_l;
         {
@@ -878,7 +885,8 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
         }
         EP_STAMP(6)                                      // wait for the statistics + combine
         const float lse = M + logf(Z);
-        const long long wt = p.feedback == 0 ? tgt : (long long)arg;
+        // (a starved launch may hold the sentinel in `arg`: the word fed back must stay a table row)
+        const long long wt = dead ? (long long)p.pad : (p.feedback == 0 ? tgt : (long long)arg);
         const float lw = p.feedback == 0 ? tlog : M;
         if (slot == 0 && eu == 0 && evalid) {
             const size_t o = (size_t)t * B + eb;

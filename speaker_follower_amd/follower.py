@@ -135,8 +135,9 @@ class FollowerEngine:
         self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
         self.two_stream_forward = False  # experiment: visual half of step t+1 on a side stream, ordered by device flags
         self.episode_call = True        # the whole decode loop (and its backward) as ONE C call
-        # inference rollouts: the S decode steps as ONE persistent launch (csrc/sf_mega.hip).  Falls back to
-        # the per-stage episode when the shape is outside what that kernel supports.
+        # EXPERIMENT (libsf_experimental.so, built on demand): inference rollouts with the S decode steps as ONE
+        # persistent launch (csrc/experimental/sf_mega.hip) -- correct, slower than the per-stage path.  Falls
+        # back to the per-stage episode when the shape is outside what that kernel supports.
         self.persistent_decode = False
         self.fused_env_step = True      # nav.DeviceNavBatch: the env step inside the scoring + glue launch
         self.persistent_debug_tapes = False   # tests: also copy t_text / cat2 / h_tilde / q / xin per step
@@ -253,7 +254,7 @@ class FollowerEngine:
             st.persistent = False
             if self.persistent_decode and not (st.differentiable or training) and ep.side_stream is None:
                 dwf = dw if fold is not None else decoder_w_struct(params, fold=decoder_fold(dec))
-                rc = _lib.lib.sf_follower_decode_persistent(byref(dwf), byref(ep), int(self.persistent_debug_tapes), *ws)
+                rc = _lib.experimental().sf_follower_decode_persistent(byref(dwf), byref(ep), int(self.persistent_debug_tapes), *ws)
                 if rc == _lib.SF_ERR_UNSUPPORTED:
                     rc = None
                 else:

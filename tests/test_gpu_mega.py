@@ -1,11 +1,20 @@
-"""GPU: the follower's decode loop as ONE persistent launch (csrc/sf_mega.hip, sf_follower_decode_persistent)
-against the per-stage engine, which is itself pinned to the reference's goldens (tests/test_gpu_follower.py,
-test_gpu_hard_parity.py)."""
+"""GPU, EXPERIMENT (skipped unless libsf_experimental.so was built: `python -m speaker_follower_amd.build
+--experimental`): the follower's decode loop as ONE persistent launch (csrc/experimental/sf_mega.hip,
+sf_follower_decode_persistent) against the per-stage engine, which is itself pinned to the reference's goldens
+(tests/test_gpu_follower.py, test_gpu_hard_parity.py).  The comparison is HIP path vs HIP path: it carries no
+parity credit of its own, it keeps a frozen, slower-than-default experiment honest."""
+import os
+
 import numpy as np
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
+
+from speaker_follower_amd import _lib                                 # noqa: E402
+if not os.path.exists(_lib.EXP_LIB_PATH):
+    pytest.skip('libsf_experimental.so not built (frozen experiment, outside the product library)',
+                allow_module_level=True)
 
 from speaker_follower_amd import synth                                # noqa: E402
 
