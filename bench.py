@@ -542,7 +542,9 @@ def main(argv=None):
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):
             out['search_full'] = bench_extras.search_full(conn, device)
-            out['real_env_rollout'] = bench_extras.real_env_rollout(conn, device)     # configs[1], inference
+            out['real_env_rollout'] = bench_extras.real_env_rollout(conn, device)     # configs[1], 31-viewpoint fixture
+        if args.n_viewpoints == 10567:             # configs[1] at its real size: 90 graphs, 10 567 viewpoints
+            out['real_env_full'] = bench_extras.real_env_full(enc, dec, store, device)
         # the full training iteration of configs[1] -- student-forcing rollout (dropout on), BPTT, two
         # Adam steps -- on the same batch (it updates the weights, so it runs last)
         if not args.no_train_extra:

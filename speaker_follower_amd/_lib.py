@@ -227,6 +227,9 @@ lib = _load()
 EXP_LIB_PATH = os.path.join(_PKG, 'libsf_experimental.so')
 _EXP_SIGNATURES = {
     'sf_follower_decode_persistent': (C.c_int, [P(DecoderW), P(FollowerEpisode), i32] + WS),
+    # (that library carries its own copy of the launch-timing state: kernel_profile(experimental()))
+    'sf_profile_begin': (C.c_int, []),
+    'sf_profile_end': (C.c_long, [C.c_char_p, C.c_size_t]),
 }
 _exp = None
 
@@ -264,14 +267,17 @@ class kernel_profile:
     library (sf_profile_begin / sf_profile_end); afterwards prof.rows maps the kernel name to
     dict(calls, total_us, avg_us, min_us, max_us).  Eager issue only (not under graph capture)."""
 
+    def __init__(self, library=None):
+        self.library = library if library is not None else lib
+
     def __enter__(self):
-        call('sf_profile_begin')
+        check(self.library.sf_profile_begin(), 'sf_profile_begin')
         self.rows = {}
         return self
 
     def __exit__(self, *exc):
         buf = C.create_string_buffer(1 << 16)
-        n = lib.sf_profile_end(buf, len(buf))
+        n = self.library.sf_profile_end(buf, len(buf))
         if n < 0:
             raise SfError('sf_profile_end failed')
         for line in buf.value.decode().splitlines():

@@ -11,6 +11,7 @@
 
 Every measurement is wrapped: a failure is reported as {"error": ...} instead of losing the line.
 """
+import os
 import time
 import traceback
 
@@ -151,8 +152,10 @@ def real_env_rollout(conn_dir, device, batch=100, steps=20, scans=('YmJkqBEsHnH'
     eng = follower.FollowerEngine(enc, dec, store)
     replay, gst = eng.capture(navb, steps, 'argmax')
     dt = _timed(replay, 3, 10)
-    out = dict(what='student-forced argmax rollout on real connectivity graphs (%d viewpoints), batch %d, %d decode '
-                    'steps, encoder included; every step executed for every row' % (n, batch, steps),
+    out = dict(what='CACHE-RESIDENT TABLE (%d viewpoints = %.0f MB: every panorama is served by L2 / MALL; the full-size '
+                    'number is real_env_full): student-forced argmax rollout on three fixture graphs, batch %d, %d '
+                    'decode steps, encoder included; every step executed for every row'
+                    % (n, n * 36 * 2048 * 4 / 1e6, batch, steps),
                unit='agent-steps/s', device_env=dict(value=batch * steps / dt, ms_per_rollout=1e3 * dt,
                                                      launch='hipGraph replay, one host sync per rollout'))
     agent = agents.Seq2SeqAgent(e, '/tmp/sf_bench_nav.json', enc, dec, episode_len=steps)
@@ -171,6 +174,94 @@ def real_env_rollout(conn_dir, device, batch=100, steps=20, scans=('YmJkqBEsHnH'
     out['host_env_per_step'] = dict(ms_per_rollout=1e3 * dth,
                                     note='reference-style loop: dense observations, D2H + Python env every step; '
                                          'exits early once every row has stopped')
+    return out
+
+
+_FULL_WORLD = {}
+
+
+def full_world(store, batch=100, seed=21):
+    """The FULL-SIZE real environment of BASELINE configs[1]: all 90 connectivity graphs (10 567 included
+    viewpoints, data/r2r_connectivity.npz) over a feature table with one row per viewpoint, a NavTable of
+    every (viewpoint, view) state, and `batch` random items (2-5 hop shortest paths, 10-79 token
+    instructions).  Cached per store: the host-side build takes a few seconds."""
+    from . import env, nav, nav_data
+    from .build import build_sim
+    key = (id(store), batch, seed)
+    if key not in _FULL_WORLD:
+        build_sim(verbose=False)
+        geo = nav_data.load_geometry()
+        row_of, n = nav_data.row_index(geo)
+        if store.n != n:
+            raise RuntimeError('the full-size environment needs a %d-row feature table (got %d)' % (n, store.n))
+        conn = nav_data.connectivity_dir()
+        graphs = {s: env.NavGraph(os.path.join(conn, s + '_connectivity.json')) for s in geo}
+        items = env.random_items(graphs, batch, np.random.default_rng(seed), min_len=10, max_len=79)
+        e = env.R2RIndexEnv(items, row_of, conn, batch_size=batch)
+        e.graphs = graphs                       # all 90 (already parsed: the objects the items were drawn from)
+        _FULL_WORLD[key] = (e, nav.NavTable(e, store))
+    return _FULL_WORLD[key]
+
+
+@_guard
+def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
+    """configs[1] at its real size: student-forced rollouts over the 10 567-viewpoint table and all 90 graphs
+    with the environment on the device (every next panorama depends on the action just chosen and is a
+    cold 295 KB block of a 3.1 GB table): (a) argmax inference as a hipGraph replay, (b) the full TRAINING
+    iteration with the reference's default `sample` feedback (train.py:299-300): rollout with dropout,
+    BPTT, two Adam steps -- follower.py:1001-1020."""
+    from . import nav, follower, dp, optim
+    t0 = time.perf_counter()
+    e, nt = full_world(store, batch)
+    build_s = time.perf_counter() - t0
+    e.reset_epoch()
+    e._next_minibatch(True)
+    items = list(e.batch)
+    navb = nav.DeviceNavBatch(nt, items, steps)
+    out = dict(what='student-forced rollouts on the FULL real environment: %d scans, %d viewpoints (feature table '
+                    '%.2f GB), %d x 36 states x <=%d candidates tabulated on the device; batch %d from %d scans, '
+                    '%d decode steps, encoder included; every step executed for every row'
+                    % (len(nt.scans), nt.n_rows, store.table.numel() * 4 / 1e9, nt.n_rows, nt.A, batch,
+                       len({it['scan'] for it in items}), steps),
+               unit='agent-steps/s', host_build_seconds=build_s)
+    enc.eval()
+    dec.eval()
+    eng = follower.FollowerEngine(enc, dec, store)
+    replay, gst = eng.capture(navb, steps, 'argmax')
+    dt = _timed(replay, 3, 10)
+    stopped = float((gst.actions == 0).any(dim=0).float().mean())
+    out['inference_argmax'] = dict(value=batch * steps / dt, ms_per_rollout=1e3 * dt,
+                                   launch='hipGraph replay, one host sync per rollout',
+                                   fraction_of_rows_that_stop=stopped)
+    # (b) training iteration, sample feedback, on copies of the weights (the caller's models stay untouched)
+    import copy
+    enc2, dec2 = copy.deepcopy(enc).train(), copy.deepcopy(dec).train()
+    pe = [p for p in enc2.parameters() if p.requires_grad]
+    pd = [p for p in dec2.parameters() if p.requires_grad]
+    flat = dp.FlatGrads(pe + pd)
+    oe = optim.FusedAdam(pe, lr=1e-4, weight_decay=5e-4)
+    od = optim.FusedAdam(pd, lr=1e-4, weight_decay=5e-4)
+    eng2 = follower.FollowerEngine(enc2, dec2, store)
+
+    def it():
+        flat.zero()
+        st = eng2.rollout(navb, steps, 'sample', train=True)
+        st.loss.backward()
+        oe.step()
+        od.step()
+        return st
+    for _ in range(2):
+        st = it()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for _ in range(train_iters):
+        st = it()
+    torch.cuda.synchronize()
+    dtt = (time.perf_counter() - t1) / train_iters
+    out['train_sample_feedback'] = dict(value=batch * steps / dtt, ms_per_iteration=1e3 * dtt, iterations=train_iters,
+                                        loss=float(st.loss.detach()),
+                                        what='rollout with dropout 0.5 + sampled actions on the device env, BPTT, '
+                                             '2x Adam; eager issue, same minibatch every iteration')
     return out
 
 
@@ -264,7 +355,7 @@ def persistent_decode(enc, dec, store, batch, steps, reps=10):
         out['actions_equal_per_stage_path'] = bool(torch.equal(st.actions, ref.actions))
         out['loss_abs_diff'] = abs(float(st.loss) - float(ref.loss))
         dt = _timed(lambda: eng.rollout(batch, steps, 'argmax', train=False), 3, reps)
-        with _lib.kernel_profile() as prof:
+        with _lib.kernel_profile(_lib.experimental()) as prof:
             eng.rollout(batch, steps, 'argmax', train=False)
         mk = [v for k, v in prof.rows.items() if 'mega_kernel' in k]
     B = batch.batch_size

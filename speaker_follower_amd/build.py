@@ -92,22 +92,28 @@ def build_experimental(force=False, verbose=True):
 
 
 def build_sim(force=False, verbose=True):
-    """The navigation-only MatterSim pybind11 module (g++, no OpenCV / GL / jsoncpp)."""
+    """The navigation-only MatterSim pybind11 module (g++, no OpenCV / GL / jsoncpp) and, next to it, the
+    batched panorama sweep `sf_sweep` (sweep_py.cpp) over the same simulator sources."""
     import sysconfig
     import pybind11
     sim = os.path.join(PKG, 'sim')
-    out = os.path.join(sim, 'MatterSim' + sysconfig.get_config_var('EXT_SUFFIX'))
-    srcs = [os.path.join(sim, f) for f in ('mattersim_nav.cpp', 'mattersim_py.cpp')]
-    deps = srcs + [os.path.join(sim, 'mattersim_nav.hpp')]
-    if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-        cmd = ['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden',
-               '-I' + pybind11.get_include(), '-I' + sysconfig.get_paths()['include']] + srcs + ['-o', out]
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError('MatterSim build failed:\n%s\n%s' % (res.stdout, res.stderr))
-        if verbose:
-            print('MatterSim module rebuilt (%d bytes)' % os.path.getsize(out))
-    return out
+    ext = sysconfig.get_config_var('EXT_SUFFIX')
+    outs = []
+    for name, files in (('MatterSim', ('mattersim_nav.cpp', 'mattersim_py.cpp')),
+                        ('sf_sweep', ('mattersim_nav.cpp', 'sweep_py.cpp'))):
+        out = os.path.join(sim, name + ext)
+        srcs = [os.path.join(sim, f) for f in files]
+        deps = srcs + [os.path.join(sim, 'mattersim_nav.hpp')]
+        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
+            cmd = ['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden',
+                   '-I' + pybind11.get_include(), '-I' + sysconfig.get_paths()['include']] + srcs + ['-o', out]
+            res = subprocess.run(cmd, capture_output=True, text=True)
+            if res.returncode != 0:
+                raise RuntimeError('%s build failed:\n%s\n%s' % (name, res.stdout, res.stderr))
+            if verbose:
+                print('%s module rebuilt (%d bytes)' % (name, os.path.getsize(out)))
+        outs.append(out)
+    return outs[0]
 
 
 if __name__ == '__main__':

@@ -137,7 +137,7 @@ class R2RIndexEnv:
     ([n,36,img] numpy, optional) enables dense observations for the dictionary-based agents."""
 
     def __init__(self, items, row_of, nav_graph_path, batch_size=100, seed=10, host_table=None,
-                 loc=128):
+                 loc=128, scans=None):
         self.data = list(items)
         self.row_of = row_of
         self.nav_graph_path = nav_graph_path
@@ -152,8 +152,9 @@ class R2RIndexEnv:
         random.shuffle(self.data)
         self.ix = 0
         self.sim = make_sim(nav_graph_path)
+        # scans: graphs to hold beyond those of `items` (a nav.NavTable covers exactly self.graphs)
         self.graphs = {s: NavGraph(os.path.join(nav_graph_path, s + '_connectivity.json'))
-                       for s in sorted({it['scan'] for it in self.data})}
+                       for s in sorted({it['scan'] for it in self.data} | set(scans or ()))}
         self._pano = {}
 
     # ---- minibatching (env.py:723-740)

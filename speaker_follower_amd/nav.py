@@ -24,8 +24,9 @@ import numpy as np
 import torch
 
 from . import _lib
+from . import sim as _sim
 from ._lib import call
-from .env import ANGLE_INC, WorldState
+from .env import ANGLE_INC, IMAGE_H, IMAGE_W, VFOV, WorldState
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded
 from .runtime import ptr, stream
@@ -37,39 +38,50 @@ class NavTable:
     """Candidate lists of every (viewpoint, view) state of the env's graphs, on the device."""
 
     def __init__(self, env, store, a_max=None):
+        """Rows = the included viewpoints of the env's graphs, scan by scan in connectivity-file order.  The
+        candidate lists come from the batched native sweep (sim/sweep_py.cpp: one call per scan, bit-identical
+        to env.panorama_sweep); a sweep does not depend on the agent's elevation, so each of the 12 heading
+        tables serves three views."""
+        sweep = _sim.load_sweep().sweep_scan
         self.scans = sorted(env.graphs)
         self.row_of = {}                 # (scan, viewpoint) -> nav row
         self.vp_of = []                  # nav row -> (scan, viewpoint)
         self.base = {}                   # scan -> first nav row
+        self.scan_rows = {}
+        per_scan = []
+        A = max(1, a_max or 0)
         for s in self.scans:
+            g = env.graphs[s]
+            nodes = [v for v, inc in zip(g.ids, g.included) if inc]
             self.base[s] = len(self.vp_of)
-            for v in env.graphs[s].nodes():
+            self.scan_rows[s] = len(nodes)
+            for v in nodes:
                 self.row_of[(s, v)] = len(self.vp_of)
                 self.vp_of.append((s, v))
+            tabs = sweep(env.nav_graph_path, s, nodes, IMAGE_W, IMAGE_H, math.radians(VFOV), 0)
+            per_scan.append(tabs)
+            A = max(A, tabs[1].shape[2])
+        self.A = A
         n = len(self.vp_of)
-        sweeps = {}
-        A = 1
-        for r, (s, v) in enumerate(self.vp_of):
-            for view in range(V):
-                ws = WorldState(s, v, (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC)
-                got_view, adj = env.panorama(ws)
-                assert got_view == view
-                sweeps[(r, view)] = adj
-                A = max(A, len(adj))
-        self.A = A = max(A, a_max or 0)
-        a_num = np.zeros(n * V, np.int32)
-        next_row = np.zeros((n * V, A), np.int32)
-        cand_view = np.zeros((n * V, A), np.int32)
-        head = np.zeros((n * V, A), np.float64)
-        elev = np.zeros((n * V, A), np.float64)
-        for (r, view), adj in sweeps.items():
-            s = r * V + view
-            a_num[s] = len(adj)
-            next_row[s, 0] = r
-            for a, d in enumerate(adj[1:], 1):
-                next_row[s, a] = self.row_of[(self.vp_of[r][0], d['nextViewpointId'])]
-                cand_view[s, a] = d['absViewIndex']
-                head[s, a], elev[s, a] = d['rel_heading'], d['rel_elevation']
+        a_num = np.zeros((n, 3, 12), np.int32)
+        next_row = np.zeros((n, 3, 12, A), np.int32)
+        cand_view = np.zeros((n, 3, 12, A), np.int32)
+        head = np.zeros((n, 3, 12, A), np.float64)
+        elev = np.zeros((n, 3, 12, A), np.float64)
+        for s, (an, nx, av, rh, re) in zip(self.scans, per_scan):
+            b, m, a = self.base[s], an.shape[0], nx.shape[2]
+            assert (nx >= 0).all(), 'a candidate of scan %s is not an included viewpoint' % s
+            av = av.copy()
+            av[:, :, 0] = 0                                    # the stop slot carries no view
+            a_num[b:b + m] = an[:, None, :]
+            next_row[b:b + m, :, :, :a] = (nx + b)[:, None]
+            next_row[b:b + m, :, :, a:] = np.arange(b, b + m, dtype=np.int32)[:, None, None, None]
+            cand_view[b:b + m, :, :, :a] = av[:, None]
+            head[b:b + m, :, :, :a] = rh[:, None]
+            elev[b:b + m, :, :, :a] = re[:, None]
+        a_num = a_num.reshape(n * V)
+        next_row, cand_view = next_row.reshape(n * V, A), cand_view.reshape(n * V, A)
+        head, elev = head.reshape(n * V, A), elev.reshape(n * V, A)
         feat_row = np.array([env.row_of[s + '_' + v] for s, v in self.vp_of], np.int32)
         dev = store.device
         up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)   # noqa: E731
@@ -77,7 +89,6 @@ class NavTable:
         self.sincos = up(cand_sincos(head, elev), torch.float32)          # the same host sin/cos the env batches use
         self.feat_row = up(feat_row, torch.int32)
         self.n_rows, self.device, self.env = n, dev, env
-        self.scan_rows = {s: len(env.graphs[s].nodes()) for s in self.scans}
         self._hops = {}
 
     def struct(self):
@@ -85,15 +96,19 @@ class NavTable:
                               self.sincos.data_ptr(), self.feat_row.data_ptr(), self.A, V)
 
     def hops(self, scan, goal):
-        """[rows of `scan`] int32: next nav row on the shortest path to `goal` (itself at the goal),
-        the table behind env.py:742-761."""
+        """[rows of `scan`] int32: next nav row on the shortest path to `goal` (itself at the goal, and
+        where no path exists), the table behind env.py:742-761."""
         key = (scan, goal)
         if key not in self._hops:
             g = self.env.graphs[scan]
-            out = np.zeros(self.scan_rows[scan], np.int32)
-            for i, v in enumerate(g.nodes()):
-                r = self.base[scan] + i
-                out[i] = r if v == goal else self.row_of[(scan, g.path(v, goal)[1])]
+            b = self.base[scan]
+            out = np.arange(b, b + self.scan_rows[scan], dtype=np.int32)
+            for i in range(self.scan_rows[scan]):
+                v = self.vp_of[b + i][1]
+                if v != goal:
+                    path = g.path(v, goal)
+                    if path is not None:
+                        out[i] = self.row_of[(scan, path[1])]
             self._hops[key] = out
         return self._hops[key]
 

@@ -11,3 +11,9 @@ if _DIR not in sys.path:
 def load():
     import MatterSim
     return MatterSim
+
+
+def load_sweep():
+    """The batched panorama sweep (sweep_py.cpp): sf_sweep.sweep_scan."""
+    import sf_sweep
+    return sf_sweep

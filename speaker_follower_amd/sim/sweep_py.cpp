@@ -1,0 +1,135 @@
+// Batched panorama sweep: the candidate lists of EVERY (viewpoint, heading
+// bin) of one scan in a single native call, instead of ~80 Python -> C++ calls per state.
+//
+// What it tabulates is tasks/R2R/env.py:149-224 (`_get_panorama_states`) as restated by
+// speaker_follower_amd/env.py:panorama_sweep: start in the state's view, look down to the bottom row, walk
+// the 36 discrete views (12 headings x 3 elevations), keep for every neighbour the view in which it is
+// closest to the image centre, express its direction relative to the agent's heading / the horizon;
+// candidate 0 is "stop", the rest is ordered by |rel_heading| (stable).  The walk drives this module's own
+// navigation-only simulator (mattersim_nav.cpp) through the same newEpisode / makeAction / getState calls
+// the Python sweep makes, and repeats its double-precision arithmetic operation for operation, so the
+// tables are bit-identical to the per-state Python sweep (tests/test_env_nav.py).
+// The result of a sweep does not depend on the agent's elevation (the walk always starts from the bottom
+// row), so one list per heading bin serves the three views that share it.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <algorithm>
+#include <cmath>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "mattersim_nav.hpp"
+
+namespace py = pybind11;
+using mattersim::Simulator;
+using mattersim::SimStatePtr;
+
+namespace {
+
+constexpr double kPi = 3.14159265358979323846;
+constexpr double kAngleInc = kPi / 6.0;            // env.py ANGLE_INC = math.pi / 6.0
+
+struct Cand {
+    unsigned ix;            // index of the neighbour in the connectivity file
+    int abs_view;           // view in which it is closest to the image centre
+    double rel_heading, rel_elevation, distance;
+};
+
+// x - 2 pi round(x / (2 pi)) with Python's round (ties to even)            (env.py:108-110)
+inline double canonical_angle(double x) { return x - 2 * kPi * std::nearbyint(x / (2 * kPi)); }
+
+// the sweep of ONE state; the simulator is left in its initial view (env.py:149-224)
+std::vector<Cand> sweep_state(Simulator& sim) {
+    SimStatePtr st = sim.getState();
+    const unsigned init_view = st->viewIndex;
+    const int delta = -(int)(st->viewIndex / 12);
+    for (int i = 0; i < std::abs(delta); ++i) sim.makeAction(0, 0, -1);
+    std::vector<Cand> adj;                          // first-seen order, like the Python dict
+    for (int rel = 0; rel < 36; ++rel) {
+        const double base_h = (rel % 12) * kAngleInc;
+        const double base_e = (rel / 12 - 1) * kAngleInc;
+        st = sim.getState();
+        for (size_t k = 1; k < st->navigableLocations.size(); ++k) {
+            const auto& loc = st->navigableLocations[k];
+            const double dist = std::sqrt(std::pow(loc->rel_heading, 2.0) + std::pow(loc->rel_elevation, 2.0));
+            auto it = std::find_if(adj.begin(), adj.end(), [&](const Cand& c) { return c.ix == loc->ix; });
+            if (it == adj.end() || dist < it->distance) {
+                const Cand c{loc->ix, (int)st->viewIndex, canonical_angle(base_h + loc->rel_heading),
+                             base_e + loc->rel_elevation, dist};
+                if (it == adj.end()) adj.push_back(c); else *it = c;
+            }
+        }
+        if ((rel + 1) % 12 == 0) sim.makeAction(0, 1, 1); else sim.makeAction(0, 1, 0);
+    }
+    const int back = -2 - delta;
+    for (int i = 0; i < std::abs(back); ++i) sim.makeAction(0, 0, back > 0 ? 1 : -1);
+    if (sim.getState()->viewIndex != init_view) throw std::logic_error("sweep: did not return to the initial view");
+    std::stable_sort(adj.begin(), adj.end(),
+                     [](const Cand& a, const Cand& b) { return std::fabs(a.rel_heading) < std::fabs(b.rel_heading); });
+    return adj;
+}
+
+// All (viewpoint, heading bin) states of a scan.  viewpoints: the ids to tabulate (included ones).
+// Returns (a_num [n,12] int32, next_ix [n,12,A] int32 (index into `viewpoints`, -1 = not listed),
+//          abs_view [n,12,A] int32, rel_heading [n,12,A] f64, rel_elevation [n,12,A] f64); slot 0 = stop.
+py::tuple sweep_scan(const std::string& nav_graph_path, const std::string& scan,
+                     const std::vector<std::string>& viewpoints, int width, int height, double vfov, int a_max) {
+    Simulator sim;
+    sim.setRenderingEnabled(false);
+    sim.setDiscretizedViewingAngles(true);
+    sim.setCameraResolution(width, height);
+    sim.setCameraVFOV(vfov);
+    sim.setNavGraphPath(nav_graph_path);
+    sim.init();
+    const size_t n = viewpoints.size();
+    std::vector<std::vector<Cand>> all(n * 12);
+    std::vector<long> ix_to_row;                     // connectivity index -> row in `viewpoints`
+    size_t A = 1;
+    for (size_t r = 0; r < n; ++r) {
+        for (int h = 0; h < 12; ++h) {
+            sim.newEpisode(scan, viewpoints[r], h * kAngleInc, 0.0);
+            if (sim.getState()->viewIndex != (unsigned)(12 + h)) throw std::logic_error("sweep: unexpected start view");
+            const unsigned own = sim.getState()->location->ix;
+            if (ix_to_row.size() <= own) ix_to_row.resize(own + 1, -1);
+            ix_to_row[own] = (long)r;
+            all[r * 12 + h] = sweep_state(sim);
+            A = std::max(A, all[r * 12 + h].size() + 1);
+        }
+    }
+    if (a_max > 0) A = std::max<size_t>(A, (size_t)a_max);
+    py::array_t<int32_t> a_num({n, (size_t)12});
+    py::array_t<int32_t> next_ix({n, (size_t)12, A}), abs_view({n, (size_t)12, A});
+    py::array_t<double> rel_h({n, (size_t)12, A}), rel_e({n, (size_t)12, A});
+    auto an = a_num.mutable_unchecked<2>();
+    auto nx = next_ix.mutable_unchecked<3>();
+    auto av = abs_view.mutable_unchecked<3>();
+    auto rh = rel_h.mutable_unchecked<3>();
+    auto re = rel_e.mutable_unchecked<3>();
+    for (size_t r = 0; r < n; ++r)
+        for (int h = 0; h < 12; ++h) {
+            const std::vector<Cand>& adj = all[r * 12 + h];
+            an(r, h) = (int32_t)adj.size() + 1;
+            for (size_t a = 0; a < A; ++a) { nx(r, h, a) = (int32_t)r; av(r, h, a) = 0; rh(r, h, a) = 0.0; re(r, h, a) = 0.0; }
+            av(r, h, 0) = -1;                        // stop: absViewIndex -1 (env.py:219)
+            for (size_t a = 0; a < adj.size(); ++a) {
+                const Cand& c = adj[a];
+                nx(r, h, a + 1) = c.ix < ix_to_row.size() ? (int32_t)ix_to_row[c.ix] : -1;
+                av(r, h, a + 1) = c.abs_view;
+                rh(r, h, a + 1) = c.rel_heading;
+                re(r, h, a + 1) = c.rel_elevation;
+            }
+        }
+    return py::make_tuple(a_num, next_ix, abs_view, rel_h, rel_e);
+}
+
+}  // namespace
+
+PYBIND11_MODULE(sf_sweep, m) {
+    m.doc() = "Batched panorama sweep over one scan (speaker_follower_amd, SURVEY N2)";
+    m.def("sweep_scan", &sweep_scan, py::arg("nav_graph_path"), py::arg("scan"), py::arg("viewpoints"),
+          py::arg("width") = 640, py::arg("height") = 480, py::arg("vfov") = 60.0 * kPi / 180.0, py::arg("a_max") = 0);
+}

@@ -138,3 +138,103 @@ def test_minibatching_cycles_through_the_data(setup):
         e.reset()
         seen += [it['instr_id'] for it in e.batch]
     assert len(seen) == 24 and len(set(seen)) == 24                    # 24 items, batch 8: one epoch
+
+
+def _fixture_env(scans):
+    from speaker_follower_amd import env
+    graphs = {s: env.NavGraph(os.path.join(CONN, s + '_connectivity.json')) for s in scans}
+    items = env.random_items(graphs, 12, np.random.default_rng(3))
+    row_of, n = {}, 0
+    for s, g in graphs.items():
+        for v in g.ids:
+            row_of[s + '_' + v] = n
+            n += 1
+    return env.R2RIndexEnv(items, row_of, CONN, batch_size=12), n
+
+
+def test_native_batched_sweep_is_bit_identical_to_the_per_state_sweep():
+    """sim/sweep_py.cpp (the panorama sweep of env.py:149-224 for every state of a scan in one
+    native call) against env.panorama_sweep driven from Python through the MatterSim binding: candidate
+    order, next viewpoint, absViewIndex and the float64 angles, all 36 views of every viewpoint."""
+    import math
+    from speaker_follower_amd import env, sim
+    from speaker_follower_amd.build import build_sim
+    build_sim(verbose=False)
+    sweep = sim.load_sweep().sweep_scan
+    e, _ = _fixture_env(['17DRP5sb8fy', 'gZ6f7yhEvPG', 'YmJkqBEsHnH'])
+    checked = 0
+    for scan, g in e.graphs.items():
+        nodes = [v for v, inc in zip(g.ids, g.included) if inc]
+        a_num, nx, av, rh, re = sweep(CONN, scan, nodes, env.IMAGE_W, env.IMAGE_H, math.radians(env.VFOV), 0)
+        for r, v in enumerate(nodes):
+            for view in range(36):
+                got_view, adj = e.panorama(env.WorldState(scan, v, (view % 12) * env.ANGLE_INC,
+                                                          (view // 12 - 1) * env.ANGLE_INC))
+                h = view % 12
+                assert got_view == view and a_num[r, h] == len(adj)
+                for a, d in enumerate(adj[1:], 1):
+                    assert nodes[nx[r, h, a]] == d['nextViewpointId'] and av[r, h, a] == d['absViewIndex']
+                    assert rh[r, h, a] == d['rel_heading'] and re[r, h, a] == d['rel_elevation']     # bit-exact
+                    checked += 1
+    assert checked > 5000
+
+
+def test_nav_table_rows_follow_the_sweep(tmp_path):
+    """nav.NavTable (host side; the tables live on whatever device the store is on -- CPU here): per state
+    a_num / next row / candidate view / sin-cos equal what env.observe would hand the agent."""
+    import torch
+    from speaker_follower_amd import env, nav, features
+    from speaker_follower_amd.build import build_sim
+    build_sim(verbose=False)
+    e, n = _fixture_env(['gZ6f7yhEvPG', 'GdvgFV5R1Z5'])
+    store = features.FeatureStore(np.zeros((n, 36, 8), np.float32), device='cpu')
+    nt = nav.NavTable(e, store)
+    assert nt.n_rows == sum(sum(g.included) for g in e.graphs.values())
+    for r, (scan, v) in enumerate(nt.vp_of):
+        for view in (0, 7, 13, 22, 35):
+            _, adj = e.panorama(env.WorldState(scan, v, (view % 12) * env.ANGLE_INC, (view // 12 - 1) * env.ANGLE_INC))
+            s = r * 36 + view
+            assert int(nt.a_num[s]) == len(adj)
+            assert int(nt.next_row[s, 0]) == r
+            for a, d in enumerate(adj[1:], 1):
+                assert nt.vp_of[int(nt.next_row[s, a])] == (scan, d['nextViewpointId'])
+                assert int(nt.cand_view[s, a]) == d['absViewIndex']
+                want = features.cand_sincos(np.array([d['rel_heading']]), np.array([d['rel_elevation']]))[0]
+                assert np.array_equal(nt.sincos[s, a].numpy(), want.astype(np.float32))
+    # the teacher table: next hop toward a goal from every viewpoint of the scan
+    scan = 'gZ6f7yhEvPG'
+    goal = nt.vp_of[nt.base[scan]][1]
+    hops = nt.hops(scan, goal)
+    g = e.graphs[scan]
+    for i, hrow in enumerate(hops):
+        v = nt.vp_of[nt.base[scan] + i][1]
+        p = g.path(v, goal)
+        assert nt.vp_of[hrow][1] == (v if v == goal or p is None else p[1])
+
+
+def test_full_r2r_geometry_table_regenerates_the_connectivity_directory(tmp_path):
+    """data/r2r_connectivity.npz (tools/make_nav_geometry.py): all 90 scans / 10 567 included viewpoints; the
+    regenerated files parse to graphs equal to the committed fixture files (same ids, flags, positions to the
+    bit, edges and weights), and the native sweep runs over every scan."""
+    import math
+    from speaker_follower_amd import env, nav_data, sim
+    from speaker_follower_amd.build import build_sim
+    build_sim(verbose=False)
+    geo = nav_data.load_geometry()
+    assert len(geo) == 90 and sum(int(g['included'].sum()) for g in geo.values()) == 10567
+    d = nav_data.connectivity_dir(out_dir=str(tmp_path / 'conn'))
+    for f in sorted(os.listdir(CONN)):
+        if not f.endswith('_connectivity.json'):
+            continue
+        a, b = env.NavGraph(os.path.join(CONN, f)), env.NavGraph(os.path.join(d, f))
+        assert a.ids == b.ids and a.included == b.included and a.adj == b.adj
+        assert all(np.array_equal(a.pos[k], b.pos[k]) for k in a.pos)
+    sweep = sim.load_sweep().sweep_scan
+    a_max, states = 0, 0
+    for s, g in geo.items():
+        nodes = [v for v, inc in zip(g['ids'], g['included']) if inc]
+        a_num, nx, _, _, _ = sweep(d, s, nodes, env.IMAGE_W, env.IMAGE_H, math.radians(env.VFOV), 0)
+        assert (nx >= 0).all() and (a_num >= 1).all()
+        a_max = max(a_max, int(a_num.max()))
+        states += a_num.size * 3
+    assert states == 10567 * 36 and a_max == 14          # SURVEY 8: A max 14 over the 90 graphs

@@ -131,7 +131,7 @@ def test_persistent_decode_timing():
         for _ in range(3):
             run()
         torch.cuda.synchronize()
-        with _lib.kernel_profile() as prof:
+        with _lib.kernel_profile(_lib.experimental()) as prof:
             for _ in range(5):
                 run()
         rows = sorted(prof.rows.items(), key=lambda kv: -kv[1]['total_us'])
