@@ -68,6 +68,8 @@ def parse(argv=None):
     # box with ONE GPU.  Ranks share cuda:0 and reduce through gloo; the line is marked oversubscribed.
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--share-gpu', action='store_true', help='(test) every rank uses cuda:0')
+    ap.add_argument('--plan', action='store_true',
+                    help='print the child commands / environment `--gpus N` would start (JSON) and exit; touches no GPU')
     return ap.parse_args(argv)
 
 
@@ -188,22 +190,31 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1)
     dec.train()
     params_e = [p for p in enc.parameters() if p.requires_grad]
     params_d = [p for p in dec.parameters() if p.requires_grad]
-    flat = dp.FlatGrads(params_e + params_d)      # gradients: one buffer (what the all-reduce wants)
+    # gradients: ONE buffer laid out in the order the backward completes them (decoder LSTM 40 MB first, the
+    # other decoder weights, the encoder last); with several ranks each bucket's all-reduce is launched from
+    # the backward as soon as the launches that complete it are issued (dp.BucketedGrads)
+    flat = dp.BucketedGrads(dp.follower_buckets(enc, dec), group=group)
     opt_e = optim.FusedAdam(params_e, lr=1e-4, weight_decay=5e-4)      # one launch per step each
     opt_d = optim.FusedAdam(params_d, lr=1e-4, weight_decay=5e-4)
     engine = follower.FollowerEngine(enc, dec, store, group=group)
     B = batch.batch_size
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+    mode = dict(sync='buckets')          # 'buckets' (overlapped), 'blocking' (one all-reduce after backward), 'none'
 
     def it(k=None):
         flat.zero()
+        engine.grad_sync = flat if (world > 1 and mode['sync'] == 'buckets') else None
         st = engine.rollout(batch, S, 'argmax', train=True)
         st.loss.backward()
-        if k is not None:
-            ev[k][0].record()
-        flat.allreduce(group)
-        if k is not None:
-            ev[k][1].record()
+        if mode['sync'] == 'buckets':
+            if world > 1:
+                flat.wait()
+        elif mode['sync'] == 'blocking':
+            if k is not None:
+                ev[k][0].record()
+            flat.allreduce(group)
+            if k is not None:
+                ev[k][1].record()
         opt_e.step()
         opt_d.step()
         return st
@@ -225,13 +236,50 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     dt /= iters
-    ar_ms = sum(a.elapsed_time(b) for a, b in ev) / iters
+    ar = dict(allreduce_ms=0.0)
+    if world > 1:
+        # the same iteration (a) with ONE blocking all-reduce of the whole buffer behind backward() -- its
+        # duration is the TOTAL all-reduce time -- and (b) with no gradient exchange at all: what the overlapped
+        # buckets leave EXPOSED is (overlapped iteration) - (b)
+        def timed(sync, n):
+            mode['sync'] = sync
+            it()
+            barrier()
+            t1 = time.perf_counter()
+            for k in range(n):
+                it(k)
+            barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / n], device=store.device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            return float(tt)
+        n2 = min(iters, 4)
+        dt_block = timed('blocking', n2)
+        total_ms = sum(a.elapsed_time(b) for a, b in ev[:n2]) / n2
+        dt_none = timed('none', n2)
+        mode['sync'] = 'buckets'
+        ar = dict(allreduce_ms=total_ms, allreduce_total_ms_blocking=total_ms,
+                  allreduce_exposed_ms_overlapped=max(0.0, 1e3 * (dt - dt_none)),
+                  ms_per_iteration_blocking_allreduce=1e3 * dt_block, ms_per_iteration_no_exchange=1e3 * dt_none,
+                  buckets_bytes=[4 * (hi - lo) for lo, hi in flat.bounds],
+                  schedule='buckets in production order (decoder LSTM, other decoder weights, encoder), each all-reduce '
+                           'launched async behind the launches that complete it; wait before Adam')
+    kernels = None
+    if world == 1:          # per-kernel table of the iteration, measured in this run (both backward streams)
+        from speaker_follower_amd import bench_extras
+        rows, us = bench_extras.kernel_table(lambda: it())
+        H, F, D = 512, 2176, 256
+        executed = 3.0 * executed_agent_step_flops(H, F, D, 36, max(batch.lengths), 5.0) * B * S
+        kernels = dict(rows=rows, kernel_time_ms_per_iteration=1e-3 * us,
+                       executed_gflop=executed / 1e9, executed_flops_frac=executed / dt / 1e12 / PEAK_TFLOPS_F32_MFMA,
+                       note='kernel times add up to more than the iteration: the backward runs on two streams; '
+                            'executed FLOPs = 3 x the forward (data + weight gradients), encoder excluded')
     enc.eval()
     dec.eval()
     return dict(value=B * S * world / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
-                allreduce_ms=ar_ms if world > 1 else 0.0, allreduce_bytes=flat.flat.numel() * 4,
+                roofline=kernels,
+                allreduce_bytes=flat.flat.numel() * 4, **ar,
                 what='student-forcing rollout (dropout 0.5) + BPTT + %s2x Adam (one HIP launch each), batch %d per GPU, '
-                     '%d decode steps, eager issue' % ('one flat sum all-reduce over %d ranks + ' % world
+                     '%d decode steps, eager issue' % ('bucketed sum all-reduce over %d ranks overlapped with the backward + ' % world
                                                        if world > 1 else '', B, S),
                 loss=float(st.loss.detach()))
 
@@ -301,6 +349,15 @@ def roofline_table(prof_rows, n_rollouts, B, S, T, A_mean, dims, pmc):
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
+    if args.plan:
+        keys = ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                'HSA_ENABLE_IPC_MODE_LEGACY')
+        child_argv = [a for a in argv if a != '--plan']
+        print(json.dumps(dict(launcher='self' if 'WORLD_SIZE' not in os.environ else 'external (torch.distributed.run)',
+                              backend=args.backend, collective='RCCL over xGMI' if args.backend == 'nccl' else 'gloo',
+                              ranks=[dict(cmd=cmd, env={k: env[k] for k in keys if k in env})
+                                     for cmd, env in launch_plan(max(1, args.gpus), child_argv)]), indent=1))
+        return
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
         sys.exit(run_launcher(args, argv))
 
@@ -337,7 +394,8 @@ def main(argv=None):
         params_e = [p for p in enc.parameters() if p.requires_grad]
         params_d = [p for p in dec.parameters() if p.requires_grad]
         from speaker_follower_amd import dp, optim
-        flat = dp.FlatGrads(params_e + params_d)       # kernels accumulate straight into this buffer
+        flat = dp.BucketedGrads(dp.follower_buckets(enc, dec), group=group)   # kernels accumulate straight into this buffer
+        engine.grad_sync = flat if world > 1 else None
         opt_e = optim.FusedAdam(params_e, lr=1e-4, weight_decay=5e-4)      # train.py:263-268
         opt_d = optim.FusedAdam(params_d, lr=1e-4, weight_decay=5e-4)
     else:
@@ -365,8 +423,9 @@ def main(argv=None):
         if train:
             flat.zero()
             st = engine.rollout(batch, S, 'argmax', train=True)
-            st.loss.backward()
-            flat.allreduce(group)                      # one RCCL sum all-reduce of 56 MB (no-op at N=1)
+            st.loss.backward()                         # (launches the bucketed RCCL all-reduces at N > 1)
+            if world > 1:
+                flat.wait()
             opt_e.step()
             opt_d.step()
         elif replay is not None:

@@ -394,6 +394,17 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
                             const sf_decoder_gtape* gtape, const float* gscale, float* dlogit,
                             float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
                             int* result_in_b, void* ws, size_t ws_bytes, sf_stream stream);
+/* The same over the decode steps [t_lo, t_hi) only (t_hi - 1 first): backpropagation through time in chunks,
+ * so that the caller can start the weight-gradient products of the steps that are done (sf_attn_decoder_wgrad
+ * over their stacked rows, on another stream) while the earlier steps are still being walked -- the slot is
+ * `loss.backward()` of follower.py:1014-1018.  dh_in / dc_in: the gradient arriving from step t_hi (the
+ * previous call's result; NULL when t_hi == S).  The call whose t_lo == 0 also forms the deferred context
+ * gradient of the whole episode. */
+int sf_follower_episode_bwd_range(const sf_decoder_w* w, const sf_follower_episode* e,
+                                  const sf_decoder_gtape* gtape, const float* gscale, float* dlogit,
+                                  float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
+                                  int* result_in_b, int t_lo, int t_hi, const float* dh_in, const float* dc_in,
+                                  void* ws, size_t ws_bytes, sf_stream stream);
 
 /* Loss bookkeeping without host syncs or atomics (deterministic order):
  * sum_cnt[t] = (sum_b term[t,b], sum_b live[t,b]) for t < T;  then, optionally after a

@@ -158,6 +158,8 @@ _SIGNATURES = {
     'sf_follower_episode_fwd': (C.c_int, [P(DecoderW), P(FollowerEpisode)] + WS),
     'sf_follower_episode_bwd': (C.c_int, [P(DecoderW), P(FollowerEpisode), P(DecoderGTape), c_f, c_f,
                                           c_f, c_f, c_f, c_f, c_f, P(C.c_int)] + WS),
+    'sf_follower_episode_bwd_range': (C.c_int, [P(DecoderW), P(FollowerEpisode), P(DecoderGTape), c_f, c_f,
+                                                c_f, c_f, c_f, c_f, c_f, P(C.c_int), i32, i32, c_f, c_f] + WS),
     'sf_attn_decoder_bwd': (C.c_int, [P(DecoderW), P(DecoderW), P(Pano), P(Cands), i32, i32, i32,
                                       i32, c_f, c_f, c_f, P(DecoderTape), P(DecoderGTape), c_f, c_f,
                                       c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),

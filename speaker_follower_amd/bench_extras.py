@@ -39,6 +39,23 @@ def _timed(fn, warm, reps):
     return (time.perf_counter() - t0) / reps
 
 
+def kernel_table(fn, reps=2, top=16):
+    """Per-kernel time of `fn` measured IN THIS RUN: HIP start / stop events on every dispatch the library makes
+    (sf_profile_begin / sf_profile_end -- the kernel's own execution time on its launch stream, what rocprofv3
+    --kernel-trace reports).  Eager issue only.  Returns (rows, kernel-us per call of fn)."""
+    from . import _lib
+    fn()
+    torch.cuda.synchronize()
+    with _lib.kernel_profile() as prof:
+        for _ in range(reps):
+            fn()
+    total = sum(r['total_us'] for r in prof.rows.values())
+    rows = [dict(kernel=k, calls_per_run=r['calls'] / reps, avg_us=r['avg_us'], us_per_run=r['total_us'] / reps,
+                 share=r['total_us'] / total)
+            for k, r in sorted(prof.rows.items(), key=lambda kv: -kv[1]['total_us'])[:top]]
+    return rows, total / reps
+
+
 def _speaker_models(device, seed=5):
     from . import synth, model
     d = synth.FULL
@@ -66,6 +83,25 @@ def speaker_decode(store, device, batch=100, words=80):
         dt = _timed(replay, 3, 10)
         out['greedy_decode' if fb == 'argmax' else 'teacher_scoring'] = dict(
             value=batch * words / dt, ms_per_batch=1e3 * dt)
+
+    def eager():
+        with torch.no_grad():
+            eng.score(b, words, 'argmax', train=False)
+    rows, us = kernel_table(eager)
+    out['kernels'] = rows
+    out['kernel_time_ms_per_batch'] = 1e-3 * us
+    # what the path executes: encoder Tp x (visual attention + gate product [B,2F+H] x [4H,2F+H]^T), decoder
+    # `words` x (recurrent product, attention over <= 7 path steps, h~, vocabulary projection)
+    d = synth.FULL
+    H, F, V = d.hidden, d.feat, d.vocab
+    Tp = int(sb.vp.shape[0])
+    flops = batch * (Tp * 2.0 * ((2 * F + H) * 4 * H + H * d.dot + d.dot * F + 2 * 36 * F)
+                     + words * 2.0 * (H * 4 * H + H * H + 2 * Tp * H + 2 * H * H + H * V))
+    ms = out['greedy_decode']['ms_per_batch']
+    out['roofline'] = dict(executed_gflop_per_batch=flops / 1e9, tflops=flops / (ms * 1e-3) / 1e12,
+                           mfma_frac=flops / (ms * 1e-3) / 1e12 / 157.3,
+                           note='executed FLOPs of one batch / hipGraph-replay time; the decoder is %d dependent word '
+                                'steps in ONE persistent launch (spk_persist_kernel): latency-, not roofline-bound' % words)
     return out
 
 
@@ -234,8 +270,14 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
                                    launch='hipGraph replay, one host sync per rollout',
                                    fraction_of_rows_that_stop=stopped)
     # (b) training iteration, sample feedback, on copies of the weights (the caller's models stay untouched)
-    import copy
-    enc2, dec2 = copy.deepcopy(enc).train(), copy.deepcopy(dec).train()
+    from . import model, synth
+    d = synth.FULL
+    enc2 = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc.embedding.weight.detach().cpu().numpy())
+    dec2 = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc2.load_state_dict(enc.state_dict())
+    dec2.load_state_dict(dec.state_dict())
+    enc2.to(device).train()
+    dec2.to(device).train()
     pe = [p for p in enc2.parameters() if p.requires_grad]
     pd = [p for p in dec2.parameters() if p.requires_grad]
     flat = dp.FlatGrads(pe + pd)

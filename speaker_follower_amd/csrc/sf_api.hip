@@ -1056,17 +1056,31 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
                             const sf_decoder_gtape* gtape, const float* gscale, float* dlogit,
                             float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
                             int* result_in_b, void* ws, size_t ws_bytes, sf_stream stream) {
+    return sf_follower_episode_bwd_range(w, e, gtape, gscale, dlogit, dh_a, dc_a, dh_b, dc_b, dctx, result_in_b,
+                                         0, e ? e->S : 0, nullptr, nullptr, ws, ws_bytes, stream);
+}
+
+int sf_follower_episode_bwd_range(const sf_decoder_w* w, const sf_follower_episode* e,
+                                  const sf_decoder_gtape* gtape, const float* gscale, float* dlogit,
+                                  float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
+                                  int* result_in_b, int t_lo, int t_hi, const float* dh_in, const float* dc_in,
+                                  void* ws, size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && e && gtape && gscale && dlogit && dh_a && dc_a && dh_b && dc_b && result_in_b &&
-                 e->S > 0 && e->B > 0);
+                 e->S > 0 && e->B > 0 && 0 <= t_lo && t_lo < t_hi && t_hi <= e->S &&
+                 (t_hi == e->S || (dh_in && dc_in)) && (!dh_in) == (!dc_in));
     const sf_dropout* drop = e->drop.p > 0.f ? &e->drop : nullptr;
     const size_t BH = (size_t)e->B * e->H;
     sf_decoder_gtape gt_all = *gtape;          // the deferred context gradient only where it is covered
     if (!(gt_all.dcat2 && gt_all.ds && dctx && ctx_grad_supported(e->S, e->L, e->H)))
         gt_all.dcat2 = gt_all.ds = nullptr;
     gtape = &gt_all;
-    const float *dh1 = nullptr, *dc1 = nullptr;
+    const float *dh1 = dh_in, *dc1 = dc_in;           // gradient arriving from step t_hi (null: the last step)
     float *dho = dh_a, *dco = dc_a, *dhn = dh_b, *dcn = dc_b;
+    if (dh_in == dh_a) {                              // a chained call: the first output must not be its own input
+        std::swap(dho, dhn);
+        std::swap(dco, dcn);
+    }
     // Software-pipelined over two streams when the caller gives a side stream and per-step dh1d
     // storage: the heads (scoring / text-attention backward, ~45 us of small dependent launches per
     // step) run ahead on the side stream, the tails (LSTM / visual backward, ~65 us) follow on the main
@@ -1084,7 +1098,10 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
         // two disjoint regions of the one workspace; both keep the real ticket region
         Arena tail_ar{(float*)ws, usable - head_n, 0, whole.tk};
         Arena head_ar{(float*)ws + (usable - head_n), head_n, 0, whole.tk};
-        if (hipEventRecord(ev[e->S], main_st) != hipSuccess || hipStreamWaitEvent(side_st, ev[e->S], 0) != hipSuccess)
+        // (only the first chunk orders the side stream behind the caller's stream -- the forward pass; the heads
+        // of a later chunk need nothing from the tails of the chunk before it and keep running ahead)
+        if (t_hi == e->S &&
+            (hipEventRecord(ev[e->S], main_st) != hipSuccess || hipStreamWaitEvent(side_st, ev[e->S], 0) != hipSuccess))
             return SF_ERR_LAUNCH;
         // ALL heads are issued first (they depend on nothing the tails produce), each followed by
         // its event; then the tails, each behind the event of its head.  (Measured on MI355X: work of
@@ -1092,7 +1109,7 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
         // 0.73 ms chain of recurrent steps beside 0.87 ms of gate products takes 1.35 ms, beside
         // chip-filling library GEMMs the plain sum, stream priority changes nothing -- so the gain of
         // the second stream is the small kernels of the heads filling the gaps of the tails.)
-        for (int t = e->S - 1; t >= 0; --t) {
+        for (int t = t_hi - 1; t >= t_lo; --t) {
             StepView v = step_view(e, t);
             const sf_decoder_gtape g = gtape_view(gtape, e, t);
             const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
@@ -1100,7 +1117,7 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
                                    g.dh1d, dctx, head_ar, side_st, &ce));
             if (hipEventRecord(ev[t], side_st) != hipSuccess) return SF_ERR_LAUNCH;
         }
-        for (int t = e->S - 1; t >= 0; --t) {
+        for (int t = t_hi - 1; t >= t_lo; --t) {
             StepView v = step_view(e, t);
             const sf_decoder_gtape g = gtape_view(gtape, e, t);
             const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
@@ -1114,7 +1131,7 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
             std::swap(dco, dcn);
         }
     } else {
-        for (int t = e->S - 1; t >= 0; --t) {
+        for (int t = t_hi - 1; t >= t_lo; --t) {
             StepView v = step_view(e, t);
             const sf_decoder_gtape g = gtape_view(gtape, e, t);
             const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
@@ -1132,7 +1149,7 @@ int sf_follower_episode_bwd(const sf_decoder_w* w, const sf_follower_episode* e,
         }
     }
     *result_in_b = (dh1 == dh_b) ? 1 : 0;
-    if (gtape->dcat2 && gtape->ds && dctx)     // the deferred context gradient, once for the episode
+    if (gtape->dcat2 && gtape->ds && dctx && t_lo == 0)     // the deferred context gradient, once for the episode
         TRY(ctx_grad_accum(e->tape.alpha, gtape->ds, gtape->dcat2, 2 * e->H, e->tape.t_text, e->S, e->B,
                            e->L, e->H, dctx, S(stream)));
     return SF_OK;

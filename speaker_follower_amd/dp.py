@@ -7,10 +7,16 @@ non-ignored rows of the WHOLE batch, follower.py:278,481).  So exactly two excha
 
   1. `allreduce_step_counts`: the [steps, 2] (sum of CE terms, live-row count) table -- a few
      hundred bytes -- so every rank scales its loss by the global denominator;
-  2. `FlatGrads.allreduce`: ONE sum all-reduce of the flat fp32 gradient buffer (56 MB for the
-     follower's 14.06 M trainable parameters) between backward() and Adam.step().  xGMI is
-     point-to-point, so one large buffer (which RCCL splits over all 7 links) beats many
-     per-tensor calls.
+  2. the gradient sum between backward() and Adam.step() (follower.py:1014-1018) over ONE flat fp32
+     buffer (56 MB for the follower's 14.06 M trainable parameters; xGMI is point-to-point, so a few
+     large messages that RCCL splits over all 7 links beat many per-tensor calls):
+       * `FlatGrads.allreduce`     -- one blocking all-reduce of the whole buffer, or
+       * `BucketedGrads`           -- the buffer laid out in PRODUCTION order of the backward (decoder
+         LSTM weights first: 40 MB, formed by the first products of sf_attn_decoder_wgrad; the other
+         decoder weights; the encoder last) and each bucket's all-reduce launched (async) from the
+         backward as soon as the launches that complete it are issued, so that the 40 MB bucket
+         travels while the rest of the weight gradients and the encoder's backward through time
+         (0.4 ms of dependent launches) still run; `wait()` before the optimizer.
 
 Gradients are SUMMED, not averaged: each rank's loss already carries the global normaliser.
 """
@@ -76,6 +82,64 @@ class FlatGrads:
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         return self.flat
+
+
+class BucketedGrads(FlatGrads):
+    """FlatGrads whose buffer is a sequence of buckets in the order the backward completes them.
+
+    `launch(b)` must be called with the CURRENT stream being the one the launches that complete
+    bucket b were issued on: torch's process group orders the collective behind that stream's work
+    and runs it on its own communication stream; `wait()` orders the current stream behind every
+    collective launched since the last wait (call it before optimizer.step()).  World size 1: both
+    are no-ops."""
+
+    def __init__(self, buckets, group=None):
+        buckets = [[p for p in b if p.requires_grad] for b in buckets]
+        buckets = [b for b in buckets if b]
+        super().__init__([p for b in buckets for p in b])
+        self.group = group
+        self.bounds, off = [], 0
+        for b in buckets:
+            n = sum(p.numel() for p in b)
+            self.bounds.append((off, off + n))
+            off += n
+        self._works = []
+        self.launched = []
+
+    @property
+    def n_buckets(self):
+        return len(self.bounds)
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def launch(self, b):
+        if b in self.launched:
+            raise RuntimeError('bucket %d launched twice before wait()' % b)
+        self.launched.append(b)
+        if self._active():
+            lo, hi = self.bounds[b]
+            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
+                                               async_op=True))
+
+    def wait(self):
+        if sorted(self.launched) != list(range(self.n_buckets)):
+            missing = sorted(set(range(self.n_buckets)) - set(self.launched))
+            self.launched = []
+            raise RuntimeError('gradient buckets %s were never launched: the backward did not run to the end' % missing)
+        for w in self._works:
+            w.wait()
+        self._works, self.launched = [], []
+        return self.flat
+
+
+def follower_buckets(encoder, decoder):
+    """The follower's trainable parameters in the order FollowerEngine._backward completes their gradients:
+    [decoder LSTM (weight_ih 35.7 MB, weight_hh, biases)], [the other decoder weights], [encoder]."""
+    lstm = list(decoder.lstm.parameters())
+    ids = {id(p) for p in lstm}
+    rest = [p for p in decoder.parameters() if id(p) not in ids]
+    return [lstm, rest, list(encoder.parameters())]
 
 
 def allreduce_gradients(params, group=None):

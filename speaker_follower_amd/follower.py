@@ -127,6 +127,13 @@ class FollowerEngine:
         self.dropout_seed = None
         self.two_stream_backward = True  # heads of the backward on a side stream (see sf_follower_episode_bwd)
         self._side_stream = None
+        # BPTT in this many chunks with the weight-gradient products of finished chunks on a third stream.
+        # Correct (tests/test_gpu_follower.py) and SLOWER on MI355X: 5.25 ms per iteration with one product
+        # over all S*B rows at the end, 5.49 with 2 or 4 chunks, 5.7 with 10 (tools/train_time.py) -- a
+        # chip-filling product does not hide beside the dependent chain, it delays it.  Off (1).
+        self.wgrad_chunks = 1
+        self.grad_sync = None            # dp.BucketedGrads(dp.follower_buckets(enc, dec)): all-reduce launched from the backward
+        self._wgrad_stream = None
         # model.decoder_fold for no-grad eval rollouts (folded Linears + the folded paired schedule of
         # sf_attn_decoder_tail_fwd).  Correct (tests/test_gpu_follower.py) but SLOWER on MI355X: the two
         # folded [2176 x 512] products read 4.4 MB of weights each and take 11.6 us, the four unfolded
@@ -459,10 +466,34 @@ class FollowerEngine:
                 ep.side_stream = self._side_stream.cuda_stream
             else:
                 ep.side_stream = None
+            # Backpropagation through time in chunks of steps: the weight-gradient products of a finished
+            # chunk (matrix-core work over its stacked rows, accumulated in place) run on a third stream
+            # while the earlier steps are still being walked (dependent, latency-bound launches that leave
+            # most of the chip idle); only the last chunk's products are left for the end, beside the
+            # encoder's backward.  `wgrad_chunks = 1` is the round-2 schedule (one product over all S*B rows).
+            overlap_w = (self.wgrad_chunks > 1 and ep.side_stream is not None and S >= 2 * self.wgrad_chunks)
+            n_chunks = self.wgrad_chunks if overlap_w else 1
+            bounds = [(S * k) // n_chunks for k in range(n_chunks + 1)]
             which = C.c_int(0)
-            call('sf_follower_episode_bwd', byref(dw), byref(ep), byref(gt0e), ptr(gscale), ptr(dlogit),
-                 ptr(dh_a), ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(which), *ws)
-            dh1, dc1 = (dh_b, dc_b) if which.value else (dh_a, dc_a)
+            tp_at = lambda t: _lib.DecoderTape(*(st.tape[k][t:].data_ptr() for k in _TAPE_KEYS))          # noqa: E731
+            gt_at = lambda t: _lib.DecoderGTape(*(gt[k][t:].data_ptr() for k in gkeys), None, None, None)  # noqa: E731
+            if overlap_w and self._wgrad_stream is None:
+                self._wgrad_stream = torch.cuda.Stream(device=dev)
+            st.wgrad_done_from = S                   # steps >= this have their weight gradients issued
+            for k in range(n_chunks - 1, -1, -1):
+                lo, hi = bounds[k], bounds[k + 1]
+                call('sf_follower_episode_bwd_range', byref(dw), byref(ep), byref(gt0e), ptr(gscale), ptr(dlogit),
+                     ptr(dh_a), ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(which), lo, hi,
+                     ptr(dh1), ptr(dc1), *ws)
+                dh1, dc1 = (dh_b, dc_b) if which.value else (dh_a, dc_a)
+                if overlap_w and k > 0:
+                    wst = self._wgrad_stream
+                    wst.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(wst):
+                        tpk, gtk = tp_at(lo), gt_at(lo)
+                        call('sf_attn_decoder_wgrad', byref(dw), byref(dg), (hi - lo) * B, H, D, F, ptr(st.hs[lo:]),
+                             byref(tpk), byref(gtk), *ws_args(dev))
+                    st.wgrad_done_from = lo
         for t in range(S - 1 if st.episode is None else -1, -1, -1):
             pano = store.pano(batch.vp[t], batch.view[t])
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
@@ -475,27 +506,47 @@ class FollowerEngine:
                  ptr(dh1), ptr(dc1), ptr(dh_a), ptr(dc_a), ptr(dctx), d_ptr, st.site0 + t, *ws)
             dh1, dc1 = dh_a, dc_a
             dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
+        # data parallelism: dp.BucketedGrads laid out as dp.follower_buckets -- each bucket's all-reduce is
+        # launched from here, behind the launches that complete it
+        sync = self.grad_sync
+        # rows whose weight gradients are still to be formed: all of them, or the first chunk's
+        Sw = getattr(st, 'wgrad_done_from', S) if st.episode is not None else S
         tp0 = _lib.DecoderTape(*(st.tape[k].data_ptr() for k in _TAPE_KEYS))
         gt0 = _lib.DecoderGTape(*(gt[k].data_ptr() for k in gkeys), None, None, None)
-        # the decoder's weight gradients (a few large products over the S*B stacked rows: matrix-core
+        # the decoder's weight gradients (a few large products over the stacked rows: matrix-core
         # work) and the encoder's backward through time (80 dependent, latency-bound steps) are
         # independent: issued on two streams they overlap
         overlap = self.two_stream_backward and not torch.cuda.is_current_stream_capturing()
         if overlap:
-            if self._side_stream is None:
-                self._side_stream = torch.cuda.Stream(device=dev)
-            side = self._side_stream
+            side = self._wgrad_stream if (st.episode is not None and Sw < S) else self._side_stream
+            if side is None:
+                side = self._side_stream = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
-                     byref(gt0), *ws_args(dev))
+                self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws_args(dev), sync)
         else:
-            call('sf_attn_decoder_wgrad', byref(dw), byref(dg), S * B, H, D, F, ptr(st.hs), byref(tp0),
-                 byref(gt0), *ws)
+            self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws, sync)
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
         ew, eg = _encoder_structs(enc), _encoder_structs(enc, grad=True)
         call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
              ptr(st.h_init), ptr(dctx), ptr(dh1), ptr(dc1), byref(etp), dropout_arg(*st.drop_enc),
              st.site0, *ws)
+        if sync is not None:
+            sync.launch(2)                       # encoder gradients: complete behind sf_encoder_lstm_bwd
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
+
+    @staticmethod
+    def _decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws, sync):
+        """sf_attn_decoder_wgrad on the current stream.  With a gradient-bucket sync the LSTM products (the
+        40 MB bucket) are issued first and their all-reduce launched behind them, then the other products."""
+        if sync is None:
+            call('sf_attn_decoder_wgrad', byref(dw), byref(dg), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
+            return
+        g_lstm, g_rest = _lib.DecoderW(), _lib.DecoderW()
+        g_lstm.lstm = dg.lstm
+        g_rest.visual, g_rest.text, g_rest.action = dg.visual, dg.text, dg.action
+        call('sf_attn_decoder_wgrad', byref(dw), byref(g_lstm), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
+        sync.launch(0)
+        call('sf_attn_decoder_wgrad', byref(dw), byref(g_rest), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
+        sync.launch(1)

@@ -35,6 +35,23 @@ def test_launcher_is_chosen_only_without_world_size(monkeypatch):
     assert calls == [(2, ['--gpus', '2', '--steps', '1'])]
 
 
+def test_plan_prints_the_eight_rank_launch_without_touching_a_gpu(capsys, monkeypatch):
+    """`bench.py --gpus 8 --plan`: the child commands and their rendezvous environment as JSON -- what the first
+    8-GPU run will start, reviewable on a box with no GPU at all."""
+    import json
+    monkeypatch.delenv('WORLD_SIZE', raising=False)
+    monkeypatch.setattr(bench, 'run_launcher', lambda *a: (_ for _ in ()).throw(AssertionError('must not launch')))
+    bench.main(['--gpus', '8', '--plan', '--steps', '5'])
+    d = json.loads(capsys.readouterr().out)
+    assert d['launcher'] == 'self' and d['collective'] == 'RCCL over xGMI' and len(d['ranks']) == 8
+    ports = {r['env']['MASTER_PORT'] for r in d['ranks']}
+    assert len(ports) == 1
+    for i, r in enumerate(d['ranks']):
+        assert r['cmd'][1].endswith('bench.py') and '--plan' not in r['cmd'] and r['cmd'][-2:] == ['--steps', '5']
+        assert r['env']['RANK'] == r['env']['LOCAL_RANK'] == str(i) and r['env']['WORLD_SIZE'] == '8'
+        assert r['env']['MASTER_ADDR'] == '127.0.0.1' and r['env']['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+
+
 def test_launcher_returns_first_failure_and_stops_the_rest(monkeypatch):
     """Children are plain processes: a failing rank ends the run with its exit code and the other
     ranks are terminated by PID (never by pattern)."""

@@ -170,3 +170,6 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert abs(d['value'] - 2 * 16 * 5 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
     t = d['train_dp']
     assert t['allreduce_ms'] > 0 and t['allreduce_bytes'] == 4 * 14059265 and np.isfinite(t['loss'])
+    # the bucketed schedule: decoder LSTM (weight_ih, weight_hh, two biases), other decoder weights, encoder
+    assert t['buckets_bytes'] == [4 * (2048 * 4352 + 2048 * 512 + 4096), 4 * (12129537 - 2048 * 4864 - 4096), 4 * 1929728]
+    assert t['allreduce_exposed_ms_overlapped'] >= 0 and t['ms_per_iteration_no_exchange'] > 0

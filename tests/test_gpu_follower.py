@@ -177,6 +177,36 @@ def test_engine_teacher_gradients_golden(follower_modules, batch8, golden, case,
         m.zero_grad(set_to_none=True)
 
 
+@pytest.mark.parametrize('chunks', [2, 4])
+def test_chunked_backward_through_time_matches_the_reference_gradients(follower_modules, golden, chunks):
+    """sf_follower_episode_bwd_range: BPTT in chunks of steps with the weight gradients of finished chunks
+    accumulated from a third stream (FollowerEngine.wgrad_chunks) gives the reference's gradients (G4, B=100,
+    20 steps) and, to summation order, those of the one-product schedule."""
+    enc, dec, _, _ = follower_modules
+    fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=256)
+    table = synth.feature_table(0, 256)
+    g = golden('g4_rollout_b100_teacher')
+    engine, follower = _engine(follower_modules, table)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    grads = {}
+    for n_chunks in (1, chunks):
+        engine.wgrad_chunks = n_chunks
+        for m in (enc, dec):
+            m.zero_grad(set_to_none=True)
+        st = engine.rollout(batch, int(g['n_steps']), 'teacher', train=False)
+        st.loss.backward()
+        torch.cuda.synchronize()
+        grads[n_chunks] = {k: p.grad.clone() for m, pre in ((enc, 'enc/'), (dec, 'dec/'))
+                           for k, p in ((pre + k, p) for k, p in m.named_parameters()) if p.grad is not None}
+    _check_grads({k[4:]: v for k, v in grads[chunks].items() if k.startswith('enc/')}, g, 'enc/')
+    _check_grads({k[4:]: v for k, v in grads[chunks].items() if k.startswith('dec/')}, g, 'dec/')
+    for k, a in grads[1].items():
+        scale = float(a.abs().max())
+        assert float((a - grads[chunks][k]).abs().max()) <= 2e-5 * max(scale, 1e-6), k
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+
+
 def test_module_api_teacher_gradients_match_engine(follower_modules, batch8):
     """The per-step nn.Module path (autograd Functions) and the fused engine agree."""
     enc, dec, _, _ = follower_modules

@@ -140,6 +140,54 @@ def test_data_parallel_gradient_and_count_allreduce_gloo_world2():
         assert attached and raised
 
 
+def _bucket_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from speaker_follower_amd import dp
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.manual_seed(0)
+    dec_lstm, dec_rest, enc = torch.nn.Linear(8, 6), torch.nn.Linear(5, 3), torch.nn.Linear(4, 2)
+    frozen = torch.nn.Parameter(torch.zeros(3), requires_grad=False)
+    bk = dp.BucketedGrads([list(dec_lstm.parameters()), list(dec_rest.parameters()) + [frozen], list(enc.parameters())])
+    one = dp.FlatGrads([torch.nn.Parameter(torch.zeros(bk.flat.numel()))])
+    g = torch.Generator().manual_seed(100 + rank)
+    vals = torch.randn(bk.flat.numel(), generator=g)
+    bk.flat.copy_(vals)                       # "backward": the kernels accumulate into the views
+    one.flat.copy_(vals)
+    # production order of the backward: decoder LSTM, other decoder weights, encoder
+    for b in range(bk.n_buckets):
+        bk.launch(b)
+    bk.wait()
+    one.allreduce()
+    again = None
+    try:
+        bk.launch(0)
+        bk.wait()                             # buckets 1, 2 never launched: the optimizer must not run
+    except RuntimeError as e:
+        again = 'never launched' in str(e)
+    out[rank] = (bk.flat.clone(), one.flat.clone(), bk.bounds, bk.attached(), again,
+                 dec_lstm.weight.grad.data_ptr() == bk.flat.data_ptr())
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_allreduce_equals_single_buffer_gloo_world2():
+    """dp.BucketedGrads: buckets laid out in production order, each reduced by its own async all-reduce,
+    give bit for bit the sum one all-reduce of the whole buffer gives; a backward that did not reach
+    every bucket is refused at wait()."""
+    import torch.multiprocessing as mp
+    world = 2
+    port = 31500 + os.getpid() % 2000
+    out = mp.Manager().dict()
+    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    for r in range(world):
+        bucketed, single, bounds, attached, refused, first = out[r]
+        assert torch.equal(bucketed, single)
+        assert bounds == [(0, 54), (54, 72), (72, 82)]            # 8*6+6 | 5*3+3 | 4*2+2
+        assert attached and refused and first
+    assert torch.equal(out[0][0], out[1][0])
+
+
 def test_feature_store_reads_reference_tsv_format(tmp_path):
     """N4: the ResNet TSV of the reference (env.py:359-370: scanId, viewpointId, image_w, image_h,
     vfov, base64 fp32 36x2048) -> table + id index."""
