@@ -94,6 +94,13 @@ def test_step_losses_global_normaliser_equals_unsharded_mean():
     np.testing.assert_allclose(float(loss2), want, rtol=1e-6)
 
 
+def _free_port():
+    import socket
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        return sk.getsockname()[1]
+
+
 def _dp_worker(rank, world, port, out):
     import torch.distributed as dist
     from speaker_follower_amd import dp
@@ -128,7 +135,7 @@ def _dp_worker(rank, world, port, out):
 def test_data_parallel_gradient_and_count_allreduce_gloo_world2():
     import torch.multiprocessing as mp
     world = 2
-    port = 29500 + os.getpid() % 2000
+    port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
     mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
@@ -177,7 +184,7 @@ def test_bucketed_gradient_allreduce_equals_single_buffer_gloo_world2():
     every bucket is refused at wait()."""
     import torch.multiprocessing as mp
     world = 2
-    port = 31500 + os.getpid() % 2000
+    port = _free_port()
     out = mp.Manager().dict()
     mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
     for r in range(world):
