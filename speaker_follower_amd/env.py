@@ -213,8 +213,11 @@ class R2RIndexEnv:
         return [self._observe_one(ws, item, include_teacher, dense)
                 for ws, item in zip(world_states, self.batch)]
 
-    def _observe_one(self, ws, item, include_teacher, dense):
-        view, adj = self.panorama(ws)
+    def _observe_one(self, ws, item, include_teacher, dense, view=None):
+        """`view`: the state's view index when the caller knows it (a discretised pose): the sweep cache is then
+        consulted without waking the simulator."""
+        hit = self._pano.get((ws.scanId, ws.viewpointId, view)) if view is not None else None
+        view, adj = hit if hit is not None else self.panorama(ws)
         ob = dict(instr_id=item['instr_id'], scan=ws.scanId, viewpoint=ws.viewpointId,
                   viewIndex=view, heading=ws.heading, elevation=ws.elevation,
                   adj_loc_list=adj, vp_row=self.row_of[ws.scanId + '_' + ws.viewpointId],

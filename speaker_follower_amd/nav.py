@@ -86,8 +86,12 @@ class NavTable:
         dev = store.device
         up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(device=dev, dtype=dt)   # noqa: E731
         self.a_num, self.next_row, self.cand_view = up(a_num, torch.int32), up(next_row, torch.int32), up(cand_view, torch.int32)
-        self.sincos = up(cand_sincos(head, elev), torch.float32)          # the same host sin/cos the env batches use
+        sincos = cand_sincos(head, elev).astype(np.float32)               # the same host sin/cos the env batches use
+        self.sincos = up(sincos, torch.float32)
         self.feat_row = up(feat_row, torch.int32)
+        # host copies: the search procedures (search.py) expand states by integer table look-ups
+        self.host = dict(a_num=a_num, next_row=next_row, cand_view=cand_view, sincos=sincos, feat_row=feat_row,
+                         heading=head, elevation=elev)
         self.n_rows, self.device, self.env = n, dev, env
         self._hops = {}
 
@@ -210,3 +214,13 @@ class DeviceNavBatch:
                     break
             out.append(tr)
         return out
+
+
+def table_for(env, store):
+    """The NavTable of `env`'s graphs over `store`, built once per (env, store) pair."""
+    cached = getattr(env, '_nav_table', None)
+    if cached is None or cached[0] is not store or cached[2] != tuple(sorted(env.graphs)):
+        from .build import build_sim
+        build_sim(verbose=False)
+        env._nav_table = (store, NavTable(env, store), tuple(sorted(env.graphs)))
+    return env._nav_table[1]
