@@ -589,12 +589,21 @@ def main(argv=None):
         if not train:
             n = len(ref['logits'])
             same = bool(np.array_equal(st.actions.cpu().numpy()[:n], ref['actions']))
-            out['parity_vs_cpu_port'] = dict(actions_bit_exact=same,
-                                             loss_abs_diff=abs(float(st.loss_buf) - float(ref['loss'])))
+            lg = st.logits.cpu().numpy()
+            worst = 0.0
+            for t_ in range(n):
+                a_ = ref['logits'][t_].shape[1]
+                fin = np.isfinite(ref['logits'][t_])
+                worst = max(worst, float(np.abs(lg[t_][:, :a_][fin] - ref['logits'][t_][fin]).max()))
+            out['parity_vs_cpu_port'] = dict(actions_bit_exact=same, loss_gpu=float(st.loss_buf), loss_cpu_port=float(ref['loss']),
+                                             loss_abs_diff=abs(float(st.loss_buf) - float(ref['loss'])),
+                                             max_abs_logit_diff=worst, max_abs_logit=float(np.abs(lg[np.isfinite(lg)]).max()),
+                                             weights='synth.follower_weights_peaky (logit std ~1.4)')
     # ---- extras (not `value`), N = 1: the other BASELINE configs on this GPU
     if extras and not train and world == 1:
         from speaker_follower_amd import bench_extras
-        out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2]
+        out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2], one batch
+        out['speaker_sweep'] = bench_extras.speaker_sweep(store, device)            # configs[2], 2000 distinct paths
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
         if os.path.exists(_lib.EXP_LIB_PATH):      # frozen experiment, only when its library was built on demand
             out['persistent_decode_experiment'] = bench_extras.persistent_decode(enc, dec, store, batch, S)

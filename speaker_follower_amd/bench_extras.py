@@ -106,6 +106,36 @@ def speaker_decode(store, device, batch=100, words=80):
 
 
 @_guard
+def speaker_sweep(store, device, n_paths=2000, batch=100, words=80):
+    """configs[2] as the reference runs it (data_augmentation_from_speaker.py:56-58: Seq2SeqSpeaker.test with argmax
+    feedback over the 178 300 sampled trajectories, one minibatch after the other): `n_paths` DISTINCT synthetic
+    paths (4-7 steps, ragged inside every minibatch) in minibatches of `batch`; host packing and upload of every
+    index batch, greedy decoding of `words` words, and the D2H copy of the generated word ids are all inside the
+    timed region.  The 178 300-path figure is this measured rate extrapolated, and labelled so."""
+    from . import synth, speaker
+    enc, dec = _speaker_models(device)
+    n_vp = store.table.shape[0]
+    sbs = [synth.speaker_batch(seed=500 + i, batch=batch, n_viewpoints=n_vp, min_path=4, max_path=7, min_len=10,
+                               max_len=79) for i in range(n_paths // batch)]
+    eng = speaker.SpeakerEngine(enc, dec, store)
+
+    def sweep():
+        out = []
+        with torch.no_grad():
+            for sb in sbs:
+                st = eng.score(speaker.DeviceSpeakerBatch.from_synth(sb, device=device), words, 'argmax', train=False)
+                out.append(st.words[1:].cpu())                       # the generated instructions leave the device
+        return out
+    dt = _timed(sweep, 1, 2)
+    n = len(sbs) * batch
+    return dict(what='greedy speaker decoding of %d distinct paths (4-7 steps) x %d words in minibatches of %d, eager issue: '
+                     'host packing + upload + decode + D2H of the words per minibatch' % (n, words, batch),
+                value=n / dt, unit='paths/s', seconds=dt, ms_per_minibatch=1e3 * dt / len(sbs),
+                extrapolated_seconds_for_178300_paths=178300 * dt / n,
+                note='the last field is an extrapolation of the measured rate, not a measurement')
+
+
+@_guard
 def search_full(conn_dir, device, scans=('YmJkqBEsHnH', 'gZ6f7yhEvPG', 'GdvgFV5R1Z5'), instances=64, k=40,
                 episode_len=8):
     """configs[4] end to end on real connectivity graphs: Seq2SeqAgent.state_factored_search(K = 40, 1)
@@ -235,7 +265,9 @@ def full_world(store, batch=100, seed=21):
         items = env.random_items(graphs, batch, np.random.default_rng(seed), min_len=10, max_len=79)
         e = env.R2RIndexEnv(items, row_of, conn, batch_size=batch)
         e.graphs = graphs                       # all 90 (already parsed: the objects the items were drawn from)
-        _FULL_WORLD[key] = (e, nav.NavTable(e, store))
+        nt = nav.NavTable(e, store)
+        e._nav_table = (store, nt, tuple(sorted(e.graphs)))        # what nav.table_for(e, store) hands the search
+        _FULL_WORLD[key] = (e, nt)
     return _FULL_WORLD[key]
 
 
@@ -300,6 +332,24 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
         st = it()
     torch.cuda.synchronize()
     dtt = (time.perf_counter() - t1) / train_iters
+    # (c) configs[4] on the same world: state-factored search K = 40 over a minibatch of 64 instructions
+    from . import agents
+    e64, _ = full_world(store, 64, seed=15)
+    agent = agents.Seq2SeqAgent(e64, '/tmp/sf_bench_search_full.json', enc, dec, episode_len=8)
+    agent.store = store
+    e64.set_beam_size(40)
+    best = None
+    for _ in range(3):
+        e64.reset_epoch()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        with torch.no_grad():
+            trajs, _, _ = agent.state_factored_search(40, 1)
+        torch.cuda.synchronize()
+        d2 = time.perf_counter() - t2
+        best = d2 if best is None else min(best, d2)
+    out['state_factored_search_k40_b64'] = dict(value=64 / best, unit='instructions/s', seconds=best,
+                                                candidates=sum(len(t_) for t_ in trajs), episode_len=8)
     out['train_sample_feedback'] = dict(value=batch * steps / dtt, ms_per_iteration=1e3 * dtt, iterations=train_iters,
                                         loss=float(st.loss.detach()),
                                         what='rollout with dropout 0.5 + sampled actions on the device env, BPTT, '

@@ -132,6 +132,9 @@ class FollowerEngine:
         # over all S*B rows at the end, 5.49 with 2 or 4 chunks, 5.7 with 10 (tools/train_time.py) -- a
         # chip-filling product does not hide beside the dependent chain, it delays it.  Off (1).
         self.wgrad_chunks = 1
+        # the eight small weight-gradient products on a third stream beside the two LSTM ones: measured no gain
+        # (5.29 vs 5.26 ms per iteration): off
+        self.split_wgrad_streams = False
         self.grad_sync = None            # dp.BucketedGrads(dp.follower_buckets(enc, dec)): all-reduce launched from the backward
         self._wgrad_stream = None
         # model.decoder_fold for no-grad eval rollouts (folded Linears + the folded paired schedule of
@@ -522,8 +525,20 @@ class FollowerEngine:
             if side is None:
                 side = self._side_stream = torch.cuda.Stream(device=dev)
             side.wait_stream(torch.cuda.current_stream())
+            third = None
+            if self.split_wgrad_streams:
+                # the eight small products (25 TFLOP/s between them) beside the two LSTM ones (dW_ih alone fills the chip
+                # at 0.76 of the matrix peak) instead of behind them: two streams, same accumulation targets
+                if self._wgrad_stream is None:
+                    self._wgrad_stream = torch.cuda.Stream(device=dev)
+                third = self._wgrad_stream if self._wgrad_stream is not side else self._side_stream
+                third.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
-                self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws_args(dev), sync)
+                self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws_args(dev), sync,
+                                    part='lstm' if third is not None else 'all')
+            if third is not None:
+                with torch.cuda.stream(third):
+                    self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws_args(dev), sync, part='rest')
         else:
             self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws, sync)
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
@@ -535,18 +550,25 @@ class FollowerEngine:
             sync.launch(2)                       # encoder gradients: complete behind sf_encoder_lstm_bwd
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
+            if third is not None:
+                torch.cuda.current_stream().wait_stream(third)
 
     @staticmethod
-    def _decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws, sync):
-        """sf_attn_decoder_wgrad on the current stream.  With a gradient-bucket sync the LSTM products (the
-        40 MB bucket) are issued first and their all-reduce launched behind them, then the other products."""
-        if sync is None:
+    def _decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws, sync, part='all'):
+        """sf_attn_decoder_wgrad on the current stream: `part` = 'lstm' (the two LSTM products + bias sums: the
+        40 MB gradient bucket), 'rest' (the other decoder weights) or 'all' (LSTM first).  With a gradient-bucket
+        sync each part's all-reduce is launched behind it."""
+        if sync is None and part == 'all':
             call('sf_attn_decoder_wgrad', byref(dw), byref(dg), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
             return
         g_lstm, g_rest = _lib.DecoderW(), _lib.DecoderW()
         g_lstm.lstm = dg.lstm
         g_rest.visual, g_rest.text, g_rest.action = dg.visual, dg.text, dg.action
-        call('sf_attn_decoder_wgrad', byref(dw), byref(g_lstm), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
-        sync.launch(0)
-        call('sf_attn_decoder_wgrad', byref(dw), byref(g_rest), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
-        sync.launch(1)
+        if part in ('all', 'lstm'):
+            call('sf_attn_decoder_wgrad', byref(dw), byref(g_lstm), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
+            if sync is not None:
+                sync.launch(0)
+        if part in ('all', 'rest'):
+            call('sf_attn_decoder_wgrad', byref(dw), byref(g_rest), M, H, D, F, ptr(st.hs), byref(tp0), byref(gt0), *ws)
+            if sync is not None:
+                sync.launch(1)
