@@ -87,6 +87,51 @@ def test_row_shards_reproduce_the_unsharded_batch(n_shards, feedback):
         off += n
 
 
+def test_bucketed_gradient_schedule_gives_the_same_gradients():
+    """dp.BucketedGrads hooked into the backward (FollowerEngine.grad_sync): the weight-gradient call split into
+    its LSTM part and the rest, each followed by its bucket's launch, then the encoder's -- every gradient equal to
+    the plain schedule's, the three buckets launched in production order, wait() accepted; a rollout whose
+    backward never ran is refused at wait()."""
+    from speaker_follower_amd import follower, features, dp
+    B, S, NVP = 20, 6, 64
+    enc, dec = fresh_modules(11)
+    enc.train()
+    dec.train()
+    fb = synth.follower_batch(seed=4, batch=B, steps=S, n_viewpoints=NVP, min_len=4, max_len=30, a_max=9)
+    store = features.FeatureStore(synth.feature_table(4, NVP))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+
+    def run(sync):
+        eng = follower.FollowerEngine(enc, dec, store)
+        eng.dropout_seed = 777
+        eng.grad_sync = sync
+        st = eng.rollout(batch, S, 'teacher', train=True)
+        st.loss.backward()
+        torch.cuda.synchronize()
+        return float(st.loss)
+
+    plain = dp.FlatGrads([p for p in list(enc.parameters()) + list(dec.parameters()) if p.requires_grad])
+    plain.zero()
+    loss_a = run(None)
+    ref = {id(p): p.grad.clone() for p in plain.params}
+    buckets = dp.follower_buckets(enc, dec)
+    sync = dp.BucketedGrads(buckets)                    # re-points every .grad into the bucketed buffer
+    assert sync.n_buckets == 3 and [hi - lo for lo, hi in sync.bounds] == [2048 * 4864 + 4096, 12129537 - 2048 * 4864 - 4096, 1929728]
+    sync.zero()
+    loss_b = run(sync)
+    assert sync.launched == [0, 1, 2]                   # decoder LSTM, other decoder weights, encoder
+    sync.wait()
+    assert loss_a == loss_b
+    for p in sync.params:
+        scale = float(ref[id(p)].abs().max())
+        assert float((p.grad - ref[id(p)]).abs().max()) <= 1e-6 * max(scale, 1e-6)
+    # the decoder LSTM bucket is the head of the buffer
+    assert dec.lstm.weight_ih.grad.data_ptr() == sync.flat.data_ptr()
+    with pytest.raises(RuntimeError, match='never launched'):
+        sync.launch(0)
+        sync.wait()
+
+
 def test_captured_rollout_follows_weight_updates():
     """A hipGraph replay after optimizer.step() must use the NEW weights everywhere -- also through
     the cached transposed copies and the encoder's embedding x W_ih^T table (rebuilt in place)."""

@@ -95,3 +95,76 @@ def test_golden_search_file_is_consistent():
                 np.testing.assert_allclose(sum(c['scores']), c['score'], rtol=1e-5, atol=1e-5)
                 n += 1
     assert n > 50
+
+
+# ---------------------------------------------------------------- frontier.py: array form of the same logic
+class _FakeSpace:
+    """Just enough of frontier.StateSpace for Hyp views: a world state per (inst, sid)."""
+
+    def world_state(self, inst, sid, start_pose):
+        return WS('s', 'vp%d' % (int(sid) // 36), float(int(sid) % 36), 0.0)
+
+    def observation(self, inst, sid, start_pose):
+        return dict(viewpoint='vp%d' % (int(sid) // 36), heading=float(int(sid) % 36), elevation=0.0)
+
+
+def _random_tree(rng, n_nodes, n_vp):
+    from speaker_follower_amd import frontier
+    t = frontier.Hypotheses(cap=4)                       # small capacity: exercises the growth path
+    t.append(np.zeros(1, np.float32), np.ones(1, bool), parent=-1, inst=0, sid=int(rng.integers(n_vp)) * 36,
+             key=0, action=-1, count=0, pool=0)
+    while t.n < n_nodes:
+        par = int(rng.integers(t.n))
+        if t.count[par] >= 6:
+            continue
+        t.append(np.array([t.score[par] - rng.random()], np.float32), np.zeros(1, bool), parent=par, inst=0,
+                 sid=int(rng.integers(n_vp)) * 36 + int(rng.integers(36)), key=0, action=1 + int(rng.integers(3)),
+                 count=t.count[par] + 1, pool=t.n)
+    return t
+
+
+def test_array_physical_walk_equals_the_pairwise_lineage_walk():
+    """frontier.physical_walks (all instances, all pairs at once, numpy) against chaining
+    search.least_common_viewpoint_path over hypothesis views, on random hypothesis trees."""
+    from speaker_follower_amd import frontier, search
+    rng = np.random.default_rng(4)
+    space = _FakeSpace()
+    for trial in range(20):
+        t = _random_tree(rng, 60, n_vp=5)
+        root_vp = t.sid[0] // 36
+        # a visiting order that always has a shared viewpoint: every node's lineage contains the root
+        visits = [[0] + [int(x) for x in rng.integers(1, t.n, size=12)] for _ in range(3)]
+        got = frontier.physical_walks(t, visits, depth=6)
+        for seq, walk in zip(visits, got):
+            want = [frontier.Hyp(t, space, seq[0])]
+            for a, b in zip(seq, seq[1:]):
+                path = search.least_common_viewpoint_path(frontier.Hyp(t, space, a), frontier.Hyp(t, space, b))
+                # (two hypotheses standing on the same viewpoint: no movement, the path is [a] alone)
+                assert path[0].node == a and path[-1].world_state.viewpointId == frontier.Hyp(t, space, b).world_state.viewpointId
+                want += path[1:]
+            assert walk == [h.node for h in want], (trial, seq)
+        assert root_vp == t.sid[0] // 36
+
+
+def test_hypothesis_views_backchain_like_the_namedtuple_states():
+    from speaker_follower_amd import frontier, search
+    rng = np.random.default_rng(9)
+    t = _random_tree(rng, 40, n_vp=4)
+    space = _FakeSpace()
+    leaf = int(np.argmax(t.count[:t.n]))
+    states, obs, actions, scores, att = search.backchain_inference_states(frontier.Hyp(t, space, leaf))
+    lin = t.lineage(leaf)[::-1]
+    assert len(states) == len(lin) and actions == [int(t.action[n]) for n in lin[1:]]
+    assert att == [int(t.pool[n]) for n in lin[1:]]
+    np.testing.assert_allclose(scores, np.diff(t.score[lin].astype(np.float64)))
+    L, ln = frontier._lineage_matrix(t, [leaf], 6)
+    assert ln[0] == len(lin) and L[0, :ln[0]].tolist() == lin[::-1]
+
+
+def test_ragged_helpers():
+    from speaker_follower_amd import frontier
+    off, owner = frontier._ragged_arange(np.array([2, 0, 3]))
+    assert off.tolist() == [0, 1, 0, 1, 2] and owner.tolist() == [0, 0, 2, 2, 2]
+    g = np.array([0, 0, 0, 2, 2, 5])
+    assert frontier._first_k_per_group(g, 2).tolist() == [True, True, False, True, True, True]
+    assert frontier._first_k_per_group(np.zeros(0, int), 3).tolist() == []
