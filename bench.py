@@ -380,6 +380,10 @@ def main(argv=None):
 
     from speaker_follower_amd import synth, features, follower, _lib
     enc, dec, enc_w, dec_w = build_models(101, device)
+    if args.share_gpu:
+        # (test mode) several PROCESSES on one GPU: the persistent encoder launch takes every CU and its device-wide
+        # lock is per process, so two of them could starve each other into the timeout path -- per-step kernels here
+        enc.persistent = False
     B, S = args.batch, args.decode_steps
     table = device_table(args.n_viewpoints, 1234, device)
     store = features.FeatureStore(table, device=device)
