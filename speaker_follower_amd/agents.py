@@ -117,6 +117,11 @@ class Seq2SeqAgent(BaseAgent):
         self.store = None          # features.FeatureStore: enables the index-form search procedures
         self.nav_table = None      # nav.NavTable: rollouts step the environment ON THE DEVICE
         self._engine = None
+        # An environment that carries its feature store and no host copy of the table (compat.env.R2RBatch, what
+        # the reference's train.py builds through the bare-name shim) can only be walked on the device: rollouts
+        # then use nav.table_for(env, store) of whatever env is current (train.py switches agent.env between
+        # the training and the validation environments, train.py:97, 111).
+        self.auto_device_env = True
 
     def use_device_env(self, nav_table):
         """Opt in to device-resident navigation (nav.py): `_rollout_with_loss` -- and with it `train`,
@@ -131,10 +136,33 @@ class Seq2SeqAgent(BaseAgent):
         self._engine = FollowerEngine(self.encoder, self.decoder, self.store)
         self._engine.dropout_seed = self._sample_seed ^ 0x1B873593
 
-    def _rollout_on_device(self):
+    def _env_store(self):
+        """The feature store the current env was built over (compat.env.MeanPooledImageFeatures.store), if any."""
+        feats = getattr(self.env, 'image_features_list', None) or [None]
+        return getattr(feats[0], 'store', None)
+
+    def _device_table(self):
+        """The navigation table to roll out on, or None for the per-step host loop: the one given to
+        use_device_env, else (auto) the current env's own when it can only be walked on the device."""
+        if self.nav_table is not None:
+            return self.nav_table
+        if not self.auto_device_env or getattr(self.env, 'host_table', 1) is not None or not hasattr(self.env, 'graphs'):
+            return None
+        if self.store is None:
+            self.store = self._env_store()
+        if self.store is None:
+            return None
+        from .follower import FollowerEngine
+        from .nav import table_for
+        if self._engine is None:
+            self._engine = FollowerEngine(self.encoder, self.decoder, self.store)
+            self._engine.dropout_seed = self._sample_seed ^ 0x1B873593
+        return table_for(self.env, self.store)
+
+    def _rollout_on_device(self, table=None):
         from .nav import DeviceNavBatch
         self.env.reset(sort=True)
-        batch = DeviceNavBatch(self.nav_table, list(self.env.batch), self.episode_len,
+        batch = DeviceNavBatch(table if table is not None else self.nav_table, list(self.env.batch), self.episode_len,
                                max_length=self.max_instruction_length, reverse=self.reverse_instruction)
         st = self._engine.rollout(batch, self.episode_len, self.feedback, train=self.decoder.training)
         self.loss = st.loss
@@ -214,8 +242,9 @@ class Seq2SeqAgent(BaseAgent):
 
     def _rollout_with_loss(self):
         """follower.py:430-539."""
-        if self.nav_table is not None:
-            return self._rollout_on_device()
+        table = self._device_table()
+        if table is not None:
+            return self._rollout_on_device(table)
         world_states = self.env.reset(sort=True)
         obs = np.array(self.env.observe(world_states))
         B = len(obs)

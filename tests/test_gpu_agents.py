@@ -125,3 +125,83 @@ def test_speaker_agent_matches_engine():
     with torch.no_grad():
         res = spk.test(feedback='argmax')
     assert len(res) == 6
+
+
+def test_reference_style_training_loop_through_the_bare_name_shim(tmp_path):
+    """What the reference's train.py does (make_env_and_models, train_val: train.py:176-205, 263-268, 92-125),
+    written with its own statements over the compat modules: ImageFeatures-style feature holder ->
+    R2RBatch(image_features_list, batch_size=, splits=, tokenizer=) -> Seq2SeqAgent(env, "", encoder, decoder,
+    episode_len, max_instruction_length=) -> agent.train(Adam, Adam, n, feedback='sample') -> agent.env = val_env
+    -> agent.test(...) -> agent.results.  The env built this way carries the feature store and no host table, so
+    the agent walks it on the device by itself (one host sync per rollout)."""
+    import json
+    import os
+    import sys
+    from torch import optim
+    from speaker_follower_amd import compat, features
+    sys.path.insert(0, compat.path())
+    try:
+        for name in ('env', 'model', 'follower'):
+            sys.modules.pop(name, None)
+        from env import R2RBatch                                   # train.py:14
+        from model import EncoderLSTM, AttnDecoderLSTM             # train.py:15
+        from follower import Seq2SeqAgent                          # train.py:16
+        import env as cenv
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        conn = os.path.join(root, 'tests', 'golden', 'connectivity')
+        scans = ['gZ6f7yhEvPG', 'YmJkqBEsHnH', 'GdvgFV5R1Z5']
+        graphs = {s: cenv.NavGraph(os.path.join(conn, s + '_connectivity.json')) for s in scans}
+        rng = np.random.default_rng(12)
+        for split, n in (('train', 24), ('val_seen', 12)):
+            items = cenv.random_items(graphs, n, rng, min_len=4, max_len=12)
+            data = [dict(path_id=1000 * (split == 'train') + i, scan=it['scan'], heading=it['heading'], path=it['path'],
+                         distance=1.0, instructions=[' '.join('w%d' % t for t in it['instr_encoding'])])
+                    for i, it in enumerate(items)]
+            (tmp_path / ('R2R_%s.json' % split)).write_text(json.dumps(data))
+
+        class Tok:                                                 # utils.Tokenizer.encode_sentence (utils.py:92-105)
+            def encode_sentence(self, s):
+                enc = np.array([int(w[1:]) for w in s.split()])
+                return enc, len(enc)
+
+        ids = [s + '_' + v for s in scans for v in graphs[s].ids]
+
+        class Feats:                                               # MeanPooledImageFeatures: .store + get_name()
+            store = features.FeatureStore(synth.feature_table(3, len(ids)), ids=ids)
+
+            def get_name(self):
+                return 'imagenet_mean_pooled'
+
+        d = synth.FULL
+        mk = lambda splits: R2RBatch([Feats()], batch_size=12, splits=splits, tokenizer=Tok(), nav_graph_path=conn,   # noqa: E731
+                                     data_json=str(tmp_path / 'R2R_%s.json'))
+        train_env, val_env = mk(['train']), mk(['val_seen'])
+        enc_w, dec_w = synth.follower_weights_peaky(5)
+        encoder = EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight']).cuda()
+        decoder = AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat).cuda()
+        agent = Seq2SeqAgent(train_env, "", encoder, decoder, 6, max_instruction_length=80)
+        filt = lambda ps: [p for p in ps if p.requires_grad]       # noqa: E731  train.py:64-65
+        eo = optim.Adam(filt(agent.encoder.parameters()), lr=1e-4, weight_decay=5e-4)
+        do = optim.Adam(filt(agent.decoder.parameters()), lr=1e-4, weight_decay=5e-4)
+        agent.train(eo, do, 3, feedback='sample')                  # train.py:100-101
+        assert len(agent.losses) == 3 and all(np.isfinite(agent.losses))
+        assert agent.nav_table is None and agent._engine is not None      # walked on the device, by itself
+        agent.env = val_env                                        # train.py:111
+        agent.test(use_dropout=True, feedback='sample', allow_cheat=True)
+        assert len(agent.losses) >= 1
+        agent.results_path = str(tmp_path / 'val_seen.json')
+        agent.test(use_dropout=False, feedback='argmax')           # train.py:123
+        agent.write_results()
+        res = json.load(open(agent.results_path))
+        assert sorted(res) == sorted(it['instr_id'] for it in val_env.data)
+        for r in res.values():                                     # trajectories stay on the graph
+            g = graphs[next(it['scan'] for it in val_env.data if it['instr_id'] == r['instr_id'])]
+            vps = [p[0] for p in r['trajectory']]
+            assert all(b == a or b in g.adj[a] for a, b in zip(vps, vps[1:]))
+        base = str(tmp_path / 'snap')
+        agent.save(base)                                           # follower.py:1022-1035
+        assert all(os.path.exists(p) for p in agent._encoder_and_decoder_paths(base))
+    finally:
+        sys.path.remove(compat.path())
+        for name in ('env', 'model', 'follower', 'speaker'):
+            sys.modules.pop(name, None)
