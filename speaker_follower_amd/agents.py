@@ -448,10 +448,66 @@ class Seq2SeqSpeaker(object):
         return ([obs[0] for obs in path_obs], [to(f) for f in feats], [to(a) for a in acts],
                 to(mask), list(seq_lengths), encoded_instructions, list(range(B)))
 
+    def _env_store(self):
+        feats = getattr(self.env, 'image_features_list', None) or [None]
+        return getattr(feats[0], 'store', None) or getattr(self, 'store', None)
+
+    def _score_on_device(self, path_obs, path_actions, encoded_instructions, feedback, store):
+        """The same scoring over INDEX-FORM observations (no 'feature' / 'action_embedding' rows: an env that
+        carries its feature store): the fused speaker engine (speaker.SpeakerEngine -- per path step visual
+        attention + LSTMCell with in-kernel gathers, the word loop as one persistent launch in inference), one
+        host sync for the whole batch.  Results in the layout of the host path below."""
+        from . import speaker as spk, synth
+        B = len(path_obs)
+        n = np.array([len(a) for a in path_actions], np.int32)
+        Tp = int(n.max())
+        z = lambda dt: np.zeros((Tp, B), dt)                               # noqa: E731
+        sb = synth.SpeakerBatch(instr=list(encoded_instructions), path_len=n, vp=z(np.int32), view=z(np.int32),
+                                act_view=z(np.int32), act_heading=z(np.float64), act_elevation=z(np.float64),
+                                act_is_stop=np.ones((Tp, B), bool))
+        for i, (obs, actions) in enumerate(zip(path_obs, path_actions)):
+            assert len(obs) == len(actions) + 1
+            for t, (ob, a) in enumerate(zip(obs[:-1], actions)):
+                assert a >= 0
+                sb.vp[t, i], sb.view[t, i] = ob['vp_row'], ob['viewIndex']
+                if a > 0:
+                    d = ob['adj_loc_list'][a]
+                    sb.act_is_stop[t, i] = False
+                    sb.act_view[t, i], sb.act_heading[t, i], sb.act_elevation[t, i] = \
+                        d['absViewIndex'], d['rel_heading'], d['rel_elevation']
+        if getattr(self, '_engine', None) is None or self._engine.store is not store:
+            self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
+        batch = spk.DeviceSpeakerBatch.from_synth(sb, device=store.device, max_length=self.instruction_len)
+        S = self.instruction_len
+        st = self._engine.score(batch, S, feedback, train=self.decoder.training)
+        words = st.words[1:].t().cpu().numpy()                             # [B,S]  (the one host sync)
+        sc = st.step_scores.t().cpu().numpy()
+        tok = getattr(self.env, 'tokenizer', None)
+        outputs = []
+        for i in range(B):
+            eos = np.flatnonzero(words[i] == EOS)
+            m = int(eos[0]) + 1 if len(eos) else S                         # up to and including the first EOS
+            total = np.float32(0)
+            for v in sc[i, :m]:
+                total = np.float32(total + v)
+            wi = [int(w) for w in words[i, :m]]
+            outputs.append({'instr_id': path_obs[i][0]['instr_id'], 'word_indices': wi, 'scores': [float(v) for v in sc[i, :m]],
+                            'score': float(total),
+                            'words': tok.decode_sentence(wi, break_on_eos=True, join=False) if tok is not None else wi})
+        # (the reference stops summing step losses once EVERY row has produced EOS, speaker.py:196; with teacher
+        # feedback -- training -- the steps behind that point have no live target and add exactly 0)
+        return outputs, st.loss
+
     def _score_obs_actions_and_instructions(self, path_obs, path_actions, encoded_instructions,
                                             feedback):
         """speaker.py:123-202."""
         assert len(path_obs) == len(path_actions) == len(encoded_instructions)
+        if 'feature' not in path_obs[0][0]:
+            store = self._env_store()
+            if store is None:
+                raise RuntimeError('index-form observations need a features.FeatureStore (env.image_features_list[0].store '
+                                   'or speaker.store)')
+            return self._score_on_device(path_obs, path_actions, encoded_instructions, feedback, store)
         start_obs, feats, acts, path_mask, _, encoded_instructions, perm = \
             self._batch_observations_and_actions(path_obs, path_actions, encoded_instructions)
         dev = self._device()

@@ -205,3 +205,62 @@ def test_reference_style_training_loop_through_the_bare_name_shim(tmp_path):
         sys.path.remove(compat.path())
         for name in ('env', 'model', 'follower', 'speaker'):
             sys.modules.pop(name, None)
+
+
+@pytest.mark.parametrize('feedback', ['teacher', 'argmax'])
+def test_speaker_agent_index_form_path_equals_the_dense_module_path(feedback):
+    """Seq2SeqSpeaker over an env WITHOUT a host feature table (index-form observations, what the bare-name shim
+    builds): the fused engine path gives the words, scores and loss of the observation-dictionary path that
+    mirrors speaker.py:123-202 on dense rows, and trains (train_speaker.py's loop)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import search_world as W
+    from torch import optim
+    from speaker_follower_amd import model, agents, features
+    d = synth.FULL
+    senc_w, sdec_w = synth.speaker_weights_peaky(W.SPEAKER_SEED)
+
+    def modules():
+        enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+        dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'])
+        enc.load_state_dict({k: torch.tensor(v) for k, v in senc_w.items()})
+        dec.load_state_dict({k: torch.tensor(v) for k, v in sdec_w.items()})
+        return enc.cuda().eval(), dec.cuda().eval()
+
+    out = {}
+    for dense in (True, False):
+        env, table = W.build_world(dense=dense)
+        enc, dec = modules()
+        spk = agents.Seq2SeqSpeaker(env, '/tmp/sf_spk_%d.json' % dense, enc, dec, W.INSTRUCTION_LEN, max_episode_len=W.EPISODE_LEN)
+        if not dense:
+            spk.store = features.FeatureStore(table)
+        env.reset_epoch()
+        spk.feedback = feedback
+        with torch.no_grad():
+            res = spk.rollout()
+        out[dense] = (res, float(spk.loss))
+    a, b = out[True], out[False]
+    assert [r['instr_id'] for r in a[0]] == [r['instr_id'] for r in b[0]]
+    for ra, rb in zip(a[0], b[0]):
+        assert ra['word_indices'] == rb['word_indices']
+        np.testing.assert_allclose(rb['scores'], ra['scores'], rtol=2e-4, atol=2e-4)
+        assert abs(ra['score'] - rb['score']) <= 3e-4 * max(1.0, abs(ra['score']))
+        assert ra['words'] == rb['words']
+    if feedback == 'teacher':                     # every step has live targets until the longest instruction ends
+        np.testing.assert_allclose(b[1], a[1], rtol=1e-4)
+    # train_speaker.py's loop on the index-form env (speaker.py:376-395)
+    env, table = W.build_world(dense=False)
+    enc, dec = modules()
+    spk = agents.Seq2SeqSpeaker(env, '/tmp/sf_spk_train.json', enc, dec, W.INSTRUCTION_LEN, max_episode_len=W.EPISODE_LEN)
+    spk.store = features.FeatureStore(table)
+    filt = lambda ps: [p for p in ps if p.requires_grad]       # noqa: E731
+    eo = optim.Adam(filt(enc.parameters()), lr=1e-3)
+    do = optim.Adam(filt(dec.parameters()), lr=1e-3)
+    env.reset_epoch()
+    spk.train(eo, do, 1, feedback='teacher')
+    first = spk.losses[0]
+    for _ in range(6):
+        env.reset_epoch()
+        spk.train(eo, do, 1, feedback='teacher')
+    assert np.isfinite(spk.losses[0]) and spk.losses[0] < first          # the same minibatch: the loss goes down
