@@ -19,7 +19,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .model import _grads, require_frozen_embedding
-from .runtime import ptr, stream, ws_args, dropout_arg, struct_of
+from .runtime import ptr, stream, ws_args, dropout_arg, struct_of, transposed
 
 byref = C.byref
 
@@ -137,7 +137,10 @@ class SpeakerEngine:
 
         # ---- encoder: Tp x (visual attention -> cat -> dropout -> LSTMCell), model.py:437-451
         ep = enc._params8()
-        vw, lw = struct_of(_lib.VisualW, ep[0:4]), struct_of(_lib.LstmW, ep[4:8])
+        # (transposed copies of W_v / W_h, cached per weight version: the query q = W_v^T t_v becomes a K-contiguous
+        # small product instead of the strided NN kernel: 6.4 instead of 15 us per path step)
+        vw = _lib.VisualW(*(p_.data_ptr() for p_ in ep[0:4]), transposed(ep[2]).data_ptr(), transposed(ep[0]).data_ptr())
+        lw = struct_of(_lib.LstmW, ep[4:8])
         st.e = dict(xin=new(Tp, B, 2 * F), alpha=new(Tp, B, V), t_v=new(Tp, B, D), q=new(Tp, B, F),
                     gates=new(Tp, B, 4 * H), hs=torch.zeros(Tp + 1, B, H, device=dev),
                     cs=torch.zeros(Tp + 1, B, H, device=dev), act_emb=new(Tp, B, F))
@@ -247,8 +250,10 @@ class SpeakerEngine:
         # ---- encoder backward
         d_enc = dropout_arg(*st.drop_enc)
         ep = enc._params8()
-        vw, vg = struct_of(_lib.VisualW, ep[0:4]), _lib.VisualW(*_grads(ep[0:4]))
-        lw, lg = struct_of(_lib.LstmW, ep[4:8]), _lib.LstmW(*_grads(ep[4:8]))
+        vw = _lib.VisualW(*(p_.data_ptr() for p_ in ep[0:4]), transposed(ep[2]).data_ptr(), transposed(ep[0]).data_ptr())
+        vg = _lib.VisualW(*_grads(ep[0:4]))
+        lw = _lib.LstmW(*(p_.data_ptr() for p_ in ep[4:8]), transposed(ep[4]).data_ptr(), transposed(ep[5]).data_ptr())
+        lg = _lib.LstmW(*_grads(ep[4:8]))
         e2d = enc.encoder2decoder
         g_e2d = _grads((e2d.weight, e2d.bias))
         # through decoder_init = tanh(W h_Tp + b): dh1 here is d h_init
