@@ -522,16 +522,20 @@ __global__ __launch_bounds__(64) void reduce_terms_kernel(const float* term, con
         sum_cnt[2 * t + 1] = c;
     }
 }
-__global__ void loss_finalize_kernel(const float* sum_cnt, int T, float* loss, float* gscale) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        float acc = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float c = sum_cnt[2 * t + 1];
-            acc += c > 0.f ? sum_cnt[2 * t] / c : 0.f;           // follower.py:481 / speaker.py:182
-            gscale[t] = c > 0.f ? 1.f / c : 0.f;
-        }
-        loss[0] = acc;
+// One wave.  Lane t loads step t's (sum, count) -- one round trip for 64 steps instead of one per step -- and the
+// per-step means are then added in step order through shuffles: the same float32 sum as a serial loop.
+__global__ __launch_bounds__(64) void loss_finalize_kernel(const float* sum_cnt, int T, float* loss, float* gscale) {
+    const int lane = threadIdx.x;
+    float acc = 0.f;
+    for (int base = 0; base < T; base += 64) {
+        const int t = base + lane;
+        const float2 sc = t < T ? reinterpret_cast<const float2*>(sum_cnt)[t] : make_float2(0.f, 0.f);
+        const float v = sc.y > 0.f ? sc.x / sc.y : 0.f;          // follower.py:481 / speaker.py:182
+        if (t < T) gscale[t] = sc.y > 0.f ? 1.f / sc.y : 0.f;
+        const int n = min(64, T - base);
+        for (int j = 0; j < n; ++j) acc += __shfl(v, j, WAVE);
     }
+    if (lane == 0) loss[0] = acc;
 }
 
 // torch.optim.Adam.step() (train.py:263-268: lr 1e-4, weight_decay 5e-4 as L2-in-gradient, default

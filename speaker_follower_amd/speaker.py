@@ -143,18 +143,23 @@ class SpeakerEngine:
         lw = struct_of(_lib.LstmW, ep[4:8])
         st.e = dict(xin=new(Tp, B, 2 * F), alpha=new(Tp, B, V), t_v=new(Tp, B, D), q=new(Tp, B, F),
                     gates=new(Tp, B, 4 * H), hs=torch.zeros(Tp + 1, B, H, device=dev),
-                    cs=torch.zeros(Tp + 1, B, H, device=dev), act_emb=new(Tp, B, F))
+                    cs=torch.zeros(Tp + 1, B, H, device=dev))
         d_enc = dropout_arg(*st.drop_enc)
+        # the chosen-action embeddings of ALL path steps in one gather ([Tp*B] rows: the index arrays are
+        # [Tp,B] contiguous), and -- without dropout -- one strided copy into the LSTM inputs of all steps
+        st.e['act_emb'] = store.gather_actions(batch.vp.reshape(-1), batch.act_view.reshape(-1),
+                                               batch.act_sincos.reshape(-1, 4), batch.act.reshape(-1)).view(Tp, B, F)
+        if d_enc is None:
+            call('sf_dropout_copy', ptr(st.e['act_emb']), F, Tp * B, F, ptr(st.e['xin']), 2 * F, None, 0, 0, ws[2])
         for t in range(Tp):
             pano = store.pano(batch.vp[t], batch.view[t])
-            st.e['act_emb'][t] = store.gather_actions(batch.vp[t], batch.act_view[t],
-                                                      batch.act_sincos[t], batch.act[t])
             xin_f = C.c_void_p(st.e['xin'][t].data_ptr() + 4 * F)
             call('sf_visual_attention_fwd', byref(vw), byref(pano), B, H, D, ptr(st.e['hs'][t]),
                  xin_f, 2 * F, ptr(st.e['alpha'][t]), ptr(st.e['t_v'][t]), ptr(st.e['q'][t]), d_enc,
                  2 * (st.site0 + t), F, *ws)
-            call('sf_dropout_copy', ptr(st.e['act_emb'][t]), F, B, F, ptr(st.e['xin'][t]), 2 * F,
-                 d_enc, 2 * (st.site0 + t), 0, ws[2])
+            if d_enc is not None:
+                call('sf_dropout_copy', ptr(st.e['act_emb'][t]), F, B, F, ptr(st.e['xin'][t]), 2 * F,
+                     d_enc, 2 * (st.site0 + t), 0, ws[2])
             call('sf_lstm_cell_fwd', byref(lw), B, 2 * F, H, ptr(st.e['xin'][t]), 2 * F,
                  ptr(st.e['hs'][t]), ptr(st.e['cs'][t]), ptr(st.e['hs'][t + 1]),
                  ptr(st.e['cs'][t + 1]), ptr(st.e['gates'][t]), None, 0, None, 0, *ws)
