@@ -745,30 +745,24 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
             alpha_l = e / row16_sum(e);
             if (slot == 0 && evalid && eu < Tp && p.alpha) p.alpha[((size_t)t * B + eb) * Tp + eu] = alpha_l;
         }
-        // ---- D. [next step's recurrent gates | W_h h1] = h1 . [W_hh ; W_h]^T over this wave's K-quarter
+        // ---- D1. W_h h1 over this wave's K-quarter: the one tile h~ waits for.  (The four gate tiles of the NEXT
+        //      step's cell are not needed before this step's word is known: they are formed in D2, behind the h~
+        //      publish, while the other workgroups' h~ tiles are still on their way.)
         {
-            f32x4 acc[5];
-#pragma unroll
-            for (int g = 0; g < 5; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const float4 af = make_float4(__uint_as_float(a[i].x), __uint_as_float(a[i].y),
                                               __uint_as_float(a[i].z), __uint_as_float(a[i].w));
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int g = 0; g < 5; ++g) acc[g] = mfma16(comp(af, c), comp(wf[g][i], c), acc[g]);
+                for (int c = 0; c < 4; ++c) acc = mfma16(comp(af, c), comp(wf[4][i], c), acc);
             }
-            __syncthreads();                             // s_part of the previous use fully consumed
+            // (s_part[.][4] was last read in phase E of the previous step, in front of that step's phase-F barrier)
 #pragma unroll
-            for (int g = 0; g < 5; ++g)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) s_part[w][g][(kk * 4 + r) * 16 + li] = acc[g][r];
+            for (int r = 0; r < 4; ++r) s_part[w][4][(kk * 4 + r) * 16 + li] = acc[r];
             __syncthreads();
         }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) R[g] = (s_part[0][g][tid] + s_part[1][g][tid]) + (s_part[2][g][tid] + s_part[3][g][tid]);
-        EP_STAMP(2)                                      // softmax + MFMA (5 tiles) + LDS reduce
+        EP_STAMP(2)                                      // softmax + W_h tile + LDS reduce
         // ---- E. h~ = tanh(sum_l alpha_l cw_l + W_h h1)   (model.py:139-141, folded)
         float ht = (s_part[0][4][tid] + s_part[1][4][tid]) + (s_part[2][4][tid] + s_part[3][4][tid]);
 #pragma unroll
@@ -781,7 +775,28 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
                 xstore(local, v4u{__float_as_uint(hp), __float_as_uint(h_1), __float_as_uint(h_2), __float_as_uint(h_3)},
                        rs, (bo + SPX_HT + patch) * 4u);
         }
-        EP_STAMP(3)                                      // h~ + publish
+        // ---- D2a. the next step's recurrent gates h1 . W_hh^T (this wave's K-quarter), input and forget gate, under
+        //      the h~ exchange; cell and output gate follow in D2b under the exchange of the softmax statistics.
+        //      The partials meet in LDS behind phase F's barrier (a) and behind the barrier that ends the step (b);
+        //      the last readers of s_part[.][0..3] -- the R sums of the previous step -- are behind those.
+        auto gate_pair = [&](int g0) {
+            f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float4 af = make_float4(__uint_as_float(a[i].x), __uint_as_float(a[i].y),
+                                              __uint_as_float(a[i].z), __uint_as_float(a[i].w));
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+#pragma unroll
+                    for (int g = 0; g < 2; ++g) acc[g] = mfma16(comp(af, c), comp(wf[g0 + g][i], c), acc[g]);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_part[w][g0 + g][(kk * 4 + r) * 16 + li] = acc[g][r];
+        };
+        gate_pair(0);
+        EP_STAMP(3)                                      // h~ + publish + gate tiles
         // ---- F. vocabulary projection of this workgroup's 32 columns (model.py:518)
         {
             v4u av[8];
@@ -816,6 +831,8 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
                 for (int r = 0; r < 4; ++r) s_voc[w][nt][(kk * 4 + r) * 16 + li] = acc[nt][r];
             __syncthreads();
         }
+#pragma unroll
+        for (int g = 0; g < 2; ++g) R[g] = (s_part[0][g][tid] + s_part[1][g][tid]) + (s_part[2][g][tid] + s_part[3][g][tid]);
         const float l0 = (s_voc[0][0][tid] + s_voc[1][0][tid]) + (s_voc[2][0][tid] + s_voc[3][0][tid]) + bv0;
         const float l1 = (s_voc[0][1][tid] + s_voc[1][1][tid]) + (s_voc[2][1][tid] + s_voc[3][1][tid]) + bv1;
         if (evalid && p.logits) {
@@ -842,7 +859,8 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
                 xstore(local, v4u{__float_as_uint(m), (unsigned)am, __float_as_uint(se), __float_as_uint(tl)}, rs,
                        (bo + SPX_ST + (unsigned)((slot * EP_ROWS + er) * 4)) * 4u);
         }
-        EP_STAMP(5)                                      // vocabulary MFMA + statistics + publish
+        gate_pair(2);                                    // D2b: under the exchange of the statistics
+        EP_STAMP(5)                                      // vocabulary MFMA + statistics + publish + gate tiles
         // ---- H. combine the 32 workgroups' statistics: every lane of row er learns the word
         float M, Z, tlog;
         int arg;
@@ -903,6 +921,9 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
         // ---- I. input row of the next step (model.py:497 + the hoisted W_ih product)
 #pragma unroll
         for (int g = 0; g < 4; ++g) xv[g] = p.xw_table[(size_t)wprev * 4 * H + g * H + ej];
+        __syncthreads();                                 // D2b's partials (cell and output gate)
+#pragma unroll
+        for (int g = 2; g < 4; ++g) R[g] = (s_part[0][g][tid] + s_part[1][g][tid]) + (s_part[2][g][tid] + s_part[3][g][tid]);
     }
     if (p.trace && lane == 0 && w == 0) {
 #pragma unroll
