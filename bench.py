@@ -68,6 +68,9 @@ def parse(argv=None):
     # box with ONE GPU.  Ranks share cuda:0 and reduce through gloo; the line is marked oversubscribed.
     ap.add_argument('--backend', choices=['nccl', 'gloo'], default='nccl')
     ap.add_argument('--share-gpu', action='store_true', help='(test) every rank uses cuda:0')
+    ap.add_argument('--force-collectives', action='store_true',
+                    help='(test) --gpus 1 only: initialise the process group (world size 1) and issue every collective of '
+                         'the data-parallel path anyway -- RCCL executes on this GPU; adds `train_dp` to the line')
     ap.add_argument('--plan', action='store_true',
                     help='print the child commands / environment `--gpus N` would start (JSON) and exit; touches no GPU')
     return ap.parse_args(argv)
@@ -181,11 +184,12 @@ def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps, threa
                        % (reps, B, n, cores, '' if cores == 1 else 's (BLAS pool)', reps)), res
 
 
-def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1):
+def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1, coll=None):
     """follower.py:1001-1020 + train.py:263-268 per iteration: zero_grad, student-forcing rollout with
     loss, backward, [gradient all-reduce,] Adam(lr 1e-4, weight_decay 5e-4) on encoder and decoder."""
     import torch
     from speaker_follower_amd import follower, dp, optim
+    coll = world > 1 if coll is None else coll       # collectives issued (world > 1, or forced at one rank)
     enc.train()
     dec.train()
     params_e = [p for p in enc.parameters() if p.requires_grad]
@@ -203,11 +207,11 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1)
 
     def it(k=None):
         flat.zero()
-        engine.grad_sync = flat if (world > 1 and mode['sync'] == 'buckets') else None
+        engine.grad_sync = flat if (coll and mode['sync'] == 'buckets') else None
         st = engine.rollout(batch, S, 'argmax', train=True)
         st.loss.backward()
         if mode['sync'] == 'buckets':
-            if world > 1:
+            if coll:
                 flat.wait()
         elif mode['sync'] == 'blocking':
             if k is not None:
@@ -220,7 +224,7 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1)
         return st
 
     def barrier():
-        if world > 1:
+        if coll:
             torch.distributed.barrier()
         torch.cuda.synchronize()
     for _ in range(warmup):
@@ -231,13 +235,13 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1)
         st = it(k)
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if coll:
         tt = torch.tensor([dt], device=store.device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         dt = float(tt)
     dt /= iters
     ar = dict(allreduce_ms=0.0)
-    if world > 1:
+    if coll:
         # the same iteration (a) with ONE blocking all-reduce of the whole buffer behind backward() -- its
         # duration is the TOTAL all-reduce time -- and (b) with no gradient exchange at all: what the overlapped
         # buckets leave EXPOSED is (overlapped iteration) - (b)
@@ -264,7 +268,7 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1)
                   schedule='buckets in production order (decoder LSTM, other decoder weights, encoder), each all-reduce '
                            'launched async behind the launches that complete it; wait before Adam')
     kernels = None
-    if world == 1:          # per-kernel table of the iteration, measured in this run (both backward streams)
+    if world == 1 and not coll:   # per-kernel table of the iteration, measured in this run (both backward streams)
         from speaker_follower_amd import bench_extras
         rows, us = bench_extras.kernel_table(lambda: it())
         H, F, D = 512, 2176, 256
@@ -370,7 +374,19 @@ def main(argv=None):
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     group = None
-    if world > 1:
+    forced = args.force_collectives and world == 1
+    if forced:
+        # one rank, real collectives: the RCCL path (library load, init with a device id, async all-reduces launched
+        # from the backward, wait before Adam) runs on this GPU; no scaling information in it
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', str(free_port()))
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
+        os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        from speaker_follower_amd import dp as _dp
+        _dp.FORCE_COLLECTIVES = True
+    coll = world > 1 or forced
+    if coll:
         import torch.distributed as dist
         if args.backend == 'nccl':
             dist.init_process_group('nccl', device_id=device)
@@ -399,7 +415,7 @@ def main(argv=None):
         params_d = [p for p in dec.parameters() if p.requires_grad]
         from speaker_follower_amd import dp, optim
         flat = dp.BucketedGrads(dp.follower_buckets(enc, dec), group=group)   # kernels accumulate straight into this buffer
-        engine.grad_sync = flat if world > 1 else None
+        engine.grad_sync = flat if coll else None
         opt_e = optim.FusedAdam(params_e, lr=1e-4, weight_decay=5e-4)      # train.py:263-268
         opt_d = optim.FusedAdam(params_d, lr=1e-4, weight_decay=5e-4)
     else:
@@ -428,7 +444,7 @@ def main(argv=None):
             flat.zero()
             st = engine.rollout(batch, S, 'argmax', train=True)
             st.loss.backward()                         # (launches the bucketed RCCL all-reduces at N > 1)
-            if world > 1:
+            if coll:
                 flat.wait()
             opt_e.step()
             opt_d.step()
@@ -441,7 +457,7 @@ def main(argv=None):
         return st
 
     def barrier():
-        if world > 1:
+        if coll:
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
@@ -466,8 +482,11 @@ def main(argv=None):
     # ---- extra (not `value`), N > 1: the data-parallel TRAINING iteration (BASELINE configs[3]) on the
     # same per-GPU batch, with the gradient all-reduce timed on its own.  Every rank takes part.
     train_dp = None
-    if extras and world > 1 and not train and not args.no_train_extra:
-        train_dp = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2, group=group, world=world)
+    if (extras or forced) and coll and not train and not args.no_train_extra:
+        train_dp = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2, group=group, world=world, coll=coll)
+        if forced:
+            train_dp['forced_collectives'] = ('TEST RUN: one rank, every collective of the data-parallel path issued anyway '
+                                              '(%s); proves the path executes, says nothing about scaling' % args.backend)
 
     # ---- extra (not `value`): serving-style throughput with several independent rollouts in flight.
     concurrent = None
@@ -494,7 +513,7 @@ def main(argv=None):
                           unit='agent-steps/s', ms_per_rollout=1e3 * dt / kk)
 
     if rank != 0:
-        if world > 1:
+        if coll:
             torch.distributed.destroy_process_group()
         return
 
@@ -591,8 +610,6 @@ def main(argv=None):
         out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2], one batch
         out['speaker_sweep'] = bench_extras.speaker_sweep(store, device)            # configs[2], 2000 distinct paths
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
-        if os.path.exists(_lib.EXP_LIB_PATH):      # frozen experiment, only when its library was built on demand
-            out['persistent_decode_experiment'] = bench_extras.persistent_decode(enc, dec, store, batch, S)
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):
             out['search_full'] = bench_extras.search_full(conn, device)
@@ -635,9 +652,12 @@ def main(argv=None):
                                              loss_abs_diff=abs(float(st.loss_buf) - float(ref['loss'])),
                                              max_abs_logit_diff=worst, max_abs_logit=float(np.abs(lg[np.isfinite(lg)]).max()),
                                              weights='synth.follower_weights_peaky (logit std ~1.4)')
+    # a starved persistent launch would have poisoned a rollout with NaN: the fault words say so (0 = healthy)
+    from speaker_follower_amd import runtime as _rt
+    out['persistent_launch_faults'] = _rt.take_fault(device)
     print(json.dumps(out))
     sys.stdout.flush()
-    if world > 1:
+    if coll:
         torch.distributed.destroy_process_group()
 
 

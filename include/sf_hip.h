@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 6
+#define SF_ABI_VERSION 7
 
 enum {
     SF_OK = 0,
@@ -156,6 +156,10 @@ typedef struct sf_decoder_tape {
  * kernels); after that the library owns its contents.  One workspace per concurrently used stream. */
 size_t sf_workspace_bytes(void);
 int sf_abi_version(void);
+/* Hash (16 hex digits) of the sources, headers and compiler flags this library was built from
+ * (speaker_follower_amd/build.py: build_id()).  The Python binding compares it with the sources on disk at import
+ * and refuses a stale library. */
+const char* sf_build_id(void);
 const char* sf_status_string(int status);
 /* hipGetErrorString of the HIP error behind the calling thread's last SF_ERR_LAUNCH */
 const char* sf_last_error_string(void);
@@ -485,11 +489,17 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
                            const float* ctx, const uint8_t* ctx_mask, const int32_t* ctx_row,
                            const sf_spk_decoder_tape* tape, const sf_dropout* drop,
                            uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream);
+/* `sample` feedback of the speaker (speaker.py:170-174, D.Categorical(probs).sample()): counter-based draw keyed on
+ * (seed, stream, row0 + b) -- csrc/sf_sampling.h; oracle/rng.py mirrors it.  `stream` names the word step (callers
+ * pass site + t; sf_speaker_decode uses stream + t for its step t); row0 = global id of local row 0 (data-parallel
+ * shards draw what the unsharded batch would). */
+typedef struct sf_sample { uint32_t seed, stream; int32_t row0; } sf_sample;
 /* The WHOLE word loop of an inference pass (speaker.py:158-197: S times SpeakerDecoderLSTM.forward +
  * sf_speaker_glue_fwd, eval mode, no tapes for a backward) as one persistent launch
  * (csrc/sf_persist.hip: weights register-resident, rows partitioned across XCDs, three in-kernel
  * exchanges per word).  targets [S,B] int64; words [S+1,B] with words[0] = the start tokens;
- * feedback 0 = teacher, 1 = argmax; step_scores / nll_term / live [S,B] as sf_speaker_glue_fwd;
+ * feedback 0 = teacher, 1 = argmax, 2 = sample (needs `sample`); step_scores / nll_term / live [S,B] as
+ * sf_speaker_glue_fwd;
  * optional outputs (NULL = skip): logits [S,B,ldv], alpha [S,B,Tp], h1_tape / c1_tape [S,B,H].
  * Needs w->xw_table and w->attn.w_in_t.  The attention is evaluated in the folded form
  * cq = ctx W_in, cw = ctx W_c^T (same function, fp32 re-association).  SF_ERR_UNSUPPORTED (H != 512,
@@ -498,8 +508,8 @@ int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab
                       int pad_idx, int eos_idx, const int64_t* targets, const float* h_init,
                       const float* c_init, const float* ctx, const uint8_t* ctx_mask, int64_t* words,
                       uint8_t* ended, float* step_scores, float* nll_term, float* live, float* logits,
-                      float* alpha, float* h1_tape, float* c1_tape, void* ws, size_t ws_bytes,
-                      sf_stream stream);
+                      float* alpha, float* h1_tape, float* c1_tape, const sf_sample* sample, void* ws,
+                      size_t ws_bytes, sf_stream stream);
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E,
                            int H, int Tp, int vocab, const float* h0, const float* c0,
                            const float* ctx, const sf_spk_decoder_tape* tape, const float* dlogit,
@@ -507,11 +517,17 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
                            const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
                            sf_stream stream);
 /* speaker.py:163-191: log-softmax over the vocabulary, NLL terms against target (PAD ignored),
- * next word (feedback 0 = teacher, 1 = argmax), score[b] = log p(w_t) (0 if w_t == PAD),
- * ended[b] |= (w_t == EOS).  nll_term/live as in sf_follower_glue_fwd. */
+ * next word (feedback 0 = teacher, 1 = argmax, 2 = sample from softmax(logit): needs `sample`, else NULL),
+ * score[b] = log p(w_t) (0 if w_t == PAD), ended[b] |= (w_t == EOS).  nll_term/live as in sf_follower_glue_fwd. */
 int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
-                        float* score, float* nll_term, float* live, sf_stream stream);
+                        float* score, float* nll_term, float* live, const sf_sample* sample, sf_stream stream);
+/* The speaker's loss from the per-step (NLL sum, live count) table (speaker.py:182, 192-197): the step means are added
+ * only up to and including the first step at which EVERY row has produced EOS (the reference leaves its word loop
+ * there); gscale[t] = 1 / count for those steps, 0 behind them.  words [T+1,B] as written by the glue / the decode
+ * launch (row 0 = start tokens).  T <= 1024. */
+int sf_speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos_idx, int T, int B, float* loss,
+                             float* gscale, sf_stream stream);
 int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int pad_idx, const float* gscale, float* dlogit, sf_stream stream);
 
@@ -560,6 +576,17 @@ void sf_debug_trace(unsigned long long* buf);
  * share an XCD and would keep the exchange inside that XCD's L2.  Lets the tests exercise the protocol
  * the kernels fall back to when the observed workgroup -> XCD placement does not hold. */
 void sf_debug_force_write_through(int on);
+/* Development aid / test hook: bound of every in-kernel wait of the persistent launches in ticks of 10 ns
+ * (< 0 restores the default, 0.25 s).  0 makes the first unsatisfied poll give up: the launch poisons its outputs
+ * and raises its fault bit -- how the tests exercise the host's fallback to the per-step kernels. */
+void sf_debug_persist_timeout(long long ticks);
+/* Byte offset, inside a workspace of `ws_bytes` bytes, of the FAULT WORD (uint32, zero in a healthy process): a
+ * persistent launch whose bounded wait gave up (co-residency lost to another process) ORs its bit into it -- 1 encoder
+ * forward (sf_encoder_lstm_fwd), 2 encoder backward, 4 speaker word loop (sf_speaker_decode), 8 device-wide lock not
+ * obtained -- and poisons its outputs with NaN.  The library never reads or clears the word: the host reads it at a
+ * sync it already has, clears it, and re-issues the pass with the per-step kernels (SF_ENC_PER_STEP / the per-step
+ * speaker entry points).  speaker_follower_amd.runtime.take_fault does exactly that. */
+size_t sf_workspace_fault_offset(size_t ws_bytes);
 /* ---- device-resident navigation (env.py:126-146 step, :149-224 panorama sweep, :742-761 teacher,
  * :763-804 observe) ---------------------------------------------------------------------------------
  * The candidate list of a state is a pure function of (viewpoint, view index): the host tabulates it

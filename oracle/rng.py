@@ -37,3 +37,41 @@ def dropout_mask(seed, stream, rows, n_cols, p):
     bits = dropout_bits(seed, stream, rows, np.arange(n_cols))
     keep = bits >= thresh
     return keep.astype(np.float32) * np.float32(1.0 / (1.0 - p))
+
+
+def sample_uniforms(seed, stream, rows):
+    """(u1 [R], u2 [R]): the two uniforms of sf_sampling.h for global rows `rows` at (seed, stream)."""
+    bits = dropout_bits(seed, stream, rows, [0, 1])
+    return (bits[:, 0] >> np.uint32(8)).astype(np.float64) / 16777216.0, \
+           (bits[:, 1] >> np.uint32(8)).astype(np.float64) / 16777216.0
+
+
+def speaker_sample(logit_row, u1, u2, slot=32):
+    """float64 mirror of the device's two-level inverse-CDF draw (speaker_follower_amd/csrc/sf_sampling.h; the
+    reference's D.Categorical(probs).sample() at speaker.py:170-174 draws from torch's stateful generator, which cannot be
+    reproduced).  Returns (word, margin): margin = the smallest relative distance of either threshold to a CDF boundary
+    -- fp32 roundoff on the device can flip a draw whose margin is ~1e-6, so callers skip those."""
+    l = np.asarray(logit_row, np.float64)
+    V = len(l)
+    ns = (V + slot - 1) // slot
+    m_s = np.full(ns, -np.inf)
+    z_s = np.zeros(ns)
+    for s in range(ns):
+        seg = l[slot * s:slot * (s + 1)]
+        m_s[s] = seg.max()
+        z_s[s] = np.exp(seg - m_s[s]).sum()
+    M = m_s.max()
+    p = z_s * np.exp(m_s - M)
+    cdf = np.cumsum(p)
+    thr = u1 * cdf[-1]
+    hit = np.flatnonzero((cdf > thr) & (p > 0))
+    s = int(hit[0]) if len(hit) else int(np.argmax(l)) // slot
+    margin = np.min(np.abs(cdf - thr)) / cdf[-1]
+    seg = l[slot * s:slot * (s + 1)]
+    e = np.exp(seg - m_s[s])
+    c2 = np.cumsum(e)
+    thr2 = u2 * z_s[s]
+    hit2 = np.flatnonzero((c2 > thr2) & (e > 0))
+    c = int(hit2[0]) if len(hit2) else len(seg) - 1
+    margin = min(margin, np.min(np.abs(c2 - thr2)) / z_s[s])
+    return slot * s + c, float(margin)

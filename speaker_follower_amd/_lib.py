@@ -101,6 +101,11 @@ class SpkDecoderG(C.Structure):
     _fields_ = [('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p), ('b_out', c_p)]
 
 
+class Sample(C.Structure):
+    """sf_sample: counter-based draw of the speaker's `sample` feedback (seed, stream, row0)."""
+    _fields_ = [('seed', C.c_uint32), ('stream', C.c_uint32), ('row0', C.c_int32)]
+
+
 class NavTableS(C.Structure):
     _fields_ = [('a_num', c_p), ('next_row', c_p), ('cand_view', c_p), ('cand_sincos', c_p),
                 ('feat_row', c_p), ('A', C.c_int32), ('V', C.c_int32)]
@@ -122,6 +127,9 @@ WS = [c_p, C.c_size_t, c_p]          # ws, ws_bytes, stream
 _SIGNATURES = {
     'sf_workspace_bytes': (C.c_size_t, []),
     'sf_abi_version': (C.c_int, []),
+    'sf_build_id': (C.c_char_p, []),
+    'sf_debug_persist_timeout': (None, [C.c_longlong]),
+    'sf_workspace_fault_offset': (C.c_size_t, [C.c_size_t]),
     'sf_debug_trace': (None, [C.c_void_p]),
     'sf_debug_force_write_through': (None, [C.c_int]),
     'sf_status_string': (C.c_char_p, [C.c_int]),
@@ -185,9 +193,10 @@ _SIGNATURES = {
                                          c_f, c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, c_f,
                                          c_f, P(Dropout), u32] + WS),
     'sf_speaker_decode': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i32, i32, i32, i64p, c_f, c_f, c_f, c_p,
-                                   i64p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f] + WS),
+                                   i64p, c_p, c_f, c_f, c_f, c_f, c_f, c_f, c_f, P(Sample)] + WS),
     'sf_speaker_glue_fwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, i32, i32, c_p, i64p, c_f, c_f,
-                                      c_f, c_p]),
+                                      c_f, P(Sample), c_p]),
+    'sf_speaker_loss_finalize': (C.c_int, [c_f, i64p, i32, i32, i32, c_f, c_f, c_p]),
     'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),
     'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
     'sf_add_f32': (C.c_int, [c_f, c_f, C.c_size_t, c_p]),
@@ -205,7 +214,7 @@ SF_OK, SF_ERR_ARG, SF_ERR_UNSUPPORTED, SF_ERR_LAUNCH, SF_ERR_WORKSPACE = 0, 1, 2
 SF_ENC_PER_STEP = 1           # sf_encoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 def _load():
@@ -220,37 +229,17 @@ def _load():
         fn.argtypes = args
     if lib.sf_abi_version() != ABI_VERSION:
         raise ImportError('libsf_hip.so ABI version mismatch')
+    # a library built from other sources than the ones on disk (stale .so after a checkout) is refused
+    from .build import build_id, CSRC
+    if os.path.isdir(CSRC) and os.environ.get('SF_SKIP_BUILD_ID_CHECK') != '1':
+        have, want = lib.sf_build_id().decode(), build_id()
+        if have != want:
+            raise ImportError('libsf_hip.so is stale: built from sources %s, the tree holds %s; run '
+                              '`python -m speaker_follower_amd.build`' % (have, want))
     return lib
 
 
 lib = _load()
-
-# ---- experiments kept out of the product library (include/sf_hip_experimental.h) ----
-EXP_LIB_PATH = os.path.join(_PKG, 'libsf_experimental.so')
-_EXP_SIGNATURES = {
-    'sf_follower_decode_persistent': (C.c_int, [P(DecoderW), P(FollowerEpisode), i32] + WS),
-    # (that library carries its own copy of the launch-timing state: kernel_profile(experimental()))
-    'sf_profile_begin': (C.c_int, []),
-    'sf_profile_end': (C.c_long, [C.c_char_p, C.c_size_t]),
-}
-_exp = None
-
-
-def experimental():
-    """libsf_experimental.so, loaded on first use.  Raises when it has not been built
-    (`python -m speaker_follower_amd.build --experimental`)."""
-    global _exp
-    if _exp is None:
-        if not os.path.exists(EXP_LIB_PATH):
-            raise ImportError('libsf_experimental.so is not built: python -m speaker_follower_amd.build --experimental')
-        e = C.CDLL(EXP_LIB_PATH)
-        for name, (res, args) in _EXP_SIGNATURES.items():
-            fn = getattr(e, name)
-            fn.restype = res
-            fn.argtypes = args
-        _exp = e
-    return _exp
-
 
 def check(status, what=''):
     if status != 0:

@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from ._lib import call
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
-from .runtime import ptr, stream, require_gpu, cands_dense
+from .runtime import ptr, stream, require_gpu, cands_dense, PersistentLaunchFault
 
 byref = C.byref
 
@@ -159,12 +159,22 @@ class Seq2SeqAgent(BaseAgent):
             self._engine.dropout_seed = self._sample_seed ^ 0x1B873593
         return table_for(self.env, self.store)
 
-    def _rollout_on_device(self, table=None):
+    def _rollout_on_device(self, table=None, reissue=False):
+        """One rollout on the device-resident environment.  `FollowerEngine.run` checks the fault word of the
+        persistent encoder launch at its sync and re-issues the rollout on the per-step kernels by itself;
+        reissue=True (train(): a fault raised by the BACKWARD) replays the current minibatch that way."""
         from .nav import DeviceNavBatch
-        self.env.reset(sort=True)
+        if not reissue:
+            self.env.reset(sort=True)
         batch = DeviceNavBatch(table if table is not None else self.nav_table, list(self.env.batch), self.episode_len,
                                max_length=self.max_instruction_length, reverse=self.reverse_instruction)
-        st = self._engine.rollout(batch, self.episode_len, self.feedback, train=self.decoder.training)
+        keep = getattr(self.encoder, 'persistent', True)
+        if reissue:
+            self.encoder.persistent = False
+        try:
+            st = self._engine.run(batch, self.episode_len, self.feedback, train=self.decoder.training)
+        finally:
+            self.encoder.persistent = keep
         self.loss = st.loss
         traj = batch.trajectories(st)                   # the one host sync of the rollout
         for tr, it in zip(traj, self.env.batch):
@@ -240,11 +250,11 @@ class Seq2SeqAgent(BaseAgent):
         loss_t = ce.sum() / n_live.clamp(min=1.0)                    # CrossEntropyLoss mean over live
         return h, c, loss_t, a_t, score, u_next
 
-    def _rollout_with_loss(self):
+    def _rollout_with_loss(self, reissue=False):
         """follower.py:430-539."""
         table = self._device_table()
         if table is not None:
-            return self._rollout_on_device(table)
+            return self._rollout_on_device(table, reissue)
         world_states = self.env.reset(sort=True)
         obs = np.array(self.env.observe(world_states))
         B = len(obs)
@@ -357,6 +367,23 @@ class Seq2SeqAgent(BaseAgent):
             decoder_optimizer.zero_grad()
             self._rollout_with_loss()
             self.loss.backward()
+            # a starved persistent launch of the BACKWARD has poisoned the gradients: never step on them -- replay
+            # the minibatch on the per-step kernels (the forward's own check sits inside FollowerEngine.run)
+            if _persistent_fault(self._device()):
+                encoder_optimizer.zero_grad()
+                decoder_optimizer.zero_grad()
+                self.losses.pop()
+                keep = getattr(self.encoder, 'persistent', True)
+                self.encoder.persistent = False
+                try:
+                    # (the device environment replays the SAME minibatch; the per-step host loop cannot rewind its
+                    # simulators and trains on the next one)
+                    self._rollout_with_loss(reissue=True)
+                    self.loss.backward()
+                finally:
+                    self.encoder.persistent = keep
+                if _persistent_fault(self._device()):
+                    raise PersistentLaunchFault('the per-step re-issue of a training iteration raised a fault again')
             encoder_optimizer.step()
             decoder_optimizer.step()
 
@@ -374,11 +401,17 @@ class Seq2SeqAgent(BaseAgent):
         self.decoder.load_state_dict(torch.load(dp, **kwargs))
 
 
+def _persistent_fault(device):
+    """Fault bits of the persistent launches since the last check (runtime.take_fault); one small D2H copy."""
+    from .runtime import take_fault
+    return take_fault(device) if device.type == 'cuda' else 0
+
+
 class _SpeakerGlueFn(torch.autograd.Function):
     """speaker.py:163-191 on a [B,vocab] logit tensor."""
 
     @staticmethod
-    def forward(ctx, logit, target, feedback, ended_dev, pad_idx, eos_idx):
+    def forward(ctx, logit, target, feedback, ended_dev, pad_idx, eos_idx, sample_cfg=None):
         B, V = logit.shape
         ldv = (V + 3) & ~3
         dev = logit.device
@@ -386,8 +419,9 @@ class _SpeakerGlueFn(torch.autograd.Function):
         lg[:, :V] = logit.detach()
         w_t = torch.empty(B, dtype=torch.int64, device=dev)
         score, nll, live = (torch.empty(B, device=dev) for _ in range(3))
+        smp = byref(_lib.Sample(sample_cfg[0] & 0xFFFFFFFF, sample_cfg[1] & 0xFFFFFFFF, 0)) if feedback == 2 else None
         call('sf_speaker_glue_fwd', B, V, ldv, ptr(lg), ptr(target), feedback, pad_idx, eos_idx,
-             ptr(ended_dev), ptr(w_t), ptr(score), ptr(nll), ptr(live), stream())
+             ptr(ended_dev), ptr(w_t), ptr(score), ptr(nll), ptr(live), smp, stream())
         ctx.save_for_backward(lg, target)
         ctx.cfg = (B, V, ldv, pad_idx)
         ctx.mark_non_differentiable(live, w_t, score)
@@ -401,7 +435,7 @@ class _SpeakerGlueFn(torch.autograd.Function):
         dl = torch.empty_like(lg)
         call('sf_speaker_glue_bwd', B, V, ldv, ptr(lg), ptr(target), pad_idx, ptr(one), ptr(dl),
              stream())
-        return dl[:, :V] * dnll.reshape(B, 1), None, None, None, None, None
+        return dl[:, :V] * dnll.reshape(B, 1), None, None, None, None, None, None
 
 
 class Seq2SeqSpeaker(object):
@@ -418,6 +452,8 @@ class Seq2SeqSpeaker(object):
         self.instruction_len = instruction_len
         self.max_episode_len = max_episode_len
         self.feedback = 'argmax'
+        self._sample_seed = torch.initial_seed() & 0xFFFFFFFF     # `sample` feedback: counter-based draws (sf_sampling.h)
+        self._sample_count = 0
 
     def write_results(self):
         with open(self.results_path, 'w') as f:
@@ -479,7 +515,7 @@ class Seq2SeqSpeaker(object):
             self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
         batch = spk.DeviceSpeakerBatch.from_synth(sb, device=store.device, max_length=self.instruction_len)
         S = self.instruction_len
-        st = self._engine.score(batch, S, feedback, train=self.decoder.training)
+        st = self._engine.run(batch, S, feedback, train=self.decoder.training)   # (fault check + per-step re-issue inside)
         words = st.words[1:].t().cpu().numpy()                             # [B,S]  (the one host sync)
         sc = st.step_scores.t().cpu().numpy()
         tok = getattr(self.env, 'tokenizer', None)
@@ -494,8 +530,8 @@ class Seq2SeqSpeaker(object):
             outputs.append({'instr_id': path_obs[i][0]['instr_id'], 'word_indices': wi, 'scores': [float(v) for v in sc[i, :m]],
                             'score': float(total),
                             'words': tok.decode_sentence(wi, break_on_eos=True, join=False) if tok is not None else wi})
-        # (the reference stops summing step losses once EVERY row has produced EOS, speaker.py:196; with teacher
-        # feedback -- training -- the steps behind that point have no live target and add exactly 0)
+        # (the reference stops summing step losses once EVERY row has produced EOS, speaker.py:196: so does
+        # sf_speaker_loss_finalize, which st.loss comes from)
         return outputs, st.loss
 
     def _score_obs_actions_and_instructions(self, path_obs, path_actions, encoded_instructions,
@@ -525,8 +561,9 @@ class Seq2SeqSpeaker(object):
         for t in range(self.instruction_len):
             h, c, alpha, logit = self.decoder(w_t.view(-1, 1), h, c, ctx, path_mask)
             target = instr_seq[:, t].contiguous()
+            self._sample_count += 1
             nll, live, w_t, score = _SpeakerGlueFn.apply(logit, target, FEEDBACK[feedback],
-                                                         ended_dev, PAD, EOS)
+                                                         ended_dev, PAD, EOS, (self._sample_seed, self._sample_count))
             seq_scores = seq_scores + score
             loss = loss + nll.sum() / live.sum().clamp(min=1.0)
             words, sc, ss = w_t.tolist(), score.tolist(), seq_scores.tolist()

@@ -427,32 +427,3 @@ def search_step(enc, dec, store, device, instances=64, k=40, words=80):
         ms_total_one_graph_extrapolated=1e3 * dt_graph,
         extrapolated_how='one captured batch replayed, x %d (an extrapolation, not a measurement)' % (n // chunk))
     return out
-
-
-@_guard
-def persistent_decode(enc, dec, store, batch, steps, reps=10):
-    """The same rollout with the S decode steps as ONE persistent launch (csrc/sf_mega.hip,
-    FollowerEngine.persistent_decode): an experiment that is correct (tests/test_gpu_mega.py) and SLOWER than
-    the per-stage path on MI355X -- reported so that the number is in the record, never as `value`."""
-    from . import follower, _lib
-    eng = follower.FollowerEngine(enc, dec, store)
-    eng.persistent_decode = True
-    out = {}
-    with torch.no_grad():
-        st = eng.rollout(batch, steps, 'argmax', train=False)
-        if not getattr(st, 'persistent', False):
-            return dict(skipped='shape outside what the persistent decode kernel supports')
-        ref = follower.FollowerEngine(enc, dec, store).rollout(batch, steps, 'argmax', train=False)
-        torch.cuda.synchronize()
-        out['actions_equal_per_stage_path'] = bool(torch.equal(st.actions, ref.actions))
-        out['loss_abs_diff'] = abs(float(st.loss) - float(ref.loss))
-        dt = _timed(lambda: eng.rollout(batch, steps, 'argmax', train=False), 3, reps)
-        with _lib.kernel_profile(_lib.experimental()) as prof:
-            eng.rollout(batch, steps, 'argmax', train=False)
-        mk = [v for k, v in prof.rows.items() if 'mega_kernel' in k]
-    B = batch.batch_size
-    out.update(what='rollout with the decode loop as one persistent launch (opt-in experiment)',
-               ms_per_rollout=dt * 1e3, agent_steps_per_s=B * steps / dt,
-               decode_us_per_step=(mk[0]['avg_us'] / steps) if mk else None)
-    return out
-

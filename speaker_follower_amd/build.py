@@ -5,7 +5,14 @@
 
 hipcc cross-compiles without a GPU; the resulting .so is git-ignored but travels to the GPU
 box with the working tree.
+
+Staleness is decided by CONTENT, not by mtime (a checkout leaves arbitrary mtimes): every object
+carries a side file with the sha256 of its source, of every header and of the compiler flags, and
+the library itself carries `build_id()` -- the same hash over ALL sources -- as the string
+`sf_build_id()` returns.  `_lib` compares that string with the sources on disk at import and refuses a
+library that was built from different ones.
 """
+import hashlib
 import os
 import shutil
 import subprocess
@@ -18,10 +25,6 @@ OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(PKG, 'libsf_hip.so')
 ARCH = 'gfx950'
 SOURCES = ['sf_gemm.hip', 'sf_attention.hip', 'sf_pointwise.hip', 'sf_persist.hip', 'sf_nav.hip', 'sf_api.hip']
-# libsf_experimental.so (on demand, --experimental): the product's kernel objects + the persistent decode loop;
-# experimental/sf_mega_api.hip textually includes sf_api.hip, so sf_api.o is NOT linked into it
-EXP_LIB = os.path.join(PKG, 'libsf_experimental.so')
-EXP_SOURCES = ['experimental/sf_mega.hip', 'experimental/sf_mega_api.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-I' + CSRC]
 
 
@@ -32,63 +35,73 @@ def _hipcc():
     return exe
 
 
-def _deps_mtime(experimental=False):
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h')]
-    headers.append(os.path.join(os.path.dirname(PKG), 'include', 'sf_hip.h'))
-    if experimental:
-        headers += [os.path.join(CSRC, 'experimental', 'sf_mega.h'), os.path.join(CSRC, 'sf_api.hip'),
-                    os.path.join(os.path.dirname(PKG), 'include', 'sf_hip_experimental.h')]
-    return max(os.path.getmtime(h) for h in headers)
+def _headers():
+    hs = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.h'))
+    return hs + [os.path.join(os.path.dirname(PKG), 'include', 'sf_hip.h')]
 
 
-def _compile(src, force):
+def _digest(paths, extra=''):
+    h = hashlib.sha256(extra.encode())
+    for path in paths:
+        h.update(os.path.basename(path).encode() + b'\0')
+        with open(path, 'rb') as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def build_id():
+    """Hash of every source and header of the library and of the compiler flags (what sf_build_id() must return)."""
+    flags = ' '.join(f for f in FLAGS if not f.startswith('-I'))
+    return _digest([os.path.join(CSRC, s) for s in SOURCES] + _headers(), flags)
+
+
+def _compile(src, force, bid):
     obj = os.path.join(OBJ, os.path.basename(src).replace('.hip', '.o'))
     path = os.path.join(CSRC, src)
-    if (not force and os.path.exists(obj)
-            and os.path.getmtime(obj) >= max(os.path.getmtime(path), _deps_mtime('experimental' in src))):
+    flags = ' '.join(f for f in FLAGS if not f.startswith('-I'))
+    # sf_api.hip holds sf_build_id(): its object depends on the id of the whole library
+    want = _digest([path] + _headers(), flags + (bid if src == 'sf_api.hip' else ''))
+    side = obj + '.sha'
+    if not force and os.path.exists(obj) and os.path.exists(side) and open(side).read().strip() == want:
         return obj, False
-    cmd = [_hipcc()] + FLAGS + ['-c', path, '-o', obj]
+    cmd = [_hipcc()] + FLAGS + ['-DSF_BUILD_ID="%s"' % bid, '-c', path, '-o', obj]
     res = subprocess.run(cmd, capture_output=True, text=True)
     if res.returncode != 0:
         raise RuntimeError('hipcc failed for %s:\n%s\n%s' % (src, res.stdout, res.stderr))
     if res.stderr.strip():
         sys.stderr.write(res.stderr)
+    with open(side, 'w') as f:
+        f.write(want)
     return obj, True
+
+
+def lib_build_id(path=LIB):
+    """The id compiled into an existing library, read without loading it (the bytes after the marker)."""
+    if not os.path.exists(path):
+        return None
+    with open(path, 'rb') as f:
+        blob = f.read()
+    i = blob.find(b'SF_BUILD_ID=')
+    return blob[i + 12:i + 28].decode('ascii', 'replace') if i >= 0 else None
 
 
 def build_lib(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
+    bid = build_id()
     with ThreadPoolExecutor(max_workers=4) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), SOURCES))
+        results = list(ex.map(lambda s: _compile(s, force, bid), SOURCES))
     objs = [o for o, _ in results]
     rebuilt = any(r for _, r in results)
-    if rebuilt or not os.path.exists(LIB):
+    if rebuilt or lib_build_id() != bid:
         cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', LIB] + objs
         res = subprocess.run(cmd, capture_output=True, text=True)
         if res.returncode != 0:
             raise RuntimeError('link failed:\n%s\n%s' % (res.stdout, res.stderr))
+        rebuilt = True
     if verbose:
-        print('libsf_hip.so %s (%d bytes)' % ('rebuilt' if rebuilt else 'up to date',
-                                              os.path.getsize(LIB)))
+        print('libsf_hip.so %s (%d bytes, build id %s)' % ('rebuilt' if rebuilt else 'up to date',
+                                                          os.path.getsize(LIB), bid))
     return LIB
-
-
-def build_experimental(force=False, verbose=True):
-    """libsf_experimental.so: sf_follower_decode_persistent (include/sf_hip_experimental.h).  Not built by
-    __graft_entry__.build(); tests/test_gpu_mega.py and FollowerEngine.persistent_decode need it."""
-    os.makedirs(OBJ, exist_ok=True)
-    shared = [s for s in SOURCES if s != 'sf_api.hip']
-    with ThreadPoolExecutor(max_workers=4) as ex:
-        results = list(ex.map(lambda s: _compile(s, force), shared + EXP_SOURCES))
-    objs = [o for o, _ in results]
-    if any(r for _, r in results) or not os.path.exists(EXP_LIB):
-        cmd = [_hipcc(), '--offload-arch=' + ARCH, '-shared', '-fPIC', '-o', EXP_LIB] + objs
-        res = subprocess.run(cmd, capture_output=True, text=True)
-        if res.returncode != 0:
-            raise RuntimeError('link failed:\n%s\n%s' % (res.stdout, res.stderr))
-    if verbose:
-        print('libsf_experimental.so (%d bytes)' % os.path.getsize(EXP_LIB))
-    return EXP_LIB
 
 
 def build_sim(force=False, verbose=True):
@@ -119,5 +132,3 @@ def build_sim(force=False, verbose=True):
 if __name__ == '__main__':
     build_lib(force='--force' in sys.argv)
     build_sim(force='--force' in sys.argv)
-    if '--experimental' in sys.argv:
-        build_experimental(force='--force' in sys.argv)

@@ -409,6 +409,17 @@ extern "C" {
 
 size_t sf_workspace_bytes(void) { return WORKSPACE_BYTES; }
 int sf_abi_version(void) { return SF_ABI_VERSION; }
+#ifndef SF_BUILD_ID
+#define SF_BUILD_ID "unknown"
+#endif
+// (the marker in front of the id lets build.py read it from the file without loading the library)
+const char* sf_build_id(void) { static const char id[] = "SF_BUILD_ID=" SF_BUILD_ID; return id + 12; }
+void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; }
+size_t sf_workspace_fault_offset(size_t ws_bytes) {
+    const size_t n = ws_bytes / 4;
+    if (n <= SYNC_WORDS) return 0;
+    return (n - SYNC_WORDS + PERSIST_TICKET + persistent_fault_word()) * 4;
+}
 const char* sf_last_error_string(void) { return hipGetErrorString(g_last_hip_error); }
 const char* sf_status_string(int s) {
     switch (s) {
@@ -1424,11 +1435,12 @@ int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab
                       int pad_idx, int eos_idx, const int64_t* targets, const float* h_init,
                       const float* c_init, const float* ctx, const uint8_t* ctx_mask, int64_t* words,
                       uint8_t* ended, float* step_scores, float* nll_term, float* live, float* logits,
-                      float* alpha, float* h1_tape, float* c1_tape, void* ws, size_t ws_bytes,
-                      sf_stream stream) {
+                      float* alpha, float* h1_tape, float* c1_tape, const sf_sample* sample, void* ws,
+                      size_t ws_bytes, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(w && targets && h_init && c_init && ctx && words && ended && step_scores && nll_term && live &&
-                 B > 0 && n_steps > 0 && Tp > 0 && (feedback == 0 || feedback == 1) && (!h1_tape == !c1_tape));
+                 B > 0 && n_steps > 0 && Tp > 0 && feedback >= 0 && feedback <= 2 && (feedback != 2 || sample) &&
+                 (!h1_tape == !c1_tape));
     if (!w->xw_table || !w->attn.w_in_t || !speaker_persistent_supported(B, H, Tp, vocab)) return SF_ERR_UNSUPPORTED;
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
@@ -1443,7 +1455,7 @@ int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab
     return speaker_persistent(w->lstm.w_hh, w->lstm.b_ih, w->lstm.b_hh, w->xw_table, w->attn.w_out, 2 * H, w->w_out,
                               w->b_out, vocab, ldv, cq, cw, ctx_mask, h_init, c_init, targets, feedback, pad_idx,
                               eos_idx, B, H, Tp, n_steps, words, step_scores, nll_term, live, logits, alpha, h1_tape,
-                              c1_tape, ended, xchg, ar.tickets() + PERSIST_TICKET, st);
+                              c1_tape, ended, xchg, ar.tickets() + PERSIST_TICKET, st, sample);
 }
 
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H,
@@ -1476,12 +1488,19 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
 
 int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
-                        float* score, float* nll_term, float* live, sf_stream stream) {
+                        float* score, float* nll_term, float* live, const sf_sample* sample, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(logit && target && ended && w_t && score && nll_term && live && B > 0 &&
-                 vocab > 0 && ldv >= vocab);
+                 vocab > 0 && ldv >= vocab && feedback >= 0 && feedback <= 2 && (feedback != 2 || sample));
     return speaker_glue_fwd(B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t,
-                            score, nll_term, live, S(stream));
+                            score, nll_term, live, S(stream), sample);
+}
+
+int sf_speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos_idx, int T, int B, float* loss,
+                             float* gscale, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(sum_cnt && words && loss && gscale && T > 0 && B > 0);
+    return speaker_loss_finalize(sum_cnt, words, eos_idx, T, B, loss, gscale, S(stream));
 }
 
 int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,

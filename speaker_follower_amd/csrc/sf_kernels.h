@@ -43,6 +43,8 @@ int lstm_step_fused(const LstmStepArgs& p, hipStream_t st);      // sf_gemm.hip
 
 extern unsigned long long* g_trace;   // sf_debug_trace buffer (development aid), null = off
 extern int g_force_sc1;               // sf_debug_force_write_through
+extern long long g_persist_timeout;   // sf_debug_persist_timeout (ticks of 10 ns; < 0 = default 0.25 s)
+size_t persistent_fault_word();       // dword index, behind the persistent launches' ticket word, of the fault word
 
 unsigned* persist_lock_addr();         // the device-wide lock of every persistent launch (sf_persist.hip)
 
@@ -64,7 +66,7 @@ int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
                        const float* c_init, const int64_t* targets, int feedback, int pad, int eos, int B, int H,
                        int Tp, int S, int64_t* words, float* step_scores, float* nll_term, float* live,
                        float* logits, float* alpha, float* h1_tape, float* c1_tape, uint8_t* ended, float* xchg,
-                       unsigned* done, hipStream_t st);
+                       unsigned* done, hipStream_t st, const sf_sample* sample = nullptr);
 // the backward recurrence (all T steps of lstm_bwd_step_fused): dgates [T,B,4H] out
 size_t encoder_bwd_persistent_xchg_floats();
 int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, int T, const float* gates,
@@ -158,7 +160,9 @@ int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* targ
                    const float* gscale, float* dlogit, hipStream_t st);
 int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                      int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
-                     float* score, float* nll_term, float* live, hipStream_t st);
+                     float* score, float* nll_term, float* live, hipStream_t st, const sf_sample* sample = nullptr);
+int speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos, int T, int B, float* loss, float* gscale,
+                          hipStream_t st);
 int reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
                  hipStream_t st);
 int loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, hipStream_t st);

@@ -23,10 +23,12 @@
 // taken in the prologue kernel and released by the last workgroup.
 #include "sf_kernels.h"
 #include "sf_gemm_small.h"
+#include "sf_sampling.h"
 
 namespace sf {
 unsigned long long* g_trace = nullptr;     // sf_debug_trace buffer (set in sf_attention.hip)
 int g_force_sc1 = 0;                       // sf_debug_force_write_through: never take the one-XCD fast path
+long long g_persist_timeout = -1;          // sf_debug_persist_timeout: wait bound in 10 ns ticks, < 0 = the default
 namespace {
 
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
@@ -36,10 +38,20 @@ constexpr int EP_SLOTS = 32;               // workgroups per group: 16 hidden un
 constexpr int EP_ROWS = 16;                // rows per group (one MFMA m-tile)
 constexpr int EP_TMAX = 128;
 constexpr unsigned EP_SENTINEL = 0xFFFFFFFFu;
-constexpr long long EP_TIMEOUT_TICKS = 25000000LL;   // 0.25 s of the 100 MHz wall clock
+constexpr long long EP_TIMEOUT_TICKS = 25000000LL;   // 0.25 s of the 100 MHz wall clock (default)
 constexpr int AUX_SC1 = 16;                // cache-policy bit 4: agent scope (bypass L1 / write through)
 
 __device__ unsigned g_persist_lock = 0;
+
+// The workspace's fault word (`done` + EP_FAULT_WORD; sf_workspace_fault_offset): every wait that gives up ORs
+// its launch's code into it.  The NaN poisoning below makes a starved launch visible in its outputs; the fault
+// word makes it visible to the HOST, which reads it at its next sync and re-issues the pass on the per-step
+// kernels (runtime.take_fault, FollowerEngine.run / SpeakerEngine.run).
+constexpr int EP_FAULT_WORD = 40;
+constexpr unsigned FAULT_ENC_FWD = 1u, FAULT_ENC_BWD = 2u, FAULT_SPK = 4u, FAULT_LOCK = 8u;
+__device__ __forceinline__ void raise_fault(unsigned* fault, unsigned code) {
+    if ((threadIdx.x & 63) == __ffsll((long long)__ballot(1)) - 1) atomicOr(fault, code);   // one lane per wave
+}
 
 // Per-launch placement record of one row group: [0] arrivals, [1] min XCC id, [2] max XCC id
 // (initialised by the prologue kernel).  EP_PLACE_WORDS dwords per group.
@@ -76,9 +88,20 @@ __device__ __forceinline__ bool group_on_one_xcd(unsigned* place, int grp) {
     return s_fast != 0;
 }
 
+__device__ __forceinline__ void take_persist_lock(unsigned* fault, long long timeout) {
+    const long long t0 = wall_clock64();
+    while (atomicCAS(&g_persist_lock, 0u, 1u) != 0u) {
+        __builtin_amdgcn_s_sleep(32);
+        if (wall_clock64() - t0 > 8 * timeout) {          // a lost unlock must not hang the stream
+            atomicOr(fault, FAULT_LOCK);
+            break;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void enc_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, float* h0,
                                                                    float* c0, size_t n_state, unsigned* place,
-                                                                   int force_sc1) {
+                                                                   int force_sc1, unsigned* fault, long long timeout) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x, force_sc1);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_xchg; i += stride) xchg[i] = EP_SENTINEL;
@@ -86,13 +109,7 @@ __global__ __launch_bounds__(256) void enc_persist_prologue_kernel(unsigned* xch
         h0[i] = 0.f;                       // model.py:67-79 init_state
         c0[i] = 0.f;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        while (atomicCAS(&g_persist_lock, 0u, 1u) != 0u) {
-            __builtin_amdgcn_s_sleep(32);
-            if (wall_clock64() - t0 > 8 * EP_TIMEOUT_TICKS) break;   // a lost unlock must not hang the stream
-        }
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) take_persist_lock(fault, timeout < 0 ? EP_TIMEOUT_TICKS : timeout);
 }
 
 // 16-byte store into an exchange buffer: plain (stays in the XCD's L2) when the group shares an XCD,
@@ -117,6 +134,7 @@ struct EncPersistArgs {
     unsigned* xchg;                                            // [8][3][16][H] dwords, sentinel-filled
     unsigned* done;                                            // arrival counter (0 before and after)
     unsigned* place;                                           // placement record (group_on_one_xcd)
+    unsigned* fault; long long timeout;                        // fault word, wait bound (ticks)
     unsigned long long* trace;                                 // sf_debug_trace: [blocks][8] tick sums, or null
 };
 
@@ -206,8 +224,9 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
                         ok = ok && a[j][cc].x != EP_SENTINEL && a[j][cc].y != EP_SENTINEL &&
                              a[j][cc].z != EP_SENTINEL && a[j][cc].w != EP_SENTINEL;
                 if (__all(ok) || dead) break;
-                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) {
+                if (wall_clock64() - t0 >= p.timeout) {
                     dead = true;
+                    raise_fault(p.fault, FAULT_ENC_FWD);
                     break;
                 }
             }
@@ -353,6 +372,7 @@ struct EncBwdPersistArgs {
     unsigned* xchg;                               // [8][2][32 dest][32 src][256] dwords, sentinel-filled
     unsigned* done;
     unsigned* place;
+    unsigned* fault; long long timeout;
     unsigned long long* trace;
 };
 constexpr int EB_LDA = 68;                        // LDS row stride of the [16 x 64] dgates tile
@@ -417,8 +437,9 @@ __global__ __launch_bounds__(256, 2) void enc_bwd_persist_kernel(EncBwdPersistAr
 #pragma unroll
                 for (int c = 0; c < EP_SLOTS; ++c) ok = ok && v[c] != EP_SENTINEL;
                 if (__all(ok) || dead_wg) break;
-                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) {
+                if (wall_clock64() - t0 >= p.timeout) {
                     dead_wg = true;
+                    raise_fault(p.fault, FAULT_ENC_BWD);
                     break;
                 }
             }
@@ -507,19 +528,13 @@ __global__ __launch_bounds__(256, 2) void enc_bwd_persist_kernel(EncBwdPersistAr
 
 // sentinel fill + device-wide lock of the backward launch (no state to zero)
 __global__ __launch_bounds__(256) void enc_bwd_persist_prologue_kernel(unsigned* xchg, size_t n_xchg, unsigned* place,
-                                                                       int force_sc1) {
+                                                                       int force_sc1, unsigned* fault, long long timeout) {
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     place_init(place, (size_t)blockIdx.x * blockDim.x + threadIdx.x, force_sc1);
     v4u* x4 = reinterpret_cast<v4u*>(xchg);
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_xchg / 4; i += stride)
         x4[i] = v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL};
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        const long long t0 = wall_clock64();
-        while (atomicCAS(&g_persist_lock, 0u, 1u) != 0u) {
-            __builtin_amdgcn_s_sleep(32);
-            if (wall_clock64() - t0 > 8 * EP_TIMEOUT_TICKS) break;
-        }
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) take_persist_lock(fault, timeout < 0 ? EP_TIMEOUT_TICKS : timeout);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -540,7 +555,8 @@ constexpr int SPX_H1 = 0;                                     // [16][512]
 constexpr int SPX_PS = EP_ROWS * 512;                         // [32 src][16][SP_TPMAX]
 constexpr int SPX_HT = SPX_PS + EP_SLOTS * EP_ROWS * SP_TPMAX;   // [16][512]
 constexpr int SPX_ST = SPX_HT + EP_ROWS * 512;                // [32 src][16][4]
-constexpr int SPX_BUF = SPX_ST + EP_SLOTS * EP_ROWS * 4;      // dwords per (group, buffer)
+constexpr int SPX_SS = SPX_ST + EP_SLOTS * EP_ROWS * 4;       // [32 src][16][2]: `sample` feedback only
+constexpr int SPX_BUF = SPX_SS + EP_SLOTS * EP_ROWS * 2;      // dwords per (group, buffer)
 
 struct SpkPersistArgs {
     const float* w_hh; const float* b_ih; const float* b_hh; const float* xw_table;
@@ -551,12 +567,14 @@ struct SpkPersistArgs {
     const float* h_init; const float* c_init;
     const int64_t* targets;                                   // [S,B]
     int feedback, pad, eos;
+    uint32_t sample_seed, sample_stream; int sample_row0;     // feedback 2 (speaker.py:170-174): counter-based draws
     int B, H, Tp, S, rpg;
     int64_t* words;                                           // [S+1,B], row 0 given
     float* step_scores; float* nll_term; float* live;         // [S,B]
     float* logits; float* alpha; float* h1_tape; float* c1_tape;   // optional tapes
     uint8_t* ended;
     unsigned* xchg; unsigned* done; unsigned* place;
+    unsigned* fault; long long timeout;
     unsigned long long* trace;
 };
 
@@ -572,13 +590,32 @@ __device__ __forceinline__ float row16_sum(float v) {          // over the 16 la
     for (int off = 8; off > 0; off >>= 1) v += __shfl_xor(v, off, 16);
     return v;
 }
-__device__ __forceinline__ float wexp(float m, float mm) { return m == -INFINITY ? 0.f : expf(m - mm); }
 __device__ __forceinline__ float row16_max(float v) {
 #pragma unroll
     for (int off = 8; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 16));
     return v;
 }
+__device__ __forceinline__ int row16_min(int v) {
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) v = min(v, __shfl_xor(v, off, 16));
+    return v;
+}
+// Inverse-CDF pick over 32 weights held two per lane by the 16 lanes of a row (lane eu: items eu and eu + 16, in
+// item order): the first item whose inclusive prefix sum exceeds `thr` and whose weight is positive, INT_MAX if none
+// (thr rounded up to the total).  This is sf_sampling.h's two-level draw with the slots spread over workgroups.
+__device__ __forceinline__ int row16_pick32(float w0, float w1, float thr, int eu) {
+    float c0 = w0, c1 = w1;
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) {
+        const float v0 = __shfl_up(c0, off, 16), v1 = __shfl_up(c1, off, 16);
+        if (eu >= off) { c0 += v0; c1 += v1; }
+    }
+    c1 += __shfl(c0, 15, 16);
+    const int cand = (c0 > thr && w0 > 0.f) ? eu : ((c1 > thr && w1 > 0.f) ? eu + 16 : 0x7FFFFFFF);
+    return row16_min(cand);
+}
 
+template <bool SAMPLING>      // `sample` feedback (speaker.py:170-174): one more pair of dwords in the statistics exchange
 __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
     __shared__ float s_part[4][5][256];
     __shared__ float s_voc[4][2][256];
@@ -714,7 +751,7 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
 #pragma unroll
                 for (int c = 0; c < EP_SLOTS; ++c) ok = ok && sc[c] != EP_SENTINEL;
                 if (__all(ok) || dead) break;
-                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) { dead = true; break; }
+                if (wall_clock64() - t0 >= p.timeout) { dead = true; raise_fault(p.fault, FAULT_SPK); break; }
             }
         }
         EP_STAMP(1)                                      // wait for h1 + scores
@@ -730,9 +767,14 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
         // statistics rows: phase H of step t-1 has no workgroup barrier behind it, and what this wave has
         // seen (the partial scores of rows [4w, 4w+4) from all 32 slots) proves only that WAVE w of every
         // workgroup is past it -- those waves are the only readers of rows [4w, 4w+4) of this block
-        if (lane < 4)
+        if (lane < 4) {
             xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
                    (bn + SPX_ST + (unsigned)((slot * EP_ROWS + 4 * w + lane) * 4)) * 4u);
+            if (SAMPLING) {
+                xstore32(local, EP_SENTINEL, rs, (bn + SPX_SS + (unsigned)((slot * EP_ROWS + 4 * w + lane) * 2)) * 4u);
+                xstore32(local, EP_SENTINEL, rs, (bn + SPX_SS + (unsigned)((slot * EP_ROWS + 4 * w + lane) * 2 + 1)) * 4u);
+            }
+        }
         // attention weights of row er: lane eu holds path step eu (model.py:131-137)
         float alpha_l;
         {
@@ -812,7 +854,7 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
                 for (int i = 0; i < 8; ++i)
                     ok = ok && av[i].x != EP_SENTINEL && av[i].y != EP_SENTINEL && av[i].z != EP_SENTINEL && av[i].w != EP_SENTINEL;
                 if (__all(ok) || dead) break;
-                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) { dead = true; break; }
+                if (wall_clock64() - t0 >= p.timeout) { dead = true; raise_fault(p.fault, FAULT_SPK); break; }
             }
             EP_STAMP(4)                                  // wait for h~
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
@@ -853,30 +895,57 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
                 const int oa = __shfl_xor(am, off, 16);
                 if (om > m || (om == m && oa < am)) { m = om; am = oa; }
             }
-            const float se = row16_sum((col0 < vocab ? expf(l0 - m) : 0.f) + (col1 < vocab ? expf(l1 - m) : 0.f));
+            const float e0 = col0 < vocab ? expf(l0 - m) : 0.f, e1 = col1 < vocab ? expf(l1 - m) : 0.f;
+            const float se = row16_sum(e0 + e1);
             const float tl = row16_sum((col0 == tgt ? l0 : 0.f) + (col1 == tgt ? l1 : 0.f));
             if (eu == 0)
                 xstore(local, v4u{__float_as_uint(m), (unsigned)am, __float_as_uint(se), __float_as_uint(tl)}, rs,
                        (bo + SPX_ST + (unsigned)((slot * EP_ROWS + er) * 4)) * 4u);
+            if (SAMPLING) {
+                // speaker.py:170-174 (Categorical(probs).sample()), two-level: THIS workgroup's draw given that the
+                // word falls into its 32 columns (second uniform of the row); which workgroup's draw counts is
+                // decided in phase H from the first uniform and the published masses (sf_sampling.h)
+                float u1, u2;
+                sample_uniforms(p.sample_seed, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
+                const int it = row16_pick32(e0, e1, u2 * se, eu);
+                const int sc_ = it != 0x7FFFFFFF ? 32 * slot + it : min(32 * slot + 31, vocab - 1);
+                const float sl_ = row16_sum((sc_ == col0 ? l0 : 0.f) + (sc_ == col1 ? l1 : 0.f));
+                if (eu == 0) {
+                    xstore32(local, (unsigned)sc_, rs, (bo + SPX_SS + (unsigned)((slot * EP_ROWS + er) * 2)) * 4u);
+                    xstore32(local, __float_as_uint(sl_), rs, (bo + SPX_SS + (unsigned)((slot * EP_ROWS + er) * 2 + 1)) * 4u);
+                }
+            }
         }
         gate_pair(2);                                    // D2b: under the exchange of the statistics
         EP_STAMP(5)                                      // vocabulary MFMA + statistics + publish + gate tiles
         // ---- H. combine the 32 workgroups' statistics: every lane of row er learns the word
-        float M, Z, tlog;
-        int arg;
+        float M, Z, tlog, slog = 0.f;
+        int arg, sarg = 0;
         {
             v4u s0, s1;
+            unsigned q0c = 0, q0l = 0, q1c = 0, q1l = 0;            // `sample`: (column, logit) drawn by slots eu, eu + 16
             const unsigned sb0 = (bo + SPX_ST + (unsigned)((eu * EP_ROWS + er) * 4)) * 4u;
             const unsigned sb1 = (bo + SPX_ST + (unsigned)(((eu + 16) * EP_ROWS + er) * 4)) * 4u;
+            const unsigned qb0 = (bo + SPX_SS + (unsigned)((eu * EP_ROWS + er) * 2)) * 4u;
+            const unsigned qb1 = (bo + SPX_SS + (unsigned)(((eu + 16) * EP_ROWS + er) * 2)) * 4u;
+            constexpr bool sampling = SAMPLING;
             const long long t0 = wall_clock64();
             for (;;) {
                 asm volatile("" ::: "memory");
                 s0 = __builtin_amdgcn_raw_buffer_load_b128(rs, sb0, 0, AUX_SC1);
                 s1 = __builtin_amdgcn_raw_buffer_load_b128(rs, sb1, 0, AUX_SC1);
-                const bool ok = s0.x != EP_SENTINEL && s0.z != EP_SENTINEL && s1.x != EP_SENTINEL && s1.z != EP_SENTINEL &&
+                if (sampling) {                              // (compile-time: no load under a run-time branch)
+                    q0c = __builtin_amdgcn_raw_buffer_load_b32(rs, qb0, 0, AUX_SC1);
+                    q0l = __builtin_amdgcn_raw_buffer_load_b32(rs, qb0 + 4u, 0, AUX_SC1);
+                    q1c = __builtin_amdgcn_raw_buffer_load_b32(rs, qb1, 0, AUX_SC1);
+                    q1l = __builtin_amdgcn_raw_buffer_load_b32(rs, qb1 + 4u, 0, AUX_SC1);
+                }
+                const bool qok = !sampling || (q0c != EP_SENTINEL && q0l != EP_SENTINEL && q1c != EP_SENTINEL && q1l != EP_SENTINEL);
+                const bool ok = qok &&
+                                s0.x != EP_SENTINEL && s0.z != EP_SENTINEL && s1.x != EP_SENTINEL && s1.z != EP_SENTINEL &&
                                 s0.w != EP_SENTINEL && s1.w != EP_SENTINEL && s0.y != EP_SENTINEL && s1.y != EP_SENTINEL;
                 if (__all(ok) || dead) break;
-                if (wall_clock64() - t0 > EP_TIMEOUT_TICKS) { dead = true; break; }
+                if (wall_clock64() - t0 >= p.timeout) { dead = true; raise_fault(p.fault, FAULT_SPK); break; }
             }
             float m0 = __uint_as_float(s0.x), m1 = __uint_as_float(s1.x);
             int a0 = (int)s0.y, a1 = (int)s1.y;
@@ -900,12 +969,23 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
             const int ts = (int)min(max(tgt, 0LL), (long long)vocab - 1) >> 5;        // workgroup that owns the target column
             const float mine = (ts & 16) ? __uint_as_float(s1.w) : __uint_as_float(s0.w);
             tlog = __shfl(mine, (lane & 48) + (ts & 15), 64);
+            if (sampling) {
+                // which workgroup's draw counts: inverse CDF over the 32 masses z_s exp(m_s - M) with the row's first uniform
+                float u1, u2;
+                sample_uniforms(p.sample_seed, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
+                int cs = row16_pick32(z0 * wexp(m0, M), z1 * wexp(m1, M), u1 * Z, eu);
+                if (cs == 0x7FFFFFFF) cs = arg >> 5;                                 // u1 Z rounded up to the total
+                const unsigned qc = (cs & 16) ? q1c : q0c, ql = (cs & 16) ? q1l : q0l;
+                sarg = (int)__shfl(qc, (lane & 48) + (cs & 15), 64);
+                slog = __uint_as_float(__shfl(ql, (lane & 48) + (cs & 15), 64));
+            }
         }
         EP_STAMP(6)                                      // wait for the statistics + combine
         const float lse = M + logf(Z);
         // (a starved launch may hold the sentinel in `arg`: the word fed back must stay a table row)
-        const long long wt = dead ? (long long)p.pad : (p.feedback == 0 ? tgt : (long long)arg);
-        const float lw = p.feedback == 0 ? tlog : M;
+        const long long wt = dead ? (long long)p.pad
+                                  : (SAMPLING ? (long long)sarg : (p.feedback == 0 ? tgt : (long long)arg));
+        const float lw = SAMPLING ? slog : (p.feedback == 0 ? tlog : M);
         if (slot == 0 && eu == 0 && evalid) {
             const size_t o = (size_t)t * B + eb;
             p.words[(size_t)(t + 1) * B + eb] = wt;
@@ -970,6 +1050,7 @@ unsigned* persist_lock_addr() {
     return cached;
 }
 
+size_t persistent_fault_word() { return EP_FAULT_WORD; }
 size_t encoder_persistent_xchg_floats(int H) { return (size_t)EP_GROUPS * 3 * EP_ROWS * H; }
 
 bool encoder_persistent_supported(int B, int H, int T) {
@@ -987,8 +1068,9 @@ int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
     a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
     a.gates = gates; a.hs = hs; a.cs = cs; a.ctx = ctx; a.ld_ctx = T * H; a.ctx_drop = ctx_drop; a.c_out = c_out;
     a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
+    a.fault = done + EP_FAULT_WORD; a.timeout = g_persist_timeout < 0 ? EP_TIMEOUT_TICKS : g_persist_timeout;
     SF_LAUNCH(enc_persist_prologue_kernel, dim3(96), dim3(256), 0, st, a.xchg, encoder_persistent_xchg_floats(H),
-              hs, cs, (size_t)B * H, a.place, g_force_sc1);
+              hs, cs, (size_t)B * H, a.place, g_force_sc1, a.fault, g_persist_timeout);
     SF_LAUNCH(enc_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }
@@ -1005,8 +1087,9 @@ int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
                        const float* c_init, const int64_t* targets, int feedback, int pad, int eos, int B, int H,
                        int Tp, int S, int64_t* words, float* step_scores, float* nll_term, float* live,
                        float* logits, float* alpha, float* h1_tape, float* c1_tape, uint8_t* ended, float* xchg,
-                       unsigned* done, hipStream_t st) {
+                       unsigned* done, hipStream_t st, const sf_sample* sample) {
     if (!speaker_persistent_supported(B, H, Tp, vocab) || !xchg || !done || !xw_table) return SF_ERR_UNSUPPORTED;
+    if (feedback == 2 && !sample) return SF_ERR_ARG;
     SpkPersistArgs a{};
     a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.xw_table = xw_table; a.w_out = w_out; a.ld_wout = ld_wout;
     a.w_d2a = w_d2a; a.b_d2a = b_d2a; a.vocab = vocab; a.ldv = ldv; a.cq = cq; a.cw = cw; a.mask = mask;
@@ -1015,9 +1098,14 @@ int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
     a.step_scores = step_scores; a.nll_term = nll_term; a.live = live; a.logits = logits; a.alpha = alpha;
     a.h1_tape = h1_tape; a.c1_tape = c1_tape; a.ended = ended; a.xchg = reinterpret_cast<unsigned*>(xchg);
     a.done = done; a.place = done + 4; a.trace = g_trace;
+    a.fault = done + EP_FAULT_WORD; a.timeout = g_persist_timeout < 0 ? EP_TIMEOUT_TICKS : g_persist_timeout;
+    if (sample) { a.sample_seed = sample->seed; a.sample_stream = sample->stream; a.sample_row0 = sample->row0; }
     SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(256), dim3(256), 0, st, a.xchg, speaker_persistent_xchg_floats(),
-              a.place, g_force_sc1);
-    SF_LAUNCH(spk_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
+              a.place, g_force_sc1, a.fault, g_persist_timeout);
+    if (feedback == 2)
+        SF_LAUNCH_AS("spk_persist_kernel<sample>", spk_persist_kernel<true>, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
+    else
+        SF_LAUNCH_AS("spk_persist_kernel", spk_persist_kernel<false>, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }
 
@@ -1031,8 +1119,9 @@ int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, 
     a.w_hh = w_hh; a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
     a.gates = gates; a.cs = cs; a.dctx = dctx; a.ctx_drop = ctx_drop; a.dh_in = dh_in; a.dc_in = dc_in;
     a.dgates = dgates; a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
+    a.fault = done + EP_FAULT_WORD; a.timeout = g_persist_timeout < 0 ? EP_TIMEOUT_TICKS : g_persist_timeout;
     SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(512), dim3(256), 0, st, a.xchg, encoder_bwd_persistent_xchg_floats(),
-              a.place, g_force_sc1);
+              a.place, g_force_sc1, a.fault, g_persist_timeout);
     SF_LAUNCH(enc_bwd_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }

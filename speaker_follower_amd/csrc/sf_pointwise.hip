@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cmath>
 #include "sf_glue.h"
+#include "sf_sampling.h"
 
 namespace sf {
 
@@ -457,7 +458,53 @@ struct SGlue {
     float* score;
     float* nll_term;
     float* live;
+    uint32_t sample_seed, sample_stream; int sample_row0;     // feedback 2
 };
+// feedback 2 (speaker.py:170-174): the two-level draw of sf_sampling.h by one wave.  Lane l holds columns
+// [16 l, 16 l + 16); slot s = lanes 2 s, 2 s + 1.  m = the row's max, am its arg max.  Returns the word.
+__device__ __forceinline__ int speaker_sample_row(const SGlue& g, const float* row, int b, float m, int am) {
+    const int lane = threadIdx.x & 63;
+    float x[16], e[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) x[j] = row[min(16 * lane + j, g.vocab - 1)];
+    float ml = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ml = 16 * lane + j < g.vocab ? fmaxf(ml, x[j]) : ml;
+    const float ms = fmaxf(ml, __shfl_xor(ml, 1, WAVE));
+    float sl = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        e[j] = 16 * lane + j < g.vocab ? expf(x[j] - ms) : 0.f;
+        sl += e[j];
+    }
+    const float so = __shfl_xor(sl, 1, WAVE);
+    const float zs = (lane & 1) ? so + sl : sl + so;
+    float u1, u2;
+    sample_uniforms(g.sample_seed, g.sample_stream, (uint32_t)(g.sample_row0 + b), &u1, &u2);
+    // level 2: this slot's column
+    const float thr2 = u2 * zs;
+    float cum = (lane & 1) ? so : 0.f;
+    int pick = 0x7FFFFFFF;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        cum += e[j];
+        if (pick == 0x7FFFFFFF && cum > thr2 && e[j] > 0.f) pick = 16 * lane + j;
+    }
+    pick = min(pick, __shfl_xor(pick, 1, WAVE));
+    if (pick == 0x7FFFFFFF) pick = min(32 * (lane >> 1) + 31, g.vocab - 1);
+    // level 1: the slot
+    const float ps = (lane & 1) ? 0.f : zs * wexp(ms, m);
+    float cdf = ps;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const float v = __shfl_up(cdf, off, WAVE);
+        if (lane >= off) cdf += v;
+    }
+    const float Z = __shfl(cdf, 63, WAVE);
+    const unsigned long long hit = __ballot(ps > 0.f && cdf > u1 * Z);
+    const int sl_lane = hit ? (int)__ffsll((long long)hit) - 1 : 2 * (am >> 5);
+    return __shfl(pick, sl_lane, WAVE);
+}
 __global__ __launch_bounds__(TPB) void speaker_glue_kernel(SGlue g) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
@@ -494,9 +541,15 @@ __global__ __launch_bounds__(TPB) void speaker_glue_kernel(SGlue g) {
     for (int i = 0; i < NV; ++i) s += (lane + 64 * i < g.vocab) ? expf(v[i] - m) : 0.f;
     for (int n = lane + 64 * NV; n < g.vocab; n += 64) s += expf(row[n] - m);
     const float lse = m + logf(wave_sum(s));
+    int ws = 0;
+    float lws = 0.f;
+    if (g.feedback == 2) {                                       // block-uniform
+        ws = speaker_sample_row(g, row, b, m, am);
+        lws = row[ws];
+    }
     if (lane == 0) {
-        const int64_t w = g.feedback == 0 ? tgt : (int64_t)am;
-        const float lw = g.feedback == 0 ? ltgt : m;            // logit of the chosen word
+        const int64_t w = g.feedback == 0 ? tgt : (g.feedback == 1 ? (int64_t)am : (int64_t)ws);
+        const float lw = g.feedback == 0 ? ltgt : (g.feedback == 1 ? m : lws);   // logit of the chosen word
         g.w_t[b] = w;
         g.score[b] = (w != g.pad_idx) ? lw - lse : 0.f;          // speaker.py:179-180 (per-step term)
         const bool lv = tgt != g.pad_idx;
@@ -536,6 +589,58 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const float* sum_cnt,
         for (int j = 0; j < n; ++j) acc += __shfl(v, j, WAVE);
     }
     if (lane == 0) loss[0] = acc;
+}
+
+// The speaker's loss (speaker.py:182, 192-197): the per-step means are added only up to and including the first step
+// at which EVERY row has produced EOS (`if ended.all(): break` sits behind the step's loss).  words [T+1,B] (row 0 =
+// the start tokens).  One block of 1024 threads: thread (b mod .., t) finds each row's first EOS step by a min over
+// steps, the block takes the max over rows, wave 0 adds the step means in step order (the float32 sum of a serial
+// loop) and zeroes gscale behind the last step (no gradient flows from steps the reference never adds).
+__global__ __launch_bounds__(1024) void speaker_loss_finalize_kernel(const float* sum_cnt, const int64_t* words, int eos,
+                                                                     int T, int B, float* loss, float* gscale) {
+    __shared__ int s_first[1024];
+    __shared__ int s_end;
+    const int tid = threadIdx.x;
+    // per row (one wave each, 16 rows at a time) the first step whose word is EOS, T - 1 if there is none
+    int t_end = 0;
+    for (int b0 = 0; b0 < B; b0 += 1024 / 64) {                 // 16 rows at a time, one wave per row
+        const int b = b0 + (tid >> 6), lane = tid & 63;
+        int first = T - 1;                                      // never ended: the loop runs all T steps
+        if (b < B) {
+            int f = 0x7FFFFFFF;
+            for (int t = lane; t < T; t += 64)
+                if (words[(size_t)(t + 1) * B + b] == eos) { f = t; break; }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) f = min(f, __shfl_xor(f, off, WAVE));
+            if (f != 0x7FFFFFFF) first = f;
+        } else {
+            first = 0;
+        }
+        t_end = max(t_end, first);
+    }
+    s_first[tid] = t_end;
+    __syncthreads();
+    if (tid == 0) {
+        int e = 0;
+        for (int i = 0; i < 1024; i += 64) e = max(e, s_first[i]);
+        s_end = e;
+    }
+    __syncthreads();
+    const int last = s_end;                                      // steps 0 .. last are added
+    if (tid < 64) {
+        const int lane = tid;
+        float acc = 0.f;
+        for (int base = 0; base < T; base += 64) {
+            const int t = base + lane;
+            const float2 sc = t < T ? reinterpret_cast<const float2*>(sum_cnt)[t] : make_float2(0.f, 0.f);
+            const bool in = t <= last;
+            const float v = (in && sc.y > 0.f) ? sc.x / sc.y : 0.f;
+            if (t < T) gscale[t] = (in && sc.y > 0.f) ? 1.f / sc.y : 0.f;
+            const int n = min(64, T - base);
+            for (int j = 0; j < n; ++j) acc += __shfl(v, j, WAVE);
+        }
+        if (lane == 0) loss[0] = acc;
+    }
 }
 
 // torch.optim.Adam.step() (train.py:263-268: lr 1e-4, weight_decay 5e-4 as L2-in-gradient, default
@@ -746,15 +851,22 @@ int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* targ
 }
 int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                      int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
-                     float* score, float* nll_term, float* live, hipStream_t st) {
+                     float* score, float* nll_term, float* live, hipStream_t st, const sf_sample* sample) {
+    if (feedback == 2 && (!sample || vocab > 1024)) return feedback == 2 && !sample ? SF_ERR_ARG : SF_ERR_UNSUPPORTED;
     SGlue g{B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t, score, nll_term,
-            live};
+            live, sample ? sample->seed : 0u, sample ? sample->stream : 0u, sample ? sample->row0 : 0};
     SF_LAUNCH(speaker_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
     return launch_status();
 }
 int reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,
                  hipStream_t st) {
     SF_LAUNCH(reduce_terms_kernel, dim3(T), dim3(64), 0, st, term, live, B, sum_cnt);
+    return launch_status();
+}
+int speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos, int T, int B, float* loss, float* gscale,
+                          hipStream_t st) {
+    if (T > 1024) return SF_ERR_UNSUPPORTED;
+    SF_LAUNCH(speaker_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sum_cnt, words, eos, T, B, loss, gscale);
     return launch_status();
 }
 int loss_finalize(const float* sum_cnt, int T, float* loss, float* gscale, hipStream_t st) {

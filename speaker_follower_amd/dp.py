@@ -23,6 +23,18 @@ Gradients are SUMMED, not averaged: each rank's loss already carries the global 
 import torch
 import torch.distributed as dist
 
+# Test switch (bench.py --force-collectives, tests/rccl_worker.py): issue every collective even in a process group of
+# ONE rank.  A one-rank run cannot give a scaling curve, but it executes the real RCCL path on the real GPU -- library
+# load, `init_process_group('nccl', device_id=...)`, the stream semantics of async all-reduces launched from the
+# backward and waited for before the optimizer -- and its results must equal the no-collective run bit for bit.
+FORCE_COLLECTIVES = False
+
+
+def collectives_on(group=None):
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return FORCE_COLLECTIVES or dist.get_world_size(group) > 1
+
 
 def shard_rows(n_rows, rank, world):
     """Contiguous row range of `rank` (remainder spread over the first ranks)."""
@@ -33,7 +45,7 @@ def shard_rows(n_rows, rank, world):
 
 def allreduce_step_counts(sum_cnt, group=None):
     """In-place sum over ranks of the [steps, 2] (term sum, live count) table."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if collectives_on(group):
         dist.all_reduce(sum_cnt, op=dist.ReduceOp.SUM, group=group)
     return sum_cnt
 
@@ -79,7 +91,7 @@ class FlatGrads:
         if not self.attached():
             raise RuntimeError('a parameter .grad was replaced (zero_grad(set_to_none=True)?); '
                                'FlatGrads views are gone')
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if collectives_on(group):
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=group)
         return self.flat
 
@@ -111,11 +123,16 @@ class BucketedGrads(FlatGrads):
         return len(self.bounds)
 
     def _active(self):
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        return collectives_on(self.group)
 
     def launch(self, b):
         if b in self.launched:
             raise RuntimeError('bucket %d launched twice before wait()' % b)
+        # an optimizer (or zero_grad(set_to_none=True)) that re-bound a .grad would leave this buffer dead: the
+        # all-reduce would then sum memory nobody writes and the real gradients would never be reduced
+        if not self.attached():
+            raise RuntimeError('a parameter .grad no longer lives in the bucket buffer (re-bound by an optimizer or '
+                               'zero_grad(set_to_none=True)); gradients would silently not be reduced')
         self.launched.append(b)
         if self._active():
             lo, hi = self.bounds[b]
@@ -145,7 +162,7 @@ def follower_buckets(encoder, decoder):
 def allreduce_gradients(params, group=None):
     """Fallback for parameters whose grads are not in a FlatGrads buffer: pack, reduce, unpack."""
     ps = [p for p in params if p.requires_grad and p.grad is not None]
-    if not ps or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not ps or not collectives_on(group):
         return
     flat = torch.cat([p.grad.reshape(-1) for p in ps])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)

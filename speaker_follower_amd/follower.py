@@ -21,7 +21,7 @@ from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, require_frozen_embedding)
-from .runtime import ptr, stream, ws_args, dropout_arg
+from .runtime import ptr, stream, ws_args, dropout_arg, take_fault, PersistentLaunchFault
 
 byref = C.byref
 
@@ -145,12 +145,8 @@ class FollowerEngine:
         self.pipelined = True           # head(t+1) next to tail(t) in paired launches (sf_hip.h)
         self.two_stream_forward = False  # experiment: visual half of step t+1 on a side stream, ordered by device flags
         self.episode_call = True        # the whole decode loop (and its backward) as ONE C call
-        # EXPERIMENT (libsf_experimental.so, built on demand): inference rollouts with the S decode steps as ONE
-        # persistent launch (csrc/experimental/sf_mega.hip) -- correct, slower than the per-stage path.  Falls
-        # back to the per-stage episode when the shape is outside what that kernel supports.
-        self.persistent_decode = False
         self.fused_env_step = True      # nav.DeviceNavBatch: the env step inside the scoring + glue launch
-        self.persistent_debug_tapes = False   # tests: also copy t_text / cat2 / h_tilde / q / xin per step
+        self.fallbacks = 0              # rollouts re-issued on the per-step kernels after a persistent-launch fault (run)
 
     # ------------------------------------------------------------------------------ forward
     def rollout(self, batch, steps, feedback='argmax', train=None, finalize=True):
@@ -261,17 +257,7 @@ class FollowerEngine:
                 if self._side_stream is None:
                     self._side_stream = torch.cuda.Stream(device=dev)
                 ep.side_stream = self._side_stream.cuda_stream
-            st.persistent = False
-            if self.persistent_decode and not (st.differentiable or training) and ep.side_stream is None:
-                dwf = dw if fold is not None else decoder_w_struct(params, fold=decoder_fold(dec))
-                rc = _lib.experimental().sf_follower_decode_persistent(byref(dwf), byref(ep), int(self.persistent_debug_tapes), *ws)
-                if rc == _lib.SF_ERR_UNSUPPORTED:
-                    rc = None
-                else:
-                    _lib.check(rc, 'sf_follower_decode_persistent')
-                    st.persistent = True
-            if not st.persistent:
-                call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
+            call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
             st.episode = (ep, dw)
         tapes = [] if st.episode else [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
                                        for t in range(S)]
@@ -325,6 +311,45 @@ class FollowerEngine:
             # global per-step normaliser so that the sharded loss equals the reference's batch mean
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
         return self.finish(st)
+
+    def run(self, batch, steps, feedback='argmax', train=None, backward=False):
+        """`rollout` (and, with backward=True, `loss.backward()`) + the fault check of the persistent encoder
+        launches (include/sf_hip.h: sf_workspace_fault_offset): ONE host sync; a launch that gave up a bounded wait
+        (co-residency lost to another process) has poisoned its outputs with NaN, so the SAME rollout -- same
+        dropout / sampling sites -- is re-issued in this process with the per-step encoder kernels
+        (SF_ENC_PER_STEP), after zeroing the gradients the poisoned backward accumulated.  Under a process group
+        the decision is taken on the OR of all ranks' fault words, so every rank re-issues (and re-enters the
+        gradient collectives) together.  Raises PersistentLaunchFault if a fault is still raised afterwards."""
+        dev = self.store.device
+        site, it = self.site_next, self.iteration
+
+        def once():
+            st = self.rollout(batch, steps, feedback, train)
+            if backward:
+                st.loss.backward()
+            bits = take_fault(dev)
+            if self.group is not None:
+                t = torch.tensor([bits], device=dev, dtype=torch.int32)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.BOR, group=self.group)
+                bits = int(t.item())
+            return st, bits
+
+        st, bits = once()
+        if bits:
+            self.fallbacks += 1
+            if backward:
+                for p_ in st.all_params:
+                    if p_.grad is not None:
+                        p_.grad.zero_()
+            keep = getattr(self.encoder, 'persistent', True)
+            self.encoder.persistent, self.site_next, self.iteration = False, site, it
+            try:
+                st, again = once()
+            finally:
+                self.encoder.persistent = keep
+            if again:
+                raise PersistentLaunchFault('fault bits %d, and %d after the per-step re-issue' % (bits, again))
+        return st
 
     def finish(self, st, total=None):
         """Second half of `rollout(..., finalize=False)`: turns the per-step (CE sum, live count) table

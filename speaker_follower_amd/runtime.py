@@ -60,6 +60,38 @@ def ws_args(device):
     return C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), stream()
 
 
+# ---- the fault word of the persistent launches (include/sf_hip.h: sf_workspace_fault_offset) ----------------
+FAULT_ENC_FWD, FAULT_ENC_BWD, FAULT_SPEAKER, FAULT_LOCK = 1, 2, 4, 8
+
+
+class PersistentLaunchFault(RuntimeError):
+    """A persistent launch gave up a bounded wait (its outputs are NaN-poisoned) and the per-step re-issue
+    failed as well, or no re-issue was possible."""
+
+
+def _fault_view(ws):
+    off = lib.sf_workspace_fault_offset(ws.numel())
+    return ws[off:off + 4].view(torch.int32)
+
+
+def take_fault(device):
+    """Reads AND clears the fault words of EVERY workspace of `device` (one per stream that ever ran library
+    calls: the backward's side streams and captured rollouts have their own).  A host sync: callers put it where
+    they synchronise anyway (the D2H copy of a rollout's actions, the loss read of a training iteration).  Returns
+    the OR of the FAULT_* bits raised since the last call; 0 in a healthy process."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    views = [_fault_view(ws) for (d, _), ws in _workspaces.items() if d == idx]
+    if not views:
+        return 0
+    words = (torch.cat(views) if len(views) > 1 else views[0]).cpu()        # (the sync)
+    bits = 0
+    for w, b in zip(views, words.tolist()):
+        if b:
+            w.zero_()
+            bits |= b
+    return bits
+
+
 def dropout_arg(p, seed, row0=0):
     """sf_dropout* (NULL when p == 0: eval mode)."""
     if not p:

@@ -19,7 +19,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .model import _grads, require_frozen_embedding
-from .runtime import ptr, stream, ws_args, dropout_arg, struct_of, transposed
+from .runtime import ptr, stream, ws_args, dropout_arg, struct_of, transposed, take_fault, PersistentLaunchFault
 
 byref = C.byref
 
@@ -84,6 +84,7 @@ class SpeakerEngine:
         self.site_next = 0              # first unused dropout site (see score)
         self.dropout_seed = None
         self.persistent = True          # inference passes: the whole word loop as ONE launch (sf_speaker_decode)
+        self.fallbacks = 0              # passes re-issued on the per-step kernels after a persistent-launch fault (run)
 
     def capture(self, batch, steps, feedback='teacher'):
         """hipGraph of one inference scoring / decoding pass: returns (replay, state); the state's
@@ -134,6 +135,12 @@ class SpeakerEngine:
         self.site_next += max(256, S + 2, Tp + 2)
         self.iteration += 1
         ws = ws_args(dev)
+        # `sample` feedback (speaker.py:170-174): word step t draws from stream site0 + t of this seed, keyed on the
+        # global row id (sf_sampling.h)
+        smp = _lib.Sample((self.dropout_seed ^ 0x3C6EF372) & 0xFFFFFFFF, st.site0, batch.row0)
+        if self.group is not None and st.feedback != 0:
+            raise NotImplementedError('row-sharded speaker passes support teacher feedback only (the point where every '
+                                      'row has produced EOS, speaker.py:196, is a property of the whole batch)')
 
         # ---- encoder: Tp x (visual attention -> cat -> dropout -> LSTMCell), model.py:437-451
         ep = enc._params8()
@@ -195,7 +202,8 @@ class SpeakerEngine:
                 byref(dw), B, H, Tp, vocab, S, st.feedback, PAD, EOS, ptr(st.targets), ptr(st.h_init),
                 ptr(st.c_init), ptr(st.ctx), ptr(batch.path_mask), ptr(st.words), ptr(st.ended),
                 ptr(st.step_scores), ptr(st.nll_term), ptr(st.live), ptr(st.tape['logit']),
-                ptr(st.tape['alpha']), ptr(st.tape['h1']), ptr(st.tape['c1']), *ws)
+                ptr(st.tape['alpha']), ptr(st.tape['h1']), ptr(st.tape['c1']),
+                byref(smp) if st.feedback == 2 else None, *ws)
             if rc != 2:                                   # SF_ERR_UNSUPPORTED: shapes outside the kernel
                 _lib.check(rc, 'sf_speaker_decode')
                 persistent = True
@@ -210,20 +218,46 @@ class SpeakerEngine:
             call('sf_speaker_decoder_fwd', byref(dw), B, E, H, Tp, vocab, ptr(st.words[t]), ptr(h0),
                  ptr(c0), ptr(st.ctx), ptr(batch.path_mask), None, byref(tp), d_dec, st.site0 + t,
                  *ws)
+            smp_t = None
+            if st.feedback == 2:
+                smp_t = byref(_lib.Sample(smp.seed, (st.site0 + t) & 0xFFFFFFFF, batch.row0))
             call('sf_speaker_glue_fwd', B, vocab, ldv, ptr(st.tape['logit'][t]),
                  ptr(st.targets[t]), st.feedback, PAD, EOS, ptr(st.ended),
                  ptr(st.words[t + 1]), ptr(st.step_scores[t]), ptr(st.nll_term[t]),
-                 ptr(st.live[t]), ws[2])
+                 ptr(st.live[t]), smp_t, ws[2])
         call('sf_reduce_terms', ptr(st.nll_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         if self.group is not None:
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
-        call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
+        # (the step means are added up to and including the first step at which every row has produced EOS,
+        # speaker.py:192-197; gscale is 0 behind it)
+        call('sf_speaker_loss_finalize', ptr(st.sum_cnt), ptr(st.words), EOS, S, B, ptr(st.loss_buf), ptr(st.gscale), ws[2])
         st.logits = st.tape['logit'][:, :, :vocab]
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
         if differentiable:
             st.loss = _SpeakerLossFn.apply(self, st, *params)
         else:
             st.loss = st.loss_buf.clone().reshape(())
+        return st
+
+    def run(self, batch, steps, feedback='teacher', train=None):
+        """`score` + the fault check of the persistent word loop (include/sf_hip.h: sf_workspace_fault_offset): one
+        host sync; if the launch gave up a bounded wait (co-residency lost to another process: its outputs are
+        NaN-poisoned) the SAME pass -- same dropout / sampling sites -- is re-issued on the per-step kernels in this
+        process.  Raises PersistentLaunchFault if a fault is still raised afterwards."""
+        site = self.site_next
+        st = self.score(batch, steps, feedback, train)
+        dev = self.store.device
+        bits = take_fault(dev)
+        if bits:
+            self.fallbacks += 1
+            keep, self.persistent, self.site_next = self.persistent, False, site
+            try:
+                st = self.score(batch, steps, feedback, train)
+            finally:
+                self.persistent = keep
+            again = take_fault(dev)
+            if again:
+                raise PersistentLaunchFault('fault bits %d, and %d after the per-step re-issue' % (bits, again))
         return st
 
     def _backward(self, st, dloss):

@@ -23,6 +23,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle import np_env, np_model                                   # noqa: E402  (checker only)
+from tests.tol import assert_logits_close                            # noqa: E402
 from speaker_follower_amd import synth                                # noqa: E402
 
 TOL = dict(rtol=1e-4, atol=1e-4)
@@ -150,9 +151,7 @@ def test_follower_rollout_on_edge_rows_matches_oracle(big):
     lg = st.logits.cpu().numpy()
     for t in range(n):
         a = ref['logits'][t].shape[1]
-        fin = np.isfinite(ref['logits'][t])
-        scale = max(1.0, float(np.abs(ref['logits'][t][fin]).max()))
-        np.testing.assert_allclose(lg[t][:, :a][fin], ref['logits'][t][fin], rtol=1e-4, atol=1e-4 * scale)
+        assert_logits_close(lg[t][:, :a], ref['logits'][t], 'full-table follower rollout, step %d' % t)
     np.testing.assert_allclose(float(st.loss), float(ref['loss']), rtol=1e-4, atol=1e-5)
 
 
@@ -184,8 +183,7 @@ def test_speaker_scoring_on_edge_rows_matches_oracle(big):
     np.testing.assert_allclose(st.ctx.cpu().numpy(), ref['ctx'], **TOL)
     lg = st.logits.cpu().numpy()
     for t in range(n):
-        scale = max(1.0, float(np.abs(ref['logits'][t]).max()))
-        np.testing.assert_allclose(lg[t], ref['logits'][t], rtol=1e-4, atol=1e-4 * scale)
+        assert_logits_close(lg[t], ref['logits'][t], 'full-table speaker scoring, word step %d' % t)
     np.testing.assert_allclose(float(st.loss), float(ref['loss']), rtol=1e-4)
     np.testing.assert_array_equal(np.argmax(lg[:n], axis=2), np.stack([np.argmax(l, axis=1) for l in ref['logits']]))
 

@@ -21,6 +21,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from tests.tol import assert_logits_close                            # noqa: E402
 from speaker_follower_amd import synth                                # noqa: E402
 
 
@@ -74,8 +75,7 @@ def test_peaky_weights_b100_argmax_all_twenty_steps(golden):
     acts = st.actions.cpu().numpy()
     assert np.array_equal(acts, g['actions'])                     # bit-exact argmax, every step, every row
     got = st.logits.cpu().numpy()
-    assert np.array_equal(np.isfinite(got), fin)
-    assert float(np.abs(got[fin] - want[fin]).max()) <= 1e-4 * scale
+    assert_logits_close(got, want, 'G8 peaky follower B=100, all 20 steps')
     # the attention rows (peaky: a wrong score would move them by orders of magnitude more)
     np.testing.assert_allclose(st.tape['alpha_v'].cpu().numpy(), g['alpha_v'], rtol=1e-3, atol=2e-5)
     np.testing.assert_allclose(st.tape['alpha'][19].cpu().numpy()[:, :g['alpha_last'].shape[1]], g['alpha_last'],
@@ -106,7 +106,7 @@ def test_peaky_weights_b100_train_mode_loss_and_gradients(golden, two_stream):
     want = g['logits']                                             # first 4 steps
     fin = np.isfinite(want)
     got = st.logits[:want.shape[0]].detach().cpu().numpy()
-    assert float(np.abs(got[fin] - want[fin]).max()) <= 1e-4 * float(np.abs(want[fin]).max())
+    assert_logits_close(got, want, 'G8 peaky follower B=100, train mode')
     np.testing.assert_allclose(float(st.loss), g['loss'], rtol=1e-4)
     st.loss.backward()
     check_grads({k: p.grad for k, p in enc.named_parameters() if p.grad is not None}, g, 'enc/')
@@ -135,8 +135,8 @@ def test_speaker_b100_golden(golden, feedback):
     lg = st.logits.detach().cpu().numpy()
     scale = float(np.abs(g['logit_last']).max())
     assert scale > 5.0
-    assert float(np.abs(lg[0] - g['logits_first'][0]).max()) <= 1e-4 * scale
-    assert float(np.abs(lg[n - 1] - g['logit_last']).max()) <= 1e-4 * scale
+    assert_logits_close(lg[0], g['logits_first'][0], 'G9 speaker B=100 %s, word step 0' % feedback)
+    assert_logits_close(lg[n - 1], g['logit_last'], 'G9 speaker B=100 %s, word step %d' % (feedback, n - 1))
     if 'ctx_rows4' in g:
         np.testing.assert_allclose(st.ctx.detach().cpu().numpy()[::4], g['ctx_rows4'], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(float(st.loss), g['loss'], rtol=1e-4)
