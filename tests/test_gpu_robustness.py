@@ -186,7 +186,7 @@ def test_speaker_argmax_loss_stops_where_every_row_has_ended(persistent):
     # make EOS the arg max early for every row: a large bias on the EOS column from the start
     sdec_w = dict(sdec_w)
     bias = sdec_w['decoder2action.bias'].copy()
-    bias[EOS] += 3.0
+    bias[EOS] += 11.0                  # (the oracle then leaves its loop after 11 of 40 steps, rows ending at 0 .. 10)
     sdec_w['decoder2action.bias'] = bias
     enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
     dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'])
