@@ -580,6 +580,11 @@ void sf_debug_force_write_through(int on);
  * (< 0 restores the default, 0.25 s).  0 makes the first unsatisfied poll give up: the launch poisons its outputs
  * and raises its fault bit -- how the tests exercise the host's fallback to the per-step kernels. */
 void sf_debug_persist_timeout(long long ticks);
+/* Development aid: on != 0 runs the large LSTM gate products (K >= 2048, M <= 128: sf_lstm_cell_fwd, the decode
+ * step) on the fp32 MFMA (v_mfma_f32_16x16x4_f32, rounds 1-3) instead of the bf16 matrix cores with three-way
+ * error-free operand splitting (csrc/sf_gemm.hip: gemm_nt_split_kernel; same fp32 accuracy class, measured closer
+ * to the exact sum, 6/16 of the matrix-pipe time).  For A/B timing and for the accuracy tests. */
+void sf_debug_gate_product_f32(int on);
 /* Byte offset, inside a workspace of `ws_bytes` bytes, of the FAULT WORD (uint32, zero in a healthy process): a
  * persistent launch whose bounded wait gave up (co-residency lost to another process) ORs its bit into it -- 1 encoder
  * forward (sf_encoder_lstm_fwd), 2 encoder backward, 4 speaker word loop (sf_speaker_decode), 8 device-wide lock not

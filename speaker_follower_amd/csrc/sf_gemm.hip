@@ -23,6 +23,8 @@
 
 namespace sf {
 
+int g_nt_force_f32 = 0;      // sf_debug_gate_product_f32: run the LSTM gate product on v_mfma_f32_16x16x4_f32 (round 1-3 kernel)
+
 namespace {
 
 // ------------------------------------------------------------------------------------------------
@@ -346,6 +348,305 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
 
     // the two K halves meet in LDS (the stage buffers are free after the loop's last barrier)
     f32x4* red = reinterpret_cast<f32x4*>(smem);
+    if (khalf == 1) {
+#pragma unroll
+        for (int t = 0; t < MT; ++t) red[(wave * MT + t) * 64 + lane] = acc[t];
+    }
+    __syncthreads();
+    if (khalf == 1) return;
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] += red[(wave * MT + t) * 64 + lane];
+
+    const int col = n0 + wave * 16 + li;
+    if (col >= a.N) return;
+    float* out = a.out + (a.ksplit > 1 ? (size_t)split * a.M * a.N : 0);
+    float bsum = 0.f;
+    if (a.bias) bsum += a.bias[col];
+    if (a.bias2) bsum += a.bias2[col];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + kk * 4 + r;
+            if (row < a.M) {
+                float* o = out + (size_t)row * a.ldo + col;
+                const float v = acc[t][r] + bsum;
+                *o = (a.accumulate && a.ksplit == 1) ? *o + v : v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same product on the BF16 matrix cores, at fp32 accuracy, by error-free operand splitting
+// (round 4).  v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16
+// matrix rate) and the gate product was the one MFMA-bound kernel of the path (loop at 92 % of that
+// rate).  Every fp32 value is the exact sum of three bf16 pieces (round-to-nearest splits:
+// a1 = bf16(a), a2 = bf16(a - a1), a3 = a - a1 - a2, |a2| <= 2^-9 |a|, |a3| <= 2^-17 |a|), so
+//     a b = a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1) + O(2^-25 |a b|)
+// is six v_mfma_f32_32x32x16_bf16 (exact bf16 x bf16 products, fp32 accumulate) = 6/16 of the fp32-MFMA
+// time.  The leading product has its own accumulator, the five small ones share a second one (a single
+// accumulator costs the leading sum one rounding per small term: measured 3x the error and a 1e-8
+// bias).  Measured against float64 on this very shape (tools/exp/bf16x6_accuracy.hip, [100 x 4864] x
+// [2048 x 4864]^T): rms error 6.0e-7 / max 6.6e-6 against 1.6e-6 / 2.0e-5 for the fp32 MFMA's fma chain
+// (fewer roundings: one per 16 products instead of one per product) -- the result is NOT bit-identical
+// to gemm_nt_tiled_kernel, it is closer to the exact sum.  Three pieces with three products (the usual
+// "bf16x3") are 5x worse than fp32 and are not used.
+//
+// Block = 64 columns x all rows (<= 128, as MT m-tiles of 16) x one K split; 8 waves = 4 n-tiles of 16
+// columns x the 2 K-halves of every 64-deep stage -- the decomposition of gemm_nt_tiled_kernel, with
+// v_mfma_f32_16x16x32_bf16 (one instruction per 32-deep half).  Operands are fetched as fp32 with full
+// 256-B row segments (as the fp32 kernel does), split by the thread that fetched them and stored to LDS
+// as three bf16 planes per operand ([row][64 k] = 128 B per row and plane, 16-B chunks XOR-swizzled with
+// (row >> 1) & 7: the ds_read_b128 lane groups of gfx950 -- 16 rows, chunk c for 8 of them and c + 1 for
+// the others -- then hit 16 distinct 16-B bank groups without padding: 2 x 3 x 176 rows x 128 B = 132 KB of
+// the 160 KB at 112 rows).  The split + LDS stores of stage s+1 and the global loads of stage s+3 sit between
+// the MFMAs of stage s: one barrier per stage.  The K halves meet in LDS as in the fp32 kernel.
+// ------------------------------------------------------------------------------------------------
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ unsigned pk_bf16_rn(float lo, float hi) {        // v_cvt_pk_bf16_f32
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+// float4 -> three planes of 4 bf16 (uint2 each): exact three-way split
+__device__ __forceinline__ void split3_f4(const float4& v, uint2& p1, uint2& p2, uint2& p3) {
+    p1.x = pk_bf16_rn(v.x, v.y);
+    p1.y = pk_bf16_rn(v.z, v.w);
+    const float r0 = v.x - __uint_as_float(p1.x << 16), r1 = v.y - __uint_as_float(p1.x & 0xFFFF0000u);
+    const float r2 = v.z - __uint_as_float(p1.y << 16), r3 = v.w - __uint_as_float(p1.y & 0xFFFF0000u);
+    p2.x = pk_bf16_rn(r0, r1);
+    p2.y = pk_bf16_rn(r2, r3);
+    const float q0 = r0 - __uint_as_float(p2.x << 16), q1 = r1 - __uint_as_float(p2.x & 0xFFFF0000u);
+    const float q2 = r2 - __uint_as_float(p2.y << 16), q3 = r3 - __uint_as_float(p2.y & 0xFFFF0000u);
+    p3.x = pk_bf16_rn(q0, q1);            // (exact: q has <= 8 significant bits)
+    p3.y = pk_bf16_rn(q2, q3);
+}
+
+constexpr int SPL_ROWB = 128;             // bytes per row and plane (64 bf16)
+
+template <int MT>
+__global__ __launch_bounds__(512) void gemm_nt_split_kernel(NtArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    constexpr int APASS = (MT + 1) / 2;                  // 32 rows x 16 float4 per staging pass
+    constexpr int AROWS = APASS * 32;                    // (whole passes: every staging store is unconditional)
+    constexpr int PLANE_A = AROWS * SPL_ROWB;
+    constexpr int BUF = 3 * PLANE_A;                     // bytes per stage buffer (A only: W never touches LDS)
+    constexpr int NPIECE = APASS + 2;                    // loads per thread and stage: APASS of A, 2 of W
+    const int tid = threadIdx.x, lane = tid & 63, wave8 = tid >> 6;
+    const int wave = wave8 & 3, khalf = wave8 >> 2;      // n-tile of 16 columns, K-half of a stage
+    const int li = lane & 15, kk = lane >> 4;
+    int n0, split;
+    {   // XCD-aware (split, n-block) map, as gemm_nt_tiled_kernel
+        const int total = gridDim.x * gridDim.y;
+        const int b = blockIdx.x + gridDim.x * blockIdx.y;
+        int g = b;
+        if ((total & 7) == 0) g = (b & 7) * (total >> 3) + (b >> 3);
+        split = g / (int)gridDim.x;
+        n0 = (g % (int)gridDim.x) * 64;
+    }
+    const int ldrow = tid >> 4, ldc4 = tid & 15;         // A staging: 32 rows x 16 float4 per pass
+    const int st0n = a.seg[0].K / TBK;
+    const int st1n = a.nseg > 1 ? a.seg[1].K / TBK : 0;
+    const int st2n = a.nseg > 2 ? a.seg[2].K / TBK : 0;
+    const int stages = st0n + st1n + st2n;
+    const int s_lo = (int)(((long)split * stages) / a.ksplit);
+    const int s_hi = (int)(((long)(split + 1) * stages) / a.ksplit);
+
+    f32x4 hi[MT], lo[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) hi[t] = lo[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Staging registers are filled by INLINE-ASM loads and released by counted `s_waitcnt vmcnt(N)`: the compiler's own
+    // bookkeeping loses the count across the loop's back edge and waits vmcnt(0) at the first use in every stage,
+    // i.e. for the loads issued one stage earlier -- a prefetch distance of one stage (~1 us) against an HBM latency
+    // of 1-2 us under load.  Loads return in order, so "at most N newer loads outstanding" means this one has landed.
+    struct Regs {
+        f32x4 a[APASS];          // A: this thread's float4 of rows 32 p + ldrow (shared through LDS)
+        f32x4 w[2];              // W: THIS WAVE's fragment rows (n-tile, K-half), never shared: registers only
+    };
+    struct StageSrc {
+        const float* A;          // wave-uniform bases (SGPR pairs): the row offset travels in one VGPR
+        const float* W;
+        int lda, ldw;
+    };
+    // The segment of a stage is picked with mask arithmetic on values that sit in SGPRs: no branch (a stage's whole
+    // body stays ONE basic block the scheduler can interleave), no load (a select of loaded values is turned into a
+    // load from a selected address, i.e. a memory round trip at the head of every stage).
+    const unsigned long long pa0 = (unsigned long long)a.seg[0].A, pw0 = (unsigned long long)a.seg[0].W,
+                             pa1 = (unsigned long long)a.seg[1].A, pw1 = (unsigned long long)a.seg[1].W,
+                             pa2 = (unsigned long long)a.seg[2].A, pw2 = (unsigned long long)a.seg[2].W;
+    const unsigned lda0 = a.seg[0].lda, ldw0 = a.seg[0].ldw, lda1 = a.seg[1].lda, ldw1 = a.seg[1].ldw, lda2 = a.seg[2].lda,
+                   ldw2 = a.seg[2].ldw;
+    auto stage_src = [&](int s) {
+        const unsigned long long m0 = s < st0n ? ~0ull : 0ull, m2 = s >= st0n + st1n ? ~0ull : 0ull, m1 = ~(m0 | m2);
+        const int k0 = (s - (int)((unsigned)st0n & (unsigned)~m0) - (int)((unsigned)st1n & (unsigned)m2)) * TBK;
+        return StageSrc{reinterpret_cast<const float*>((pa0 & m0) | (pa1 & m1) | (pa2 & m2)) + k0,
+                        reinterpret_cast<const float*>((pw0 & m0) | (pw1 & m1) | (pw2 & m2)) + k0,
+                        (int)((lda0 & (unsigned)m0) | (lda1 & (unsigned)m1) | (lda2 & (unsigned)m2)),
+                        (int)((ldw0 & (unsigned)m0) | (ldw1 & (unsigned)m1) | (ldw2 & (unsigned)m2))};
+    };
+    auto gld = [&](f32x4& dst, const float* base, unsigned byte_off) {
+        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(dst) : "v"(byte_off), "s"(base) : "memory");
+    };
+    // The K index inside one MFMA is free as long as A and B agree.  Lane (li, kk) holds, of its row's 32-deep half,
+    // k = 4 kk .. 4 kk + 3 and 16 + 4 kk .. 16 + 4 kk + 3: a W fragment is then two 16-byte loads per lane whose 16-lane
+    // groups read FULL 64-byte lines of a row (the straight 8-consecutive-k mapping reads half of every line twice).
+    const int wrow = min(n0 + wave * 16 + li, a.N - 1);
+    auto gpiece = [&](Regs& r, const StageSrc& ss, int piece) {       // one global load of the staging set
+        if (piece < APASS) {
+            const int row = min(piece * 32 + ldrow, a.M - 1);
+            gld(r.a[piece < APASS ? piece : 0], ss.A, (unsigned)(row * ss.lda + 4 * ldc4) * 4u);
+        } else if (piece < NPIECE) {
+            const int e = piece - APASS;
+            gld(r.w[e & 1], ss.W, (unsigned)(wrow * ss.ldw + 32 * khalf + 16 * e + 4 * kk) * 4u);
+        }
+    };
+    // piece `piece` of `r` has landed once at most `newer` younger loads are outstanding
+#define SPL_LANDED(reg, newer) asm volatile("s_waitcnt vmcnt(%1)" : "+v"(reg) : "n"(newer))
+    // A planes in LDS: [plane][row][64 k bf16]; inside a row the 16-byte chunk (half g, lane group kk) holds
+    // k = 32 g + 4 kk .. + 3 (first 8 bytes) and 32 g + 16 + 4 kk .. + 3 (last 8 bytes); chunks XOR-swizzled with (row >> 1) & 7
+    auto st_off = [&](int row, int c4) {
+        const int chunk = ((c4 >> 3) << 2) | (c4 & 3), e = (c4 >> 2) & 1;
+        return row * SPL_ROWB + (((chunk ^ (row >> 1)) & 7) << 4) + (e << 3);
+    };
+    auto spiece_a = [&](const Regs& r, int buf, int piece) {          // split one float4 of A, three 8-byte LDS stores
+        uint2 p1, p2, p3;
+        const f32x4 v = r.a[piece < APASS ? piece : 0];
+        split3_f4(make_float4(v[0], v[1], v[2], v[3]), p1, p2, p3);
+        unsigned char* d = smem_b + buf * BUF + st_off(piece * 32 + ldrow, ldc4);
+        *reinterpret_cast<uint2*>(d) = p1;
+        *reinterpret_cast<uint2*>(d + PLANE_A) = p2;
+        *reinterpret_cast<uint2*>(d + 2 * PLANE_A) = p3;
+    };
+    struct BFrag {
+        bf16x8 p[3];
+    };
+    auto split_w = [&](const Regs& r, BFrag& f) {                     // this wave's W fragment of the next stage
+        uint2 x1, x2, x3, y1, y2, y3;
+        split3_f4(make_float4(r.w[0][0], r.w[0][1], r.w[0][2], r.w[0][3]), x1, x2, x3);
+        split3_f4(make_float4(r.w[1][0], r.w[1][1], r.w[1][2], r.w[1][3]), y1, y2, y3);
+        f.p[0] = __builtin_bit_cast(bf16x8, uint4{x1.x, x1.y, y1.x, y1.y});
+        f.p[1] = __builtin_bit_cast(bf16x8, uint4{x2.x, x2.y, y2.x, y2.y});
+        f.p[2] = __builtin_bit_cast(bf16x8, uint4{x3.x, x3.y, y3.x, y3.y});
+    };
+    const int fchunk = 4 * khalf + kk;
+    auto frag = [&](const unsigned char* plane, int row) {
+        return *reinterpret_cast<const bf16x8*>(plane + row * SPL_ROWB + (((fchunk ^ (row >> 1)) & 7) << 4));
+    };
+    // One stage: 6 MT MFMAs on buffer `buf` with the W fragment `bc`.  `rs` holds the raw operands of the NEXT stage:
+    // its A pieces are split into LDS buffer `sbuf`, its W pieces into the fragment `bn`, and every register is
+    // reloaded with its piece of stage `s_next` right behind its use.
+    auto compute = [&](int buf, const BFrag& bc, Regs& rs, BFrag& bn, int s_next, int sbuf) {
+        const unsigned char* Ab = smem_b + buf * BUF;
+        const StageSrc ss = stage_src(s_next);
+        // the staging work of slot t (between the MFMAs of tile t)
+        auto stage_work_a = [&](int t) {
+            if (t < APASS) {
+                // younger than this piece's load: the other set's NPIECE loads of the previous stage and this set's t
+                // reloads of this stage
+                SPL_LANDED(rs.a[t < APASS ? t : 0], NPIECE + t);
+                spiece_a(rs, sbuf, t);
+            } else if (t == APASS) {
+                SPL_LANDED(rs.w[0], NPIECE + APASS);
+                SPL_LANDED(rs.w[1], NPIECE + APASS);
+                split_w(rs, bn);
+            }
+        };
+        auto stage_work_b = [&](int t) {
+            if (t < APASS) gpiece(rs, ss, t);
+            else if (t == APASS) { gpiece(rs, ss, APASS); gpiece(rs, ss, APASS + 1); }
+        };
+        // Tiles go in PAIRS with their MFMAs interleaved (consecutive MFMAs never share an accumulator) and the
+        // fragments of the next pair are requested before the current pair's MFMAs are issued.
+        bf16x8 fa[2][2][3];                                           // [parity][tile of the pair][plane]
+        auto fetch = [&](int pr, int t0) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (t0 + u < MT) {
+                    const int arow = (t0 + u) * 16 + li;
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) fa[pr][u][pl] = frag(Ab + pl * PLANE_A, arow);
+                }
+        };
+        fetch(0, 0);
+#pragma unroll
+        for (int t0 = 0; t0 < MT; t0 += 2) {
+            const int pr = (t0 >> 1) & 1;
+            if (t0 + 2 < MT) fetch(pr ^ 1, t0 + 2);
+            const bool two = t0 + 1 < MT;
+            const int t1 = two ? t0 + 1 : t0;
+#define SPL_MM(acc, t, pa, pb) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[pr][(t) - t0][pa], bc.p[pb], acc[t], 0, 0, 0)
+            SPL_MM(lo, t0, 2, 0);
+            if (two) SPL_MM(lo, t1, 2, 0);
+            SPL_MM(lo, t0, 0, 2);
+            if (two) SPL_MM(lo, t1, 0, 2);
+            stage_work_a(t0);
+            SPL_MM(lo, t0, 1, 1);
+            if (two) SPL_MM(lo, t1, 1, 1);
+            SPL_MM(lo, t0, 1, 0);
+            if (two) SPL_MM(lo, t1, 1, 0);
+            stage_work_b(t0);
+            if (two) stage_work_a(t1);
+            SPL_MM(lo, t0, 0, 1);
+            if (two) SPL_MM(lo, t1, 0, 1);
+            SPL_MM(hi, t0, 0, 0);
+            if (two) SPL_MM(hi, t1, 0, 0);
+            if (two) stage_work_b(t1);
+#undef SPL_MM
+        }
+        if (MT <= APASS) {                                            // (MT = 1: the W pieces did not fit above)
+            SPL_LANDED(rs.w[0], NPIECE + APASS);
+            SPL_LANDED(rs.w[1], NPIECE + APASS);
+            split_w(rs, bn);
+            gpiece(rs, ss, APASS);
+            gpiece(rs, ss, APASS + 1);
+        }
+    };
+    auto gload = [&](Regs& r, int s) {
+        const StageSrc ss = stage_src(s);
+#pragma unroll
+        for (int piece = 0; piece < NPIECE; ++piece) gpiece(r, ss, piece);
+    };
+
+    // Register sets ra / rb alternate: at the top of stage s the buffer of s holds its A planes and one fragment its W
+    // pieces; one set holds the raw operands of stage s+1 (landed) and the other those of stage s+2 (in flight).
+    // Stage indices are clamped, not predicated.
+    if (s_lo < s_hi) {
+        const int last = s_hi - 1;
+        Regs ra, rb;
+        BFrag b0, b1;
+        gload(ra, s_lo);
+        gload(rb, min(s_lo + 1, last));
+#pragma unroll
+        for (int piece = 0; piece < APASS; ++piece) {
+            SPL_LANDED(ra.a[piece], NPIECE);                          // (rb's loads are younger)
+            spiece_a(ra, 0, piece);
+        }
+        SPL_LANDED(ra.w[0], NPIECE);
+        SPL_LANDED(ra.w[1], NPIECE);
+        split_w(ra, b0);
+        gload(ra, min(s_lo + 2, last));
+        __syncthreads();
+        for (int s = s_lo; s < s_hi; s += 2) {
+            compute(0, b0, rb, b1, min(s + 3, last), 1);      // stage s on buffer 0; rb (s+1) -> buffer 1 / b1; rb <- s+3
+            __syncthreads();
+            if (s + 1 >= s_hi) break;
+            compute(1, b1, ra, b0, min(s + 4, last), 0);      // stage s+1 on buffer 1; ra (s+2) -> buffer 0 / b0; ra <- s+4
+            __syncthreads();
+        }
+    }
+    // (the clamped prefetches of the last stages are still in flight: nothing below may reuse their registers yet)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+#undef SPL_LANDED
+
+    // the two K halves meet in LDS (the stage buffers are free behind the loop's last barrier)
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = hi[t] + lo[t];
+    f32x4* red = reinterpret_cast<f32x4*>(smem_b);
     if (khalf == 1) {
 #pragma unroll
         for (int t = 0; t < MT; ++t) red[(wave * MT + t) * 64 + lane] = acc[t];
@@ -1210,7 +1511,25 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
     const NtArgs& k = a;   // raw slabs with ks == 1: slab 0 is written without bias
     bool tiled = !launched && mblocks == 1 && chunks >= 128 && N % 64 == 0 && a.epi == EPI_NONE;
     for (int s = 0; s < nseg; ++s) tiled = tiled && segs[s].K % TBK == 0;
-    if (tiled) {
+    if (tiled && M <= 128 && !g_nt_force_f32) {
+        // fp32 accuracy on the bf16 matrix cores (gemm_nt_split_kernel): 6/16 of the fp32-MFMA time
+        dim3 tgrid(N / 64, ks);
+        const size_t lds = std::max<size_t>((size_t)2 * 3 * (((mt + 1) / 2) * 32) * SPL_ROWB, (size_t)4 * mt * 64 * 16);
+#define SF_SPLIT(MTV)                                                                               \
+    case MTV: {                                                                                    \
+        static bool attr_set = false;                                                              \
+        if (!attr_set) {                                                                           \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_split_kernel<MTV>),    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);     \
+            attr_set = true;                                                                       \
+        }                                                                                          \
+        SF_LAUNCH(gemm_nt_split_kernel<MTV>, tgrid, dim3(512), lds, st, k);                        \
+    } break;
+        switch (mt) {
+            SF_SPLIT(1) SF_SPLIT(2) SF_SPLIT(3) SF_SPLIT(4) SF_SPLIT(5) SF_SPLIT(6) SF_SPLIT(7) SF_SPLIT(8)
+        }
+#undef SF_SPLIT
+    } else if (tiled) {
         dim3 tgrid(N / 64, ks);
         const size_t lds = (size_t)2 * (mt * 16 + 64) * TLD * sizeof(float);
 #define SF_TILED(MTV)                                                                              \

@@ -395,6 +395,14 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
         todo = np.flatnonzero(~np.where(eh, held_t.expanded[ei, ek], open_t.expanded[ei, ek])
                               & (n_comp[ei] < completion_size))
         pick = todo[np.lexsort((todo, eh[todo], -t.score[node[todo]], ei[todo]))]
+        tie_log = getattr(agent, 'tie_log', None)
+        if tie_log is not None and successor_size == 1:
+            # diagnostics (tools/search_tie_probe.py): per pick, how far behind the runner-up of the same instance was
+            grp = ei[pick]
+            first = np.flatnonzero(np.r_[True, grp[1:] != grp[:-1]])
+            has2 = (first + 1 < len(pick)) & (np.r_[grp[1:], -1][first] == grp[first])
+            sc_ = t.score[node[pick]]
+            tie_log.append((grp[first][has2], sc_[first][has2], sc_[np.minimum(first + 1, len(pick) - 1)][has2]))
         pick = pick[_first_k_per_group(ei[pick], successor_size)]
         pi, pk, ph, pn = ei[pick], ek[pick], eh[pick], node[pick]
         held_t.expanded[pi[ph], pk[ph]] = True

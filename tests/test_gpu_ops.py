@@ -299,3 +299,41 @@ def test_linear_slabs_sum_to_the_product():
     slabs = workspace(x.device)[:ks.value * M * N * 4].view(torch.float32).view(ks.value, M, N)
     ref = x.double() @ w.double().T + h.double() @ u.double().T
     torch.testing.assert_close(slabs.sum(0).double(), ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize('M', [100, 1, 16, 37, 64, 113, 128])
+def test_gate_product_on_the_bf16_matrix_cores_keeps_fp32_accuracy(M):
+    """csrc/sf_gemm.hip: gemm_nt_split_kernel (three-way error-free bf16 splitting, six bf16 MFMAs per product,
+    fp32 accumulate) against float64 and against the fp32-MFMA kernel it replaces (sf_debug_gate_product_f32): the
+    error stays in the fp32-roundoff class -- bounded by 2.5e-7 sum|a b| -- and is no larger than the fp32 kernel's."""
+    import ctypes as C
+    from speaker_follower_amd._lib import call, lib, kernel_profile
+    from speaker_follower_amd.runtime import ptr, ws_args, workspace
+    g = torch.Generator().manual_seed(M)
+    N, K1, K2 = 2048, 4352, 512
+    # [u | feature] post-ReLU non-negative with dropout (x2 or 0), h in (-1, 1): the decoder's LSTM input
+    x = (torch.relu(torch.randn(M, K1, generator=g) * 0.5 + 0.4) * 2 * (torch.rand(M, K1, generator=g) < 0.5)).cuda()
+    h = torch.tanh(torch.randn(M, K2, generator=g)).cuda()
+    w, u = (torch.randn(N, K1, generator=g) * 0.03).cuda(), (torch.randn(N, K2, generator=g) * 0.05).cuda()
+    ref = x.double() @ w.double().T + h.double() @ u.double().T
+    mag = x.double().abs() @ w.double().abs().T + h.double().abs() @ u.double().abs().T
+    out = {}
+    for f32 in (1, 0):
+        lib.sf_debug_gate_product_f32(f32)
+        try:
+            ks = C.c_int(0)
+            with kernel_profile() as prof:
+                call('sf_linear_slabs_fwd', ptr(x), K1, ptr(w), K1, ptr(h), K2, ptr(u), K2, M, N, C.byref(ks),
+                     *ws_args(x.device))
+            torch.cuda.synchronize()
+        finally:
+            lib.sf_debug_gate_product_f32(0)
+        names = ' '.join(prof.rows)
+        assert ('gemm_nt_split_kernel' in names) == (f32 == 0), names
+        slabs = workspace(x.device)[:ks.value * M * N * 4].view(torch.float32).view(ks.value, M, N)
+        err = slabs.sum(0).double() - ref
+        out[f32] = (float(err.abs().max()), float((err.abs() / mag).max()), float(err.pow(2).mean().sqrt()))
+    print('[gate product M=%d] fp32 MFMA: max %.2e rel %.2e rms %.2e | bf16 x 6: max %.2e rel %.2e rms %.2e'
+          % (M, *out[1], *out[0]))
+    assert out[0][1] <= 2.5e-7
+    assert out[0][2] <= out[1][2] * 1.05 and out[0][0] <= out[1][0] * 1.25

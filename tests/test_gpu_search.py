@@ -123,6 +123,7 @@ def test_state_factored_search_batch64_k40_matches_reference():
     dec.cuda().eval()
     agent = agents.Seq2SeqAgent(env, '/tmp/sf_search_big.json', enc, dec, episode_len=W.BIG_EPISODE_LEN)
     agent.store = features.FeatureStore(table)
+    agent.tie_log = []                    # per expansion: score of the expanded state and of its frontier's runner-up
     env.set_beam_size(W.BIG_K)
     env.reset_epoch()
     torch.cuda.synchronize()
@@ -133,10 +134,25 @@ def test_state_factored_search_batch64_k40_matches_reference():
     want = gold['results']
     assert len(trajs) == len(want) == 64
     n_cands = 0
-    for g, tr, w in zip(trajs, traversed, want):
-        check_candidates(g, w['cands'])
-        assert [s.world_state.viewpointId for s in tr] == w['traversed']
+    tie_inst = np.concatenate([x[0] for x in agent.tie_log])
+    tie_gap = np.concatenate([np.abs(x[1] - x[2]) for x in agent.tie_log])
+    tie_ulp = np.concatenate([np.spacing(np.abs(x[1]).astype(np.float32)) for x in agent.tie_log])
+    reordered = []
+    for i, (g, tr, w) in enumerate(zip(trajs, traversed, want)):
+        check_candidates(g, w['cands'])           # the completions, their order and their scores: always
+        if [s.world_state.viewpointId for s in tr] != w['traversed']:
+            # A best-first search expands the best frontier state; where two states score EQUAL to the last bit or two
+            # of fp32 the order is decided by the summation order of the arithmetic, the reference's or any other
+            # (3 933 expansions here, 1 of them with a gap below 1e-5: instruction 31, gap 0 at score -6.676 with the
+            # gate product on the bf16 matrix cores, 1 ulp the other way in the reference; tools/search_tie_probe.py).
+            # Such an instruction may walk its (identical) set of expansions in another order -- nothing else may.
+            m = tie_inst == i
+            assert m.any() and float((tie_gap[m] / tie_ulp[m]).min()) <= 2.0, (i, float((tie_gap[m] / tie_ulp[m]).min()))
+            reordered.append(i)
         n_cands += len(g)
+    assert len(reordered) <= 2, reordered
+    print('traversal identical to the reference for %d of 64 instructions; fp32 ties (<= 2 ulp) re-ordered: %s'
+          % (64 - len(reordered), reordered))
     assert n_cands == sum(len(w['cands']) for w in want) and n_cands > 64 * 20
     print('state-factored search, batch 64, K = 40: %.2f s here; the reference took %.1f s on %d CPU threads'
           % (dt, cfg['reference_cpu_seconds'], cfg['reference_threads']))
