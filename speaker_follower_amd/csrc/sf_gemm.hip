@@ -18,6 +18,7 @@
 #include "sf_gemm.h"
 #include "sf_gemm_small.h"
 #include "sf_lstm.h"
+#include "sf_split.h"
 
 #include <cstdlib>
 
@@ -377,20 +378,11 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// The same product on the BF16 matrix cores, at fp32 accuracy, by error-free operand splitting
-// (round 4).  v_mfma_f32_16x16x4_f32 runs at the f32 VECTOR rate (157 TFLOP/s, 1/16 of the bf16
-// matrix rate) and the gate product was the one MFMA-bound kernel of the path (loop at 92 % of that
-// rate).  Every fp32 value is the exact sum of three bf16 pieces (round-to-nearest splits:
-// a1 = bf16(a), a2 = bf16(a - a1), a3 = a - a1 - a2, |a2| <= 2^-9 |a|, |a3| <= 2^-17 |a|), so
-//     a b = a1 b1 + (a1 b2 + a2 b1) + (a2 b2 + a1 b3 + a3 b1) + O(2^-25 |a b|)
-// is six v_mfma_f32_32x32x16_bf16 (exact bf16 x bf16 products, fp32 accumulate) = 6/16 of the fp32-MFMA
-// time.  The leading product has its own accumulator, the five small ones share a second one (a single
-// accumulator costs the leading sum one rounding per small term: measured 3x the error and a 1e-8
-// bias).  Measured against float64 on this very shape (tools/exp/bf16x6_accuracy.hip, [100 x 4864] x
-// [2048 x 4864]^T): rms error 6.0e-7 / max 6.6e-6 against 1.6e-6 / 2.0e-5 for the fp32 MFMA's fma chain
-// (fewer roundings: one per 16 products instead of one per product) -- the result is NOT bit-identical
-// to gemm_nt_tiled_kernel, it is closer to the exact sum.  Three pieces with three products (the usual
-// "bf16x3") are 5x worse than fp32 and are not used.
+// The same product on the BF16 matrix cores, at fp32 accuracy, by error-free operand splitting (round 4; the
+// arithmetic, its error analysis and the measurements against float64 are in sf_split.h).  The gate product was the
+// one MFMA-bound kernel of the path (fp32 MFMA loop at 92 % of the f32 vector rate); six bf16 MFMAs per product are
+// 6/16 of that time, and what bounds the kernel now is moving its operands (timed with the MFMAs removed: 16 of its
+// 20 us).
 //
 // Block = 64 columns x all rows (<= 128, as MT m-tiles of 16) x one K split; 8 waves = 4 n-tiles of 16
 // columns x the 2 K-halves of every 64-deep stage -- the decomposition of gemm_nt_tiled_kernel, with
@@ -402,28 +394,6 @@ __global__ __launch_bounds__(512) void gemm_nt_tiled_kernel(NtArgs a) {
 // the 160 KB at 112 rows).  The split + LDS stores of stage s+1 and the global loads of stage s+3 sit between
 // the MFMAs of stage s: one barrier per stage.  The K halves meet in LDS as in the fp32 kernel.
 // ------------------------------------------------------------------------------------------------
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float f32x2_t __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ unsigned pk_bf16_rn(float lo, float hi) {        // v_cvt_pk_bf16_f32
-    const f32x2_t v = {lo, hi};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
-}
-// float4 -> three planes of 4 bf16 (uint2 each): exact three-way split
-__device__ __forceinline__ void split3_f4(const float4& v, uint2& p1, uint2& p2, uint2& p3) {
-    p1.x = pk_bf16_rn(v.x, v.y);
-    p1.y = pk_bf16_rn(v.z, v.w);
-    const float r0 = v.x - __uint_as_float(p1.x << 16), r1 = v.y - __uint_as_float(p1.x & 0xFFFF0000u);
-    const float r2 = v.z - __uint_as_float(p1.y << 16), r3 = v.w - __uint_as_float(p1.y & 0xFFFF0000u);
-    p2.x = pk_bf16_rn(r0, r1);
-    p2.y = pk_bf16_rn(r2, r3);
-    const float q0 = r0 - __uint_as_float(p2.x << 16), q1 = r1 - __uint_as_float(p2.x & 0xFFFF0000u);
-    const float q2 = r2 - __uint_as_float(p2.y << 16), q3 = r3 - __uint_as_float(p2.y & 0xFFFF0000u);
-    p3.x = pk_bf16_rn(q0, q1);            // (exact: q has <= 8 significant bits)
-    p3.y = pk_bf16_rn(q2, q3);
-}
-
 constexpr int SPL_ROWB = 128;             // bytes per row and plane (64 bf16)
 
 template <int MT>

@@ -7,16 +7,20 @@
 //   * grid = 256 workgroups of 4 waves, one per CU; workgroup b belongs to row group b % 8 (the
 //     XCD it is dispatched to -- a placement that is observed, used for speed only and never relied
 //     on for correctness) and owns hidden units [16 (b / 8), +16) of that group's <= 16 batch rows;
-//   * its [64 gate rows x 512] slice of W_hh lives in REGISTERS for all T steps (128 VGPRs: wave w
-//     holds K-slices {w, w+8, w+4, w+12} of 32 for all four gates), the cell state too;
+//   * its [64 gate rows x 512] slice of W_hh lives in REGISTERS for all T steps (wave w holds K-slices
+//     {w, w+8, w+4, w+12} of 32 for all four gates), the cell state too.  Round 4: the slice is held as
+//     three bf16 planes (192 VGPRs) and the recurrent product runs on the BF16 matrix cores with error-free
+//     operand splitting (sf_split.h: fp32 accuracy, 6/16 of the fp32-MFMA time -- the MFMAs were 1.9 of a
+//     step's 4.5 us); h_t is split by the wave that has just gathered it;
 //   * only h_t travels, and only inside a row group: 32 KB per workgroup per step, through the
 //     group's own L2 when the placement holds.  The exchange needs no flag, counter or fence: every
 //     dword of h IS its own flag.  Three buffers rotate; a producer resets its 1 KB patch of the
 //     buffer two steps ahead to a sentinel (0xFFFFFFFF, a NaN no cell can produce) and consumers
 //     re-read with L1-bypassing (sc1) loads until no sentinel is left.  Stores are write-through
 //     (sc1), so the protocol is correct for ANY workgroup placement.
-//   * summation order is that of lstm_step_wide_kernel (16 K-slices of 32, paired (k, k+8), then
-//     added in order to bias + table row): the two paths give bit-identical h, c, ctx.
+//   * the K-slice partials are combined as in lstm_step_wide_kernel (16 slices of 32, paired (k, k+8), then
+//     added in order to bias + table row); since round 4 the products inside a slice are formed on the bf16
+//     matrix cores, so the two paths agree to fp32 roundoff (1e-6), no longer bit for bit.
 // Every wait is bounded (wall clock): on a timeout the workgroup stops waiting and poisons its
 // outputs with NaN, so a starved launch (co-residency lost to another process) ends instead of
 // hanging, and the loss shows it.  Launches of one process are serialised by a device-wide lock
@@ -24,6 +28,7 @@
 #include "sf_kernels.h"
 #include "sf_gemm_small.h"
 #include "sf_sampling.h"
+#include "sf_split.h"
 
 namespace sf {
 unsigned long long* g_trace = nullptr;     // sf_debug_trace buffer (set in sf_attention.hip)
@@ -138,7 +143,7 @@ struct EncPersistArgs {
     unsigned long long* trace;                                 // sf_debug_trace: [blocks][8] tick sums, or null
 };
 
-__global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
+__global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
     __shared__ float s_red[2][8][4][256];               // paired K-slice partials R_k of the 4 gates, double
                                                         // buffered by step parity: ONE barrier per step
     __shared__ int s_tok[EP_ROWS][EP_TMAX];
@@ -152,14 +157,16 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
     // ---- resident operands --------------------------------------------------------------------
     // wave w: K-slices sj = {w, w+8 | w+4, w+12} (32 k each = chunks 2s, 2s+1), all four gates
     const int sj[4] = {w, w + 8, w + 4, w + 12};
-    float4 wf[4][4][2];
+    // (lane (li, kk) holds, of K-slice sj, k = 32 sj + 4 kk + {0..3} and 32 sj + 16 + 4 kk + {0..3}: the K order inside
+    // an MFMA is free as long as A and B agree, and this one is what the 16-byte exchange loads deliver)
+    Split8 wq[4][4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int cc = 0; cc < 2; ++cc)
-                wf[g][j][cc] = ld4(p.w_hh + (size_t)(g * H + 16 * slot + li) * H + 16 * (2 * sj[j] + cc) + 4 * kk);
+        for (int j = 0; j < 4; ++j) {
+            const float* wp = p.w_hh + (size_t)(g * H + 16 * slot + li) * H + 32 * sj[j] + 4 * kk;
+            wq[g][j] = split3_f8(ld4(wp), ld4(wp + 16));
+        }
     for (int i = tid; i < EP_ROWS * T; i += 256) {
         const int r = i / T, t = i - r * T;
         s_tok[r][t] = r < nrows ? (int)p.seq[(size_t)(row0 + r) * p.Lpad + t] : 0;
@@ -239,28 +246,25 @@ __global__ __launch_bounds__(256, 2) void enc_persist_kernel(EncPersistArgs p) {
             }
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                f32x4 acc[4][2];
+                f32x4 hi[4][2], lo[4][2];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g][0] = acc[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < 4; ++g) hi[g][0] = hi[g][1] = lo[g][0] = lo[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = 2 * h2 + jj;
+                    const Split8 as = split3_f8(
+                        make_float4(__uint_as_float(a[j][0].x), __uint_as_float(a[j][0].y), __uint_as_float(a[j][0].z),
+                                    __uint_as_float(a[j][0].w)),
+                        make_float4(__uint_as_float(a[j][1].x), __uint_as_float(a[j][1].y), __uint_as_float(a[j][1].z),
+                                    __uint_as_float(a[j][1].w)));
 #pragma unroll
-                    for (int cc = 0; cc < 2; ++cc) {
-                        const float4 af = make_float4(__uint_as_float(a[j][cc].x), __uint_as_float(a[j][cc].y),
-                                                      __uint_as_float(a[j][cc].z), __uint_as_float(a[j][cc].w));
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-#pragma unroll
-                            for (int g = 0; g < 4; ++g)
-                                acc[g][jj] = mfma16(comp(af, c), comp(wf[g][j][cc], c), acc[g][jj]);
-                    }
+                    for (int g = 0; g < 4; ++g) mfma_split6(as, wq[g][j], hi[g][jj], lo[g][jj]);
                 }
                 // R_k = P_{k+8} + P_k goes to LDS at once (the stores of the first half ride under
                 // the MFMAs of the second)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 Rk = acc[g][1] + acc[g][0];
+                    const f32x4 Rk = (hi[g][1] + lo[g][1]) + (hi[g][0] + lo[g][0]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s_red[t & 1][w + 4 * h2][g][(kk * 4 + r) * 16 + li] = Rk[r];
                 }

@@ -309,7 +309,8 @@ def test_training_iteration_survives_a_starved_backward(forced_timeout):
         a, b = grads[0][k], grads[1][k]
         assert torch.isfinite(b).all(), k
         s = float(a.abs().max())
-        assert float((a - b).abs().max()) <= 2e-5 * max(s, 1e-6), k     # persistent vs per-step backward: 1e-5 of scale
+        # (persistent bf16-split products vs per-step fp32 MFMA kernels; biases whose true gradient is zero hold 1e-8 roundoff)
+        assert float((a - b).abs().max()) <= 1e-4 * max(s, 1e-3), k
 
 
 def test_speaker_run_falls_back_to_the_per_step_kernels(forced_timeout):
