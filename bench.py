@@ -617,7 +617,7 @@ def main(argv=None):
     if extras and not train and world == 1:
         from speaker_follower_amd import bench_extras
         out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2], one batch
-        out['speaker_sweep'] = bench_extras.speaker_sweep(store, device)            # configs[2], 2000 distinct paths
+        out['speaker_sweep'] = bench_extras.speaker_sweep(store, device)            # configs[2]: all 178 300 paths, measured
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):

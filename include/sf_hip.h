@@ -465,6 +465,14 @@ int sf_gather_candidates(const sf_cands* U, int B, float* all_u /* [B,A,F] */,
                          float* is_valid /* [B,A] */, sf_stream stream);
 /* rows [B,F] of single chosen actions (speaker.py:104): a == 0 / vp < 0 => zeros */
 int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf_stream stream);
+/* The chosen-action embeddings of all N = Tp*B (path step, path) pairs of a speaker batch (speaker.py:87-104:
+ * `ob['action_embedding'][a]`, zeros for a stop action or a padded step) in one launch: row n of `out` (row stride
+ * ld_out floats >= IMG + LOC, so the rows can be the first half of the encoder's LSTM inputs) =
+ * table[vp[n], act_view[n]] || [sin h]xg,[cos h]xg,[sin e]xg,[cos e]xg (g = LOC/4; env.py:60-75) where act[n] > 0 and
+ * vp[n] >= 0, zeros elsewhere.  table [n_vp,V,IMG]; act_sincos [N,4]. */
+int sf_gather_path_actions(const float* table, int V, int IMG, int LOC, const int32_t* vp, const int32_t* act_view,
+                           const float* act_sincos, const int32_t* act, int N, float* out, int ld_out,
+                           sf_stream stream);
 
 /* ---- speaker (model.py:429-457, 487-519; speaker.py:158-197) ---------------------------------- */
 typedef struct sf_spk_decoder_w {

@@ -106,33 +106,48 @@ def speaker_decode(store, device, batch=100, words=80):
 
 
 @_guard
-def speaker_sweep(store, device, n_paths=2000, batch=100, words=80):
+def speaker_sweep(store, device, n_paths=178300, batch=100, words=80):
     """configs[2] as the reference runs it (data_augmentation_from_speaker.py:56-58: Seq2SeqSpeaker.test with argmax
-    feedback over the 178 300 sampled trajectories, one minibatch after the other): `n_paths` DISTINCT synthetic
-    paths (4-7 steps, ragged inside every minibatch) in minibatches of `batch`; host packing and upload of every
-    index batch, greedy decoding of `words` words, and the D2H copy of the generated word ids are all inside the
-    timed region.  The 178 300-path figure is this measured rate extrapolated, and labelled so."""
+    feedback over the 178 300 sampled trajectories, one minibatch after the other), MEASURED over all `n_paths`
+    distinct synthetic paths (4-7 steps, ragged inside every minibatch) in minibatches of `batch`: host packing of
+    every index batch into pinned memory, one H2D copy, greedy decoding of `words` words, and the D2H copy of the
+    generated word ids are all inside the timed region (speaker.SpeakerSweep: two streams, one hipGraph per stream
+    and path-step count, packing of minibatch n+1 beside the device work of n).  The data set itself -- the index
+    arrays of the paths -- is generated before the clock starts, as the reference loads its json before its loop."""
     from . import synth, speaker
+    import time
     enc, dec = _speaker_models(device)
     n_vp = store.table.shape[0]
+    nb = (n_paths + batch - 1) // batch
     sbs = [synth.speaker_batch(seed=500 + i, batch=batch, n_viewpoints=n_vp, min_path=4, max_path=7, min_len=10,
-                               max_len=79) for i in range(n_paths // batch)]
+                               max_len=79) for i in range(nb)]
+    sweep = speaker.SpeakerSweep(enc, dec, store, batch, words)
+    sweep.run(sbs[:40])                                  # warm-up: graph capture for every path-step count, clocks
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = sweep.run(sbs)
+    dt = time.perf_counter() - t0
+    # the same minibatches one after the other on ONE stream, eager issue (round 3's way), on a sample
     eng = speaker.SpeakerEngine(enc, dec, store)
 
-    def sweep():
-        out = []
+    def eager():
+        res = []
         with torch.no_grad():
-            for sb in sbs:
+            for sb in sbs[:20]:
                 st = eng.score(speaker.DeviceSpeakerBatch.from_synth(sb, device=device), words, 'argmax', train=False)
-                out.append(st.words[1:].cpu())                       # the generated instructions leave the device
-        return out
-    dt = _timed(sweep, 1, 2)
-    n = len(sbs) * batch
-    return dict(what='greedy speaker decoding of %d distinct paths (4-7 steps) x %d words in minibatches of %d, eager issue: '
-                     'host packing + upload + decode + D2H of the words per minibatch' % (n, words, batch),
-                value=n / dt, unit='paths/s', seconds=dt, ms_per_minibatch=1e3 * dt / len(sbs),
-                extrapolated_seconds_for_178300_paths=178300 * dt / n,
-                note='the last field is an extrapolation of the measured rate, not a measurement')
+                res.append(st.words[1:].cpu())
+        return res
+    dt_e = _timed(eager, 1, 2)
+    ref = torch.stack(eager()).numpy()
+    n = nb * batch
+    return dict(what='greedy speaker decoding of %d distinct paths (4-7 steps) x %d words in minibatches of %d: host packing '
+                     '+ one H2D copy + decode (hipGraph per stream and path-step count, two streams) + D2H of the words per '
+                     'minibatch, ALL inside the timed region' % (n, words, batch),
+                value=n / dt, unit='paths/s', seconds=dt, paths=n, ms_per_minibatch=1e3 * dt / nb,
+                host_packing_seconds=sweep.host_pack_s,
+                words_equal_single_stream_eager=bool((out[:20].astype('int64') == ref).all()),
+                single_stream_eager_ms_per_minibatch=1e3 * dt_e / 20,
+                note='measured over the whole sweep, nothing extrapolated')
 
 
 @_guard

@@ -1382,6 +1382,14 @@ int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf
     return gather_actions(cands(U), B, a, out, S(stream));
 }
 
+int sf_gather_path_actions(const float* table, int V, int IMG, int LOC, const int32_t* vp, const int32_t* act_view,
+                           const float* act_sincos, const int32_t* act, int N, float* out, int ld_out,
+                           sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(table && vp && act_view && act_sincos && act && out && N > 0 && V > 0 && ld_out >= IMG + LOC);
+    return gather_path_actions(table, V, IMG, LOC, vp, act_view, act_sincos, act, N, out, ld_out, S(stream));
+}
+
 // ---- search helpers -----------------------------------------------------------------------
 int sf_gather_rows(const float* src, int ld_src, const int32_t* idx, int n, int width, float* dst,
                    int ld_dst, sf_stream stream) {

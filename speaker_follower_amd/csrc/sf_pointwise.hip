@@ -298,6 +298,28 @@ __global__ __launch_bounds__(TPB) void gather_action_kernel(CandSrc s, int B, co
     }
 }
 
+// The chosen-action embeddings of ALL path steps of a speaker batch (speaker.py:87-104: `action_embedding[a]` of
+// every (step, path), zeros for stop actions and padded steps) in one launch, written with a row stride -- i.e.
+// straight into the first half of the encoder's LSTM inputs.  Row n: table[vp[n], act_view[n]] || sin/cos groups.
+__global__ __launch_bounds__(TPB) void gather_path_actions_kernel(const float* table, int V, int IMG, int LOC, const int* vp,
+                                                                  const int* act_view, const float* sincos, const int* act,
+                                                                  int N, float* out, int ldo) {
+    const int n4 = (IMG + LOC) >> 2;
+    const size_t total = (size_t)N * n4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % n4), n = (int)(i / n4);
+        const int v = vp[n], view = act_view[n];
+        const float4 sc = reinterpret_cast<const float4*>(sincos)[n];
+        CandRow r;
+        r.I4 = IMG >> 2;
+        r.g4 = max(LOC >> 4, 1);
+        r.img = reinterpret_cast<const float4*>(table) + ((size_t)max(v, 0) * V + min(max(view, 0), V - 1)) * r.I4;
+        r.s0 = sc.x; r.s1 = sc.y; r.s2 = sc.z; r.s3 = sc.w;
+        r.zero = false;
+        reinterpret_cast<float4*>(out + (size_t)n * ldo)[c] = cand_load(r, c, act[n] > 0 && v >= 0, n4);
+    }
+}
+
 // ---- search helpers (follower.py:541-980, speaker.py:211-318) ---------------------------------------
 // dst[i, :w] = src[idx[i], :w]  (idx < 0 => zeros): `h_t[flat_indices]`, `c_t[flat_indices]`
 __global__ __launch_bounds__(TPB) void gather_rows_kernel(const float* src, int lds, const int* idx,
@@ -598,33 +620,27 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const float* sum_cnt,
 // loop) and zeroes gscale behind the last step (no gradient flows from steps the reference never adds).
 __global__ __launch_bounds__(1024) void speaker_loss_finalize_kernel(const float* sum_cnt, const int64_t* words, int eos,
                                                                      int T, int B, float* loss, float* gscale) {
-    __shared__ int s_first[1024];
+    __shared__ int s_first[1024];              // per row (B <= 1024): first step whose word is EOS
     __shared__ int s_end;
     const int tid = threadIdx.x;
-    // per row (one wave each, 16 rows at a time) the first step whose word is EOS, T - 1 if there is none
-    int t_end = 0;
-    for (int b0 = 0; b0 < B; b0 += 1024 / 64) {                 // 16 rows at a time, one wave per row
-        const int b = b0 + (tid >> 6), lane = tid & 63;
-        int first = T - 1;                                      // never ended: the loop runs all T steps
-        if (b < B) {
-            int f = 0x7FFFFFFF;
-            for (int t = lane; t < T; t += 64)
-                if (words[(size_t)(t + 1) * B + b] == eos) { f = t; break; }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) f = min(f, __shfl_xor(f, off, WAVE));
-            if (f != 0x7FFFFFFF) first = f;
-        } else {
-            first = 0;
-        }
-        t_end = max(t_end, first);
-    }
-    s_first[tid] = t_end;
+    s_first[tid] = T - 1;                      // never ended: the reference's loop runs all T steps
+    if (tid == 0) s_end = 0;
     __syncthreads();
-    if (tid == 0) {
-        int e = 0;
-        for (int i = 0; i < 1024; i += 64) e = max(e, s_first[i]);
-        s_end = e;
+    // every (step, row) is looked at once; the loads of a pass are issued together, straight-line on clamped indices
+    // (a load behind the EOS test would cost one memory round trip per iteration)
+    const int n = T * B;
+    for (int base = 0; base < n; base += 8 * 1024) {
+        int64_t w[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) w[u] = words[(size_t)B + min(base + u * 1024 + tid, n - 1)];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = base + u * 1024 + tid;
+            if (i < n && w[u] == eos) atomicMin(&s_first[i % B], i / B);
+        }
     }
+    __syncthreads();
+    if (tid < B) atomicMax(&s_end, s_first[tid]);
     __syncthreads();
     const int last = s_end;                                      // steps 0 .. last are added
     if (tid < 64) {
@@ -824,6 +840,13 @@ int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_
                        dim3(TPB), 0, st, s, B, a, out);
     return launch_status();
 }
+int gather_path_actions(const float* table, int V, int IMG, int LOC, const int* vp, const int* act_view,
+                        const float* sincos, const int* act, int N, float* out, int ldo, hipStream_t st) {
+    if ((IMG & 3) || (LOC & 15) || (ldo & 3)) return SF_ERR_UNSUPPORTED;
+    SF_LAUNCH(gather_path_actions_kernel, dim3(grid1d((size_t)N * ((IMG + LOC) >> 2))), dim3(TPB), 0, st, table, V, IMG,
+              LOC, vp, act_view, sincos, act, N, out, ldo);
+    return launch_status();
+}
 int gather_rows(const float* src, int lds, const int* idx, int n, int w, float* dst, int ldd,
                 hipStream_t st) {
     if ((w & 3) || (lds & 3) || (ldd & 3)) return SF_ERR_UNSUPPORTED;
@@ -865,7 +888,7 @@ int reduce_terms(const float* term, const float* live, int T, int B, float* sum_
 }
 int speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos, int T, int B, float* loss, float* gscale,
                           hipStream_t st) {
-    if (T > 1024) return SF_ERR_UNSUPPORTED;
+    if (T > 1024 || B > 1024) return SF_ERR_UNSUPPORTED;
     SF_LAUNCH(speaker_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sum_cnt, words, eos, T, B, loss, gscale);
     return launch_status();
 }

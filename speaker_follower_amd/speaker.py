@@ -154,10 +154,18 @@ class SpeakerEngine:
         d_enc = dropout_arg(*st.drop_enc)
         # the chosen-action embeddings of ALL path steps in one gather ([Tp*B] rows: the index arrays are
         # [Tp,B] contiguous), and -- without dropout -- one strided copy into the LSTM inputs of all steps
-        st.e['act_emb'] = store.gather_actions(batch.vp.reshape(-1), batch.act_view.reshape(-1),
-                                               batch.act_sincos.reshape(-1, 4), batch.act.reshape(-1)).view(Tp, B, F)
+        # the chosen-action embeddings of ALL path steps in one launch (the index arrays are [Tp,B] contiguous): without
+        # dropout straight into the first half of the LSTM inputs, with dropout into a dense copy the steps mask
+        gat = lambda out, ld: call('sf_gather_path_actions', ptr(store.table), V, store.IMG, store.LOC, ptr(batch.vp),   # noqa: E731
+                                   ptr(batch.act_view), ptr(batch.act_sincos), ptr(batch.act), Tp * B, ptr(out), ld, ws[2])
         if d_enc is None:
-            call('sf_dropout_copy', ptr(st.e['act_emb']), F, Tp * B, F, ptr(st.e['xin']), 2 * F, None, 0, 0, ws[2])
+            st.e['act_emb'] = None
+            gat(st.e['xin'], 2 * F)
+        else:
+            st.e['act_emb'] = new(Tp, B, F)
+            gat(st.e['act_emb'], F)
+        # eval mode: the LSTM cell also writes h_t into ctx[:, t] (its second output), no stacking copy afterwards
+        st.ctx = new(B, Tp, H)
         for t in range(Tp):
             pano = store.pano(batch.vp[t], batch.view[t])
             xin_f = C.c_void_p(st.e['xin'][t].data_ptr() + 4 * F)
@@ -169,17 +177,19 @@ class SpeakerEngine:
                      d_enc, 2 * (st.site0 + t), 0, ws[2])
             call('sf_lstm_cell_fwd', byref(lw), B, 2 * F, H, ptr(st.e['xin'][t]), 2 * F,
                  ptr(st.e['hs'][t]), ptr(st.e['cs'][t]), ptr(st.e['hs'][t + 1]),
-                 ptr(st.e['cs'][t + 1]), ptr(st.e['gates'][t]), None, 0, None, 0, *ws)
+                 ptr(st.e['cs'][t + 1]), ptr(st.e['gates'][t]),
+                 C.c_void_p(st.ctx.data_ptr() + 4 * t * H) if d_enc is None else None, Tp * H if d_enc is None else 0,
+                 None, 0, *ws)
         # decoder_init = tanh(encoder2decoder(h)) (model.py:453); ctx = dropout(stack(h)) (:455-456)
         st.h_init = new(B, H)
         e2d = enc.encoder2decoder
         call('sf_linear_fwd', ptr(st.e['hs'][Tp]), H, ptr(e2d.weight), ptr(e2d.bias), B, H, H, 1,
              ptr(st.h_init), H, *ws)
         st.c_init = st.e['cs'][Tp]
-        ctx_raw = st.e['hs'][1:].permute(1, 0, 2).contiguous()          # [B,Tp,H]
-        st.ctx = new(B, Tp, H)
-        call('sf_dropout_copy', ptr(ctx_raw), Tp * H, B, Tp * H, ptr(st.ctx), Tp * H, d_enc,
-             2 * (st.site0 + Tp) + 1, 0, ws[2])
+        if d_enc is not None:
+            ctx_raw = st.e['hs'][1:].permute(1, 0, 2).contiguous()      # [B,Tp,H]
+            call('sf_dropout_copy', ptr(ctx_raw), Tp * H, B, Tp * H, ptr(st.ctx), Tp * H, d_enc,
+                 2 * (st.site0 + Tp) + 1, 0, ws[2])
 
         # ---- decoder: S x (embedding -> LSTMCell -> dropout -> attention -> vocab projection)
         shapes = dict(emb=(E,), gates=(4 * H,), c1=(H,), h1=(H,), cat2=(2 * H,), t_text=(H,),
@@ -322,3 +332,132 @@ class SpeakerEngine:
                  2 * (st.site0 + t), F, ptr(dh_out), *ws)
             dh_in, dh_out = dh_out, dh_in
             dc_in, k = dc_bufs[k], k ^ 1
+
+
+# ------------------------------------------------------------------------------------------------
+# Throughput path for configs[2] (data_augmentation_from_speaker.py:35-82: Seq2SeqSpeaker.test over 178 300 sampled
+# trajectories, one minibatch after the other): packed index batches, double-buffered pinned staging, two streams.
+# ------------------------------------------------------------------------------------------------
+def packed_layout(B, Tp, Lmax):
+    """Byte offsets of one index-form speaker minibatch inside ONE contiguous buffer (8-byte aligned sections):
+    what the host packs, one H2D copy moves and DeviceSpeakerBatch.from_packed views on the device."""
+    off, lay = 0, {}
+    for name, n, isz in (('instr_seq', B * Lmax, 8), ('vp', Tp * B, 4), ('view', Tp * B, 4), ('act', Tp * B, 4),
+                         ('act_view', Tp * B, 4), ('act_sincos', Tp * B * 4, 4), ('path_mask', B * Tp, 1)):
+        lay[name] = (off, n * isz)
+        off = (off + n * isz + 7) & ~7
+    lay['bytes'] = off
+    return lay
+
+
+def pack_speaker_batch(sb, out, Lmax=80, Tp=None):
+    """Writes a synth.SpeakerBatch-like index batch (instr, path_len, vp, view, act_view, act_heading, act_elevation,
+    act_is_stop: speaker.py:68-121 in index form) into the uint8 numpy buffer `out` in `packed_layout` order.  Same
+    values as DeviceSpeakerBatch.from_synth.  Returns (B, Tp)."""
+    Tp_all, B = sb.vp.shape
+    Tp = int(sb.path_len.max()) if Tp is None else Tp
+    lay = packed_layout(B, Tp, Lmax)
+    view = lambda name, dt, shape: out[lay[name][0]:lay[name][0] + lay[name][1]].view(dt).reshape(shape)   # noqa: E731
+    seq = view('instr_seq', np.int64, (B, Lmax))
+    seq[:] = PAD
+    for i, inst in enumerate(sb.instr):                                   # follower.py:75-105, reverse=False
+        n = min(len(inst), Lmax - 1)
+        seq[i, :n] = inst[:n]
+        if len(inst) + 1 <= Lmax:
+            seq[i, n] = EOS
+        else:
+            seq[i, Lmax - 1] = inst[Lmax - 1]
+    live = np.arange(Tp)[:, None] < sb.path_len[None, :]
+    view('vp', np.int32, (Tp, B))[:] = np.where(live, sb.vp[:Tp], -1)
+    view('view', np.int32, (Tp, B))[:] = sb.view[:Tp]
+    view('act', np.int32, (Tp, B))[:] = live & ~sb.act_is_stop[:Tp]
+    view('act_view', np.int32, (Tp, B))[:] = sb.act_view[:Tp]
+    view('act_sincos', np.float32, (Tp, B, 4))[:] = cand_sincos(sb.act_heading[:Tp], sb.act_elevation[:Tp])
+    view('path_mask', np.uint8, (B, Tp))[:] = (~live).T
+    return B, Tp
+
+
+def batch_from_packed(buf, B, Tp, Lmax=80, row0=0):
+    """DeviceSpeakerBatch whose tensors are VIEWS of the device uint8 buffer `buf` (packed_layout order)."""
+    lay = packed_layout(B, Tp, Lmax)
+    view = lambda name, dt, shape: buf[lay[name][0]:lay[name][0] + lay[name][1]].view(dt).view(shape)   # noqa: E731
+    return DeviceSpeakerBatch(instr_seq=view('instr_seq', torch.int64, (B, Lmax)),
+                              path_mask=view('path_mask', torch.uint8, (B, Tp)),
+                              vp=view('vp', torch.int32, (Tp, B)), view=view('view', torch.int32, (Tp, B)),
+                              act=view('act', torch.int32, (Tp, B)), act_view=view('act_view', torch.int32, (Tp, B)),
+                              act_sincos=view('act_sincos', torch.float32, (Tp, B, 4)), row0=row0)
+
+
+class SpeakerSweep:
+    """Greedy (or sampled) decoding of MANY path minibatches at full device rate.
+
+    Per stream (two by default) and per path-step count Tp one captured hipGraph of the whole pass (encoder + the
+    persistent word loop) over a static device staging buffer; per minibatch the host packs the index arrays into a
+    pinned buffer (its own, one per stream and slot: packing minibatch n+1 overlaps the device work of n), ONE
+    asynchronous H2D copy, a graph replay, and an asynchronous D2H copy of the words (int16) into a pinned result
+    array.  The streams alternate, so the encoder kernels of one minibatch run beside the other's word loop -- a
+    persistent launch of one 4-wave workgroup per CU that leaves most issue slots idle.  Every persistent launch is
+    checked through the fault word at the end (runtime.take_fault); a sweep that saw a fault is re-run per-step."""
+
+    def __init__(self, encoder, decoder, store, batch_size, words, feedback='argmax', Lmax=80, n_streams=2, slots=2):
+        self.enc, self.dec, self.store = encoder, decoder, store
+        self.B, self.S, self.Lmax, self.feedback = batch_size, words, Lmax, feedback
+        self.streams = [torch.cuda.Stream(device=store.device) for _ in range(n_streams)]
+        self.slots = slots
+        self.graphs = {}                 # (stream index, Tp) -> (replay, state, device staging buffer)
+        cap = packed_layout(batch_size, 16, Lmax)['bytes']
+        self.pinned = [[torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(slots)] for _ in self.streams]
+        self.free_ev = [[None] * slots for _ in self.streams]
+        self.host_pack_s = 0.0
+
+    def _graph(self, si, Tp):
+        key = (si, Tp)
+        if key not in self.graphs:
+            dev = self.store.device
+            buf = torch.zeros(packed_layout(self.B, Tp, self.Lmax)['bytes'], dtype=torch.uint8, device=dev)
+            batch = batch_from_packed(buf, self.B, Tp, self.Lmax)
+            batch.vp.fill_(0)
+            batch.instr_seq.fill_(EOS)
+            with torch.cuda.stream(self.streams[si]):
+                eng = SpeakerEngine(self.enc, self.dec, self.store)
+                replay, st = eng.capture(batch, self.S, self.feedback)
+                words16 = torch.empty(self.S, self.B, dtype=torch.int16, device=dev)
+            torch.cuda.synchronize(dev)
+            self.graphs[key] = (replay, st, buf, words16)
+        return self.graphs[key]
+
+    def run(self, batches):
+        """`batches`: sequence of synth.SpeakerBatch-like index batches of `batch_size` paths.  Returns an int16 array
+        [n, S, B] of generated word ids (pinned host memory)."""
+        import time
+        dev = self.store.device
+        n = len(batches)
+        out = torch.empty(n, self.S, self.B, dtype=torch.int16).pin_memory()
+        self.host_pack_s = 0.0
+        from .runtime import take_fault
+        take_fault(dev)
+        for i, sb in enumerate(batches):
+            si, slot = i % len(self.streams), (i // len(self.streams)) % self.slots
+            pin = self.pinned[si][slot]
+            if self.free_ev[si][slot] is not None:
+                self.free_ev[si][slot].synchronize()            # its previous H2D copy has left the buffer
+            t0 = time.perf_counter()
+            B, Tp = pack_speaker_batch(sb, pin.numpy(), self.Lmax)
+            self.host_pack_s += time.perf_counter() - t0
+            assert B == self.B
+            replay, st, buf, words16 = self._graph(si, Tp)
+            with torch.cuda.stream(self.streams[si]):
+                buf.copy_(pin[:buf.numel()], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                self.free_ev[si][slot] = ev
+                replay()
+                words16.copy_(st.words[1:])                      # int64 -> int16 on the device (ids < 2^15)
+                out[i].copy_(words16, non_blocking=True)
+        for s in self.streams:
+            s.synchronize()
+        bits = take_fault(dev)
+        if bits:
+            raise PersistentLaunchFault('a persistent word loop of the sweep gave up a wait (fault bits %d): re-run with '
+                                        'SpeakerEngine.persistent = False' % bits)
+        return out.numpy()

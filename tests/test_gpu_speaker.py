@@ -136,3 +136,22 @@ def test_speaker_engine_golden(speaker_modules, sbatch, golden, feedback):
         _check_grads({k: p.grad for k, p in dec.named_parameters() if p.grad is not None}, g, 'dec/')
         for m in (enc, dec):
             m.zero_grad(set_to_none=True)
+
+
+def test_pipelined_sweep_equals_minibatch_by_minibatch_decoding(speaker_modules):
+    """speaker.SpeakerSweep (configs[2]: packed index batches, pinned double buffers, two streams, one hipGraph per
+    stream and path-step count) generates exactly the words the plain engine generates minibatch by minibatch --
+    including minibatches whose longest path differs (the encoder runs max(path_len) steps, speaker.py:87-104)."""
+    from speaker_follower_amd import features, speaker
+    enc, dec = speaker_modules
+    store = features.FeatureStore(synth.feature_table(7, 64))
+    B, S = 24, 20
+    sbs = [synth.speaker_batch(seed=100 + i, batch=B, n_viewpoints=64, min_path=2 + i % 3, max_path=4 + i % 4,
+                               min_len=3, max_len=25) for i in range(9)]
+    assert len({int(sb.path_len.max()) for sb in sbs}) >= 3
+    out = speaker.SpeakerSweep(enc, dec, store, B, S).run(sbs)
+    eng = speaker.SpeakerEngine(enc, dec, store)
+    for i, sb in enumerate(sbs):
+        with torch.no_grad():
+            st = eng.score(speaker.DeviceSpeakerBatch.from_synth(sb), S, 'argmax', train=False)
+        assert np.array_equal(out[i].astype(np.int64), st.words[1:].cpu().numpy()), i

@@ -261,3 +261,23 @@ def test_checkpoint_files_and_result_json_follow_the_reference_layout(tmp_path):
     agent.write_results()
     out = json.load(open(tmp_path / 'res.json'))
     assert out == {'7_0': {'instr_id': '7_0', 'trajectory': [['vp', 0.0, 0.0]]}}
+
+
+def test_packed_speaker_batch_equals_the_field_by_field_upload():
+    """speaker.pack_speaker_batch / batch_from_packed (one buffer, one H2D copy per minibatch: the configs[2] sweep)
+    hold exactly what DeviceSpeakerBatch.from_synth uploads field by field -- ragged paths, instructions longer than
+    the word budget included."""
+    import torch
+    from speaker_follower_amd import synth, speaker
+    sb = synth.speaker_batch(seed=11, batch=9, n_viewpoints=50, min_path=2, max_path=6, min_len=3, max_len=40)
+    Lmax = 24                                       # some instructions are longer than this: truncation path
+    want = speaker.DeviceSpeakerBatch.from_synth(sb, device='cpu', max_length=Lmax)
+    Tp = int(sb.path_len.max())
+    buf = torch.zeros(speaker.packed_layout(9, Tp, Lmax)['bytes'], dtype=torch.uint8)
+    B, Tp2 = speaker.pack_speaker_batch(sb, buf.numpy(), Lmax)
+    assert (B, Tp2) == (9, Tp)
+    got = speaker.batch_from_packed(buf, B, Tp, Lmax)
+    for f in ('instr_seq', 'path_mask', 'view', 'act', 'act_view', 'act_sincos'):
+        a, b = getattr(got, f), getattr(want, f)
+        assert a.dtype == b.dtype and torch.equal(a, b[:Tp] if f not in ('instr_seq', 'path_mask') else b[:, :a.shape[1]]), f
+    assert torch.equal(got.vp, want.vp[:Tp])
