@@ -444,7 +444,21 @@ typedef struct sf_encoder_w {
     int32_t flags;
 } sf_encoder_w;
 #define SF_ENC_PER_STEP 1
-typedef struct sf_encoder_g { sf_lstm_g lstm; float *w_e2d, *b_e2d; } sf_encoder_g;
+/* The embedding is TRAINABLE (glove=None, model.py:57-60): the reference then also applies its dropout module to
+ * the embedded tokens (model.py:86-87), with the probability of `drop` at site drop_stream ^ 0x40000000, keyed on
+ * (global row b, column t*E + e).  Needs tape->emb and tape->xg and xw_table == NULL (the input product of dropped
+ * embeddings is not a table row). */
+#define SF_ENC_EMB_DROPOUT 2
+/* embedding (optional): gradient of embedding.weight [vocab,E], accumulated: row seq[b,t] += dropout-mask x
+ * (dgates[t,b] W_ih); rows of token `padding_idx` receive nothing (nn.Embedding(padding_idx), model.py:55).  Needs
+ * seq / Lpad as given to the forward. */
+typedef struct sf_encoder_g {
+    sf_lstm_g lstm;
+    float *w_e2d, *b_e2d;
+    float* embedding;
+    const int64_t* seq;
+    int32_t Lpad, padding_idx;
+} sf_encoder_g;
 typedef struct sf_encoder_tape { float *emb, *xg, *gates, *hs, *cs; } sf_encoder_tape;
 int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, int H,
                         const int64_t* seq, const int32_t* lengths, float* ctx,
@@ -484,8 +498,14 @@ typedef struct sf_spk_decoder_w {
      * input half of the LSTM gates becomes a row lookup by the previous word (model.py:497 + :515)
      * and the recurrent step is as short as the encoder's.  NULL = multiply every step. */
     const float* xw_table;
+    /* SF_SPK_EMB_DROPOUT: the embedding is trainable (glove=None): model.py:499-500 applies dropout to the embedded
+     * word in train mode -- site 2*step_id of `drop`; needs tape->emb and xw_table == NULL. */
+    int32_t flags;
 } sf_spk_decoder_w;
-typedef struct sf_spk_decoder_g { sf_lstm_g lstm; sf_softdot_g attn; float *w_out, *b_out; } sf_spk_decoder_g;
+#define SF_SPK_EMB_DROPOUT 1
+/* embedding (optional): gradient of embedding.weight [vocab,E], accumulated: row prev_word[b] += mask x (dgates W_ih)
+ * (no padding row: model.py:467 builds the speaker's nn.Embedding without padding_idx). */
+typedef struct sf_spk_decoder_g { sf_lstm_g lstm; sf_softdot_g attn; float *w_out, *b_out; float* embedding; } sf_spk_decoder_g;
 typedef struct sf_spk_decoder_tape {
     float *emb;     /* [B,E] */
     float *gates, *c1, *h1, *cat2, *t_text, *alpha, *h_tilde;
@@ -518,8 +538,9 @@ int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab
                       uint8_t* ended, float* step_scores, float* nll_term, float* live, float* logits,
                       float* alpha, float* h1_tape, float* c1_tape, const sf_sample* sample, void* ws,
                       size_t ws_bytes, sf_stream stream);
+/* prev_word [B]: the words the forward embedded (only read when g->embedding is set; NULL otherwise). */
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E,
-                           int H, int Tp, int vocab, const float* h0, const float* c0,
+                           int H, int Tp, int vocab, const int64_t* prev_word, const float* h0, const float* c0,
                            const float* ctx, const sf_spk_decoder_tape* tape, const float* dlogit,
                            const float* dh1, const float* dc1, float* dh0, float* dc0, float* dctx,
                            const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,

@@ -86,7 +86,8 @@ class EncoderW(C.Structure):
 
 
 class EncoderG(C.Structure):
-    _fields_ = [('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p)]
+    _fields_ = [('lstm', LstmW), ('w_e2d', c_p), ('b_e2d', c_p), ('embedding', c_p), ('seq', c_p),
+                ('Lpad', C.c_int32), ('padding_idx', C.c_int32)]
 
 
 EncoderTape = _ptr_struct('EncoderTape', ['emb', 'xg', 'gates', 'hs', 'cs'])
@@ -94,11 +95,11 @@ EncoderTape = _ptr_struct('EncoderTape', ['emb', 'xg', 'gates', 'hs', 'cs'])
 
 class SpkDecoderW(C.Structure):
     _fields_ = [('embedding', c_p), ('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p),
-                ('b_out', c_p), ('xw_table', c_p)]
+                ('b_out', c_p), ('xw_table', c_p), ('flags', C.c_int32)]
 
 
 class SpkDecoderG(C.Structure):
-    _fields_ = [('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p), ('b_out', c_p)]
+    _fields_ = [('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p), ('b_out', c_p), ('embedding', c_p)]
 
 
 class Sample(C.Structure):
@@ -191,7 +192,7 @@ _SIGNATURES = {
     'sf_logprob_topk': (C.c_int, [c_f, i32, i32, i32, c_p, i32, c_p, c_f, c_p]),
     'sf_speaker_decoder_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i64p, c_f, c_f,
                                          c_f, c_p, c_p, P(SpkDecoderTape), P(Dropout), u32] + WS),
-    'sf_speaker_decoder_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32,
+    'sf_speaker_decoder_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32, i64p,
                                          c_f, c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, c_f,
                                          c_f, P(Dropout), u32] + WS),
     'sf_speaker_decode': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i32, i32, i32, i64p, c_f, c_f, c_f, c_p,
@@ -214,6 +215,8 @@ _SIGNATURES = {
 
 SF_OK, SF_ERR_ARG, SF_ERR_UNSUPPORTED, SF_ERR_LAUNCH, SF_ERR_WORKSPACE = 0, 1, 2, 3, 4
 SF_ENC_PER_STEP = 1           # sf_encoder_w.flags
+SF_ENC_EMB_DROPOUT = 2
+SF_SPK_EMB_DROPOUT = 1        # sf_spk_decoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)
 ABI_VERSION = 7

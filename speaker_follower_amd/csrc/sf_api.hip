@@ -1238,6 +1238,10 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     // backward's dW_ih; an inference call with the input-product table passes tape->emb = NULL)
     SF_CHECK_ARG(tp->emb || w->xw_table);
     if (tp->emb) TRY(embedding_tm(w->embedding, E, seq, B, Lpad, T, tp->emb, st));
+    if (w->flags & SF_ENC_EMB_DROPOUT) {         // trainable embedding: model.py:86-87 drops the embedded tokens
+        SF_CHECK_ARG(tp->emb && !w->xw_table);
+        TRY(dropout_tm(tp->emb, T, B, E, make_dropout(drop, drop_stream ^ 0x40000000u), st));
+    }
     // input product: a row of the host's [vocab,4H] table per token, or hoisted for all steps at
     // once ([T*B,E] x [E,4H])
     if (!w->xw_table) SF_CHECK_ARG(tp->emb && tp->xg);
@@ -1361,6 +1365,18 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
         if (g->lstm.w_hh) TRY(gemm_tn(tp->xg, 4 * H, tp->hs, H, T * B, 4 * H, H, g->lstm.w_hh, H, 1, st, ar.rest(), ar.rest_n()));
         if (g->lstm.w_ih) TRY(gemm_tn(tp->xg, 4 * H, tp->emb, E, T * B, 4 * H, E, g->lstm.w_ih, E, 1, st, ar.rest(), ar.rest_n()));
         TRY(colsum_pair(tp->xg, 4 * H, T * B, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
+        if (g->embedding) {
+            // trainable embedding (model.py:57-60): d emb = dgates W_ih for all steps at once, through the dropout of
+            // the embedded tokens, scattered into the rows of their tokens
+            SF_CHECK_ARG(g->seq && g->Lpad >= T);
+            Arena ea = ar;
+            float* demb = ea.take((size_t)T * B * E);
+            NEED(demb);
+            TRY(data_grad(tp->xg, 4 * H, w->lstm.w_ih, w->lstm.w_ih_t, T * B, 4 * H, E, demb, E, 0, ea, st));
+            const Dropout de = (w->flags & SF_ENC_EMB_DROPOUT) ? make_dropout(drop, drop_stream ^ 0x40000000u)
+                                                               : make_dropout(nullptr, 0);
+            TRY(embedding_bwd(demb, E, g->seq, g->Lpad, T, B, E, g->padding_idx, de, g->embedding, st));
+        }
     }
     return SF_OK;
 }
@@ -1418,6 +1434,10 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
     const int ldv = (vocab + 3) & ~3;
     const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
     if (tp->emb) TRY(embedding_rows(w->embedding, E, prev_word, B, tp->emb, st));   // :497-498
+    if (w->flags & SF_SPK_EMB_DROPOUT) {          // trainable embedding: :499-500 drops the embedded word
+        SF_CHECK_ARG(tp->emb && !w->xw_table);
+        TRY(dropout_tm(tp->emb, 1, B, E, make_dropout(drop, 2 * step_id), st));
+    }
     if (w->xw_table && H % 16 == 0 && H <= 1024) {
         // x W_ih^T is a row of the precomputed [vocab,4H] table: recurrent half only
         LstmStepArgs f{};
@@ -1468,7 +1488,7 @@ int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab
 }
 
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H,
-                           int Tp, int vocab, const float* h0, const float* c0, const float* ctx,
+                           int Tp, int vocab, const int64_t* prev_word, const float* h0, const float* c0, const float* ctx,
                            const sf_spk_decoder_tape* tp, const float* dlogit, const float* dh1,
                            const float* dc1, float* dh0, float* dc0, float* dctx,
                            const sf_dropout* drop, uint32_t step_id, void* ws, size_t ws_bytes,
@@ -1490,9 +1510,18 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
     TRY(softdot_bwd_i(&w->attn, g ? &g->attn : nullptr, B, Tp, H, ctx, tp->alpha, tp->cat2,
                       tp->t_text, tp->h_tilde, dht, dh1d, H, dctx, ar, st));
     TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
-    // the GloVe embedding is frozen (model.py:472): no gradient wrt the LSTM input is needed
-    return lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, E, H, tp->emb, E, h0, c0, tp->c1,
-                      tp->gates, dh1, dh1m, dc1, nullptr, 0, dh0, dc0, ar, st);
+    // a frozen (GloVe) embedding needs no gradient wrt the LSTM input (model.py:472); a trainable one gets
+    // d emb = dgates W_ih through its dropout, scattered into the rows of the previous words
+    if (!(g && g->embedding))
+        return lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, E, H, tp->emb, E, h0, c0, tp->c1,
+                          tp->gates, dh1, dh1m, dc1, nullptr, 0, dh0, dc0, ar, st);
+    SF_CHECK_ARG(prev_word && tp->emb);
+    float* demb = ar.take((size_t)B * E);
+    NEED(demb);
+    TRY(lstm_bwd_i(&w->lstm, &g->lstm, B, E, H, tp->emb, E, h0, c0, tp->c1, tp->gates, dh1, dh1m, dc1, demb, E, dh0, dc0,
+                   ar, st));
+    const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * step_id) : make_dropout(nullptr, 0);
+    return embedding_bwd(demb, E, prev_word, 1, 1, B, E, -1, de, g->embedding, st);
 }
 
 int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,

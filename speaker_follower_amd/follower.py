@@ -20,7 +20,7 @@ from . import _lib
 from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
-                    grad_ptr, require_frozen_embedding)
+                    grad_ptr, trainable_embedding)
 from .runtime import ptr, stream, ws_args, dropout_arg, take_fault, PersistentLaunchFault
 
 byref = C.byref
@@ -162,7 +162,6 @@ class FollowerEngine:
         T = max(batch.lengths)
         Lpad = batch.seq.shape[1]
         training = dec.training if train is None else train
-        require_frozen_embedding(enc, training)          # same refusal as EncoderLSTM.forward
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         st = RolloutState()
         st.batch, st.steps, st.dims = batch, S, (B, A, H, E, F, V, D, T)
@@ -194,7 +193,10 @@ class FollowerEngine:
                            gates=new(T, B, 4 * H) if keep else None, hs=new(T + 1, B, H), cs=new(T + 1, B, H))
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() if st.enc_tape[k] is not None else None
                                  for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
-        ew = _encoder_structs(enc)
+        # a trainable (non-GloVe) embedding with a backward to follow: the input product is formed from the embedded
+        # (train mode: dropped, model.py:86-87) tokens, not read from the cached table
+        st.enc_table = not (keep and trainable_embedding(enc))
+        ew = _encoder_structs(enc, table=st.enc_table)
         call('sf_encoder_lstm_fwd', byref(ew), B, Lpad, T, E, H, ptr(batch.seq),
              ptr(batch.lengths_dev), ptr(st.ctx), ptr(st.h_init), ptr(st.c_init), byref(etp),
              dropout_arg(*st.drop_enc), st.site0, *ws_args(dev))
@@ -460,7 +462,6 @@ class FollowerEngine:
         weight gradient is one product over all S*B stacked rows at the end (sf_attn_decoder_wgrad),
         accumulated in place into param.grad."""
         enc, dec, store = self.encoder, self.decoder, self.store
-        require_frozen_embedding(enc, True)              # no embedding gradient is formed on this path
         batch, S = st.batch, st.steps
         B, A, H, E, F, V, D, T = st.dims
         dev = store.device
@@ -567,7 +568,8 @@ class FollowerEngine:
         else:
             self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws, sync)
         etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
-        ew, eg = _encoder_structs(enc), _encoder_structs(enc, grad=True)
+        ew = _encoder_structs(enc, table=st.enc_table)
+        eg = _encoder_structs(enc, grad=True, seq=None if st.enc_table else batch.seq)
         call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
              ptr(st.h_init), ptr(dctx), ptr(dh1), ptr(dc1), byref(etp), dropout_arg(*st.drop_enc),
              st.site0, *ws)

@@ -237,16 +237,33 @@ class EltwiseProdScoring(nn.Module):
 # ------------------------------------------------------------------------------------------------
 # EncoderLSTM (model.py:43-104)
 # ------------------------------------------------------------------------------------------------
-def _encoder_structs(mod, grad=False):
+def trainable_embedding(mod):
+    """True when a backward may follow that has to reach embedding.weight (glove=None, model.py:57-60): the input
+    product is then formed from the embedded (and, in train mode, dropped: model.py:86-87) tokens instead of being
+    read as a row of the cached [vocab,4H] table, and the embedded tokens are kept for the backward."""
+    return mod.embedding.weight.requires_grad and torch.is_grad_enabled()
+
+
+def _encoder_structs(mod, grad=False, seq=None, table=True):
+    """`table` = read the input product as rows of the cached [vocab,4H] table (False: form it from the embedded
+    tokens, kept for the backward -- what a trainable embedding needs; callers decide with trainable_embedding() in
+    THEIR grad mode: inside autograd.Function.forward / backward the grad mode says nothing)."""
     lstm = mod.lstm
     l4 = (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
     e2d = (mod.encoder2decoder.weight, mod.encoder2decoder.bias)
+    emb = mod.embedding
     if grad:
-        return _lib.EncoderG(_lib.LstmW(*_grads(l4)), *_grads(e2d))
-    lw = _lib.LstmW(*(p.data_ptr() for p in l4), None, transposed(l4[1]).data_ptr())
-    return _lib.EncoderW(mod.embedding.weight.data_ptr(), lw, *(p.data_ptr() for p in e2d),
-                         transposed(e2d[0]).data_ptr(), _xw_table(mod, mod.embedding.weight, l4[0]).data_ptr(),
-                         0 if getattr(mod, 'persistent', True) else _lib.SF_ENC_PER_STEP)
+        ge = _grads((emb.weight,))[0] if (emb.weight.requires_grad and seq is not None) else None
+        return _lib.EncoderG(_lib.LstmW(*_grads(l4)), *_grads(e2d), ge, seq.data_ptr() if ge else None,
+                             seq.shape[1] if ge else 0, emb.padding_idx if emb.padding_idx is not None else -1)
+    table = _xw_table(mod, emb.weight, l4[0]).data_ptr() if table else None
+    flags = 0 if getattr(mod, 'persistent', True) else _lib.SF_ENC_PER_STEP
+    if table is None and not mod.use_glove:
+        flags |= _lib.SF_ENC_EMB_DROPOUT               # (a no-op in eval mode: the dropout argument is NULL there)
+    lw = _lib.LstmW(*(p.data_ptr() for p in l4), transposed(l4[0]).data_ptr() if table is None else None,
+                    transposed(l4[1]).data_ptr())
+    return _lib.EncoderW(emb.weight.data_ptr(), lw, *(p.data_ptr() for p in e2d),
+                         transposed(e2d[0]).data_ptr(), table, flags)
 
 
 def _xw_table(mod, emb, w_ih):
@@ -254,18 +271,9 @@ def _xw_table(mod, emb, w_ih):
     return xw_table(mod, emb, w_ih)
 
 
-def require_frozen_embedding(mod, training):
-    """The HIP encoder / speaker decoder read `W_ih . embedding[token]` as a table row and form no
-    embedding gradient; the reference also applies dropout to a trainable (non-GloVe) embedding
-    (model.py:86-87).  That configuration is refused instead of silently training another model."""
-    if training and not mod.use_glove and mod.embedding.weight.requires_grad:
-        raise NotImplementedError('HIP %s: trainable (non-GloVe) embeddings are not supported in '
-                                  'training mode' % type(mod).__name__)
-
-
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, seq, lengths_dev, T, drop_cfg, *params):
+    def forward(ctx, mod, seq, lengths_dev, T, drop_cfg, use_table, *params):
         B, Lpad = seq.shape
         E, H = mod.embedding_size, mod.hidden_size
         dev = seq.device
@@ -274,28 +282,29 @@ class _EncoderFn(torch.autograd.Function):
         tape = dict(emb=new(T, B, E), xg=new(T, B, 4 * H), gates=new(T, B, 4 * H),
                     hs=new(T + 1, B, H), cs=new(T + 1, B, H))
         tp = _lib.EncoderTape(*(tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
-        w = _encoder_structs(mod)
+        w = _encoder_structs(mod, table=use_table)
         p, seed, site = drop_cfg
         call('sf_encoder_lstm_fwd', byref(w), B, Lpad, T, E, H, ptr(seq), ptr(lengths_dev),
              ptr(ctx_out), ptr(dinit), ptr(c_t), byref(tp), dropout_arg(p, seed), site,
              *ws_args(dev))
-        ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, T, E, H, drop_cfg)
-        ctx.save_for_backward(lengths_dev, dinit)
+        ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, T, E, H, drop_cfg, use_table)
+        ctx.save_for_backward(lengths_dev, dinit, seq)
         return ctx_out, dinit, c_t
 
     @staticmethod
     def backward(ctx, dctx, dinit_g, dct_g):
-        lengths_dev, dinit = ctx.saved_tensors
+        lengths_dev, dinit, seq = ctx.saved_tensors
         mod, tape = ctx.mod, ctx.tape
-        B, T, E, H, (p, seed, site) = ctx.cfg
+        B, T, E, H, (p, seed, site), use_table = ctx.cfg
         tp = _lib.EncoderTape(*(tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
-        w, g = _encoder_structs(mod), _encoder_structs(mod, grad=True)
+        w = _encoder_structs(mod, table=use_table)
+        g = _encoder_structs(mod, grad=True, seq=None if use_table else seq)
         cont = lambda t: t.contiguous() if t is not None else None  # noqa: E731
         dctx, dinit_g, dct_g = cont(dctx), cont(dinit_g), cont(dct_g)
         call('sf_encoder_lstm_bwd', byref(w), byref(g), B, T, E, H, ptr(lengths_dev), ptr(dinit),
              ptr(dctx), ptr(dinit_g), ptr(dct_g), byref(tp), dropout_arg(p, seed), site,
              *ws_args(dinit.device))
-        return (None,) * (5 + 7)
+        return (None,) * (6 + 7)
 
 
 class EncoderLSTM(nn.Module):
@@ -325,7 +334,6 @@ class EncoderLSTM(nn.Module):
 
     def forward(self, inputs, lengths):
         require_gpu(inputs)
-        require_frozen_embedding(self, self.training)
         lengths = [int(x) for x in lengths]
         T = max(lengths)
         lengths_dev = torch.tensor(lengths, dtype=torch.int32, device=inputs.device)
@@ -333,7 +341,7 @@ class EncoderLSTM(nn.Module):
         params = [self.lstm.weight_ih_l0, self.lstm.weight_hh_l0, self.lstm.bias_ih_l0,
                   self.lstm.bias_hh_l0, self.encoder2decoder.weight, self.encoder2decoder.bias,
                   self.embedding.weight]
-        return _EncoderFn.apply(self, inputs.contiguous(), lengths_dev, T, cfg, *params)
+        return _EncoderFn.apply(self, inputs.contiguous(), lengths_dev, T, cfg, not trainable_embedding(self), *params)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -588,7 +596,7 @@ _SPK_TAPE = ('emb', 'gates', 'c1', 'h1', 'cat2', 't_text', 'alpha', 'h_tilde', '
 
 class _SpeakerDecoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, drop_cfg, prev_word, h0, c0, context, mask, *params):
+    def forward(ctx, mod, drop_cfg, use_table, prev_word, h0, c0, context, mask, *params):
         B, H = h0.shape
         Tp = context.shape[1]
         E, vocab = mod.vocab_embedding_size, mod.vocab_size
@@ -599,12 +607,13 @@ class _SpeakerDecoderFn(torch.autograd.Function):
                     cat2=new(B, 2 * H), t_text=new(B, H), alpha=new(B, Tp), h_tilde=new(B, H),
                     logit=new(B, ldv))
         tp = _lib.SpkDecoderTape(*(tape[k].data_ptr() for k in _SPK_TAPE))
-        w = mod._w_struct()
+        w = mod._w_struct(table=use_table)
         p, seed, site = drop_cfg
         call('sf_speaker_decoder_fwd', byref(w), B, E, H, Tp, vocab, ptr(prev_word), ptr(h0),
              ptr(c0), ptr(context), ptr(mask), None, byref(tp), dropout_arg(p, seed), site,
              *ws_args(dev))
-        ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, E, H, Tp, vocab, ldv, drop_cfg)
+        ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, E, H, Tp, vocab, ldv, drop_cfg, use_table)
+        ctx.words = prev_word
         ctx.save_for_backward(h0, c0, context)
         ctx.mark_non_differentiable(tape['alpha'])
         return tape['h1'], tape['c1'], tape['alpha'], tape['logit'][:, :vocab]
@@ -612,10 +621,10 @@ class _SpeakerDecoderFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh1, dc1, _da, dlogit):
         h0, c0, context = ctx.saved_tensors
-        B, E, H, Tp, vocab, ldv, (p, seed, site) = ctx.cfg
+        B, E, H, Tp, vocab, ldv, (p, seed, site), use_table = ctx.cfg
         mod = ctx.mod
         dev = h0.device
-        w, g = mod._w_struct(), mod._w_struct(grad=True)
+        w, g = mod._w_struct(table=use_table), mod._w_struct(grad=True, table=use_table)
         tp = _lib.SpkDecoderTape(*(ctx.tape[k].data_ptr() for k in _SPK_TAPE))
         dl = torch.zeros(B, ldv, device=dev, dtype=torch.float32)
         if dlogit is not None:
@@ -623,11 +632,11 @@ class _SpeakerDecoderFn(torch.autograd.Function):
         cont = lambda t: t.contiguous() if t is not None else None  # noqa: E731
         dh1, dc1 = cont(dh1), cont(dc1)
         dh0, dc0 = torch.empty_like(h0), torch.empty_like(c0)
-        dctx = torch.zeros_like(context) if ctx.needs_input_grad[5] else None
-        call('sf_speaker_decoder_bwd', byref(w), byref(g), B, E, H, Tp, vocab, ptr(h0), ptr(c0),
+        dctx = torch.zeros_like(context) if ctx.needs_input_grad[6] else None
+        call('sf_speaker_decoder_bwd', byref(w), byref(g), B, E, H, Tp, vocab, ptr(ctx.words), ptr(h0), ptr(c0),
              ptr(context), byref(tp), ptr(dl), ptr(dh1), ptr(dc1), ptr(dh0), ptr(dc0), ptr(dctx),
              dropout_arg(p, seed), site, *ws_args(dev))
-        return (None, None, None, dh0, dc0, dctx, None) + (None,) * 9
+        return (None, None, None, None, dh0, dc0, dctx, None) + (None,) * 9
 
 
 class SpeakerDecoderLSTM(nn.Module):
@@ -662,15 +671,19 @@ class SpeakerDecoderLSTM(nn.Module):
                 self.lstm.bias_hh, a.linear_in.weight, a.linear_out.weight,
                 self.decoder2action.weight, self.decoder2action.bias)
 
-    def _w_struct(self, grad=False):
+    def _w_struct(self, grad=False, table=True):
+        """`table`: see _encoder_structs (False = trainable embedding with a backward to follow)."""
         ps = self._params9()
         if grad:
             v = _grads(ps[1:])
-            return _lib.SpkDecoderG(_lib.LstmW(*v[0:4]), _lib.SoftdotW(*v[4:6]), v[6], v[7])
+            ge = _grads(ps[0:1])[0] if (ps[0].requires_grad and not table) else None
+            return _lib.SpkDecoderG(_lib.LstmW(*v[0:4]), _lib.SoftdotW(*v[4:6]), v[6], v[7], ge)
         v = [p.data_ptr() for p in ps]
-        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5]),
+        table = self._xw_table().data_ptr() if table else None
+        flags = _lib.SF_SPK_EMB_DROPOUT if (table is None and not self.use_glove) else 0
+        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5], transposed(ps[1]).data_ptr() if table is None else None, None),
                                 _lib.SoftdotW(v[5], v[6], transposed(ps[5]).data_ptr(), None), v[7], v[8],
-                                self._xw_table().data_ptr())
+                                table, flags)
 
     def _xw_table(self):
         """[vocab, 4H] = embedding W_ih^T (runtime.xw_table): the LSTM's input product becomes a
@@ -679,8 +692,7 @@ class SpeakerDecoderLSTM(nn.Module):
 
     def forward(self, previous_word, h_0, c_0, ctx, ctx_mask=None):
         require_gpu(previous_word, h_0, c_0, ctx)
-        require_frozen_embedding(self, self.training)
         cfg = self._drop_state.next(self, self.drop.p)
         words = previous_word.reshape(-1).contiguous()                 # model.py:497-498
-        return _SpeakerDecoderFn.apply(self, cfg, words, h_0.contiguous(), c_0.contiguous(),
+        return _SpeakerDecoderFn.apply(self, cfg, not trainable_embedding(self), words, h_0.contiguous(), c_0.contiguous(),
                                        ctx.contiguous(), ops.mask_u8(ctx_mask), *self._params9())

@@ -18,7 +18,7 @@ from . import _lib
 from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
-from .model import _grads, require_frozen_embedding
+from .model import _grads, trainable_embedding
 from .runtime import ptr, stream, ws_args, dropout_arg, struct_of, transposed, take_fault, PersistentLaunchFault
 
 byref = C.byref
@@ -121,7 +121,6 @@ class SpeakerEngine:
         E, vocab = dec.vocab_embedding_size, dec.vocab_size
         ldv = (vocab + 3) & ~3
         training = dec.training if train is None else train
-        require_frozen_embedding(dec, training)          # same refusal as SpeakerDecoderLSTM.forward
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         st = SpeakerState()
         st.batch, st.steps, st.dims = batch, S, (B, Tp, H, F, V, D, E, vocab, ldv)
@@ -200,11 +199,14 @@ class SpeakerEngine:
         st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
         st.step_scores, st.nll_term, st.live = new(S, B), new(S, B), new(S, B)
         st.sum_cnt, st.gscale, st.loss_buf = new(S, 2), new(S), new(1)
-        dw = dec._w_struct()
         d_dec = dropout_arg(*st.drop_dec)
         st.targets = batch.instr_seq[:, :S].t().contiguous()              # [S,B] (speaker.py:163)
         params = list(ep) + [enc.encoder2decoder.weight, enc.encoder2decoder.bias] + list(dec._params9())
         differentiable = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        # a trainable (non-GloVe) embedding with a backward to follow: embedded (train mode: dropped, model.py:499-500)
+        # words instead of rows of the cached input-product table
+        st.dec_table = not (differentiable and trainable_embedding(dec))
+        dw = dec._w_struct(table=st.dec_table)
         persistent = False
         if self.persistent and not training and not differentiable:
             # inference: all S word steps in one persistent launch (csrc/sf_persist.hip)
@@ -272,14 +274,13 @@ class SpeakerEngine:
 
     def _backward(self, st, dloss):
         enc, dec, store = self.encoder, self.decoder, self.store
-        require_frozen_embedding(dec, True)              # no embedding gradient is formed on this path
         batch, S = st.batch, st.steps
         B, Tp, H, F, V, D, E, vocab, ldv = st.dims
         dev = store.device
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         ws = ws_args(dev)
         gscale = st.gscale * dloss.to(torch.float32)
-        dw, dg = dec._w_struct(), dec._w_struct(grad=True)
+        dw, dg = dec._w_struct(table=st.dec_table), dec._w_struct(grad=True, table=st.dec_table)
         d_dec = dropout_arg(*st.drop_dec)
         dlogit = new(B, ldv)
         dh_a, dc_a, dh_b, dc_b = new(B, H), new(B, H), new(B, H), new(B, H)
@@ -291,7 +292,7 @@ class SpeakerEngine:
             c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
             call('sf_speaker_glue_bwd', B, vocab, ldv, ptr(st.tape['logit'][t]), ptr(st.targets[t]),
                  PAD, ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
-            call('sf_speaker_decoder_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, ptr(h0), ptr(c0),
+            call('sf_speaker_decoder_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, ptr(st.words[t]), ptr(h0), ptr(c0),
                  ptr(st.ctx), byref(tp), ptr(dlogit), ptr(dh1), ptr(dc1), ptr(dh_a), ptr(dc_a),
                  ptr(dctx), d_dec, st.site0 + t, *ws)
             dh1, dc1 = dh_a, dc_a
