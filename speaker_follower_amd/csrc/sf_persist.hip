@@ -381,7 +381,7 @@ struct EncBwdPersistArgs {
 };
 constexpr int EB_LDA = 68;                        // LDS row stride of the [16 x 64] dgates tile
 
-__global__ __launch_bounds__(256, 2) void enc_bwd_persist_kernel(EncBwdPersistArgs p) {
+__global__ __launch_bounds__(256, 1) void enc_bwd_persist_kernel(EncBwdPersistArgs p) {
     __shared__ float sA[2][EP_ROWS][EB_LDA];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
@@ -389,13 +389,20 @@ __global__ __launch_bounds__(256, 2) void enc_bwd_persist_kernel(EncBwdPersistAr
     const int H = p.H, T = p.T, B = p.B;
     const int row0 = grp * p.rpg;
     const int nrows = max(0, min(p.rpg, B - row0));
-    // resident: wave w covers units [128 w, +128) = 8 n-tiles; k = 16 kk + c  <->  gate kk, unit c
-    float wf[8][16];
+    // resident: wave w covers units [128 w, +128) = 8 n-tiles; k = 16 kk + c  <->  gate kk, unit c.  Round 4: held as
+    // three bf16 planes (sf_split.h: the product runs on the bf16 matrix cores at fp32 accuracy); lane (li, kk) holds
+    // units c = 8 s .. 8 s + 7 of gate kk in the operand of MFMA s (K = 64 = 2 x 32)
+    Split8 wq[8][2];
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt)
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
-            wf[nt][c] = p.w_hh[(size_t)(kk * H + 16 * slot + c) * H + 16 * (8 * w + nt) + li];
+        for (int s2 = 0; s2 < 2; ++s2) {
+            float v[8];
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                v[c] = p.w_hh[(size_t)(kk * H + 16 * slot + 8 * s2 + c) * H + 16 * (8 * w + nt) + li];
+            wq[nt][s2] = split3_f8(make_float4(v[0], v[1], v[2], v[3]), make_float4(v[4], v[5], v[6], v[7]));
+        }
     // this thread's element in the MFMA output layout: index e = (kk*16 + col)*4 + r
     const int er = 4 * (tid >> 6) + (tid & 3), eu = (tid >> 2) & 15;
     const bool evalid = er < nrows;
@@ -498,12 +505,19 @@ __global__ __launch_bounds__(256, 2) void enc_bwd_persist_kernel(EncBwdPersistAr
             }
         }
         f32x4 acc[8];
+        {
+            const Split8 a0 = split3_f8(make_float4(a[0], a[1], a[2], a[3]), make_float4(a[4], a[5], a[6], a[7]));
+            const Split8 a1 = split3_f8(make_float4(a[8], a[9], a[10], a[11]), make_float4(a[12], a[13], a[14], a[15]));
+            f32x4 hi[8], lo[8];
 #pragma unroll
-        for (int nt = 0; nt < 8; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int nt = 0; nt < 8; ++nt) hi[nt] = lo[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int c = 0; c < 16; ++c)
+            for (int nt = 0; nt < 8; ++nt) mfma_split6(a0, wq[nt][0], hi[nt], lo[nt]);
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt) acc[nt] = mfma16(a[c], wf[nt][c], acc[nt]);
+            for (int nt = 0; nt < 8; ++nt) mfma_split6(a1, wq[nt][1], hi[nt], lo[nt]);
+#pragma unroll
+            for (int nt = 0; nt < 8; ++nt) acc[nt] = hi[nt] + lo[nt];
+        }
         // ---- 4. publish: block (dest = 8 w + nt, src = slot), lane's four rows contiguous
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // the resets above are behind us
         const unsigned pb = (unsigned)((t & 1) * EP_SLOTS * EP_SLOTS * 256) * 4u;
