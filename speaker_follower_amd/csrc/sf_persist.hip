@@ -643,14 +643,21 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
     const int H = p.H, B = p.B, Tp = p.Tp, S = p.S, vocab = p.vocab;
     const int row0 = grp * p.rpg;
     const int nrows = max(0, min(p.rpg, B - row0));
-    // ---- resident weights
-    float4 wf[5][8];                                    // K-quarter w of: 4 gate tiles, W_h tile
+    // ---- resident weights.  Round 4: the four gate tiles and the W_h tile are held as three bf16 planes and their
+    // products run on the bf16 matrix cores with error-free operand splitting (sf_split.h: fp32 accuracy, 6/16 of the
+    // fp32-MFMA time; these five tiles were 160 of a step's 224 fp32 MFMAs per wave).  The two vocabulary tiles stay
+    // fp32 (the register file is full: 512 per lane).
+    Split8 wq[5][4];                                    // K-quarter w of: 4 gate tiles, W_h tile; [.][j] = chunks 2j, 2j+1
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = 16 * (8 * w + i) + 4 * kk;
+    for (int j = 0; j < 4; ++j) {
+        const int k = 16 * (8 * w + 2 * j) + 4 * kk;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) wf[g][i] = ld4(p.w_hh + (size_t)(g * H + 16 * slot + li) * H + k);
-        wf[4][i] = ld4(p.w_out + (size_t)(16 * slot + li) * p.ld_wout + H + k);
+        for (int g = 0; g < 4; ++g) {
+            const float* wp = p.w_hh + (size_t)(g * H + 16 * slot + li) * H + k;
+            wq[g][j] = split3_f8(ld4(wp), ld4(wp + 16));
+        }
+        const float* wp = p.w_out + (size_t)(16 * slot + li) * p.ld_wout + H + k;
+        wq[4][j] = split3_f8(ld4(wp), ld4(wp + 16));
     }
     float4 wv[2][8];                                    // both vocabulary tiles, this wave's K-quarter
 #pragma unroll
@@ -692,17 +699,18 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
     float R[4];
     {
         const int arow = li < nrows ? row0 + li : B - 1;
-        f32x4 acc[4];
+        f32x4 acc[4], accl[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) acc[g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int g = 0; g < 4; ++g) acc[g] = accl[g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const float4 af = ld4(p.h_init + (size_t)arow * H + 16 * (8 * w + i) + 4 * kk);
+        for (int j = 0; j < 4; ++j) {
+            const float* hp = p.h_init + (size_t)arow * H + 16 * (8 * w + 2 * j) + 4 * kk;
+            const Split8 as = split3_f8(ld4(hp), ld4(hp + 16));
 #pragma unroll
-            for (int c = 0; c < 4; ++c)
-#pragma unroll
-                for (int g = 0; g < 4; ++g) acc[g] = mfma16(comp(af, c), comp(wf[g][i], c), acc[g]);
+            for (int g = 0; g < 4; ++g) mfma_split6(as, wq[g][j], acc[g], accl[g]);
         }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc[g] += accl[g];
 #pragma unroll
         for (int g = 0; g < 4; ++g)
 #pragma unroll
@@ -805,18 +813,22 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
             alpha_l = e / row16_sum(e);
             if (slot == 0 && evalid && eu < Tp && p.alpha) p.alpha[((size_t)t * B + eb) * Tp + eu] = alpha_l;
         }
+        // h1 (this wave's K-quarter) as bf16 planes: the operand of the W_h tile and of the four gate tiles
+        Split8 as[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            as[j] = split3_f8(make_float4(__uint_as_float(a[2 * j].x), __uint_as_float(a[2 * j].y), __uint_as_float(a[2 * j].z),
+                                          __uint_as_float(a[2 * j].w)),
+                              make_float4(__uint_as_float(a[2 * j + 1].x), __uint_as_float(a[2 * j + 1].y),
+                                          __uint_as_float(a[2 * j + 1].z), __uint_as_float(a[2 * j + 1].w)));
         // ---- D1. W_h h1 over this wave's K-quarter: the one tile h~ waits for.  (The four gate tiles of the NEXT
         //      step's cell are not needed before this step's word is known: they are formed in D2, behind the h~
         //      publish, while the other workgroups' h~ tiles are still on their way.)
         {
-            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f}, accl = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 af = make_float4(__uint_as_float(a[i].x), __uint_as_float(a[i].y),
-                                              __uint_as_float(a[i].z), __uint_as_float(a[i].w));
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc = mfma16(comp(af, c), comp(wf[4][i], c), acc);
-            }
+            for (int j = 0; j < 4; ++j) mfma_split6(as[j], wq[4][j], acc, accl);
+            acc += accl;
             // (s_part[.][4] was last read in phase E of the previous step, in front of that step's phase-F barrier)
 #pragma unroll
             for (int r = 0; r < 4; ++r) s_part[w][4][(kk * 4 + r) * 16 + li] = acc[r];
@@ -841,19 +853,15 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
         //      the last readers of s_part[.][0..3] -- the R sums of the previous step -- are behind those.
         auto gate_pair = [&](int g0) {
             f32x4 acc[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            f32x4 accl[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const float4 af = make_float4(__uint_as_float(a[i].x), __uint_as_float(a[i].y),
-                                              __uint_as_float(a[i].z), __uint_as_float(a[i].w));
+            for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-#pragma unroll
-                    for (int g = 0; g < 2; ++g) acc[g] = mfma16(comp(af, c), comp(wf[g0 + g][i], c), acc[g]);
-            }
+                for (int g = 0; g < 2; ++g) mfma_split6(as[j], wq[g0 + g][j], acc[g], accl[g]);
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) s_part[w][g0 + g][(kk * 4 + r) * 16 + li] = acc[g][r];
+                for (int r = 0; r < 4; ++r) s_part[w][g0 + g][(kk * 4 + r) * 16 + li] = acc[g][r] + accl[g][r];
         };
         gate_pair(0);
         EP_STAMP(3)                                      // h~ + publish + gate tiles

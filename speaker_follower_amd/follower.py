@@ -412,6 +412,9 @@ class FollowerEngine:
                 with torch.cuda.graph(graph, stream=side):
                     st = self.rollout(batch, steps, feedback, train=False)
             torch.cuda.current_stream().wait_stream(side)
+        # (the graph bakes the capture stream's workspace -- runtime.workspace is keyed on the stream handle -- so the
+        # stream lives as long as the state: a recycled handle would hand the same scratch to someone else)
+        st.capture_stream = side
         return self._guarded(graph.replay), st
 
     def capture_sharded(self, shards, steps, feedback='argmax'):

@@ -107,6 +107,11 @@ class SpeakerEngine:
             if bytes(self.decoder._w_struct()) != baked:
                 raise RuntimeError('a speaker weight moved since this pass was captured; capture() again')
             graph.replay()
+        # The graph bakes the capture stream's workspace (runtime.workspace is keyed on the stream handle): the stream
+        # must live as long as the graph, or a later stream could be handed the same handle -- and with it the same
+        # scratch, exchange buffers and tickets -- while this graph still replays on them.
+        replay.capture_stream = side
+        st.capture_stream = side
         return replay, st
 
     def score(self, batch, steps, feedback='teacher', train=None):
@@ -419,6 +424,9 @@ class SpeakerSweep:
             batch = batch_from_packed(buf, self.B, Tp, self.Lmax)
             batch.vp.fill_(0)
             batch.instr_seq.fill_(EOS)
+            # (the staging buffer was just initialised on the CURRENT stream: the sweep stream must see that, or its
+            # warm-up pass gathers with whatever indices the recycled memory holds)
+            self.streams[si].wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self.streams[si]):
                 eng = SpeakerEngine(self.enc, self.dec, self.store)
                 replay, st = eng.capture(batch, self.S, self.feedback)
