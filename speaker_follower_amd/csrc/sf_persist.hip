@@ -246,9 +246,9 @@ __global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
             }
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2) {
-                f32x4 hi[4][2], lo[4][2];
+                f32x4 hi[2][4], lo[2][4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) hi[g][0] = hi[g][1] = lo[g][0] = lo[g][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                for (int g = 0; g < 4; ++g) hi[0][g] = hi[1][g] = lo[0][g] = lo[1][g] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int jj = 0; jj < 2; ++jj) {
                     const int j = 2 * h2 + jj;
@@ -257,14 +257,15 @@ __global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
                                     __uint_as_float(a[j][0].w)),
                         make_float4(__uint_as_float(a[j][1].x), __uint_as_float(a[j][1].y), __uint_as_float(a[j][1].z),
                                     __uint_as_float(a[j][1].w)));
+                    // (per tile, not product by product across the four tiles: measured 325 vs 336 us per launch)
 #pragma unroll
-                    for (int g = 0; g < 4; ++g) mfma_split6(as, wq[g][j], hi[g][jj], lo[g][jj]);
+                    for (int g = 0; g < 4; ++g) mfma_split6(as, wq[g][j], hi[jj][g], lo[jj][g]);
                 }
                 // R_k = P_{k+8} + P_k goes to LDS at once (the stores of the first half ride under
                 // the MFMAs of the second)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 Rk = (hi[g][1] + lo[g][1]) + (hi[g][0] + lo[g][0]);
+                    const f32x4 Rk = (hi[1][g] + lo[1][g]) + (hi[0][g] + lo[0][g]);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) s_red[t & 1][w + 4 * h2][g][(kk * 4 + r) * 16 + li] = Rk[r];
                 }
@@ -511,10 +512,8 @@ __global__ __launch_bounds__(256, 1) void enc_bwd_persist_kernel(EncBwdPersistAr
             f32x4 hi[8], lo[8];
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) hi[nt] = lo[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) mfma_split6(a0, wq[nt][0], hi[nt], lo[nt]);
-#pragma unroll
-            for (int nt = 0; nt < 8; ++nt) mfma_split6(a1, wq[nt][1], hi[nt], lo[nt]);
+            mfma_split6_across<8>(a0, [&](int nt) -> const Split8& { return wq[nt][0]; }, hi, lo);
+            mfma_split6_across<8>(a1, [&](int nt) -> const Split8& { return wq[nt][1]; }, hi, lo);
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) acc[nt] = hi[nt] + lo[nt];
         }
@@ -857,7 +856,7 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int g = 0; g < 2; ++g) mfma_split6(as[j], wq[g0 + g][j], acc[g], accl[g]);
+                for (int g = 0; g < 2; ++g) mfma_split6(as[j], wq[g0 + g][j], acc[g], accl[g]);   // (the across-tiles order spills here)
 #pragma unroll
             for (int g = 0; g < 2; ++g)
 #pragma unroll

@@ -62,4 +62,22 @@ __device__ __forceinline__ void mfma_split6(const Split8& a, const Split8& b, f3
     hi = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], b.p[0], hi, 0, 0, 0);
 }
 
+// The same for N independent accumulator pairs that share the A operand (N weight tiles against one activation
+// fragment), product by product ACROSS the tiles: consecutive MFMAs never wait for each other's accumulator.
+template <int N, typename BOf>
+__device__ __forceinline__ void mfma_split6_across(const Split8& a, BOf b_of, f32x4 (&hi)[N], f32x4 (&lo)[N]) {
+#pragma unroll
+    for (int n = 0; n < N; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[2], b_of(n).p[0], lo[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], b_of(n).p[2], lo[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1], b_of(n).p[1], lo[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[1], b_of(n).p[0], lo[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) lo[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], b_of(n).p[1], lo[n], 0, 0, 0);
+#pragma unroll
+    for (int n = 0; n < N; ++n) hi[n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.p[0], b_of(n).p[0], hi[n], 0, 0, 0);
+}
+
 }  // namespace sf
