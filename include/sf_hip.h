@@ -449,6 +449,15 @@ typedef struct sf_encoder_w {
  * (global row b, column t*E + e).  Needs tape->emb and tape->xg and xw_table == NULL (the input product of dropped
  * embeddings is not a table row). */
 #define SF_ENC_EMB_DROPOUT 2
+/* One DIRECTION of a bidirectional encoder (model.py:47-66, 92-94: nn.LSTM(bidirectional=True), hidden_size // 2 per
+ * direction): the call neither applies encoder2decoder nor tanh -- decoder_init receives the raw h_T, and in the
+ * backward d_init is the gradient wrt that raw h_T -- and ctx is written WITHOUT dropout (`drop` then only feeds
+ * SF_ENC_EMB_DROPOUT).  The host mirror runs the two directions (the reverse one over per-row reversed tokens),
+ * concatenates, drops, and applies encoder2decoder to [h_reverse ; h_forward] itself. */
+#define SF_ENC_RAW_STATE 4
+/* seq holds every row's tokens in REVERSED order (step t = position lengths[b] - 1 - t): the SF_ENC_EMB_DROPOUT mask is
+ * keyed on the position, so that the two directions of a bidirectional encoder drop the same embedded tokens. */
+#define SF_ENC_REVERSED 8
 /* embedding (optional): gradient of embedding.weight [vocab,E], accumulated: row seq[b,t] += dropout-mask x
  * (dgates[t,b] W_ih); rows of token `padding_idx` receive nothing (nn.Embedding(padding_idx), model.py:55).  Needs
  * seq / Lpad as given to the forward. */

@@ -216,6 +216,8 @@ _SIGNATURES = {
 SF_OK, SF_ERR_ARG, SF_ERR_UNSUPPORTED, SF_ERR_LAUNCH, SF_ERR_WORKSPACE = 0, 1, 2, 3, 4
 SF_ENC_PER_STEP = 1           # sf_encoder_w.flags
 SF_ENC_EMB_DROPOUT = 2
+SF_ENC_RAW_STATE = 4
+SF_ENC_REVERSED = 8
 SF_SPK_EMB_DROPOUT = 1        # sf_spk_decoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)

@@ -1240,7 +1240,8 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     if (tp->emb) TRY(embedding_tm(w->embedding, E, seq, B, Lpad, T, tp->emb, st));
     if (w->flags & SF_ENC_EMB_DROPOUT) {         // trainable embedding: model.py:86-87 drops the embedded tokens
         SF_CHECK_ARG(tp->emb && !w->xw_table);
-        TRY(dropout_tm(tp->emb, T, B, E, make_dropout(drop, drop_stream ^ 0x40000000u), st));
+        TRY(dropout_tm(tp->emb, T, B, E, make_dropout(drop, drop_stream ^ 0x40000000u),
+                       (w->flags & SF_ENC_REVERSED) ? lengths : nullptr, st));
     }
     // input product: a row of the host's [vocab,4H] table per token, or hoisted for all steps at
     // once ([T*B,E] x [E,4H])
@@ -1248,7 +1249,8 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
     if (!w->xw_table)
         TRY(linear_plain(tp->emb, E, w->lstm.w_ih, E, nullptr, T * B, 4 * H, E, EPI_NONE, tp->xg,
                          4 * H, ar, st));
-    const Dropout dctx = make_dropout(drop, drop_stream);
+    // (SF_ENC_RAW_STATE: ctx is handed over raw as well -- the caller drops the assembled [forward | reverse] rows)
+    const Dropout dctx = (w->flags & SF_ENC_RAW_STATE) ? make_dropout(nullptr, 0) : make_dropout(drop, drop_stream);
     // all T steps as ONE persistent launch (sf_persist.hip) where it applies; bit-identical results
     bool persistent = false;
     if (w->xw_table && !(w->flags & SF_ENC_PER_STEP) && encoder_persistent_supported(B, H, T)) {
@@ -1284,8 +1286,11 @@ int sf_encoder_lstm_fwd(const sf_encoder_w* w, int B, int Lpad, int T, int E, in
         TRY(lstm_step_fused(f, st));
     }
     // model.py:96-99  decoder_init = tanh(encoder2decoder(h_T)); c_T raw
-    TRY(linear_plain(tp->hs + T * BH, H, w->w_e2d, H, w->b_e2d, B, H, H, EPI_TANH, decoder_init, H,
-                     ar, st));
+    if (w->flags & SF_ENC_RAW_STATE)               // one direction of a bidirectional encoder: the raw h_T
+        TRY(add2(tp->hs + T * BH, H, nullptr, 0, B, H, decoder_init, H, st));
+    else
+        TRY(linear_plain(tp->hs + T * BH, H, w->w_e2d, H, w->b_e2d, B, H, H, EPI_TANH, decoder_init, H,
+                         ar, st));
     if (persistent) return SF_OK;                 // (the persistent launch wrote c_T itself)
     return add2(tp->cs + T * BH, H, nullptr, 0, B, H, c_t, H, st);
 }
@@ -1308,7 +1313,9 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
     float* dpre = ar.take(BH);
     NEED(dh && dc && dcn && dctx_t && dpass && dpre);
     // through decoder_init = tanh(W h_T + b)
-    if (d_init) {
+    if (d_init && (w->flags & SF_ENC_RAW_STATE)) {
+        TRY(add2(d_init, H, nullptr, 0, B, H, dh, H, st));          // gradient wrt the raw h_T
+    } else if (d_init) {
         TRY(tanh_bwd(decoder_init, H, d_init, H, B, H, dpre, H, st));
         TRY(data_grad(dpre, H, w->w_e2d, w->w_e2d_t, B, H, H, dh, H, 0, ar, st));
         if (g && g->w_e2d) TRY(gemm_tn(dpre, H, tp->hs + T * BH, H, B, H, H, g->w_e2d, H, 1, st, ar.rest(), ar.rest_n()));
@@ -1317,7 +1324,7 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
         TRY(fill(dh, BH, 0.f, st));
     }
     TRY(add2(d_ct, H, nullptr, 0, B, H, dc, H, st));
-    const Dropout dd = make_dropout(drop, drop_stream);
+    const Dropout dd = (w->flags & SF_ENC_RAW_STATE) ? make_dropout(nullptr, 0) : make_dropout(drop, drop_stream);
     // dgates for step t overwrite tp->xg[t] (the hoisted product is dead after the forward)
     bool persistent = false;
     if (!(w->flags & SF_ENC_PER_STEP) && encoder_persistent_supported(B, H, T) && ar.tickets()) {
@@ -1375,7 +1382,8 @@ int sf_encoder_lstm_bwd(const sf_encoder_w* w, const sf_encoder_g* g, int B, int
             TRY(data_grad(tp->xg, 4 * H, w->lstm.w_ih, w->lstm.w_ih_t, T * B, 4 * H, E, demb, E, 0, ea, st));
             const Dropout de = (w->flags & SF_ENC_EMB_DROPOUT) ? make_dropout(drop, drop_stream ^ 0x40000000u)
                                                                : make_dropout(nullptr, 0);
-            TRY(embedding_bwd(demb, E, g->seq, g->Lpad, T, B, E, g->padding_idx, de, g->embedding, st));
+            TRY(embedding_bwd(demb, E, g->seq, g->Lpad, T, B, E, g->padding_idx, de,
+                              (w->flags & SF_ENC_REVERSED) ? lengths : nullptr, g->embedding, st));
         }
     }
     return SF_OK;
@@ -1436,7 +1444,7 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
     if (tp->emb) TRY(embedding_rows(w->embedding, E, prev_word, B, tp->emb, st));   // :497-498
     if (w->flags & SF_SPK_EMB_DROPOUT) {          // trainable embedding: :499-500 drops the embedded word
         SF_CHECK_ARG(tp->emb && !w->xw_table);
-        TRY(dropout_tm(tp->emb, 1, B, E, make_dropout(drop, 2 * step_id), st));
+        TRY(dropout_tm(tp->emb, 1, B, E, make_dropout(drop, 2 * step_id), nullptr, st));
     }
     if (w->xw_table && H % 16 == 0 && H <= 1024) {
         // x W_ih^T is a row of the precomputed [vocab,4H] table: recurrent half only
@@ -1521,7 +1529,7 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
     TRY(lstm_bwd_i(&w->lstm, &g->lstm, B, E, H, tp->emb, E, h0, c0, tp->c1, tp->gates, dh1, dh1m, dc1, demb, E, dh0, dc0,
                    ar, st));
     const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * step_id) : make_dropout(nullptr, 0);
-    return embedding_bwd(demb, E, prev_word, 1, 1, B, E, -1, de, g->embedding, st);
+    return embedding_bwd(demb, E, prev_word, 1, 1, B, E, -1, de, nullptr, g->embedding, st);
 }
 
 int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,

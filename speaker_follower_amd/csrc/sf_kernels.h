@@ -116,9 +116,9 @@ int flag_set(unsigned* flag, unsigned value, hipStream_t st);
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
               double beta2, double eps, double wd, int step, hipStream_t st);
 int transpose(const float* src, int R, int C, float* dst, hipStream_t st);   // dst[C,R] = src^T
-int dropout_tm(float* x, int T, int B, int E, const Dropout& d, hipStream_t st);
+int dropout_tm(float* x, int T, int B, int E, const Dropout& d, const int* rev, hipStream_t st);
 int embedding_bwd(const float* demb, int ldd, const int64_t* seq, int Lpad, int T, int B, int E, int padding_idx,
-                  const Dropout& d, float* grad, hipStream_t st);
+                  const Dropout& d, const int* rev, float* grad, hipStream_t st);
 int embedding_tm(const float* table, int E, const int64_t* seq, int B, int Lpad, int T, float* out,
                  hipStream_t st);          // out[t, b, :] = table[seq[b, t], :]
 int embedding_rows(const float* table, int E, const int64_t* idx, int B, float* out,

@@ -811,18 +811,27 @@ int transpose(const float* src, int R, int C, float* dst, hipStream_t st) {
 }
 // Dropout of the embedded tokens of a trainable embedding (model.py:86-87), in place on the time-major tape
 // x [T,B,E]: key (global row b, column t*E + e).
-__global__ __launch_bounds__(TPB) void dropout_tm_kernel(float* x, int T, int B, int E, Dropout d) {
+// `rev` (per-row lengths or null): step t of row b holds the token of position len_b - 1 - t (the reverse direction
+// of a bidirectional encoder); the mask is keyed on the POSITION, so both directions drop the same embedded tokens
+// (model.py:86-87 drops them once, ahead of the LSTM).
+__device__ __forceinline__ int tm_position(const int* rev, int b, int t) {
+    if (!rev) return t;
+    const int len = rev[b];
+    return t < len ? len - 1 - t : t;
+}
+__global__ __launch_bounds__(TPB) void dropout_tm_kernel(float* x, int T, int B, int E, Dropout d, const int* rev) {
     const size_t total = (size_t)T * B * E;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
         const int e = (int)(i % E), b = (int)((i / E) % B), t = (int)(i / ((size_t)E * B));
         const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
-        x[i] = dropout_keep(rk, (uint32_t)(t * E + e), d.thresh) ? x[i] * d.scale : 0.f;
+        x[i] = dropout_keep(rk, (uint32_t)(tm_position(rev, b, t) * E + e), d.thresh) ? x[i] * d.scale : 0.f;
     }
 }
 // Embedding gradient (nn.Embedding backward): grad[tok(n), :] += mask x demb[n, :], n = (t, b) time-major (tok =
 // seq[b*Lpad + t]) or n = b with step == 0 (tok = seq[b], Lpad = 1).  fp32 atomics: token rows collide.
 __global__ __launch_bounds__(TPB) void embedding_bwd_kernel(const float* demb, int ldd, const int64_t* seq, int Lpad, int T,
-                                                            int B, int E, int padding_idx, Dropout d, float* grad) {
+                                                            int B, int E, int padding_idx, Dropout d, const int* rev,
+                                                            float* grad) {
     const size_t total = (size_t)T * B * E;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
         const int e = (int)(i % E), b = (int)((i / E) % B), t = (int)(i / ((size_t)E * B));
@@ -830,20 +839,20 @@ __global__ __launch_bounds__(TPB) void embedding_bwd_kernel(const float* demb, i
         float v = demb[((size_t)t * B + b) * ldd + e];
         if (d.on()) {
             const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
-            v = dropout_keep(rk, (uint32_t)(t * E + e), d.thresh) ? v * d.scale : 0.f;
+            v = dropout_keep(rk, (uint32_t)(tm_position(rev, b, t) * E + e), d.thresh) ? v * d.scale : 0.f;
         }
         if (tok != padding_idx && v != 0.f) atomicAdd(grad + (size_t)tok * E + e, v);
     }
 }
-int dropout_tm(float* x, int T, int B, int E, const Dropout& d, hipStream_t st) {
+int dropout_tm(float* x, int T, int B, int E, const Dropout& d, const int* rev, hipStream_t st) {
     if (!d.on()) return SF_OK;
-    SF_LAUNCH(dropout_tm_kernel, dim3(grid1d((size_t)T * B * E)), dim3(TPB), 0, st, x, T, B, E, d);
+    SF_LAUNCH(dropout_tm_kernel, dim3(grid1d((size_t)T * B * E)), dim3(TPB), 0, st, x, T, B, E, d, rev);
     return launch_status();
 }
 int embedding_bwd(const float* demb, int ldd, const int64_t* seq, int Lpad, int T, int B, int E, int padding_idx,
-                  const Dropout& d, float* grad, hipStream_t st) {
+                  const Dropout& d, const int* rev, float* grad, hipStream_t st) {
     SF_LAUNCH(embedding_bwd_kernel, dim3(grid1d((size_t)T * B * E)), dim3(TPB), 0, st, demb, ldd, seq, Lpad, T, B, E,
-              padding_idx, d, grad);
+              padding_idx, d, rev, grad);
     return launch_status();
 }
 int embedding_tm(const float* table, int E, const int64_t* seq, int B, int Lpad, int T, float* out,

@@ -156,7 +156,8 @@ class FollowerEngine:
         enc, dec, store = self.encoder, self.decoder, self.store
         dev = store.device
         B, A, S = batch.batch_size, batch.a_max, steps
-        H, E = enc.hidden_size, enc.embedding_size
+        bidir = enc.num_directions == 2          # train.py:197-199: hidden_size // 2 per direction
+        H, E = enc.hidden_size * enc.num_directions, enc.embedding_size
         F, V = store.F, store.V
         D = dec.visual_attention_layer.linear_in_h.weight.shape[0]
         T = max(batch.lengths)
@@ -189,17 +190,32 @@ class FollowerEngine:
         # (an inference rollout keeps no embedded tokens / gate tape: nothing will run backward)
         keep = training or (torch.is_grad_enabled() and any(
             p.requires_grad for p in list(enc.parameters()) + list(dec.parameters())))
-        st.enc_tape = dict(emb=new(T, B, E) if keep else None, xg=new(T, B, 4 * H) if keep else None,
-                           gates=new(T, B, 4 * H) if keep else None, hs=new(T + 1, B, H), cs=new(T + 1, B, H))
-        etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() if st.enc_tape[k] is not None else None
+        st.enc_tape = {} if bidir else \
+            dict(emb=new(T, B, E) if keep else None, xg=new(T, B, 4 * H) if keep else None,
+                 gates=new(T, B, 4 * H) if keep else None, hs=new(T + 1, B, H), cs=new(T + 1, B, H))
+        etp = None if bidir else _lib.EncoderTape(*(st.enc_tape[k].data_ptr() if st.enc_tape[k] is not None else None
                                  for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
         # a trainable (non-GloVe) embedding with a backward to follow: the input product is formed from the embedded
         # (train mode: dropped, model.py:86-87) tokens, not read from the cached table
         st.enc_table = not (keep and trainable_embedding(enc))
-        ew = _encoder_structs(enc, table=st.enc_table)
-        call('sf_encoder_lstm_fwd', byref(ew), B, Lpad, T, E, H, ptr(batch.seq),
-             ptr(batch.lengths_dev), ptr(st.ctx), ptr(st.h_init), ptr(st.c_init), byref(etp),
-             dropout_arg(*st.drop_enc), st.site0, *ws_args(dev))
+        st.enc_graph = None
+        if bidir:
+            # the module's composition of the two directions (model.EncoderLSTM._forward_bidirectional); its autograd
+            # graph is the encoder's tape, and _backward() enters it with the decoder's (dctx, dh, dc)
+            p_e, seed_e, row0 = st.drop_enc
+            cfg = (p_e, (seed_e + 0x9E3779B1 * row0) & 0xFFFFFFFF, st.site0)
+            with torch.set_grad_enabled(keep and torch.is_grad_enabled()):
+                ctx_e, h_e, c_e = enc._forward_bidirectional(batch.seq, batch.lengths_dev, T, cfg, st.enc_table)
+            st.ctx = ctx_e.detach()
+            st.h_init.copy_(h_e.detach())
+            st.c_init.copy_(c_e.detach())
+            if ctx_e.requires_grad:
+                st.enc_graph = (ctx_e, h_e, c_e)
+        else:
+            ew = _encoder_structs(enc, table=st.enc_table)
+            call('sf_encoder_lstm_fwd', byref(ew), B, Lpad, T, E, H, ptr(batch.seq),
+                 ptr(batch.lengths_dev), ptr(st.ctx), ptr(st.h_init), ptr(st.c_init), byref(etp),
+                 dropout_arg(*st.drop_enc), st.site0, *ws_args(dev))
 
         # ---- decode steps
         shapes = dict(t_v=(D,), q=(F,), alpha_v=(V,), xin=(2 * F,), gates=(4 * H,), c1=(H,),
@@ -372,10 +388,16 @@ class FollowerEngine:
         """Every weight-side device pointer a captured rollout bakes into its hipGraph: the parameters
         and their derived copies (transposed layouts, the encoder's [vocab,4H] table).  Building the
         structs also refreshes stale derived copies IN PLACE, on the current stream."""
-        ew = _encoder_structs(self.encoder)
+        enc = self.encoder
+        if enc.num_directions == 2:
+            e2d = enc.encoder2decoder
+            ew = b''.join(bytes(_encoder_structs(enc, direction=d)) for d in (0, 1)) + \
+                repr((e2d.weight.data_ptr(), e2d.bias.data_ptr())).encode()
+        else:
+            ew = bytes(_encoder_structs(enc))
         dw = decoder_w_struct(decoder_params(self.decoder))
         fold = bytes(decoder_fold(self.decoder)) if self.fold_inference else b''
-        return bytes(ew) + bytes(dw) + fold
+        return ew + bytes(dw) + fold
 
     def _guarded(self, graph_replay):
         baked = self._baked_pointers()
@@ -570,12 +592,16 @@ class FollowerEngine:
                     self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws_args(dev), sync, part='rest')
         else:
             self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws, sync)
-        etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
-        ew = _encoder_structs(enc, table=st.enc_table)
-        eg = _encoder_structs(enc, grad=True, seq=None if st.enc_table else batch.seq)
-        call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
-             ptr(st.h_init), ptr(dctx), ptr(dh1), ptr(dc1), byref(etp), dropout_arg(*st.drop_enc),
-             st.site0, *ws)
+        if enc.num_directions == 2:
+            if st.enc_graph is not None:         # the two directions' tapes: entered with the decoder's gradients
+                torch.autograd.backward(list(st.enc_graph), [dctx, dh1, dc1])
+        else:
+            etp = _lib.EncoderTape(*(st.enc_tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
+            ew = _encoder_structs(enc, table=st.enc_table)
+            eg = _encoder_structs(enc, grad=True, seq=None if st.enc_table else batch.seq)
+            call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
+                 ptr(st.h_init), ptr(dctx), ptr(dh1), ptr(dc1), byref(etp), dropout_arg(*st.drop_enc),
+                 st.site0, *ws)
         if sync is not None:
             sync.launch(2)                       # encoder gradients: complete behind sf_encoder_lstm_bwd
         if overlap:

@@ -40,6 +40,10 @@ def _grads(params):
     return [_v(grad_ptr(p)) for p in params]
 
 
+class _Holder:
+    """An attribute bag (cache slot owner)."""
+
+
 class _DropState:
     """Per-module dropout bookkeeping: a seed and a call counter, so every forward in
     training mode draws a fresh, reproducible mask (site id = counter)."""
@@ -244,24 +248,36 @@ def trainable_embedding(mod):
     return mod.embedding.weight.requires_grad and torch.is_grad_enabled()
 
 
-def _encoder_structs(mod, grad=False, seq=None, table=True):
+def _lstm_dir_params(mod, direction):
+    sfx = '_reverse' if direction else ''
+    return tuple(getattr(mod.lstm, n + '_l0' + sfx) for n in ('weight_ih', 'weight_hh', 'bias_ih', 'bias_hh'))
+
+
+def _encoder_structs(mod, grad=False, seq=None, table=True, direction=None):
     """`table` = read the input product as rows of the cached [vocab,4H] table (False: form it from the embedded
     tokens, kept for the backward -- what a trainable embedding needs; callers decide with trainable_embedding() in
-    THEIR grad mode: inside autograd.Function.forward / backward the grad mode says nothing)."""
-    lstm = mod.lstm
-    l4 = (lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0)
-    e2d = (mod.encoder2decoder.weight, mod.encoder2decoder.bias)
+    THEIR grad mode: inside autograd.Function.forward / backward the grad mode says nothing).
+    `direction` (0 forward / 1 reverse): one direction of a bidirectional encoder (SF_ENC_RAW_STATE: no encoder2decoder)."""
+    l4 = _lstm_dir_params(mod, direction or 0)
+    raw = direction is not None
+    e2d = (None, None) if raw else (mod.encoder2decoder.weight, mod.encoder2decoder.bias)
     emb = mod.embedding
     if grad:
         ge = _grads((emb.weight,))[0] if (emb.weight.requires_grad and seq is not None) else None
-        return _lib.EncoderG(_lib.LstmW(*_grads(l4)), *_grads(e2d), ge, seq.data_ptr() if ge else None,
+        return _lib.EncoderG(_lib.LstmW(*_grads(l4)), *(_grads(e2d) if not raw else (None, None)), ge,
+                             seq.data_ptr() if ge else None,
                              seq.shape[1] if ge else 0, emb.padding_idx if emb.padding_idx is not None else -1)
-    table = _xw_table(mod, emb.weight, l4[0]).data_ptr() if table else None
+    owner = mod if not direction else mod._rev_cache         # (the cached table of the reverse direction lives apart)
+    table = _xw_table(owner, emb.weight, l4[0]).data_ptr() if table else None
     flags = 0 if getattr(mod, 'persistent', True) else _lib.SF_ENC_PER_STEP
+    if raw:
+        flags |= _lib.SF_ENC_RAW_STATE | (_lib.SF_ENC_REVERSED if direction else 0)
     if table is None and not mod.use_glove:
         flags |= _lib.SF_ENC_EMB_DROPOUT               # (a no-op in eval mode: the dropout argument is NULL there)
     lw = _lib.LstmW(*(p.data_ptr() for p in l4), transposed(l4[0]).data_ptr() if table is None else None,
                     transposed(l4[1]).data_ptr())
+    if raw:
+        return _lib.EncoderW(emb.weight.data_ptr(), lw, None, None, None, table, flags)
     return _lib.EncoderW(emb.weight.data_ptr(), lw, *(p.data_ptr() for p in e2d),
                          transposed(e2d[0]).data_ptr(), table, flags)
 
@@ -273,7 +289,7 @@ def _xw_table(mod, emb, w_ih):
 
 class _EncoderFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, mod, seq, lengths_dev, T, drop_cfg, use_table, *params):
+    def forward(ctx, mod, seq, lengths_dev, T, drop_cfg, use_table, direction, *params):
         B, Lpad = seq.shape
         E, H = mod.embedding_size, mod.hidden_size
         dev = seq.device
@@ -282,12 +298,13 @@ class _EncoderFn(torch.autograd.Function):
         tape = dict(emb=new(T, B, E), xg=new(T, B, 4 * H), gates=new(T, B, 4 * H),
                     hs=new(T + 1, B, H), cs=new(T + 1, B, H))
         tp = _lib.EncoderTape(*(tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
-        w = _encoder_structs(mod, table=use_table)
+        w = _encoder_structs(mod, table=use_table, direction=direction)
         p, seed, site = drop_cfg
         call('sf_encoder_lstm_fwd', byref(w), B, Lpad, T, E, H, ptr(seq), ptr(lengths_dev),
              ptr(ctx_out), ptr(dinit), ptr(c_t), byref(tp), dropout_arg(p, seed), site,
              *ws_args(dev))
-        ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, T, E, H, drop_cfg, use_table)
+        ctx.mod, ctx.tape, ctx.cfg = mod, tape, (B, T, E, H, drop_cfg, use_table, direction)
+        ctx.n_params = len(params)
         ctx.save_for_backward(lengths_dev, dinit, seq)
         return ctx_out, dinit, c_t
 
@@ -295,16 +312,58 @@ class _EncoderFn(torch.autograd.Function):
     def backward(ctx, dctx, dinit_g, dct_g):
         lengths_dev, dinit, seq = ctx.saved_tensors
         mod, tape = ctx.mod, ctx.tape
-        B, T, E, H, (p, seed, site), use_table = ctx.cfg
+        B, T, E, H, (p, seed, site), use_table, direction = ctx.cfg
         tp = _lib.EncoderTape(*(tape[k].data_ptr() for k in ('emb', 'xg', 'gates', 'hs', 'cs')))
-        w = _encoder_structs(mod, table=use_table)
-        g = _encoder_structs(mod, grad=True, seq=None if use_table else seq)
+        w = _encoder_structs(mod, table=use_table, direction=direction)
+        g = _encoder_structs(mod, grad=True, seq=None if use_table else seq, direction=direction)
         cont = lambda t: t.contiguous() if t is not None else None  # noqa: E731
         dctx, dinit_g, dct_g = cont(dctx), cont(dinit_g), cont(dct_g)
         call('sf_encoder_lstm_bwd', byref(w), byref(g), B, T, E, H, ptr(lengths_dev), ptr(dinit),
              ptr(dctx), ptr(dinit_g), ptr(dct_g), byref(tp), dropout_arg(p, seed), site,
              *ws_args(dinit.device))
-        return (None,) * (6 + 7)
+        return (None,) * (7 + ctx.n_params)
+
+
+class _BiAssembleFn(torch.autograd.Function):
+    """model.py:92-102 for nn.LSTM(bidirectional=True): ctx[b, t] = [forward output at t | reverse output at t] (the
+    reverse direction ran over the row's tokens in reversed order, so its output for position t is its step
+    len_b - 1 - t), zeros beyond the row's length; h_t = [h_reverse ; h_forward], c_t likewise.  Pure data movement
+    through the C ABI (row-strided copies and an index gather); the backward is the transposed movement."""
+
+    @staticmethod
+    def forward(ctx, idx_rev, ctx_f, ctx_r, h_f, h_r, c_f, c_r):
+        B, T, Hd = ctx_f.shape
+        dev = ctx_f.device
+        s = stream()
+        out = torch.empty(B, T, 2 * Hd, device=dev)
+        call('sf_dropout_copy', ptr(ctx_f), Hd, B * T, Hd, ptr(out), 2 * Hd, None, 0, 0, s)
+        call('sf_gather_rows', ptr(ctx_r), Hd, ptr(idx_rev), B * T, Hd, C.c_void_p(out.data_ptr() + 4 * Hd), 2 * Hd, s)
+        h_t, c_t = torch.empty(B, 2 * Hd, device=dev), torch.empty(B, 2 * Hd, device=dev)
+        for dst, first, second in ((h_t, h_r, h_f), (c_t, c_r, c_f)):              # model.py:93-94: [-1] (reverse) first
+            call('sf_dropout_copy', ptr(first), Hd, B, Hd, ptr(dst), 2 * Hd, None, 0, 0, s)
+            call('sf_dropout_copy', ptr(second), Hd, B, Hd, C.c_void_p(dst.data_ptr() + 4 * Hd), 2 * Hd, None, 0, 0, s)
+        ctx.save_for_backward(idx_rev)
+        ctx.dims = (B, T, Hd)
+        return out, h_t, c_t
+
+    @staticmethod
+    def backward(ctx, dout, dh_t, dc_t):
+        (idx_rev,) = ctx.saved_tensors
+        B, T, Hd = ctx.dims
+        dev = idx_rev.device
+        s = stream()
+        dout, dh_t, dc_t = dout.contiguous(), dh_t.contiguous(), dc_t.contiguous()
+        dctx_f, dctx_r = torch.empty(B, T, Hd, device=dev), torch.empty(B, T, Hd, device=dev)
+        call('sf_dropout_copy', ptr(dout), 2 * Hd, B * T, Hd, ptr(dctx_f), Hd, None, 0, 0, s)
+        # (the reversal is an involution on the live positions; idx < 0 -- beyond the row's length -- gives zeros)
+        call('sf_gather_rows', C.c_void_p(dout.data_ptr() + 4 * Hd), 2 * Hd, ptr(idx_rev), B * T, Hd, ptr(dctx_r), Hd, s)
+        outs = []
+        for d in (dh_t, dc_t):
+            first, second = torch.empty(B, Hd, device=dev), torch.empty(B, Hd, device=dev)
+            call('sf_dropout_copy', ptr(d), 2 * Hd, B, Hd, ptr(first), Hd, None, 0, 0, s)
+            call('sf_dropout_copy', C.c_void_p(d.data_ptr() + 4 * Hd), 2 * Hd, B, Hd, ptr(second), Hd, None, 0, 0, s)
+            outs += [second, first]                                   # (forward half, reverse half)
+        return None, dctx_f, dctx_r, outs[0], outs[1], outs[2], outs[3]
 
 
 class EncoderLSTM(nn.Module):
@@ -314,13 +373,13 @@ class EncoderLSTM(nn.Module):
     def __init__(self, vocab_size, embedding_size, hidden_size, padding_idx, dropout_ratio,
                  bidirectional=False, num_layers=1, glove=None):
         super().__init__()
-        if bidirectional or num_layers != 1:
-            raise NotImplementedError('HIP EncoderLSTM: unidirectional single layer only '
-                                      '(the only configuration the reference scripts train)')
+        if num_layers != 1:
+            raise NotImplementedError('HIP EncoderLSTM: a single layer only (the reference scripts never pass another '
+                                      'num_layers, train.py:197-199)')
         self.embedding_size = embedding_size
         self.hidden_size = hidden_size
         self.drop = nn.Dropout(p=dropout_ratio)
-        self.num_directions = 1
+        self.num_directions = 2 if bidirectional else 1
         self.num_layers = 1
         self.embedding = nn.Embedding(vocab_size, embedding_size, padding_idx)
         self.use_glove = glove is not None
@@ -328,9 +387,10 @@ class EncoderLSTM(nn.Module):
             print('Using GloVe embedding')
             self.embedding.weight.data[...] = torch.from_numpy(glove)
             self.embedding.weight.requires_grad = False
-        self.lstm = nn.LSTM(embedding_size, hidden_size, 1, batch_first=True)
-        self.encoder2decoder = nn.Linear(hidden_size, hidden_size)
+        self.lstm = nn.LSTM(embedding_size, hidden_size, 1, batch_first=True, bidirectional=bidirectional)
+        self.encoder2decoder = nn.Linear(hidden_size * self.num_directions, hidden_size * self.num_directions)
         self._drop_state = _DropState(1)
+        self._rev_cache = _Holder()          # cached input-product table of the reverse direction (runtime.xw_table)
 
     def forward(self, inputs, lengths):
         require_gpu(inputs)
@@ -338,10 +398,39 @@ class EncoderLSTM(nn.Module):
         T = max(lengths)
         lengths_dev = torch.tensor(lengths, dtype=torch.int32, device=inputs.device)
         cfg = self._drop_state.next(self, self.drop.p)
+        table = not trainable_embedding(self)
+        if self.num_directions == 2:
+            return self._forward_bidirectional(inputs.contiguous(), lengths_dev, T, cfg, table)
         params = [self.lstm.weight_ih_l0, self.lstm.weight_hh_l0, self.lstm.bias_ih_l0,
                   self.lstm.bias_hh_l0, self.encoder2decoder.weight, self.encoder2decoder.bias,
                   self.embedding.weight]
-        return _EncoderFn.apply(self, inputs.contiguous(), lengths_dev, T, cfg, not trainable_embedding(self), *params)
+        return _EncoderFn.apply(self, inputs.contiguous(), lengths_dev, T, cfg, table, None, *params)
+
+    def _forward_bidirectional(self, seq, lengths_dev, T, cfg, table):
+        """model.py:61-66, 88-102 with bidirectional=True (train.py:197-199: hidden_size // 2 per direction): two
+        recurrences over the packed sequences -- the reverse one over every row's tokens in reversed order --, ctx =
+        dropout([forward | reverse]), decoder_init = tanh(encoder2decoder([h_reverse ; h_forward])), c_t = [c_reverse ;
+        c_forward].  Each direction is the unidirectional C entry (SF_ENC_RAW_STATE); per-step kernels (the persistent
+        launch is built for hidden 512)."""
+        B, Lpad = seq.shape
+        dev = seq.device
+        ln = lengths_dev.view(B, 1).long()
+        t_ = torch.arange(Lpad, device=dev).view(1, Lpad)
+        src = torch.where(t_ < ln, ln - 1 - t_, t_)                    # position read by step t of the reverse direction
+        seq_rev = torch.gather(seq, 1, src).contiguous()
+        tt = torch.arange(T, device=dev).view(1, T)
+        base = torch.arange(B, device=dev).view(B, 1) * T
+        idx_rev = torch.where(tt < ln, base + ln - 1 - tt, torch.full_like(tt, -1)).to(torch.int32).reshape(-1).contiguous()
+        outs = []
+        for direction, s_ in ((0, seq), (1, seq_rev)):                 # (cfg: only the embedded tokens' dropout here)
+            params = list(_lstm_dir_params(self, direction)) + [self.embedding.weight]
+            outs.append(_EncoderFn.apply(self, s_, lengths_dev, T, cfg, table, direction, *params))
+        (ctx_f, h_f, c_f), (ctx_r, h_r, c_r) = outs
+        ctx_raw, h_t, c_t = _BiAssembleFn.apply(idx_rev, ctx_f, ctx_r, h_f, h_r, c_f, c_r)
+        decoder_init = linear(self.encoder2decoder, h_t, act=1)        # model.py:99
+        p, seed, site = cfg
+        ctx_out = _DropoutFn.apply(ctx_raw, p, seed, site) if p > 0 else ctx_raw     # model.py:101-102
+        return ctx_out, decoder_init, c_t
 
 
 # ------------------------------------------------------------------------------------------------

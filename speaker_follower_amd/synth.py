@@ -108,6 +108,28 @@ def follower_weights_peaky(seed, dims=FULL):
     return enc, dec
 
 
+def bidirectional_encoder_weights(seed, dims=FULL):
+    """State of EncoderLSTM(..., hidden_size // 2, bidirectional=True) (model.py:47-66; train.py:197-199): the two
+    directions' LSTM weights at hidden // 2 each (with the PEAKY_GAINS of the unidirectional encoder) and
+    encoder2decoder over the concatenated state."""
+    rng = np.random.default_rng(seed)
+    Hd, E, V = dims.hidden // 2, dims.word, dims.vocab
+    k = 1.0 / np.sqrt(Hd)
+    enc = OrderedDict()
+    emb = (rng.standard_normal((V, E)) * 0.4).astype(np.float32)
+    emb[PAD] = 0.0
+    enc['embedding.weight'] = emb
+    for sfx in ('', '_reverse'):
+        enc['lstm.weight_ih_l0' + sfx] = _uniform(rng, (4 * Hd, E), k) * np.float32(3.0)
+        enc['lstm.weight_hh_l0' + sfx] = _uniform(rng, (4 * Hd, Hd), k) * np.float32(2.0)
+        enc['lstm.bias_ih_l0' + sfx] = _uniform(rng, (4 * Hd,), k)
+        enc['lstm.bias_hh_l0' + sfx] = _uniform(rng, (4 * Hd,), k)
+    k2 = 1.0 / np.sqrt(2 * Hd)
+    enc['encoder2decoder.weight'] = _uniform(rng, (2 * Hd, 2 * Hd), k2)
+    enc['encoder2decoder.bias'] = _uniform(rng, (2 * Hd,), k2)
+    return enc
+
+
 def speaker_weights_peaky(seed, dims=FULL):
     """`speaker_weights(seed)` with attention and output gains (path attention max ~0.7, word
     distribution with a clear mode)."""
