@@ -578,9 +578,16 @@ int sf_gather_rows(const float* src, int ld_src, const int32_t* idx, int n, int 
  * n <= 1024): columns >= n_valid[row] are set to -inf in place when n_valid is given
  * (`logit[is_valid == 0] = -inf`), then log_softmax, then the k best columns in descending order
  * (ties: lower column first): idx [N,k] int32, logp [N,k] = log_softmax(logit)[row, idx].  k == n
- * returns the whole row sorted, which is what state_factored_search consumes (follower.py:802). */
+ * returns the whole row sorted (follower.py:802).  idx == NULL (k == n required): no selection -- logp [N,n] =
+ * log_softmax(logit) in COLUMN order, -inf beyond n_valid: what state_factored_search consumes (it walks every
+ * successor of a state, follower.py:802-836). */
 int sf_logprob_topk(float* logit, int ld, int N, int n, const int32_t* n_valid, int k, int32_t* idx,
                     float* logp, sf_stream stream);
+/* dst[idx[i], :width] = src[i, :width] (idx < 0: row i skipped): the h / c / attention rows of newly expanded
+ * search states into the state pool (the reference keeps them on its InferenceState tuples, follower.py:826-836);
+ * width, ld_src, ld_dst multiples of 4; the idx >= 0 must be distinct. */
+int sf_scatter_rows(const float* src, int ld_src, const int32_t* idx, int n, int width, float* dst,
+                    int ld_dst, sf_stream stream);
 
 /* Small utilities used by the host mirror (kept on the stream so rollouts never sync). */
 int sf_fill_f32(float* p, size_t n, float v, sf_stream stream);

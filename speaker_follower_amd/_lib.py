@@ -189,6 +189,7 @@ _SIGNATURES = {
     'sf_gather_actions': (C.c_int, [P(Cands), i32, c_p, c_f, c_p]),
     'sf_gather_path_actions': (C.c_int, [c_f, i32, i32, i32, c_p, c_p, c_f, c_p, i32, c_f, i32, c_p]),
     'sf_gather_rows': (C.c_int, [c_f, i32, c_p, i32, i32, c_f, i32, c_p]),
+    'sf_scatter_rows': (C.c_int, [c_f, i32, c_p, i32, i32, c_f, i32, c_p]),
     'sf_logprob_topk': (C.c_int, [c_f, i32, i32, i32, c_p, i32, c_p, c_f, c_p]),
     'sf_speaker_decoder_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i64p, c_f, c_f,
                                          c_f, c_p, c_p, P(SpkDecoderTape), P(Dropout), u32] + WS),

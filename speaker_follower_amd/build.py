@@ -106,14 +106,16 @@ def build_lib(force=False, verbose=True):
 
 def build_sim(force=False, verbose=True):
     """The navigation-only MatterSim pybind11 module (g++, no OpenCV / GL / jsoncpp) and, next to it, the
-    batched panorama sweep `sf_sweep` (sweep_py.cpp) over the same simulator sources."""
+    batched panorama sweep `sf_sweep` (sweep_py.cpp) over the same simulator sources and the
+    state-factored search's bookkeeping `sf_frontier` (frontier_core.cpp)."""
     import sysconfig
     import pybind11
     sim = os.path.join(PKG, 'sim')
     ext = sysconfig.get_config_var('EXT_SUFFIX')
     outs = []
     for name, files in (('MatterSim', ('mattersim_nav.cpp', 'mattersim_py.cpp')),
-                        ('sf_sweep', ('mattersim_nav.cpp', 'sweep_py.cpp'))):
+                        ('sf_sweep', ('mattersim_nav.cpp', 'sweep_py.cpp')),
+                        ('sf_frontier', ('frontier_core.cpp',))):
         out = os.path.join(sim, name + ext)
         srcs = [os.path.join(sim, f) for f in files]
         deps = srcs + [os.path.join(sim, 'mattersim_nav.hpp')]

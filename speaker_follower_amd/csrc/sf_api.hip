@@ -1425,8 +1425,14 @@ int sf_gather_rows(const float* src, int ld_src, const int32_t* idx, int n, int 
 int sf_logprob_topk(float* logit, int ld, int N, int n, const int32_t* n_valid, int k, int32_t* idx,
                     float* logp, sf_stream stream) {
     SF_ENTER();
-    SF_CHECK_ARG(logit && idx && logp && N > 0 && n > 0 && ld >= n);
+    SF_CHECK_ARG(logit && logp && N > 0 && n > 0 && ld >= n && (idx || k == n));
     return logprob_topk(logit, ld, N, n, n_valid, k, idx, logp, S(stream));
+}
+int sf_scatter_rows(const float* src, int ld_src, const int32_t* idx, int n, int width, float* dst,
+                    int ld_dst, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(src && idx && dst && n > 0 && width > 0);
+    return scatter_rows(src, ld_src, idx, n, width, dst, ld_dst, S(stream));
 }
 
 // ---- a9 SpeakerDecoderLSTM.forward (model.py:497-519) -----------------------------------------------------

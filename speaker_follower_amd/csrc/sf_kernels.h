@@ -134,6 +134,8 @@ int gather_path_actions(const float* table, int V, int IMG, int LOC, const int* 
 
 int gather_rows(const float* src, int lds, const int* idx, int n, int w, float* dst, int ldd,
                 hipStream_t st);
+int scatter_rows(const float* src, int lds, const int* idx, int n, int w, float* dst, int ldd,
+                 hipStream_t st);
 int logprob_topk(float* logit, int ld, int N, int n, const int* n_valid, int k, int* idx,
                  float* logp, hipStream_t st);
 

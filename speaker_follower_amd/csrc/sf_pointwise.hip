@@ -335,6 +335,19 @@ __global__ __launch_bounds__(TPB) void gather_rows_kernel(const float* src, int 
     }
 }
 
+// dst[idx[i], :w] = src[i, :w]  (idx < 0: row skipped): new search states into the rows of the state pool
+__global__ __launch_bounds__(TPB) void scatter_rows_kernel(const float* src, int lds, const int* idx,
+                                                           int n, int w, float* dst, int ldd) {
+    const int w4 = w >> 2;
+    const size_t total = (size_t)n * w4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % w4), r = (int)(i / w4);
+        const int d = idx[r];
+        if (d >= 0)
+            reinterpret_cast<float4*>(dst + (size_t)d * ldd)[c] = reinterpret_cast<const float4*>(src + (size_t)r * lds)[c];
+    }
+}
+
 // Masked log-softmax + the k best columns of every row in descending order (ties: lower column
 // first).  One block per row, up to TOPK_E * TPB columns, k rounds of a block-wide arg-max.
 constexpr int TOPK_E = 4;
@@ -368,6 +381,14 @@ __global__ __launch_bounds__(TPB) void logprob_topk_kernel(float* logit, int ld,
     if (lane == 0) s_red[wave] = se;
     __syncthreads();
     const float lse = logf((s_red[0] + s_red[1]) + (s_red[2] + s_red[3]));
+    if (!idx) {                                  // the whole row in COLUMN order (k == n): log_softmax, -inf beyond n_valid
+#pragma unroll
+        for (int e = 0; e < TOPK_E; ++e) {
+            const int c = tid + TPB * e;
+            if (c < n) logp[(size_t)row * k + c] = c < nv ? (v[e] - m) - lse : -INFINITY;
+        }
+        return;
+    }
     unsigned taken = 0;
     for (int r = 0; r < k; ++r) {
         float bv = -INFINITY;
@@ -900,9 +921,16 @@ int gather_rows(const float* src, int lds, const int* idx, int n, int w, float* 
                        lds, idx, n, w, dst, ldd);
     return launch_status();
 }
+int scatter_rows(const float* src, int lds, const int* idx, int n, int w, float* dst, int ldd,
+                 hipStream_t st) {
+    if ((w & 3) || (lds & 3) || (ldd & 3)) return SF_ERR_UNSUPPORTED;
+    SF_LAUNCH(scatter_rows_kernel, dim3(grid1d((size_t)n * (w >> 2))), dim3(TPB), 0, st, src,
+                       lds, idx, n, w, dst, ldd);
+    return launch_status();
+}
 int logprob_topk(float* logit, int ld, int N, int n, const int* n_valid, int k, int* idx,
                  float* logp, hipStream_t st) {
-    if (n > TOPK_E * TPB || k < 1 || k > n) return SF_ERR_UNSUPPORTED;
+    if (n > TOPK_E * TPB || k < 1 || k > n || (!idx && k != n)) return SF_ERR_UNSUPPORTED;
     SF_LAUNCH(logprob_topk_kernel, dim3(N), dim3(TPB), 0, st, logit, ld, n, n_valid, k, idx,
                        logp);
     return launch_status();

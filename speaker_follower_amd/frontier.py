@@ -23,10 +23,30 @@ repository's own form:
 Observation dictionaries (the reference's result format carries them: rational_follower.py:79-82 feeds them to
 the speaker) are materialised once per distinct state of the RETURNED candidates only.
 """
+import functools
+import gc
+
 import numpy as np
 import torch
 
 from .env import ANGLE_INC, WorldState
+
+
+def _gc_paused(fn):
+    """A search allocates ~10^5 small containers (hypothesis views, result dictionaries); every 700 of them the
+    cyclic collector would start walking the process' object graph -- with 90 parsed scans that is tens of
+    milliseconds a pass, several times the search itself.  Nothing the search builds is cyclic garbage: the
+    collector is paused for the duration and left as it was found."""
+    @functools.wraps(fn)
+    def run(*a, **k):
+        was = gc.isenabled()
+        gc.disable()
+        try:
+            return fn(*a, **k)
+        finally:
+            if was:
+                gc.enable()
+    return run
 
 V = 36
 F32 = np.float32
@@ -35,6 +55,15 @@ F32 = np.float32
 class Hypotheses:
     """Append-only struct-of-arrays of search hypotheses."""
     INT_FIELDS = ('parent', 'inst', 'sid', 'key', 'action', 'count', 'pool')
+
+    @classmethod
+    def from_arrays(cls, parent, inst, sid, key, action, count, pool, score, start_pose):
+        """The finished table of the native bookkeeping (sim/frontier_core.cpp: StateFactored.hypotheses)."""
+        t = cls.__new__(cls)
+        t.n = t.cap = len(parent)
+        t.parent, t.inst, t.sid, t.key, t.action, t.count, t.pool = parent, inst, sid, key, action, count, pool
+        t.score, t.start_pose = score, start_pose.astype(bool)
+        return t
 
     def __init__(self, cap=8192):
         self.n = 0
@@ -120,6 +149,9 @@ class StateSpace:
         ob = self._obs.get(k)
         if ob is None:
             ws = self.world_state(*k)
+            pk = (ws.scanId, ws.viewpointId, k[1] % V)
+            if pk not in self.env._pano:                           # the candidate list from the tables, not a sweep
+                self.env._pano[pk] = (k[1] % V, self.nav.adj_loc_list(k[1]))
             ob = self.env._observe_one(ws, self.items[k[0]], False, self.env.host_table is not None, view=k[1] % V)
             self._obs[k] = ob
         return ob
@@ -215,27 +247,36 @@ def _trajectories(fd, t, space, completed_lists, depth):
     """Result dictionaries (follower.py:694-716 / 953-975) of the final hypotheses of every instance."""
     flat = np.array([n for lst in completed_lists for n in lst], np.int64)
     L, ln = _lineage_matrix(t, flat, depth)
-    Ls = np.maximum(L, 0)
-    act, sc, pool = t.action[Ls], t.score[Ls].astype(np.float64), t.pool[Ls]
-    inst, sid, sp = t.inst[Ls], t.sid[Ls], t.start_pose[Ls]
-    rows = np.unique(pool[:, :-1][L[:, 1:] >= 0])                   # every non-root hypothesis on a returned path
-    att = dict(zip(rows.tolist(), fd.attention_rows(rows.tolist())))
-    all_obs = space.observations(inst, sid, sp)                     # (padding columns alias hypothesis 0: never read)
+    # root first: column j of every row = the j-th hypothesis of the path (columns >= its length: junk, sliced off)
+    L = np.take_along_axis(L, np.maximum(ln[:, None] - 1 - np.arange(depth + 1)[None, :], 0), axis=1)
+    act, sc, pool = t.action[L], t.score[L].astype(np.float64), t.pool[L]
+    live = np.arange(depth + 1)[None, :] < ln[:, None]
+    rows, inv = np.unique(pool[:, 1:][live[:, 1:]], return_inverse=True)      # every non-root hypothesis on a path
+    att_rows = np.empty(len(rows), object)
+    att_rows[:] = fd.attention_rows(rows.tolist())
+    att = np.empty(pool.shape, object)
+    att[:, 1:][live[:, 1:]] = att_rows[inv]
+    all_obs = space.observations(t.inst[L], t.sid[L], t.start_pose[L])
+    pose = np.empty(L.shape, object)
+    uniq = {}
+    flat_obs, flat_pose = all_obs.reshape(-1), pose.reshape(-1)
+    for j, ob in enumerate(flat_obs.tolist()):                      # (viewpoint, heading, elevation), one tuple per state
+        p = uniq.get(id(ob))
+        if p is None:
+            p = uniq[id(ob)] = (ob['viewpoint'], ob['heading'], ob['elevation'])
+        flat_pose[j] = p
+    step_sc = sc[:, 1:] - sc[:, :-1]
     out, i = [], 0
     for lst in completed_lists:
         assert lst
         cands = []
         for _ in lst:
-            m = ln[i]
-            idx = slice(m - 1, None, -1)                            # root first
-            obs = all_obs[i, idx].tolist()
-            s64 = sc[i, idx]
+            m = int(ln[i])
+            obs = all_obs[i, :m].tolist()
             cands.append({
                 'instr_id': obs[0]['instr_id'], 'instr_encoding': obs[0]['instr_encoding'],
-                'trajectory': [(ob['viewpoint'], ob['heading'], ob['elevation']) for ob in obs],
-                'observations': obs, 'actions': act[i, m - 2::-1].tolist() if m > 1 else [],
-                'score': float(s64[-1]), 'scores': (s64[1:] - s64[:-1]).tolist(),
-                'attentions': [att[r] for r in (pool[i, m - 2::-1].tolist() if m > 1 else [])]})
+                'trajectory': pose[i, :m].tolist(), 'observations': obs, 'actions': act[i, 1:m].tolist(),
+                'score': float(sc[i, m - 1]), 'scores': step_sc[i, :m - 1].tolist(), 'attentions': att[i, 1:m].tolist()})
             i += 1
         out.append(cands)
     return out
@@ -262,7 +303,10 @@ class HypList:
         return list(self) + list(other)
 
 
-def _setup(agent, load_next_minibatch, key_fields=4):
+def _setup_space(agent, load_next_minibatch, key_fields=4, graph_cap=0):
+    """env.reset + the minibatch's state space + the encoder pass + the decoder-step object: search.FlatDecoder
+    (host-issued launches over any number of states), or -- graph_cap > 0 -- the agent's search.GraphStep of that
+    capacity (one hipGraph replay per iteration)."""
     from . import nav, search
     env = agent.env
     search._require_store(agent)
@@ -271,9 +315,18 @@ def _setup(agent, load_next_minibatch, key_fields=4):
     table = nav.table_for(env, agent.store)
     space = StateSpace(env, table, items, key_fields)
     ctx, seq_mask, h_t, c_t = search._encode_items(agent, items)
-    fd = search.FlatDecoder(agent.decoder, agent.store, ctx, seq_mask)
-    fd.seed(h_t, c_t)
-    B = len(items)
+    if graph_cap:
+        fd = search.graph_step_for(agent, table, len(items), graph_cap)
+        fd.load(ctx, seq_mask, h_t, c_t)
+    else:
+        fd = search.FlatDecoder(agent.decoder, agent.store, ctx, seq_mask)
+        fd.seed(h_t, c_t)
+    return env, space, fd
+
+
+def _setup(agent, load_next_minibatch, key_fields=4):
+    env, space, fd = _setup_space(agent, load_next_minibatch, key_fields)
+    B = len(space.items)
     t = Hypotheses()
     roots = t.append(np.zeros(B, F32), np.ones(B, bool), parent=-1, inst=np.arange(B), sid=space.root_sid,
                      key=space.root_key, action=-1, count=0, pool=np.arange(B))
@@ -281,6 +334,7 @@ def _setup(agent, load_next_minibatch, key_fields=4):
 
 
 # ------------------------------------------------------------------------------------------- beam search
+@_gc_paused
 def beam_search(agent, beam_size, load_next_minibatch=True, mask_undo=False):
     """Seq2SeqAgent.beam_search (follower.py:541-718): per instance the `beam_size` best partial paths are
     extended by their `beam_size` best actions each step; a path is complete when it stops or reaches the
@@ -327,20 +381,107 @@ def beam_search(agent, beam_size, load_next_minibatch=True, mask_undo=False):
 # --------------------------------------------------------------------------------- state-factored search
 class _KeyTable:
     """One of the reference's per-instance dictionaries {world state key: (hypothesis, expanded)} for the whole
-    minibatch: dense [instance, key] arrays."""
+    minibatch: a dense [instance, key] array of hypotheses, and the dictionary's ENTRIES in insertion order as rows
+    of [instance, slot] matrices -- `pick_score[b, slot]` = the score of the entry's current hypothesis while it
+    waits to be expanded, -inf once it has been (or for a slot not in use).  "The best entry not expanded yet" of
+    every instance is then one argmax over a [B, slots] matrix (first maximum = oldest entry: the tie order of the
+    reference's heapq.nlargest over an insertion-ordered dict), whatever the number of entries the search has
+    accumulated."""
 
-    def __init__(self, B, n_keys):
+    def __init__(self, B, n_keys, cap=128):
         self.node = np.full((B, n_keys), -1, np.int64)
-        self.expanded = np.zeros((B, n_keys), bool)
+        self.slot = np.full((B, n_keys), -1, np.int32)
+        self.n_slots = np.zeros(B, np.int64)
+        self.pick_score = np.full((B, cap), -np.inf, F32)
+        self.slot_key = np.zeros((B, cap), np.int64)
+
+    def put(self, inst, key, node, score):
+        """Entries (inst, key) <- node (waiting to be expanded again).  inst grouped (equal values adjacent), in
+        processing order: new entries take the instance's next slots in that order."""
+        if len(inst) == 0:
+            return
+        slot = self.slot[inst, key]
+        fresh = slot < 0
+        if fresh.any():
+            fi = inst[fresh]
+            rank = np.arange(len(fi)) - np.flatnonzero(np.r_[True, fi[1:] != fi[:-1]])[
+                np.cumsum(np.r_[True, fi[1:] != fi[:-1]]) - 1]
+            new = self.n_slots[fi] + rank
+            np.add.at(self.n_slots, fi, 1)
+            need = int(new.max()) + 1
+            if need > self.pick_score.shape[1]:
+                cap = max(2 * self.pick_score.shape[1], need)
+                for name, fill in (('pick_score', -np.inf), ('slot_key', 0)):
+                    old = getattr(self, name)
+                    grown = np.full((old.shape[0], cap), fill, old.dtype)
+                    grown[:, :old.shape[1]] = old
+                    setattr(self, name, grown)
+            slot[fresh] = new
+            self.slot[fi, key[fresh]] = new
+            self.slot_key[fi, new] = key[fresh]
+        self.node[inst, key] = node
+        self.pick_score[inst, slot] = score
 
 
+def _inputs_from_block(space, block, n):
+    """The index-form inputs of `search.FlatDecoder.step_arrays` from the [8, cap] block of
+    frontier_core.cpp:fill_inputs (host-issued decoder steps: fakes in the host tests, agents without a graph)."""
+    h = space.h
+    row, view, prow, pview, act, hrow, crow = (block[j, :n].astype(np.int64) for j in range(7))
+    sid, psid = row * V + view, prow * V + pview
+    return dict(vp=h['feat_row'][row], view=view, a_num=h['a_num'][sid], cand_view=h['cand_view'][sid],
+                sincos=h['sincos'][sid], hrow=hrow, crow=crow, has_u=act != 0,      # (an expanded state never follows
+                u_vp=h['feat_row'][prow], u_view=h['cand_view'][psid, act],         # a stop: only roots have act 0)
+                u_sincos=h['sincos'][psid, act])
+
+
+@_gc_paused
 def state_factored_search(agent, completion_size, successor_size, load_next_minibatch=True, mask_undo=False,
                           first_n_ws_key=4):
     """Seq2SeqAgent.state_factored_search (follower.py:720-980): best-first search over WORLD STATES -- per
     instance and state only the best-scoring hypothesis is kept; every iteration expands, per instance, the
     `successor_size` best states not expanded yet (a finished hypothesis is "expanded" by recording its state
     as completed) until `completion_size` distinct end states are completed.  Returns (trajs, completed
-    hypotheses, the physical traversal of every instance: the walk between successively expanded states)."""
+    hypotheses, the physical traversal of every instance: the walk between successively expanded states).
+
+    Per iteration: ONE hipGraph replay on the device (search.GraphStep) and ONE native call for the bookkeeping
+    (sim/frontier_core.cpp).  `agent.search_backend = 'numpy'` (or a `tie_log`) runs the numpy restatement below
+    with host-issued decoder steps instead; both produce the same hypotheses, node for node."""
+    if getattr(agent, 'tie_log', None) is not None or getattr(agent, 'search_backend', 'native') == 'numpy':
+        return _state_factored_search_numpy(agent, completion_size, successor_size, load_next_minibatch, mask_undo,
+                                            first_n_ws_key)
+    from .sim import load_frontier
+    n_inst = getattr(agent.env, 'batch_size', None) or len(agent.env.batch)
+    use_graph = getattr(agent, 'search_graph', True) and hasattr(agent.decoder, 'visual_attention_layer')
+    cap = n_inst * successor_size
+    env, space, fd = _setup_space(agent, load_next_minibatch, first_n_ws_key, graph_cap=cap if use_graph else 0)
+    assert env.beam_size >= successor_size
+    h = space.h
+    core = load_frontier().StateFactored(completion_size, successor_size, agent.episode_len, first_n_ws_key, V,
+                                         h['next_row'], h['cand_view'], h['a_num'], space.base_row, space.root_sid,
+                                         space.root_key)
+    block = fd.inputs if use_graph else np.zeros((8, cap), np.int32)
+    while True:
+        if use_graph:
+            base = fd.n
+            logp = fd.run(core.fill_inputs(block, base))
+        else:
+            n = core.fill_inputs(block, 0)
+            base, logp = fd.step_logprobs(_inputs_from_block(space, block, n))
+        if core.advance(logp, base) == 0 or core.done():
+            break
+    t = Hypotheses.from_arrays(*core.hypotheses())
+    completed, visits = core.results()
+    traversed = [HypList(t, space, w) for w in physical_walks(t, visits, agent.episode_len)]
+    return (_trajectories(fd, t, space, completed, agent.episode_len), [HypList(t, space, lst) for lst in completed],
+            traversed)
+
+
+def _state_factored_search_numpy(agent, completion_size, successor_size, load_next_minibatch=True, mask_undo=False,
+                                 first_n_ws_key=4):
+    """state_factored_search with the per-instance dictionaries as dense [instance, key] numpy tables updated over
+    the whole minibatch: the readable restatement of what sim/frontier_core.cpp does per instance, and its
+    cross-check (tests/test_search_host.py)."""
     env, space, fd, t, roots = _setup(agent, load_next_minibatch, first_n_ws_key)
     assert env.beam_size >= successor_size
     B, K = len(space.items), space.n_keys
@@ -348,11 +489,10 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
     comp_node = np.full((B, K), -1, np.int64)            # completed end states
     n_comp = np.zeros(B, np.int64)
     comp_order = [[] for _ in range(B)]                  # keys in the order they were first completed
-    # insertion-ordered entry list of both tables (ties between equal scores go to the older entry,
-    # states-to-expand before finished ones: heapq.nlargest over chain(cache, holding), follower.py:861-865)
-    e_inst, e_key, e_held = [np.arange(B)], [space.root_key.copy()], [np.zeros(B, bool)]
-    open_t.node[np.arange(B), space.root_key] = roots
-    open_t.expanded[np.arange(B), space.root_key] = True
+    # (ties between equal scores go to the older entry, states-to-expand before finished ones: heapq.nlargest over
+    # chain(cache, holding), follower.py:861-865)
+    all_b = np.arange(B)
+    open_t.put(all_b, space.root_key.copy(), roots, np.full(B, -np.inf, F32))      # the roots: expanded from the start
     frontier = roots
     visits = [[int(r)] for r in roots]                   # successively expanded hypotheses per instance
     episode_len = agent.episode_len
@@ -384,29 +524,42 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
         ids = t.append(score[cand], t.start_pose[par[cand]] & stay[cand], parent=par[cand], inst=ci, sid=nsid[cand],
                        key=ck, action=act[cand], count=count[cand], pool=base + owner[cand])
         for tab, m in ((held_t, cf), (open_t, ~cf)):
-            tab.node[ci[m], ck[m]] = ids[m]
-            tab.expanded[ci[m], ck[m]] = False
-        fresh = cur < 0
-        e_inst.append(ci[fresh]); e_key.append(ck[fresh]); e_held.append(cf[fresh])            # noqa: E702
+            tab.put(ci[m], ck[m], ids[m], score[cand[m]])
         # ---- per instance: the `successor_size` best entries not expanded yet
-        ei, ek, eh = np.concatenate(e_inst), np.concatenate(e_key), np.concatenate(e_held)
-        e_inst, e_key, e_held = [ei], [ek], [eh]
-        node = np.where(eh, held_t.node[ei, ek], open_t.node[ei, ek])
-        todo = np.flatnonzero(~np.where(eh, held_t.expanded[ei, ek], open_t.expanded[ei, ek])
-                              & (n_comp[ei] < completion_size))
-        pick = todo[np.lexsort((todo, eh[todo], -t.score[node[todo]], ei[todo]))]
+        active = np.flatnonzero(n_comp < completion_size)
         tie_log = getattr(agent, 'tie_log', None)
-        if tie_log is not None and successor_size == 1:
-            # diagnostics (tools/search_tie_probe.py): per pick, how far behind the runner-up of the same instance was
-            grp = ei[pick]
-            first = np.flatnonzero(np.r_[True, grp[1:] != grp[:-1]])
-            has2 = (first + 1 < len(pick)) & (np.r_[grp[1:], -1][first] == grp[first])
-            sc_ = t.score[node[pick]]
-            tie_log.append((grp[first][has2], sc_[first][has2], sc_[np.minimum(first + 1, len(pick) - 1)][has2]))
-        pick = pick[_first_k_per_group(ei[pick], successor_size)]
-        pi, pk, ph, pn = ei[pick], ek[pick], eh[pick], node[pick]
-        held_t.expanded[pi[ph], pk[ph]] = True
-        open_t.expanded[pi[~ph], pk[~ph]] = True
+        picks = []
+        for rnd in range(successor_size):
+            so, sh = open_t.pick_score[active], held_t.pick_score[active]
+            ao, ah = so.argmax(1), sh.argmax(1)
+            r = np.arange(len(active))
+            mo, mh = so[r, ao], sh[r, ah]
+            use_h = mh > mo                                   # equal scores: the state to expand first
+            got = np.maximum(mo, mh) > -np.inf
+            if tie_log is not None and successor_size == 1:
+                # diagnostics (tools/search_tie_probe.py): per pick, how far behind the runner-up of the same instance was
+                best = np.where(use_h, mh, mo)
+                so2, sh2 = so.copy(), sh.copy()
+                so2[r[~use_h], ao[~use_h]] = -np.inf
+                sh2[r[use_h], ah[use_h]] = -np.inf
+                second = np.maximum(so2.max(1), sh2.max(1))
+                has2 = got & (second > -np.inf)
+                tie_log.append((active[has2], best[has2], second[has2]))
+            a_i, u_h = active[got], use_h[got]
+            slot = np.where(u_h, ah[got], ao[got])
+            held_t.pick_score[a_i[u_h], slot[u_h]] = -np.inf  # expanded
+            open_t.pick_score[a_i[~u_h], slot[~u_h]] = -np.inf
+            key_ = np.empty(len(a_i), np.int64)
+            key_[u_h] = held_t.slot_key[a_i[u_h], slot[u_h]]
+            key_[~u_h] = open_t.slot_key[a_i[~u_h], slot[~u_h]]
+            picks.append((a_i, key_, u_h))
+            if not got.all():
+                active = active[got]                          # (an instance with nothing left has nothing later either)
+        pi, pk, ph = (np.concatenate(x) for x in zip(*picks))
+        if successor_size > 1:
+            o = np.argsort(pi, kind='stable')                 # instance-major, each instance's picks best first
+            pi, pk, ph = pi[o], pk[o], ph[o]
+        pn = np.where(ph, held_t.node[pi, pk], open_t.node[pi, pk])
         # finished hypotheses: their end state is completed (the better one if it already was)
         fi, fk, fn = pi[ph], pk[ph], pn[ph]
         old = comp_node[fi, fk]
@@ -468,6 +621,7 @@ def physical_walks(t, visits, depth):
 
 
 # ------------------------------------------------------------------------------------ speaker beam search
+@_gc_paused
 def speaker_beam_search(speaker, beam_size, path_obs, path_actions):
     """Seq2SeqSpeaker.beam_search (speaker.py:211-318): one flat SpeakerDecoderLSTM step per word over all live
     hypotheses of all paths; hypotheses are rows (parent, path, word, float32 score, pool row)."""

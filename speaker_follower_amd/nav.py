@@ -68,7 +68,8 @@ class NavTable:
         cand_view = np.zeros((n, 3, 12, A), np.int32)
         head = np.zeros((n, 3, 12, A), np.float64)
         elev = np.zeros((n, 3, 12, A), np.float64)
-        for s, (an, nx, av, rh, re) in zip(self.scans, per_scan):
+        dist12 = np.zeros((n, 12, A), np.float64)              # (per heading bin: the sweep ignores the elevation)
+        for s, (an, nx, av, rh, re, ds) in zip(self.scans, per_scan):
             b, m, a = self.base[s], an.shape[0], nx.shape[2]
             assert (nx >= 0).all(), 'a candidate of scan %s is not an included viewpoint' % s
             av = av.copy()
@@ -79,6 +80,7 @@ class NavTable:
             cand_view[b:b + m, :, :, :a] = av[:, None]
             head[b:b + m, :, :, :a] = rh[:, None]
             elev[b:b + m, :, :, :a] = re[:, None]
+            dist12[b:b + m, :, :a] = ds
         a_num = a_num.reshape(n * V)
         next_row, cand_view = next_row.reshape(n * V, A), cand_view.reshape(n * V, A)
         head, elev = head.reshape(n * V, A), elev.reshape(n * V, A)
@@ -91,9 +93,26 @@ class NavTable:
         self.feat_row = up(feat_row, torch.int32)
         # host copies: the search procedures (search.py) expand states by integer table look-ups
         self.host = dict(a_num=a_num, next_row=next_row, cand_view=cand_view, sincos=sincos, feat_row=feat_row,
-                         heading=head, elevation=elev)
+                         heading=head, elevation=elev, distance12=dist12)
         self.n_rows, self.device, self.env = n, dev, env
         self._hops = {}
+
+    def adj_loc_list(self, sid):
+        """The candidate list of state `sid` (= nav row * 36 + view) in the env's dictionary form (env.py:149-224 /
+        env.panorama_sweep: stop first, then by |rel_heading|) straight from the tables -- equal to what the
+        simulator sweep of that state returns, without waking the simulator."""
+        h = self.host
+        row, view = int(sid) // V, int(sid) % V
+        n = int(h['a_num'][sid])
+        nxt, cv = h['next_row'][sid, :n].tolist(), h['cand_view'][sid, :n].tolist()
+        rh, re = h['heading'][sid, :n].tolist(), h['elevation'][sid, :n].tolist()
+        ds = h['distance12'][row, view % 12, :n].tolist()
+        vp_of = self.vp_of
+        adj = [dict(absViewIndex=-1, nextViewpointId=vp_of[row][1], rel_heading=0.0, rel_elevation=0.0, distance=0.0)]
+        for a in range(1, n):
+            adj.append(dict(absViewIndex=cv[a], nextViewpointId=vp_of[nxt[a]][1], rel_heading=rh[a],
+                            rel_elevation=re[a], distance=ds[a]))
+        return adj
 
     def struct(self):
         return _lib.NavTableS(self.a_num.data_ptr(), self.next_row.data_ptr(), self.cand_view.data_ptr(),

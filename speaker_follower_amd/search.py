@@ -245,6 +245,151 @@ class FlatDecoder:
         return list(self.apool.buf[r].cpu().numpy())
 
 
+class GraphStep:
+    """The decoder step of the state-factored search as ONE hipGraph over fixed buffers (follower.py:783-836 per
+    iteration: observations of the expanded states, `h_t[flat_indices]`, the AttnDecoderLSTM step, log_softmax).
+
+    An iteration expands at most `successor_size` states per instance, so the step has a fixed capacity; what changes
+    between iterations is a [8, cap] block of int32 (frontier_core.cpp: fill_inputs) written into pinned memory.  The
+    graph: that block H2D; sf_nav_step twice (the states' and their parents' candidate lists straight from the device
+    navigation table -- nothing but the eight integers per state is packed on the host); the previous action's
+    embedding (sf_gather_actions over the parent's candidates; action 0 = zeros = u_begin); h / c rows from the state
+    pool; sf_attn_decoder_fwd with per-state instruction rows; log_softmax in column order; h / c / attention rows of
+    the new states scattered to their pool rows; the [cap, A] log-probabilities D2H into pinned memory.  One replay
+    and one stream sync per iteration instead of ~25 host-issued launches, an upload and a blocking download.
+
+    Instructions live in a [instances, t_max] buffer (padding masked out), so the graph outlives the minibatch: it is
+    captured once per (decoder, store, navigation table, sizes) and re-captured only when a weight (or one of its
+    cached layouts) moved or the state pool had to grow."""
+
+    def __init__(self, decoder, store, nav, n_inst, cap, t_max, pool_rows=1 << 14):
+        dev = store.device
+        self.dec, self.store, self.nav, self.dev = decoder, store, nav, dev
+        self.n_inst, self.cap, self.T, self.A = n_inst, cap, t_max, nav.A
+        self.H = decoder.hidden_size
+        self.D = decoder.visual_attention_layer.linear_in_h.weight.shape[0]
+        f32 = lambda *s: torch.zeros(*s, device=dev, dtype=torch.float32)           # noqa: E731
+        i32 = lambda *s: torch.zeros(*s, device=dev, dtype=torch.int32)             # noqa: E731
+        self.pin_in = torch.zeros(8, cap, dtype=torch.int32).pin_memory()
+        self.inputs = self.pin_in.numpy()                                            # what fill_inputs writes
+        self.dev_in = i32(8, cap)
+        A = self.A
+        self.obs = [dict(row=i32(cap), vp=i32(cap), view=i32(cap), a_num=i32(cap), cand_view=i32(cap, A),
+                         sincos=f32(cap, A, 4)) for _ in range(2)]                   # the states, their parents
+        self.h0, self.c0, self.u_prev = f32(cap, self.H), f32(cap, self.H), f32(cap, store.F)
+        self.tape = decoder_tape(cap, self.H, store.F, self.D, store.V, t_max, A, dev)
+        self.logp = f32(cap, A)
+        self.pin_out = torch.zeros(cap, A, dtype=torch.float32).pin_memory()
+        self.out = self.pin_out.numpy()
+        self.ctx = f32(n_inst, t_max, self.H)
+        self.mask = torch.ones(n_inst, t_max, dtype=torch.uint8, device=dev)
+        self.pool_rows = pool_rows
+        self.hpool, self.cpool, self.apool = f32(pool_rows, self.H), f32(pool_rows, self.H), f32(pool_rows, t_max)
+        self.n = 0
+        self.graph = self.baked = self._stream = None
+
+    # ---- per search
+    def load(self, ctx, mask, h, c):
+        """The minibatch's encoder outputs: instruction rows 0..B-1, pool rows 0..B-1."""
+        B, T = ctx.shape[0], ctx.shape[1]
+        if B > self.n_inst or T > self.T:
+            raise ValueError('GraphStep built for %d instructions of <= %d tokens' % (self.n_inst, self.T))
+        self.mask.fill_(1)
+        self.mask[:B, :T].copy_(mask.to(torch.uint8))
+        self.ctx[:B, :T].copy_(ctx)
+        self.hpool[:B].copy_(h)
+        self.cpool[:B].copy_(c)
+        self.n = B
+        w = bytes(decoder_w_struct(decoder_params(self.dec)))        # (also refreshes stale cached layouts in place)
+        if self.graph is None or w != self.baked:
+            self._capture()
+
+    def _issue(self):
+        st, nav, cap, A = self.store, self.nav, self.cap, self.A
+        s = stream()
+        self.dev_in.copy_(self.pin_in, non_blocking=True)
+        row, view, prow, pview, act, hrow, crow, dst = (self.dev_in[j] for j in range(8))
+        ns = nav.struct()
+        for o, (r_, v_) in zip(self.obs, ((row, view), (prow, pview))):
+            call('sf_nav_step', byref(ns), cap, ptr(r_), ptr(v_), None, None, None, 0, None, ptr(o['row']), ptr(o['vp']),
+                 ptr(o['view']), ptr(o['a_num']), ptr(o['cand_view']), ptr(o['sincos']), None, s)
+        cur, par = self.obs
+        ucand = st.cands(par['vp'], par['cand_view'], par['sincos'], par['a_num'], A)
+        call('sf_gather_actions', byref(ucand), cap, ptr(act), ptr(self.u_prev), s)
+        call('sf_gather_rows', ptr(self.hpool), self.H, ptr(hrow), cap, self.H, ptr(self.h0), self.H, s)
+        call('sf_gather_rows', ptr(self.cpool), self.H, ptr(hrow), cap, self.H, ptr(self.c0), self.H, s)
+        pano = st.pano(cur['vp'], cur['view'])
+        cnd = st.cands(cur['vp'], cur['cand_view'], cur['sincos'], cur['a_num'], A)
+        w = decoder_w_struct(decoder_params(self.dec))
+        tp = tape_struct(self.tape)
+        call('sf_attn_decoder_fwd', byref(w), byref(pano), byref(cnd), cap, self.H, self.D, self.T,
+             ptr(self.u_prev), ptr(self.h0), ptr(self.c0), ptr(self.ctx), ptr(self.mask), ptr(crow), byref(tp), None,
+             None, 0, *ws_args(self.dev))
+        call('sf_logprob_topk', ptr(self.tape['logit']), A, cap, A, ptr(cur['a_num']), A, None, ptr(self.logp), s)
+        for src, pool, width in ((self.tape['h1'], self.hpool, self.H), (self.tape['c1'], self.cpool, self.H),
+                                 (self.tape['alpha'], self.apool, self.T)):
+            call('sf_scatter_rows', ptr(src), width, ptr(dst), cap, width, ptr(pool), width, s)
+        self.pin_out.copy_(self.logp, non_blocking=True)
+        self._keep = (ns, ucand, pano, cnd, w, tp)
+
+    def _capture(self):
+        self.pin_in.zero_()
+        self.pin_in[7].fill_(-1)                                     # (a warm-up that writes no pool row)
+        side = torch.cuda.Stream(device=self.dev)
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad(), torch.cuda.stream(side):
+            self._issue()                                            # warm-up: workspace, cached layouts
+            side.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph, stream=side):
+                self._issue()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph, self._stream = graph, side                       # (the graph bakes the capture stream's workspace)
+        self.baked = bytes(decoder_w_struct(decoder_params(self.dec)))
+
+    # ---- per iteration
+    def run(self, n):
+        """Inputs are in `self.inputs` (columns 0..n-1; the rest padding with destination -1).  Returns the
+        log-probabilities [cap, A] (host view, valid until the next run); the new states are pool rows
+        self.n - n .. self.n - 1."""
+        if self.n + n > self.pool_rows:
+            self._grow(self.n + n)
+        self.n += n
+        self.graph.replay()
+        torch.cuda.current_stream().synchronize()
+        return self.out
+
+    def _grow(self, need):
+        rows = max(2 * self.pool_rows, need)
+        for name in ('hpool', 'cpool', 'apool'):
+            old = getattr(self, name)
+            new = torch.zeros(rows, old.shape[1], device=self.dev, dtype=torch.float32)
+            new[:self.n].copy_(old[:self.n])
+            setattr(self, name, new)
+        self.pool_rows = rows
+        keep = self.pin_in.clone()
+        self._capture()                                              # the graph holds the pools' addresses
+        self.pin_in.copy_(keep)
+
+    def attention_rows(self, rows):
+        if not rows:
+            return []
+        r = torch.tensor(rows, dtype=torch.int64, device=self.dev)
+        return list(self.apool[r].cpu().numpy())
+
+
+def graph_step_for(agent, nav, n_inst, cap):
+    """The agent's GraphStep for these sizes (built on first use, kept on the agent)."""
+    t_max = agent.max_instruction_length
+    key = (id(agent.decoder), id(agent.store), id(nav), n_inst, cap, t_max)
+    cache = agent.__dict__.setdefault('_graph_steps', {})
+    gs = cache.get(key)
+    if gs is None or gs.dec is not agent.decoder or gs.store is not agent.store or gs.nav is not nav:
+        cache.clear()                                                # (one live configuration: the pools are ~100 MB)
+        gs = cache[key] = GraphStep(agent.decoder, agent.store, nav, n_inst, cap, t_max)
+    return gs
+
+
 def _require_store(agent):
     if getattr(agent, 'store', None) is None:
         raise RuntimeError('search runs on index-form observations: give the agent a '

@@ -13,6 +13,12 @@ def load():
     return MatterSim
 
 
+def load_frontier():
+    """The state-factored search's bookkeeping (frontier_core.cpp): sf_frontier.StateFactored."""
+    import sf_frontier
+    return sf_frontier
+
+
 def load_sweep():
     """The batched panorama sweep (sweep_py.cpp): sf_sweep.sweep_scan."""
     import sf_sweep

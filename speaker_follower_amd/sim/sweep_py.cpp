@@ -75,7 +75,8 @@ std::vector<Cand> sweep_state(Simulator& sim) {
 
 // All (viewpoint, heading bin) states of a scan.  viewpoints: the ids to tabulate (included ones).
 // Returns (a_num [n,12] int32, next_ix [n,12,A] int32 (index into `viewpoints`, -1 = not listed),
-//          abs_view [n,12,A] int32, rel_heading [n,12,A] f64, rel_elevation [n,12,A] f64); slot 0 = stop.
+//          abs_view [n,12,A] int32, rel_heading [n,12,A] f64, rel_elevation [n,12,A] f64,
+//          distance [n,12,A] f64 (angular distance from the image centre of the chosen view)); slot 0 = stop.
 py::tuple sweep_scan(const std::string& nav_graph_path, const std::string& scan,
                      const std::vector<std::string>& viewpoints, int width, int height, double vfov, int a_max) {
     Simulator sim;
@@ -103,17 +104,18 @@ py::tuple sweep_scan(const std::string& nav_graph_path, const std::string& scan,
     if (a_max > 0) A = std::max<size_t>(A, (size_t)a_max);
     py::array_t<int32_t> a_num({n, (size_t)12});
     py::array_t<int32_t> next_ix({n, (size_t)12, A}), abs_view({n, (size_t)12, A});
-    py::array_t<double> rel_h({n, (size_t)12, A}), rel_e({n, (size_t)12, A});
+    py::array_t<double> rel_h({n, (size_t)12, A}), rel_e({n, (size_t)12, A}), dist({n, (size_t)12, A});
     auto an = a_num.mutable_unchecked<2>();
     auto nx = next_ix.mutable_unchecked<3>();
     auto av = abs_view.mutable_unchecked<3>();
     auto rh = rel_h.mutable_unchecked<3>();
     auto re = rel_e.mutable_unchecked<3>();
+    auto ds = dist.mutable_unchecked<3>();
     for (size_t r = 0; r < n; ++r)
         for (int h = 0; h < 12; ++h) {
             const std::vector<Cand>& adj = all[r * 12 + h];
             an(r, h) = (int32_t)adj.size() + 1;
-            for (size_t a = 0; a < A; ++a) { nx(r, h, a) = (int32_t)r; av(r, h, a) = 0; rh(r, h, a) = 0.0; re(r, h, a) = 0.0; }
+            for (size_t a = 0; a < A; ++a) { nx(r, h, a) = (int32_t)r; av(r, h, a) = 0; rh(r, h, a) = 0.0; re(r, h, a) = 0.0; ds(r, h, a) = 0.0; }
             av(r, h, 0) = -1;                        // stop: absViewIndex -1 (env.py:219)
             for (size_t a = 0; a < adj.size(); ++a) {
                 const Cand& c = adj[a];
@@ -121,9 +123,10 @@ py::tuple sweep_scan(const std::string& nav_graph_path, const std::string& scan,
                 av(r, h, a + 1) = c.abs_view;
                 rh(r, h, a + 1) = c.rel_heading;
                 re(r, h, a + 1) = c.rel_elevation;
+                ds(r, h, a + 1) = c.distance;
             }
         }
-    return py::make_tuple(a_num, next_ix, abs_view, rel_h, rel_e);
+    return py::make_tuple(a_num, next_ix, abs_view, rel_h, rel_e, dist);
 }
 
 }  // namespace

@@ -165,7 +165,7 @@ def test_native_batched_sweep_is_bit_identical_to_the_per_state_sweep():
     checked = 0
     for scan, g in e.graphs.items():
         nodes = [v for v, inc in zip(g.ids, g.included) if inc]
-        a_num, nx, av, rh, re = sweep(CONN, scan, nodes, env.IMAGE_W, env.IMAGE_H, math.radians(env.VFOV), 0)
+        a_num, nx, av, rh, re, ds = sweep(CONN, scan, nodes, env.IMAGE_W, env.IMAGE_H, math.radians(env.VFOV), 0)
         for r, v in enumerate(nodes):
             for view in range(36):
                 got_view, adj = e.panorama(env.WorldState(scan, v, (view % 12) * env.ANGLE_INC,
@@ -175,6 +175,7 @@ def test_native_batched_sweep_is_bit_identical_to_the_per_state_sweep():
                 for a, d in enumerate(adj[1:], 1):
                     assert nodes[nx[r, h, a]] == d['nextViewpointId'] and av[r, h, a] == d['absViewIndex']
                     assert rh[r, h, a] == d['rel_heading'] and re[r, h, a] == d['rel_elevation']     # bit-exact
+                    assert ds[r, h, a] == d['distance']
                     checked += 1
     assert checked > 5000
 
@@ -196,6 +197,9 @@ def test_nav_table_rows_follow_the_sweep(tmp_path):
             s = r * 36 + view
             assert int(nt.a_num[s]) == len(adj)
             assert int(nt.next_row[s, 0]) == r
+            # the dictionary form rebuilt from the tables: the sweep's own list, key order and every float included
+            rebuilt = nt.adj_loc_list(s)
+            assert rebuilt == adj and [list(d) for d in rebuilt] == [list(d) for d in adj]
             for a, d in enumerate(adj[1:], 1):
                 assert nt.vp_of[int(nt.next_row[s, a])] == (scan, d['nextViewpointId'])
                 assert int(nt.cand_view[s, a]) == d['absViewIndex']
@@ -233,7 +237,7 @@ def test_full_r2r_geometry_table_regenerates_the_connectivity_directory(tmp_path
     a_max, states = 0, 0
     for s, g in geo.items():
         nodes = [v for v, inc in zip(g['ids'], g['included']) if inc]
-        a_num, nx, _, _, _ = sweep(d, s, nodes, env.IMAGE_W, env.IMAGE_H, math.radians(env.VFOV), 0)
+        a_num, nx, _, _, _, _ = sweep(d, s, nodes, env.IMAGE_W, env.IMAGE_H, math.radians(env.VFOV), 0)
         assert (nx >= 0).all() and (a_num >= 1).all()
         a_max = max(a_max, int(a_num.max()))
         states += a_num.size * 3

@@ -168,3 +168,89 @@ def test_ragged_helpers():
     g = np.array([0, 0, 0, 2, 2, 5])
     assert frontier._first_k_per_group(g, 2).tolist() == [True, True, False, True, True, True]
     assert frontier._first_k_per_group(np.zeros(0, int), 3).tolist() == []
+
+
+# ---- the native bookkeeping of the state-factored search against its numpy restatement ----------------------
+class _FakeStore:
+    n, F, V = 0, 2176, 36
+
+    def __init__(self):
+        import torch
+        self.device = torch.device('cpu')
+
+
+class _FakeDecoder:
+    """Stands where search.FlatDecoder stands: log-probabilities that are a deterministic function of the state and
+    the hypothesis' history, QUANTISED to 1/4 so that exactly equal scores are common (the tie rules are what the
+    two implementations could disagree on)."""
+
+    def __init__(self, *a):
+        self.base = 0
+
+    def seed(self, h, c):
+        self.base = h.shape[0]
+
+    def step_logprobs(self, inp):
+        n, a_max = len(inp['vp']), int(inp['a_num'].max())
+        out = np.full((n, a_max), -np.inf, np.float32)
+        for i in range(n):
+            r = np.random.default_rng(int(inp['vp'][i]) * 36 + int(inp['view'][i]) + 977 * int(inp['crow'][i]))
+            k = int(inp['a_num'][i])
+            out[i, :k] = -np.round(r.random(k) * 12) / 4 - 0.25
+        base = self.base
+        self.base += n
+        return base, out
+
+    def attention_rows(self, rows):
+        return [np.zeros(4, np.float32) for _ in rows]
+
+
+def _fake_agent(monkeypatch, episode_len=6):
+    import torch
+    from speaker_follower_amd import search
+    env, _ = W.build_world(dense=False, n_items=24, batch=24, item_seed=7)
+    monkeypatch.setattr(search, 'FlatDecoder', _FakeDecoder)
+    monkeypatch.setattr(search, '_require_store', lambda a: None)
+    monkeypatch.setattr(search, '_encode_items', lambda agent, items: (
+        torch.zeros(len(items), 4, 8), torch.zeros(len(items), 4), torch.zeros(len(items), 8), torch.zeros(len(items), 8)))
+
+    class Agent:
+        pass
+    agent = Agent()
+    agent.env, agent.store, agent.episode_len, agent.decoder = env, _FakeStore(), episode_len, None
+    env.set_beam_size(8)
+    return agent
+
+
+def _search_record(out):
+    trajs, completed, traversed = out
+    return ([[(c['instr_id'], c['trajectory'], c['actions'], c['score'], c['scores']) for c in cands] for cands in trajs],
+            [lst.nodes for lst in completed], [lst.nodes for lst in traversed])
+
+
+def test_native_state_factored_bookkeeping_equals_the_numpy_restatement(monkeypatch):
+    """sim/frontier_core.cpp against frontier._state_factored_search_numpy: the same hypotheses node for node
+    (ids, scores, completion order, physical traversal) for several completion / successor sizes and state keys,
+    with many exactly tied scores."""
+    from speaker_follower_amd import frontier
+    agent = _fake_agent(monkeypatch)
+    n_ties = 0
+    for k, s, key_fields in ((10, 1, 4), (40, 1, 4), (6, 3, 4), (12, 2, 3), (5, 1, 2)):
+        recs = []
+        for backend in ('numpy', 'native'):
+            agent.search_backend = backend
+            agent.env.reset_epoch()
+            out = frontier.state_factored_search(agent, k, s, first_n_ws_key=key_fields)
+            recs.append(_search_record(out))
+            if backend == 'numpy':
+                t = out[1][0].t
+                sc = np.sort(t.score[:t.n])
+                n_ties += int((np.diff(sc) == 0).sum())
+        assert recs[0] == recs[1], (k, s, key_fields)
+        assert all(len(c) >= 1 for c in recs[0][1])
+    assert n_ties > 100                                   # the case really exercises the tie rules
+    agent.search_backend = 'nonsense'
+    agent.tie_log = []                                    # the diagnostics hook runs the numpy path
+    agent.env.reset_epoch()
+    frontier.state_factored_search(agent, 5, 1)
+    assert agent.tie_log
