@@ -497,38 +497,56 @@ class Seq2SeqSpeaker(object):
         B = len(path_obs)
         n = np.array([len(a) for a in path_actions], np.int32)
         Tp = int(n.max())
-        z = lambda dt: np.zeros((Tp, B), dt)                               # noqa: E731
-        sb = synth.SpeakerBatch(instr=list(encoded_instructions), path_len=n, vp=z(np.int32), view=z(np.int32),
-                                act_view=z(np.int32), act_heading=z(np.float64), act_elevation=z(np.float64),
-                                act_is_stop=np.ones((Tp, B), bool))
+        # one row (vp_row, viewIndex, absViewIndex, rel_heading, rel_elevation, is_stop) per (observation, action) pair,
+        # formed once per DISTINCT pair: the candidate routes of a search share their observation dictionaries
+        seen, rows, at = {}, [], []
         for i, (obs, actions) in enumerate(zip(path_obs, path_actions)):
             assert len(obs) == len(actions) + 1
-            for t, (ob, a) in enumerate(zip(obs[:-1], actions)):
-                assert a >= 0
-                sb.vp[t, i], sb.view[t, i] = ob['vp_row'], ob['viewIndex']
-                if a > 0:
-                    d = ob['adj_loc_list'][a]
-                    sb.act_is_stop[t, i] = False
-                    sb.act_view[t, i], sb.act_heading[t, i], sb.act_elevation[t, i] = \
-                        d['absViewIndex'], d['rel_heading'], d['rel_elevation']
+            for t, a in enumerate(actions):
+                ob = obs[t]
+                k = (id(ob), a)
+                r = seen.get(k)
+                if r is None:
+                    assert a >= 0
+                    if a > 0:
+                        d = ob['adj_loc_list'][a]
+                        r = (ob['vp_row'], ob['viewIndex'], d['absViewIndex'], d['rel_heading'], d['rel_elevation'], 0.0)
+                    else:
+                        r = (ob['vp_row'], ob['viewIndex'], 0, 0.0, 0.0, 1.0)
+                    seen[k] = r
+                rows.append(r)
+                at.append(t * B + i)
+        rows = np.array(rows, np.float64).reshape(-1, 6)
+        at = np.array(at, np.int64)
+
+        def grid(col, dt, fill=0):
+            out = np.full(Tp * B, fill, dt)
+            out[at] = rows[:, col]
+            return out.reshape(Tp, B)
+        sb = synth.SpeakerBatch(instr=list(encoded_instructions), path_len=n, vp=grid(0, np.int32), view=grid(1, np.int32),
+                                act_view=grid(2, np.int32), act_heading=grid(3, np.float64),
+                                act_elevation=grid(4, np.float64), act_is_stop=grid(5, np.float64, 1.0) != 0)
         if getattr(self, '_engine', None) is None or self._engine.store is not store:
             self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
         batch = spk.DeviceSpeakerBatch.from_synth(sb, device=store.device, max_length=self.instruction_len)
         S = self.instruction_len
+        if feedback == 'teacher':
+            # the reference's loop ends once every row has ended (speaker.py:199-200): with teacher forcing that is the
+            # longest instruction's EOS -- steps behind it add nothing to any score or to the loss
+            S = max(1, min(S, max(len(e_) for e_ in encoded_instructions) + 1))
         st = self._engine.run(batch, S, feedback, train=self.decoder.training)   # (fault check + per-step re-issue inside)
-        words = st.words[1:].t().cpu().numpy()                             # [B,S]  (the one host sync)
-        sc = st.step_scores.t().cpu().numpy()
+        both = torch.cat((st.words[1:].to(torch.float32), st.step_scores), dim=0).cpu().numpy()   # (the one host sync)
+        words, sc = both[:S].T.astype(np.int64), np.ascontiguousarray(both[S:].T)                  # [B,S] each
+        is_eos = words == EOS
+        m_all = np.where(is_eos.any(1), is_eos.argmax(1) + 1, S)           # up to and including the first EOS
+        totals = np.cumsum(sc, axis=1, dtype=np.float32)                   # (sequential float32 partial sums)
         tok = getattr(self.env, 'tokenizer', None)
         outputs = []
         for i in range(B):
-            eos = np.flatnonzero(words[i] == EOS)
-            m = int(eos[0]) + 1 if len(eos) else S                         # up to and including the first EOS
-            total = np.float32(0)
-            for v in sc[i, :m]:
-                total = np.float32(total + v)
-            wi = [int(w) for w in words[i, :m]]
-            outputs.append({'instr_id': path_obs[i][0]['instr_id'], 'word_indices': wi, 'scores': [float(v) for v in sc[i, :m]],
-                            'score': float(total),
+            m = int(m_all[i])
+            wi = words[i, :m].tolist()
+            outputs.append({'instr_id': path_obs[i][0]['instr_id'], 'word_indices': wi, 'scores': sc[i, :m].tolist(),
+                            'score': float(totals[i, m - 1]),
                             'words': tok.decode_sentence(wi, break_on_eos=True, join=False) if tok is not None else wi})
         # (the reference stops summing step losses once EVERY row has produced EOS, speaker.py:196: so does
         # sf_speaker_loss_finalize, which st.loss comes from)

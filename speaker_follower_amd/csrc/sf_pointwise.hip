@@ -641,7 +641,7 @@ __global__ __launch_bounds__(64) void loss_finalize_kernel(const float* sum_cnt,
 // loop) and zeroes gscale behind the last step (no gradient flows from steps the reference never adds).
 __global__ __launch_bounds__(1024) void speaker_loss_finalize_kernel(const float* sum_cnt, const int64_t* words, int eos,
                                                                      int T, int B, float* loss, float* gscale) {
-    __shared__ int s_first[1024];              // per row (B <= 1024): first step whose word is EOS
+    __shared__ int s_first[1024];              // per row (the B <= 1024 form): first step whose word is EOS
     __shared__ int s_end;
     const int tid = threadIdx.x;
     s_first[tid] = T - 1;                      // never ended: the reference's loop runs all T steps
@@ -650,18 +650,37 @@ __global__ __launch_bounds__(1024) void speaker_loss_finalize_kernel(const float
     // every (step, row) is looked at once; the loads of a pass are issued together, straight-line on clamped indices
     // (a load behind the EOS test would cost one memory round trip per iteration)
     const int n = T * B;
-    for (int base = 0; base < n; base += 8 * 1024) {
-        int64_t w[8];
+    if (B <= 1024) {
+        for (int base = 0; base < n; base += 8 * 1024) {
+            int64_t w[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) w[u] = words[(size_t)B + min(base + u * 1024 + tid, n - 1)];
+            for (int u = 0; u < 8; ++u) w[u] = words[(size_t)B + min(base + u * 1024 + tid, n - 1)];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int i = base + u * 1024 + tid;
-            if (i < n && w[u] == eos) atomicMin(&s_first[i % B], i / B);
+            for (int u = 0; u < 8; ++u) {
+                const int i = base + u * 1024 + tid;
+                if (i < n && w[u] == eos) atomicMin(&s_first[i % B], i / B);
+            }
         }
+        __syncthreads();
+        if (tid < B) atomicMax(&s_end, s_first[tid]);
+    } else {
+        // more rows than threads (the pragmatic re-ranking scores ~2 500 candidate routes as ONE batch,
+        // rational_follower.py:67-69): every thread walks the steps of its own rows, eight loads in flight
+        int mine = 0;
+        for (int b = tid; b < B; b += 1024) {
+            int first = T - 1;
+            for (int t0 = 0; t0 < T; t0 += 8) {
+                int64_t w[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) w[u] = words[(size_t)B * (size_t)(min(t0 + u, T - 1) + 1) + b];
+#pragma unroll
+                for (int u = 7; u >= 0; --u)
+                    if (t0 + u < T && w[u] == eos) first = min(first, t0 + u);
+            }
+            mine = max(mine, first);
+        }
+        atomicMax(&s_end, mine);
     }
-    __syncthreads();
-    if (tid < B) atomicMax(&s_end, s_first[tid]);
     __syncthreads();
     const int last = s_end;                                      // steps 0 .. last are added
     if (tid < 64) {
@@ -962,7 +981,7 @@ int reduce_terms(const float* term, const float* live, int T, int B, float* sum_
 }
 int speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos, int T, int B, float* loss, float* gscale,
                           hipStream_t st) {
-    if (T > 1024 || B > 1024) return SF_ERR_UNSUPPORTED;
+    if (T > 1024) return SF_ERR_UNSUPPORTED;
     SF_LAUNCH(speaker_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sum_cnt, words, eos, T, B, loss, gscale);
     return launch_status();
 }

@@ -186,6 +186,11 @@ class R2RIndexEnv:
         the sweep cache serve any number of states, so this only records the size."""
         self.beam_size = beam_size
 
+    def start_view(self, ws):
+        """The discrete view index newEpisode snaps a pose to (env.py:814-819), without the panorama sweep."""
+        self.sim.newEpisode(ws.scanId, ws.viewpointId, ws.heading, ws.elevation)
+        return self.sim.getState().viewIndex
+
     # ---- cached panorama sweep
     def panorama(self, ws):
         self.sim.newEpisode(ws.scanId, ws.viewpointId, ws.heading, ws.elevation)

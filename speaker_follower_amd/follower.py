@@ -33,10 +33,20 @@ def batch_instructions_from_encoded(encoded_instructions, max_length, reverse=Fa
                                     device=None):
     """follower.py:75-105.  Returns (seq [B,max_length] int64, mask [B,max(len)] bool
     (True = PAD), lengths list[, perm list]); tensors on `device` (default: cuda if present)."""
-    n = len(encoded_instructions)
-    seq = np.full((n, max_length), PAD, np.int64)
+    # (rows that are the SAME object -- the candidate routes of one instruction in the pragmatic re-ranking,
+    # rational_follower.py:67-69 -- are encoded once)
+    first, src = {}, []
+    for inst in encoded_instructions:
+        j = first.get(id(inst))
+        if j is None:
+            j = first[id(inst)] = len(first)
+        src.append(j)
+    distinct = [None] * len(first)
+    for inst, j in zip(encoded_instructions, src):
+        distinct[j] = inst
+    seq = np.full((len(distinct), max_length), PAD, np.int64)
     lengths = []
-    for i, inst in enumerate(encoded_instructions):
+    for i, inst in enumerate(distinct):
         inst = np.asarray(inst, np.int64)
         if len(inst) > 0:
             assert inst[-1] != EOS
@@ -45,6 +55,9 @@ def batch_instructions_from_encoded(encoded_instructions, max_length, reverse=Fa
         inst = np.concatenate((inst, [EOS]))[:max_length]
         seq[i, :len(inst)] = inst
         lengths.append(len(inst))
+    if len(distinct) < len(src):
+        seq = seq[src]
+        lengths = [lengths[j] for j in src]
     perm = None
     if sort:
         perm = np.argsort(-np.asarray(lengths), kind='stable')

@@ -109,7 +109,7 @@ class StateSpace:
         self.base_row = np.array([nav.base[it['scan']] for it in items], np.int64)
         self.rows = np.array([nav.scan_rows[it['scan']] for it in items], np.int64)
         root_row = np.array([nav.row_of[(it['scan'], it['path'][0])] for it in items], np.int64)
-        root_view = np.array([env.panorama(WorldState(it['scan'], it['path'][0], it['heading'], 0))[0]
+        root_view = np.array([env.start_view(WorldState(it['scan'], it['path'][0], it['heading'], 0))
                               for it in items], np.int64)         # newEpisode snaps the heading (env.py:814-819)
         self.root_sid = root_row * V + root_view
         # keys: what the reference's `world_state[0:first_n_ws_key]` distinguishes (follower.py:722, 843)

@@ -162,7 +162,7 @@ class DeviceNavBatch:
         hop = np.zeros((B, ld), np.int32)
         base = np.zeros(B, np.int32)
         for b, it in enumerate(items):
-            view, _ = env.panorama(WorldState(it['scan'], it['path'][0], it['heading'], 0))
+            view = env.start_view(WorldState(it['scan'], it['path'][0], it['heading'], 0))
             rows.append(nav.row_of[(it['scan'], it['path'][0])])
             views.append(view)
             h = nav.hops(it['scan'], it['path'][-1])

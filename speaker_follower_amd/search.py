@@ -491,16 +491,19 @@ def speaker_beam_search(speaker, beam_size, path_obs, path_actions):
 def rational_mix(candidate_lists_by_instr_id, speaker_weight):
     """rational_follower.py:117-148: standardise follower and speaker scores over ALL candidates,
     pick per instruction the candidate maximising the weighted sum.  Returns (results, index counts)."""
-    follower_scores = [c['follower_score'] for l in candidate_lists_by_instr_id.values() for c in l]
-    speaker_scores = [c['speaker_score'] for l in candidate_lists_by_instr_id.values() for c in l]
+    lists = list(candidate_lists_by_instr_id.values())
+    follower_scores = np.array([c['follower_score'] for l in lists for c in l], np.float64)
+    speaker_scores = np.array([c['speaker_score'] for l in lists for c in l], np.float64)
     speaker_std, follower_std = np.std(speaker_scores), np.std(follower_scores)
     sw = speaker_weight / speaker_std
     fw = (1 - speaker_weight) / follower_std
+    mixed = speaker_scores * sw + follower_scores * fw           # (the reference's float64 expression, element-wise)
     results, index_count = {}, Counter()
+    lo = 0
     for instr_id, candidates in candidate_lists_by_instr_id.items():
-        best_ix, best_cand = max(enumerate(candidates),
-                                 key=lambda tp: tp[1]['speaker_score'] * sw + tp[1]['follower_score'] * fw)
-        results[instr_id] = best_cand
+        best_ix = int(np.argmax(mixed[lo:lo + len(candidates)]))   # first maximum, like max() over enumerate
+        lo += len(candidates)
+        results[instr_id] = candidates[best_ix]
         index_count[best_ix] += 1
     return results, index_count
 

@@ -329,3 +329,44 @@ def test_speaker_run_falls_back_to_the_per_step_kernels(forced_timeout):
     assert good.persistent
     assert torch.equal(good.words, st.words)
     np.testing.assert_allclose(st.step_scores.cpu().numpy(), good.step_scores.cpu().numpy(), rtol=1e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize('B', [7, 100, 1024, 1025, 2600])
+def test_speaker_loss_finalize_for_any_batch_size(B):
+    """sf_speaker_loss_finalize directly (speaker.py:192-197): the step means are added up to and including the first
+    step at which EVERY row has produced EOS -- also for more rows than the kernel has threads (the pragmatic
+    re-ranking scores all ~2 500 candidate routes of a minibatch as one batch, rational_follower.py:67-69)."""
+    from speaker_follower_amd import _lib
+    from speaker_follower_amd.runtime import ptr, stream as cur
+    T = 37
+    g = np.random.default_rng(B)
+    words = g.integers(3, 900, size=(T + 1, B)).astype(np.int64)
+    first = g.integers(2, 20, size=B)
+    first[g.integers(B)] = 29                                   # the slowest row
+    for b in range(B):
+        words[1 + first[b], b] = EOS                            # (row 0 of `words` = the start tokens)
+        if b % 3 == 0:
+            words[1 + min(first[b] + 4, T - 1), b] = EOS        # a later EOS does not matter
+    sum_cnt = np.stack((g.random(T) * 50 + 1, g.integers(1, B + 1, size=T)), 1).astype(np.float32)
+    sum_cnt[5, 1] = 0.0                                         # a step without live rows adds nothing
+    loss = torch.zeros(1, device='cuda')
+    gscale = torch.full((T,), -1.0, device='cuda')
+    d_sc, d_w = torch.tensor(sum_cnt).cuda(), torch.tensor(words).cuda()
+    _lib.call('sf_speaker_loss_finalize', ptr(d_sc), ptr(d_w), EOS, T, B, ptr(loss), ptr(gscale), cur())
+    torch.cuda.synchronize()
+    last = int(first.max())
+    assert last == 29
+    want = np.float32(0)
+    want_g = np.zeros(T, np.float32)
+    for t in range(last + 1):
+        if sum_cnt[t, 1] > 0:
+            want = np.float32(want + np.float32(sum_cnt[t, 0] / sum_cnt[t, 1]))
+            want_g[t] = np.float32(1.0) / sum_cnt[t, 1]
+    assert float(loss) == float(want)
+    assert np.array_equal(gscale.cpu().numpy(), want_g)
+    # no row ever ends: all T steps count
+    words[words == EOS] = 5
+    d_w = torch.tensor(words).cuda()
+    _lib.call('sf_speaker_loss_finalize', ptr(d_sc), ptr(d_w), EOS, T, B, ptr(loss), ptr(gscale), cur())
+    torch.cuda.synchronize()
+    assert int((gscale.cpu().numpy() > 0).sum()) == T - 1       # (every step but the one without live rows)

@@ -101,6 +101,22 @@ def _free_port():
         return sk.getsockname()[1]
 
 
+def _spawn_world(worker, world, out):
+    """mp.spawn of a gloo world on a free port; the port is found by bind-and-release, so another process can take it
+    before rank 0 binds it: a rendezvous that fails for THAT reason is retried on a fresh port."""
+    import torch.multiprocessing as mp
+    for attempt in range(3):
+        try:
+            mp.spawn(worker, args=(world, _free_port(), out), nprocs=world, join=True)
+            return
+        except Exception as e:                                     # noqa: BLE001
+            text = str(e).lower()
+            if attempt == 2 or not any(s in text for s in ('address already in use', 'eaddrinuse', 'connection refused',
+                                                           'connection reset', 'timed out')):
+                raise
+            out.clear()
+
+
 def _dp_worker(rank, world, port, out):
     import torch.distributed as dist
     from speaker_follower_amd import dp
@@ -135,10 +151,9 @@ def _dp_worker(rank, world, port, out):
 def test_data_parallel_gradient_and_count_allreduce_gloo_world2():
     import torch.multiprocessing as mp
     world = 2
-    port = _free_port()
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_dp_worker, args=(world, port, out), nprocs=world, join=True)
+    _spawn_world(_dp_worker, world, out)
     for r in range(world):
         w, b, sc, o, attached, raised = out[r]
         assert torch.all(w == 3.0) and torch.all(b == 30.0)        # 1+2, 10+20: SUM not mean
@@ -184,9 +199,8 @@ def test_bucketed_gradient_allreduce_equals_single_buffer_gloo_world2():
     every bucket is refused at wait()."""
     import torch.multiprocessing as mp
     world = 2
-    port = _free_port()
     out = mp.Manager().dict()
-    mp.spawn(_bucket_worker, args=(world, port, out), nprocs=world, join=True)
+    _spawn_world(_bucket_worker, world, out)
     for r in range(world):
         bucketed, single, bounds, attached, refused, first = out[r]
         assert torch.equal(bucketed, single)

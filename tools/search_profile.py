@@ -3,11 +3,14 @@
 
     python tools/search_profile.py [--cprofile]
 
+    python tools/search_profile.py --numpy     # the round-3 form: numpy bookkeeping, host-issued decoder steps
+
 Phases are wall-clock sections of the search with a device sync at each boundary (so the sum is a little above
-the unsynchronised run, which is printed first): setup (env.reset, encoder, tables), per iteration `inputs` (numpy
-fancy indexing of the step's index arrays), `device step` (packing + one H2D + gathers + decoder step + top-k + one
-D2H, and how much of that the device was busy: HIP events around the launches), `frontier` (numpy bookkeeping of the
-successors), and `results` (lineages, observation dictionaries, attention rows).
+the unsynchronised run, which is printed first): setup (env.reset, encoder, tables), per iteration the device step
+(native path: one hipGraph replay + stream sync; numpy path: packing + one H2D + ~25 launches + one D2H), the
+bookkeeping by difference (native: sim/frontier_core.cpp fill_inputs + advance; numpy: ~100 numpy calls), and
+`results` (lineages, observation dictionaries, attention rows, physical walks).  Every timed search runs on a
+minibatch the process has not seen before (fresh states: nothing is served from the env's sweep cache).
 """
 import argparse
 import cProfile
@@ -52,9 +55,10 @@ def instrument(ph):
             return out
         setattr(obj, name, timed)
         saved.append((obj, name, fn))
-    wrap(frontier, '_setup', 'setup (env.reset, encoder pass, state space)')
-    wrap(frontier, '_step_inputs', 'inputs (numpy gathers of the index arrays)', sync=False)
-    wrap(search.FlatDecoder, 'step_arrays', 'device step (pack + H2D + decoder + top-k + D2H)')
+    wrap(frontier, '_setup_space', 'setup (env.reset, encoder pass, state space, graph inputs)')
+    wrap(frontier, '_step_inputs', 'numpy path: inputs (gathers of the index arrays)', sync=False)
+    wrap(search.FlatDecoder, 'step_arrays', 'numpy path: device step (pack + H2D + launches + top-k + D2H)')
+    wrap(search.GraphStep, 'run', 'device step (hipGraph replay + stream sync)', sync=False)
     wrap(frontier, '_trajectories', 'results (lineages, observation dicts, attention rows)')
     wrap(frontier, 'physical_walks', 'results: physical walks', sync=False)
 
@@ -64,24 +68,27 @@ def instrument(ph):
     return undo
 
 
-def device_busy_of_step(agent, reps=20):
-    """HIP-event time of ONE flat decoder step over 64 states (launches only, inputs already uploaded) next to its
-    wall time: what the device is busy for inside `device step`."""
-    env, space, fd, t, roots = frontier._setup(agent, True)
-    inputs, _ = frontier._step_inputs(space, t, roots)
-    fd.step_arrays(inputs, 0)
+def graph_replay_time(agent, reps=50):
+    """Device time of one replay of the step graph (HIP events around back-to-back replays of the last inputs)."""
+    gs = next(iter(agent._graph_steps.values()))
+    keep = gs.pin_in.clone()
+    gs.pin_in[7].fill_(-1)                          # (write no pool row)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    gs.graph.replay()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
+    e0.record()
     for _ in range(reps):
-        fd.step_arrays(inputs, 0)
+        gs.graph.replay()
+    e1.record()
     torch.cuda.synchronize()
-    wall = (time.perf_counter() - t0) / reps
-    return wall
+    gs.pin_in.copy_(keep)
+    return e0.elapsed_time(e1) / reps * 1e-3
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--cprofile', action='store_true')
+    ap.add_argument('--numpy', action='store_true', help='numpy bookkeeping + host-issued decoder steps')
     args = ap.parse_args()
     dev = torch.device('cuda', 0)
     enc, dec, _, _ = bench.build_models(101, dev)
@@ -89,13 +96,15 @@ def main():
     dec.eval()
     table = bench.device_table(10567, 1234, dev)
     store = features.FeatureStore(table, device=dev)
-    e64, _ = bench_extras.full_world(store, 64, seed=15)
+    e64, _ = bench_extras.full_world(store, 64, seed=15, n_items=64 * 12)
     agent = agents.Seq2SeqAgent(e64, '/tmp/sf_search_profile.json', enc, dec, episode_len=8)
     agent.store = store
+    if args.numpy:
+        agent.search_backend = 'numpy'
     e64.set_beam_size(40)
+    e64.reset_epoch()
 
     def run():
-        e64.reset_epoch()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         with torch.no_grad():
@@ -104,8 +113,10 @@ def main():
         return time.perf_counter() - t0, out
     for _ in range(2):
         run()
-    best = min(run()[0] for _ in range(5))
-    print('state_factored_search(40, 1), 64 instructions, full world: %.1f ms (best of 5, unsynchronised phases)' % (1e3 * best))
+    ts = [run()[0] for _ in range(6)]
+    print('state_factored_search(40, 1), 64 instructions, full world, %s path: %.1f ms mean / %.1f best / %.1f worst over 6 '
+          'minibatches never seen before' % ('numpy' if args.numpy else 'native + graph', 1e3 * np.mean(ts), 1e3 * min(ts),
+                                             1e3 * max(ts)))
 
     ph = Phases()
     undo = instrument(ph)
@@ -116,14 +127,13 @@ def main():
     print('%-62s %9s %7s %10s' % ('phase', 'ms', 'calls', 'us/call'))
     for k, v in sorted(ph.t.items(), key=lambda kv: -kv[1]):
         print('%-62s %9.2f %7d %10.1f' % (k, 1e3 * v, ph.n[k], 1e6 * v / ph.n[k]))
-    print('%-62s %9.2f' % ('frontier bookkeeping + everything else (numpy, by difference)', 1e3 * (dt - acc)))
-    e64.reset_epoch()
-    wall = device_busy_of_step(agent)
-    print('\none flat decoder step over 64 root states, back to back: %.1f us wall per step' % (1e6 * wall))
+    print('%-62s %9.2f' % ('bookkeeping + the Python loop around it (by difference)', 1e3 * (dt - acc)))
+    if not args.numpy:
+        print('\none replay of the step graph (64 states: H2D, 2x nav look-up, gathers, decoder step, log-softmax, scatter, '
+              'D2H): %.1f us on the device' % (1e6 * graph_replay_time(agent)))
 
     if args.cprofile:
         pr = cProfile.Profile()
-        e64.reset_epoch()
         pr.enable()
         with torch.no_grad():
             agent.state_factored_search(40, 1)
