@@ -156,6 +156,28 @@ def test_state_factored_search_batch64_k40_matches_reference():
     assert n_cands == sum(len(w['cands']) for w in want) and n_cands > 64 * 20
     print('state-factored search, batch 64, K = 40: %.2f s here; the reference took %.1f s on %d CPU threads'
           % (dt, cfg['reference_cpu_seconds'], cfg['reference_threads']))
+    # ---- the production path (no diagnostics hook): one hipGraph replay (search.GraphStep) + one native bookkeeping
+    # call (sim/frontier_core.cpp) per iteration, against the same golden and against the numpy path above
+    del agent.tie_log
+    env.reset_epoch()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    trajs_n, completed_n, traversed_n = agent.state_factored_search(W.BIG_K, 1)
+    torch.cuda.synchronize()
+    dt_n = time.time() - t0
+    assert agent._graph_steps, 'the production path did not run'
+    differ = []
+    for i, (g, tr, w, tr_np) in enumerate(zip(trajs_n, traversed_n, want, traversed)):
+        check_candidates(g, w['cands'])
+        for a, b in zip(g, trajs[i]):                       # and the numpy path's, to roundoff
+            assert a['actions'] == b['actions'] and a['trajectory'] == b['trajectory']
+            assert abs(a['score'] - b['score']) <= 2e-5
+        if [s.world_state.viewpointId for s in tr] != w['traversed']:
+            m = tie_inst == i
+            assert m.any() and float((tie_gap[m] / tie_ulp[m]).min()) <= 2.0, i
+            differ.append(i)
+    assert len(differ) <= 2, differ
+    print('production path (graph + native): %.3f s, traversal re-ordered at fp32 ties: %s' % (dt_n, differ))
 
 
 def test_beam_one_equals_greedy_rollout(world):
@@ -233,6 +255,84 @@ def test_logprob_topk_kernel_against_torch():
             assert torch.equal(xin[:, :n], ref)                    # masked in place
 
 
+def test_logprob_rows_in_column_order():
+    """sf_logprob_topk with idx = NULL: the whole row, log_softmax in column order, -inf beyond n_valid."""
+    from speaker_follower_amd import _lib
+    from speaker_follower_amd._lib import call
+    from speaker_follower_amd.runtime import ptr, stream
+    g = torch.Generator().manual_seed(5)
+    for N, n in ((64, 14), (7, 5), (3, 991)):
+        ld = (n + 3) & ~3
+        x = torch.randn(N, ld, generator=g).cuda()
+        nv = torch.randint(1, n + 1, (N,), generator=g).to(torch.int32).cuda()
+        ref = x[:, :n].clone()
+        ref[torch.arange(n, device='cuda')[None, :] >= nv[:, None]] = -float('inf')
+        out = torch.full((N, n), 7.0, device='cuda')
+        call('sf_logprob_topk', ptr(x.clone()), ld, N, n, ptr(nv), n, None, ptr(out), stream())
+        want = torch.log_softmax(ref, 1)
+        assert torch.equal(torch.isinf(out), torch.isinf(want))
+        fin = ~torch.isinf(want)
+        torch.testing.assert_close(out[fin], want[fin], rtol=1e-5, atol=1e-5)
+        # the same numbers as the sorted form
+        idx = torch.empty(N, n, dtype=torch.int32, device='cuda')
+        logp = torch.empty(N, n, device='cuda')
+        call('sf_logprob_topk', ptr(x.clone()), ld, N, n, ptr(nv), n, ptr(idx), ptr(logp), stream())
+        ok = idx >= 0
+        rows = torch.arange(N, device='cuda')[:, None].expand(N, n)
+        assert torch.equal(out[rows[ok], idx.long()[ok]], logp[ok])
+    rc = _lib.lib.sf_logprob_topk(ptr(x), ld, N, n, None, 3, None, ptr(out), stream())        # NULL idx needs k == n
+    assert rc == _lib.SF_ERR_ARG
+
+
+def test_scatter_rows_kernel():
+    from speaker_follower_amd._lib import call
+    from speaker_follower_amd.runtime import ptr, stream
+    src = torch.randn(6, 512, device='cuda')
+    idx = torch.tensor([40, 3, -1, 0, 49, -1], dtype=torch.int32, device='cuda')
+    dst = torch.full((50, 516), 9.0, device='cuda')
+    call('sf_scatter_rows', ptr(src), 512, ptr(idx), 6, 512, ptr(dst), 516, stream())
+    want = torch.full((50, 516), 9.0, device='cuda')
+    for i, d in enumerate(idx.tolist()):
+        if d >= 0:
+            want[d, :512] = src[i]
+    assert torch.equal(dst, want)
+
+
+def test_graph_step_equals_host_issued_steps_and_survives_pool_growth(world):
+    """search.GraphStep (one hipGraph replay per iteration: nav look-ups on the device, instructions padded to the
+    agent's maximum length) against search.FlatDecoder over host-packed inputs, for the same frontier: same
+    log-probabilities to roundoff, same state rows; a pool that has to grow re-captures and keeps its rows."""
+    from speaker_follower_amd import frontier, search, nav
+    env, agent, _ = world
+    env.reset_epoch()
+    env_, space, fd, t, roots = frontier._setup(agent, True)
+    inputs, _ = frontier._step_inputs(space, t, roots)
+    base, logp = fd.step_logprobs(inputs)
+    B = len(roots)
+    env.reset_epoch()
+    agent.__dict__.pop('_graph_steps', None)
+    env2, space2, gs = frontier._setup_space(agent, True, graph_cap=B + 3)          # (capacity above the frontier)
+    gs.pool_rows = 0                                                               # force _grow on the first run
+    from speaker_follower_amd.sim import load_frontier
+    h = space2.h
+    core = load_frontier().StateFactored(10, 1, agent.episode_len, 4, 36, h['next_row'], h['cand_view'], h['a_num'],
+                                         space2.base_row, space2.root_sid, space2.root_key)
+    n = core.fill_inputs(gs.inputs, gs.n)
+    assert n == B and (gs.inputs[7, n:] == -1).all()
+    out = gs.run(n).copy()
+    A = logp.shape[1]
+    assert np.array_equal(np.isinf(out[:n, :A]), np.isinf(logp)) and np.isinf(out[:n, A:]).all()
+    fin = ~np.isinf(logp)
+    np.testing.assert_allclose(out[:n, :A][fin], logp[fin], rtol=0, atol=2e-5)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(gs.hpool[B:B + n].cpu().numpy(), fd.hpool.buf[base:base + n].cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(gs.hpool[:B].cpu().numpy(), fd.hpool.buf[:B].cpu().numpy(), atol=0)   # seeds survived _grow
+    Tn = fd.apool.buf.shape[1]
+    np.testing.assert_allclose(gs.apool[B:B + n, :Tn].cpu().numpy(), fd.apool.buf[base:base + n].cpu().numpy(), atol=2e-5)
+    assert float(gs.apool[B:B + n, Tn:].abs().max()) == 0.0                        # padded instruction positions: weight 0
+    agent.__dict__.pop('_graph_steps', None)
+
+
 def test_gather_rows_kernel():
     from speaker_follower_amd._lib import call
     from speaker_follower_amd.runtime import ptr, stream
@@ -243,3 +343,30 @@ def test_gather_rows_kernel():
     want = src[idx.long().clamp(min=0)]
     want[3] = 0
     assert torch.equal(dst, want)
+
+
+def test_speaker_rescoring_of_all_candidates_at_once_equals_small_batches(world):
+    """rational_follower.py:67-69 scores ALL candidate routes of a minibatch as one batch (~2 500 rows at configs[4]:
+    more than the persistent word loop's 128 rows and than sf_speaker_loss_finalize's 1 024 threads).  The one-batch
+    result equals scoring the same routes in batches of 100 (the persistent launch), route for route."""
+    from speaker_follower_amd import search
+    env, agent, speaker = world
+    env.reset_epoch()
+    env.set_beam_size(40)
+    with torch.no_grad():
+        cands, _, _ = agent.state_factored_search(40, 1)
+    flat = search.flatten(cands) * 9                                   # > 1 024 rows
+    assert len(flat) > 1100
+    args = ([c['observations'] for c in flat], [c['actions'] for c in flat], [c['instr_encoding'] for c in flat])
+    with torch.no_grad():
+        big, _ = speaker._score_obs_actions_and_instructions(*args, feedback='teacher')
+        small = []
+        for lo in range(0, len(flat), 100):
+            out, _ = speaker._score_obs_actions_and_instructions(*(a[lo:lo + 100] for a in args), feedback='teacher')
+            small += out
+    assert len(big) == len(small) == len(flat)
+    for a, b, c in zip(big, small, flat):
+        assert a['instr_id'] == b['instr_id'] == c['instr_id']
+        assert a['word_indices'] == b['word_indices'] == ([int(x) for x in c['instr_encoding']] + [2])[:W.INSTRUCTION_LEN]
+        assert abs(a['score'] - b['score']) <= 2e-4 * max(1.0, abs(b['score']))
+        np.testing.assert_allclose(a['scores'], b['scores'], rtol=0, atol=2e-4)
