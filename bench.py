@@ -625,6 +625,8 @@ def main(argv=None):
             out['real_env_rollout'] = bench_extras.real_env_rollout(conn, device)     # configs[1], 31-viewpoint fixture
         if args.n_viewpoints == 10567:             # configs[1] at its real size: 90 graphs, 10 567 viewpoints
             out['real_env_full'] = bench_extras.real_env_full(enc, dec, store, device)
+            # configs[4] end to end through the agents' API: search + one-batch speaker rescoring + rational_mix
+            out['pragmatic_inference'] = bench_extras.pragmatic_inference(enc, dec, store, device)
         # the full training iteration of configs[1] -- student-forcing rollout (dropout on), BPTT, two
         # Adam steps -- on the same batch (it updates the weights, so it runs last)
         if not args.no_train_extra:

@@ -630,6 +630,10 @@ void sf_debug_persist_timeout(long long ticks);
  * error-free operand splitting (csrc/sf_gemm.hip: gemm_nt_split_kernel; same fp32 accuracy class, measured closer
  * to the exact sum, 6/16 of the matrix-pipe time).  For A/B timing and for the accuracy tests. */
 void sf_debug_gate_product_f32(int on);
+/* Test switch: the weight-gradient products dW += dY^T X whose shape is a whole number of 128 x 128 tiles run as bf16x6
+ * split products (gemm_tn_split_kernel) from `rows` reduction rows on (default 4096: where it is faster than the
+ * fp32-MFMA kernels; rows < 0 restores the default). */
+void sf_debug_tn_split_min_rows(int rows);
 /* Byte offset, inside a workspace of `ws_bytes` bytes, of the FAULT WORD (uint32, zero in a healthy process): a
  * persistent launch whose bounded wait gave up (co-residency lost to another process) ORs its bit into it -- 1 encoder
  * forward (sf_encoder_lstm_fwd), 2 encoder backward, 4 speaker word loop (sf_speaker_decode), 8 device-wide lock not

@@ -131,6 +131,7 @@ _SIGNATURES = {
     'sf_build_id': (C.c_char_p, []),
     'sf_debug_persist_timeout': (None, [C.c_longlong]),
     'sf_debug_gate_product_f32': (None, [C.c_int]),
+    'sf_debug_tn_split_min_rows': (None, [C.c_int]),
     'sf_workspace_fault_offset': (C.c_size_t, [C.c_size_t]),
     'sf_debug_trace': (None, [C.c_void_p]),
     'sf_debug_force_write_through': (None, [C.c_int]),

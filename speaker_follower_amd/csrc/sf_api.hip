@@ -416,6 +416,7 @@ int sf_abi_version(void) { return SF_ABI_VERSION; }
 const char* sf_build_id(void) { static const char id[] = "SF_BUILD_ID=" SF_BUILD_ID; return id + 12; }
 void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; }
 void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
+void sf_debug_tn_split_min_rows(int rows) { sf::g_tn_split_min_rows = rows < 0 ? 4096 : rows; }
 size_t sf_workspace_fault_offset(size_t ws_bytes) {
     const size_t n = ws_bytes / 4;
     if (n <= SYNC_WORDS) return 0;

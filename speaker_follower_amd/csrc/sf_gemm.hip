@@ -24,6 +24,7 @@
 
 namespace sf {
 
+int g_tn_split_min_rows = 4096;   // sf_debug_tn_split_min_rows (tests run the split weight-gradient kernel on small shapes)
 int g_nt_force_f32 = 0;      // sf_debug_gate_product_f32: run the LSTM gate product on v_mfma_f32_16x16x4_f32 (round 1-3 kernel)
 
 namespace {
@@ -1300,6 +1301,138 @@ __global__ __launch_bounds__(256) void gemm_tn_tiled_kernel(TnArgs a) {
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// TN on the bf16 matrix cores (round 4): the weight gradients out[P,Q] (+)= Y[M,P]^T X[M,Q] as bf16x6 split products
+// (sf_split.h: fp32-class accuracy, 6/16 of the fp32-MFMA time).  v_mfma_f32_16x16x32_bf16 wants, per lane, EIGHT
+// consecutive values of the reduction index for one output row / column -- here eight different batch rows m of one
+// column of Y (or X): the operands are transposed on their way into LDS.
+//   block = 4 waves = 2 x 2 wave tiles of 64 x 64 -> 128 P-rows x 128 Q-cols; a stage = 64 batch rows.
+//   staging: a thread loads an 8 (m) x 4 (columns) patch of Y and of X (8 + 8 float4), splits each COLUMN's eight values
+//   into three bf16x8 pieces and stores each as one ds_write_b128 into plane[piece][column][m]: LDS rows = tile columns,
+//   64 m = 128 bytes, 16-byte chunks XOR-swizzled with (row >> 1) -- the lanes of every write and of every fragment
+//   read spread evenly over the eight chunk positions.  One stage buffer (96 KB: 2 operands x 3 planes x 16 KB, one
+//   workgroup per CU); the next stage's global loads are in flight in registers while the 192 MFMAs of a stage run.
+//   MEASURED (round 4): 3.8 us per stage where the MFMAs alone take 1.3 -- the split costs ~8 VALU operations per value
+//   and every element of Y is split again by each of the Q / 128 column blocks; with one wave per SIMD the split, the
+//   LDS traffic and the matrix pipe take turns.  It wins where the reduction is deep and the output small (the
+//   encoder's dW_hh over T*B = 8 000 rows: 196 -> 131 us) and loses on the decoder's dW_ih (320 -> 351 us), so the
+//   dispatch uses it for M >= 4096 only.  A variant that splits stage s+1 column by column between the MFMA groups
+//   of stage s (32-row stages, two LDS buffers, one barrier per stage) was built and is slower still (210 us on the
+//   encoder shape: 256 AGPRs, twice the barriers).  The next step is operands split ONCE (a pre-pass writing bf16
+//   planes [column][m]) so that the product kernel only copies.
+//   split-M over grid.z into slabs for small outputs (same reduce_slabs as the fp32 kernels: deterministic order).
+// ------------------------------------------------------------------------------------------------
+constexpr int TNS_B = 128, TNS_K = 64, TNS_ROWB = 128;
+constexpr int TNS_PLANE = TNS_B * TNS_ROWB;           // one piece plane of one operand: 16 KB
+constexpr int TNS_LDS = 2 * 3 * TNS_PLANE;
+
+__global__ __launch_bounds__(256, 1) void gemm_tn_split_kernel(TnArgs a) {
+    extern __shared__ __align__(16) unsigned char tns_smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int p0b = blockIdx.y * TNS_B, q0b = blockIdx.x * TNS_B;
+    if (a.msplit > 1) {    // row range of this split; its slab is a dense [P, Q] matrix
+        const int z = blockIdx.z;
+        const int m_lo = (int)(((long)z * a.M) / a.msplit), m_hi = (int)(((long)(z + 1) * a.M) / a.msplit);
+        a.Y += (size_t)m_lo * a.ldy;
+        a.X += (size_t)m_lo * a.ldx;
+        a.M = m_hi - m_lo;
+        a.out += (size_t)z * a.P * a.ldo;
+    }
+    const int mg = lane >> 3, cg = wave * 8 + (lane & 7);       // staging patch: rows 8 mg .. +7 of the stage, columns 4 cg .. +3
+    const int li = lane & 15, kk = lane >> 4;
+    const int stages = (a.M + TNS_K - 1) / TNS_K;
+    const float* yp = a.Y + p0b + 4 * cg;
+    const float* xp = a.X + q0b + 4 * cg;
+
+    f32x4 hi[4][4], lo[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hi[i][j] = lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    float4 ry[8], rx[8];
+    auto gload = [&](int st) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int m = min(st * TNS_K + 8 * mg + r, a.M - 1);  // clamped, not predicated
+            ry[r] = ld4(yp + (size_t)m * a.ldy);
+            rx[r] = ld4(xp + (size_t)m * a.ldx);
+        }
+    };
+    auto lstore = [&](int st) {
+        const int live = a.M - (st * TNS_K + 8 * mg);             // rows of this patch inside the batch
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const float z = r < live ? 1.f : 0.f;                 // rows beyond M contribute zeros
+            ry[r] = make_float4(ry[r].x * z, ry[r].y * z, ry[r].z * z, ry[r].w * z);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const int row = 4 * cg + c;
+            const int off = row * TNS_ROWB + ((mg ^ (row >> 1)) & 7) * 16;
+            const Split8 sy = split3_f8(make_float4(comp(ry[0], c), comp(ry[1], c), comp(ry[2], c), comp(ry[3], c)),
+                                        make_float4(comp(ry[4], c), comp(ry[5], c), comp(ry[6], c), comp(ry[7], c)));
+            const Split8 sx = split3_f8(make_float4(comp(rx[0], c), comp(rx[1], c), comp(rx[2], c), comp(rx[3], c)),
+                                        make_float4(comp(rx[4], c), comp(rx[5], c), comp(rx[6], c), comp(rx[7], c)));
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                *reinterpret_cast<bf16x8*>(tns_smem + pl * TNS_PLANE + off) = sy.p[pl];
+                *reinterpret_cast<bf16x8*>(tns_smem + (3 + pl) * TNS_PLANE + off) = sx.p[pl];
+            }
+        }
+    };
+
+    gload(0);
+    for (int st = 0; st < stages; ++st) {
+        lstore(st);
+        __syncthreads();
+        gload(min(st + 1, stages - 1));                           // in flight while this stage's MFMAs run
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            Split8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int rowa = wp * 64 + 16 * i + li, rowb = wq * 64 + 16 * i + li;
+                const int offa = rowa * TNS_ROWB + (((4 * ks + kk) ^ (rowa >> 1)) & 7) * 16;
+                const int offb = rowb * TNS_ROWB + (((4 * ks + kk) ^ (rowb >> 1)) & 7) * 16;
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl) {
+                    fa[i].p[pl] = *reinterpret_cast<const bf16x8*>(tns_smem + pl * TNS_PLANE + offa);
+                    fb[i].p[pl] = *reinterpret_cast<const bf16x8*>(tns_smem + (3 + pl) * TNS_PLANE + offb);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) mfma_split6(fa[i], fb[j], hi[i][j], lo[i][j]);
+        }
+        __syncthreads();
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // (the clamped prefetch of the last stage)
+
+    // D[row 4 kk + r][col li] of every 16 x 16 tile; a gradient tile is read-modified-written 16 values at a time
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float* orow = a.out + (size_t)(p0b + wp * 64 + 16 * i + 4 * kk) * a.ldo + q0b + wq * 64 + li;
+        float old[4][4];
+        if (a.accumulate) {                                       // block-uniform
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) old[j][r] = orow[(size_t)r * a.ldo + 16 * j];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v = hi[i][j][r] + lo[i][j][r];
+                if (a.accumulate) v += old[j][r];
+                orow[(size_t)r * a.ldo + 16 * j] = v;
+            }
+    }
+}
+
 int pick_ksplit(int waves_per_split, int chunks) {
     // aim for ~2 waves per SIMD over the chip (1024 SIMDs), at least 4 16-deep chunks per split,
     // and at most 8 partial slabs (each split costs one extra write + read of the output)
@@ -1657,6 +1790,31 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
     // A small weight matrix with a deep reduction (e.g. [256, 2176] over 2000 stacked rows) is a
     // handful of waves each walking all M rows: split the rows over grid.z into slabs and add them
     // up (deterministic order) until the chip is covered.
+    if (P % TNS_B == 0 && Q % TNS_B == 0 && M >= g_tn_split_min_rows && !g_nt_force_f32) {
+        // bf16x6 split products (gemm_tn_split_kernel) where they are faster: deep reductions (see the kernel's note)
+        const int blocks = (P / TNS_B) * (Q / TNS_B);
+        int ms = blocks >= 512 ? 1 : std::min(16, std::max(1, std::min(512 / blocks, M / 256)));
+        if (ms > 1 && (!ws || ws_floats < (size_t)ms * P * Q)) ms = 1;
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tn_split_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        dim3 grid(Q / TNS_B, P / TNS_B, ms);
+        if (ms > 1) {
+            TnArgs a{Y, ldy, X, ldx, M, P, Q, ws, Q, 0, ms};
+            SF_LAUNCH(gemm_tn_split_kernel, grid, dim3(256), TNS_LDS, st, a);
+            RedArgs r{};
+            r.slabs = ws; r.ks = ms; r.M = P; r.N = Q; r.y = out; r.ldy = ldo; r.epi = EPI_NONE;
+            r.accumulate = accumulate;
+            SF_LAUNCH(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
+            return launch_status();
+        }
+        TnArgs a{Y, ldy, X, ldx, M, P, Q, out, ldo, accumulate, 1};
+        SF_LAUNCH(gemm_tn_split_kernel, grid, dim3(256), TNS_LDS, st, a);
+        return launch_status();
+    }
     if (P >= 128 && Q >= 128 && ldy >= 128 && M >= 4096) {   // (measured: pays for the deep encoder reductions)
         // LDS-tiled kernel: 128 x 128 per block; small outputs split the batch rows into slabs
         const int blocks = ceil_div(Q, TNT_B) * ceil_div(P, TNT_B);

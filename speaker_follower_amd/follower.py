@@ -11,6 +11,7 @@
   entry points, accumulating weight gradients in place.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 
 import numpy as np
@@ -148,6 +149,7 @@ class FollowerEngine:
         # the eight small weight-gradient products on a third stream beside the two LSTM ones: measured no gain
         # (5.29 vs 5.26 ms per iteration): off
         self.split_wgrad_streams = False
+        self.encoder_backward_first = os.environ.get('SF_ENC_BWD_FIRST', '0') == '1'   # (experiment switch, see _backward)
         self.grad_sync = None            # dp.BucketedGrads(dp.follower_buckets(enc, dec)): all-reduce launched from the backward
         self._wgrad_stream = None
         # model.decoder_fold for no-grad eval rollouts (folded Linears + the folded paired schedule of
@@ -597,13 +599,9 @@ class FollowerEngine:
                     self._wgrad_stream = torch.cuda.Stream(device=dev)
                 third = self._wgrad_stream if self._wgrad_stream is not side else self._side_stream
                 third.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws_args(dev), sync,
-                                    part='lstm' if third is not None else 'all')
-            if third is not None:
-                with torch.cuda.stream(third):
-                    self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws_args(dev), sync, part='rest')
-        else:
+        if overlap and not self.encoder_backward_first:
+            self._issue_wgrad(side, third, dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, dev, sync)
+        elif not overlap:
             self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws, sync)
         if enc.num_directions == 2:
             if st.enc_graph is not None:         # the two directions' tapes: entered with the decoder's gradients
@@ -617,10 +615,21 @@ class FollowerEngine:
                  st.site0, *ws)
         if sync is not None:
             sync.launch(2)                       # encoder gradients: complete behind sf_encoder_lstm_bwd
+        if overlap and self.encoder_backward_first:
+            self._issue_wgrad(side, third, dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, dev, sync)
         if overlap:
             torch.cuda.current_stream().wait_stream(side)
             if third is not None:
                 torch.cuda.current_stream().wait_stream(third)
+
+    def _issue_wgrad(self, side, third, dw, dg, params, M, H, D, F, st, tp0, gt0, dev, sync):
+        """The decoder's weight gradients on the side stream(s) (which already wait for the backward through time)."""
+        with torch.cuda.stream(side):
+            self._decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws_args(dev), sync,
+                                part='lstm' if third is not None else 'all')
+        if third is not None:
+            with torch.cuda.stream(third):
+                self._decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws_args(dev), sync, part='rest')
 
     @staticmethod
     def _decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws, sync, part='all'):

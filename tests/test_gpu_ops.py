@@ -68,6 +68,35 @@ def test_linear_fwd_bwd(sf, M, N, K, act):
     np.testing.assert_allclose(db.cpu().numpy(), dpre.sum(0), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize('M,N,K', [(2000, 256, 2176), (300, 128, 128), (333, 256, 128), (8000, 2048, 512),
+                                   (2000, 2048, 4352), (257, 384, 256)])
+def test_weight_gradient_on_the_bf16_matrix_cores(sf, M, N, K):
+    """dW [N,K] += dY^T X through gemm_tn_split_kernel (bf16x6 split product, operands transposed on their way into
+    LDS; split-M slabs for small outputs; ragged last stage) against float64: accumulated INTO a non-zero dW, asymmetric
+    operands (a swapped fragment mapping or a wrong swizzle cannot pass), accuracy better than the fp32-MFMA kernel's."""
+    rng = np.random.default_rng(M + N + K)
+    x = rnd(rng, M, K) + (np.arange(K, dtype=np.float32) % 7)[None, :] * 0.1
+    dy = rnd(rng, M, N) * (1.0 + (np.arange(N, dtype=np.float32) % 5)[None, :])
+    w = rnd(rng, N, K, scale=K ** -0.5)
+    dw0 = rnd(rng, N, K)
+    ref = dw0.astype(np.float64) + dy.astype(np.float64).T @ x.astype(np.float64)
+    scale = float(np.abs(ref).max())
+    errs = {}
+    for f32_path in (0, 1):
+        sf.lib.lib.sf_debug_gate_product_f32(f32_path)
+        sf.lib.lib.sf_debug_tn_split_min_rows(256)          # (the dispatch uses the split kernel from 4 096 rows on)
+        try:
+            dw = dev(dw0.copy())
+            sf.ops.linear_bwd(dev(x), dev(w), None, dev(dy), 0, False, dw, None)
+            torch.cuda.synchronize()
+        finally:
+            sf.lib.lib.sf_debug_gate_product_f32(0)
+            sf.lib.lib.sf_debug_tn_split_min_rows(-1)
+        errs[f32_path] = float(np.abs(dw.cpu().numpy() - ref).max()) / scale
+    print('[wgrad %dx%dx%d] max error / scale: bf16x6 %.2e, fp32 MFMA %.2e' % (M, N, K, errs[0], errs[1]))
+    assert errs[0] <= 2e-6 and errs[0] <= 1.5 * errs[1] + 1e-7
+
+
 def test_gemm_is_transpose_safe(sf):
     """Asymmetric operands: catches a row/column swap in the MFMA fragment mapping."""
     M, N, K = 48, 80, 32
