@@ -20,7 +20,7 @@ import torch
 from . import _lib
 from ._lib import call
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
-from .runtime import ptr, stream, require_gpu, cands_dense, PersistentLaunchFault
+from .runtime import ptr, stream, require_gpu, cands_dense, PersistentLaunchFault, gc_paused
 
 byref = C.byref
 
@@ -438,6 +438,13 @@ class _SpeakerGlueFn(torch.autograd.Function):
         return dl[:, :V] * dnll.reshape(B, 1), None, None, None, None, None, None
 
 
+def _ragged(counts):
+    """[0..c0-1, 0..c1-1, ...] and the index of the owner of each element."""
+    owner = np.repeat(np.arange(len(counts)), counts)
+    starts = np.cumsum(counts) - counts
+    return np.arange(len(owner)) - starts[owner], owner
+
+
 class Seq2SeqSpeaker(object):
     """speaker.py:34-410 (teacher / argmax / sample decoding, scoring, train, save/load)."""
     feedback_options = ['teacher', 'argmax', 'sample']
@@ -488,57 +495,135 @@ class Seq2SeqSpeaker(object):
         feats = getattr(self.env, 'image_features_list', None) or [None]
         return getattr(feats[0], 'store', None) or getattr(self, 'store', None)
 
+    SCORE_CHUNK = 128          # rows of one persistent word-loop launch (csrc/sf_persist.hip)
+
+    @gc_paused
     def _score_on_device(self, path_obs, path_actions, encoded_instructions, feedback, store):
         """The same scoring over INDEX-FORM observations (no 'feature' / 'action_embedding' rows: an env that
         carries its feature store): the fused speaker engine (speaker.SpeakerEngine -- per path step visual
-        attention + LSTMCell with in-kernel gathers, the word loop as one persistent launch in inference), one
-        host sync for the whole batch.  Results in the layout of the host path below."""
+        attention + LSTMCell with in-kernel gathers, the word loop as one persistent launch in inference).  Results in
+        the layout of the host path below.
+
+        A large inference batch (the pragmatic re-ranking hands over ALL ~2 500 candidate routes of a minibatch at
+        once, rational_follower.py:67-69) is walked in chunks of SCORE_CHUNK rows, each one persistent launch: the
+        host packs chunk k + 1 while the device decodes chunk k, one download and one fault check at the end.  Rows
+        are independent; the loss (a mean over ALL rows per step, up to the first step at which every row has ended,
+        speaker.py:188-197) is re-assembled from the chunks' (sum, count) tables."""
         from . import speaker as spk, synth
+        from .runtime import take_fault, PersistentLaunchFault
+        import time
+        marks = getattr(self, 'score_marks', None)       # tools/pragmatic_profile.py: wall-clock marks of the phases
+        mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
+        mark('start')
         B = len(path_obs)
         n = np.array([len(a) for a in path_actions], np.int32)
-        Tp = int(n.max())
         # one row (vp_row, viewIndex, absViewIndex, rel_heading, rel_elevation, is_stop) per (observation, action) pair,
         # formed once per DISTINCT pair: the candidate routes of a search share their observation dictionaries
-        seen, rows, at = {}, [], []
-        for i, (obs, actions) in enumerate(zip(path_obs, path_actions)):
-            assert len(obs) == len(actions) + 1
-            for t, a in enumerate(actions):
-                ob = obs[t]
-                k = (id(ob), a)
-                r = seen.get(k)
-                if r is None:
-                    assert a >= 0
-                    if a > 0:
-                        d = ob['adj_loc_list'][a]
-                        r = (ob['vp_row'], ob['viewIndex'], d['absViewIndex'], d['rel_heading'], d['rel_elevation'], 0.0)
-                    else:
-                        r = (ob['vp_row'], ob['viewIndex'], 0, 0.0, 0.0, 1.0)
-                    seen[k] = r
-                rows.append(r)
-                at.append(t * B + i)
-        rows = np.array(rows, np.float64).reshape(-1, 6)
-        at = np.array(at, np.int64)
+        seen = {}
 
-        def grid(col, dt, fill=0):
-            out = np.full(Tp * B, fill, dt)
-            out[at] = rows[:, col]
-            return out.reshape(Tp, B)
-        sb = synth.SpeakerBatch(instr=list(encoded_instructions), path_len=n, vp=grid(0, np.int32), view=grid(1, np.int32),
-                                act_view=grid(2, np.int32), act_heading=grid(3, np.float64),
-                                act_elevation=grid(4, np.float64), act_is_stop=grid(5, np.float64, 1.0) != 0)
+        def pair_rows(lo, hi):                                        # [sum of n[lo:hi], 6], candidate-major
+            rows = []
+            for obs, actions in zip(path_obs[lo:hi], path_actions[lo:hi]):
+                assert len(obs) == len(actions) + 1
+                for t, a in enumerate(actions):
+                    ob = obs[t]
+                    k = (id(ob), a)
+                    r = seen.get(k)
+                    if r is None:
+                        assert a >= 0
+                        if a > 0:
+                            d = ob['adj_loc_list'][a]
+                            r = (ob['vp_row'], ob['viewIndex'], d['absViewIndex'], d['rel_heading'], d['rel_elevation'], 0.0)
+                        else:
+                            r = (ob['vp_row'], ob['viewIndex'], 0, 0.0, 0.0, 1.0)
+                        seen[k] = r
+                    rows.append(r)
+            return np.array(rows, np.float64).reshape(-1, 6)
         if getattr(self, '_engine', None) is None or self._engine.store is not store:
             self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
-        batch = spk.DeviceSpeakerBatch.from_synth(sb, device=store.device, max_length=self.instruction_len)
+        eng = self._engine
+        training = self.decoder.training
         S = self.instruction_len
         if feedback == 'teacher':
             # the reference's loop ends once every row has ended (speaker.py:199-200): with teacher forcing that is the
             # longest instruction's EOS -- steps behind it add nothing to any score or to the loss
             S = max(1, min(S, max(len(e_) for e_ in encoded_instructions) + 1))
-        st = self._engine.run(batch, S, feedback, train=self.decoder.training)   # (fault check + per-step re-issue inside)
-        both = torch.cat((st.words[1:].to(torch.float32), st.step_scores), dim=0).cpu().numpy()   # (the one host sync)
+
+        def index_batch(lo, hi):
+            m = n[lo:hi]
+            Tp, Bc = int(m.max()), hi - lo
+            t_of, owner = _ragged(m)
+            at = t_of * Bc + owner
+            part = pair_rows(lo, hi)                                  # (per chunk: formed while the device decodes the last one)
+
+            def grid(col, dt, fill=0):
+                out = np.full(Tp * Bc, fill, dt)
+                out[at] = part[:, col]
+                return out.reshape(Tp, Bc)
+            return synth.SpeakerBatch(instr=list(encoded_instructions[lo:hi]), path_len=m, vp=grid(0, np.int32),
+                                      view=grid(1, np.int32), act_view=grid(2, np.int32), act_heading=grid(3, np.float64),
+                                      act_elevation=grid(4, np.float64), act_is_stop=grid(5, np.float64, 1.0) != 0)
+
+        def batch_of(lo, hi):
+            return spk.DeviceSpeakerBatch.from_synth(index_batch(lo, hi), device=store.device,
+                                                     max_length=self.instruction_len, row0=lo)
+
+        def staged_batch(k, lo, hi):
+            """Chunk k through ONE pinned staging slice and ONE asynchronous H2D copy (a pageable `.to(device)` is a
+            blocking copy: it would wait for the previous chunk's launches and serialise host and device)."""
+            sb = index_batch(lo, hi)
+            Tp, Bc = sb.vp.shape
+            nbytes = spk.packed_layout(Bc, Tp, self.instruction_len)['bytes']
+            pin, dev_buf = self._staging(store.device, k, nbytes)
+            spk.pack_speaker_batch(sb, pin.numpy(), Lmax=self.instruction_len, Tp=Tp)
+            dev_buf[:nbytes].copy_(pin[:nbytes], non_blocking=True)
+            return spk.batch_from_packed(dev_buf, Bc, Tp, Lmax=self.instruction_len, row0=lo)
+
+        chunked = B > 2 * self.SCORE_CHUNK and not training and not torch.is_grad_enabled() and eng.group is None
+        if not chunked:
+            st = eng.run(batch_of(0, B), S, feedback, train=training)        # (fault check + per-step re-issue inside)
+            both = torch.cat((st.words[1:].to(torch.float32), st.step_scores), dim=0).cpu().numpy()  # (the one host sync)
+            loss = st.loss
+        else:
+            def sweep():
+                parts = []
+                for k, lo in enumerate(range(0, B, self.SCORE_CHUNK)):
+                    st = eng.score(staged_batch(k, lo, min(lo + self.SCORE_CHUNK, B)), S, feedback, train=False)
+                    parts.append((st.words[1:].to(torch.float32), st.step_scores, st.sum_cnt))
+                return parts
+            site = eng.site_next
+            parts = sweep()
+            mark('issued')
+            dev = store.device
+            bits = take_fault(dev)                                            # (one sync for the whole sweep)
+            mark('device done')
+            if bits:                                                          # a starved persistent launch: per-step kernels
+                eng.fallbacks += 1
+                keep, eng.persistent, eng.site_next = eng.persistent, False, site
+                try:
+                    parts = sweep()
+                finally:
+                    eng.persistent = keep
+                again = take_fault(dev)
+                if again:
+                    raise PersistentLaunchFault('fault bits %d, and %d after the per-step re-issue' % (bits, again))
+            both = torch.cat((torch.cat([p_[0] for p_ in parts], dim=1), torch.cat([p_[1] for p_ in parts], dim=1)),
+                             dim=0).cpu().numpy()
+            sum_cnt = torch.stack([p_[2] for p_ in parts]).sum(0).cpu().numpy()        # [S,2]: all rows
+            loss = None
+        mark('downloaded')
         words, sc = both[:S].T.astype(np.int64), np.ascontiguousarray(both[S:].T)                  # [B,S] each
         is_eos = words == EOS
         m_all = np.where(is_eos.any(1), is_eos.argmax(1) + 1, S)           # up to and including the first EOS
+        if loss is None:
+            # speaker.py:188-197 over the whole batch: step means up to and including the first step at which every row
+            # has produced EOS, summed in step order in float32 (what sf_speaker_loss_finalize does for one batch)
+            last = int(m_all.max()) - 1
+            total = np.float32(0)
+            for t in range(last + 1):
+                if sum_cnt[t, 1] > 0:
+                    total = np.float32(total + np.float32(sum_cnt[t, 0] / sum_cnt[t, 1]))
+            loss = torch.tensor(float(total), device=store.device)
         totals = np.cumsum(sc, axis=1, dtype=np.float32)                   # (sequential float32 partial sums)
         tok = getattr(self.env, 'tokenizer', None)
         outputs = []
@@ -548,9 +633,19 @@ class Seq2SeqSpeaker(object):
             outputs.append({'instr_id': path_obs[i][0]['instr_id'], 'word_indices': wi, 'scores': sc[i, :m].tolist(),
                             'score': float(totals[i, m - 1]),
                             'words': tok.decode_sentence(wi, break_on_eos=True, join=False) if tok is not None else wi})
-        # (the reference stops summing step losses once EVERY row has produced EOS, speaker.py:196: so does
-        # sf_speaker_loss_finalize, which st.loss comes from)
-        return outputs, st.loss
+        mark('outputs')
+        return outputs, loss
+
+    def _staging(self, device, k, nbytes):
+        """Pinned host / device staging buffers of chunk k of a chunked scoring pass (kept across calls; one pair per
+        chunk, so that a chunk's buffer is never rewritten while its copy or its kernels are in flight)."""
+        pool = self.__dict__.setdefault('_stage_pool', [])
+        while len(pool) <= k:
+            pool.append(None)
+        if pool[k] is None or pool[k][0].numel() < nbytes or pool[k][1].device != device:
+            cap = max(nbytes, 1 << 17)
+            pool[k] = (torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=device))
+        return pool[k]
 
     def _score_obs_actions_and_instructions(self, path_obs, path_actions, encoded_instructions,
                                             feedback):

@@ -399,7 +399,9 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
     spk.store = store
     follower.set_beam_size(k)
     e.reset_epoch()
+    spk.score_marks = []
     t_search, t_score, t_mix, n_cand = [], [], [], []
+    phases = {}
     for i in range(minibatches + 2):
         timed = i >= 2
         if timed and profiler is not None:
@@ -411,6 +413,7 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
         torch.cuda.synchronize()
         t1 = time.perf_counter()
         flat = search.flatten(cands)
+        del spk.score_marks[:]
         with torch.no_grad():
             spoken, _ = spk._score_obs_actions_and_instructions(
                 [c['observations'] for c in flat], [c['actions'] for c in flat], [c['instr_encoding'] for c in flat],
@@ -430,6 +433,8 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
             t_score.append(t2 - t1)
             t_mix.append(t3 - t2)
             n_cand.append(len(flat))
+            for (_, a_), (name, b_) in zip(spk.score_marks, spk.score_marks[1:]):
+                phases[name] = phases.get(name, 0.0) + (b_ - a_) / minibatches
     total = [a + b + c for a, b, c in zip(t_search, t_score, t_mix)]
     ms = lambda x: 1e3 * sum(x) / len(x)                                   # noqa: E731
     return dict(what='pragmatic inference per minibatch of %d instructions on the full world (90 scans): '
@@ -438,7 +443,8 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
                      % (instances, k, minibatches),
                 value=instances / (sum(total) / len(total)), unit='instructions/s', ms_per_minibatch=ms(total),
                 ms_best=1e3 * min(total), ms_worst=1e3 * max(total), ms_search=ms(t_search), ms_speaker_scoring=ms(t_score),
-                ms_rational_mix=ms(t_mix), candidates_per_minibatch=sum(n_cand) / len(n_cand))
+                ms_rational_mix=ms(t_mix), candidates_per_minibatch=sum(n_cand) / len(n_cand),
+                ms_speaker_scoring_phases={k_: round(1e3 * v, 2) for k_, v in phases.items()})
 
 
 def _synthetic_states(rng, n, n_vp, a_max=14):

@@ -23,30 +23,11 @@ repository's own form:
 Observation dictionaries (the reference's result format carries them: rational_follower.py:79-82 feeds them to
 the speaker) are materialised once per distinct state of the RETURNED candidates only.
 """
-import functools
-import gc
-
 import numpy as np
 import torch
 
 from .env import ANGLE_INC, WorldState
-
-
-def _gc_paused(fn):
-    """A search allocates ~10^5 small containers (hypothesis views, result dictionaries); every 700 of them the
-    cyclic collector would start walking the process' object graph -- with 90 parsed scans that is tens of
-    milliseconds a pass, several times the search itself.  Nothing the search builds is cyclic garbage: the
-    collector is paused for the duration and left as it was found."""
-    @functools.wraps(fn)
-    def run(*a, **k):
-        was = gc.isenabled()
-        gc.disable()
-        try:
-            return fn(*a, **k)
-        finally:
-            if was:
-                gc.enable()
-    return run
+from .runtime import gc_paused as _gc_paused
 
 V = 36
 F32 = np.float32

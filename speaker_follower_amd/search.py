@@ -35,7 +35,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, EOS, BOS
 from .model import decoder_params, decoder_w_struct, decoder_tape, tape_struct
-from .runtime import ptr, stream, ws_args
+from .runtime import ptr, stream, ws_args, gc_paused
 
 byref = C.byref
 
@@ -488,6 +488,7 @@ def speaker_beam_search(speaker, beam_size, path_obs, path_actions):
 
 
 # ------------------------------------------------------------------------------ pragmatic re-ranking
+@gc_paused
 def rational_mix(candidate_lists_by_instr_id, speaker_weight):
     """rational_follower.py:117-148: standardise follower and speaker scores over ALL candidates,
     pick per instruction the candidate maximising the weighted sum.  Returns (results, index counts)."""

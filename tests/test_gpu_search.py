@@ -359,7 +359,15 @@ def test_speaker_rescoring_of_all_candidates_at_once_equals_small_batches(world)
     assert len(flat) > 1100
     args = ([c['observations'] for c in flat], [c['actions'] for c in flat], [c['instr_encoding'] for c in flat])
     with torch.no_grad():
-        big, _ = speaker._score_obs_actions_and_instructions(*args, feedback='teacher')
+        big, loss_big = speaker._score_obs_actions_and_instructions(*args, feedback='teacher')     # chunks of 128 rows
+        type(speaker).SCORE_CHUNK, keep = 1 << 20, type(speaker).SCORE_CHUNK
+        try:                                                                                          # ONE batch of all rows
+            one, loss_one = speaker._score_obs_actions_and_instructions(*args, feedback='teacher')
+        finally:
+            type(speaker).SCORE_CHUNK = keep
+        assert abs(float(loss_big) - float(loss_one)) <= 1e-4 * abs(float(loss_one))
+        for a, b in zip(big, one):
+            assert a['word_indices'] == b['word_indices'] and abs(a['score'] - b['score']) <= 2e-4 * max(1.0, abs(b['score']))
         small = []
         for lo in range(0, len(flat), 100):
             out, _ = speaker._score_obs_actions_and_instructions(*(a[lo:lo + 100] for a in args), feedback='teacher')
