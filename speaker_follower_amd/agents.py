@@ -438,6 +438,15 @@ class _SpeakerGlueFn(torch.autograd.Function):
         return dl[:, :V] * dnll.reshape(B, 1), None, None, None, None, None, None
 
 
+class _PendingScores:
+    """A chunked scoring sweep that has been issued and not collected yet (Seq2SeqSpeaker._issue_scores)."""
+    obs_lists = None
+
+    def matches(self, path_obs, feedback):
+        return (self.obs_lists is not None and feedback == self.feedback and len(path_obs) == len(self.obs_lists)
+                and all(a is b for a, b in zip(path_obs, self.obs_lists)))
+
+
 def _ragged(counts):
     """[0..c0-1, 0..c1-1, ...] and the index of the owner of each element."""
     owner = np.repeat(np.arange(len(counts)), counts)
@@ -509,13 +518,19 @@ class Seq2SeqSpeaker(object):
         host packs chunk k + 1 while the device decodes chunk k, one download and one fault check at the end.  Rows
         are independent; the loss (a mean over ALL rows per step, up to the first step at which every row has ended,
         speaker.py:188-197) is re-assembled from the chunks' (sum, count) tables."""
-        from . import speaker as spk, synth
-        from .runtime import take_fault, PersistentLaunchFault
+        from . import speaker as spk
         import time
         marks = getattr(self, 'score_marks', None)       # tools/pragmatic_profile.py: wall-clock marks of the phases
         mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
         mark('start')
         B = len(path_obs)
+        instr_ids = [obs[0]['instr_id'] for obs in path_obs]
+        pend = self.__dict__.pop('_pending_scores', None)
+        if pend is not None:
+            if pend.matches(path_obs, feedback) and not torch.is_grad_enabled():   # issued by the search itself: collect
+                self.prefetch_hits = getattr(self, 'prefetch_hits', 0) + 1
+                return self._finish_scores(pend, instr_ids, mark)
+            torch.cuda.synchronize()                      # (not the routes it was issued for: let it drain, drop it)
         n = np.array([len(a) for a in path_actions], np.int32)
         # one row (vp_row, viewIndex, absViewIndex, rel_heading, rel_elevation, is_stop) per (observation, action) pair,
         # formed once per DISTINCT pair: the candidate routes of a search share their observation dictionaries
@@ -543,35 +558,58 @@ class Seq2SeqSpeaker(object):
             self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
         eng = self._engine
         training = self.decoder.training
+        chunked = B > 2 * self.SCORE_CHUNK and not training and not torch.is_grad_enabled() and eng.group is None
+        if chunked:          # (pairs per chunk: formed while the device decodes the previous one)
+            return self._finish_scores(self._issue_scores(n, pair_rows, encoded_instructions, feedback, store, mark),
+                                       instr_ids, mark)
+        S = self._score_steps(encoded_instructions, feedback)
+        batch = spk.DeviceSpeakerBatch.from_synth(self._index_batch(n, pair_rows, encoded_instructions, 0, B),
+                                                  device=store.device, max_length=self.instruction_len)
+        st = eng.run(batch, S, feedback, train=training)                   # (fault check + per-step re-issue inside)
+        both = torch.cat((st.words[1:].to(torch.float32), st.step_scores), dim=0).cpu().numpy()   # (the one host sync)
+        mark('downloaded')
+        return self._score_outputs(instr_ids, both, S, st.loss, None, store.device, mark)
+
+    def _score_steps(self, encoded_instructions, feedback):
         S = self.instruction_len
         if feedback == 'teacher':
             # the reference's loop ends once every row has ended (speaker.py:199-200): with teacher forcing that is the
             # longest instruction's EOS -- steps behind it add nothing to any score or to the loss
             S = max(1, min(S, max(len(e_) for e_ in encoded_instructions) + 1))
+        return S
 
-        def index_batch(lo, hi):
-            m = n[lo:hi]
-            Tp, Bc = int(m.max()), hi - lo
-            t_of, owner = _ragged(m)
-            at = t_of * Bc + owner
-            part = pair_rows(lo, hi)                                  # (per chunk: formed while the device decodes the last one)
+    @staticmethod
+    def _index_batch(n, rows_of, encoded_instructions, lo, hi):
+        """synth.SpeakerBatch (index form, speaker.py:68-121) of routes lo..hi-1: rows_of(lo, hi) = their [sum n, 6]
+        (vp_row, viewIndex, absViewIndex, rel_heading, rel_elevation, is_stop) rows, route-major."""
+        from . import synth
+        m = n[lo:hi]
+        Tp, Bc = int(m.max()), hi - lo
+        t_of, owner = _ragged(m)
+        at = t_of * Bc + owner
+        part = rows_of(lo, hi)
 
-            def grid(col, dt, fill=0):
-                out = np.full(Tp * Bc, fill, dt)
-                out[at] = part[:, col]
-                return out.reshape(Tp, Bc)
-            return synth.SpeakerBatch(instr=list(encoded_instructions[lo:hi]), path_len=m, vp=grid(0, np.int32),
-                                      view=grid(1, np.int32), act_view=grid(2, np.int32), act_heading=grid(3, np.float64),
-                                      act_elevation=grid(4, np.float64), act_is_stop=grid(5, np.float64, 1.0) != 0)
+        def grid(col, dt, fill=0):
+            out = np.full(Tp * Bc, fill, dt)
+            out[at] = part[:, col]
+            return out.reshape(Tp, Bc)
+        return synth.SpeakerBatch(instr=list(encoded_instructions[lo:hi]), path_len=m, vp=grid(0, np.int32),
+                                  view=grid(1, np.int32), act_view=grid(2, np.int32), act_heading=grid(3, np.float64),
+                                  act_elevation=grid(4, np.float64), act_is_stop=grid(5, np.float64, 1.0) != 0)
 
-        def batch_of(lo, hi):
-            return spk.DeviceSpeakerBatch.from_synth(index_batch(lo, hi), device=store.device,
-                                                     max_length=self.instruction_len, row0=lo)
+    def _issue_scores(self, n, rows_of, encoded_instructions, feedback, store, mark=lambda name: None):
+        """Issues the chunked scoring sweep (no host sync) and returns what _finish_scores needs to collect it."""
+        from . import speaker as spk
+        if getattr(self, '_engine', None) is None or self._engine.store is not store:
+            self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
+        eng = self._engine
+        B = len(n)
+        S = self._score_steps(encoded_instructions, feedback)
 
         def staged_batch(k, lo, hi):
             """Chunk k through ONE pinned staging slice and ONE asynchronous H2D copy (a pageable `.to(device)` is a
             blocking copy: it would wait for the previous chunk's launches and serialise host and device)."""
-            sb = index_batch(lo, hi)
+            sb = self._index_batch(n, rows_of, encoded_instructions, lo, hi)
             Tp, Bc = sb.vp.shape
             nbytes = spk.packed_layout(Bc, Tp, self.instruction_len)['bytes']
             pin, dev_buf = self._staging(store.device, k, nbytes)
@@ -579,39 +617,42 @@ class Seq2SeqSpeaker(object):
             dev_buf[:nbytes].copy_(pin[:nbytes], non_blocking=True)
             return spk.batch_from_packed(dev_buf, Bc, Tp, Lmax=self.instruction_len, row0=lo)
 
-        chunked = B > 2 * self.SCORE_CHUNK and not training and not torch.is_grad_enabled() and eng.group is None
-        if not chunked:
-            st = eng.run(batch_of(0, B), S, feedback, train=training)        # (fault check + per-step re-issue inside)
-            both = torch.cat((st.words[1:].to(torch.float32), st.step_scores), dim=0).cpu().numpy()  # (the one host sync)
-            loss = st.loss
-        else:
-            def sweep():
-                parts = []
-                for k, lo in enumerate(range(0, B, self.SCORE_CHUNK)):
-                    st = eng.score(staged_batch(k, lo, min(lo + self.SCORE_CHUNK, B)), S, feedback, train=False)
-                    parts.append((st.words[1:].to(torch.float32), st.step_scores, st.sum_cnt))
-                return parts
-            site = eng.site_next
-            parts = sweep()
-            mark('issued')
-            dev = store.device
-            bits = take_fault(dev)                                            # (one sync for the whole sweep)
-            mark('device done')
-            if bits:                                                          # a starved persistent launch: per-step kernels
-                eng.fallbacks += 1
-                keep, eng.persistent, eng.site_next = eng.persistent, False, site
-                try:
-                    parts = sweep()
-                finally:
-                    eng.persistent = keep
-                again = take_fault(dev)
-                if again:
-                    raise PersistentLaunchFault('fault bits %d, and %d after the per-step re-issue' % (bits, again))
-            both = torch.cat((torch.cat([p_[0] for p_ in parts], dim=1), torch.cat([p_[1] for p_ in parts], dim=1)),
-                             dim=0).cpu().numpy()
-            sum_cnt = torch.stack([p_[2] for p_ in parts]).sum(0).cpu().numpy()        # [S,2]: all rows
-            loss = None
+        def sweep():
+            parts = []
+            for k, lo in enumerate(range(0, B, self.SCORE_CHUNK)):
+                st = eng.score(staged_batch(k, lo, min(lo + self.SCORE_CHUNK, B)), S, feedback, train=False)
+                parts.append((st.words[1:].to(torch.float32), st.step_scores, st.sum_cnt))
+            return parts
+        pend = _PendingScores()
+        pend.B, pend.S, pend.feedback, pend.store, pend.sweep, pend.site = B, S, feedback, store, sweep, eng.site_next
+        pend.parts = sweep()
+        mark('issued')
+        return pend
+
+    def _finish_scores(self, pend, instr_ids, mark=lambda name: None):
+        from .runtime import take_fault
+        eng, dev = self._engine, pend.store.device
+        bits = take_fault(dev)                                                # (one sync for the whole sweep)
+        mark('device done')
+        parts = pend.parts
+        if bits:                                                              # a starved persistent launch: per-step kernels
+            eng.fallbacks += 1
+            keep, eng.persistent, eng.site_next = eng.persistent, False, pend.site
+            try:
+                parts = pend.sweep()
+            finally:
+                eng.persistent = keep
+            again = take_fault(dev)
+            if again:
+                raise PersistentLaunchFault('fault bits %d, and %d after the per-step re-issue' % (bits, again))
+        both = torch.cat((torch.cat([p_[0] for p_ in parts], dim=1), torch.cat([p_[1] for p_ in parts], dim=1)),
+                         dim=0).cpu().numpy()
+        sum_cnt = torch.stack([p_[2] for p_ in parts]).sum(0).cpu().numpy()            # [S,2]: all rows
         mark('downloaded')
+        return self._score_outputs(instr_ids, both, pend.S, None, sum_cnt, dev, mark)
+
+    def _score_outputs(self, instr_ids, both, S, loss, sum_cnt, device, mark=lambda name: None):
+        B = len(instr_ids)
         words, sc = both[:S].T.astype(np.int64), np.ascontiguousarray(both[S:].T)                  # [B,S] each
         is_eos = words == EOS
         m_all = np.where(is_eos.any(1), is_eos.argmax(1) + 1, S)           # up to and including the first EOS
@@ -623,18 +664,48 @@ class Seq2SeqSpeaker(object):
             for t in range(last + 1):
                 if sum_cnt[t, 1] > 0:
                     total = np.float32(total + np.float32(sum_cnt[t, 0] / sum_cnt[t, 1]))
-            loss = torch.tensor(float(total), device=store.device)
+            loss = torch.tensor(float(total), device=device)
         totals = np.cumsum(sc, axis=1, dtype=np.float32)                   # (sequential float32 partial sums)
         tok = getattr(self.env, 'tokenizer', None)
         outputs = []
         for i in range(B):
             m = int(m_all[i])
             wi = words[i, :m].tolist()
-            outputs.append({'instr_id': path_obs[i][0]['instr_id'], 'word_indices': wi, 'scores': sc[i, :m].tolist(),
+            outputs.append({'instr_id': instr_ids[i], 'word_indices': wi, 'scores': sc[i, :m].tolist(),
                             'score': float(totals[i, m - 1]),
                             'words': tok.decode_sentence(wi, break_on_eos=True, join=False) if tok is not None else wi})
         mark('outputs')
         return outputs, loss
+
+    def route_scores_hook(self, feedback='teacher'):
+        """For Seq2SeqAgent.candidates_hook (frontier.state_factored_search): the search hands over its completed routes
+        in index form -- n [routes] steps each, rows [sum n, 6], the instruction of every route -- the moment its last
+        iteration is done, BEFORE it builds their result dictionaries; the scoring sweep is issued right there, so the
+        device decodes while the host builds ~2 500 dictionaries.  The hook returns `bind`: called with the routes'
+        observation lists once they exist; the next _score_obs_actions_and_instructions over exactly those lists
+        collects the scores instead of issuing them again (rational_follower.py:67-69 is that call)."""
+        def hook(n, rows, instructions):
+            store = self._env_store()
+            if store is None or len(n) <= 2 * self.SCORE_CHUNK or self.decoder.training:
+                return None
+            stale = self.__dict__.pop('_pending_scores', None)
+            if stale is not None:
+                torch.cuda.synchronize()
+            from . import speaker as spk
+            if getattr(self, '_engine', None) is None or self._engine.store is not store:
+                self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
+            if self._engine.group is not None:
+                return None
+            first = np.concatenate(([0], np.cumsum(n)))
+            with torch.no_grad():       # (an inference sweep; a caller that wants gradients does not collect it)
+                pend = self._issue_scores(np.asarray(n, np.int32), lambda lo, hi: rows[first[lo]:first[hi]], instructions,
+                                          feedback, store)
+
+            def bind(obs_lists):
+                pend.obs_lists = list(obs_lists)
+                self._pending_scores = pend
+            return bind
+        return hook
 
     def _staging(self, device, k, nbytes):
         """Pinned host / device staging buffers of chunk k of a chunked scoring pass (kept across calls; one pair per

@@ -398,15 +398,18 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
     spk = agents.Seq2SeqSpeaker(e, '/tmp/sf_bench_pragmatic_speaker.json', senc, sdec, 80)
     spk.store = store
     follower.set_beam_size(k)
+    follower.candidates_hook = spk.route_scores_hook('teacher')           # (what search.run_rational_follower sets up)
     e.reset_epoch()
     spk.score_marks = []
+    follower.search_marks = []
     t_search, t_score, t_mix, n_cand = [], [], [], []
-    phases = {}
+    phases, sphases = {}, {}
     for i in range(minibatches + 2):
         timed = i >= 2
         if timed and profiler is not None:
             profiler.enable()
         torch.cuda.synchronize()
+        del follower.search_marks[:]
         t0 = time.perf_counter()
         with torch.no_grad():
             cands, hyps, walks = search._follower_candidates(follower, k, False, False, True, 4)
@@ -435,6 +438,8 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
             n_cand.append(len(flat))
             for (_, a_), (name, b_) in zip(spk.score_marks, spk.score_marks[1:]):
                 phases[name] = phases.get(name, 0.0) + (b_ - a_) / minibatches
+            for (_, a_), (name, b_) in zip(follower.search_marks, follower.search_marks[1:]):
+                sphases[name] = sphases.get(name, 0.0) + (b_ - a_) / minibatches
     total = [a + b + c for a, b, c in zip(t_search, t_score, t_mix)]
     ms = lambda x: 1e3 * sum(x) / len(x)                                   # noqa: E731
     return dict(what='pragmatic inference per minibatch of %d instructions on the full world (90 scans): '
@@ -444,6 +449,7 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
                 value=instances / (sum(total) / len(total)), unit='instructions/s', ms_per_minibatch=ms(total),
                 ms_best=1e3 * min(total), ms_worst=1e3 * max(total), ms_search=ms(t_search), ms_speaker_scoring=ms(t_score),
                 ms_rational_mix=ms(t_mix), candidates_per_minibatch=sum(n_cand) / len(n_cand),
+                ms_search_phases={k_: round(1e3 * v, 2) for k_, v in sphases.items()},
                 ms_speaker_scoring_phases={k_: round(1e3 * v, 2) for k_, v in phases.items()})
 
 

@@ -141,10 +141,30 @@ class StateSpace:
         """`observation` for arrays of any shape: an object array of the same shape, every distinct state built once."""
         code = (inst * (self.nav.n_rows * V) + sid) * 2 + start_pose
         uniq, first, inv = np.unique(code.reshape(-1), return_index=True, return_inverse=True)
-        fi, fs, fp = inst.reshape(-1)[first], sid.reshape(-1)[first], start_pose.reshape(-1)[first]
+        fi, fs, fp = (x.reshape(-1)[first].tolist() for x in (inst, sid, start_pose))
         objs = np.empty(len(uniq), object)
-        for j in range(len(uniq)):
-            objs[j] = self.observation(fi[j], fs[j], fp[j])
+        env, nav, items, cache, pano = self.env, self.nav, self.items, self._obs, self.env._pano
+        plain = env.host_table is None                              # index-form observations: the dictionary is built inline
+        for j, k in enumerate(zip(fi, fs, fp)):
+            ob = cache.get(k)
+            if ob is None and plain:
+                b, s, sp = k
+                it = items[b]
+                view = s % V
+                scan = it['scan']
+                if sp:
+                    vp, heading, elevation = it['path'][0], it['heading'], 0
+                else:
+                    vp, heading, elevation = nav.vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC
+                hit = pano.get((scan, vp, view))
+                if hit is None:                                     # the candidate list from the tables, not a sweep
+                    hit = pano[(scan, vp, view)] = (view, nav.adj_loc_list(s))
+                ob = cache[k] = dict(instr_id=it['instr_id'], scan=scan, viewpoint=vp, viewIndex=view, heading=heading,
+                                     elevation=elevation, adj_loc_list=hit[1], vp_row=env.row_of[scan + '_' + vp],
+                                     instr_encoding=it['instr_encoding'], instructions=it.get('instructions', ''))
+            elif ob is None:
+                ob = self.observation(*k)
+            objs[j] = ob
         return objs[inv].reshape(code.shape)
 
 
@@ -224,8 +244,12 @@ def _lineage_matrix(t, nodes, depth):
     return L, (L >= 0).sum(1)
 
 
-def _trajectories(fd, t, space, completed_lists, depth):
-    """Result dictionaries (follower.py:694-716 / 953-975) of the final hypotheses of every instance."""
+def _trajectories(fd, t, space, completed_lists, depth, hook=None):
+    """Result dictionaries (follower.py:694-716 / 953-975) of the final hypotheses of every instance.
+    `hook(n, rows, instructions)` (Seq2SeqSpeaker.route_scores_hook): called with the routes in index form -- per
+    route its number of steps, per step (feature row, view index, the action's view, rel_heading, rel_elevation,
+    is_stop), per route its instruction -- once the device is idle and BEFORE the dictionaries are built; what it
+    returns is called with the routes' observation lists when they exist."""
     flat = np.array([n for lst in completed_lists for n in lst], np.int64)
     L, ln = _lineage_matrix(t, flat, depth)
     # root first: column j of every row = the j-th hypothesis of the path (columns >= its length: junk, sliced off)
@@ -237,6 +261,19 @@ def _trajectories(fd, t, space, completed_lists, depth):
     att_rows[:] = fd.attention_rows(rows.tolist())
     att = np.empty(pool.shape, object)
     att[:, 1:][live[:, 1:]] = att_rows[inv]
+    bind = None
+    if hook is not None:
+        # step k of a route: the state of its k-th hypothesis, the action that led to the (k+1)-th
+        h = space.h
+        step = live[:, 1:]
+        sid_k, a_k = t.sid[L[:, :-1]][step], act[:, 1:][step]              # route-major
+        move = a_k > 0
+        a_c = np.where(move, a_k, 0)
+        rows = np.stack((h['feat_row'][sid_k // V], sid_k % V, np.where(move, h['cand_view'][sid_k, a_c], 0),
+                         np.where(move, h['heading'][sid_k, a_c], 0.0), np.where(move, h['elevation'][sid_k, a_c], 0.0),
+                         (~move).astype(np.float64)), axis=1).astype(np.float64)
+        items = space.items
+        bind = hook(ln - 1, rows, [items[b]['instr_encoding'] for b in t.inst[L[:, 0]].tolist()])
     all_obs = space.observations(t.inst[L], t.sid[L], t.start_pose[L])
     pose = np.empty(L.shape, object)
     uniq = {}
@@ -247,19 +284,25 @@ def _trajectories(fd, t, space, completed_lists, depth):
             p = uniq[id(ob)] = (ob['viewpoint'], ob['heading'], ob['elevation'])
         flat_pose[j] = p
     step_sc = sc[:, 1:] - sc[:, :-1]
+    # (whole matrices to nested Python lists ONCE; a candidate's fields are then plain list slices)
+    obs_l, pose_l, act_l, step_l, att_l = all_obs.tolist(), pose.tolist(), act.tolist(), step_sc.tolist(), att.tolist()
+    last_sc = sc[np.arange(len(flat)), ln - 1].tolist()
+    lens = ln.tolist()
     out, i = [], 0
     for lst in completed_lists:
         assert lst
         cands = []
         for _ in lst:
-            m = int(ln[i])
-            obs = all_obs[i, :m].tolist()
+            m = lens[i]
+            obs = obs_l[i][:m]
             cands.append({
                 'instr_id': obs[0]['instr_id'], 'instr_encoding': obs[0]['instr_encoding'],
-                'trajectory': pose[i, :m].tolist(), 'observations': obs, 'actions': act[i, 1:m].tolist(),
-                'score': float(sc[i, m - 1]), 'scores': step_sc[i, :m - 1].tolist(), 'attentions': att[i, 1:m].tolist()})
+                'trajectory': pose_l[i][:m], 'observations': obs, 'actions': act_l[i][1:m],
+                'score': last_sc[i], 'scores': step_l[i][:m - 1], 'attentions': att_l[i][1:m]})
             i += 1
         out.append(cands)
+    if bind is not None:
+        bind([c['observations'] for cands in out for c in cands])
     return out
 
 
@@ -432,6 +475,10 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
         return _state_factored_search_numpy(agent, completion_size, successor_size, load_next_minibatch, mask_undo,
                                             first_n_ws_key)
     from .sim import load_frontier
+    import time
+    marks = getattr(agent, 'search_marks', None)         # tools/pragmatic_profile.py: wall-clock marks of the phases
+    mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
+    mark('start')
     n_inst = getattr(agent.env, 'batch_size', None) or len(agent.env.batch)
     use_graph = getattr(agent, 'search_graph', True) and hasattr(agent.decoder, 'visual_attention_layer')
     cap = n_inst * successor_size
@@ -442,6 +489,7 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
                                          h['next_row'], h['cand_view'], h['a_num'], space.base_row, space.root_sid,
                                          space.root_key)
     block = fd.inputs if use_graph else np.zeros((8, cap), np.int32)
+    mark('setup')
     while True:
         if use_graph:
             base = fd.n
@@ -451,11 +499,15 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
             base, logp = fd.step_logprobs(_inputs_from_block(space, block, n))
         if core.advance(logp, base) == 0 or core.done():
             break
+    mark('iterations')
     t = Hypotheses.from_arrays(*core.hypotheses())
     completed, visits = core.results()
+    # (results first: a candidates_hook issues device work the rest of this function then runs beside)
+    trajs = _trajectories(fd, t, space, completed, agent.episode_len, getattr(agent, 'candidates_hook', None))
+    mark('results')
     traversed = [HypList(t, space, w) for w in physical_walks(t, visits, agent.episode_len)]
-    return (_trajectories(fd, t, space, completed, agent.episode_len), [HypList(t, space, lst) for lst in completed],
-            traversed)
+    mark('walks')
+    return trajs, [HypList(t, space, lst) for lst in completed], traversed
 
 
 def _state_factored_search_numpy(agent, completion_size, successor_size, load_next_minibatch=True, mask_undo=False,

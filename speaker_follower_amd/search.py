@@ -551,6 +551,11 @@ def run_rational_follower(envir, evaluator, follower, speaker, beam_size, includ
     for module in (follower.encoder, follower.decoder, speaker.encoder, speaker.decoder):
         module.eval()
     follower.set_beam_size(beam_size)
+    # the search hands its routes to the speaker in index form the moment its last iteration is done: the device scores
+    # them while the host builds their result dictionaries (a gold route in front of every list changes the batch: off)
+    follower.candidates_hook = (speaker.route_scores_hook('teacher')
+                                if state_factored_search and not include_gold and hasattr(speaker, 'route_scores_hook')
+                                else None)
     by_instruction = {}
     while True:                                         # one epoch: until an instruction comes round again
         cands, hyps, walks = _follower_candidates(follower, beam_size, include_gold, mask_undo, state_factored_search,
@@ -584,6 +589,7 @@ def run_rational_follower(envir, evaluator, follower, speaker, beam_size, includ
                 by_instruction[instr_id] = group
         if wrapped:
             break
+    follower.candidates_hook = None
     outcome, picks = {}, {}
     for w in speaker_weights:
         chosen, picks[w] = rational_mix(by_instruction, w)

@@ -378,3 +378,40 @@ def test_speaker_rescoring_of_all_candidates_at_once_equals_small_batches(world)
         assert a['word_indices'] == b['word_indices'] == ([int(x) for x in c['instr_encoding']] + [2])[:W.INSTRUCTION_LEN]
         assert abs(a['score'] - b['score']) <= 2e-4 * max(1.0, abs(b['score']))
         np.testing.assert_allclose(a['scores'], b['scores'], rtol=0, atol=2e-4)
+
+
+def test_rational_follower_with_scores_issued_by_the_search_equals_the_plain_pipeline(world):
+    """search.run_rational_follower hands the search's routes to the speaker in index form before their result
+    dictionaries exist (Seq2SeqSpeaker.route_scores_hook): the scores collected by the later
+    _score_obs_actions_and_instructions call equal those of the plain call over the dictionaries, route for route."""
+    from speaker_follower_amd import search, agents, features
+    _, dense_agent, dense_speaker = world
+    env, table = W.build_world(dense=False)                    # index-form observations: the speaker scores on the device
+    store = features.FeatureStore(table)
+    agent = agents.Seq2SeqAgent(env, '/tmp/sf_search_ix.json', dense_agent.encoder, dense_agent.decoder,
+                                episode_len=W.EPISODE_LEN)
+    agent.store = store
+    speaker = agents.Seq2SeqSpeaker(env, '/tmp/sf_search_ix_spk.json', dense_speaker.encoder, dense_speaker.decoder,
+                                    W.INSTRUCTION_LEN, max_episode_len=W.EPISODE_LEN)
+    speaker.store = store
+    cls = type(speaker)
+    keep = cls.SCORE_CHUNK
+    try:
+        cls.SCORE_CHUNK = 16                                   # (the fixture yields ~100 routes per minibatch)
+        speaker.prefetch_hits = 0
+        res_a, cnt_a = search.run_rational_follower(env, None, agent, speaker, beam_size=20, state_factored_search=True)
+        assert speaker.prefetch_hits >= 1 and agent.candidates_hook is None
+        cls.SCORE_CHUNK = 1 << 20                              # no chunks, no hook: one engine batch over the dictionaries
+        speaker.prefetch_hits = 0
+        res_b, cnt_b = search.run_rational_follower(env, None, agent, speaker, beam_size=20, state_factored_search=True)
+        assert speaker.prefetch_hits == 0
+    finally:
+        cls.SCORE_CHUNK = keep
+    assert cnt_a == cnt_b
+    for w in res_a:
+        assert set(res_a[w]) == set(res_b[w])
+        for k in res_a[w]:
+            a, b = res_a[w][k], res_b[w][k]
+            assert a['actions'] == b['actions'] and a['trajectory'] == b['trajectory']
+            assert abs(a['speaker_score'] - b['speaker_score']) <= 2e-4 * max(1.0, abs(b['speaker_score']))
+            assert a['follower_score'] == b['follower_score']
