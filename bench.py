@@ -630,7 +630,9 @@ def main(argv=None):
         # the full training iteration of configs[1] -- student-forcing rollout (dropout on), BPTT, two
         # Adam steps -- on the same batch (it updates the weights, so it runs last)
         if not args.no_train_extra:
-            out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2)
+            # (ten timed iterations behind five warm-up ones: the extra in front of it ends with host-bound work,
+            # during which the device clocks fall)
+            out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(10, args.steps // 2), 5)
     # (the host-only baseline comes LAST: seconds of CPU work let the GPU clocks fall, and the extras above were
     # measured with a warm device)
     if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only

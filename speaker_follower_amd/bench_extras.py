@@ -286,6 +286,12 @@ def full_world(store, batch=100, seed=21, n_items=None):
         _FULL_WORLD[('nav', id(store))] = (graphs, nt)
         e._nav_table = (store, nt, tuple(sorted(e.graphs)))        # what nav.table_for(e, store) hands the search
         _FULL_WORLD[key] = (e, nt)
+        # The world is ~10^6 long-lived Python objects (90 parsed graphs, the items): moved out of the cyclic
+        # collector's sight, or every later full collection walks them -- milliseconds added to whatever host-bound
+        # measurement it happens to interrupt (what a long-running training / evaluation process does once after set-up)
+        import gc
+        gc.collect()
+        gc.freeze()
     return _FULL_WORLD[key]
 
 
@@ -444,8 +450,10 @@ def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches
     ms = lambda x: 1e3 * sum(x) / len(x)                                   # noqa: E731
     return dict(what='pragmatic inference per minibatch of %d instructions on the full world (90 scans): '
                      'state_factored_search(K=%d, 1) + speaker teacher-forced scoring of every candidate route (one batch '
-                     'of all of them) + rational_mix, through the agents\' API; mean over %d distinct minibatches'
-                     % (instances, k, minibatches),
+                     'of all of them) + rational_mix, through the agents\' API as search.run_rational_follower drives them (the '
+                     'search hands its routes to the speaker in index form before it builds their result dictionaries: '
+                     'ms_search includes issuing the scoring sweep, ms_speaker_scoring is what is left to collect); mean '
+                     'over %d distinct minibatches' % (instances, k, minibatches),
                 value=instances / (sum(total) / len(total)), unit='instructions/s', ms_per_minibatch=ms(total),
                 ms_best=1e3 * min(total), ms_worst=1e3 * max(total), ms_search=ms(t_search), ms_speaker_scoring=ms(t_score),
                 ms_rational_mix=ms(t_mix), candidates_per_minibatch=sum(n_cand) / len(n_cand),

@@ -22,7 +22,7 @@ from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, trainable_embedding)
-from .runtime import ptr, stream, ws_args, dropout_arg, take_fault, PersistentLaunchFault
+from .runtime import ptr, stream, ws_args, dropout_arg, take_fault, PersistentLaunchFault, concurrent_stream
 
 byref = C.byref
 
@@ -288,7 +288,7 @@ class FollowerEngine:
             ep.side_stream = None
             if self.two_stream_forward and fold is None:
                 if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(device=dev)
+                    self._side_stream = concurrent_stream(dev)
                 ep.side_stream = self._side_stream.cuda_stream
             call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
             st.episode = (ep, dw)
@@ -531,7 +531,7 @@ class FollowerEngine:
             # visual backward of step t (not under stream capture: eager issue only)
             if self.two_stream_backward and not torch.cuda.is_current_stream_capturing():
                 if self._side_stream is None:
-                    self._side_stream = torch.cuda.Stream(device=dev)
+                    self._side_stream = concurrent_stream(dev)
                 ep.side_stream = self._side_stream.cuda_stream
             else:
                 ep.side_stream = None
@@ -547,7 +547,7 @@ class FollowerEngine:
             tp_at = lambda t: _lib.DecoderTape(*(st.tape[k][t:].data_ptr() for k in _TAPE_KEYS))          # noqa: E731
             gt_at = lambda t: _lib.DecoderGTape(*(gt[k][t:].data_ptr() for k in gkeys), None, None, None)  # noqa: E731
             if overlap_w and self._wgrad_stream is None:
-                self._wgrad_stream = torch.cuda.Stream(device=dev)
+                self._wgrad_stream = concurrent_stream(dev, exclude=[x for x in (self._side_stream,) if x is not None])
             st.wgrad_done_from = S                   # steps >= this have their weight gradients issued
             for k in range(n_chunks - 1, -1, -1):
                 lo, hi = bounds[k], bounds[k + 1]
@@ -589,14 +589,14 @@ class FollowerEngine:
         if overlap:
             side = self._wgrad_stream if (st.episode is not None and Sw < S) else self._side_stream
             if side is None:
-                side = self._side_stream = torch.cuda.Stream(device=dev)
+                side = self._side_stream = concurrent_stream(dev)
             side.wait_stream(torch.cuda.current_stream())
             third = None
             if self.split_wgrad_streams:
                 # the eight small products (25 TFLOP/s between them) beside the two LSTM ones (dW_ih alone fills the chip
                 # at 0.76 of the matrix peak) instead of behind them: two streams, same accumulation targets
                 if self._wgrad_stream is None:
-                    self._wgrad_stream = torch.cuda.Stream(device=dev)
+                    self._wgrad_stream = concurrent_stream(dev, exclude=[x for x in (self._side_stream,) if x is not None])
                 third = self._wgrad_stream if self._wgrad_stream is not side else self._side_stream
                 third.wait_stream(torch.cuda.current_stream())
         if overlap and not self.encoder_backward_first:

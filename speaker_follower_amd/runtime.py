@@ -36,6 +36,52 @@ def gc_paused(fn):
     return run
 
 
+_concurrent = {}
+
+
+def concurrent_stream(device, exclude=()):
+    """A torch stream whose kernels really run BESIDE the current stream's.
+
+    HIP multiplexes streams onto a handful of hardware queues; two streams that land on the same queue execute in
+    order, whatever the program says.  Measured on MI355X (tools/stream_queue_probe.py): the training iteration takes
+    5.05-5.17 ms with the backward's side stream on most pool streams and 5.63 ms on one of them -- which one an engine
+    gets depends on how many streams the process created before.  So a candidate is PROBED: a spin kernel on the
+    current stream and one on the candidate, started together; if the pair takes much more than one of them, the
+    candidate shares the queue and the next pool stream is tried.  Once per (device, current stream), ~2 ms."""
+    import time
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(device)
+    key = (idx, cur.cuda_stream)
+    found = _concurrent.setdefault(key, [])
+    for s in found:
+        if not any(s is x for x in exclude):
+            return s
+    if not hasattr(torch.cuda, '_sleep') or torch.cuda.is_current_stream_capturing():
+        return torch.cuda.Stream(device=device)
+    spin = 400000                                       # ~0.2 ms of device cycles
+
+    def timed(streams):
+        torch.cuda.synchronize(device)
+        t0 = time.perf_counter()
+        for st in streams:
+            with torch.cuda.stream(st):
+                torch.cuda._sleep(spin)
+        torch.cuda.synchronize(device)
+        return time.perf_counter() - t0
+    timed([cur])                                         # (first launch of the spin kernel)
+    one = min(timed([cur]) for _ in range(2))
+    cand = None
+    for _ in range(8):
+        cand = torch.cuda.Stream(device=device)
+        if any(cand is x or cand.cuda_stream == getattr(x, 'cuda_stream', None) for x in list(exclude) + found):
+            continue
+        timed([cur, cand])
+        if min(timed([cur, cand]) for _ in range(2)) < 1.5 * one:
+            found.append(cand)
+            return cand
+    return cand                                          # (none ran concurrently: e.g. one hardware queue)
+
+
 def require_gpu(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
