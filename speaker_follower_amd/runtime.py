@@ -52,10 +52,10 @@ def concurrent_stream(device, exclude=()):
     idx = device.index if device.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(device)
     key = (idx, cur.cuda_stream)
-    found = _concurrent.setdefault(key, [])
-    for s in found:
-        if not any(s is x for x in exclude):
-            return s
+    exclude = [x for x in exclude if x is not None]
+    found = _concurrent.setdefault((key, tuple(x.cuda_stream for x in exclude)), [])
+    if found:
+        return found[0]
     if not hasattr(torch.cuda, '_sleep') or torch.cuda.is_current_stream_capturing():
         return torch.cuda.Stream(device=device)
     spin = 400000                                       # ~0.2 ms of device cycles
@@ -73,10 +73,11 @@ def concurrent_stream(device, exclude=()):
     cand = None
     for _ in range(8):
         cand = torch.cuda.Stream(device=device)
-        if any(cand is x or cand.cuda_stream == getattr(x, 'cuda_stream', None) for x in list(exclude) + found):
+        if any(cand.cuda_stream == x.cuda_stream for x in exclude):
             continue
-        timed([cur, cand])
-        if min(timed([cur, cand]) for _ in range(2)) < 1.5 * one:
+        group = [cur] + exclude + [cand]                 # (concurrent with the current stream AND with the excluded ones)
+        timed(group)
+        if min(timed(group) for _ in range(2)) < 1.5 * one:
             found.append(cand)
             return cand
     return cand                                          # (none ran concurrently: e.g. one hardware queue)
