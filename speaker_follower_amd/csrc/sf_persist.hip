@@ -789,9 +789,10 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
         }
         if (eu < SP_TPMAX)
             xstore32(local, EP_SENTINEL, rs, (bn + SPX_PS + (unsigned)((slot * EP_ROWS + er) * SP_TPMAX + eu)) * 4u);
-        // statistics rows: phase H of step t-1 has no workgroup barrier behind it, and what this wave has
-        // seen (the partial scores of rows [4w, 4w+4) from all 32 slots) proves only that WAVE w of every
-        // workgroup is past it -- those waves are the only readers of rows [4w, 4w+4) of this block
+        // statistics rows: what this wave has seen (the partial scores of rows [4w, 4w+4) from all 32 slots) proves
+        // only that WAVE w of every workgroup is past phase H of step t-1 -- those waves are the only readers of rows
+        // [4w, 4w+4) of this block, so each wave resets exactly the rows its own evidence covers (the end-of-step
+        // __syncthreads orders the waves of ONE workgroup, not the other workgroups' readers)
         if (lane < 4) {
             xstore(local, v4u{EP_SENTINEL, EP_SENTINEL, EP_SENTINEL, EP_SENTINEL}, rs,
                    (bn + SPX_ST + (unsigned)((slot * EP_ROWS + 4 * w + lane) * 4)) * 4u);

@@ -244,7 +244,7 @@ def _lineage_matrix(t, nodes, depth):
     return L, (L >= 0).sum(1)
 
 
-def _trajectories(fd, t, space, completed_lists, depth, hook=None):
+def _trajectories(fd, t, space, completed_lists, depth, hook=None, fp32_steps=False):
     """Result dictionaries (follower.py:694-716 / 953-975) of the final hypotheses of every instance.
     `hook(n, rows, instructions)` (Seq2SeqSpeaker.route_scores_hook): called with the routes in index form -- per
     route its number of steps, per step (feature row, view index, the action's view, rel_heading, rel_elevation,
@@ -283,7 +283,10 @@ def _trajectories(fd, t, space, completed_lists, depth, hook=None):
         if p is None:
             p = uniq[id(ob)] = (ob['viewpoint'], ob['heading'], ob['elevation'])
         flat_pose[j] = p
-    step_sc = sc[:, 1:] - sc[:, :-1]
+    # per-action scores = differences of the cumulative ones: the reference's beam search holds them as Python floats
+    # (follower.py:636: float64 differences of fp32-rounded sums), its state-factored search as fp32 tensors
+    # (follower.py:851, :46: the difference is rounded to fp32)
+    step_sc = (t.score[L][:, 1:] - t.score[L][:, :-1]).astype(np.float64) if fp32_steps else sc[:, 1:] - sc[:, :-1]
     # (whole matrices to nested Python lists ONCE; a candidate's fields are then plain list slices)
     obs_l, pose_l, act_l, step_l, att_l = all_obs.tolist(), pose.tolist(), act.tolist(), step_sc.tolist(), att.tolist()
     last_sc = sc[np.arange(len(flat)), ln - 1].tolist()
@@ -503,7 +506,8 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
     t = Hypotheses.from_arrays(*core.hypotheses())
     completed, visits = core.results()
     # (results first: a candidates_hook issues device work the rest of this function then runs beside)
-    trajs = _trajectories(fd, t, space, completed, agent.episode_len, getattr(agent, 'candidates_hook', None))
+    trajs = _trajectories(fd, t, space, completed, agent.episode_len, getattr(agent, 'candidates_hook', None),
+                          fp32_steps=True)
     mark('results')
     traversed = [HypList(t, space, w) for w in physical_walks(t, visits, agent.episode_len)]
     mark('walks')
@@ -615,7 +619,8 @@ def _state_factored_search_numpy(agent, completion_size, successor_size, load_ne
         completed.append([nodes[i] for i in np.lexsort((np.arange(len(nodes)), -sc))[:completion_size]])
         visits[b].extend(completed[b])
     traversed = [HypList(t, space, w) for w in physical_walks(t, visits, episode_len)]
-    return (_trajectories(fd, t, space, completed, episode_len), [HypList(t, space, lst) for lst in completed], traversed)
+    return (_trajectories(fd, t, space, completed, episode_len, fp32_steps=True),
+            [HypList(t, space, lst) for lst in completed], traversed)
 
 
 def physical_walks(t, visits, depth):

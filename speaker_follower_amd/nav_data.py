@@ -40,7 +40,11 @@ def connectivity_dir(path=GEOMETRY, scans=None, out_dir=None):
     if out_dir is None:
         h = hashlib.sha1(open(path, 'rb').read()).hexdigest()[:12]
         out_dir = os.path.join(tempfile.gettempdir(), 'sf_connectivity_%s_%d' % (h, os.getuid()))
-    os.makedirs(out_dir, exist_ok=True)
+    os.makedirs(out_dir, mode=0o700, exist_ok=True)
+    st = os.stat(out_dir)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+        # a predictable path under a shared temp directory: contents are trusted only if the directory is ours alone
+        raise RuntimeError('%s is not owned by this user or is writable by others; remove it or pass out_dir' % out_dir)
     names = list(geo) if scans is None else list(scans)
     for s in names:
         f = os.path.join(out_dir, s + '_connectivity.json')
@@ -57,8 +61,12 @@ def connectivity_dir(path=GEOMETRY, scans=None, out_dir=None):
         with open(tmp, 'w') as fh:
             fh.write('[' + ',\n'.join(rows) + ']')
         os.replace(tmp, f)                      # atomic: concurrent ranks may build the same cache
-    with open(os.path.join(out_dir, 'scans.txt'), 'w') as fh:
-        fh.write('\n'.join(names) + '\n')
+    # scans.txt lists what the directory HOLDS (the union over all callers), written atomically
+    present = sorted(f[:-len('_connectivity.json')] for f in os.listdir(out_dir) if f.endswith('_connectivity.json'))
+    tmp = os.path.join(out_dir, 'scans.txt.tmp%d' % os.getpid())
+    with open(tmp, 'w') as fh:
+        fh.write('\n'.join(present) + '\n')
+    os.replace(tmp, os.path.join(out_dir, 'scans.txt'))
     return out_dir
 
 
