@@ -23,21 +23,27 @@ for i in range(N):
         same = torch.equal(st.actions, a0) and torch.equal(torch.nan_to_num(st.logits, neginf=0.), torch.nan_to_num(l0, neginf=0.)) and torch.equal(st.loss_buf, loss0)
         bad += 0 if same else 1
 print('replays %d: %s' % (N, 'bit-identical' if bad == 0 else '%d mismatching checks' % bad))
-# the persistent decode loop (opt-in): repeated launches must reproduce the per-stage actions and never time out
-engp = follower.FollowerEngine(enc, dec, store); engp.persistent_decode = True
-M = int(os.environ.get('PERSISTENT', 300))
-badp = 0
+# the state-factored search on its production path (one hipGraph replay + one native bookkeeping call per iteration, pools
+# and graph kept on the agent): the same minibatch searched again and again must return the same candidates
+from speaker_follower_amd import agents, bench_extras
+M = int(os.environ.get('SEARCHES', 60))
+store_full = features.FeatureStore(bench.device_table(10567, 1234, dev), device=dev)
+e64, _ = bench_extras.full_world(store_full, 64, seed=15)
+agent = agents.Seq2SeqAgent(e64, '/tmp/sf_soak_search.json', enc, dec, episode_len=8)
+agent.store = store_full
+e64.set_beam_size(40)
+first, bads = None, 0
 t0 = time.time()
 with torch.no_grad():
     for i in range(M):
-        sp = engp.rollout(batch, 20, 'argmax', train=False)
-        if i % 25 == 24:
-            torch.cuda.synchronize()
-            ok = sp.persistent and torch.equal(sp.actions, a0) and not torch.isnan(sp.h).any()
-            badp += 0 if ok else 1
-torch.cuda.synchronize()
-print('persistent decode %d rollouts in %.2f s: %s' % (M, time.time() - t0, 'actions identical to the per-stage path' if badp == 0 else '%d bad checks' % badp))
-assert badp == 0
+        e64.reset_epoch()
+        trajs, _, walks = agent.state_factored_search(40, 1)
+        rec = [[(c['actions'], c['score']) for c in cands] for cands in trajs], [w.nodes for w in walks]
+        if first is None:
+            first = rec
+        bads += 0 if rec == first else 1
+print('state-factored search x %d in %.2f s: %s' % (M, time.time() - t0, 'identical every time' if bads == 0 else '%d differ' % bads))
+assert bads == 0
 enc.train(); dec.train()
 pe = [p for p in enc.parameters() if p.requires_grad]; pd = [p for p in dec.parameters() if p.requires_grad]
 flat = dp.FlatGrads(pe + pd)
