@@ -370,3 +370,96 @@ def test_speaker_loss_finalize_for_any_batch_size(B):
     _lib.call('sf_speaker_loss_finalize', ptr(d_sc), ptr(d_w), EOS, T, B, ptr(loss), ptr(gscale), cur())
     torch.cuda.synchronize()
     assert int((gscale.cpu().numpy() > 0).sum()) == T - 1       # (every step but the one without live rows)
+
+
+def _index_world():
+    """Index-form env + agents over the search fixture graphs (the speaker scores on the device)."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import search_world as W
+    from speaker_follower_amd import model, features, agents
+    env, table = W.build_world(dense=False)
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights(W.FOLLOWER_SEED)
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    senc_w, sdec_w = synth.speaker_weights(W.SPEAKER_SEED)
+    senc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    sdec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'])
+    senc.load_state_dict({k: torch.tensor(v) for k, v in senc_w.items()})
+    sdec.load_state_dict({k: torch.tensor(v) for k, v in sdec_w.items()})
+    for m in (enc, dec, senc, sdec):
+        m.cuda().eval()
+    store = features.FeatureStore(table)
+    agent = agents.Seq2SeqAgent(env, '/tmp/sf_rob_agent.json', enc, dec, episode_len=W.EPISODE_LEN)
+    agent.store = store
+    speaker = agents.Seq2SeqSpeaker(env, '/tmp/sf_rob_speaker.json', senc, sdec, W.INSTRUCTION_LEN,
+                                    max_episode_len=W.EPISODE_LEN)
+    speaker.store = store
+    env.set_beam_size(20)
+    return env, agent, speaker
+
+
+def _routes(agent, env):
+    from speaker_follower_amd import search
+    env.reset_epoch()
+    with torch.no_grad():
+        cands, _, _ = agent.state_factored_search(20, 1)
+    flat = search.flatten(cands)
+    return [c['observations'] for c in flat], [c['actions'] for c in flat], [c['instr_encoding'] for c in flat]
+
+
+def test_scores_issued_for_other_routes_are_not_collected():
+    """Seq2SeqSpeaker.route_scores_hook issued a sweep for the search's routes; a scoring call over DIFFERENT observation
+    lists (here: the same routes in another order, as new list objects) must not collect it -- it drops the pending
+    sweep and scores what it was given."""
+    env, agent, speaker = _index_world()
+    cls = type(speaker)
+    keep = cls.SCORE_CHUNK
+    try:
+        cls.SCORE_CHUNK = 16
+        agent.candidates_hook = speaker.route_scores_hook('teacher')
+        obs, acts, instr = _routes(agent, env)
+        assert getattr(speaker, '_pending_scores', None) is not None and len(obs) > 40
+        order = list(range(len(obs)))[::-1]
+        speaker.prefetch_hits = 0
+        with torch.no_grad():
+            out, _ = speaker._score_obs_actions_and_instructions([list(obs[i]) for i in order], [acts[i] for i in order],
+                                                                  [instr[i] for i in order], feedback='teacher')
+        assert speaker.prefetch_hits == 0 and getattr(speaker, '_pending_scores', None) is None
+        agent.candidates_hook = None
+        with torch.no_grad():
+            ref, _ = speaker._score_obs_actions_and_instructions(obs, acts, instr, feedback='teacher')
+        for k, i in enumerate(order):
+            assert out[k]['instr_id'] == ref[i]['instr_id'] and out[k]['word_indices'] == ref[i]['word_indices']
+            assert abs(out[k]['score'] - ref[i]['score']) <= 2e-4 * max(1.0, abs(ref[i]['score']))
+    finally:
+        cls.SCORE_CHUNK = keep
+
+
+def test_chunked_route_scoring_survives_starved_persistent_launches(forced_timeout):
+    """Every persistent word-loop launch of a chunked scoring sweep gives up its first wait (forced): the fault word is
+    read once at the end of the sweep and the whole sweep re-issued on the per-step kernels -- same scores as a healthy
+    run, `fallbacks` counted."""
+    from speaker_follower_amd import _lib
+    env, agent, speaker = _index_world()
+    _lib.lib.sf_debug_persist_timeout(-1)                     # (a healthy search and a healthy reference first)
+    obs, acts, instr = _routes(agent, env)
+    cls = type(speaker)
+    keep = cls.SCORE_CHUNK
+    try:
+        cls.SCORE_CHUNK = 16
+        with torch.no_grad():
+            ref, _ = speaker._score_obs_actions_and_instructions(obs, acts, instr, feedback='teacher')
+        assert speaker._engine.fallbacks == 0
+        _lib.lib.sf_debug_persist_timeout(0)
+        with torch.no_grad():
+            out, _ = speaker._score_obs_actions_and_instructions(obs, acts, instr, feedback='teacher')
+        assert speaker._engine.fallbacks == 1
+    finally:
+        cls.SCORE_CHUNK = keep
+    for a, b in zip(out, ref):
+        assert a['word_indices'] == b['word_indices'] and np.isfinite(a['score'])
+        assert abs(a['score'] - b['score']) <= 2e-4 * max(1.0, abs(b['score']))
