@@ -348,6 +348,10 @@ def roofline_table(prof_rows, n_rollouts, B, S, T, A_mean, dims, pmc):
             if '%.2f' in what:
                 what = what % (6.0 * fl / (r['avg_us'] * 1e-6) / 2.5e15)
                 row['what'] = what
+                # the same launch priced as what it EXECUTES: 6 bf16 MFMA products per fp32 product, dense bf16 peak
+                row['executed'] = dict(dtype='bf16 (3-way error-free split of fp32 operands, fp32 accumulate)',
+                                       tflops=6.0 * fl / (r['avg_us'] * 1e-6) / 1e12, peak=2500.0,
+                                       frac=6.0 * fl / (r['avg_us'] * 1e-6) / 2.5e15)
             tf = fl / (r['avg_us'] * 1e-6) / 1e12
             gbs = by / (r['avg_us'] * 1e-6) / 1e9
             row.update(flops_per_launch=fl, bytes_per_launch=by, tflops=tf, mfma_frac=tf / PEAK_TFLOPS_F32_MFMA,
@@ -579,6 +583,7 @@ def main(argv=None):
         launch_us=top['avg_us'], flops_per_launch=top['flops_per_launch'],
         bytes_per_launch=top['bytes_per_launch'],
         mfma_frac=top['mfma_frac'], hbm_frac=top['hbm_frac'],
+        executed=top.get('executed'),
         kernels=kernels[:8],
         kernel_time_ms_per_rollout=1e-3 * kernel_us / n_prof,
         rollout=dict(flops_frac=AGENT_STEP_FLOPS * B * S / (ms_rollout * 1e-3) / 1e12 / PEAK_TFLOPS_F32_MFMA,
