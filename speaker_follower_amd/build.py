@@ -119,12 +119,16 @@ def build_sim(force=False, verbose=True):
         out = os.path.join(sim, name + ext)
         srcs = [os.path.join(sim, f) for f in files]
         deps = srcs + [os.path.join(sim, 'mattersim_nav.hpp')]
-        if force or not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(d) for d in deps):
-            cmd = ['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden',
-                   '-I' + pybind11.get_include(), '-I' + sysconfig.get_paths()['include']] + srcs + ['-o', out]
+        gxx = ['g++', '-O2', '-std=c++17', '-shared', '-fPIC', '-fvisibility=hidden']
+        want = _digest(deps, ' '.join(gxx) + ext)                  # staleness by content, like the HIP library
+        side = out + '.sha'
+        if force or not os.path.exists(out) or not os.path.exists(side) or open(side).read().strip() != want:
+            cmd = gxx + ['-I' + pybind11.get_include(), '-I' + sysconfig.get_paths()['include']] + srcs + ['-o', out]
             res = subprocess.run(cmd, capture_output=True, text=True)
             if res.returncode != 0:
                 raise RuntimeError('%s build failed:\n%s\n%s' % (name, res.stdout, res.stderr))
+            with open(side, 'w') as f:
+                f.write(want)
             if verbose:
                 print('%s module rebuilt (%d bytes)' % (name, os.path.getsize(out)))
         outs.append(out)
