@@ -371,6 +371,10 @@ int sf_attn_decoder_wgrad(const sf_decoder_w* w, const sf_decoder_g* g, int M, i
  * glue.u_next / ld_u_next / u_drop / u_drop_stream / sample_stream are ignored: u_next of step t
  * always goes, through the next step's input dropout, into tape.xin of step t+1.
  * fwd  = sf_attn_decoder_head_fwd(0) then S x sf_attn_decoder_tail_fwd, with no host work between.
+ *        glue.nav != NULL (sf_nav_io of STEP 0 of a device-resident environment, state buffers stacked
+ *        [S + 1][...]): per step sf_attn_decoder_tail_fwd with tape_next but no X_next -- the environment steps
+ *        inside its scoring + glue launch -- followed by sf_attn_decoder_attend_fwd over the panorama just chosen
+ *        (needs w->visual.w_v_t, no folded weights).
  * bwd  = per step t = S-1..0: sf_follower_glue_bwd (gscale[t]) + sf_attn_decoder_bwd (g = NULL, dY
  *        operands into the stacked gtape), ping-ponging (dh, dc) between the two buffer pairs;
  *        *result_in_b tells which pair holds d h_init / d c_init; dctx [B,L,H] is ADDED to.

@@ -980,6 +980,22 @@ StepView step_view(const sf_follower_episode* e, int t) {
     return v;
 }
 
+// step t of a device-resident environment: state slot t -> slot t + 1 of the stacked [S + 1][...] buffers
+sf_nav_io nav_view(const sf_nav_io* n, const sf_follower_episode* e, int t) {
+    const size_t B = e->B, A = e->A;
+    sf_nav_io v = *n;
+    v.row = adv(n->row, t * B);
+    v.view = adv(n->view, t * B);
+    v.row_next = adv(n->row_next, t * B);
+    v.vp_next = adv(n->vp_next, t * B);
+    v.view_next = adv(n->view_next, t * B);
+    v.a_num_next = adv(n->a_num_next, t * B);
+    v.cand_view_next = adv(n->cand_view_next, t * B * A);
+    v.sincos_next = adv(n->sincos_next, t * B * A * 4);
+    v.target_next = adv(n->target_next, t * B);
+    return v;
+}
+
 sf_decoder_gtape gtape_view(const sf_decoder_gtape* g, const sf_follower_episode* e, int t) {
     const size_t B = e->B, H = e->H, D = e->D, F = e->X.IMG + e->X.LOC;
     sf_decoder_gtape v;
@@ -1011,6 +1027,29 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
     StepView cur = step_view(e, 0);
     TRY(decoder_head_i(w, &cur.X, e->B, e->H, e->D, e->h_init, &cur.tp, drop, e->step0, ws, ws_bytes,
                        stream));
+    if (e->glue.nav) {
+        // A device-resident environment (sf_nav_io of step 0 in glue.nav; state buffers stacked [S + 1][...]): the
+        // panorama of step t + 1 is only known once the glue of step t has chosen its action and stepped the
+        // environment (inside the scoring + glue launch), so its attention cannot ride beside tail(t); its QUERY can
+        // (tape_next without X_next), and the attention follows as its own launch -- the schedule the host loop of
+        // FollowerEngine.rollout issues call by call, here without host work between the launches.
+        SF_CHECK_ARG(!w->fold && w->visual.w_v_t);
+        for (int t = 0; t < e->S; ++t) {
+            const bool more = t + 1 < e->S;
+            StepView nxt = more ? step_view(e, t + 1) : cur;
+            const sf_nav_io nv = nav_view(e->glue.nav, e, t);
+            cur.glue.nav = &nv;
+            const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
+            const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
+            TRY(decoder_tail_i(w, &cur.U, e->B, e->H, e->D, e->L, nullptr, h0, c0, e->ctx, e->ctx_mask,
+                               nullptr, &cur.tp, &cur.glue, drop, e->step0 + t, nullptr, more ? &nxt.tp : nullptr, ws,
+                               ws_bytes, stream));
+            if (more)
+                TRY(sf_attn_decoder_attend_fwd(&nxt.X, e->B, &nxt.tp, drop, e->step0 + t + 1, ws, ws_bytes, stream));
+            cur = nxt;
+        }
+        return SF_OK;
+    }
     if (e->side_stream && e->side_stream != stream && !w->fold && e->S > 1) {
         // Two chains, ONE fork and ONE join per episode, ordered per step by device flags
         // (flag_wait / flag_set kernels) instead of events:

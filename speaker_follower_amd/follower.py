@@ -269,7 +269,12 @@ class FollowerEngine:
             batch.advance(-1)                           # slot 0 = the initial observation
         pipelined = self.pipelined and not on_device_env
         st.episode = None
-        if pipelined and self.episode_call:
+        # the same one-call episode for a device-resident environment (the env step inside every scoring + glue launch,
+        # the attention of step t + 1 behind it): no host work between the launches of a TRAINING rollout either, and
+        # the backward takes the two-stream episode path
+        nav_episode = (on_device_env and self.pipelined and self.episode_call and self.fused_env_step and fold is None
+                       and bool(dw.visual.w_v_t))
+        if (pipelined or nav_episode) and self.episode_call:
             # every per-step tensor is a stacked [S][...] array: hand step 0 to the library once
             ep = _lib.FollowerEpisode()
             ep.S, ep.B, ep.H, ep.D, ep.L, ep.A = S, B, H, D, T, A
@@ -286,7 +291,10 @@ class FollowerEngine:
             ep.drop = d_dec
             ep.step0 = st.site0
             ep.side_stream = None
-            if self.two_stream_forward and fold is None:
+            if nav_episode:
+                st.navio0 = batch.fused_step(0)               # (sf_nav_io of step 0; the library strides it per step)
+                ep.glue.nav = C.cast(C.pointer(st.navio0), C.c_void_p)
+            if self.two_stream_forward and fold is None and not nav_episode:
                 if self._side_stream is None:
                     self._side_stream = concurrent_stream(dev)
                 ep.side_stream = self._side_stream.cuda_stream
@@ -298,7 +306,7 @@ class FollowerEngine:
         if pipelined and not st.episode:
             call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
                  byref(tapes[0]), d_ptr, st.site0, *ws)
-        deferred = on_device_env and self.pipelined and fold is None and dw.visual.w_v_t
+        deferred = on_device_env and self.pipelined and fold is None and dw.visual.w_v_t and not st.episode
         if deferred:
             call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
                  byref(tapes[0]), d_ptr, st.site0, *ws)

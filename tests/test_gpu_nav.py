@@ -100,22 +100,25 @@ def test_device_rollout_equals_the_per_step_host_loop(world, feedback):
 
 @pytest.mark.parametrize('feedback', ['argmax', 'sample'])
 def test_env_step_schedules_agree_bit_for_bit(world, feedback):
-    """The three schedules of a device-environment rollout -- attention of step t+1 deferred behind the env step
-    with the env step inside the scoring + glue launch (default), the same with a separate sf_nav_step launch,
-    and the plain per-step order -- produce identical states, actions and logits."""
+    """The schedules of a device-environment rollout -- the whole decode loop as ONE library call
+    (sf_follower_episode_fwd with glue.nav: default), the same launches issued call by call from the host loop
+    (attention of step t+1 deferred behind the env step, the env step inside the scoring + glue launch), the same
+    with a separate sf_nav_step launch, and the plain per-step order -- produce identical states, actions and
+    logits."""
     from speaker_follower_amd import follower, nav
     env, agent, store, nt, enc, dec = world
     env.reset_epoch()
     items = list(env.batch)
     outs = []
-    for fused, pipelined in ((True, True), (False, True), (False, False)):
+    for fused, pipelined, episode in ((True, True, True), (True, True, False), (False, True, True), (False, False, True)):
         eng = follower.FollowerEngine(enc, dec, store)
         eng.dropout_seed, eng.site_next = 12345, 1
-        eng.fused_env_step, eng.pipelined = fused, pipelined
+        eng.fused_env_step, eng.pipelined, eng.episode_call = fused, pipelined, episode
         navb = nav.DeviceNavBatch(nt, items, EPISODE)
         with torch.no_grad():
             st = eng.rollout(navb, EPISODE, feedback, train=False)
         torch.cuda.synchronize()
+        assert (st.episode is not None) == (fused and pipelined and episode)
         outs.append((st.actions.clone(), st.logits.clone(), navb.row.clone(), navb.view.clone(), navb.target.clone(),
                      navb.cand_view.clone(), navb.sincos.clone(), st.loss.clone()))
     for other in outs[1:]:
