@@ -623,6 +623,7 @@ def main(argv=None):
         from speaker_follower_amd import bench_extras
         out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2], one batch
         out['speaker_sweep'] = bench_extras.speaker_sweep(store, device)            # configs[2]: all 178 300 paths, measured
+        out['speaker_train_iteration'] = bench_extras.speaker_train_iteration(store, device)   # a13, the speaker's half
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):

@@ -514,6 +514,9 @@ typedef struct sf_spk_decoder_w {
     /* SF_SPK_EMB_DROPOUT: the embedding is trainable (glove=None): model.py:499-500 applies dropout to the embedded
      * word in train mode -- site 2*step_id of `drop`; needs tape->emb and xw_table == NULL. */
     int32_t flags;
+    /* optional, backward only: decoder2action^T as [H, ldv] (ldv = vocab rounded up to 4, padding columns zero): the
+     * gradient wrt h~ = dlogit W_out becomes a K-contiguous product (NULL: the strided NN kernel, 26 us instead of 7). */
+    const float* w_out_t;
 } sf_spk_decoder_w;
 #define SF_SPK_EMB_DROPOUT 1
 /* embedding (optional): gradient of embedding.weight [vocab,E], accumulated: row prev_word[b] += mask x (dgates W_ih)
@@ -572,6 +575,37 @@ int sf_speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos
                              float* gscale, sf_stream stream);
 int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int pad_idx, const float* gscale, float* dlogit, sf_stream stream);
+
+/* ---- the speaker's word loop with its tape, in one call each way (speaker.py:158-197 forward, the backward
+ * `loss.backward()` of speaker.py:385 walks) -- what a TRAINING iteration runs (sf_speaker_decode keeps no tape):
+ * fwd = for t in 0..S-1: sf_speaker_decoder_fwd(words[t], state t-1 -> tape[t], dropout / sampling site step0 + t) then
+ *       sf_speaker_glue_fwd(tape[t].logit, targets[t] -> words[t+1], step_scores[t], nll_term[t], live[t]);
+ * bwd = for t in S-1..0: sf_speaker_glue_bwd(gscale[t]) then sf_speaker_decoder_bwd, ping-ponging (dh, dc) between the
+ *       two buffer pairs; *result_in_b tells which pair holds d h_init / d c_init; dctx [B,Tp,H] is ADDED to.
+ * `tape0` holds the pointers of STEP 0 of stacked [S][B][..] tensors (emb may be NULL when nothing will run
+ * backward); words [S+1,B] (row 0 = start tokens), targets / step_scores / nll_term / live [S,B], gscale [S].
+ * gtape != NULL (needs h0_all [S,B,H]: every step's incoming hidden state, i.e. h_init followed by tape h1 of steps
+ * 0..S-2 in ONE array): per step only the DATA gradients are formed and the dY operands kept in the stacked gtape;
+ * every weight gradient of `g` is then ONE product over all S*B rows at the end (reduction depth 8 000 instead of
+ * 80 products of depth 100 each) -- the follower's scheme (sf_attn_decoder_wgrad).  A trainable embedding
+ * (g->embedding) still scatters per step.  dlogit [B,ldv] is scratch and may be NULL with a gtape. */
+typedef struct sf_spk_decoder_gtape {
+    float *dlogit;   /* [S,B,ldv] */
+    float *dpre;     /* [S,B,H]  d(pre-tanh) of attention.linear_out */
+    float *dt_text;  /* [S,B,H]  d(linear_in output) */
+    float *dgates;   /* [S,B,4H] pre-activation gate gradients */
+} sf_spk_decoder_gtape;
+int sf_speaker_words_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab, int S, int feedback,
+                         int pad_idx, int eos_idx, const int64_t* targets, const float* h_init, const float* c_init,
+                         const float* ctx, const uint8_t* ctx_mask, int64_t* words, uint8_t* ended, float* step_scores,
+                         float* nll_term, float* live, const sf_spk_decoder_tape* tape0, const sf_dropout* drop,
+                         uint32_t step0, const sf_sample* sample, void* ws, size_t ws_bytes, sf_stream stream);
+int sf_speaker_words_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H, int Tp, int vocab,
+                         int S, int pad_idx, const int64_t* words, const int64_t* targets, const float* h_init,
+                         const float* c_init, const float* ctx, const sf_spk_decoder_tape* tape0, const float* gscale,
+                         float* dlogit, float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
+                         int* result_in_b, const sf_dropout* drop, uint32_t step0, const sf_spk_decoder_gtape* gtape,
+                         const float* h0_all, void* ws, size_t ws_bytes, sf_stream stream);
 
 /* ---- search helpers (follower.py:541-980 beam / state-factored search, speaker.py:211-318) ------
  * dst[i, :width] = src[idx[i], :width] (idx < 0 => zeros): `h_t[flat_indices]`, `c_t[flat_indices]`

@@ -95,11 +95,16 @@ EncoderTape = _ptr_struct('EncoderTape', ['emb', 'xg', 'gates', 'hs', 'cs'])
 
 class SpkDecoderW(C.Structure):
     _fields_ = [('embedding', c_p), ('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p),
-                ('b_out', c_p), ('xw_table', c_p), ('flags', C.c_int32)]
+                ('b_out', c_p), ('xw_table', c_p), ('flags', C.c_int32), ('w_out_t', c_p)]
 
 
 class SpkDecoderG(C.Structure):
     _fields_ = [('lstm', LstmW), ('attn', SoftdotW), ('w_out', c_p), ('b_out', c_p), ('embedding', c_p)]
+
+
+class SpkDecoderGTape(C.Structure):
+    """sf_spk_decoder_gtape: stacked [S][B][..] dY operands of the speaker's word-loop backward."""
+    _fields_ = [(n, C.c_void_p) for n in ('dlogit', 'dpre', 'dt_text', 'dgates')]
 
 
 class Sample(C.Structure):
@@ -203,6 +208,11 @@ _SIGNATURES = {
                                       c_f, P(Sample), c_p]),
     'sf_speaker_loss_finalize': (C.c_int, [c_f, i64p, i32, i32, i32, c_f, c_f, c_p]),
     'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),
+    'sf_speaker_words_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i32, i32, i32, i32, i64p, c_f, c_f, c_f,
+                                       c_p, i64p, c_p, c_f, c_f, c_f, P(SpkDecoderTape), P(Dropout), u32, P(Sample)] + WS),
+    'sf_speaker_words_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32, i32, i32, i64p, i64p, c_f,
+                                       c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, c_f, c_f, c_f, P(C.c_int),
+                                       P(Dropout), u32, P(SpkDecoderGTape), c_f] + WS),
     'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
     'sf_add_f32': (C.c_int, [c_f, c_f, C.c_size_t, c_p]),
     'sf_adam_step': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,

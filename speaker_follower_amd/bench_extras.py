@@ -389,6 +389,45 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
 
 
 @_guard
+def speaker_train_iteration(store, device, batch=100, words=80, iters=10):
+    """The speaker's training iteration (speaker.py:376-395 + train_speaker.py:28-31): teacher-forced scoring of a
+    minibatch of `batch` paths x `words` words with dropout, backward, two Adam steps -- the word loop and its backward as
+    one library call each (sf_speaker_words_fwd / _bwd), weight gradients as one product over all S*B rows."""
+    from . import synth, speaker, optim, dp
+    senc, sdec = _speaker_models(device)
+    senc.train()
+    sdec.train()
+    n_vp = store.table.shape[0]
+    sb = synth.speaker_batch(seed=0, batch=batch, n_viewpoints=n_vp, min_path=4, max_path=7, min_len=10, max_len=79)
+    b = speaker.DeviceSpeakerBatch.from_synth(sb, device=device)
+    pe = [p for p in senc.parameters() if p.requires_grad]
+    pd = [p for p in sdec.parameters() if p.requires_grad]
+    flat = dp.FlatGrads(pe + pd)
+    oe, od = optim.FusedAdam(pe, lr=1e-4, weight_decay=5e-4), optim.FusedAdam(pd, lr=1e-4, weight_decay=5e-4)
+    eng = speaker.SpeakerEngine(senc, sdec, store)
+
+    def it():
+        flat.zero()
+        st = eng.score(b, words, 'teacher', train=True)
+        st.loss.backward()
+        oe.step()
+        od.step()
+        return st
+    for _ in range(3):
+        it()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        st = it()
+    host = (time.perf_counter() - t0) / iters
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    return dict(what='speaker training iteration: %d paths x %d words, teacher forcing, dropout 0.5, BPTT, 2x Adam; eager issue'
+                     % (batch, words), value=batch * words / dt, unit='word-steps/s', ms_per_iteration=1e3 * dt,
+                ms_host_issue=1e3 * host, loss=float(st.loss.detach()))
+
+
+@_guard
 def pragmatic_inference(enc, dec, store, device, instances=64, k=40, minibatches=6, profiler=None):
     """BASELINE configs[4] END TO END through the agents' API on the full world, per minibatch of `instances`
     instructions (rational_follower.py:35-148): Seq2SeqAgent.state_factored_search(K, 1), the speaker's teacher-forced

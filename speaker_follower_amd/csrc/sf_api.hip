@@ -1541,6 +1541,20 @@ int sf_speaker_decode(const sf_spk_decoder_w* w, int B, int H, int Tp, int vocab
                               c1_tape, ended, xchg, ar.tickets() + PERSIST_TICKET, st, sample);
 }
 
+// d h~ = dlogit W_out (dlogit [B,ldv] with zero padding columns): K-contiguous through decoder2action^T when the host
+// keeps it (sf_spk_decoder_w.w_out_t [H,ldv]), else the strided NN kernel
+static int spk_dlogit_to_dht(const sf_spk_decoder_w* w, const float* dlogit, int ldv, int B, int H, int vocab, float* dht,
+                             Arena& ar, hipStream_t st) {
+    if (w->w_out_t) {
+        Seg sg{dlogit, ldv, w->w_out_t, ldv, ldv};
+        LinearOut o{};
+        o.y = dht; o.ldy = H; o.epi = EPI_NONE;
+        const int rc = linear_nt(&sg, 1, B, H, o, ar.rest(), ar.rest_n(), st);
+        if (rc != SF_ERR_UNSUPPORTED) return rc;
+    }
+    return gemm_nn_ws(dlogit, ldv, w->w_out, H, B, H, vocab, dht, H, 0, ar.rest(), ar.rest_n(), st);
+}
+
 int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H,
                            int Tp, int vocab, const int64_t* prev_word, const float* h0, const float* c0, const float* ctx,
                            const sf_spk_decoder_tape* tp, const float* dlogit, const float* dh1,
@@ -1558,7 +1572,7 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
     float* dh1m = ar.take((size_t)B * H);
     NEED(dht && dh1d && dh1m);
     // dlogit [B,ldv] has zeros in its padding columns
-    TRY(gemm_nn_ws(dlogit, ldv, w->w_out, H, B, H, vocab, dht, H, 0, ar.rest(), ar.rest_n(), st));
+    TRY(spk_dlogit_to_dht(w, dlogit, ldv, B, H, vocab, dht, ar, st));
     if (g && g->w_out) TRY(gemm_tn(dlogit, ldv, tp->h_tilde, H, B, vocab, H, g->w_out, H, 1, st, ar.rest(), ar.rest_n()));
     if (g && g->b_out) TRY(colsum(dlogit, ldv, B, vocab, g->b_out, 1, st, nullptr, ar.rest(), ar.rest_n()));
     TRY(softdot_bwd_i(&w->attn, g ? &g->attn : nullptr, B, Tp, H, ctx, tp->alpha, tp->cat2,
@@ -1586,6 +1600,127 @@ int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int
                  vocab > 0 && ldv >= vocab && feedback >= 0 && feedback <= 2 && (feedback != 2 || sample));
     return speaker_glue_fwd(B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t,
                             score, nll_term, live, S(stream), sample);
+}
+
+// ---- the speaker's word loop with its tape, one call each way (speaker.py:158-197 and its backward) ------------------
+namespace {
+sf_spk_decoder_tape spk_tape_view(const sf_spk_decoder_tape* p, int t, int B, int E, int H, int Tp, int ldv) {
+    sf_spk_decoder_tape v;
+    const size_t n = (size_t)t * B;
+    v.emb = adv(p->emb, n * E);
+    v.gates = adv(p->gates, n * 4 * H);
+    v.c1 = adv(p->c1, n * H);
+    v.h1 = adv(p->h1, n * H);
+    v.cat2 = adv(p->cat2, n * 2 * H);
+    v.t_text = adv(p->t_text, n * H);
+    v.alpha = adv(p->alpha, n * Tp);
+    v.h_tilde = adv(p->h_tilde, n * H);
+    v.logit = adv(p->logit, n * ldv);
+    return v;
+}
+}  // namespace
+
+int sf_speaker_words_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab, int S, int feedback,
+                         int pad_idx, int eos_idx, const int64_t* targets, const float* h_init, const float* c_init,
+                         const float* ctx, const uint8_t* ctx_mask, int64_t* words, uint8_t* ended, float* step_scores,
+                         float* nll_term, float* live, const sf_spk_decoder_tape* tape0, const sf_dropout* drop,
+                         uint32_t step0, const sf_sample* sample, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && tape0 && tape0->h1 && tape0->c1 && tape0->logit && targets && h_init && c_init && ctx && words &&
+                 ended && step_scores && nll_term && live && B > 0 && S > 0 && (feedback != 2 || sample));
+    const int ldv = (vocab + 3) & ~3;
+    const size_t BH = (size_t)B * H;
+    for (int t = 0; t < S; ++t) {
+        const sf_spk_decoder_tape tp = spk_tape_view(tape0, t, B, E, H, Tp, ldv);
+        const float* h0 = t == 0 ? h_init : tape0->h1 + (size_t)(t - 1) * BH;
+        const float* c0 = t == 0 ? c_init : tape0->c1 + (size_t)(t - 1) * BH;
+        TRY(sf_speaker_decoder_fwd(w, B, E, H, Tp, vocab, words + (size_t)t * B, h0, c0, ctx, ctx_mask, nullptr, &tp, drop,
+                                   step0 + t, ws, ws_bytes, stream));
+        sf_sample smp{};
+        if (sample) {
+            smp = *sample;
+            smp.stream = sample->stream + (uint32_t)t;
+        }
+        TRY(sf_speaker_glue_fwd(B, vocab, ldv, tp.logit, targets + (size_t)t * B, feedback, pad_idx, eos_idx, ended,
+                                words + (size_t)(t + 1) * B, step_scores + (size_t)t * B, nll_term + (size_t)t * B,
+                                live + (size_t)t * B, sample ? &smp : nullptr, stream));
+    }
+    return SF_OK;
+}
+
+int sf_speaker_words_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H, int Tp, int vocab,
+                         int S, int pad_idx, const int64_t* words, const int64_t* targets, const float* h_init,
+                         const float* c_init, const float* ctx, const sf_spk_decoder_tape* tape0, const float* gscale,
+                         float* dlogit, float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
+                         int* result_in_b, const sf_dropout* drop, uint32_t step0, const sf_spk_decoder_gtape* gtape,
+                         const float* h0_all, void* ws, size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && tape0 && tape0->h1 && tape0->c1 && tape0->logit && words && targets && h_init && c_init && ctx &&
+                 gscale && (dlogit || gtape) && dh_a && dc_a && dh_b && dc_b && dctx && result_in_b && B > 0 && S > 0 &&
+                 (!gtape || (gtape->dlogit && gtape->dpre && gtape->dt_text && gtape->dgates && h0_all)));
+    const int ldv = (vocab + 3) & ~3;
+    const size_t BH = (size_t)B * H;
+    const float *dh1 = nullptr, *dc1 = nullptr;
+    float *dho = dh_a, *dco = dc_a, *dhn = dh_b, *dcn = dc_b;
+    hipStream_t st = (hipStream_t)stream;        // (the parameter S shadows the S() cast helper here)
+    for (int t = S - 1; t >= 0; --t) {
+        const sf_spk_decoder_tape tp = spk_tape_view(tape0, t, B, E, H, Tp, ldv);
+        const float* h0 = t == 0 ? h_init : tape0->h1 + (size_t)(t - 1) * BH;
+        const float* c0 = t == 0 ? c_init : tape0->c1 + (size_t)(t - 1) * BH;
+        float* dl = gtape ? gtape->dlogit + (size_t)t * B * ldv : dlogit;
+        TRY(sf_speaker_glue_bwd(B, vocab, ldv, tp.logit, targets + (size_t)t * B, pad_idx, gscale + t, dl, stream));
+        if (!gtape) {
+            TRY(sf_speaker_decoder_bwd(w, g, B, E, H, Tp, vocab, words + (size_t)t * B, h0, c0, ctx, &tp, dl, dh1, dc1, dho,
+                                       dco, dctx, drop, step0 + t, ws, ws_bytes, stream));
+        } else {
+            // data gradients only; dY operands into the stacked gtape (sf_speaker_decoder_bwd with g = NULL)
+            Arena ar = arena(ws, ws_bytes);
+            const Dropout d_h = make_dropout(drop, 2 * (step0 + t) + 1);
+            float* dht = ar.take(BH);
+            float* dh1d = ar.take(BH);
+            float* dh1m = ar.take(BH);
+            NEED(dht && dh1d && dh1m);
+            TRY(spk_dlogit_to_dht(w, dl, ldv, B, H, vocab, dht, ar, st));
+            TRY(softdot_bwd_i(&w->attn, nullptr, B, Tp, H, ctx, tp.alpha, tp.cat2, tp.t_text, tp.h_tilde, dht, dh1d, H, dctx,
+                              ar, st, gtape->dpre + (size_t)t * BH, gtape->dt_text + (size_t)t * BH));
+            TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
+            float* dgt = gtape->dgates + (size_t)t * B * 4 * H;
+            if (!(g && g->embedding)) {
+                TRY(lstm_bwd_i(&w->lstm, nullptr, B, E, H, tp.emb, E, h0, c0, tp.c1, tp.gates, dh1, dh1m, dc1, nullptr, 0,
+                               dho, dco, ar, st, dgt));
+            } else {
+                SF_CHECK_ARG(tp.emb);
+                float* demb = ar.take((size_t)B * E);
+                NEED(demb);
+                TRY(lstm_bwd_i(&w->lstm, nullptr, B, E, H, tp.emb, E, h0, c0, tp.c1, tp.gates, dh1, dh1m, dc1, demb, E, dho,
+                               dco, ar, st, dgt));
+                const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * (step0 + t))
+                                                                   : make_dropout(nullptr, 0);
+                TRY(embedding_bwd(demb, E, words + (size_t)t * B, 1, 1, B, E, -1, de, nullptr, g->embedding, st));
+            }
+        }
+        dh1 = dho;
+        dc1 = dco;
+        std::swap(dho, dhn);
+        std::swap(dco, dcn);
+    }
+    *result_in_b = (dh1 == dh_b) ? 1 : 0;
+    if (gtape && g) {
+        // every weight gradient as ONE product over the S*B stacked rows
+        Arena ar = arena(ws, ws_bytes);
+        const int M = S * B;
+        if (g->w_out) TRY(gemm_tn(gtape->dlogit, ldv, tape0->h_tilde, H, M, vocab, H, g->w_out, H, 1, st, ar.rest(), ar.rest_n()));
+        if (g->b_out) TRY(colsum(gtape->dlogit, ldv, M, vocab, g->b_out, 1, st, nullptr, ar.rest(), ar.rest_n()));
+        if (g->attn.w_out) TRY(gemm_tn(gtape->dpre, H, tape0->cat2, 2 * H, M, H, 2 * H, g->attn.w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
+        if (g->attn.w_in) TRY(gemm_tn(gtape->dt_text, H, tape0->cat2 + H, 2 * H, M, H, H, g->attn.w_in, H, 1, st, ar.rest(), ar.rest_n()));
+        if (g->lstm.w_ih) {
+            SF_CHECK_ARG(tape0->emb);
+            TRY(gemm_tn(gtape->dgates, 4 * H, tape0->emb, E, M, 4 * H, E, g->lstm.w_ih, E, 1, st, ar.rest(), ar.rest_n()));
+        }
+        if (g->lstm.w_hh) TRY(gemm_tn(gtape->dgates, 4 * H, h0_all, H, M, 4 * H, H, g->lstm.w_hh, H, 1, st, ar.rest(), ar.rest_n()));
+        TRY(colsum_pair(gtape->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
+    }
+    return SF_OK;
 }
 
 int sf_speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos_idx, int T, int B, float* loss,

@@ -713,7 +713,7 @@ class _SpeakerDecoderFn(torch.autograd.Function):
         B, E, H, Tp, vocab, ldv, (p, seed, site), use_table = ctx.cfg
         mod = ctx.mod
         dev = h0.device
-        w, g = mod._w_struct(table=use_table), mod._w_struct(grad=True, table=use_table)
+        w, g = mod._w_struct(table=use_table, bwd=True), mod._w_struct(grad=True, table=use_table)
         tp = _lib.SpkDecoderTape(*(ctx.tape[k].data_ptr() for k in _SPK_TAPE))
         dl = torch.zeros(B, ldv, device=dev, dtype=torch.float32)
         if dlogit is not None:
@@ -760,8 +760,24 @@ class SpeakerDecoderLSTM(nn.Module):
                 self.lstm.bias_hh, a.linear_in.weight, a.linear_out.weight,
                 self.decoder2action.weight, self.decoder2action.bias)
 
-    def _w_struct(self, grad=False, table=True):
-        """`table`: see _encoder_structs (False = trainable embedding with a backward to follow)."""
+    def _w_out_t(self):
+        """decoder2action^T as [H, ldv] (padding columns zero), rebuilt in place when the weight changes: the backward's
+        d h~ = dlogit W_out reads it K-contiguous."""
+        w = self.decoder2action.weight
+        key = weight_key(w)
+        if getattr(self, '_wot_key', None) != key:
+            V, H = w.shape
+            ldv = (V + 3) & ~3
+            buf = getattr(self, '_wot', None)
+            if buf is None or buf.shape != (H, ldv) or buf.device != w.device:
+                buf = torch.zeros(H, ldv, device=w.device, dtype=torch.float32)
+            buf[:, :V].copy_(w.detach().t())
+            self._wot, self._wot_key = buf, key
+        return self._wot
+
+    def _w_struct(self, grad=False, table=True, bwd=False):
+        """`table`: see _encoder_structs (False = trainable embedding with a backward to follow).  `bwd`: with the
+        transposed copies the backward's data gradients read K-contiguous (no strided NN products)."""
         ps = self._params9()
         if grad:
             v = _grads(ps[1:])
@@ -770,9 +786,10 @@ class SpeakerDecoderLSTM(nn.Module):
         v = [p.data_ptr() for p in ps]
         table = self._xw_table().data_ptr() if table else None
         flags = _lib.SF_SPK_EMB_DROPOUT if (table is None and not self.use_glove) else 0
-        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5], transposed(ps[1]).data_ptr() if table is None else None, None),
-                                _lib.SoftdotW(v[5], v[6], transposed(ps[5]).data_ptr(), None), v[7], v[8],
-                                table, flags)
+        return _lib.SpkDecoderW(v[0], _lib.LstmW(*v[1:5], transposed(ps[1]).data_ptr() if table is None else None,
+                                                 transposed(ps[2]).data_ptr() if bwd else None),
+                                _lib.SoftdotW(v[5], v[6], transposed(ps[5]).data_ptr(), transposed(ps[6]).data_ptr() if bwd else None),
+                                v[7], v[8], table, flags, self._w_out_t().data_ptr() if bwd else None)
 
     def _xw_table(self):
         """[vocab, 4H] = embedding W_ih^T (runtime.xw_table): the LSTM's input product becomes a

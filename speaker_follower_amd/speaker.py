@@ -84,6 +84,7 @@ class SpeakerEngine:
         self.site_next = 0              # first unused dropout site (see score)
         self.dropout_seed = None
         self.persistent = True          # inference passes: the whole word loop as ONE launch (sf_speaker_decode)
+        self.stacked_wgrad = True       # backward: weight gradients as one product over all S*B rows (False: per step)
         self.fallbacks = 0              # passes re-issued on the per-step kernels after a persistent-launch fault (run)
 
     def capture(self, batch, steps, feedback='teacher'):
@@ -185,7 +186,10 @@ class SpeakerEngine:
                  C.c_void_p(st.ctx.data_ptr() + 4 * t * H) if d_enc is None else None, Tp * H if d_enc is None else 0,
                  None, 0, *ws)
         # decoder_init = tanh(encoder2decoder(h)) (model.py:453); ctx = dropout(stack(h)) (:455-456)
-        st.h_init = new(B, H)
+        # hidden states of all word steps stacked: hs_all[t] is step t's incoming h (h_init first), hs_all[t + 1] its
+        # output -- the batched weight-gradient products read hs_all[0:S] as one [S*B, H] matrix
+        st.hs_all = new(S + 1, B, H)
+        st.h_init = st.hs_all[0]
         e2d = enc.encoder2decoder
         call('sf_linear_fwd', ptr(st.e['hs'][Tp]), H, ptr(e2d.weight), ptr(e2d.bias), B, H, H, 1,
              ptr(st.h_init), H, *ws)
@@ -198,7 +202,8 @@ class SpeakerEngine:
         # ---- decoder: S x (embedding -> LSTMCell -> dropout -> attention -> vocab projection)
         shapes = dict(emb=(E,), gates=(4 * H,), c1=(H,), h1=(H,), cat2=(2 * H,), t_text=(H,),
                       alpha=(Tp,), h_tilde=(H,), logit=(ldv,))
-        st.tape = {k: new(S, B, *shapes[k]) for k in _DEC_TAPE}
+        st.tape = {k: new(S, B, *shapes[k]) for k in _DEC_TAPE if k != 'h1'}
+        st.tape['h1'] = st.hs_all[1:]
         st.words = torch.empty(S + 1, B, dtype=torch.int64, device=dev)
         st.words[0] = BOS                                                  # speaker.py:137
         st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
@@ -225,23 +230,17 @@ class SpeakerEngine:
                 _lib.check(rc, 'sf_speaker_decode')
                 persistent = True
         st.persistent = persistent
-        for t in range(0 if not persistent else S, S):
-            # the embedded words are only kept for the backward (dW_ih); the forward looks the
-            # input product up in the [vocab,4H] table (sf_spk_decoder_w.xw_table)
-            tp = _lib.SpkDecoderTape(*(st.tape[k][t].data_ptr() if (k != 'emb' or differentiable)
-                                       else None for k in _DEC_TAPE))
-            h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
-            c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
-            call('sf_speaker_decoder_fwd', byref(dw), B, E, H, Tp, vocab, ptr(st.words[t]), ptr(h0),
-                 ptr(c0), ptr(st.ctx), ptr(batch.path_mask), None, byref(tp), d_dec, st.site0 + t,
-                 *ws)
-            smp_t = None
-            if st.feedback == 2:
-                smp_t = byref(_lib.Sample(smp.seed, (st.site0 + t) & 0xFFFFFFFF, batch.row0))
-            call('sf_speaker_glue_fwd', B, vocab, ldv, ptr(st.tape['logit'][t]),
-                 ptr(st.targets[t]), st.feedback, PAD, EOS, ptr(st.ended),
-                 ptr(st.words[t + 1]), ptr(st.step_scores[t]), ptr(st.nll_term[t]),
-                 ptr(st.live[t]), smp_t, ws[2])
+        if not persistent:
+            # the per-step word loop WITH its tape (training, or shapes outside the persistent kernel), one library call:
+            # sf_speaker_decoder_fwd + sf_speaker_glue_fwd per word with no host work between the launches.  The embedded
+            # words are only kept for the backward (dW_ih); the forward looks the input product up in the [vocab,4H]
+            # table (sf_spk_decoder_w.xw_table)
+            tp0 = _lib.SpkDecoderTape(*(st.tape[k].data_ptr() if (k != 'emb' or differentiable) else None
+                                        for k in _DEC_TAPE))
+            call('sf_speaker_words_fwd', byref(dw), B, E, H, Tp, vocab, S, st.feedback, PAD, EOS, ptr(st.targets),
+                 ptr(st.h_init), ptr(st.c_init), ptr(st.ctx), ptr(batch.path_mask), ptr(st.words), ptr(st.ended),
+                 ptr(st.step_scores), ptr(st.nll_term), ptr(st.live), byref(tp0), d_dec, st.site0,
+                 byref(smp) if st.feedback == 2 else None, *ws)
         call('sf_reduce_terms', ptr(st.nll_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         if self.group is not None:
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
@@ -285,23 +284,22 @@ class SpeakerEngine:
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731
         ws = ws_args(dev)
         gscale = st.gscale * dloss.to(torch.float32)
-        dw, dg = dec._w_struct(table=st.dec_table), dec._w_struct(grad=True, table=st.dec_table)
+        dw, dg = dec._w_struct(table=st.dec_table, bwd=True), dec._w_struct(grad=True, table=st.dec_table)
         d_dec = dropout_arg(*st.drop_dec)
         dlogit = new(B, ldv)
         dh_a, dc_a, dh_b, dc_b = new(B, H), new(B, H), new(B, H), new(B, H)
         dctx = torch.zeros(B, Tp, H, device=dev, dtype=torch.float32)
-        dh1 = dc1 = None
-        for t in range(S - 1, -1, -1):
-            tp = _lib.SpkDecoderTape(*(st.tape[k][t].data_ptr() for k in _DEC_TAPE))
-            h0 = st.h_init if t == 0 else st.tape['h1'][t - 1]
-            c0 = st.c_init if t == 0 else st.tape['c1'][t - 1]
-            call('sf_speaker_glue_bwd', B, vocab, ldv, ptr(st.tape['logit'][t]), ptr(st.targets[t]),
-                 PAD, ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
-            call('sf_speaker_decoder_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, ptr(st.words[t]), ptr(h0), ptr(c0),
-                 ptr(st.ctx), byref(tp), ptr(dlogit), ptr(dh1), ptr(dc1), ptr(dh_a), ptr(dc_a),
-                 ptr(dctx), d_dec, st.site0 + t, *ws)
-            dh1, dc1 = dh_a, dc_a
-            dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
+        # the backward of all S word steps (glue + decoder, last step first) as one library call
+        tp0 = _lib.SpkDecoderTape(*(st.tape[k].data_ptr() for k in _DEC_TAPE))
+        in_b = C.c_int(0)
+        # per step only the data gradients; every weight gradient is ONE product over all S*B stacked rows at the end
+        gt = dict(dlogit=new(S, B, ldv), dpre=new(S, B, H), dt_text=new(S, B, H), dgates=new(S, B, 4 * H))
+        gtape = _lib.SpkDecoderGTape(*(gt[k].data_ptr() for k in ('dlogit', 'dpre', 'dt_text', 'dgates')))
+        call('sf_speaker_words_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, S, PAD, ptr(st.words), ptr(st.targets),
+             ptr(st.h_init), ptr(st.c_init), ptr(st.ctx), byref(tp0), ptr(gscale.contiguous()), ptr(dlogit), ptr(dh_a),
+             ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(in_b), d_dec, st.site0,
+             byref(gtape) if self.stacked_wgrad else None, ptr(st.hs_all), *ws)
+        dh1, dc1 = (dh_b, dc_b) if in_b.value else (dh_a, dc_a)
         # ---- encoder backward
         d_enc = dropout_arg(*st.drop_enc)
         ep = enc._params8()
