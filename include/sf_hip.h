@@ -576,6 +576,20 @@ int sf_speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos
 int sf_speaker_glue_bwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                         int pad_idx, const float* gscale, float* dlogit, sf_stream stream);
 
+/* ---- SpeakerEncoderLSTM.forward (model.py:437-457) in one call: for t in 0..Tp-1: visual attention over the panorama
+ * of path step t with the previous hidden state (a1) -> [action embedding | attended feature] -> dropout -> LSTMCell (a2);
+ * then decoder_init = tanh(encoder2decoder(h_Tp)).  X0 = the sf_pano of path step 0 of stacked [Tp][B] vp / view index
+ * arrays; xin [Tp,B,2F] holds the action embeddings in its first halves on entry (sf_gather_path_actions) unless
+ * act_emb [Tp,B,F] is given (train mode: they are dropped into xin here, site 2*(step0+t)); alpha [Tp,B,V], t_v
+ * [Tp,B,D], q [Tp,B,F], gates [Tp,B,4H] are the backward's tape; hs, cs [Tp+1,B,H] with row 0 = zeros on entry.
+ * ctx [B,Tp,H] (optional, eval mode only: h_t written straight into ctx[:, t]); h_init [B,H].
+ * The loop this replaces issued 3 library calls per path step from Python. */
+int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const float* w_e2d, const float* b_e2d,
+                           const sf_pano* X0, int Tp, int B, int H, int D, float* xin, float* alpha, float* t_v,
+                           float* q, float* gates, float* hs, float* cs, float* ctx, const float* act_emb,
+                           float* h_init, const sf_dropout* drop, uint32_t step0, void* ws, size_t ws_bytes,
+                           sf_stream stream);
+
 /* ---- the speaker's word loop with its tape, in one call each way (speaker.py:158-197 forward, the backward
  * `loss.backward()` of speaker.py:385 walks) -- what a TRAINING iteration runs (sf_speaker_decode keeps no tape):
  * fwd = for t in 0..S-1: sf_speaker_decoder_fwd(words[t], state t-1 -> tape[t], dropout / sampling site step0 + t) then

@@ -208,6 +208,8 @@ _SIGNATURES = {
                                       c_f, P(Sample), c_p]),
     'sf_speaker_loss_finalize': (C.c_int, [c_f, i64p, i32, i32, i32, c_f, c_f, c_p]),
     'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),
+    'sf_speaker_encoder_fwd': (C.c_int, [P(VisualW), P(LstmW), c_f, c_f, P(Pano), i32, i32, i32, i32, c_f, c_f, c_f, c_f,
+                                         c_f, c_f, c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),
     'sf_speaker_words_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i32, i32, i32, i32, i64p, c_f, c_f, c_f,
                                        c_p, i64p, c_p, c_f, c_f, c_f, P(SpkDecoderTape), P(Dropout), u32, P(Sample)] + WS),
     'sf_speaker_words_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32, i32, i32, i64p, i64p, c_f,

@@ -1602,6 +1602,34 @@ int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int
                             score, nll_term, live, S(stream), sample);
 }
 
+// ---- a8 SpeakerEncoderLSTM.forward (model.py:437-457), all path steps in one call -------------------------------------
+int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const float* w_e2d, const float* b_e2d,
+                           const sf_pano* X0, int Tp, int B, int H, int D, float* xin, float* alpha, float* t_v,
+                           float* q, float* gates, float* hs, float* cs, float* ctx, const float* act_emb,
+                           float* h_init, const sf_dropout* drop, uint32_t step0, void* ws, size_t ws_bytes,
+                           sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(vw && lw && w_e2d && X0 && X0->vp && X0->view && Tp > 0 && B > 0 && xin && alpha && t_v && q && gates && hs &&
+                 cs && h_init && (!act_emb || drop) && (!ctx || !drop));
+    const int F = X0->IMG + X0->LOC, V = X0->V;
+    const size_t BH = (size_t)B * H;
+    for (int t = 0; t < Tp; ++t) {
+        sf_pano X = *X0;
+        X.vp = adv(X0->vp, (size_t)t * B);
+        X.view = adv(X0->view, (size_t)t * B);
+        float* x_t = xin + (size_t)t * B * 2 * F;
+        TRY(sf_visual_attention_fwd(vw, &X, B, H, D, hs + t * BH, x_t + F, 2 * F, alpha + (size_t)t * B * V,
+                                    t_v + (size_t)t * B * D, q + (size_t)t * B * F, drop, 2 * (step0 + t), F, ws, ws_bytes,
+                                    stream));
+        if (act_emb)
+            TRY(sf_dropout_copy(act_emb + (size_t)t * B * F, F, B, F, x_t, 2 * F, drop, 2 * (step0 + t), 0, stream));
+        TRY(sf_lstm_cell_fwd(lw, B, 2 * F, H, x_t, 2 * F, hs + t * BH, cs + t * BH, hs + (t + 1) * BH, cs + (t + 1) * BH,
+                             gates + (size_t)t * B * 4 * H, ctx ? ctx + (size_t)t * H : nullptr, ctx ? Tp * H : 0, nullptr, 0,
+                             ws, ws_bytes, stream));
+    }
+    return sf_linear_fwd(hs + Tp * BH, H, w_e2d, b_e2d, B, H, H, 1, h_init, H, ws, ws_bytes, stream);
+}
+
 // ---- the speaker's word loop with its tape, one call each way (speaker.py:158-197 and its backward) ------------------
 namespace {
 sf_spk_decoder_tape spk_tape_view(const sf_spk_decoder_tape* p, int t, int B, int E, int H, int Tp, int ldv) {

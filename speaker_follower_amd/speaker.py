@@ -171,28 +171,18 @@ class SpeakerEngine:
             gat(st.e['act_emb'], F)
         # eval mode: the LSTM cell also writes h_t into ctx[:, t] (its second output), no stacking copy afterwards
         st.ctx = new(B, Tp, H)
-        for t in range(Tp):
-            pano = store.pano(batch.vp[t], batch.view[t])
-            xin_f = C.c_void_p(st.e['xin'][t].data_ptr() + 4 * F)
-            call('sf_visual_attention_fwd', byref(vw), byref(pano), B, H, D, ptr(st.e['hs'][t]),
-                 xin_f, 2 * F, ptr(st.e['alpha'][t]), ptr(st.e['t_v'][t]), ptr(st.e['q'][t]), d_enc,
-                 2 * (st.site0 + t), F, *ws)
-            if d_enc is not None:
-                call('sf_dropout_copy', ptr(st.e['act_emb'][t]), F, B, F, ptr(st.e['xin'][t]), 2 * F,
-                     d_enc, 2 * (st.site0 + t), 0, ws[2])
-            call('sf_lstm_cell_fwd', byref(lw), B, 2 * F, H, ptr(st.e['xin'][t]), 2 * F,
-                 ptr(st.e['hs'][t]), ptr(st.e['cs'][t]), ptr(st.e['hs'][t + 1]),
-                 ptr(st.e['cs'][t + 1]), ptr(st.e['gates'][t]),
-                 C.c_void_p(st.ctx.data_ptr() + 4 * t * H) if d_enc is None else None, Tp * H if d_enc is None else 0,
-                 None, 0, *ws)
-        # decoder_init = tanh(encoder2decoder(h)) (model.py:453); ctx = dropout(stack(h)) (:455-456)
         # hidden states of all word steps stacked: hs_all[t] is step t's incoming h (h_init first), hs_all[t + 1] its
         # output -- the batched weight-gradient products read hs_all[0:S] as one [S*B, H] matrix
         st.hs_all = new(S + 1, B, H)
         st.h_init = st.hs_all[0]
         e2d = enc.encoder2decoder
-        call('sf_linear_fwd', ptr(st.e['hs'][Tp]), H, ptr(e2d.weight), ptr(e2d.bias), B, H, H, 1,
-             ptr(st.h_init), H, *ws)
+        # all Tp path steps (attention -> [action | feature] -> dropout -> cell) and decoder_init = tanh(encoder2decoder(h))
+        # (model.py:437-453) as ONE library call
+        pano0 = store.pano(batch.vp, batch.view)
+        call('sf_speaker_encoder_fwd', byref(vw), byref(lw), ptr(e2d.weight), ptr(e2d.bias), byref(pano0), Tp, B, H, D,
+             ptr(st.e['xin']), ptr(st.e['alpha']), ptr(st.e['t_v']), ptr(st.e['q']), ptr(st.e['gates']), ptr(st.e['hs']),
+             ptr(st.e['cs']), ptr(st.ctx) if d_enc is None else None, ptr(st.e['act_emb']), ptr(st.h_init), d_enc,
+             st.site0, *ws)
         st.c_init = st.e['cs'][Tp]
         if d_enc is not None:
             ctx_raw = st.e['hs'][1:].permute(1, 0, 2).contiguous()      # [B,Tp,H]
