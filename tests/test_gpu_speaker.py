@@ -155,3 +155,40 @@ def test_pipelined_sweep_equals_minibatch_by_minibatch_decoding(speaker_modules)
         with torch.no_grad():
             st = eng.score(speaker.DeviceSpeakerBatch.from_synth(sb), S, 'argmax', train=False)
         assert np.array_equal(out[i].astype(np.int64), st.words[1:].cpu().numpy()), i
+
+
+@pytest.mark.parametrize('glove', [True, False])
+def test_stacked_weight_gradients_equal_the_per_step_ones(glove):
+    """SpeakerEngine training pass (dropout on, teacher forcing): sf_speaker_words_bwd with the stacked gtape (every
+    weight gradient ONE product over all S*B rows) against the same call forming them per word step -- frozen (GloVe)
+    and trainable embedding (its gradient scatters per step in both forms): every gradient within 2e-5 of its scale."""
+    from speaker_follower_amd import model, features, speaker
+    from speaker_follower_amd import synth as sy
+    d = sy.FULL
+    senc_w, sdec_w = sy.speaker_weights_peaky(77)
+    enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'] if glove else None)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in senc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in sdec_w.items()})
+    enc.cuda().train()
+    dec.cuda().train()
+    store = features.FeatureStore(sy.feature_table(8, 128))
+    batch = speaker.DeviceSpeakerBatch.from_synth(sy.speaker_batch(seed=5, batch=40, n_viewpoints=128, min_len=5, max_len=30))
+    grads = []
+    for stacked in (True, False):
+        for m in (enc, dec):
+            m.zero_grad(set_to_none=True)
+        eng = speaker.SpeakerEngine(enc, dec, store)
+        eng.dropout_seed, eng.stacked_wgrad = 4242, stacked
+        st = eng.score(batch, 32, 'teacher', train=True)
+        assert not st.persistent
+        st.loss.backward()
+        torch.cuda.synchronize()
+        grads.append((float(st.loss.detach()),
+                      {k: p.grad.clone() for mod in (enc, dec) for k, p in mod.named_parameters() if p.grad is not None}))
+    (la, ga), (lb, gb) = grads
+    assert la == lb and set(ga) == set(gb)
+    assert ('embedding.weight' in ga) == (not glove)
+    for k in ga:
+        scale = float(gb[k].abs().max())
+        assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * max(scale, 1e-6), k
