@@ -1658,8 +1658,12 @@ int sf_speaker_words_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp,
                  ended && step_scores && nll_term && live && B > 0 && S > 0 && (feedback != 2 || sample));
     const int ldv = (vocab + 3) & ~3;
     const size_t BH = (size_t)B * H;
+    // with the input-product table the steps never read the embedded words: they are only kept for the backward's
+    // dW_ih, so ALL S*B of them are gathered by one launch behind the loop (words [S+1,B] is complete by then)
+    const bool emb_late = tape0->emb && w->xw_table && !(w->flags & SF_SPK_EMB_DROPOUT) && H % 16 == 0 && H <= 1024;
     for (int t = 0; t < S; ++t) {
-        const sf_spk_decoder_tape tp = spk_tape_view(tape0, t, B, E, H, Tp, ldv);
+        sf_spk_decoder_tape tp = spk_tape_view(tape0, t, B, E, H, Tp, ldv);
+        if (emb_late) tp.emb = nullptr;
         const float* h0 = t == 0 ? h_init : tape0->h1 + (size_t)(t - 1) * BH;
         const float* c0 = t == 0 ? c_init : tape0->c1 + (size_t)(t - 1) * BH;
         TRY(sf_speaker_decoder_fwd(w, B, E, H, Tp, vocab, words + (size_t)t * B, h0, c0, ctx, ctx_mask, nullptr, &tp, drop,
@@ -1673,6 +1677,7 @@ int sf_speaker_words_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp,
                                 words + (size_t)(t + 1) * B, step_scores + (size_t)t * B, nll_term + (size_t)t * B,
                                 live + (size_t)t * B, sample ? &smp : nullptr, stream));
     }
+    if (emb_late) TRY(embedding_rows(w->embedding, E, words, S * B, tape0->emb, (hipStream_t)stream));
     return SF_OK;
 }
 
@@ -1711,17 +1716,18 @@ int sf_speaker_words_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, i
             TRY(spk_dlogit_to_dht(w, dl, ldv, B, H, vocab, dht, ar, st));
             TRY(softdot_bwd_i(&w->attn, nullptr, B, Tp, H, ctx, tp.alpha, tp.cat2, tp.t_text, tp.h_tilde, dht, dh1d, H, dctx,
                               ar, st, gtape->dpre + (size_t)t * BH, gtape->dt_text + (size_t)t * BH));
-            TRY(dropout_copy(dh1d, H, B, H, dh1m, H, d_h, 0, st));
+            // (the mask of dropout(h1) is applied to dh1d inside the LSTM pointwise backward: no copy launch)
+            (void)dh1m;
             float* dgt = gtape->dgates + (size_t)t * B * 4 * H;
             if (!(g && g->embedding)) {
-                TRY(lstm_bwd_i(&w->lstm, nullptr, B, E, H, tp.emb, E, h0, c0, tp.c1, tp.gates, dh1, dh1m, dc1, nullptr, 0,
-                               dho, dco, ar, st, dgt));
+                TRY(lstm_bwd_i(&w->lstm, nullptr, B, E, H, tp.emb, E, h0, c0, tp.c1, tp.gates, dh1, dh1d, dc1, nullptr, 0,
+                               dho, dco, ar, st, dgt, 0, &d_h));
             } else {
                 SF_CHECK_ARG(tp.emb);
                 float* demb = ar.take((size_t)B * E);
                 NEED(demb);
-                TRY(lstm_bwd_i(&w->lstm, nullptr, B, E, H, tp.emb, E, h0, c0, tp.c1, tp.gates, dh1, dh1m, dc1, demb, E, dho,
-                               dco, ar, st, dgt));
+                TRY(lstm_bwd_i(&w->lstm, nullptr, B, E, H, tp.emb, E, h0, c0, tp.c1, tp.gates, dh1, dh1d, dc1, demb, E, dho,
+                               dco, ar, st, dgt, 0, &d_h));
                 const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * (step0 + t))
                                                                    : make_dropout(nullptr, 0);
                 TRY(embedding_bwd(demb, E, words + (size_t)t * B, 1, 1, B, E, -1, de, nullptr, g->embedding, st));
