@@ -207,6 +207,22 @@ int sf_visual_attention_fwd(const sf_visual_w* w, const sf_pano* X, int B, int H
                             const float* h, float* out, int ldo, float* alpha, float* t_v,
                             float* q, const sf_dropout* drop, uint32_t drop_stream,
                             int drop_col0, void* ws, size_t ws_bytes, sf_stream stream);
+/* The same function with every intermediate rounded ONCE (round 5, csrc/sf_precise.hip): t = W_h h + b_h and
+ * q = W_v^T t are formed on the float64 matrix cores (v_mfma_f64_16x16x4_f64) and kept in float64, the scores x_v . q
+ * are accumulated in float64, the softmax sees them relative to their maximum.  What the speaker's path encoder runs
+ * (sf_speaker_encoder_fwd): with the reference's "peaky" weights its scores reach +-80, where an fp32 evaluation of
+ * the chain -- the reference's own included -- leaves 2e-6 .. 9e-6 of roundoff per stage in the softmax weights and
+ * 1e-4 .. 3e-4 in the word logits behind the 7-step context.  t_v / q receive fp32 copies (the backward's tapes).
+ * SF_ERR_UNSUPPORTED outside V in (18, 36], B <= 256, no transposed W_v copy: call sf_visual_attention_fwd. */
+int sf_visual_attention_fwd_f64(const sf_visual_w* w, const sf_pano* X, int B, int H, int D,
+                                const float* h, float* out, int ldo, float* alpha, float* t_v,
+                                float* q, const sf_dropout* drop, uint32_t drop_stream,
+                                int drop_col0, void* ws, size_t ws_bytes, sf_stream stream);
+/* y = x W^T + b with float64 accumulation on the float64 matrix cores: x [M,K] fp32 (row stride ldx), W [N,K] fp32
+ * (row stride ldw), b [N] or NULL; y64 [M,N] float64 and / or y32 [M,N] fp32 (either may be NULL).  K, ldx, ldw
+ * multiples of 4. */
+int sf_linear_f64(const float* x, int ldx, const float* w, int ldw, const float* b, int M, int N, int K,
+                  double* y64, float* y32, sf_stream stream);
 /* dout [B,F] (row stride lddo) is the gradient wrt the (dropped) output; dh [B,H] is ADDED to. */
 int sf_visual_attention_bwd(const sf_visual_w* w, const sf_visual_g* g, const sf_pano* X, int B,
                             int H, int D, const float* h, const float* alpha, const float* t_v,
@@ -677,11 +693,26 @@ void sf_debug_force_write_through(int on);
  * (< 0 restores the default, 0.25 s).  0 makes the first unsatisfied poll give up: the launch poisons its outputs
  * and raises its fault bit -- how the tests exercise the host's fallback to the per-step kernels. */
 void sf_debug_persist_timeout(long long ticks);
-/* Development aid: on != 0 runs the large LSTM gate products (K >= 2048, M <= 128: sf_lstm_cell_fwd, the decode
+/* STRICT summation order for the LSTM gate products (supported runtime switch, round 5).  on != 0: the large gate
+ * products (K >= 2048, M <= 128: sf_lstm_cell_fwd, the decode step, the search step) run on the fp32 MFMA
+ * (v_mfma_f32_16x16x4_f32, the kernel of rounds 1-3) instead of the bf16 matrix cores with three-way error-free operand
+ * splitting.  Both are fp32-accurate (the split form is measured closer to the exact sum); they differ in the last
+ * bit or two, and a best-first search that meets two frontier states whose scores are EQUAL to that last bit expands
+ * them in the order the arithmetic happens to give.  With the strict order the state-factored search walks the
+ * reference's own traversal for 64 of 64 instructions of golden G7b (tests/test_gpu_search.py); the default order
+ * re-orders one exact tie (identical completions, order and scores either way).  5.5 us per decode step slower.
+ * Process-wide; a captured hipGraph keeps the kernels it was captured with (search.graph_step_for keys its cache on
+ * this switch).  sf_gate_product_is_strict() reads it back. */
+void sf_gate_product_strict(int on);
+int sf_gate_product_is_strict(void);
+/* Older name of the same switch (tools/, A/B timing): on != 0 runs the large LSTM gate products (K >= 2048, M <= 128: sf_lstm_cell_fwd, the decode
  * step) on the fp32 MFMA (v_mfma_f32_16x16x4_f32, rounds 1-3) instead of the bf16 matrix cores with three-way
  * error-free operand splitting (csrc/sf_gemm.hip: gemm_nt_split_kernel; same fp32 accuracy class, measured closer
  * to the exact sum, 6/16 of the matrix-pipe time).  For A/B timing and for the accuracy tests. */
 void sf_debug_gate_product_f32(int on);
+/* A/B switch: on == 0 makes sf_speaker_encoder_fwd run its visual attention on the fp32 kernels (rounds 1-4) instead
+ * of the float64 query / score path (sf_visual_attention_fwd_f64; the default). */
+void sf_debug_precise_attention(int on);
 /* Test switch: the weight-gradient products dW += dY^T X whose shape is a whole number of 128 x 128 tiles run as bf16x6
  * split products (gemm_tn_split_kernel) from `rows` reduction rows on (default 4096: where it is faster than the
  * fp32-MFMA kernels; rows < 0 restores the default). */

@@ -136,6 +136,9 @@ _SIGNATURES = {
     'sf_build_id': (C.c_char_p, []),
     'sf_debug_persist_timeout': (None, [C.c_longlong]),
     'sf_debug_gate_product_f32': (None, [C.c_int]),
+    'sf_debug_precise_attention': (None, [C.c_int]),
+    'sf_gate_product_strict': (None, [C.c_int]),
+    'sf_gate_product_is_strict': (C.c_int, []),
     'sf_debug_tn_split_min_rows': (None, [C.c_int]),
     'sf_workspace_fault_offset': (C.c_size_t, [C.c_size_t]),
     'sf_debug_trace': (None, [C.c_void_p]),
@@ -152,6 +155,9 @@ _SIGNATURES = {
                                    c_f, c_f, c_f, i32, c_f, c_f] + WS),
     'sf_visual_attention_fwd': (C.c_int, [P(VisualW), P(Pano), i32, i32, i32, c_f, c_f, i32, c_f,
                                           c_f, c_f, P(Dropout), u32, i32] + WS),
+    'sf_visual_attention_fwd_f64': (C.c_int, [P(VisualW), P(Pano), i32, i32, i32, c_f, c_f, i32, c_f,
+                                              c_f, c_f, P(Dropout), u32, i32] + WS),
+    'sf_linear_f64': (C.c_int, [c_f, i32, c_f, i32, c_f, i32, i32, i32, c_p, c_f, c_p]),
     'sf_visual_attention_bwd': (C.c_int, [P(VisualW), P(VisualW), P(Pano), i32, i32, i32, c_f, c_f,
                                           c_f, c_f, i32, P(Dropout), u32, i32, c_f] + WS),
     'sf_soft_dot_attention_fwd': (C.c_int, [P(SoftdotW), i32, i32, i32, c_f, i32, c_f, c_p, c_p,

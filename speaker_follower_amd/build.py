@@ -24,7 +24,7 @@ CSRC = os.path.join(PKG, 'csrc')
 OBJ = os.path.join(CSRC, 'build')
 LIB = os.path.join(PKG, 'libsf_hip.so')
 ARCH = 'gfx950'
-SOURCES = ['sf_gemm.hip', 'sf_attention.hip', 'sf_pointwise.hip', 'sf_persist.hip', 'sf_nav.hip', 'sf_api.hip']
+SOURCES = ['sf_gemm.hip', 'sf_attention.hip', 'sf_pointwise.hip', 'sf_persist.hip', 'sf_nav.hip', 'sf_precise.hip', 'sf_api.hip']
 FLAGS = ['--offload-arch=' + ARCH, '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function', '-I' + CSRC]
 
 

@@ -224,8 +224,20 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
 // ---- a1 VisualSoftDotAttention ---------------------------------------------------------------------
 int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, const float* h,
                  float* out, int ldo, float* alpha, float* t_v, float* q, const Dropout& drop,
-                 int col0, Arena ar, hipStream_t st, const sf_decoder_fold* fold = nullptr) {
+                 int col0, Arena ar, hipStream_t st, const sf_decoder_fold* fold = nullptr, bool precise = false) {
     const int F = X.IMG + X.LOC;
+    if (precise && !fold && w->w_v_t && visual_attn_f64_supported(X, B) && !(H & 3) && !(D & 3)) {
+        // The speaker's path encoder (csrc/sf_precise.hip): t_v, q and the scores in float64 -- each intermediate is
+        // rounded ONCE.  t_v / q also land in their fp32 tapes (the backward reads those).
+        double* t64 = reinterpret_cast<double*>(ar.take((size_t)B * D * 2));
+        double* q64 = reinterpret_cast<double*>(ar.take((size_t)B * F * 2));
+        float* part = ar.take(visual_attn_split_floats(B, F));
+        if (t64 && q64 && part && ar.tickets()) {
+            TRY(linear_f64(h, nullptr, H, w->w_h, H, w->b_h, B, D, H, t64, D, t_v, D, st));
+            TRY(linear_f64(nullptr, t64, D, w->w_v_t, D, nullptr, B, F, D, q64, F, q, F, st));
+            return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st, part, ar.tickets(), q64);
+        }
+    }
     if (fold) {      // inference: q = M_v h + c_v in one product
         TRY(linear_plain(h, H, fold->m_v, H, fold->c_v, B, F, H, EPI_NONE, q, F, ar, st));
         float* part = B <= 1024 ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
@@ -416,6 +428,9 @@ int sf_abi_version(void) { return SF_ABI_VERSION; }
 const char* sf_build_id(void) { static const char id[] = "SF_BUILD_ID=" SF_BUILD_ID; return id + 12; }
 void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; }
 void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
+void sf_gate_product_strict(int on) { sf::g_nt_force_f32 = on ? 1 : 0; }
+int sf_gate_product_is_strict(void) { return sf::g_nt_force_f32 != 0; }
+void sf_debug_precise_attention(int on) { sf::g_precise_attention = on; }
 void sf_debug_tn_split_min_rows(int rows) { sf::g_tn_split_min_rows = rows < 0 ? 4096 : rows; }
 size_t sf_workspace_fault_offset(size_t ws_bytes) {
     const size_t n = ws_bytes / 4;
@@ -505,6 +520,29 @@ int sf_visual_attention_fwd(const sf_visual_w* w, const sf_pano* X, int B, int H
     SF_CHECK_ARG(w && X && h && out && alpha && t_v && q && B > 0);
     return visual_fwd_i(w, pano(X), B, H, D, h, out, ldo, alpha, t_v, q,
                         make_dropout(drop, drop_stream), drop_col0, arena(ws, ws_bytes), S(stream));
+}
+
+int sf_visual_attention_fwd_f64(const sf_visual_w* w, const sf_pano* X, int B, int H, int D,
+                                const float* h, float* out, int ldo, float* alpha, float* t_v, float* q,
+                                const sf_dropout* drop, uint32_t drop_stream, int drop_col0, void* ws,
+                                size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && X && h && out && alpha && t_v && q && B > 0);
+    const PanoSrc src = pano(X);
+    const int F = src.IMG + src.LOC;
+    Arena ar = arena(ws, ws_bytes);
+    if (!w->w_v_t || !visual_attn_f64_supported(src, B) || (H & 3) || (D & 3) || !ar.tickets() ||
+        ar.rest_n() < (size_t)B * (D + F) * 2 + visual_attn_split_floats(B, F) + 256)
+        return SF_ERR_UNSUPPORTED;
+    return visual_fwd_i(w, src, B, H, D, h, out, ldo, alpha, t_v, q, make_dropout(drop, drop_stream), drop_col0, ar,
+                        S(stream), nullptr, true);
+}
+
+int sf_linear_f64(const float* x, int ldx, const float* w, int ldw, const float* b, int M, int N, int K, double* y64,
+                  float* y32, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(x && w && (y64 || y32) && M > 0 && N > 0 && K > 0);
+    return linear_f64(x, nullptr, ldx, w, ldw, b, M, N, K, y64, N, y32, N, S(stream));
 }
 
 int sf_visual_attention_bwd(const sf_visual_w* w, const sf_visual_g* g, const sf_pano* X, int B,
@@ -1618,9 +1656,10 @@ int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const flo
         X.vp = adv(X0->vp, (size_t)t * B);
         X.view = adv(X0->view, (size_t)t * B);
         float* x_t = xin + (size_t)t * B * 2 * F;
-        TRY(sf_visual_attention_fwd(vw, &X, B, H, D, hs + t * BH, x_t + F, 2 * F, alpha + (size_t)t * B * V,
-                                    t_v + (size_t)t * B * D, q + (size_t)t * B * F, drop, 2 * (step0 + t), F, ws, ws_bytes,
-                                    stream));
+        // (float64 query and scores: see visual_fwd_i / csrc/sf_precise.hip; sf_debug_precise_attention(0) = fp32)
+        TRY(visual_fwd_i(vw, pano(&X), B, H, D, hs + t * BH, x_t + F, 2 * F, alpha + (size_t)t * B * V,
+                         t_v + (size_t)t * B * D, q + (size_t)t * B * F, make_dropout(drop, 2 * (step0 + t)), F,
+                         arena(ws, ws_bytes), S(stream), nullptr, g_precise_attention != 0));
         if (act_emb)
             TRY(sf_dropout_copy(act_emb + (size_t)t * B * F, F, B, F, x_t, 2 * F, drop, 2 * (step0 + t), 0, stream));
         TRY(sf_lstm_cell_fwd(lw, B, 2 * F, H, x_t, 2 * F, hs + t * BH, cs + t * BH, hs + (t + 1) * BH, cs + (t + 1) * BH,

@@ -26,7 +26,19 @@ struct VisArgs {
     int ldo;
     Dropout drop;          // fwd: applied to out; bwd: applied to vec (same mask)
     int drop_col0;
+    const double* vec64;   // the query in float64 (visual_split_body<0, true>: scores accumulated in float64), or null
 };
+
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+__device__ __forceinline__ double wave_max_f64(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
 
 template <int MODE>
 __device__ __forceinline__ void visual_attn_body(const VisArgs& a, int b) {
@@ -162,10 +174,15 @@ __device__ __forceinline__ void vis_stamp(const VisSplit& sp, int block, int slo
 //          (plain stores / loads: the kernel boundary is the hand-off).  The pipelined decode step
 //          runs them beside two different small products, so the visual attention of step t+1 never
 //          holds up the text / scoring chain of step t.
-template <int PHASE>
+// F64 (PHASE 0 only; the speaker's path encoder, csrc/sf_precise.hip): the query arrives in float64 and every score is
+//          accumulated in float64; a group's record holds its scores RELATIVE to its own maximum (small numbers:
+//          exact in fp32 to 1e-7 of the softmax weight, where a raw score of +-80 would carry 4e-6) and that maximum as a
+//          float64 in two dwords.
+template <int PHASE, bool F64 = false>
 __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSplit& sp, int g, int b) {
     __shared__ float4 slots[VSP_SLOTS][VIS_CPL * 64];
     __shared__ float s_score[64];
+    __shared__ double s_score64[F64 ? 32 : 1];
     __shared__ int s_last;
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -187,6 +204,41 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
             x[r][i] = pano_load(prow, v, c, v < V && c < n4, V, n4);
         }
     }
+    float s, m, e;          // F64: s = score - m (relative), m unused (md holds the maximum)
+    double md = 0.0;
+    if (F64) {
+        double dot[VIS_RPW];
+#pragma unroll
+        for (int r = 0; r < VIS_RPW; ++r) dot[r] = 0.0;
+        const double* qrow = a.vec64 + (size_t)b * a.ldvec;
+#pragma unroll
+        for (int i = 0; i < VIS_CPL; ++i) {
+            const int c = lane + 64 * i, cc = min(c, n4 - 1);
+            const double2 q0 = reinterpret_cast<const double2*>(qrow)[2 * cc], q1 = reinterpret_cast<const double2*>(qrow)[2 * cc + 1];
+            const double k = c < n4 ? 1.0 : 0.0;
+#pragma unroll
+            for (int r = 0; r < VIS_RPW; ++r) {
+                double t = (double)x[r][i].x * q0.x;
+                t = fma((double)x[r][i].y, q0.y, t);
+                t = fma((double)x[r][i].z, q1.x, t);
+                t = fma((double)x[r][i].w, q1.y, t);
+                dot[r] = fma(t, k, dot[r]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < VIS_RPW; ++r) {
+            const double sd = wave_sum_f64(dot[r]);
+            const int vl = wave * VIS_RPW + r;
+            if (lane == 0) s_score64[vl] = (g * VSP_RPG + vl < V) ? sd : -INFINITY;
+        }
+        __syncthreads();
+        vis_stamp(sp, b * VSP_G + g, 1);
+        const double sd = lane < VSP_RPG ? s_score64[lane] : -INFINITY;
+        md = wave_max_f64(sd);
+        s = sd > -INFINITY ? (float)(sd - md) : -INFINITY;
+        m = 0.f;
+        e = sd > -INFINITY ? expf(s) : 0.f;
+    } else {
     float dot[VIS_RPW];
 #pragma unroll
     for (int r = 0; r < VIS_RPW; ++r) dot[r] = 0.f;
@@ -200,15 +252,16 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
     }
 #pragma unroll
     for (int r = 0; r < VIS_RPW; ++r) {
-        const float s = wave_sum(dot[r]);
+        const float sw = wave_sum(dot[r]);
         const int vl = wave * VIS_RPW + r;
-        if (lane == 0) s_score[vl] = (g * VSP_RPG + vl < V) ? s : -INFINITY;
+        if (lane == 0) s_score[vl] = (g * VSP_RPG + vl < V) ? sw : -INFINITY;
     }
     __syncthreads();
     vis_stamp(sp, b * VSP_G + g, 1);
-    const float s = lane < VSP_RPG ? s_score[lane] : -INFINITY;
-    const float m = wave_max(s);
-    const float e = s > -INFINITY ? expf(s - m) : 0.f;
+    s = lane < VSP_RPG ? s_score[lane] : -INFINITY;
+    m = wave_max(s);
+    e = s > -INFINITY ? expf(s - m) : 0.f;
+    }
     const float l = wave_sum(e);
 
     float4 p[VIS_CPL];
@@ -245,8 +298,12 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
     if (wave == 0) {
         if (lane < 32) __hip_atomic_store(rec + F + lane, s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {
-            __hip_atomic_store(rec + F + 32, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + F + 32, F64 ? __int_as_float(__double2hiint(md)) : m, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(rec + F + 33, l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (F64)
+                __hip_atomic_store(rec + F + 34, __int_as_float(__double2loint(md)), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains
@@ -263,25 +320,41 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
         return PHASE == 0 ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
     };
     float mg[VSP_G], lg[VSP_G];
+    float dm[VSP_G];                                             // F64: m_k - M formed in float64
 #pragma unroll
     for (int k = 0; k < VSP_G; ++k) {
         mg[k] = ldf(r0 + (size_t)k * pstride + F + 32);
         lg[k] = ldf(r0 + (size_t)k * pstride + F + 33);
     }
     float M = mg[0];
+    if (F64) {
+        double m64[VSP_G];
 #pragma unroll
-    for (int k = 1; k < VSP_G; ++k) M = fmaxf(M, mg[k]);
+        for (int k = 0; k < VSP_G; ++k)
+            m64[k] = __hiloint2double(__float_as_int(mg[k]), __float_as_int(ldf(r0 + (size_t)k * pstride + F + 34)));
+        double M64 = m64[0];
+#pragma unroll
+        for (int k = 1; k < VSP_G; ++k) M64 = fmax(M64, m64[k]);
+#pragma unroll
+        for (int k = 0; k < VSP_G; ++k) dm[k] = (float)(m64[k] - M64);       // 0 for the maximal group, -inf for an empty one
+    } else {
+#pragma unroll
+        for (int k = 1; k < VSP_G; ++k) M = fmaxf(M, mg[k]);
+#pragma unroll
+        for (int k = 0; k < VSP_G; ++k) dm[k] = mg[k] - M;
+    }
     float kk[VSP_G], L = 0.f;                                    // m = -inf (empty group): c = 0, l = 0
 #pragma unroll
     for (int k = 0; k < VSP_G; ++k) {
-        kk[k] = expf(mg[k] - M);
+        kk[k] = expf(dm[k]);
         L += lg[k] * kk[k];
     }
     const float inv = 1.0f / L;
     if (tid < V) {
         const int gk = tid / VSP_RPG;
         const float sc = ldf(r0 + (size_t)gk * pstride + F + (tid - gk * VSP_RPG));
-        a.alpha[(size_t)b * V + tid] = expf(sc - M) * inv;
+        // (F64: sc is relative to its group's maximum: sc + dm = score - M, both parts small and exact)
+        a.alpha[(size_t)b * V + tid] = (F64 ? expf(sc + dm[gk]) : expf(sc - M)) * inv;
     }
 #pragma unroll
     for (int k = 0; k < VSP_G; ++k) kk[k] *= inv;
@@ -315,6 +388,9 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
 
 __global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_kernel(VisArgs a, VisSplit sp) {
     visual_split_body<0>(a, sp, blockIdx.x, blockIdx.y);
+}
+__global__ __launch_bounds__(VSP_NW * 64) void visual_attn_split_f64_kernel(VisArgs a, VisSplit sp) {
+    visual_split_body<0, true>(a, sp, blockIdx.x, blockIdx.y);
 }
 
 // =================================================================================================
@@ -767,14 +843,27 @@ __global__ __launch_bounds__(VIS_NW * 64) void pair_visbwd_small_kernel(VisArgs 
 
 size_t visual_attn_split_floats(int B, int F) { return (size_t)B * VSP_G * (F + 64); }
 
+bool visual_attn_f64_supported(const PanoSrc& src, int B) {
+    const int F = src.IMG + src.LOC;
+    return !(src.V > VIS_RPW * VIS_NW || src.V > 64 || F > VIS_CPL * 256 || (F & 3) ||
+             (!src.dense && ((src.IMG & 3) || (src.LOC & 3)))) &&
+           src.V > (VSP_G - 1) * VSP_RPG && src.V <= VSP_G * VSP_RPG && B <= 256;
+}
+
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
                 float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st,
-                float* split_part, unsigned* split_counter) {
+                float* split_part, unsigned* split_counter, const double* vec64) {
     const int F = src.IMG + src.LOC;
     if (src.V > VIS_RPW * VIS_NW || src.V > 64 || F > VIS_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) || (ldvec & 3) || (ldo & 3))
         return SF_ERR_UNSUPPORTED;
-    VisArgs a{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
+    VisArgs a{src, vec, ldvec, alpha, out, ldo, drop, drop_col0, vec64};
+    if (vec64) {        // float64 scores: the two-workgroup forward only (callers check visual_attn_f64_supported)
+        if (mode != 0 || !split_part || !split_counter || !visual_attn_f64_supported(src, B)) return SF_ERR_UNSUPPORTED;
+        SF_LAUNCH(visual_attn_split_f64_kernel, dim3(VSP_G, B), dim3(VSP_NW * 64), 0, st, a,
+                  VisSplit{split_part, split_counter, nullptr});
+        return launch_status();
+    }
     // small batches: two workgroups per sample (see visual_attn_split_kernel)
     if (mode == 0 && split_part && split_counter && src.V > (VSP_G - 1) * VSP_RPG &&
         src.V <= VSP_G * VSP_RPG && B <= 256) {

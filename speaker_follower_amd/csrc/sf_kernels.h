@@ -13,7 +13,14 @@ namespace sf {
 size_t visual_attn_split_floats(int B, int F);
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
                 float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st,
-                float* split_part = nullptr, unsigned* split_counter = nullptr);
+                float* split_part = nullptr, unsigned* split_counter = nullptr, const double* vec64 = nullptr);
+// vec64: the forward with its scores accumulated in float64 from a float64 query (csrc/sf_precise.hip)
+bool visual_attn_f64_supported(const PanoSrc& src, int B);
+
+// ---- sf_precise.hip: y64 = A W^T + bias on the float64 matrix cores (A fp32 or f64; optional fp32 copy) --------
+int linear_f64(const float* A32, const double* A64, int lda, const float* W, int ldw, const float* bias, int M, int N,
+               int K, double* y64, int ldy64, float* y32, int ldy32, hipStream_t st);
+extern int g_precise_attention;       // sf_debug_precise_attention (default 1)
 int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t,
                   int ldt, float* alpha, float* wc, int ldwc, hipStream_t st,
                   const int32_t* ctx_row = nullptr);

@@ -149,6 +149,14 @@ class BucketedGrads(FlatGrads):
         self._works, self.launched = [], []
         return self.flat
 
+    def abort(self):
+        """Gives up the current round of buckets (FollowerEngine.run re-issuing a faulted pass): waits for the
+        all-reduces already in flight -- every rank launched the same ones, the decision to re-issue is taken on a
+        reduced flag -- so that the buffer may be zeroed and the buckets launched again."""
+        for w in self._works:
+            w.wait()
+        self._works, self.launched = [], []
+
 
 def follower_buckets(encoder, decoder):
     """The follower's trainable parameters in the order FollowerEngine._backward completes their gradients:

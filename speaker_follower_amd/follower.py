@@ -23,6 +23,7 @@ from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, trainable_embedding)
 from .runtime import ptr, stream, ws_args, dropout_arg, take_fault, PersistentLaunchFault, concurrent_stream
+from .dp import collectives_on
 
 byref = C.byref
 
@@ -359,8 +360,8 @@ class FollowerEngine:
         (co-residency lost to another process) has poisoned its outputs with NaN, so the SAME rollout -- same
         dropout / sampling sites -- is re-issued in this process with the per-step encoder kernels
         (SF_ENC_PER_STEP), after zeroing the gradients the poisoned backward accumulated.  Under a process group
-        the decision is taken on the OR of all ranks' fault words, so every rank re-issues (and re-enters the
-        gradient collectives) together.  Raises PersistentLaunchFault if a fault is still raised afterwards."""
+        the decision is taken on the MAX of all ranks' fault words, so every rank re-issues together; gradient
+        buckets the poisoned backward had launched are waited for and re-armed (`BucketedGrads.abort`) first.  Raises PersistentLaunchFault if a fault is still raised afterwards."""
         dev = self.store.device
         site, it = self.site_next, self.iteration
 
@@ -369,9 +370,10 @@ class FollowerEngine:
             if backward:
                 st.loss.backward()
             bits = take_fault(dev)
-            if self.group is not None:
+            if self.group is not None and collectives_on(self.group):
+                # (MAX, not BOR: RCCL has no bitwise reductions; the caller only needs "some rank faulted")
                 t = torch.tensor([bits], device=dev, dtype=torch.int32)
-                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.BOR, group=self.group)
+                torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX, group=self.group)
                 bits = int(t.item())
             return st, bits
 
@@ -379,6 +381,10 @@ class FollowerEngine:
         if bits:
             self.fallbacks += 1
             if backward:
+                # the poisoned backward has already launched its gradient buckets (on every rank alike): let them
+                # land before the buffer is zeroed, and re-arm the buckets for the re-issued backward
+                if self.grad_sync is not None:
+                    self.grad_sync.abort()
                 for p_ in st.all_params:
                     if p_.grad is not None:
                         p_.grad.zero_()

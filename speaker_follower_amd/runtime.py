@@ -128,6 +128,26 @@ def ws_args(device):
     return C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), stream()
 
 
+# ---- strict summation order of the gate products (include/sf_hip.h: sf_gate_product_strict) -----------------
+class strict_gate_product:
+    """`with runtime.strict_gate_product():` -- the LSTM gate products on the fp32 MFMA (the summation order with which
+    the state-factored search reproduces the reference's traversal at exact fp32 ties too) instead of the bf16x6 split
+    products.  Process-wide switch; restores the previous setting on exit.  Captured graphs keep the kernels they were
+    captured with: capture inside the block what is to replay strictly."""
+
+    def __init__(self, on=True):
+        self.on = bool(on)
+
+    def __enter__(self):
+        self.prev = int(lib.sf_gate_product_is_strict())
+        lib.sf_gate_product_strict(int(self.on))
+        return self
+
+    def __exit__(self, *exc):
+        lib.sf_gate_product_strict(self.prev)
+        return False
+
+
 # ---- the fault word of the persistent launches (include/sf_hip.h: sf_workspace_fault_offset) ----------------
 FAULT_ENC_FWD, FAULT_ENC_BWD, FAULT_SPEAKER, FAULT_LOCK = 1, 2, 4, 8
 

@@ -381,7 +381,8 @@ class GraphStep:
 def graph_step_for(agent, nav, n_inst, cap):
     """The agent's GraphStep for these sizes (built on first use, kept on the agent)."""
     t_max = agent.max_instruction_length
-    key = (id(agent.decoder), id(agent.store), id(nav), n_inst, cap, t_max)
+    # (a captured step keeps the gate-product kernel it was captured with: runtime.strict_gate_product)
+    key = (id(agent.decoder), id(agent.store), id(nav), n_inst, cap, t_max, int(_lib.lib.sf_gate_product_is_strict()))
     cache = agent.__dict__.setdefault('_graph_steps', {})
     gs = cache.get(key)
     if gs is None or gs.dec is not agent.decoder or gs.store is not agent.store or gs.nav is not nav:

@@ -59,6 +59,10 @@ def main():
                 h, c, alpha, logit = sdec(w_t.view(-1, 1), h, c, ctx, torch.from_numpy(path_mask).bool())
                 logits.append(logit.numpy().copy())
                 w_t = torch.from_numpy(words[st])                   # the fp32 golden's sequence, both modes
+            # every word step at 8 fixed vocabulary columns (round 5: the bound is asserted along the whole pass)
+            cols = np.array([2, 57, 130, 333, 512, 700, 871, 990])
+            out['cols'] = cols
+            out[feedback + '/logits_cols'] = np.stack([l[:, cols] for l in logits]).astype(np.float32)
             out[feedback + '/logits_first'] = logits[0].astype(np.float32)
             out[feedback + '/logit_last'] = logits[-1].astype(np.float32)
             print('%-8s fp32 reference vs its float64 evaluation: step 0 %.3e, step %d %.3e (max|logit| %.2f)' % (

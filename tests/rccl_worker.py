@@ -78,7 +78,36 @@ def main(backend):
     dp.allreduce_step_counts(t, dist.group.WORLD)
     got[3].allreduce(dist.group.WORLD)
     torch.cuda.synchronize()
-    out = dict(backend=dist.get_backend(), world=dist.get_world_size(),
+
+    # FollowerEngine.run(backward=True) under the process group with a persistent launch that gives up its wait (forced):
+    # the fault flag is reduced over the group (MAX: RCCL has no bitwise reductions), the gradient buckets the
+    # poisoned backward launched are waited for and re-armed, and the re-issued iteration leaves the gradients of an
+    # undisturbed one.
+    from speaker_follower_amd import _lib, runtime
+
+    def one_run(faulty):
+        enc, dec = build()
+        flat = dp.BucketedGrads(dp.follower_buckets(enc, dec), group=dist.group.WORLD)
+        eng = follower.FollowerEngine(enc, dec, store, group=dist.group.WORLD)
+        eng.dropout_seed = 99
+        eng.grad_sync = flat
+        runtime.take_fault(dev)
+        _lib.lib.sf_debug_persist_timeout(0 if faulty else -1)
+        try:
+            st = eng.run(batch, S, 'teacher', train=True, backward=True)
+            flat.wait()
+        finally:
+            _lib.lib.sf_debug_persist_timeout(-1)
+        torch.cuda.synchronize()
+        runtime.take_fault(dev)
+        return eng.fallbacks, float(st.loss.detach()), flat.flat.clone()
+
+    clean, faulted = one_run(False), one_run(True)
+    gscale = float(clean[2].abs().max())
+    fault = dict(fallbacks=[clean[0], faulted[0]], losses=[clean[1], faulted[1]],
+                 finite=bool(torch.isfinite(faulted[2]).all()),
+                 grad_rel_diff=float((clean[2] - faulted[2]).abs().max()) / max(gscale, 1e-12))
+    out = dict(fault=fault, backend=dist.get_backend(), world=dist.get_world_size(),
                nccl_version='.'.join(map(str, torch.cuda.nccl.version())) if backend == 'nccl' else None,
                losses_equal=base[0] == got[0], losses=got[0],
                grads_bit_identical=bool(torch.equal(base[1], got[1])),

@@ -113,9 +113,26 @@ def test_peaky_weights_b100_train_mode_loss_and_gradients(golden, two_stream):
     check_grads({k: p.grad for k, p in dec.named_parameters() if p.grad is not None}, g, 'dec/')
 
 
+@pytest.mark.parametrize('gate_product', ['bf16x6', 'fp32'])
 @pytest.mark.parametrize('feedback', ['teacher', 'argmax'])
-def test_speaker_b100_golden(golden, feedback):
-    from speaker_follower_amd import model, features, speaker
+def test_speaker_b100_golden(golden, feedback, gate_product):
+    """G9: the speaker at B = 100 on the reference's peaky weights (attention scores up to +-80, |logit| up to 17).
+
+    north_star: logits within 1e-4 ABSOLUTE of the reference.  The reference's own fp32 output lies 2.3e-4 (word step
+    0) / 0.98e-4 (teacher, step 79) / 1.36e-4 (argmax, step 39) from the SAME modules evaluated in float64
+    (tests/golden/make_golden_f64.py): at this scale an fp32 evaluation of the path encoder's attention chain loses
+    2e-6 .. 9e-6 per stage in the softmax weights and the 7-step context carries it into every word step
+    (tools/speaker_drift.py).  Rounds 1-4 ran the same chain in fp32 and sat at 1.5e-4 .. 2.1e-4; since round 5 the
+    encoder's query and scores are float64 (csrc/sf_precise.hip) and the bound is asserted WITHOUT widening:
+      * every word step (8 vocabulary columns of all rows), the first and the last step (all columns): within 1e-4
+        absolute of the float64 anchor -- measured 5e-5;
+      * never further from exact arithmetic than the reference's own fp32 run is, at the first and the last step;
+      * against the fp32 golden itself only what the triangle inequality allows: 1e-4 + the golden's own distance.
+    The default gate product (bf16x6 split) is held to all three.  The STRICT order (fp32 MFMA gate product,
+    runtime.strict_gate_product: 1 216 fp32 roundings per gate where the split form has 152) is the less accurate
+    kernel -- 2.9e-7 against 1.1e-7 per step in h (tools/speaker_drift.py) -- and is held to 1e-4 at word step 0 and
+    along the pass, and at the last step to the triangle bound only (measured 0.5e-4 teacher / 1.4e-4 argmax)."""
+    from speaker_follower_amd import model, features, speaker, _lib
     g = golden('g9_speaker_b100_' + feedback)
     d = synth.FULL
     senc_w, sdec_w = synth.speaker_weights_peaky(int(g['weight_seed']))
@@ -129,34 +146,33 @@ def test_speaker_b100_golden(golden, feedback):
     store = features.FeatureStore(synth.feature_table(int(g['table_seed']), 256))
     batch = speaker.DeviceSpeakerBatch.from_synth(sb)
     n = int(g['n_steps'])
-    with torch.set_grad_enabled(feedback == 'teacher'):
-        st = speaker.SpeakerEngine(enc, dec, store).score(batch, n, feedback, train=False)
+    _lib.lib.sf_debug_gate_product_f32(1 if gate_product == 'fp32' else 0)
+    try:
+        with torch.set_grad_enabled(feedback == 'teacher'):
+            st = speaker.SpeakerEngine(enc, dec, store).score(batch, n, feedback, train=False)
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib.sf_debug_gate_product_f32(0)
     np.testing.assert_array_equal(st.words[1:].cpu().numpy(), g['words'])        # bit-exact greedy words
     lg = st.logits.detach().cpu().numpy()
     scale = float(np.abs(g['logit_last']).max())
     assert scale > 5.0
-    # north_star: within 1e-4 ABSOLUTE of the reference.  At this logit scale (|logit| 11 .. 17) the reference's OWN fp32
-    # output lies 2.3e-4 (word step 0) / 1.0e-4 (teacher, step 79) / 1.4e-4 (argmax, step 39) from the SAME reference
-    # modules evaluated in float64 (tests/golden/make_golden_f64.py): its summation order alone costs more than the
-    # bound, so the fp32 golden cannot anchor a 1e-4 comparison.  The bound is therefore NOT scaled but asserted
-    #   * at word step 0 (no recurrence behind it yet) against the exact-arithmetic anchor: measured 3.1e-5 .. 4.4e-5;
-    #   * at the LAST word step -- 40 / 80 dependent fp32 steps of a recurrence that amplifies a 1e-7 difference a
-    #     thousandfold, for the reference's arithmetic exactly as for any other -- against the anchor widened by the
-    #     reference's own measured distance from it: any two fp32 evaluations (the reference's, this one) are two
-    #     draws of that drift.  Measured: reference 0.98e-4 / 1.36e-4, HIP 0.9e-4 .. 1.9e-4 depending on the kernel
-    #     generation (fp32 MFMA gate product: 0.92e-4 / 1.49e-4; bf16-split gate product: 1.51e-4 / 1.85e-4).
-    # Against the fp32 golden itself only what the triangle inequality allows is asserted.  All figures are printed.
     f64 = golden('g9_speaker_b100_f64')
+    tag = 'G9 speaker B=100 %s (%s gate product)' % (feedback, gate_product)
+    cols = f64['cols']
+    assert_logits_close(lg[:, :, cols], f64[feedback + '/logits_cols'], tag + ', EVERY word step at 8 columns, vs float64')
     for name, got, key in (('word step 0', lg[0], 'first'), ('word step %d' % (n - 1), lg[n - 1], 'last')):
         anchor = f64['%s/%s' % (feedback, 'logits_first' if key == 'first' else 'logit_last')]
         ref32 = g['logits_first'][0] if key == 'first' else g['logit_last']
         own = float(f64['%s/ref32_dist_%s' % (feedback, key)])
-        drift = own if key == 'last' else 0.0
-        assert_logits_close(got, anchor, 'G9 speaker B=100 %s, %s, vs the reference in float64' % (feedback, name),
-                            atol=1e-4 + drift)
+        strict_last = gate_product == 'fp32' and key == 'last'
+        dist = assert_logits_close(got, anchor, '%s, %s, vs the reference in float64' % (tag, name),
+                                   atol=1e-4 + own if strict_last else 1e-4)
         d32 = float(np.abs(got - ref32).max())
         print('[parity]   ... vs the fp32 golden: %.3e; the fp32 golden is itself %.3e from its float64 evaluation' % (d32, own))
-        assert d32 <= 1e-4 + drift + own
+        if not strict_last:
+            assert dist <= own, 'further from exact arithmetic (%.3e) than the reference\'s own fp32 run (%.3e)' % (dist, own)
+        assert d32 <= 1e-4 + own + (own if strict_last else 0.0)
     if 'ctx_rows4' in g:
         np.testing.assert_allclose(st.ctx.detach().cpu().numpy()[::4], g['ctx_rows4'], rtol=1e-4, atol=1e-4)
     np.testing.assert_allclose(float(st.loss), g['loss'], rtol=1e-4)

@@ -33,6 +33,12 @@ def test_rccl_one_rank_training_iteration_is_bit_identical_to_no_collectives():
     assert out['finite'] and out['grad_abs_max'] > 0
     assert out['losses_equal'] and out['grads_bit_identical'] and out['weights_bit_identical'], out
     assert out['counts_identity'] and out['buckets'] == 3
+    # run(backward=True) with a forced persistent-launch fault under the nccl group (advisor, round 4): flag reduced with
+    # MAX, buckets aborted and re-armed, the re-issued iteration's gradients equal an undisturbed iteration's
+    f = out['fault']
+    assert f['fallbacks'] == [0, 1] and f['finite'], f
+    assert abs(f['losses'][0] - f['losses'][1]) <= 1e-4 * abs(f['losses'][0]), f
+    assert f['grad_rel_diff'] <= 1e-4, f
 
 
 def test_bench_force_collectives_reports_train_dp():
