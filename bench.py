@@ -62,7 +62,7 @@ def parse(argv=None):
                          'a half-batch chain is as long as a full one)')
     ap.add_argument('--in-flight', type=int, default=2,
                     help='extra measurement: this many independent batch-100 rollouts in flight on separate streams')
-    ap.add_argument('--cpu-reps', type=int, default=2)
+    ap.add_argument('--cpu-reps', type=int, default=5, help='timed CPU-port rollouts behind one warm-up (median reported)')
     ap.add_argument('--two-stream-forward', action='store_true', help='(experiment) visual half on a side stream, device-flag ordering')
     # test-only switches: exercise the N > 1 code path (launcher, rendezvous, collectives, JSON) on a
     # box with ONE GPU.  Ranks share cuda:0 and reduce through gloo; the line is marked oversubscribed.
@@ -71,9 +71,19 @@ def parse(argv=None):
     ap.add_argument('--force-collectives', action='store_true',
                     help='(test) --gpus 1 only: initialise the process group (world size 1) and issue every collective of '
                          'the data-parallel path anyway -- RCCL executes on this GPU; adds `train_dp` to the line')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='weak (default): every rank takes its own batch of --batch rows; strong: ONE global batch of --batch '
+                         'rows (the reference\'s batch is 100 globally, train.py:28) split over the ranks with dp.shard_rows')
     ap.add_argument('--plan', action='store_true',
                     help='print the child commands / environment `--gpus N` would start (JSON) and exit; touches no GPU')
     return ap.parse_args(argv)
+
+
+def _shard(n_rows, rank, world):
+    """dp.shard_rows without importing the package (the --plan path touches neither torch nor the GPU)."""
+    base, rem = divmod(n_rows, world)
+    start = rank * base + min(rank, rem)
+    return slice(start, start + base + (1 if rank < rem else 0))
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -165,9 +175,9 @@ def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps, threa
     loc = np_env.static_loc_embeddings()
     seq, mask, lens = np_env.batch_instructions_from_encoded(fb.instr, 80, reverse=True)
     B = len(lens)
-    best, res = None, None
+    rates, res = [], None
     with threadpool_limits(limits=threads):
-        for _ in range(reps):
+        for rep in range(reps + 1):           # one warm-up, then `reps` timed, MEDIAN
             t0 = time.perf_counter()
             res = np_model.follower_rollout(
                 enc_w, dec_w, seq, lens, mask, decode_steps,
@@ -175,18 +185,20 @@ def cpu_baseline(enc_w, dec_w, fb, table_rows, row_of, decode_steps, reps, threa
                 2176, early_exit=False)       # same work as the GPU: every step for every row
             dt = time.perf_counter() - t0
             n = len(res['logits'])
-            rate = B * n / dt
-            best = rate if best is None else max(best, rate)
+            if rep > 0:
+                rates.append(B * n / dt)
     cores = threads if threads else os.cpu_count()
-    return dict(value=best, unit='agent-steps/s', cores=cores, kind='port',
+    return dict(value=float(np.median(rates)), unit='agent-steps/s', cores=cores, kind='port',
                 sample='%d full rollouts of the same batch (B=%d, %d decode steps, encoder included), '
-                       'numpy oracle, %d thread%s, best of %d'
-                       % (reps, B, n, cores, '' if cores == 1 else 's (BLAS pool)', reps)), res
+                       'numpy oracle, %d thread%s: 1 warm-up + %d timed, median (min %.0f, max %.0f)'
+                       % (reps + 1, B, n, cores, '' if cores == 1 else 's (BLAS pool)', reps, min(rates), max(rates))), res
 
 
-def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1, coll=None):
+def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1, coll=None, global_rows=None):
     """follower.py:1001-1020 + train.py:263-268 per iteration: zero_grad, student-forcing rollout with
-    loss, backward, [gradient all-reduce,] Adam(lr 1e-4, weight_decay 5e-4) on encoder and decoder."""
+    loss, backward, [gradient all-reduce,] Adam(lr 1e-4, weight_decay 5e-4) on encoder and decoder.
+    `global_rows`: rows of the whole job per iteration (strong scaling: `batch` is this rank's shard of ONE global
+    batch); default = batch rows x world (weak scaling)."""
     import torch
     from speaker_follower_amd import follower, dp, optim
     coll = world > 1 if coll is None else coll       # collectives issued (world > 1, or forced at one rank)
@@ -267,6 +279,25 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
                   buckets_bytes=[4 * (hi - lo) for lo, hi in flat.bounds],
                   schedule='buckets in production order (decoder LSTM, other decoder weights, encoder), each all-reduce '
                            'launched async behind the launches that complete it; wait before Adam')
+    # the fault words of the persistent launches (0 = healthy), and the production entry point once: FollowerEngine.run
+    # (rollout + backward + fault check, the flag reduced over the group, per-step re-issue on a fault) -- per rank
+    from speaker_follower_amd import runtime as _rt
+    faults = _rt.take_fault(store.device)
+    health = None
+    if coll:
+        engine.grad_sync = flat
+        for _ in range(2):
+            flat.zero()
+            engine.run(batch, S, 'argmax', train=True, backward=True)
+            flat.wait()
+        engine.grad_sync = None
+        torch.cuda.synchronize()
+        mine = torch.tensor([faults, engine.fallbacks], device=store.device, dtype=torch.int32)
+        every = [torch.zeros_like(mine) for _ in range(torch.distributed.get_world_size(group))]
+        torch.distributed.all_gather(every, mine, group=group)
+        health = dict(persistent_launch_faults=[int(t[0]) for t in every], fallbacks=[int(t[1]) for t in every],
+                      note='per rank; faults = fault words raised by the timed iterations (0 = every persistent launch '
+                           'completed), fallbacks = iterations FollowerEngine.run re-issued on the per-step kernels')
     kernels = None
     if world == 1 and not coll:   # per-kernel table of the iteration, measured in this run (both backward streams)
         from speaker_follower_amd import bench_extras
@@ -279,12 +310,17 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
                             'executed FLOPs = 3 x the forward (data + weight gradients), encoder excluded')
     enc.eval()
     dec.eval()
-    return dict(value=B * S * world / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
-                roofline=kernels,
+    rows = B * world if global_rows is None else global_rows
+    return dict(value=rows * S / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
+                scaling='weak' if global_rows is None else 'strong', global_batch=rows, rows_this_rank=B,
+                roofline=kernels, health=health,
                 allreduce_bytes=flat.flat.numel() * 4, **ar,
-                what='student-forcing rollout (dropout 0.5) + BPTT + %s2x Adam (one HIP launch each), batch %d per GPU, '
+                what='student-forcing rollout (dropout 0.5) + BPTT + %s2x Adam (one HIP launch each), %s, '
                      '%d decode steps, eager issue' % ('bucketed sum all-reduce over %d ranks overlapped with the backward + ' % world
-                                                       if world > 1 else '', B, S),
+                                                       if world > 1 else '',
+                                                       'batch %d per GPU' % B if global_rows is None else
+                                                       'ONE global batch of %d rows split over %d ranks (dp.shard_rows; %d here)'
+                                                       % (rows, world, B), S),
                 loss=float(st.loss.detach()))
 
 
@@ -372,6 +408,10 @@ def main(argv=None):
         child_argv = [a for a in argv if a != '--plan']
         print(json.dumps(dict(launcher='self' if 'WORLD_SIZE' not in os.environ else 'external (torch.distributed.run)',
                               backend=args.backend, collective='RCCL over xGMI' if args.backend == 'nccl' else 'gloo',
+                              scaling=args.scaling,
+                              rows_per_rank=[(lambda sl: sl.stop - sl.start)(_shard(args.batch, r, max(1, args.gpus)))
+                                             if args.scaling == 'strong' else args.batch for r in range(max(1, args.gpus))],
+                              global_batch=args.batch if args.scaling == 'strong' else args.batch * max(1, args.gpus),
                               ranks=[dict(cmd=cmd, env={k: env[k] for k in keys if k in env})
                                      for cmd, env in launch_plan(max(1, args.gpus), child_argv)]), indent=1))
         return
@@ -416,8 +456,17 @@ def main(argv=None):
     B, S = args.batch, args.decode_steps
     table = device_table(args.n_viewpoints, 1234, device)
     store = features.FeatureStore(table, device=device)
-    fb = synth.follower_batch(seed=rank, batch=B, steps=S, n_viewpoints=args.n_viewpoints)
-    batch = follower.DeviceFollowerBatch.from_synth(fb, device=device, row0=rank * B)
+    from speaker_follower_amd import dp as _dp_rows
+    strong = args.scaling == 'strong'
+    if strong:
+        # ONE global batch (the same on every rank), this rank's contiguous rows of it; dropout / sampling streams are
+        # keyed on the GLOBAL row id, so the sharded job draws what the unsharded batch would
+        fb = synth.follower_batch(seed=0, batch=B, steps=S, n_viewpoints=args.n_viewpoints)
+        my_rows = _dp_rows.shard_rows(B, rank, world)
+        batch = follower.DeviceFollowerBatch.from_synth(fb, device=device, rows=my_rows, row0=my_rows.start)
+    else:
+        fb = synth.follower_batch(seed=rank, batch=B, steps=S, n_viewpoints=args.n_viewpoints)
+        batch = follower.DeviceFollowerBatch.from_synth(fb, device=device, row0=rank * B)
     train = args.workload == 'train'
     engine = follower.FollowerEngine(enc, dec, store, group=group if train else None)
     engine.two_stream_forward = args.two_stream_forward
@@ -486,7 +535,7 @@ def main(argv=None):
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
-    agent_steps = B * S * world * args.steps
+    agent_steps = B * S * (1 if strong else world) * args.steps
     value = agent_steps / elapsed
     if shard_states is not None:                # outside the timed region: stitch shard results
         graph_state.actions = torch.cat([x.actions for x in shard_states], dim=1)
@@ -496,7 +545,17 @@ def main(argv=None):
     # same per-GPU batch, with the gradient all-reduce timed on its own.  Every rank takes part.
     train_dp = None
     if (extras or forced) and coll and not train and not args.no_train_extra:
-        train_dp = measure_train(enc, dec, store, batch, S, max(3, args.steps // 4), 2, group=group, world=world, coll=coll)
+        n_it = max(3, args.steps // 4)
+        if strong:
+            train_dp = measure_train(enc, dec, store, batch, S, n_it, 2, group=group, world=world, coll=coll, global_rows=B)
+        else:
+            train_dp = measure_train(enc, dec, store, batch, S, n_it, 2, group=group, world=world, coll=coll)
+            # ... and the reference's own semantics next to it: ONE global batch of B rows split over the ranks
+            fb_g = synth.follower_batch(seed=0, batch=B, steps=S, n_viewpoints=args.n_viewpoints)
+            rws = _dp_rows.shard_rows(B, rank, world)
+            batch_g = follower.DeviceFollowerBatch.from_synth(fb_g, device=device, rows=rws, row0=rws.start)
+            train_dp['strong'] = measure_train(enc, dec, store, batch_g, S, n_it, 2, group=group, world=world, coll=coll,
+                                               global_rows=B)
         if forced:
             train_dp['forced_collectives'] = ('TEST RUN: one rank, every collective of the data-parallel path issued anyway '
                                               '(%s); proves the path executes, says nothing about scaling' % args.backend)
@@ -601,15 +660,15 @@ def main(argv=None):
 
     out = dict(metric='agent-steps/sec (follower rollout, batch %d)' % B, value=value,
                unit='agent-steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
-               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling='weak',
+               ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling=args.scaling,
                vs_baseline=None, dtype='f32', data='synthetic',
-               config=dict(workload='follower %s: batch %d per GPU, 36 views x 2048-d features from a '
+               config=dict(workload='follower %s: batch %d ' + ('GLOBALLY, split over the ranks' if strong else 'per GPU') + ', 36 views x 2048-d features from a '
                                     '%d-viewpoint HBM table, <=80-token instructions, %d decode steps, '
                                     'argmax (student-forcing) feedback, every step executed for every row (no early exit), encoder included%s'
                                     % (args.workload, B, args.n_viewpoints, S,
                                        ', batch run as %d concurrent row shards' % args.row_shards
                                        if shard_states else ''),
-                           global_batch=B * world, parallelism='dp%d' % world),
+                           global_batch=B if strong else B * world, parallelism='dp%d' % world),
                roofline=roofline, concurrent=concurrent, loss=float(st.loss_buf),
                launch=('hipGraph replay, %d concurrent row shards' % args.row_shards if shard_states
                        else 'hipGraph replay') if replay else 'eager')
@@ -678,6 +737,15 @@ def main(argv=None):
     sys.stdout.flush()
     if coll:
         torch.distributed.destroy_process_group()
+    # a data-parallel run in which ANY rank's persistent launch gave up a wait is not a valid measurement: say so
+    # with the exit status (the line above still carries the per-rank words)
+    bad = out['persistent_launch_faults'] != 0
+    for td in (train_dp, (train_dp or {}).get('strong')):
+        if td and td.get('health') and any(td['health']['persistent_launch_faults']):
+            bad = True
+    if bad:
+        sys.stderr.write('bench.py: persistent-launch faults were raised (see persistent_launch_faults / train_dp.health)\n')
+        sys.exit(3)
 
 
 if __name__ == '__main__':

@@ -693,6 +693,12 @@ void sf_debug_force_write_through(int on);
  * (< 0 restores the default, 0.25 s).  0 makes the first unsatisfied poll give up: the launch poisons its outputs
  * and raises its fault bit -- how the tests exercise the host's fallback to the per-step kernels. */
 void sf_debug_persist_timeout(long long ticks);
+/* Test co-tenant: `blocks` workgroups of `threads` threads with `lds_bytes` (<= 65536) of LDS each that stay resident
+ * for `ticks` x 10 ns, touching LDS and (sink != NULL: [blocks] floats) a little global memory -- the shape of a
+ * collective's channel workgroups (RCCL: a few dozen workgroups of 256-512 threads) -- to be launched on ANOTHER stream
+ * beside the persistent launches (tests/test_gpu_cotenancy.py: data-parallel training launches the first gradient
+ * bucket's all-reduce beside the persistent encoder backward). */
+int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, sf_stream stream);
 /* STRICT summation order for the LSTM gate products (supported runtime switch, round 5).  on != 0: the large gate
  * products (K >= 2048, M <= 128: sf_lstm_cell_fwd, the decode step, the search step) run on the fp32 MFMA
  * (v_mfma_f32_16x16x4_f32, the kernel of rounds 1-3) instead of the bf16 matrix cores with three-way error-free operand

@@ -137,6 +137,7 @@ _SIGNATURES = {
     'sf_debug_persist_timeout': (None, [C.c_longlong]),
     'sf_debug_gate_product_f32': (None, [C.c_int]),
     'sf_debug_precise_attention': (None, [C.c_int]),
+    'sf_debug_cotenant': (C.c_int, [i32, i32, i32, C.c_longlong, c_f, c_p]),
     'sf_gate_product_strict': (None, [C.c_int]),
     'sf_gate_product_is_strict': (C.c_int, []),
     'sf_debug_tn_split_min_rows': (None, [C.c_int]),

@@ -428,6 +428,10 @@ int sf_abi_version(void) { return SF_ABI_VERSION; }
 const char* sf_build_id(void) { static const char id[] = "SF_BUILD_ID=" SF_BUILD_ID; return id + 12; }
 void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; }
 void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
+int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, sf_stream stream) {
+    SF_ENTER();
+    return sf::cotenant(blocks, threads, lds_bytes, ticks, sink, S(stream));
+}
 void sf_gate_product_strict(int on) { sf::g_nt_force_f32 = on ? 1 : 0; }
 int sf_gate_product_is_strict(void) { return sf::g_nt_force_f32 != 0; }
 void sf_debug_precise_attention(int on) { sf::g_precise_attention = on; }

@@ -118,6 +118,7 @@ int dot_rows_accum(const float* s, const float* x, int ldx, int M, int N, float*
                    hipStream_t st);        // out[n] += sum_m s[m] * x[m,n]
 int sum_accum(const float* s, int M, float* out, hipStream_t st);   // out[0] += sum_m s[m]
 int fill(float* p, size_t n, float v, hipStream_t st);
+int cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, hipStream_t st);   // sf_debug_cotenant
 // device-flag ordering between two streams (sf_pointwise.hip)
 int flag_wait(const unsigned* flag, unsigned target, hipStream_t st);
 int flag_set(unsigned* flag, unsigned value, hipStream_t st);

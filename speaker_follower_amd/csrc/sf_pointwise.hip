@@ -839,6 +839,29 @@ int flag_set(unsigned* flag, unsigned value, hipStream_t st) {
     return launch_status();
 }
 
+// Test co-tenant (sf_debug_cotenant): a kernel shaped like a collective's channel workgroups -- a few dozen large
+// workgroups with a big LDS allocation that stay resident for a given time, touching LDS and a little global memory --
+// to run beside the persistent launches on another stream (tests/test_gpu_cotenancy.py).
+__global__ void cotenant_kernel(long long ticks, float* sink) {
+    extern __shared__ float co_lds[];
+    const long long t0 = wall_clock64();
+    const int i = threadIdx.x, n = blockDim.x;
+    float acc = (float)i;
+    while (wall_clock64() - t0 < ticks) {
+        co_lds[i] = acc;
+        __syncthreads();
+        acc = acc * 0.5f + co_lds[(i * 33 + 7) % n];
+        __syncthreads();
+        if (sink && i == 0) sink[blockIdx.x] = acc;
+        __builtin_amdgcn_s_sleep(4);
+    }
+}
+int cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, hipStream_t st) {
+    if (blocks <= 0 || threads <= 0 || threads > 1024 || lds_bytes < threads * 4 || lds_bytes > 65536) return SF_ERR_ARG;
+    SF_LAUNCH(cotenant_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, st, ticks, sink);
+    return launch_status();
+}
+
 int fill(float* p, size_t n, float v, hipStream_t st) {
     if (n == 0) return SF_OK;
     SF_LAUNCH(fill_kernel, dim3(grid1d(n)), dim3(TPB), 0, st, p, n, v);

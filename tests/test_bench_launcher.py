@@ -74,3 +74,19 @@ def test_kernel_work_prices_the_gate_product_like_survey_8d():
     assert abs(by - 42.6e6) < 0.1e6
     fl, by, _ = bench.kernel_work('lstm_step_wide_kernel<2>', 100, 20, 80, 5.0, (512, 2176, 256, 36))
     assert fl == 2.0 * 100 * 512 * 2048
+
+
+def test_plan_shows_the_strong_scaling_mode(capsys):
+    """`--scaling strong`: ONE global batch of 100 (train.py:28) split over the ranks with dp.shard_rows -- the plan says
+    how many rows each rank takes; the default stays weak (100 rows per GPU)."""
+    import json
+    from speaker_follower_amd import dp
+    bench.main(['--gpus', '8', '--plan', '--scaling', 'strong'])
+    plan = json.loads(capsys.readouterr().out)
+    assert plan['scaling'] == 'strong' and plan['global_batch'] == 100
+    assert plan['rows_per_rank'] == [13, 13, 13, 13, 12, 12, 12, 12]
+    assert plan['rows_per_rank'] == [(lambda s: s.stop - s.start)(dp.shard_rows(100, r, 8)) for r in range(8)]
+    assert all(r['cmd'][-2:] == ['--scaling', 'strong'] for r in plan['ranks'])
+    bench.main(['--gpus', '8', '--plan'])
+    plan = json.loads(capsys.readouterr().out)
+    assert plan['scaling'] == 'weak' and plan['global_batch'] == 800 and plan['rows_per_rank'] == [100] * 8

@@ -218,3 +218,24 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     # the bucketed schedule: decoder LSTM (weight_ih, weight_hh, two biases), other decoder weights, encoder
     assert t['buckets_bytes'] == [4 * (2048 * 4352 + 2048 * 512 + 4096), 4 * (12129537 - 2048 * 4864 - 4096), 4 * 1929728]
     assert t['allreduce_exposed_ms_overlapped'] >= 0 and t['ms_per_iteration_no_exchange'] > 0
+    # per-rank health of the persistent launches + the production entry point (FollowerEngine.run) under the group
+    assert t['scaling'] == 'weak' and t['health']['persistent_launch_faults'] == [0, 0] and t['health']['fallbacks'] == [0, 0]
+    # the reference's own semantics next to it: ONE global batch split over the ranks
+    ts = t['strong']
+    assert ts['scaling'] == 'strong' and ts['global_batch'] == 16 and ts['rows_this_rank'] == 8
+    assert ts['health']['persistent_launch_faults'] == [0, 0] and np.isfinite(ts['loss'])
+
+
+def test_bench_strong_scaling_two_ranks_on_one_gpu_over_gloo():
+    """`--scaling strong`: the headline loop itself over ONE global batch split with dp.shard_rows."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-gpu',
+                          '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--n-viewpoints', '96',
+                          '--batch', '18', '--decode-steps', '5', '--scaling', 'strong', '--no-cpu-baseline'],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT,
+                         env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
+    assert out.returncode == 0, out.stderr[-3000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
+    assert d['scaling'] == 'strong' and d['n_gpus'] == 2 and d['config']['global_batch'] == 18
+    assert abs(d['value'] - 18 * 5 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
+    t = d['train_dp']
+    assert t['scaling'] == 'strong' and t['global_batch'] == 18 and t['rows_this_rank'] == 9 and 'strong' not in t
