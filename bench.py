@@ -662,10 +662,11 @@ def main(argv=None):
                unit='agent-steps/s', n_gpus=world, steps=args.steps, warmup=args.warmup,
                ms_per_step=1e3 * elapsed / args.steps, higher_is_better=True, scaling=args.scaling,
                vs_baseline=None, dtype='f32', data='synthetic',
-               config=dict(workload='follower %s: batch %d ' + ('GLOBALLY, split over the ranks' if strong else 'per GPU') + ', 36 views x 2048-d features from a '
+               config=dict(workload='follower %s: batch %d %s, 36 views x 2048-d features from a '
                                     '%d-viewpoint HBM table, <=80-token instructions, %d decode steps, '
                                     'argmax (student-forcing) feedback, every step executed for every row (no early exit), encoder included%s'
-                                    % (args.workload, B, args.n_viewpoints, S,
+                                    % (args.workload, B, 'GLOBALLY, split over the ranks' if strong else 'per GPU',
+                                       args.n_viewpoints, S,
                                        ', batch run as %d concurrent row shards' % args.row_shards
                                        if shard_states else ''),
                            global_batch=B if strong else B * world, parallelism='dp%d' % world),
