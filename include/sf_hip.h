@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 7
+#define SF_ABI_VERSION 8
 
 enum {
     SF_OK = 0,
@@ -48,7 +48,24 @@ typedef struct sf_dropout {
     float p;
     uint32_t seed;
     int32_t row0; /* global id of local row 0 (data-parallel shards pass their offset) */
+    /* Device-side site offset (ABI 8, optional: NULL = none).  A kernel forms its mask for site
+     * `stream_id + site_mul * *site_dev`: the stream ids the host passes are then RELATIVE to a counter that lives in
+     * device memory, and a hipGraph that captured a training iteration draws fresh masks on every replay once
+     * sf_site_advance (captured at the end of the iteration) has moved the counter -- kernel arguments are frozen in a
+     * graph, device memory is not.  Entry points that number their sites 2 * step_id + k internally (the decoder
+     * steps) scale the offset by 2 themselves; site_mul (0 = 1) scales it for entry points that take a raw stream
+     * id, so that host and device numbering agree: a replay draws exactly the masks of the eager iteration whose
+     * host-side site counter equals the device word. */
+    const uint32_t* site_dev;
+    uint32_t site_mul;
 } sf_dropout;
+/* *word += by, on the stream (one thread): advances a device-side site counter (sf_dropout.site_dev,
+ * sf_sample.stream_dev, sf_follower_glue.sample_site_dev). */
+int sf_site_advance(uint32_t* word, uint32_t by, sf_stream stream);
+/* dst[0..3] = a, b, c, d on the stream (values travel as kernel arguments: no host buffer to keep alive).  How the host
+ * hands a replayed training graph its per-replay inputs -- site counter and optimizer step counters -- in ONE tiny
+ * launch in front of the graph launch (runtime.TrainingGraph). */
+int sf_store_u32x4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, sf_stream stream);
 
 /* Panorama rows of a batch: either the dense [B,V,F] tensor the reference's
  * Seq2SeqAgent._feature_variables builds (follower.py:291-298, env.py:330-332, 771-773) or the
@@ -284,6 +301,7 @@ typedef struct sf_follower_glue {
     float* live;              /* [B] out */
     uint32_t sample_seed, sample_stream; /* feedback 2 only */
     int32_t row0;                        /* global id of row 0 (sampling stream) */
+    const uint32_t* sample_site_dev;     /* ABI 8, optional: device word added to sample_stream (sf_dropout.site_dev) */
     /* optional (scoring + glue launch only): env.step + env.observe + teacher of a device-resident
      * environment right behind the action choice, instead of a separate sf_nav_step launch */
     const struct sf_nav_io* nav;
@@ -553,7 +571,12 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
  * (seed, stream, row0 + b) -- csrc/sf_sampling.h; oracle/rng.py mirrors it.  `stream` names the word step (callers
  * pass site + t; sf_speaker_decode uses stream + t for its step t); row0 = global id of local row 0 (data-parallel
  * shards draw what the unsharded batch would). */
-typedef struct sf_sample { uint32_t seed, stream; int32_t row0; } sf_sample;
+typedef struct sf_sample {
+    uint32_t seed, stream;
+    int32_t row0;
+    const uint32_t* stream_dev; /* ABI 8, optional: device word added to `stream` (see sf_dropout.site_dev) -- a captured
+                                 * `sample` pass draws new words on every replay */
+} sf_sample;
 /* The WHOLE word loop of an inference pass (speaker.py:158-197: S times SpeakerDecoderLSTM.forward +
  * sf_speaker_glue_fwd, eval mode, no tapes for a backward) as one persistent launch
  * (csrc/sf_persist.hip: weights register-resident, rows partitioned across XCDs, three in-kernel
@@ -678,6 +701,11 @@ int sf_embedding_fwd(const float* table, int E, const int64_t* idx, int B, float
  * optimizer when its parameters, gradients and moments are laid out flat (optim.FusedAdam). */
 int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
                  double beta2, double eps, double weight_decay, int step, sf_stream stream);
+/* The same step with its 1-based step counter IN DEVICE MEMORY (ABI 8): `*step_dev` is incremented by the call and the
+ * bias corrections are formed from it on the device (double, rounded once, as on the host), so that a hipGraph which
+ * captured the call performs step n + 1 on its n-th replay.  coef: 2 floats of device scratch owned by the optimizer. */
+int sf_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, int32_t* step_dev, float* coef, sf_stream stream);
 
 /* Development aid (no reference counterpart): while `buf` is non-null, the visual-attention body of
  * the pipelined decode step stamps wall_clock64() (100 MHz) per workgroup into buf[block * 8 + k]

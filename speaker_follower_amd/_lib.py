@@ -26,7 +26,8 @@ class SfError(RuntimeError):
 
 
 class Dropout(C.Structure):
-    _fields_ = [('p', C.c_float), ('seed', C.c_uint32), ('row0', C.c_int32)]
+    _fields_ = [('p', C.c_float), ('seed', C.c_uint32), ('row0', C.c_int32),
+                ('site_dev', c_p), ('site_mul', C.c_uint32)]        # ABI 8: device-side site offset (optional)
 
 
 class Pano(C.Structure):
@@ -69,7 +70,7 @@ class FollowerGlue(C.Structure):
                 ('a_t', c_p), ('target_used', c_p), ('score', c_p), ('u_next', c_p),
                 ('ld_u_next', C.c_int32), ('u_drop', C.POINTER(Dropout)), ('u_drop_stream', C.c_uint32),
                 ('ce_term', c_p), ('live', c_p), ('sample_seed', C.c_uint32),
-                ('sample_stream', C.c_uint32), ('row0', C.c_int32), ('nav', c_p)]
+                ('sample_stream', C.c_uint32), ('row0', C.c_int32), ('sample_site_dev', c_p), ('nav', c_p)]
 
 
 class FollowerEpisode(C.Structure):
@@ -109,7 +110,7 @@ class SpkDecoderGTape(C.Structure):
 
 class Sample(C.Structure):
     """sf_sample: counter-based draw of the speaker's `sample` feedback (seed, stream, row0)."""
-    _fields_ = [('seed', C.c_uint32), ('stream', C.c_uint32), ('row0', C.c_int32)]
+    _fields_ = [('seed', C.c_uint32), ('stream', C.c_uint32), ('row0', C.c_int32), ('stream_dev', c_p)]
 
 
 class NavTableS(C.Structure):
@@ -137,6 +138,10 @@ _SIGNATURES = {
     'sf_debug_persist_timeout': (None, [C.c_longlong]),
     'sf_debug_gate_product_f32': (None, [C.c_int]),
     'sf_debug_precise_attention': (None, [C.c_int]),
+    'sf_site_advance': (C.c_int, [c_p, u32, c_p]),
+    'sf_store_u32x4': (C.c_int, [c_p, u32, u32, u32, u32, c_p]),
+    'sf_adam_step_dev': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
+                                   C.c_double, c_p, c_f, c_p]),
     'sf_debug_cotenant': (C.c_int, [i32, i32, i32, C.c_longlong, c_f, c_p]),
     'sf_gate_product_strict': (None, [C.c_int]),
     'sf_gate_product_is_strict': (C.c_int, []),
@@ -242,7 +247,7 @@ SF_ENC_REVERSED = 8
 SF_SPK_EMB_DROPOUT = 1        # sf_spk_decoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 def _load():

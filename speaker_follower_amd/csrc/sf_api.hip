@@ -91,9 +91,10 @@ inline FGlue make_glue(const CandSrc& src, int B, float* logit, const sf_followe
     f.src = src; f.B = B; f.logit = logit; f.is_valid = g->is_valid; f.target = g->target;
     f.feedback = g->feedback; f.ended = g->ended; f.a_t = g->a_t; f.target_used = g->target_used;
     f.score = g->score; f.u_next = g->u_next; f.ld_u = g->ld_u_next;
-    f.u_drop = make_dropout(g->u_drop, g->u_drop_stream);
+    f.u_drop = make_dropout(g->u_drop, g->u_drop_stream, 2);     // (numbered 2 * (step + 1))
     f.ce_term = g->ce_term; f.live = g->live; f.sample_seed = g->sample_seed;
     f.sample_stream = g->sample_stream; f.row0 = g->row0;
+    f.sample_site = g->sample_site_dev ? g->sample_site_dev : site_zero();
     if (g->nav) {
         const sf_nav_io& n = *g->nav;
         f.nav = NavIO{n.nav, n.row, n.view, n.goal_hop, n.ld_hop, n.hop_base, n.row_next, n.vp_next, n.view_next,
@@ -613,7 +614,7 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
     hipStream_t st = S(stream);
     const PanoSrc xs = pano(X);
     const int F = xs.IMG + xs.LOC;
-    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+    const Dropout d_in = make_dropout(drop, 2 * step_id, 2), d_h = make_dropout(drop, 2 * step_id + 1, 2);
     // model.py:389  feature, alpha_v = visual_attention(h_0, X)  -> straight into xin[:, F:2F]
     TRY(visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
                      d_in, F, ar, st, w->fold));
@@ -642,7 +643,7 @@ static int decoder_head_i(const sf_decoder_w* w, const sf_pano* X, int B, int H,
     const PanoSrc xs = pano(X);
     const int F = xs.IMG + xs.LOC;
     return visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
-                        make_dropout(drop, 2 * step_id), F, arena(ws, ws_bytes), S(stream), w->fold);
+                        make_dropout(drop, 2 * step_id, 2), F, arena(ws, ws_bytes), S(stream), w->fold);
 }
 
 int sf_attn_decoder_head_fwd(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
@@ -677,7 +678,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     // (sf_attn_decoder_attend_fwd).
     const bool query_only = !X_next && tn && w->visual.w_v_t && !w->fold;
     const int F = us.IMG + us.LOC;
-    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+    const Dropout d_in = make_dropout(drop, 2 * step_id, 2), d_h = make_dropout(drop, 2 * step_id + 1, 2);
     if (u_prev) TRY(dropout_copy(u_prev, F, B, F, tp->xin, 2 * F, d_in, 0, st));
     TRY(lstm_fwd_i(&w->lstm, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->h1, tp->c1, tp->gates,
                    tp->cat2 + H, 2 * H, d_h, ar, st));
@@ -693,7 +694,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         //   (3) h~ = tanh(W_out [wc ; h1])        ||  merge of the partials
         //   (4) [r | c] = M_a h~ + c_a            (5) scoring + glue
         const PanoSrc xn = pano(X_next);
-        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1));
+        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1), 2);
         SmallPlan pa, pb;
         const bool ok1 =
             plan_linear(tp->cat2 + H, 2 * H, tw->w_in, H, nullptr, B, H, H, EPI_NONE, tp->t_text, H, &pa) == SF_OK &&
@@ -723,7 +724,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         }
     } else if (paired) {
         const PanoSrc xn = pano(X_next);
-        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1));
+        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1), 2);
         SmallPlan pa, pb;
         // (1) t_text = W_in dropout(h1)   ||   t_v' = W_h h1 + b_h
         const bool ok1 =
@@ -790,7 +791,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
                           tp->t_text, ar, st, ctx_row));
         if (X_next)
             TRY(visual_fwd_i(vw, pano(X_next), B, H, D, tp->h1, tn->xin + F, 2 * F, tn->alpha_v,
-                             tn->t_v, tn->q, make_dropout(drop, 2 * (step_id + 1)), F, ar, st, w->fold));
+                             tn->t_v, tn->q, make_dropout(drop, 2 * (step_id + 1), 2), F, ar, st, w->fold));
     }
     return scoring_fwd_i(&w->action, us, B, H, D, tp->h_tilde, tp->logit, tp->t_a, tp->wt, tp->r, ar,
                          st, glue, w->fold);
@@ -808,7 +809,7 @@ static int decoder_tail_split_i(const sf_decoder_w* w, const sf_cands* U, int B,
     Arena ar{(float*)ws, n, 0, tickets};
     const CandSrc us = cands(U);
     const int F = us.IMG + us.LOC;
-    const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
+    const Dropout d_h = make_dropout(drop, 2 * step_id + 1, 2);
     TRY(lstm_fwd_i(&w->lstm, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->h1, tp->c1, tp->gates, tp->cat2 + H, 2 * H,
                    d_h, ar, st));
     if (flag_h1) TRY(flag_set(flag_h1, flag_value, st));
@@ -826,7 +827,7 @@ int sf_attn_decoder_attend_fwd(const sf_pano* X, int B, const sf_decoder_tape* t
     const PanoSrc xs = pano(X);
     const int F = xs.IMG + xs.LOC;
     float* part = B <= 1024 ? ar.take(visual_attn_split_floats(B, F)) : nullptr;
-    return visual_attn(0, xs, B, tp->q, F, tp->alpha_v, tp->xin + F, 2 * F, make_dropout(drop, 2 * step_id), F,
+    return visual_attn(0, xs, B, tp->q, F, tp->alpha_v, tp->xin + F, 2 * F, make_dropout(drop, 2 * step_id, 2), F,
                        S(stream), part, part ? ar.tickets() : nullptr);
 }
 
@@ -901,7 +902,7 @@ static int decoder_bwd_tail_i(const sf_decoder_w* w, const sf_decoder_g* g, cons
                               const sf_dropout* drop, uint32_t step_id, Arena ar, hipStream_t st) {
     const PanoSrc xs = pano(X);
     const int F = xs.IMG + xs.LOC;
-    const Dropout d_in = make_dropout(drop, 2 * step_id), d_h = make_dropout(drop, 2 * step_id + 1);
+    const Dropout d_in = make_dropout(drop, 2 * step_id, 2), d_h = make_dropout(drop, 2 * step_id + 1, 2);
     float* dxin = ar.take((size_t)B * 2 * F);  // d LSTM input
     NEED(dxin);
     SmallPlan dh0_plan;
@@ -1125,7 +1126,7 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
                 const PanoSrc xs = pano(&nxt.X);
                 const int F = xs.IMG + xs.LOC;
                 TRY(visual_fwd_i(&w->visual, xs, e->B, e->H, e->D, cur.tp.h1, nxt.tp.xin + F, 2 * F, nxt.tp.alpha_v,
-                                 nxt.tp.t_v, nxt.tp.q, make_dropout(drop, 2 * (e->step0 + t + 1)), F, sar, ss, nullptr));
+                                 nxt.tp.t_v, nxt.tp.q, make_dropout(drop, 2 * (e->step0 + t + 1), 2), F, sar, ss, nullptr));
                 TRY(flag_set(flag_ft, (unsigned)(t + 1), ss));
             }
             cur = nxt;
@@ -1528,11 +1529,11 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
     const int ldv = (vocab + 3) & ~3;
-    const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
+    const Dropout d_h = make_dropout(drop, 2 * step_id + 1, 2);
     if (tp->emb) TRY(embedding_rows(w->embedding, E, prev_word, B, tp->emb, st));   // :497-498
     if (w->flags & SF_SPK_EMB_DROPOUT) {          // trainable embedding: :499-500 drops the embedded word
         SF_CHECK_ARG(tp->emb && !w->xw_table);
-        TRY(dropout_tm(tp->emb, 1, B, E, make_dropout(drop, 2 * step_id), nullptr, st));
+        TRY(dropout_tm(tp->emb, 1, B, E, make_dropout(drop, 2 * step_id, 2), nullptr, st));
     }
     if (w->xw_table && H % 16 == 0 && H <= 1024) {
         // x W_ih^T is a row of the precomputed [vocab,4H] table: recurrent half only
@@ -1608,7 +1609,7 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
     Arena ar = arena(ws, ws_bytes);
     hipStream_t st = S(stream);
     const int ldv = (vocab + 3) & ~3;
-    const Dropout d_h = make_dropout(drop, 2 * step_id + 1);
+    const Dropout d_h = make_dropout(drop, 2 * step_id + 1, 2);
     float* dht = ar.take((size_t)B * H);
     float* dh1d = ar.take((size_t)B * H);
     float* dh1m = ar.take((size_t)B * H);
@@ -1630,7 +1631,7 @@ int sf_speaker_decoder_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g,
     NEED(demb);
     TRY(lstm_bwd_i(&w->lstm, &g->lstm, B, E, H, tp->emb, E, h0, c0, tp->c1, tp->gates, dh1, dh1m, dc1, demb, E, dh0, dc0,
                    ar, st));
-    const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * step_id) : make_dropout(nullptr, 0);
+    const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * step_id, 2) : make_dropout(nullptr, 0);
     return embedding_bwd(demb, E, prev_word, 1, 1, B, E, -1, de, nullptr, g->embedding, st);
 }
 
@@ -1662,10 +1663,11 @@ int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const flo
         float* x_t = xin + (size_t)t * B * 2 * F;
         // (float64 query and scores: see visual_fwd_i / csrc/sf_precise.hip; sf_debug_precise_attention(0) = fp32)
         TRY(visual_fwd_i(vw, pano(&X), B, H, D, hs + t * BH, x_t + F, 2 * F, alpha + (size_t)t * B * V,
-                         t_v + (size_t)t * B * D, q + (size_t)t * B * F, make_dropout(drop, 2 * (step0 + t)), F,
+                         t_v + (size_t)t * B * D, q + (size_t)t * B * F, make_dropout(drop, 2 * (step0 + t), 2), F,
                          arena(ws, ws_bytes), S(stream), nullptr, g_precise_attention != 0));
         if (act_emb)
-            TRY(sf_dropout_copy(act_emb + (size_t)t * B * F, F, B, F, x_t, 2 * F, drop, 2 * (step0 + t), 0, stream));
+            TRY(dropout_copy(act_emb + (size_t)t * B * F, F, B, F, x_t, 2 * F, make_dropout(drop, 2 * (step0 + t), 2), 0,
+                             S(stream)));
         TRY(sf_lstm_cell_fwd(lw, B, 2 * F, H, x_t, 2 * F, hs + t * BH, cs + t * BH, hs + (t + 1) * BH, cs + (t + 1) * BH,
                              gates + (size_t)t * B * 4 * H, ctx ? ctx + (size_t)t * H : nullptr, ctx ? Tp * H : 0, nullptr, 0,
                              ws, ws_bytes, stream));
@@ -1751,7 +1753,7 @@ int sf_speaker_words_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, i
         } else {
             // data gradients only; dY operands into the stacked gtape (sf_speaker_decoder_bwd with g = NULL)
             Arena ar = arena(ws, ws_bytes);
-            const Dropout d_h = make_dropout(drop, 2 * (step0 + t) + 1);
+            const Dropout d_h = make_dropout(drop, 2 * (step0 + t) + 1, 2);
             float* dht = ar.take(BH);
             float* dh1d = ar.take(BH);
             float* dh1m = ar.take(BH);
@@ -1771,7 +1773,7 @@ int sf_speaker_words_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, i
                 NEED(demb);
                 TRY(lstm_bwd_i(&w->lstm, nullptr, B, E, H, tp.emb, E, h0, c0, tp.c1, tp.gates, dh1, dh1d, dc1, demb, E, dho,
                                dco, ar, st, dgt, 0, &d_h));
-                const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * (step0 + t))
+                const Dropout de = (w->flags & SF_SPK_EMB_DROPOUT) ? make_dropout(drop, 2 * (step0 + t), 2)
                                                                    : make_dropout(nullptr, 0);
                 TRY(embedding_bwd(demb, E, words + (size_t)t * B, 1, 1, B, E, -1, de, nullptr, g->embedding, st));
             }
@@ -1834,6 +1836,26 @@ int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double 
     SF_CHECK_ARG(step >= 1 && beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1.);
     if (n == 0) return SF_OK;
     return adam_step(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, S(stream));
+}
+
+int sf_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+                     double eps, double weight_decay, int32_t* step_dev, float* coef, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(((p && g && m && v) || n == 0) && step_dev && coef);
+    SF_CHECK_ARG(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1.);
+    return adam_step_dev(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, coef, S(stream));
+}
+
+int sf_store_u32x4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(dst != nullptr);
+    return store_u32x4(dst, a, b, c, d, S(stream));
+}
+
+int sf_site_advance(uint32_t* word, uint32_t by, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(word != nullptr);
+    return site_advance(word, by, S(stream));
 }
 
 int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,

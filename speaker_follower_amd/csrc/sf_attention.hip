@@ -60,7 +60,7 @@ __device__ __forceinline__ void visual_attn_body(const VisArgs& a, int b) {
         }
     }
 
-    const uint32_t rkey = dropout_row_key(a.drop.seed, a.drop.stream, (uint32_t)(a.drop.row0 + b));
+    const uint32_t rkey = drop_key(a.drop, (uint32_t)(a.drop.row0 + b));
     float dot[VIS_RPW];
 #pragma unroll
     for (int r = 0; r < VIS_RPW; ++r) dot[r] = 0.f;
@@ -360,7 +360,7 @@ __device__ __forceinline__ void visual_split_body(const VisArgs& a, const VisSpl
     for (int k = 0; k < VSP_G; ++k) kk[k] *= inv;
     float* orow = a.out + (size_t)b * a.ldo;
     const Dropout dr = a.drop;
-    const uint32_t rkey = dropout_row_key(dr.seed, dr.stream, (uint32_t)(dr.row0 + b));
+    const uint32_t rkey = drop_key(dr, (uint32_t)(dr.row0 + b));
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(r0, 0, VSP_G * pstride * 4, 0x00020000);
     for (int c = tid; c < n4; c += VSP_NW * 64) {
         v4u pk[VSP_G];

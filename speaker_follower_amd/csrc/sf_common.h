@@ -109,13 +109,31 @@ struct Dropout {            // p == 0 (thresh == 0) means "eval mode": everythin
     uint32_t thresh;        // p * 2^32
     float scale;            // 1 / (1 - p)
     int row0;               // global row id of local row 0
+    // Device-side site offset (sf_dropout.site_dev, round 5): the site of this mask is stream + site_mul * *site.
+    // `site` is never null (a device zero word when the caller gave none), so kernels read it unconditionally.  A
+    // captured training iteration advances the word at its end: every replay draws fresh masks from the same graph.
+    const uint32_t* site;
+    uint32_t site_mul;
     __host__ __device__ bool on() const { return thresh != 0; }
 };
 
-static inline Dropout make_dropout(const sf_dropout* d, uint32_t stream) {
+const uint32_t* site_zero();        // a device word that holds 0 (sf_pointwise.hip)
+
+// key of (seed, stream + mul * *site, row): seed + G * (stream + off) == (seed + G * off) + G * stream
+__device__ __forceinline__ uint32_t drop_seed(const Dropout& d) { return d.seed + 0x9E3779B9u * (d.site_mul * *d.site); }
+__device__ __forceinline__ uint32_t drop_key(const Dropout& d, uint32_t row) {
+    return dropout_row_key(drop_seed(d), d.stream, row);
+}
+
+// `mul`: how many stream ids one unit of the device-side site counter stands for at this call site -- 2 where the
+// streams are numbered 2 * step + k (the decoder steps), the caller's sf_dropout.site_mul (default 1) where the entry
+// point takes a raw stream id
+static inline Dropout make_dropout(const sf_dropout* d, uint32_t stream, uint32_t mul = 0) {
     Dropout r;
     r.seed = d ? d->seed : 0;
     r.stream = stream;
+    r.site = d && d->site_dev ? d->site_dev : site_zero();
+    r.site_mul = mul ? mul : (d && d->site_mul ? d->site_mul : 1u);
     double p = d ? (double)d->p : 0.0;
     if (p <= 0.0) {
         r.thresh = 0;

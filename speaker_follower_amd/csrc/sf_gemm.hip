@@ -897,8 +897,7 @@ __global__ __launch_bounds__(BWS_WAVES * 64) void lstm_bwd_step_fused_kernel(Lst
     if (p.dctx) {                                                // block-uniform
         float v = p.dctx[((size_t)qb * p.T + p.t) * H + pj];
         if (p.ctx_drop.on()) {
-            const uint32_t rk = dropout_row_key(p.ctx_drop.seed, p.ctx_drop.stream,
-                                                (uint32_t)(p.ctx_drop.row0 + qb));
+            const uint32_t rk = drop_key(p.ctx_drop, (uint32_t)(p.ctx_drop.row0 + qb));
             v = dropout_keep(rk, (uint32_t)(p.t * H + pj), p.ctx_drop.thresh) ? v * p.ctx_drop.scale : 0.f;
         }
         dh += v;

@@ -73,6 +73,7 @@ struct FGlue {
     float* live;             // [B]
     uint32_t sample_seed;    // feedback 2: counter-based uniform per (seed, stream, row)
     uint32_t sample_stream;
+    const uint32_t* sample_site;   // device-side stream offset (never null), see Dropout.site
     int row0;
     NavIO nav;               // nav.on: env step of a device-resident environment behind the action choice
 };
@@ -124,7 +125,7 @@ __device__ __forceinline__ int follower_glue_row(const FGlue& g, int b, float ra
         // follower.py:491-497: sample from softmax(logit) (invalid candidates have probability 0).
         // Inverse CDF over <= 64 lanes with a counter-based uniform (the reference's torch RNG
         // stream cannot be reproduced; parity is defined on teacher / argmax).
-        const uint32_t key = dropout_row_key(g.sample_seed, g.sample_stream, (uint32_t)(g.row0 + b));
+        const uint32_t key = dropout_row_key(g.sample_seed + 0x9E3779B9u * *g.sample_site, g.sample_stream, (uint32_t)(g.row0 + b));
         const float u = (float)(fmix32(key) >> 8) * (1.0f / 16777216.0f) * se;
         float cdf = e;                                           // inclusive prefix sum over lanes
 #pragma unroll
@@ -151,7 +152,7 @@ __device__ __forceinline__ int follower_glue_row(const FGlue& g, int b, float ra
 // u_next[b, 4c..4c+3] = dropout(chunk) for the chosen action's row (follower.py:502 + model.py:392)
 __device__ __forceinline__ void store_u_next(const FGlue& g, int b, int c, float4 v) {
     if (g.u_drop.on()) {
-        const uint32_t rk = dropout_row_key(g.u_drop.seed, g.u_drop.stream, (uint32_t)(g.u_drop.row0 + b));
+        const uint32_t rk = drop_key(g.u_drop, (uint32_t)(g.u_drop.row0 + b));
         const uint32_t col = (uint32_t)(4 * c);
         v.x = dropout_keep(rk, col + 0, g.u_drop.thresh) ? v.x * g.u_drop.scale : 0.f;
         v.y = dropout_keep(rk, col + 1, g.u_drop.thresh) ? v.y * g.u_drop.scale : 0.f;

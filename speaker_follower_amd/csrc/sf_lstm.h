@@ -65,8 +65,7 @@ __device__ __forceinline__ void lstm_cell_update(const LstmPwFwd& a, int b, int 
         if (!live) { c1 = c0; h1 = lv.h0; }
         float cv = live ? h1 : 0.f;
         if (live && a.ctx_drop.on()) {
-            const uint32_t rk = dropout_row_key(a.ctx_drop.seed, a.ctx_drop.stream,
-                                                (uint32_t)(a.ctx_drop.row0 + b));
+            const uint32_t rk = drop_key(a.ctx_drop, (uint32_t)(a.ctx_drop.row0 + b));
             cv = dropout_keep(rk, (uint32_t)(a.t * H + j), a.ctx_drop.thresh)
                      ? cv * a.ctx_drop.scale : 0.f;
         }
@@ -77,8 +76,7 @@ __device__ __forceinline__ void lstm_cell_update(const LstmPwFwd& a, int b, int 
     if (a.h1_drop) {
         float hd = h1;
         if (a.drop.on()) {
-            const uint32_t rk = dropout_row_key(a.drop.seed, a.drop.stream,
-                                                (uint32_t)(a.drop.row0 + b));
+            const uint32_t rk = drop_key(a.drop, (uint32_t)(a.drop.row0 + b));
             hd = dropout_keep(rk, (uint32_t)j, a.drop.thresh) ? hd * a.drop.scale : 0.f;
         }
         a.h1_drop[(size_t)b * a.ld_h1_drop + j] = hd;

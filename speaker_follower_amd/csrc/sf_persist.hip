@@ -181,7 +181,7 @@ __global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = p.b_ih[g * H + ej] + p.b_hh[g * H + ej];
     const int len_b = p.lengths[eb];
-    const uint32_t rk = dropout_row_key(p.ctx_drop.seed, p.ctx_drop.stream, (uint32_t)(p.ctx_drop.row0 + eb));
+    const uint32_t rk = drop_key(p.ctx_drop, (uint32_t)(p.ctx_drop.row0 + eb));
     float c_state = 0.f, h_state = 0.f;
     const size_t BH = (size_t)B * H;
 
@@ -410,7 +410,7 @@ __global__ __launch_bounds__(256, 1) void enc_bwd_persist_kernel(EncBwdPersistAr
     const int eb = evalid ? row0 + er : B - 1;
     const int ej = 16 * slot + eu;
     const int len_b = p.lengths[eb];
-    const uint32_t rk = dropout_row_key(p.ctx_drop.seed, p.ctx_drop.stream, (uint32_t)(p.ctx_drop.row0 + eb));
+    const uint32_t rk = drop_key(p.ctx_drop, (uint32_t)(p.ctx_drop.row0 + eb));
     const size_t BH = (size_t)B * H;
     float dc = p.dc_in ? p.dc_in[(size_t)eb * H + ej] : 0.f;
     float dh_pass = p.dh_in ? p.dh_in[(size_t)eb * H + ej] : 0.f;
@@ -585,6 +585,7 @@ struct SpkPersistArgs {
     const int64_t* targets;                                   // [S,B]
     int feedback, pad, eos;
     uint32_t sample_seed, sample_stream; int sample_row0;     // feedback 2 (speaker.py:170-174): counter-based draws
+    const uint32_t* sample_site;                              // device-side stream offset (never null), see Dropout.site
     int B, H, Tp, S, rpg;
     int64_t* words;                                           // [S+1,B], row 0 given
     float* step_scores; float* nll_term; float* live;         // [S,B]
@@ -932,7 +933,7 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
                 // word falls into its 32 columns (second uniform of the row); which workgroup's draw counts is
                 // decided in phase H from the first uniform and the published masses (sf_sampling.h)
                 float u1, u2;
-                sample_uniforms(p.sample_seed, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
+                sample_uniforms(p.sample_seed + 0x9E3779B9u * *p.sample_site, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
                 const int it = row16_pick32(e0, e1, u2 * se, eu);
                 const int sc_ = it != 0x7FFFFFFF ? 32 * slot + it : min(32 * slot + 31, vocab - 1);
                 const float sl_ = row16_sum((sc_ == col0 ? l0 : 0.f) + (sc_ == col1 ? l1 : 0.f));
@@ -998,7 +999,7 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
             if (sampling) {
                 // which workgroup's draw counts: inverse CDF over the 32 masses z_s exp(m_s - M) with the row's first uniform
                 float u1, u2;
-                sample_uniforms(p.sample_seed, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
+                sample_uniforms(p.sample_seed + 0x9E3779B9u * *p.sample_site, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
                 int cs = row16_pick32(z0 * wexp(m0, M), z1 * wexp(m1, M), u1 * Z, eu);
                 if (cs == 0x7FFFFFFF) cs = arg >> 5;                                 // u1 Z rounded up to the total
                 const unsigned qc = (cs & 16) ? q1c : q0c, ql = (cs & 16) ? q1l : q0l;
@@ -1125,6 +1126,7 @@ int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
     a.h1_tape = h1_tape; a.c1_tape = c1_tape; a.ended = ended; a.xchg = reinterpret_cast<unsigned*>(xchg);
     a.done = done; a.place = done + 4; a.trace = g_trace;
     a.fault = done + EP_FAULT_WORD; a.timeout = g_persist_timeout < 0 ? EP_TIMEOUT_TICKS : g_persist_timeout;
+    a.sample_site = sample && sample->stream_dev ? sample->stream_dev : site_zero();
     if (sample) { a.sample_seed = sample->seed; a.sample_stream = sample->stream; a.sample_row0 = sample->row0; }
     SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(256), dim3(256), 0, st, a.xchg, speaker_persistent_xchg_floats(),
               a.place, g_force_sc1, a.fault, g_persist_timeout);

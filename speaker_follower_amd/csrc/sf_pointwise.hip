@@ -70,8 +70,7 @@ __global__ __launch_bounds__(TPB) void lstm_pw_bwd_kernel(LstmPwBwd a) {
         if (a.dh1_b) {
             float v = a.dh1_b[idx];
             if (a.dh1b_drop.on()) {
-                const uint32_t rk = dropout_row_key(a.dh1b_drop.seed, a.dh1b_drop.stream,
-                                                    (uint32_t)(a.dh1b_drop.row0 + b));
+                const uint32_t rk = drop_key(a.dh1b_drop, (uint32_t)(a.dh1b_drop.row0 + b));
                 v = dropout_keep(rk, (uint32_t)j, a.dh1b_drop.thresh) ? v * a.dh1b_drop.scale : 0.f;
             }
             dh += v;
@@ -82,8 +81,7 @@ __global__ __launch_bounds__(TPB) void lstm_pw_bwd_kernel(LstmPwBwd a) {
         if (a.dctx) {                                     // encoder: gradient of ctx[b, t, :]
             float v = a.dctx[((size_t)b * a.T + a.t) * H + j];
             if (a.ctx_drop.on()) {
-                const uint32_t rk = dropout_row_key(a.ctx_drop.seed, a.ctx_drop.stream,
-                                                    (uint32_t)(a.ctx_drop.row0 + b));
+                const uint32_t rk = drop_key(a.ctx_drop, (uint32_t)(a.ctx_drop.row0 + b));
                 v = dropout_keep(rk, (uint32_t)(a.t * H + j), a.ctx_drop.thresh)
                         ? v * a.ctx_drop.scale : 0.f;
             }
@@ -111,7 +109,7 @@ __global__ __launch_bounds__(TPB) void dropout_copy_kernel(const float* src, int
         const int b = (int)(i / N), n = (int)(i % N);
         float v = src[(size_t)b * lds + n];
         if (d.on()) {
-            const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
+            const uint32_t rk = drop_key(d, (uint32_t)(d.row0 + b));
             v = dropout_keep(rk, (uint32_t)(col0 + n), d.thresh) ? v * d.scale : 0.f;
         }
         dst[(size_t)b * ldd + n] = v;
@@ -125,7 +123,7 @@ __global__ __launch_bounds__(TPB) void ctx_grad_slice_kernel(const float* dctx, 
         const int b = idx / H, j = idx - b * H;
         float v = dctx[((size_t)b * T + t) * H + j];
         if (d.on()) {
-            const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
+            const uint32_t rk = drop_key(d, (uint32_t)(d.row0 + b));
             v = dropout_keep(rk, (uint32_t)(t * H + j), d.thresh) ? v * d.scale : 0.f;
         }
         out[idx] = v;
@@ -502,6 +500,7 @@ struct SGlue {
     float* nll_term;
     float* live;
     uint32_t sample_seed, sample_stream; int sample_row0;     // feedback 2
+    const uint32_t* sample_site;                              // device-side stream offset (never null), see Dropout.site
 };
 // feedback 2 (speaker.py:170-174): the two-level draw of sf_sampling.h by one wave.  Lane l holds columns
 // [16 l, 16 l + 16); slot s = lanes 2 s, 2 s + 1.  m = the row's max, am its arg max.  Returns the word.
@@ -523,7 +522,7 @@ __device__ __forceinline__ int speaker_sample_row(const SGlue& g, const float* r
     const float so = __shfl_xor(sl, 1, WAVE);
     const float zs = (lane & 1) ? so + sl : sl + so;
     float u1, u2;
-    sample_uniforms(g.sample_seed, g.sample_stream, (uint32_t)(g.sample_row0 + b), &u1, &u2);
+    sample_uniforms(g.sample_seed + 0x9E3779B9u * *g.sample_site, g.sample_stream, (uint32_t)(g.sample_row0 + b), &u1, &u2);
     // level 2: this slot's column
     const float thr2 = u2 * zs;
     float cum = (lane & 1) ? so : 0.f;
@@ -705,6 +704,7 @@ __global__ __launch_bounds__(1024) void speaker_loss_finalize_kernel(const float
 struct AdamArgs {
     float* p; const float* g; float* m; float* v; size_t n;
     float beta2, om_beta1, om_beta2, eps, wd, step_size, inv_sqrt_bc2;   // om = 1 - beta, rounded from double
+    const float* coef;          // device-side {step_size, inv_sqrt_bc2} (sf_adam_step_dev), or null
 };
 __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, const AdamArgs& a) {
     if (a.wd != 0.f) g = g + a.wd * p;
@@ -713,7 +713,21 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
     const float denom = sqrtf(v) * a.inv_sqrt_bc2 + a.eps;
     p = p - a.step_size * (m / denom);
 }
+// the step counter of a CAPTURED optimizer step lives on the device: ++step, then the two step-dependent constants in
+// double, rounded to float once (what adam_step does on the host)
+__global__ void adam_coef_kernel(int* step, double lr, double beta1, double beta2, float* coef) {
+    if (threadIdx.x != 0) return;
+    const int s = *step + 1;
+    *step = s;
+    const double bc1 = 1.0 - pow(beta1, (double)s), bc2 = 1.0 - pow(beta2, (double)s);
+    coef[0] = (float)(lr / bc1);
+    coef[1] = (float)(1.0 / sqrt(bc2));
+}
 __global__ __launch_bounds__(TPB) void adam_kernel(AdamArgs a) {
+    if (a.coef) {
+        a.step_size = a.coef[0];
+        a.inv_sqrt_bc2 = a.coef[1];
+    }
     const size_t n4 = a.n >> 2;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (size_t)gridDim.x * TPB) {
         float4 p = reinterpret_cast<float4*>(a.p)[i];
@@ -804,7 +818,17 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr,
     const double bc1 = 1.0 - pow(beta1, (double)step);
     const double bc2 = 1.0 - pow(beta2, (double)step);
     AdamArgs a{p, g, m, v, n, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
-               (float)wd, (float)(lr / bc1), (float)(1.0 / sqrt(bc2))};
+               (float)wd, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), nullptr};
+    const size_t n4 = (n + 3) >> 2;
+    SF_LAUNCH(adam_kernel, dim3((unsigned)std::min<size_t>((n4 + TPB - 1) / TPB, 4096)), dim3(TPB), 0,
+                       st, a);
+    return launch_status();
+}
+int adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+                  double eps, double wd, int* step_dev, float* coef, hipStream_t st) {
+    SF_LAUNCH(adam_coef_kernel, dim3(1), dim3(64), 0, st, step_dev, lr, beta1, beta2, coef);
+    AdamArgs a{p, g, m, v, n, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
+               (float)wd, 0.f, 0.f, coef};
     const size_t n4 = (n + 3) >> 2;
     SF_LAUNCH(adam_kernel, dim3((unsigned)std::min<size_t>((n4 + TPB - 1) / TPB, 4096)), dim3(TPB), 0,
                        st, a);
@@ -836,6 +860,31 @@ int flag_wait(const unsigned* flag, unsigned target, hipStream_t st) {
 }
 int flag_set(unsigned* flag, unsigned value, hipStream_t st) {
     SF_LAUNCH(flag_set_kernel, dim3(1), dim3(64), 0, st, flag, value);
+    return launch_status();
+}
+
+// ---- device-side site counters (include/sf_hip.h: sf_dropout.site_dev, sf_site_advance) -----------------------------
+__device__ uint32_t g_site_zero_word = 0;
+const uint32_t* site_zero() {
+    static const uint32_t* p = [] {
+        void* q = nullptr;
+        (void)hipGetSymbolAddress(&q, HIP_SYMBOL(g_site_zero_word));
+        return static_cast<const uint32_t*>(q);
+    }();
+    return p;
+}
+__global__ void site_advance_kernel(uint32_t* word, uint32_t by) {
+    if (threadIdx.x == 0) *word += by;
+}
+__global__ void store_u32x4_kernel(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    if (threadIdx.x == 0) { dst[0] = a; dst[1] = b; dst[2] = c; dst[3] = d; }
+}
+int store_u32x4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, hipStream_t st) {
+    SF_LAUNCH(store_u32x4_kernel, dim3(1), dim3(64), 0, st, dst, a, b, c, d);
+    return launch_status();
+}
+int site_advance(uint32_t* word, uint32_t by, hipStream_t st) {
+    SF_LAUNCH(site_advance_kernel, dim3(1), dim3(64), 0, st, word, by);
     return launch_status();
 }
 
@@ -886,7 +935,7 @@ __global__ __launch_bounds__(TPB) void dropout_tm_kernel(float* x, int T, int B,
     const size_t total = (size_t)T * B * E;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
         const int e = (int)(i % E), b = (int)((i / E) % B), t = (int)(i / ((size_t)E * B));
-        const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
+        const uint32_t rk = drop_key(d, (uint32_t)(d.row0 + b));
         x[i] = dropout_keep(rk, (uint32_t)(tm_position(rev, b, t) * E + e), d.thresh) ? x[i] * d.scale : 0.f;
     }
 }
@@ -901,7 +950,7 @@ __global__ __launch_bounds__(TPB) void embedding_bwd_kernel(const float* demb, i
         const int64_t tok = seq[(size_t)b * Lpad + t];
         float v = demb[((size_t)t * B + b) * ldd + e];
         if (d.on()) {
-            const uint32_t rk = dropout_row_key(d.seed, d.stream, (uint32_t)(d.row0 + b));
+            const uint32_t rk = drop_key(d, (uint32_t)(d.row0 + b));
             v = dropout_keep(rk, (uint32_t)(tm_position(rev, b, t) * E + e), d.thresh) ? v * d.scale : 0.f;
         }
         if (tok != padding_idx && v != 0.f) atomicAdd(grad + (size_t)tok * E + e, v);
@@ -993,7 +1042,8 @@ int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_
                      float* score, float* nll_term, float* live, hipStream_t st, const sf_sample* sample) {
     if (feedback == 2 && (!sample || vocab > 1024)) return feedback == 2 && !sample ? SF_ERR_ARG : SF_ERR_UNSUPPORTED;
     SGlue g{B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t, score, nll_term,
-            live, sample ? sample->seed : 0u, sample ? sample->stream : 0u, sample ? sample->row0 : 0};
+            live, sample ? sample->seed : 0u, sample ? sample->stream : 0u, sample ? sample->row0 : 0,
+            sample && sample->stream_dev ? sample->stream_dev : site_zero()};
     SF_LAUNCH(speaker_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
     return launch_status();
 }

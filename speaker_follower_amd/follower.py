@@ -139,6 +139,9 @@ class FollowerEngine:
         self.group = group              # torch.distributed process group for data parallelism
         self.iteration = 0              # rollouts issued so far
         self.site_next = 0              # first unused dropout / sampling site (see rollout)
+        # device-side site counter (capture_training): when set, the kernels receive stream ids RELATIVE to this word
+        # and `site_next` only mirrors it on the host
+        self.site_word = None
         self.dropout_seed = None
         self.two_stream_backward = True  # heads of the backward on a side stream (see sf_follower_episode_bwd)
         self._side_stream = None
@@ -195,8 +198,14 @@ class FollowerEngine:
         # next rollout starts behind them, at least 64 further on (so that S <= 62 keeps the
         # `iteration * 64` numbering the oracle tests mirror).  Identical on every data-parallel rank.
         st.site0 = self.site_next
-        self.site_next += max(64, S + 2)
+        st.site_stride = max(64, S + 2)
+        self.site_next += st.site_stride
         self.iteration += 1
+        # what the kernels are given: the absolute site, or (device-side counter) 0 + the word's address
+        st.site_dev = C.c_void_p(self.site_word.data_ptr()) if self.site_word is not None else None
+        st.site_rel = 0 if self.site_word is not None else st.site0
+        st.drop_dec += (st.site_dev, 1)
+        st.drop_enc += (st.site_dev, 1)
 
         # ---- encoder (model.py:81-104)
         st.ctx = new(B, T, H)
@@ -218,7 +227,7 @@ class FollowerEngine:
         if bidir:
             # the module's composition of the two directions (model.EncoderLSTM._forward_bidirectional); its autograd
             # graph is the encoder's tape, and _backward() enters it with the decoder's (dctx, dh, dc)
-            p_e, seed_e, row0 = st.drop_enc
+            p_e, seed_e, row0 = st.drop_enc[:3]
             cfg = (p_e, (seed_e + 0x9E3779B1 * row0) & 0xFFFFFFFF, st.site0)
             with torch.set_grad_enabled(keep and torch.is_grad_enabled()):
                 ctx_e, h_e, c_e = enc._forward_bidirectional(batch.seq, batch.lengths_dev, T, cfg, st.enc_table)
@@ -231,7 +240,7 @@ class FollowerEngine:
             ew = _encoder_structs(enc, table=st.enc_table)
             call('sf_encoder_lstm_fwd', byref(ew), B, Lpad, T, E, H, ptr(batch.seq),
                  ptr(batch.lengths_dev), ptr(st.ctx), ptr(st.h_init), ptr(st.c_init), byref(etp),
-                 dropout_arg(*st.drop_enc), st.site0, *ws_args(dev))
+                 dropout_arg(*st.drop_enc), st.site_rel, *ws_args(dev))
 
         # ---- decode steps
         shapes = dict(t_v=(D,), q=(F,), alpha_v=(V,), xin=(2 * F,), gates=(4 * H,), c1=(H,),
@@ -259,7 +268,7 @@ class FollowerEngine:
         fold = None if (st.differentiable or training or not self.fold_inference) else decoder_fold(dec)
         dw = decoder_w_struct(params, fold=fold)
         ws = ws_args(dev)
-        d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
+        d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]), st.site_dev, 1)
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
         # A nav.DeviceNavBatch produces its observations ON THE DEVICE, one step ahead of the decoder,
         # from the action the glue kernel has just chosen (real student forcing: the next panorama
@@ -288,9 +297,9 @@ class FollowerEngine:
                 None, batch.target[0].data_ptr(), st.feedback, st.ended.data_ptr(),
                 st.actions[0].data_ptr(), st.target_used[0].data_ptr(), st.step_scores[0].data_ptr(),
                 None, 0, None, 0, st.ce_term[0].data_ptr(), st.live[0].data_ptr(),
-                int(st.drop_dec[1]) ^ 0x1B873593, 0, batch.row0)
+                int(st.drop_dec[1]) ^ 0x1B873593, 0, batch.row0, st.site_dev)
             ep.drop = d_dec
-            ep.step0 = st.site0
+            ep.step0 = st.site_rel
             ep.side_stream = None
             if nav_episode:
                 st.navio0 = batch.fused_step(0)               # (sf_nav_io of step 0; the library strides it per step)
@@ -306,11 +315,11 @@ class FollowerEngine:
         panos = [] if st.episode else [store.pano(batch.vp[t], batch.view[t]) for t in range(S)]
         if pipelined and not st.episode:
             call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
-                 byref(tapes[0]), d_ptr, st.site0, *ws)
+                 byref(tapes[0]), d_ptr, st.site_rel, *ws)
         deferred = on_device_env and self.pipelined and fold is None and dw.visual.w_v_t and not st.episode
         if deferred:
             call('sf_attn_decoder_head_fwd', byref(dw), byref(panos[0]), B, H, D, ptr(st.h_init),
-                 byref(tapes[0]), d_ptr, st.site0, *ws)
+                 byref(tapes[0]), d_ptr, st.site_rel, *ws)
         for t in range(0 if not st.episode else S, S):
             pano = panos[t]
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
@@ -320,9 +329,9 @@ class FollowerEngine:
             glue = _lib.FollowerGlue(
                 None, batch.target[t].data_ptr(), st.feedback, st.ended.data_ptr(),
                 st.actions[t].data_ptr(), st.target_used[t].data_ptr(), st.step_scores[t].data_ptr(),
-                st.tape['xin'][t + 1].data_ptr(), 2 * F, d_ptr, 2 * (st.site0 + t + 1),
+                st.tape['xin'][t + 1].data_ptr(), 2 * F, d_ptr, 2 * (st.site_rel + t + 1),
                 st.ce_term[t].data_ptr(), st.live[t].data_ptr(),
-                int(st.drop_dec[1]) ^ 0x1B873593, st.site0 + t, batch.row0)
+                int(st.drop_dec[1]) ^ 0x1B873593, st.site_rel + t, batch.row0, st.site_dev)
             navio = None
             if deferred and self.fused_env_step:        # env.step + observe in the scoring + glue launch
                 navio = batch.fused_step(t)
@@ -331,18 +340,18 @@ class FollowerEngine:
                 nxt = t + 1 < S
                 call('sf_attn_decoder_tail_fwd', byref(dw), byref(cnd), B, H, D, T, None, ptr(h0),
                      ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue), d_ptr,
-                     st.site0 + t, byref(panos[t + 1]) if nxt and not deferred else None,
+                     st.site_rel + t, byref(panos[t + 1]) if nxt and not deferred else None,
                      byref(tapes[t + 1]) if nxt else None, *ws)
             else:
                 call('sf_attn_decoder_fwd', byref(dw), byref(pano), byref(cnd), B, H, D, T, None,
                      ptr(h0), ptr(c0), ptr(st.ctx), ptr(batch.mask), None, byref(tp), byref(glue),
-                     d_ptr, st.site0 + t, *ws)
+                     d_ptr, st.site_rel + t, *ws)
             if on_device_env:                           # env.step + observe + teacher for step t + 1
                 if navio is None:
                     batch.advance(t, st.actions[t], st.ended)
                 if deferred and t + 1 < S:              # the attention of step t + 1 over the panorama just chosen
                     call('sf_attn_decoder_attend_fwd', byref(panos[t + 1]), B, byref(tapes[t + 1]), d_ptr,
-                         st.site0 + t + 1, *ws)
+                         st.site_rel + t + 1, *ws)
         call('sf_reduce_terms', ptr(st.ce_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         st.logits = st.tape['logit']
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
@@ -531,7 +540,7 @@ class FollowerEngine:
         dh_a, dc_a, dh_b, dc_b = new(B, H), new(B, H), new(B, H), new(B, H)
         dctx = torch.zeros(B, T, H, device=dev, dtype=torch.float32)
         ws = ws_args(dev)
-        d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]))
+        d_dec = _lib.Dropout(float(st.drop_dec[0]), int(st.drop_dec[1]) & 0xFFFFFFFF, int(st.drop_dec[2]), st.site_dev, 1)
         d_ptr = C.pointer(d_dec) if st.drop_dec[0] else None
         dh1 = dc1 = None
         if st.episode is not None:
@@ -586,7 +595,7 @@ class FollowerEngine:
                  ptr(gscale[t:t + 1]), ptr(dlogit), ws[2])
             call('sf_attn_decoder_bwd', byref(dw), None, byref(pano), byref(cnd), B, H, D, T,
                  ptr(st.hs[t]), ptr(st.cs[t]), ptr(st.ctx), byref(tp), byref(gtp), ptr(dlogit),
-                 ptr(dh1), ptr(dc1), ptr(dh_a), ptr(dc_a), ptr(dctx), d_ptr, st.site0 + t, *ws)
+                 ptr(dh1), ptr(dc1), ptr(dh_a), ptr(dc_a), ptr(dctx), d_ptr, st.site_rel + t, *ws)
             dh1, dc1 = dh_a, dc_a
             dh_a, dc_a, dh_b, dc_b = dh_b, dc_b, dh_a, dc_a
         # data parallelism: dp.BucketedGrads laid out as dp.follower_buckets -- each bucket's all-reduce is
@@ -626,7 +635,7 @@ class FollowerEngine:
             eg = _encoder_structs(enc, grad=True, seq=None if st.enc_table else batch.seq)
             call('sf_encoder_lstm_bwd', byref(ew), byref(eg), B, T, E, H, ptr(batch.lengths_dev),
                  ptr(st.h_init), ptr(dctx), ptr(dh1), ptr(dc1), byref(etp), dropout_arg(*st.drop_enc),
-                 st.site0, *ws)
+                 st.site_rel, *ws)
         if sync is not None:
             sync.launch(2)                       # encoder gradients: complete behind sf_encoder_lstm_bwd
         if overlap and self.encoder_backward_first:

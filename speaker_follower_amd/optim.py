@@ -60,7 +60,7 @@ class FusedAdam(torch.optim.Optimizer):
                     flat_p[off:off + n].copy_(p.data.reshape(-1))
                     p.data = flat_p[off:off + n].view_as(p)      # the parameter now lives in the flat buffer
                     off += n
-            self._flat.append(dict(params=ps, p=flat_p, g=None, step=0,
+            self._flat.append(dict(params=ps, p=flat_p, g=None, step=0, step_dev=None, coef=None,
                                    m=torch.zeros(total, dtype=torch.float32, device=dev),
                                    v=torch.zeros(total, dtype=torch.float32, device=dev)))
 
@@ -100,14 +100,50 @@ class FusedAdam(torch.optim.Optimizer):
             g = self._grads(f)
             f['step'] += 1
             b1, b2 = group['betas']
-            _lib.call('sf_adam_step', ptr(f['p']), ptr(g), ptr(f['m']), ptr(f['v']), f['p'].numel(),
-                      float(group['lr']), float(b1), float(b2), float(group['eps']),
-                      float(group['weight_decay']), int(f['step']), stream())
+            if f['step_dev'] is not None:
+                # the step counter lives on the device (bind_device_steps): the kernel increments and uses it
+                _lib.call('sf_adam_step_dev', ptr(f['p']), ptr(g), ptr(f['m']), ptr(f['v']), f['p'].numel(),
+                          float(group['lr']), float(b1), float(b2), float(group['eps']),
+                          float(group['weight_decay']), f['step_dev'], ptr(f['coef']), stream())
+            else:
+                _lib.call('sf_adam_step', ptr(f['p']), ptr(g), ptr(f['m']), ptr(f['v']), f['p'].numel(),
+                          float(group['lr']), float(b1), float(b2), float(group['eps']),
+                          float(group['weight_decay']), int(f['step']), stream())
             # the kernel wrote behind torch's back: bump the version counters so that everything
             # keyed on `param._version` (transposed weight copies, folded tables) is rebuilt
             ps = f['params']
             torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
         return loss
+
+    # ---- a step that can live inside a hipGraph (runtime.TrainingGraph): the 1-based step counter is a device word the
+    # host writes in front of every replay (kernel arguments are frozen in a graph, device memory is not)
+    def live_groups(self):
+        return [f for f in self._flat if f is not None]
+
+    def bind_device_steps(self, words):
+        """words: device int32 tensor views, one per live parameter group (None: back to host-side counters)."""
+        live = self.live_groups()
+        if words is None:
+            for f in live:
+                f['step_dev'] = f['coef'] = None
+            return
+        assert len(words) == len(live)
+        for f, w in zip(live, words):
+            f['step_dev'] = _lib.C.c_void_p(w.data_ptr())
+            f['coef'] = torch.zeros(2, dtype=torch.float32, device=f['p'].device)
+            f['step_word'] = w
+
+    def host_steps(self):
+        return [f['step'] for f in self.live_groups()]
+
+    def set_host_steps(self, steps):
+        for f, s_ in zip(self.live_groups(), steps):
+            f['step'] = int(s_)
+
+    def bump_versions(self):
+        for f in self.live_groups():
+            ps = f['params']
+            torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
 
     # moments in the layout of torch.optim.Adam's state (per parameter), for inspection / tests
     def moments(self, p):

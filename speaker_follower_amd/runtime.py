@@ -180,11 +180,21 @@ def take_fault(device):
     return bits
 
 
-def dropout_arg(p, seed, row0=0):
-    """sf_dropout* (NULL when p == 0: eval mode)."""
+def dropout_arg(p, seed, row0=0, site_dev=None, site_mul=1):
+    """sf_dropout* (NULL when p == 0: eval mode).  site_dev: device word added (x site_mul) to every stream id of this
+    configuration -- the site counter of a captured training iteration (include/sf_hip.h: sf_dropout.site_dev)."""
     if not p:
         return None
-    return C.byref(_lib.Dropout(float(p), int(seed) & 0xFFFFFFFF, int(row0)))
+    return C.byref(_lib.Dropout(float(p), int(seed) & 0xFFFFFFFF, int(row0), site_dev, int(site_mul)))
+
+
+def site_word(device, value=0):
+    """A device-side site counter (one uint32 word, held as int32) for sf_dropout.site_dev / sf_sample.stream_dev."""
+    return torch.full((1,), int(value), dtype=torch.int32, device=device)
+
+
+def site_advance(word, by):
+    _lib.call('sf_site_advance', C.c_void_p(word.data_ptr()), int(by), stream())
 
 
 def grad_ptr(param):
