@@ -462,20 +462,69 @@ class FollowerEngine:
         weights; if a weight tensor itself was re-allocated, `replay()` raises and the rollout must be
         captured again.  Dropout sites are fixed at capture time: a captured TRAINING rollout would
         replay one mask forever, which is why only inference is captured here."""
+        # `sample` feedback: the sampling stream of a replay is a device word replay() writes first (kernel arguments are
+        # frozen in a graph): every replay draws new actions (sf_follower_glue.sample_site_dev)
+        sampled = feedback == 'sample'
+        ctl = torch.zeros(4, dtype=torch.int32, device=self.store.device) if sampled else None
         with torch.no_grad():
             self.rollout(batch, steps, feedback, train=False)          # warm-up: allocations, caches
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    st = self.rollout(batch, steps, feedback, train=False)
+            keep = (self.site_next, self.iteration)
+            self.site_word = ctl[0:1] if sampled else None
+            try:
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side):
+                        st = self.rollout(batch, steps, feedback, train=False)
+            finally:
+                self.site_word = None
+            if sampled:
+                self.site_next, self.iteration = keep                  # (the capture ran nothing)
             torch.cuda.current_stream().wait_stream(side)
         # (the graph bakes the capture stream's workspace -- runtime.workspace is keyed on the stream handle -- so the
         # stream lives as long as the state: a recycled handle would hand the same scratch to someone else)
         st.capture_stream = side
-        return self._guarded(graph.replay), st
+
+        def graph_replay():
+            if sampled:
+                call('sf_store_u32x4', C.c_void_p(ctl.data_ptr()), int(self.site_next) & 0xFFFFFFFF, 0, 0, 0, stream())
+                st.site0 = self.site_next
+                self.site_next += st.site_stride
+                self.iteration += 1
+            graph.replay()
+        return self._guarded(graph_replay), st
+
+    def capture_training(self, batch, steps, feedback='sample', optimizers=(), zero=None):
+        """hipGraph of ONE WHOLE TRAINING ITERATION (follower.py:1001-1020 + train.py:263-268): zero the gradients,
+        rollout in train mode (dropout on, `feedback` as given), BPTT, `optimizer.step()` for every optimizer
+        (optim.FusedAdam).  Returns a runtime.TrainingGraph; `.replay()` is one iteration, `.state` the rollout state
+        its replays overwrite.  Runs one eager iteration first (a real training step).
+
+        Every replay draws fresh dropout masks / samples and takes the next Adam step: sites and step counters are
+        device words the graph reads (sf_dropout.site_dev, sf_adam_step_dev), numbered exactly like the eager loop's.
+        Single process only (a gradient all-reduce cannot live in the graph); unidirectional encoder; pre-drawn
+        observations or a device-resident environment (nav.DeviceNavBatch)."""
+        from .runtime import TrainingGraph
+        if self.group is not None or self.grad_sync is not None:
+            raise NotImplementedError('capture_training: data-parallel iterations are issued eagerly')
+        if self.encoder.num_directions == 2:
+            raise NotImplementedError('capture_training: unidirectional encoder only')
+        opts = list(optimizers)
+
+        def body():
+            if zero is not None:
+                zero.zero()
+            else:
+                for o in opts:
+                    o.zero_grad()
+            st = self.rollout(batch, steps, feedback, train=True)
+            st.loss.backward()
+            for o in opts:
+                o.step()
+            return st
+        return TrainingGraph(self, body, opts, self.store.device)
 
     def capture_sharded(self, shards, steps, feedback='argmax'):
         """Runs the row shards of ONE batch as concurrent chains (inference): one hipGraph per
@@ -552,7 +601,8 @@ class FollowerEngine:
                                      gt_dh1d.data_ptr())
             # second stream: the scoring / text-attention backward of step t-1 runs beside the LSTM /
             # visual backward of step t (not under stream capture: eager issue only)
-            if self.two_stream_backward and not torch.cuda.is_current_stream_capturing():
+            # (under stream capture only with a side stream that already exists: probing one launches timed kernels)
+            if self.two_stream_backward and (self._side_stream is not None or not torch.cuda.is_current_stream_capturing()):
                 if self._side_stream is None:
                     self._side_stream = concurrent_stream(dev)
                 ep.side_stream = self._side_stream.cuda_stream
@@ -608,7 +658,7 @@ class FollowerEngine:
         # the decoder's weight gradients (a few large products over the stacked rows: matrix-core
         # work) and the encoder's backward through time (80 dependent, latency-bound steps) are
         # independent: issued on two streams they overlap
-        overlap = self.two_stream_backward and not torch.cuda.is_current_stream_capturing()
+        overlap = self.two_stream_backward and (self._side_stream is not None or not torch.cuda.is_current_stream_capturing())
         if overlap:
             side = self._wgrad_stream if (st.episode is not None and Sw < S) else self._side_stream
             if side is None:

@@ -197,6 +197,79 @@ def site_advance(word, by):
     _lib.call('sf_site_advance', C.c_void_p(word.data_ptr()), int(by), stream())
 
 
+class TrainingGraph:
+    """ONE whole training iteration -- zero the gradients, rollout / scoring pass in train mode, backward through
+    time, optimizer steps -- as a hipGraph (follower.py:1001-1020, speaker.py:376-395 per replay).
+
+    Kernel arguments are frozen in a graph; what must differ between two iterations lives in device memory instead:
+    the dropout / sampling SITE counter (sf_dropout.site_dev, sf_sample.stream_dev) and the optimizers' step counters
+    (sf_adam_step_dev).  `replay()` writes those four words with one tiny launch (values travel as kernel arguments of
+    THAT launch) and launches the graph: iteration n of a replayed loop draws exactly the masks, samples and bias
+    corrections of iteration n of the eager loop (tests/test_gpu_training_graph.py).
+
+    `body()` must issue one complete iteration on the current stream and return the pass state; it is run ONCE
+    eagerly (a real training step: caches, workspaces, streams; its state is `.first`) and then captured (`.state`: the
+    tensors every replay overwrites).  `engine` carries `site_next`
+    (host mirror of the counter), `iteration` and `site_word`."""
+
+    def __init__(self, engine, body, optimizers, device):
+        self.engine, self.optimizers = engine, list(optimizers)
+        groups = sum(len(o.live_groups()) for o in self.optimizers)
+        if groups > 3:
+            raise ValueError('at most three optimizer parameter groups per training graph')
+        self.ctl = torch.zeros(4, dtype=torch.int32, device=device)            # [site, step, step, step]
+        k = 1
+        for o in self.optimizers:
+            n = len(o.live_groups())
+            o.bind_device_steps([self.ctl[k + i:k + i + 1] for i in range(n)])
+            k += n
+        engine.site_word = self.ctl[0:1]
+        self.stream = torch.cuda.Stream(device=device)
+        cur = torch.cuda.current_stream(device)
+        self.stream.wait_stream(cur)
+        try:
+            with torch.cuda.stream(self.stream):
+                self._store()
+                self.first = body()                     # eager: a real iteration, on the capture stream (its state)
+                torch.cuda.synchronize(device)
+                invalidate_caches()                     # every derived weight copy is refreshed INSIDE the graph
+                keep = (engine.site_next, engine.iteration, [o.host_steps() for o in self.optimizers])
+                self.graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.graph, stream=self.stream):
+                    self.state = body()
+                # the capture advanced the host mirrors without running anything
+                engine.site_next, engine.iteration = keep[0], keep[1]
+                for o, st_ in zip(self.optimizers, keep[2]):
+                    o.set_host_steps(st_)
+            cur.wait_stream(self.stream)
+        finally:
+            engine.site_word = None
+            for o in self.optimizers:
+                o.bind_device_steps(None)
+        self.stride = self.state.site_stride
+        self.replays = 0
+
+    def _store(self):
+        steps = [s for o in self.optimizers for s in o.host_steps()] + [0, 0, 0]
+        _lib.call('sf_store_u32x4', C.c_void_p(self.ctl.data_ptr()), int(self.engine.site_next) & 0xFFFFFFFF,
+                  int(steps[0]), int(steps[1]), int(steps[2]), stream())
+
+    def replay(self):
+        """One training iteration on the current stream.  Returns the (static) pass state: its tensors are
+        overwritten by every replay; `state.site0` is the host mirror of the sites this replay uses."""
+        eng = self.engine
+        self._store()
+        self.graph.replay()
+        self.state.site0 = eng.site_next
+        eng.site_next += self.stride
+        eng.iteration += 1
+        for o in self.optimizers:
+            o.set_host_steps([s + 1 for s in o.host_steps()])
+            o.bump_versions()                           # eager code that follows must rebuild its derived weight copies
+        self.replays += 1
+        return self.state
+
+
 def grad_ptr(param):
     """Pointer to the in-place gradient accumulator of a parameter (NULL if frozen).
 

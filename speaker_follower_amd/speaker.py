@@ -82,6 +82,7 @@ class SpeakerEngine:
         self.group = group
         self.iteration = 0
         self.site_next = 0              # first unused dropout site (see score)
+        self.site_word = None           # device-side site counter while a training graph is captured (runtime.TrainingGraph)
         self.dropout_seed = None
         self.persistent = True          # inference passes: the whole word loop as ONE launch (sf_speaker_decode)
         self.stacked_wgrad = True       # backward: weight gradients as one product over all S*B rows (False: per step)
@@ -90,15 +91,26 @@ class SpeakerEngine:
     def capture(self, batch, steps, feedback='teacher'):
         """hipGraph of one inference scoring / decoding pass: returns (replay, state); the state's
         tensors are overwritten by every replay (same contract as FollowerEngine.capture)."""
+        # `sample` feedback: the sampling stream must differ between replays, and kernel arguments are frozen in a graph --
+        # the pass reads it from a device word that replay() writes first (sf_sample.stream_dev)
+        sampled = feedback == 'sample'
+        ctl = torch.zeros(4, dtype=torch.int32, device=self.store.device) if sampled else None
         with torch.no_grad():
             self.score(batch, steps, feedback, train=False)
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                with torch.cuda.graph(graph, stream=side):
-                    st = self.score(batch, steps, feedback, train=False)
+            keep = (self.site_next, self.iteration)
+            self.site_word = ctl[0:1] if sampled else None
+            try:
+                with torch.cuda.stream(side):
+                    with torch.cuda.graph(graph, stream=side):
+                        st = self.score(batch, steps, feedback, train=False)
+            finally:
+                self.site_word = None
+            if sampled:
+                self.site_next, self.iteration = keep           # (the capture ran nothing)
             torch.cuda.current_stream().wait_stream(side)
         baked = bytes(self.decoder._w_struct())
 
@@ -107,6 +119,11 @@ class SpeakerEngine:
             # re-allocated weight cannot be patched into the graph (FollowerEngine.capture)
             if bytes(self.decoder._w_struct()) != baked:
                 raise RuntimeError('a speaker weight moved since this pass was captured; capture() again')
+            if sampled:
+                call('sf_store_u32x4', C.c_void_p(ctl.data_ptr()), int(self.site_next) & 0xFFFFFFFF, 0, 0, 0, stream())
+                st.site0 = self.site_next
+                self.site_next += st.site_stride
+                self.iteration += 1
             graph.replay()
         # The graph bakes the capture stream's workspace (runtime.workspace is keyed on the stream handle): the stream
         # must live as long as the graph, or a later stream could be handed the same handle -- and with it the same
@@ -133,16 +150,21 @@ class SpeakerEngine:
         st.feedback = FEEDBACK[feedback]
         if self.dropout_seed is None:
             self.dropout_seed = torch.initial_seed() & 0xFFFFFFFF
-        st.drop_enc = (enc.drop.p if training else 0.0, self.dropout_seed ^ 0x2545F491, batch.row0)
-        st.drop_dec = (dec.drop.p if training else 0.0, self.dropout_seed, batch.row0)
         # sites site0 .. site0 + max(S, Tp) + 1 are used by this pass; the next one starts behind them
         st.site0 = self.site_next
-        self.site_next += max(256, S + 2, Tp + 2)
+        st.site_stride = max(256, S + 2, Tp + 2)
+        self.site_next += st.site_stride
         self.iteration += 1
+        # what the kernels are given: the absolute site, or (device-side counter) 0 + the word's address.  The encoder's
+        # raw stream ids are numbered 2 * (site + t) (+ 1): its configuration scales the device offset by 2
+        st.site_dev = C.c_void_p(self.site_word.data_ptr()) if self.site_word is not None else None
+        st.site_rel = 0 if self.site_word is not None else st.site0
+        st.drop_enc = (enc.drop.p if training else 0.0, self.dropout_seed ^ 0x2545F491, batch.row0, st.site_dev, 2)
+        st.drop_dec = (dec.drop.p if training else 0.0, self.dropout_seed, batch.row0, st.site_dev, 1)
         ws = ws_args(dev)
         # `sample` feedback (speaker.py:170-174): word step t draws from stream site0 + t of this seed, keyed on the
         # global row id (sf_sampling.h)
-        smp = _lib.Sample((self.dropout_seed ^ 0x3C6EF372) & 0xFFFFFFFF, st.site0, batch.row0)
+        smp = _lib.Sample((self.dropout_seed ^ 0x3C6EF372) & 0xFFFFFFFF, st.site_rel, batch.row0, st.site_dev)
         if self.group is not None and st.feedback != 0:
             raise NotImplementedError('row-sharded speaker passes support teacher feedback only (the point where every '
                                       'row has produced EOS, speaker.py:196, is a property of the whole batch)')
@@ -182,12 +204,12 @@ class SpeakerEngine:
         call('sf_speaker_encoder_fwd', byref(vw), byref(lw), ptr(e2d.weight), ptr(e2d.bias), byref(pano0), Tp, B, H, D,
              ptr(st.e['xin']), ptr(st.e['alpha']), ptr(st.e['t_v']), ptr(st.e['q']), ptr(st.e['gates']), ptr(st.e['hs']),
              ptr(st.e['cs']), ptr(st.ctx) if d_enc is None else None, ptr(st.e['act_emb']), ptr(st.h_init), d_enc,
-             st.site0, *ws)
+             st.site_rel, *ws)
         st.c_init = st.e['cs'][Tp]
         if d_enc is not None:
             ctx_raw = st.e['hs'][1:].permute(1, 0, 2).contiguous()      # [B,Tp,H]
             call('sf_dropout_copy', ptr(ctx_raw), Tp * H, B, Tp * H, ptr(st.ctx), Tp * H, d_enc,
-                 2 * (st.site0 + Tp) + 1, 0, ws[2])
+                 2 * (st.site_rel + Tp) + 1, 0, ws[2])
 
         # ---- decoder: S x (embedding -> LSTMCell -> dropout -> attention -> vocab projection)
         shapes = dict(emb=(E,), gates=(4 * H,), c1=(H,), h1=(H,), cat2=(2 * H,), t_text=(H,),
@@ -229,7 +251,7 @@ class SpeakerEngine:
                                         for k in _DEC_TAPE))
             call('sf_speaker_words_fwd', byref(dw), B, E, H, Tp, vocab, S, st.feedback, PAD, EOS, ptr(st.targets),
                  ptr(st.h_init), ptr(st.c_init), ptr(st.ctx), ptr(batch.path_mask), ptr(st.words), ptr(st.ended),
-                 ptr(st.step_scores), ptr(st.nll_term), ptr(st.live), byref(tp0), d_dec, st.site0,
+                 ptr(st.step_scores), ptr(st.nll_term), ptr(st.live), byref(tp0), d_dec, st.site_rel,
                  byref(smp) if st.feedback == 2 else None, *ws)
         call('sf_reduce_terms', ptr(st.nll_term), ptr(st.live), S, B, ptr(st.sum_cnt), ws[2])
         if self.group is not None:
@@ -244,6 +266,26 @@ class SpeakerEngine:
         else:
             st.loss = st.loss_buf.clone().reshape(())
         return st
+
+    def capture_training(self, batch, steps, optimizers=(), feedback='teacher'):
+        """hipGraph of ONE WHOLE TRAINING ITERATION of the speaker (speaker.py:376-395: zero_grad, teacher-forced scoring
+        pass with dropout, loss.backward(), optimizer steps).  Returns a runtime.TrainingGraph (see
+        FollowerEngine.capture_training): the ~1 300 launches of an iteration cost 6.7 ms of host issue when issued one
+        by one and nothing when replayed."""
+        from .runtime import TrainingGraph
+        if self.group is not None:
+            raise NotImplementedError('capture_training: row-sharded passes are issued eagerly')
+        opts = list(optimizers)
+
+        def body():
+            for o in opts:
+                o.zero_grad()
+            st = self.score(batch, steps, feedback, train=True)
+            st.loss.backward()
+            for o in opts:
+                o.step()
+            return st
+        return TrainingGraph(self, body, opts, self.store.device)
 
     def run(self, batch, steps, feedback='teacher', train=None):
         """`score` + the fault check of the persistent word loop (include/sf_hip.h: sf_workspace_fault_offset): one
@@ -287,7 +329,7 @@ class SpeakerEngine:
         gtape = _lib.SpkDecoderGTape(*(gt[k].data_ptr() for k in ('dlogit', 'dpre', 'dt_text', 'dgates')))
         call('sf_speaker_words_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, S, PAD, ptr(st.words), ptr(st.targets),
              ptr(st.h_init), ptr(st.c_init), ptr(st.ctx), byref(tp0), ptr(gscale.contiguous()), ptr(dlogit), ptr(dh_a),
-             ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(in_b), d_dec, st.site0,
+             ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(in_b), d_dec, st.site_rel,
              byref(gtape) if self.stacked_wgrad else None, ptr(st.hs_all), *ws)
         dh1, dc1 = (dh_b, dc_b) if in_b.value else (dh_a, dc_a)
         # ---- encoder backward
@@ -307,7 +349,7 @@ class SpeakerEngine:
         # through ctx = dropout(stack(h_1..h_Tp))
         dctx_raw = new(B, Tp, H)
         call('sf_dropout_copy', ptr(dctx), Tp * H, B, Tp * H, ptr(dctx_raw), Tp * H, d_enc,
-             2 * (st.site0 + Tp) + 1, 0, ws[2])
+             2 * (st.site_rel + Tp) + 1, 0, ws[2])
         dctx_t = dctx_raw.permute(1, 0, 2).contiguous()    # [Tp,B,H]
         dxin = new(B, 2 * F)
         dh_in, dh_out = dh, new(B, H)
@@ -323,7 +365,7 @@ class SpeakerEngine:
             dxin_f = C.c_void_p(dxin.data_ptr() + 4 * F)
             call('sf_visual_attention_bwd', byref(vw), byref(vg), byref(pano), B, H, D,
                  ptr(st.e['hs'][t]), ptr(st.e['alpha'][t]), ptr(st.e['t_v'][t]), dxin_f, 2 * F, d_enc,
-                 2 * (st.site0 + t), F, ptr(dh_out), *ws)
+                 2 * (st.site_rel + t), F, ptr(dh_out), *ws)
             dh_in, dh_out = dh_out, dh_in
             dc_in, k = dc_bufs[k], k ^ 1
 
