@@ -310,8 +310,28 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
                             'executed FLOPs = 3 x the forward (data + weight gradients), encoder excluded')
     enc.eval()
     dec.eval()
+    graph = None
+    if world == 1 and not coll:
+        # the same iteration as ONE hipGraph replay (runtime.TrainingGraph): the dependent chain without launch gaps
+        engine.grad_sync = None
+        enc.train()
+        dec.train()
+        tg = engine.capture_training(batch, S, 'argmax', optimizers=(opt_e, opt_d), zero=flat)
+        for _ in range(3):
+            tg.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(iters):
+            tg.replay()
+        torch.cuda.synchronize()
+        dt_g = (time.perf_counter() - t1) / iters
+        graph = dict(ms_per_iteration=1e3 * dt_g, value=B * S / dt_g, unit='agent-steps/s', loss=float(tg.state.loss_buf),
+                     what='the same iteration as one hipGraph replay (dropout sites / Adam steps through device words: every '
+                          'replay is a new valid iteration, bit-identical to the eager loop)')
+        enc.eval()
+        dec.eval()
     rows = B * world if global_rows is None else global_rows
-    return dict(value=rows * S / dt, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
+    return dict(value=rows * S / dt, graph=graph, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
                 scaling='weak' if global_rows is None else 'strong', global_batch=rows, rows_this_rank=B,
                 roofline=kernels, health=health,
                 allreduce_bytes=flat.flat.numel() * 4, **ar,

@@ -659,6 +659,32 @@ int sf_speaker_words_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, i
                          float* dlogit, float* dh_a, float* dc_a, float* dh_b, float* dc_b, float* dctx,
                          int* result_in_b, const sf_dropout* drop, uint32_t step0, const sf_spk_decoder_gtape* gtape,
                          const float* h0_all, void* ws, size_t ws_bytes, sf_stream stream);
+/* TEACHER-FORCED pass over S word steps (speaker.py:158-197 with feedback = teacher; ABI 8).  The next input word is
+ * the target, so the recurrence does not depend on attention / projection / glue: it runs alone as ONE persistent
+ * launch (the encoder's recurrence kernel with a given initial state) and everything else -- dropout(h1), attention over
+ * the path context, h~, vocabulary projection, log-soft-max / NLL / score (model.py:516-518, speaker.py:163-191) -- runs
+ * for all S*B rows at once.  hs_all / cs_all [S+1,B,H]: slot 0 = the initial state (in), slots 1..S = h1 / c1 of the
+ * steps (out; tape0->h1 / c1 must point at slot 1); tape0->gates / cat2 / t_text / alpha / h_tilde / logit are the
+ * stacked [S,B,...] tapes of sf_speaker_decoder_fwd (emb optional: all S*B embedded words, for the backward's dW_ih);
+ * words [S+1,B] receives words[t+1] = targets[t]; ended / step_scores / nll_term / live as sf_speaker_glue_fwd.
+ * Needs w->xw_table, no embedding dropout.  SF_ERR_UNSUPPORTED (H != 512, B > 128, S > 128, < 256 CUs): run
+ * sf_speaker_words_fwd. */
+int sf_speaker_teacher_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab, int S, int pad_idx,
+                           int eos_idx, const int64_t* targets, float* hs_all, float* cs_all, const float* ctx,
+                           const uint8_t* ctx_mask, int64_t* words, uint8_t* ended, float* step_scores, float* nll_term,
+                           float* live, const sf_spk_decoder_tape* tape0, const sf_dropout* drop, uint32_t step0, void* ws,
+                           size_t ws_bytes, sf_stream stream);
+/* Its backward: the head's backward for all S*B rows at once, the recurrence's backward as one persistent launch with the
+ * head's d h1 as per-step external gradient, every weight gradient as ONE product over the stacked rows (g may be NULL:
+ * data gradients only).  gscale [S]; dh_init / dc_init [B,H] out (gradient wrt slot 0 of hs_all / cs_all); dctx
+ * [B,Tp,H] accumulated; gtape as sf_speaker_words_bwd; dcat2 [S*B,2H], ds [S*B,Tp], dh1_ext [S*B,H]: caller-owned
+ * scratch.  SF_ERR_UNSUPPORTED as the forward (and with a trainable embedding): run sf_speaker_words_bwd. */
+int sf_speaker_teacher_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H, int Tp, int vocab,
+                           int S, int pad_idx, const int64_t* words, const int64_t* targets, const float* hs_all,
+                           const float* cs_all, const float* ctx, const sf_spk_decoder_tape* tape0, const float* gscale,
+                           float* dh_init, float* dc_init, float* dctx, const sf_dropout* drop, uint32_t step0,
+                           const sf_spk_decoder_gtape* gtape, float* dcat2, float* ds, float* dh1_ext, void* ws,
+                           size_t ws_bytes, sf_stream stream);
 
 /* ---- search helpers (follower.py:541-980 beam / state-factored search, speaker.py:211-318) ------
  * dst[i, :width] = src[idx[i], :width] (idx < 0 => zeros): `h_t[flat_indices]`, `c_t[flat_indices]`

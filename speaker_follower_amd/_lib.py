@@ -227,6 +227,11 @@ _SIGNATURES = {
     'sf_speaker_words_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32, i32, i32, i64p, i64p, c_f,
                                        c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, c_f, c_f, c_f, P(C.c_int),
                                        P(Dropout), u32, P(SpkDecoderGTape), c_f] + WS),
+    'sf_speaker_teacher_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i32, i32, i32, i64p, c_f, c_f, c_f, c_p,
+                                         i64p, c_p, c_f, c_f, c_f, P(SpkDecoderTape), P(Dropout), u32] + WS),
+    'sf_speaker_teacher_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32, i32, i32, i64p, i64p, c_f,
+                                         c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, P(Dropout), u32,
+                                         P(SpkDecoderGTape), c_f, c_f, c_f] + WS),
     'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
     'sf_add_f32': (C.c_int, [c_f, c_f, C.c_size_t, c_p]),
     'sf_adam_step': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -812,6 +812,27 @@ class Seq2SeqSpeaker(object):
             decoder_optimizer.zero_grad()
             self.rollout()
             self.loss.backward()
+            # teacher-forced passes run their recurrence (forward and backward) as persistent launches since round 5: a
+            # starved BACKWARD has poisoned the gradients -- never step on them; train this iteration on the next
+            # minibatch with the per-step kernels instead (the forward's own check sits inside SpeakerEngine.run)
+            dev = next(self.decoder.parameters()).device
+            if _persistent_fault(dev):
+                encoder_optimizer.zero_grad()
+                decoder_optimizer.zero_grad()
+                self.losses.pop()
+                eng = getattr(self, '_engine', None)
+                keep = eng.persistent if eng is not None else True
+                if eng is not None:
+                    eng.persistent = False
+                    eng.fallbacks += 1
+                try:
+                    self.rollout()
+                    self.loss.backward()
+                finally:
+                    if eng is not None:
+                        eng.persistent = keep
+                if _persistent_fault(dev):
+                    raise PersistentLaunchFault('the per-step re-issue of a training iteration raised a fault again')
             encoder_optimizer.step()
             decoder_optimizer.step()
 

@@ -422,9 +422,24 @@ def speaker_train_iteration(store, device, batch=100, words=80, iters=10):
     host = (time.perf_counter() - t0) / iters
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    return dict(what='speaker training iteration: %d paths x %d words, teacher forcing, dropout 0.5, BPTT, 2x Adam; eager issue'
-                     % (batch, words), value=batch * words / dt, unit='word-steps/s', ms_per_iteration=1e3 * dt,
-                ms_host_issue=1e3 * host, loss=float(st.loss.detach()))
+    eager = dict(ms_per_iteration=1e3 * dt, ms_host_issue=1e3 * host, loss=float(st.loss.detach()))
+    # the same iteration as ONE hipGraph replay (runtime.TrainingGraph: dropout sites and Adam steps are device words
+    # written in front of each replay, so every replay is a new, valid iteration -- tests/test_gpu_training_graph.py)
+    tg = eng.capture_training(b, words, optimizers=(oe, od))
+    for _ in range(3):
+        tg.replay()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        tg.replay()
+    host_g = (time.perf_counter() - t0) / iters
+    torch.cuda.synchronize()
+    dt_g = (time.perf_counter() - t0) / iters
+    return dict(what='speaker training iteration: %d paths x %d words, teacher forcing, dropout 0.5, BPTT, 2x Adam; ONE hipGraph '
+                     'replay per iteration (fresh dropout sites / Adam steps through device words); `eager` = the same iteration '
+                     'issued launch by launch' % (batch, words),
+                value=batch * words / dt_g, unit='word-steps/s', ms_per_iteration=1e3 * dt_g, ms_host_issue=1e3 * host_g,
+                loss=float(tg.state.loss_buf), eager=eager)
 
 
 @_guard

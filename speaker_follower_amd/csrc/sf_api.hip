@@ -304,7 +304,8 @@ int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, in
                   const float* h_tilde, const float* dh_tilde, float* dh, int lddh, float* dctx,
                   Arena ar, hipStream_t st, float* dpre_out = nullptr, float* dt_out = nullptr,
                   bool dpre_ready = false,     // dh_tilde already IS dpre (written to dpre_out)
-                  float* dcat2_out = nullptr, float* ds_out = nullptr) {   // both: dctx is deferred
+                  float* dcat2_out = nullptr, float* ds_out = nullptr,     // both: dctx is deferred
+                  const int32_t* ctx_row = nullptr) {                      // (deferred only) row b reads ctx row ctx_row[b]
     float* dpre = dpre_out ? dpre_out : ar.take((size_t)B * H);
     float* dt = dt_out ? dt_out : ar.take((size_t)B * H);
     float* dcat2 = dcat2_out ? dcat2_out : ar.take((size_t)B * 2 * H);
@@ -315,7 +316,7 @@ int softdot_bwd_i(const sf_softdot_w* w, const sf_softdot_g* g, int B, int L, in
     TRY(data_grad(dpre, H, w->w_out, w->w_out_t, B, H, 2 * H, dcat2, 2 * H, 0, ar, st));
     if (g && g->w_out) TRY(gemm_tn(dpre, H, cat2, 2 * H, B, H, 2 * H, g->w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
     TRY(text_attn_bwd(ctx, B, L, H, dcat2, 2 * H, t_text, H, alpha, dt, H, defer ? nullptr : dctx, st,
-                      defer ? ds_out : nullptr));
+                      defer ? ds_out : nullptr, ctx_row));
     // dh = dcat2[:, H:] + dt W_in: the addend rides in the epilogue of the product
     bool dh_done = false;
     if (w->w_in_t) {
@@ -1797,6 +1798,106 @@ int sf_speaker_words_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, i
             TRY(gemm_tn(gtape->dgates, 4 * H, tape0->emb, E, M, 4 * H, E, g->lstm.w_ih, E, 1, st, ar.rest(), ar.rest_n()));
         }
         if (g->lstm.w_hh) TRY(gemm_tn(gtape->dgates, 4 * H, h0_all, H, M, 4 * H, H, g->lstm.w_hh, H, 1, st, ar.rest(), ar.rest_n()));
+        TRY(colsum_pair(gtape->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
+    }
+    return SF_OK;
+}
+
+// ---- TEACHER-FORCED speaker passes (round 5) ------------------------------------------------------------------------
+// With teacher forcing the next input word is the target (speaker.py:166-167): the recurrence h_t = LSTM(emb(w_t), h_{t-1})
+// does not depend on the attention, the vocabulary projection or the glue of any step.  So the S word steps split into
+//   (1) the recurrence alone -- structurally the follower's EncoderLSTM with a given initial state: ONE persistent launch
+//       (enc_persist_kernel, 4.5 us per step instead of 11 us for the full persistent word loop and ~50 us per-step), and
+//   (2) everything else -- dropout(h1), attention over the path context, h~, vocabulary projection, log-soft-max / NLL /
+//       score -- for all S*B rows AT ONCE: five products with M = S*B instead of 5 S launch-bound ones with M = B.
+// The backward likewise: the head's backward for all rows at once, then enc_bwd_persist_kernel with the head's dh1 as the
+// per-step external gradient.  Same arithmetic per element as the per-step entry points (sf_speaker_words_fwd / _bwd are
+// the checkers in tests/test_gpu_speaker_teacher.py).
+int sf_speaker_teacher_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int Tp, int vocab, int S, int pad_idx,
+                           int eos_idx, const int64_t* targets, float* hs_all, float* cs_all, const float* ctx,
+                           const uint8_t* ctx_mask, int64_t* words, uint8_t* ended, float* step_scores, float* nll_term,
+                           float* live, const sf_spk_decoder_tape* tape0, const sf_dropout* drop, uint32_t step0, void* ws,
+                           size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && targets && hs_all && cs_all && ctx && words && ended && step_scores && nll_term && live && tape0 &&
+                 tape0->gates && tape0->cat2 && tape0->t_text && tape0->alpha && tape0->h_tilde && tape0->logit && B > 0 &&
+                 S > 0 && Tp > 0 && vocab > 0);
+    if (!w->xw_table || (w->flags & SF_SPK_EMB_DROPOUT) || !encoder_persistent_supported(B, H, S)) return SF_ERR_UNSUPPORTED;
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = (hipStream_t)stream;        // (the parameter S shadows the S() cast helper here)
+    const size_t BH = (size_t)B * H;
+    const int M = S * B, ldv = (vocab + 3) & ~3;
+    SF_CHECK_ARG(tape0->h1 == hs_all + BH && tape0->c1 == cs_all + BH);
+    float* xchg = ar.take(encoder_persistent_xchg_floats(H));
+    int* crow = reinterpret_cast<int*>(ar.take((size_t)M));
+    NEED(xchg && crow && ar.tickets());
+    // teacher forcing: words[t + 1] = targets[t] (speaker.py:167) -- known before the first step
+    if (hipMemcpyAsync(words + B, targets, (size_t)M * sizeof(int64_t), hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return SF_ERR_LAUNCH;
+    // (1) the recurrence: tokens words[t][b] (time-major: stride B per step), initial state = slot 0 of the tapes
+    TRY(encoder_persistent(w->lstm.w_hh, w->lstm.b_ih, w->lstm.b_hh, w->xw_table, words, 1, nullptr, B, H, S,
+                           tape0->gates, hs_all, cs_all, nullptr, make_dropout(nullptr, 0), xchg,
+                           ar.tickets() + PERSIST_TICKET, st, nullptr, hs_all, cs_all, (long)B));
+    if (tape0->emb) TRY(embedding_rows(w->embedding, E, words, M, tape0->emb, st));      // (only the backward's dW_ih reads them)
+    // (2) the head over all S*B rows: dropout(h1) with the per-step sites 2 (step0 + t) + 1 (model.py:516) ...
+    TRY(dropout_steps(hs_all + BH, H, S, B, H, tape0->cat2 + H, 2 * H, make_dropout(drop, 2 * step0 + 1, 2), 2, st));
+    // ... attention over the path context of row m % B, h~ (model.py:517), vocabulary projection (:518)
+    TRY(row_mod(crow, M, B, st));
+    TRY(softdot_fwd_i(&w->attn, M, Tp, H, nullptr, 0, ctx, ctx_mask, tape0->h_tilde, tape0->alpha, tape0->cat2,
+                      tape0->t_text, ar, st, crow));
+    TRY(linear_plain(tape0->h_tilde, H, w->w_out, H, w->b_out, M, vocab, H, EPI_NONE, tape0->logit, ldv, ar, st));
+    // glue of every step (speaker.py:163-191; teacher feedback: rows are independent, `ended` is an OR)
+    return speaker_glue_fwd(M, vocab, ldv, tape0->logit, targets, 0, pad_idx, eos_idx, ended, words + B, step_scores,
+                            nll_term, live, st, nullptr, B);
+}
+
+int sf_speaker_teacher_bwd(const sf_spk_decoder_w* w, const sf_spk_decoder_g* g, int B, int E, int H, int Tp, int vocab,
+                           int S, int pad_idx, const int64_t* words, const int64_t* targets, const float* hs_all,
+                           const float* cs_all, const float* ctx, const sf_spk_decoder_tape* tape0, const float* gscale,
+                           float* dh_init, float* dc_init, float* dctx, const sf_dropout* drop, uint32_t step0,
+                           const sf_spk_decoder_gtape* gtape, float* dcat2, float* ds, float* dh1_ext, void* ws,
+                           size_t ws_bytes, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && words && targets && hs_all && cs_all && ctx && tape0 && gscale && dh_init && dc_init && dctx && gtape &&
+                 gtape->dlogit && gtape->dpre && gtape->dt_text && gtape->dgates && dcat2 && ds && dh1_ext && B > 0 && S > 0);
+    if (!w->xw_table || (w->flags & SF_SPK_EMB_DROPOUT) || (g && g->embedding) || !encoder_persistent_supported(B, H, S) ||
+        !ctx_grad_supported(S, Tp, H))
+        return SF_ERR_UNSUPPORTED;
+    Arena ar = arena(ws, ws_bytes);
+    hipStream_t st = (hipStream_t)stream;        // (the parameter S shadows the S() cast helper here)
+    const size_t BH = (size_t)B * H;
+    const int M = S * B, ldv = (vocab + 3) & ~3;
+    float* xchg = ar.take(encoder_bwd_persistent_xchg_floats());
+    int* crow = reinterpret_cast<int*>(ar.take((size_t)M));
+    NEED(xchg && crow && ar.tickets());
+    // ---- the head's backward for all S*B rows at once
+    TRY(softmax_ce_bwd(M, vocab, ldv, tape0->logit, targets, pad_idx, gscale, gtape->dlogit, st, B));
+    TRY(spk_dlogit_to_dht(w, gtape->dlogit, ldv, M, H, vocab, gtape->dpre, ar, st));             // d h~ ...
+    TRY(tanh_bwd(tape0->h_tilde, H, gtape->dpre, H, M, H, gtape->dpre, H, st));                  // ... -> d pre, in place
+    TRY(row_mod(crow, M, B, st));
+    // (dh1_ext receives d dropout(h1) = dcat2[:, H:] + dt W_in; the context gradient is deferred: dcat2 / ds)
+    TRY(softdot_bwd_i(&w->attn, nullptr, M, Tp, H, ctx, tape0->alpha, tape0->cat2, tape0->t_text, tape0->h_tilde,
+                      gtape->dpre, dh1_ext, H, nullptr, ar, st, gtape->dpre, gtape->dt_text, true, dcat2, ds, crow));
+    TRY(ctx_grad_accum(tape0->alpha, ds, dcat2, 2 * H, tape0->t_text, S, B, Tp, H, dctx, st));
+    // through dropout(h1): the forward's masks, in place
+    TRY(dropout_steps(dh1_ext, H, S, B, H, dh1_ext, H, make_dropout(drop, 2 * step0 + 1, 2), 2, st));
+    // ---- the recurrence's backward: all S steps in one persistent launch, dh1_ext[t] the external gradient of h_t
+    TRY(encoder_bwd_persistent(w->lstm.w_hh, nullptr, B, H, S, tape0->gates, cs_all, dh1_ext, make_dropout(nullptr, 0),
+                               nullptr, nullptr, gtape->dgates, xchg, ar.tickets() + PERSIST_TICKET, st, (long)H,
+                               (long)BH, dc_init));
+    // d h_init = dgates_0 W_hh
+    TRY(data_grad(gtape->dgates, 4 * H, w->lstm.w_hh, w->lstm.w_hh_t, B, 4 * H, H, dh_init, H, 0, ar, st));
+    if (g) {
+        // every weight gradient as ONE product over the S*B stacked rows (as sf_speaker_words_bwd with a gtape)
+        if (g->w_out) TRY(gemm_tn(gtape->dlogit, ldv, tape0->h_tilde, H, M, vocab, H, g->w_out, H, 1, st, ar.rest(), ar.rest_n()));
+        if (g->b_out) TRY(colsum(gtape->dlogit, ldv, M, vocab, g->b_out, 1, st, nullptr, ar.rest(), ar.rest_n()));
+        if (g->attn.w_out) TRY(gemm_tn(gtape->dpre, H, tape0->cat2, 2 * H, M, H, 2 * H, g->attn.w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
+        if (g->attn.w_in) TRY(gemm_tn(gtape->dt_text, H, tape0->cat2 + H, 2 * H, M, H, H, g->attn.w_in, H, 1, st, ar.rest(), ar.rest_n()));
+        if (g->lstm.w_ih) {
+            SF_CHECK_ARG(tape0->emb);
+            TRY(gemm_tn(gtape->dgates, 4 * H, tape0->emb, E, M, 4 * H, E, g->lstm.w_ih, E, 1, st, ar.rest(), ar.rest_n()));
+        }
+        if (g->lstm.w_hh) TRY(gemm_tn(gtape->dgates, 4 * H, hs_all, H, M, 4 * H, H, g->lstm.w_hh, H, 1, st, ar.rest(), ar.rest_n()));
         TRY(colsum_pair(gtape->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
     }
     return SF_OK;

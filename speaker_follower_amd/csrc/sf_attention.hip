@@ -901,10 +901,10 @@ int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, co
 
 int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc,
                   const float* t, int ldt, const float* alpha, float* dt, int lddt, float* dctx,
-                  hipStream_t st, float* ds_out) {
-    if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (lddwc & 3) || (lddt & 3) || L < 1)
+                  hipStream_t st, float* ds_out, const int32_t* ctx_row) {
+    if (H > TXT_CPL * 256 || (H & 3) || (ldt & 3) || (lddwc & 3) || (lddt & 3) || L < 1 || (ctx_row && dctx))
         return SF_ERR_UNSUPPORTED;
-    TxtArgs a{ctx, nullptr, L, H, dwc, lddwc, t, ldt, const_cast<float*>(alpha), dt, lddt, dctx, nullptr, ds_out};
+    TxtArgs a{ctx, nullptr, L, H, dwc, lddwc, t, ldt, const_cast<float*>(alpha), dt, lddt, dctx, ctx_row, ds_out};
     return text_attn_launch<1>(a, B, st);
 }
 

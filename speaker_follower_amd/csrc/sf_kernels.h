@@ -26,7 +26,8 @@ int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, co
                   const int32_t* ctx_row = nullptr);
 int text_attn_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc,
                   const float* t, int ldt, const float* alpha, float* dt, int lddt, float* dctx,
-                  hipStream_t st, float* ds_out = nullptr);   // dctx null + ds_out: deferred update
+                  hipStream_t st, float* ds_out = nullptr,    // dctx null + ds_out: deferred update
+                  const int32_t* ctx_row = nullptr);          // (deferred form only) row b reads ctx row ctx_row[b]
 // dctx[b,l,:] += sum_t (alpha[t,b,l] dcat2[t,b,:H] + ds[t,b,l] tt[t,b,:]) over S stacked steps
 bool ctx_grad_supported(int S, int L, int H);
 int ctx_grad_accum(const float* alpha, const float* ds, const float* dcat2, int lddc, const float* tt,
@@ -65,7 +66,10 @@ bool encoder_persistent_supported(int B, int H, int T);
 int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
                        const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
                        float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
-                       hipStream_t st, float* c_out = nullptr);
+                       hipStream_t st, float* c_out = nullptr,
+                       // round 5 (the speaker's teacher-forced word recurrence): a given initial state (hs / cs slot 0 are
+                       // then the caller's), tokens at seq[b * Lpad + t * seq_st], lengths / ctx may be null
+                       const float* h_init = nullptr, const float* c_init = nullptr, long seq_st = 1);
 // the speaker's S word steps (inference) as one persistent launch; cq = ctx W_in, cw = ctx W_c^T [B,Tp,H]
 size_t speaker_persistent_xchg_floats();
 bool speaker_persistent_supported(int B, int H, int Tp, int vocab);
@@ -80,7 +84,10 @@ int speaker_persistent(const float* w_hh, const float* b_ih, const float* b_hh, 
 size_t encoder_bwd_persistent_xchg_floats();
 int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, int T, const float* gates,
                            const float* cs, const float* dctx, const Dropout& ctx_drop, const float* dh_in,
-                           const float* dc_in, float* dgates, float* xchg, unsigned* done, hipStream_t st);
+                           const float* dc_in, float* dgates, float* xchg, unsigned* done, hipStream_t st,
+                           // round 5: the external gradient of h_t at dctx[b * dctx_sb + t * dctx_st + j] (0, 0 = [B,T,H]);
+                           // dc0_out [B,H] = gradient wrt a given initial cell state; lengths may be null
+                           long dctx_sb = 0, long dctx_st = 0, float* dc0_out = nullptr);
 
 struct LstmPwBwd {
     const float* gates; const float* c0; const float* c1;
@@ -101,6 +108,10 @@ int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st);
 
 int dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd, const Dropout& d,
                  int col0, hipStream_t st);
+// S stacked steps of B rows: row t * B + b masked with site d.stream + stream_step * t, row key b
+int dropout_steps(const float* src, int lds, int S, int B, int N, float* dst, int ldd, const Dropout& d,
+                  uint32_t stream_step, hipStream_t st);
+int row_mod(int* out, int M, int B, hipStream_t st);              // out[i] = i % B
 // dst = (a ? a : 0) + (b ? b : 0)   [M,N] with row strides
 int add2(const float* a, int lda, const float* b, int ldb, int M, int N, float* dst, int ldd,
          hipStream_t st);
@@ -178,11 +189,13 @@ int follower_glue_fwd(const FGlue& g, hipStream_t st);
 int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float* wt,
                    const float* b_a, const float* b_out, const FGlue& g, hipStream_t st, int ldr = 0,
                    const float* cst = nullptr);
+// rps > 0: S stacked steps of rps rows each -- row m takes gscale[m / rps]
 int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,
-                   const float* gscale, float* dlogit, hipStream_t st);
+                   const float* gscale, float* dlogit, hipStream_t st, int rps = 0);
 int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                      int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
-                     float* score, float* nll_term, float* live, hipStream_t st, const sf_sample* sample = nullptr);
+                     float* score, float* nll_term, float* live, hipStream_t st, const sf_sample* sample = nullptr,
+                     int rps = 0);      // rps > 0: S stacked steps of rps rows each (row m sets ended[m % rps])
 int speaker_loss_finalize(const float* sum_cnt, const int64_t* words, int eos, int T, int B, float* loss, float* gscale,
                           hipStream_t st);
 int reduce_terms(const float* term, const float* live, int T, int B, float* sum_cnt,

@@ -130,8 +130,9 @@ __device__ __forceinline__ void xstore(bool local, v4u v, RS rs, unsigned off) {
 struct EncPersistArgs {
     const float* w_hh; const float* b_ih; const float* b_hh;   // [4H,H], [4H], [4H]
     const float* xw_table;                                     // [vocab,4H] = embedding W_ih^T
-    const int64_t* seq; int Lpad;                              // [B,Lpad] tokens
-    const int* lengths;                                        // [B]
+    const int64_t* seq; long seq_sb, seq_st;                   // token of (row b, step t) = seq[b * seq_sb + t * seq_st]
+    const int* lengths;                                        // [B], or null: every row runs all T steps
+    const float* h_init; const float* c_init;                  // [B,H] initial state, or null: zero (model.py:67-79)
     int B, H, T, rpg;                                          // rpg = rows per group
     float* gates; float* hs; float* cs;                        // tapes [T,B,4H], [T+1,B,H] x2
     float* ctx; int ld_ctx; Dropout ctx_drop;                  // ctx[b, t, :], row stride T*H
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
         }
     for (int i = tid; i < EP_ROWS * T; i += 256) {
         const int r = i / T, t = i - r * T;
-        s_tok[r][t] = r < nrows ? (int)p.seq[(size_t)(row0 + r) * p.Lpad + t] : 0;
+        s_tok[r][t] = r < nrows ? (int)p.seq[(size_t)(row0 + r) * p.seq_sb + (size_t)t * p.seq_st] : 0;
     }
     // the (row, unit) this thread updates; rows beyond the group's share compute on row B-1's
     // operands (clamped, as the per-step kernel does) and store nothing
@@ -180,9 +181,10 @@ __global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
     float bias[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) bias[g] = p.b_ih[g * H + ej] + p.b_hh[g * H + ej];
-    const int len_b = p.lengths[eb];
+    const int len_b = p.lengths ? p.lengths[eb] : T;
     const uint32_t rk = drop_key(p.ctx_drop, (uint32_t)(p.ctx_drop.row0 + eb));
-    float c_state = 0.f, h_state = 0.f;
+    float c_state = p.c_init ? p.c_init[(size_t)eb * H + ej] : 0.f;
+    float h_state = p.h_init ? p.h_init[(size_t)eb * H + ej] : 0.f;
     const size_t BH = (size_t)B * H;
 
     unsigned* xg = p.xchg + (size_t)grp * 3 * EP_ROWS * H;
@@ -211,10 +213,20 @@ __global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
     for (int t = 0; t < T; ++t) {
         EP_STAMP(4)                                      // tapes + loop back
         float xn[4] = {0.f, 0.f, 0.f, 0.f};
-        if (t > 0) {                                     // h_0 = 0: the first step has no product
+        if (t > 0 || p.h_init) {                         // h_0 = 0 (no initial state given): the first step has no product
             v4u a[4][2];
             const unsigned base = (unsigned)((((t % 3) * EP_ROWS + li) * H) * 4);
             const long long t0 = wall_clock64();
+            if (t == 0) {                                // the given initial state: an input, read where it lies
+                const float* hrow = p.h_init + (size_t)min(row0 + li, B - 1) * H;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const float4 x = ld4(hrow + 16 * (2 * sj[j] + cc) + 4 * kk);
+                        a[j][cc] = v4u{__float_as_uint(x.x), __float_as_uint(x.y), __float_as_uint(x.z), __float_as_uint(x.w)};
+                    }
+            } else
             for (;;) {
                 asm volatile("" ::: "memory");           // the loads below are re-issued every pass
                 bool ok = true;
@@ -324,7 +336,7 @@ __global__ __launch_bounds__(256, 1) void enc_persist_kernel(EncPersistArgs p) {
             float cv = live ? h1 : 0.f;
             if (live && p.ctx_drop.on())
                 cv = dropout_keep(rk, (uint32_t)(t * H + ej), p.ctx_drop.thresh) ? cv * p.ctx_drop.scale : 0.f;
-            p.ctx[(size_t)eb * p.ld_ctx + (size_t)t * H + ej] = cv;
+            if (p.ctx) p.ctx[(size_t)eb * p.ld_ctx + (size_t)t * H + ej] = cv;
             if (p.gates || t == T - 1) {                 // inference (no gates tape): only the final state
                 p.cs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = c1;
                 p.hs[(size_t)(t + 1) * BH + (size_t)eb * H + ej] = h1;
@@ -371,9 +383,11 @@ struct EncBwdPersistArgs {
     const int* lengths;
     int B, H, T, rpg;
     const float* gates; const float* cs;          // tapes [T,B,4H] (activated gates), [T+1,B,H]
-    const float* dctx; Dropout ctx_drop;          // [B,T,H] gradient wrt the dropped ctx, or null
+    const float* dctx; Dropout ctx_drop;          // gradient wrt the (dropped) h_t handed out at step t, or null:
+    long dctx_sb, dctx_st;                        //   element (b, t, j) at dctx[b * dctx_sb + t * dctx_st + j]
     const float* dh_in; const float* dc_in;       // [B,H] incoming dh_T, dc_T
     float* dgates;                                // [T,B,4H] out (pre-activation gate gradients)
+    float* dc0_out;                               // [B,H] gradient wrt the initial cell state, or null (zero initial state)
     unsigned* xchg;                               // [8][2][32 dest][32 src][256] dwords, sentinel-filled
     unsigned* done;
     unsigned* place;
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void enc_bwd_persist_kernel(EncBwdPersistAr
     const bool evalid = er < nrows;
     const int eb = evalid ? row0 + er : B - 1;
     const int ej = 16 * slot + eu;
-    const int len_b = p.lengths[eb];
+    const int len_b = p.lengths ? p.lengths[eb] : T;
     const uint32_t rk = drop_key(p.ctx_drop, (uint32_t)(p.ctx_drop.row0 + eb));
     const size_t BH = (size_t)B * H;
     float dc = p.dc_in ? p.dc_in[(size_t)eb * H + ej] : 0.f;
@@ -428,7 +442,7 @@ __global__ __launch_bounds__(256, 1) void enc_bwd_persist_kernel(EncBwdPersistAr
         g_i = gp[0]; g_f = gp[H]; g_g = gp[2 * H]; g_o = gp[3 * H];
         c0v = p.cs[(size_t)t * BH + (size_t)eb * H + ej];
         c1v = p.cs[(size_t)(t + 1) * BH + (size_t)eb * H + ej];
-        dcx = p.dctx ? p.dctx[((size_t)eb * T + t) * H + ej] : 0.f;
+        dcx = p.dctx ? p.dctx[(size_t)eb * p.dctx_sb + (size_t)t * p.dctx_st + ej] : 0.f;
     };
     fetch(T - 1);
 
@@ -493,7 +507,10 @@ __global__ __launch_bounds__(256, 1) void enc_bwd_persist_kernel(EncBwdPersistAr
                        rb + (unsigned)((tid + 256 * i) * 16));
         }
         EP_STAMP(1)                                      // cell backward + tile + barrier + reset issue
-        if (t == 0) break;                               // h_0 = 0 carries no gradient: nothing to publish
+        if (t == 0) {                                    // nothing to publish (the caller forms d h_init = dgates_0 W_hh)
+            if (p.dc0_out && evalid) p.dc0_out[(size_t)eb * H + ej] = dc;
+            break;
+        }
         fetch(t - 1);
         // ---- 3. partial[16 x 512] = dgates_t[16 x 64] . W_hh[own 64 rows, :]
         float a[16];
@@ -1088,16 +1105,18 @@ bool encoder_persistent_supported(int B, int H, int T) {
 int encoder_persistent(const float* w_hh, const float* b_ih, const float* b_hh, const float* xw_table,
                        const int64_t* seq, int Lpad, const int* lengths, int B, int H, int T, float* gates,
                        float* hs, float* cs, float* ctx, const Dropout& ctx_drop, float* xchg, unsigned* done,
-                       hipStream_t st, float* c_out) {
-    if (!encoder_persistent_supported(B, H, T) || !xw_table || !xchg || !done) return SF_ERR_UNSUPPORTED;
+                       hipStream_t st, float* c_out, const float* h_init, const float* c_init, long seq_st) {
+    if (!encoder_persistent_supported(B, H, T) || !xw_table || !xchg || !done || (!h_init != !c_init)) return SF_ERR_UNSUPPORTED;
     EncPersistArgs a{};
-    a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.xw_table = xw_table; a.seq = seq; a.Lpad = Lpad;
+    a.w_hh = w_hh; a.b_ih = b_ih; a.b_hh = b_hh; a.xw_table = xw_table; a.seq = seq;
+    a.seq_sb = Lpad; a.seq_st = seq_st; a.h_init = h_init; a.c_init = c_init;
     a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
     a.gates = gates; a.hs = hs; a.cs = cs; a.ctx = ctx; a.ld_ctx = T * H; a.ctx_drop = ctx_drop; a.c_out = c_out;
     a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
     a.fault = done + EP_FAULT_WORD; a.timeout = g_persist_timeout < 0 ? EP_TIMEOUT_TICKS : g_persist_timeout;
+    // (slot 0 of the tapes: zeroed here, or -- given an initial state -- the caller's)
     SF_LAUNCH(enc_persist_prologue_kernel, dim3(96), dim3(256), 0, st, a.xchg, encoder_persistent_xchg_floats(H),
-              hs, cs, (size_t)B * H, a.place, g_force_sc1, a.fault, g_persist_timeout);
+              hs, cs, h_init ? (size_t)0 : (size_t)B * H, a.place, g_force_sc1, a.fault, g_persist_timeout);
     SF_LAUNCH(enc_persist_kernel, dim3(EP_GROUPS * EP_SLOTS), dim3(256), 0, st, a);
     return launch_status();
 }
@@ -1141,11 +1160,13 @@ size_t encoder_bwd_persistent_xchg_floats() { return (size_t)EP_GROUPS * 2 * EP_
 
 int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, int T, const float* gates,
                            const float* cs, const float* dctx, const Dropout& ctx_drop, const float* dh_in,
-                           const float* dc_in, float* dgates, float* xchg, unsigned* done, hipStream_t st) {
+                           const float* dc_in, float* dgates, float* xchg, unsigned* done, hipStream_t st,
+                           long dctx_sb, long dctx_st, float* dc0_out) {
     if (!encoder_persistent_supported(B, H, T) || !xchg || !done) return SF_ERR_UNSUPPORTED;
     EncBwdPersistArgs a{};
     a.w_hh = w_hh; a.lengths = lengths; a.B = B; a.H = H; a.T = T; a.rpg = ceil_div(B, EP_GROUPS);
     a.gates = gates; a.cs = cs; a.dctx = dctx; a.ctx_drop = ctx_drop; a.dh_in = dh_in; a.dc_in = dc_in;
+    a.dctx_sb = dctx_sb ? dctx_sb : (long)T * H; a.dctx_st = dctx_st ? dctx_st : (long)H; a.dc0_out = dc0_out;
     a.dgates = dgates; a.xchg = reinterpret_cast<unsigned*>(xchg); a.done = done; a.place = done + 4; a.trace = g_trace;
     a.fault = done + EP_FAULT_WORD; a.timeout = g_persist_timeout < 0 ? EP_TIMEOUT_TICKS : g_persist_timeout;
     SF_LAUNCH(enc_bwd_persist_prologue_kernel, dim3(512), dim3(256), 0, st, a.xchg, encoder_bwd_persistent_xchg_floats(),

@@ -116,6 +116,29 @@ __global__ __launch_bounds__(TPB) void dropout_copy_kernel(const float* src, int
     }
 }
 
+// The same over S stacked steps of B rows each: row m = t * B + b is masked with site `d.stream + stream_step * t`, row
+// key b -- what S per-step launches with streams 2 (step0 + t) + 1 would apply (the speaker's dropout(h1), model.py:516,
+// for all word steps of a teacher-forced pass at once, and its backward).
+__global__ __launch_bounds__(TPB) void dropout_steps_kernel(const float* src, int lds, int S, int B, int N, float* dst,
+                                                            int ldd, Dropout d, uint32_t stream_step) {
+    const size_t total = (size_t)S * B * N;
+    const uint32_t seed = drop_seed(d);
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int m = (int)(i / N), n = (int)(i % N);
+        float v = src[(size_t)m * lds + n];
+        if (d.on()) {
+            const int t = m / B, b = m - t * B;
+            const uint32_t rk = dropout_row_key(seed, d.stream + stream_step * (uint32_t)t, (uint32_t)(d.row0 + b));
+            v = dropout_keep(rk, (uint32_t)n, d.thresh) ? v * d.scale : 0.f;
+        }
+        dst[(size_t)m * ldd + n] = v;
+    }
+}
+__global__ void row_mod_kernel(int* out, int M, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < M) out[i] = i % B;
+}
+
 // enc: dctx for the encoder arrives per (b, t, :) and must be dropout-masked with col = t*H + j
 __global__ __launch_bounds__(TPB) void ctx_grad_slice_kernel(const float* dctx, int T, int H, int B,
                                                              int t, Dropout d, float* out) {
@@ -463,7 +486,7 @@ __global__ __launch_bounds__(TPB) void follower_glue_kernel(FGlue g) {
 __global__ __launch_bounds__(TPB) void softmax_ce_bwd_kernel(int B, int N, int ld,
                                                              const float* logit,
                                                              const int64_t* target, int ignore,
-                                                             const float* gscale, float* dlogit) {
+                                                             const float* gscale, float* dlogit, int rps) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (b >= B) return;
@@ -480,7 +503,7 @@ __global__ __launch_bounds__(TPB) void softmax_ce_bwd_kernel(int B, int N, int l
     float s = 0.f;
     for (int n = lane; n < N; n += 64) s += expf(row[n] - m);
     s = wave_sum(s);
-    const float gs = gscale[0];
+    const float gs = gscale[rps ? b / rps : 0];          // (stacked steps: rows [t rps, +rps) belong to step t)
     for (int n = lane; n < ld; n += 64) {
         float v = 0.f;
         if (n < N) v = gs * (expf(row[n] - m) / s - (n == tgt ? 1.f : 0.f));
@@ -501,6 +524,7 @@ struct SGlue {
     float* live;
     uint32_t sample_seed, sample_stream; int sample_row0;     // feedback 2
     const uint32_t* sample_site;                              // device-side stream offset (never null), see Dropout.site
+    int rps;                                                  // > 0: S stacked steps of rps rows: row m sets ended[m % rps]
 };
 // feedback 2 (speaker.py:170-174): the two-level draw of sf_sampling.h by one wave.  Lane l holds columns
 // [16 l, 16 l + 16); slot s = lanes 2 s, 2 s + 1.  m = the row's max, am its arg max.  Returns the word.
@@ -597,7 +621,7 @@ __global__ __launch_bounds__(TPB) void speaker_glue_kernel(SGlue g) {
         const bool lv = tgt != g.pad_idx;
         g.nll_term[b] = lv ? lse - ltgt : 0.f;                   // speaker.py:182
         g.live[b] = lv ? 1.f : 0.f;
-        if (w == g.eos_idx) g.ended[b] = 1;                      // speaker.py:190-191
+        if (w == g.eos_idx) g.ended[g.rps ? b % g.rps : b] = 1;  // speaker.py:190-191
     }
 }
 
@@ -769,6 +793,16 @@ int dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd, c
                  int col0, hipStream_t st) {
     SF_LAUNCH(dropout_copy_kernel, dim3(grid1d((size_t)B * N)), dim3(TPB), 0, st, src, lds,
                        B, N, dst, ldd, d, col0);
+    return launch_status();
+}
+int dropout_steps(const float* src, int lds, int S, int B, int N, float* dst, int ldd, const Dropout& d,
+                  uint32_t stream_step, hipStream_t st) {
+    SF_LAUNCH(dropout_steps_kernel, dim3(grid1d((size_t)S * B * N)), dim3(TPB), 0, st, src, lds, S, B, N, dst, ldd, d,
+              stream_step);
+    return launch_status();
+}
+int row_mod(int* out, int M, int B, hipStream_t st) {
+    SF_LAUNCH(row_mod_kernel, dim3(ceil_div(M, 256)), dim3(256), 0, st, out, M, B);
     return launch_status();
 }
 int ctx_grad_slice(const float* dctx, int T, int H, int B, int t, const Dropout& d, float* out,
@@ -1032,18 +1066,18 @@ int follower_glue_fwd(const FGlue& g, hipStream_t st) {
     return launch_status();
 }
 int softmax_ce_bwd(int B, int N, int ld, const float* logit, const int64_t* target, int ignore,
-                   const float* gscale, float* dlogit, hipStream_t st) {
+                   const float* gscale, float* dlogit, hipStream_t st, int rps) {
     SF_LAUNCH(softmax_ce_bwd_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, B, N,
-                       ld, logit, target, ignore, gscale, dlogit);
+                       ld, logit, target, ignore, gscale, dlogit, rps);
     return launch_status();
 }
 int speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int64_t* target,
                      int feedback, int pad_idx, int eos_idx, uint8_t* ended, int64_t* w_t,
-                     float* score, float* nll_term, float* live, hipStream_t st, const sf_sample* sample) {
+                     float* score, float* nll_term, float* live, hipStream_t st, const sf_sample* sample, int rps) {
     if (feedback == 2 && (!sample || vocab > 1024)) return feedback == 2 && !sample ? SF_ERR_ARG : SF_ERR_UNSUPPORTED;
     SGlue g{B, vocab, ldv, logit, target, feedback, pad_idx, eos_idx, ended, w_t, score, nll_term,
             live, sample ? sample->seed : 0u, sample ? sample->stream : 0u, sample ? sample->row0 : 0,
-            sample && sample->stream_dev ? sample->stream_dev : site_zero()};
+            sample && sample->stream_dev ? sample->stream_dev : site_zero(), rps};
     SF_LAUNCH(speaker_glue_kernel, dim3(ceil_div(B, TPB / 64)), dim3(TPB), 0, st, g);
     return launch_status();
 }

@@ -84,8 +84,12 @@ class SpeakerEngine:
         self.site_next = 0              # first unused dropout site (see score)
         self.site_word = None           # device-side site counter while a training graph is captured (runtime.TrainingGraph)
         self.dropout_seed = None
-        self.persistent = True          # inference passes: the whole word loop as ONE launch (sf_speaker_decode)
+        self.persistent = True          # persistent launches allowed: the inference word loop as ONE launch (sf_speaker_decode),
+                                        # the recurrence of teacher-forced passes (sf_speaker_teacher_fwd / _bwd)
         self.stacked_wgrad = True       # backward: weight gradients as one product over all S*B rows (False: per step)
+        # teacher-forced passes: the recurrence as one persistent launch + the attention / projection / glue of all S*B
+        # rows at once (sf_speaker_teacher_fwd / _bwd); False: the word loop step by step (or sf_speaker_decode)
+        self.teacher_batched = True
         self.fallbacks = 0              # passes re-issued on the per-step kernels after a persistent-launch fault (run)
 
     def capture(self, batch, steps, feedback='teacher'):
@@ -214,8 +218,10 @@ class SpeakerEngine:
         # ---- decoder: S x (embedding -> LSTMCell -> dropout -> attention -> vocab projection)
         shapes = dict(emb=(E,), gates=(4 * H,), c1=(H,), h1=(H,), cat2=(2 * H,), t_text=(H,),
                       alpha=(Tp,), h_tilde=(H,), logit=(ldv,))
-        st.tape = {k: new(S, B, *shapes[k]) for k in _DEC_TAPE if k != 'h1'}
+        st.tape = {k: new(S, B, *shapes[k]) for k in _DEC_TAPE if k not in ('h1', 'c1')}
         st.tape['h1'] = st.hs_all[1:]
+        st.cs_all = new(S + 1, B, H)              # cell states likewise: slot 0 = c_init, slot t + 1 = c1 of step t
+        st.tape['c1'] = st.cs_all[1:]
         st.words = torch.empty(S + 1, B, dtype=torch.int64, device=dev)
         st.words[0] = BOS                                                  # speaker.py:137
         st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
@@ -230,7 +236,21 @@ class SpeakerEngine:
         st.dec_table = not (differentiable and trainable_embedding(dec))
         dw = dec._w_struct(table=st.dec_table)
         persistent = False
-        if self.persistent and not training and not differentiable:
+        st.teacher_path = False
+        # (`persistent = False` rules out every persistent launch: what the fault fallback of run() relies on)
+        if self.teacher_batched and self.persistent and st.feedback == 0 and st.dec_table:
+            # teacher forcing: the recurrence alone in one persistent launch, the rest for all S*B rows at once
+            st.cs_all[0].copy_(st.c_init)
+            tp0 = _lib.SpkDecoderTape(*(st.tape[k].data_ptr() if (k != 'emb' or differentiable) else None
+                                        for k in _DEC_TAPE))
+            rc = _lib.lib.sf_speaker_teacher_fwd(
+                byref(dw), B, E, H, Tp, vocab, S, PAD, EOS, ptr(st.targets), ptr(st.hs_all), ptr(st.cs_all), ptr(st.ctx),
+                ptr(batch.path_mask), ptr(st.words), ptr(st.ended), ptr(st.step_scores), ptr(st.nll_term), ptr(st.live),
+                byref(tp0), d_dec, st.site_rel, *ws)
+            if rc != 2:                                   # SF_ERR_UNSUPPORTED: shapes outside the persistent recurrence
+                _lib.check(rc, 'sf_speaker_teacher_fwd')
+                st.teacher_path = True
+        if not st.teacher_path and self.persistent and not training and not differentiable:
             # inference: all S word steps in one persistent launch (csrc/sf_persist.hip)
             rc = _lib.lib.sf_speaker_decode(
                 byref(dw), B, H, Tp, vocab, S, st.feedback, PAD, EOS, ptr(st.targets), ptr(st.h_init),
@@ -241,8 +261,9 @@ class SpeakerEngine:
             if rc != 2:                                   # SF_ERR_UNSUPPORTED: shapes outside the kernel
                 _lib.check(rc, 'sf_speaker_decode')
                 persistent = True
-        st.persistent = persistent
-        if not persistent:
+        st.persistent = persistent           # (the whole word loop as one persistent launch: sf_speaker_decode)
+        if not persistent and not st.teacher_path:
+            st.cs_all[0].copy_(st.c_init)
             # the per-step word loop WITH its tape (training, or shapes outside the persistent kernel), one library call:
             # sf_speaker_decoder_fwd + sf_speaker_glue_fwd per word with no host work between the launches.  The embedded
             # words are only kept for the backward (dW_ih); the forward looks the input product up in the [vocab,4H]
@@ -327,11 +348,23 @@ class SpeakerEngine:
         # per step only the data gradients; every weight gradient is ONE product over all S*B stacked rows at the end
         gt = dict(dlogit=new(S, B, ldv), dpre=new(S, B, H), dt_text=new(S, B, H), dgates=new(S, B, 4 * H))
         gtape = _lib.SpkDecoderGTape(*(gt[k].data_ptr() for k in ('dlogit', 'dpre', 'dt_text', 'dgates')))
-        call('sf_speaker_words_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, S, PAD, ptr(st.words), ptr(st.targets),
-             ptr(st.h_init), ptr(st.c_init), ptr(st.ctx), byref(tp0), ptr(gscale.contiguous()), ptr(dlogit), ptr(dh_a),
-             ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(in_b), d_dec, st.site_rel,
-             byref(gtape) if self.stacked_wgrad else None, ptr(st.hs_all), *ws)
-        dh1, dc1 = (dh_b, dc_b) if in_b.value else (dh_a, dc_a)
+        done = False
+        if st.teacher_path and self.stacked_wgrad:
+            # teacher-forced pass: head backward over all S*B rows + the recurrence's backward as one persistent launch
+            scratch = (new(S, B, 2 * H), new(S, B, Tp), new(S, B, H))
+            rc = _lib.lib.sf_speaker_teacher_bwd(
+                byref(dw), byref(dg), B, E, H, Tp, vocab, S, PAD, ptr(st.words), ptr(st.targets), ptr(st.hs_all),
+                ptr(st.cs_all), ptr(st.ctx), byref(tp0), ptr(gscale.contiguous()), ptr(dh_a), ptr(dc_a), ptr(dctx), d_dec,
+                st.site_rel, byref(gtape), ptr(scratch[0]), ptr(scratch[1]), ptr(scratch[2]), *ws)
+            if rc != 2:
+                _lib.check(rc, 'sf_speaker_teacher_bwd')
+                dh1, dc1, done = dh_a, dc_a, True
+        if not done:
+            call('sf_speaker_words_bwd', byref(dw), byref(dg), B, E, H, Tp, vocab, S, PAD, ptr(st.words), ptr(st.targets),
+                 ptr(st.h_init), ptr(st.c_init), ptr(st.ctx), byref(tp0), ptr(gscale.contiguous()), ptr(dlogit), ptr(dh_a),
+                 ptr(dc_a), ptr(dh_b), ptr(dc_b), ptr(dctx), byref(in_b), d_dec, st.site_rel,
+                 byref(gtape) if self.stacked_wgrad else None, ptr(st.hs_all), *ws)
+            dh1, dc1 = (dh_b, dc_b) if in_b.value else (dh_a, dc_a)
         # ---- encoder backward
         d_enc = dropout_arg(*st.drop_enc)
         ep = enc._params8()

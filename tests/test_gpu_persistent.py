@@ -234,6 +234,7 @@ def test_persistent_speaker_decode_matches_per_step(B, feedback, peaky):
     for persistent in (False, True):
         eng = speaker.SpeakerEngine(enc, dec, store)
         eng.persistent = persistent
+        eng.teacher_batched = False          # (teacher mode of sf_speaker_decode itself; the batched form: test_gpu_speaker_teacher.py)
         with torch.no_grad():
             st = eng.score(batch, S, feedback, train=False)
         assert st.persistent == persistent

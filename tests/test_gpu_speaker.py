@@ -180,8 +180,9 @@ def test_stacked_weight_gradients_equal_the_per_step_ones(glove):
             m.zero_grad(set_to_none=True)
         eng = speaker.SpeakerEngine(enc, dec, store)
         eng.dropout_seed, eng.stacked_wgrad = 4242, stacked
+        eng.teacher_batched = False              # (the word loop step by step; its batched form: test_gpu_speaker_teacher.py)
         st = eng.score(batch, 32, 'teacher', train=True)
-        assert not st.persistent
+        assert not st.persistent and not st.teacher_path
         st.loss.backward()
         torch.cuda.synchronize()
         grads.append((float(st.loss.detach()),
