@@ -770,6 +770,10 @@ int sf_gate_product_is_strict(void);
  * error-free operand splitting (csrc/sf_gemm.hip: gemm_nt_split_kernel; same fp32 accuracy class, measured closer
  * to the exact sum, 6/16 of the matrix-pipe time).  For A/B timing and for the accuracy tests. */
 void sf_debug_gate_product_f32(int on);
+/* A/B switch (round 5): on == 0 sends the many-row products (M >= 512: the speaker's teacher-forced head over all S*B rows,
+ * the beam search's flat steps) back to the register-streaming kernel of rounds 1-4 instead of the LDS-tiled 128 x 128
+ * bf16x6 kernel (csrc/sf_gemm.hip: gemm_nt_big_kernel; the default). */
+void sf_debug_many_row_product(int on);
 /* A/B switch: on == 0 makes sf_speaker_encoder_fwd run its visual attention on the fp32 kernels (rounds 1-4) instead
  * of the float64 query / score path (sf_visual_attention_fwd_f64; the default). */
 void sf_debug_precise_attention(int on);

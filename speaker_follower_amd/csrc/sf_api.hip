@@ -430,6 +430,7 @@ int sf_abi_version(void) { return SF_ABI_VERSION; }
 const char* sf_build_id(void) { static const char id[] = "SF_BUILD_ID=" SF_BUILD_ID; return id + 12; }
 void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; }
 void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
+void sf_debug_many_row_product(int on) { sf::g_nt_big = on; }
 int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, sf_stream stream) {
     SF_ENTER();
     return sf::cotenant(blocks, threads, lds_bytes, ticks, sink, S(stream));

@@ -25,6 +25,7 @@
 namespace sf {
 
 int g_tn_split_min_rows = 4096;   // sf_debug_tn_split_min_rows (tests run the split weight-gradient kernel on small shapes)
+int g_nt_big = 1;            // sf_debug_many_row_product: M >= 512 products on gemm_nt_big_kernel (0: gemm_nt_kernel, rounds 1-4)
 int g_nt_force_f32 = 0;      // sf_debug_gate_product_f32: run the LSTM gate product on v_mfma_f32_16x16x4_f32 (round 1-3 kernel)
 
 namespace {
@@ -644,6 +645,119 @@ __global__ __launch_bounds__(512) void gemm_nt_split_kernel(NtArgs a) {
                 *o = (a.accumulate && a.ksplit == 1) ? *o + v : v;
             }
         }
+}
+
+// ------------------------------------------------------------------------------------------------
+// MANY-ROW NT product (round 5): C[M,N] = A[M,K] W[N,K]^T (+ bias, + addend, tanh) for M >= 512 -- the speaker's
+// teacher-forced head over all S*B = 8 000 rows (t_text, h~, vocabulary projection and their data gradients), the beam
+// search's flat decoder steps over 2 560 states.  gemm_nt_kernel streams its operands straight from global memory (7
+// FLOPs per operand byte: 38-55 TFLOP/s at M = 8 000); here a workgroup forms a 128 x 128 tile from 32-deep stages of
+// both operands staged through LDS as three bf16 planes each (error-free three-way split, sf_split.h: fp32 accuracy on
+// the bf16 matrix cores, 32 FLOPs per operand byte).  512 threads = 2 x 4 waves of 64 x 32 outputs (8 MFMA tiles, hi / lo
+// accumulators); per stage a thread fetches 2 + 2 float4, splits them once and stores 12 x 8 bytes; double-buffered LDS
+// (96 KB), the next stage's global loads in flight under the current stage's 48 MFMAs per wave; one barrier per stage.
+// Row layout of a plane: 64 bytes per row and stage = four 16-byte chunks, chunk kk = {k = 4 kk .. +3 | 16 + 4 kk .. +3}:
+// what one lane feeds one v_mfma_f32_16x16x32_bf16 (the K order inside an MFMA is free as long as A and B agree).
+// ------------------------------------------------------------------------------------------------
+struct NtBigArgs {
+    const float* A; int lda;
+    const float* W; int ldw;
+    int M, N, K;
+    float* y; int ldy;
+    const float* bias; const float* bias2;
+    const float* addend; int ld_addend;
+    int epi, accumulate;
+};
+constexpr int NB_T = 128, NB_K = 32, NB_PLANE = NB_T * 64;          // bytes per plane and stage (128 rows x 64 B)
+
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char nb_smem[];   // [2 buffers][A | W][3 planes][128 rows][64 B]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, kk = lane >> 4;
+    const int wm = wave >> 2, wn = wave & 3;                          // 64-row half, 32-column quarter of the tile
+    // tile map: consecutive workgroups walk down the rows of one column block (W's 128 rows stay hot in the L2s)
+    const int mtiles = (a.M + NB_T - 1) / NB_T;
+    const int m0 = (blockIdx.x % mtiles) * NB_T, n0 = (blockIdx.x / mtiles) * NB_T;
+    // staging: thread -> (row = tid >> 3 (+64), float4 c4 = tid & 7 of the 32-deep stage)
+    const int srow = tid >> 3, c4 = tid & 7;
+    const float* ap[2];
+    const float* wp[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        ap[p] = a.A + (size_t)min(m0 + srow + 64 * p, a.M - 1) * a.lda + 4 * c4;
+        wp[p] = a.W + (size_t)min(n0 + srow + 64 * p, a.N - 1) * a.ldw + 4 * c4;
+    }
+    const int soff = srow * 64 + ((c4 & 3) << 4) + ((c4 >> 2) << 3);  // byte offset of this thread's 8 bytes inside a plane
+    auto stage_store = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
+        unsigned char* base = nb_smem + buf * (6 * NB_PLANE);
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            uint2 p1, p2, p3;
+            split3_f4(ra[p], p1, p2, p3);
+            unsigned char* d = base + soff + p * 64 * 64;
+            *reinterpret_cast<uint2*>(d) = p1;
+            *reinterpret_cast<uint2*>(d + NB_PLANE) = p2;
+            *reinterpret_cast<uint2*>(d + 2 * NB_PLANE) = p3;
+            split3_f4(rw[p], p1, p2, p3);
+            d += 3 * NB_PLANE;
+            *reinterpret_cast<uint2*>(d) = p1;
+            *reinterpret_cast<uint2*>(d + NB_PLANE) = p2;
+            *reinterpret_cast<uint2*>(d + 2 * NB_PLANE) = p3;
+        }
+    };
+    f32x4 hi[4][2], lo[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) hi[i][j] = lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int stages = a.K / NB_K;
+    float4 ra[2], rw[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) { ra[p] = ld4(ap[p]); rw[p] = ld4(wp[p]); }
+    stage_store(0, ra, rw);
+    __syncthreads();
+    for (int s = 0; s < stages; ++s) {
+        const int nxt = min(s + 1, stages - 1);                       // (clamped, not predicated: the last prefetch is unused)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) { ra[p] = ld4(ap[p] + nxt * NB_K); rw[p] = ld4(wp[p] + nxt * NB_K); }
+        const unsigned char* Ab = nb_smem + (s & 1) * (6 * NB_PLANE) + (wm * 64 + li) * 64 + kk * 16;
+        const unsigned char* Wb = nb_smem + (s & 1) * (6 * NB_PLANE) + 3 * NB_PLANE + (wn * 32 + li) * 64 + kk * 16;
+        Split8 wf[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) wf[j].p[pl] = *reinterpret_cast<const bf16x8*>(Wb + pl * NB_PLANE + j * 16 * 64);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            Split8 af;
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) af.p[pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * NB_PLANE + i * 16 * 64);
+            mfma_split6_across<2>(af, [&](int j) -> const Split8& { return wf[j]; }, hi[i], lo[i]);
+        }
+        if (s + 1 < stages) stage_store((s + 1) & 1, ra, rw);
+        __syncthreads();
+    }
+    // epilogue: lane (li, kk) holds rows 4 kk + r, column li of every 16 x 16 tile
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 32 + j * 16 + li;
+        if (col >= a.N) continue;
+        float bsum = 0.f;
+        if (a.bias) bsum += a.bias[col];
+        if (a.bias2) bsum += a.bias2[col];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = m0 + wm * 64 + i * 16 + kk * 4 + r;
+                if (row >= a.M) continue;
+                float v = (hi[i][j][r] + lo[i][j][r]) + bsum;
+                if (a.addend) v += a.addend[(size_t)row * a.ld_addend + col];
+                if (a.epi == EPI_TANH) v = tanhf(v);
+                float* o = a.y + (size_t)row * a.ldy + col;
+                *o = a.accumulate ? *o + v : v;
+            }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1581,6 +1695,21 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         const int rc = launch_small_plan(sp, st);
         if (ksplit_out) *ksplit_out = 1;
         return rc;
+    }
+    if (!raw_slabs && nseg == 1 && M >= 512 && N >= 64 && segs[0].K % NB_K == 0 && segs[0].K >= 64 && !out.r1_s &&
+        (out.epi == EPI_NONE || out.epi == EPI_TANH) && !(out.accumulate && out.epi != EPI_NONE) && g_nt_big) {
+        // many rows: 128 x 128 tiles through LDS on the bf16 matrix cores (gemm_nt_big_kernel)
+        NtBigArgs b{segs[0].A, segs[0].lda, segs[0].W, segs[0].ldw, M, N, segs[0].K, out.y, out.ldy, out.bias, out.bias2,
+                    out.addend, out.ld_addend, (int)out.epi, out.accumulate};
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_big_kernel),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        SF_LAUNCH(gemm_nt_big_kernel, dim3(ceil_div(M, NB_T) * ceil_div(N, NB_T)), dim3(512), (size_t)2 * 6 * NB_PLANE, st, b);
+        if (ksplit_out) *ksplit_out = 1;
+        return launch_status();
     }
     if (out.addend || out.r1_s || out.epi == EPI_TANHBWD) return SF_ERR_UNSUPPORTED;   // small kernel only
     nt_shape(M, N, chunks, &mt, &mblocks, &ks);

@@ -279,7 +279,13 @@ class SpeakerEngine:
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
         # (the step means are added up to and including the first step at which every row has produced EOS,
         # speaker.py:192-197; gscale is 0 behind it)
-        call('sf_speaker_loss_finalize', ptr(st.sum_cnt), ptr(st.words), EOS, S, B, ptr(st.loss_buf), ptr(st.gscale), ws[2])
+        if self.group is not None:
+            # a row shard sees only ITS rows' EOS: the step at which every row of the BATCH has ended (speaker.py:196) is
+            # not a local property.  Teacher feedback (the only sharded mode): behind that step every target is PAD, the
+            # reduced table's counts are 0 and its steps add nothing -- the plain per-step means are the batch's loss
+            call('sf_loss_finalize', ptr(st.sum_cnt), S, ptr(st.loss_buf), ptr(st.gscale), ws[2])
+        else:
+            call('sf_speaker_loss_finalize', ptr(st.sum_cnt), ptr(st.words), EOS, S, B, ptr(st.loss_buf), ptr(st.gscale), ws[2])
         st.logits = st.tape['logit'][:, :, :vocab]
         st.h, st.c = st.tape['h1'][S - 1], st.tape['c1'][S - 1]
         if differentiable:
@@ -466,21 +472,27 @@ class SpeakerSweep:
     asynchronous H2D copy, a graph replay, and an asynchronous D2H copy of the words (int16) into a pinned result
     array.  The streams alternate, so the encoder kernels of one minibatch run beside the other's word loop -- a
     persistent launch of one 4-wave workgroup per CU that leaves most issue slots idle.  Every persistent launch is
-    checked through the fault word at the end (runtime.take_fault); a sweep that saw a fault is re-run per-step."""
+    checked through the fault word at the end (runtime.take_fault); a sweep that saw a fault is re-run -- all of it -- on
+    graphs captured with the per-step kernels (`fallbacks` counts them).  `sample` feedback needs vocab <= 1024 (the
+    two-level draw of sf_sampling.h); the pinned staging buffers grow with the longest path met."""
 
     def __init__(self, encoder, decoder, store, batch_size, words, feedback='argmax', Lmax=80, n_streams=2, slots=2):
         self.enc, self.dec, self.store = encoder, decoder, store
         self.B, self.S, self.Lmax, self.feedback = batch_size, words, Lmax, feedback
         self.streams = [torch.cuda.Stream(device=store.device) for _ in range(n_streams)]
         self.slots = slots
-        self.graphs = {}                 # (stream index, Tp) -> (replay, state, device staging buffer)
+        self.graphs = {}                 # (stream index, Tp, persistent) -> (replay, state, device staging buffer)
+        self.fallbacks = 0               # sweeps re-run on the per-step kernels after a persistent-launch fault
+        if feedback == 'sample' and decoder.vocab_size > 1024:
+            raise NotImplementedError('sample feedback draws with the two-level sampler of sf_sampling.h: vocab <= 1024 '
+                                      '(%d here)' % decoder.vocab_size)
         cap = packed_layout(batch_size, 16, Lmax)['bytes']
         self.pinned = [[torch.empty(cap, dtype=torch.uint8).pin_memory() for _ in range(slots)] for _ in self.streams]
         self.free_ev = [[None] * slots for _ in self.streams]
         self.host_pack_s = 0.0
 
-    def _graph(self, si, Tp):
-        key = (si, Tp)
+    def _graph(self, si, Tp, persistent=True):
+        key = (si, Tp, persistent)
         if key not in self.graphs:
             dev = self.store.device
             buf = torch.zeros(packed_layout(self.B, Tp, self.Lmax)['bytes'], dtype=torch.uint8, device=dev)
@@ -492,13 +504,14 @@ class SpeakerSweep:
             self.streams[si].wait_stream(torch.cuda.current_stream(dev))
             with torch.cuda.stream(self.streams[si]):
                 eng = SpeakerEngine(self.enc, self.dec, self.store)
+                eng.persistent = persistent
                 replay, st = eng.capture(batch, self.S, self.feedback)
                 words16 = torch.empty(self.S, self.B, dtype=torch.int16, device=dev)
             torch.cuda.synchronize(dev)
             self.graphs[key] = (replay, st, buf, words16)
         return self.graphs[key]
 
-    def run(self, batches):
+    def run(self, batches, _persistent=True):
         """`batches`: sequence of synth.SpeakerBatch-like index batches of `batch_size` paths.  Returns an int16 array
         [n, S, B] of generated word ids (pinned host memory)."""
         import time
@@ -514,10 +527,14 @@ class SpeakerSweep:
             if self.free_ev[si][slot] is not None:
                 self.free_ev[si][slot].synchronize()            # its previous H2D copy has left the buffer
             t0 = time.perf_counter()
+            need = packed_layout(len(sb.instr), int(sb.path_len.max()), self.Lmax)['bytes']
+            if need > pin.numel():                               # a longer path than any before: grow this slot
+                pin = self.pinned[si][slot] = torch.empty(need, dtype=torch.uint8).pin_memory()
             B, Tp = pack_speaker_batch(sb, pin.numpy(), self.Lmax)
             self.host_pack_s += time.perf_counter() - t0
-            assert B == self.B
-            replay, st, buf, words16 = self._graph(si, Tp)
+            if B != self.B:
+                raise ValueError('SpeakerSweep was built for minibatches of %d paths, got %d' % (self.B, B))
+            replay, st, buf, words16 = self._graph(si, Tp, _persistent)
             with torch.cuda.stream(self.streams[si]):
                 buf.copy_(pin[:buf.numel()], non_blocking=True)
                 ev = torch.cuda.Event()
@@ -530,6 +547,9 @@ class SpeakerSweep:
             s.synchronize()
         bits = take_fault(dev)
         if bits:
-            raise PersistentLaunchFault('a persistent word loop of the sweep gave up a wait (fault bits %d): re-run with '
-                                        'SpeakerEngine.persistent = False' % bits)
+            if not _persistent:
+                raise PersistentLaunchFault('fault bits %d raised by a sweep on the per-step kernels' % bits)
+            # a starved persistent launch poisoned some minibatch: the whole sweep again on the per-step kernels
+            self.fallbacks += 1
+            return self.run(batches, _persistent=False)
         return out.numpy()

@@ -97,6 +97,36 @@ def test_weight_gradient_on_the_bf16_matrix_cores(sf, M, N, K):
     assert errs[0] <= 2e-6 and errs[0] <= 1.5 * errs[1] + 1e-7
 
 
+@pytest.mark.parametrize('M,N,K,act', [(8000, 512, 512, 0), (8000, 512, 1024, 1), (8000, 991, 512, 0), (2560, 512, 512, 0),
+                                       (515, 130, 96, 1), (4100, 64, 64, 0), (1000, 2048, 992, 0)])
+def test_many_row_product_on_the_bf16_matrix_cores(sf, M, N, K, act):
+    """y = act(x W^T + b) for M >= 512 through gemm_nt_big_kernel (128 x 128 tiles, both operands staged through LDS as
+    three bf16 planes) against float64: asymmetric, badly scaled operands (a swapped fragment mapping, a wrong chunk
+    order or a dropped plane cannot pass), ragged last row / column tiles, and not worse than the register-streaming
+    kernel of rounds 1-4."""
+    rng = np.random.default_rng(M + N + K)
+    x = (rnd(rng, M, K) * (1.0 + 3.0 * (np.arange(K) % 7 == 0))[None, :] + 0.25).astype(np.float32)
+    w = (rnd(rng, N, K, scale=K ** -0.5) * (1.0 + (np.arange(N) % 5)[:, None])).astype(np.float32)
+    b = rnd(rng, N)
+    ref = x.astype(np.float64) @ w.astype(np.float64).T + b
+    pre_scale = float(np.abs(ref).max())
+    if act:
+        ref = np.tanh(ref)
+    errs = {}
+    for big in (1, 0):
+        sf.lib.lib.sf_debug_many_row_product(big)
+        try:
+            y = sf.ops.linear_fwd(dev(x), dev(w), dev(b), act)
+            torch.cuda.synchronize()
+        finally:
+            sf.lib.lib.sf_debug_many_row_product(1)
+        errs[big] = float(np.abs(y.cpu().numpy() - ref).max()) / float(np.abs(ref).max())
+    print('[many-row product %dx%dx%d] max error / scale: LDS-tiled bf16x6 %.2e, register-streaming fp32 MFMA %.2e'
+          % (M, N, K, errs[1], errs[0]))
+    # (with tanh the error of the pre-activation -- up to |x W^T| ~ 30 here -- passes through a slope <= 1)
+    assert errs[1] <= 1e-6 * (max(1.0, pre_scale) if act else 1.0) and errs[1] <= 1.5 * errs[0] + 1e-7
+
+
 def test_gemm_is_transpose_safe(sf):
     """Asymmetric operands: catches a row/column swap in the MFMA fragment mapping."""
     M, N, K = 48, 80, 32
