@@ -660,9 +660,9 @@ __global__ __launch_bounds__(512) void gemm_nt_split_kernel(NtArgs a) {
 // what one lane feeds one v_mfma_f32_16x16x32_bf16 (the K order inside an MFMA is free as long as A and B agree).
 // ------------------------------------------------------------------------------------------------
 struct NtBigArgs {
-    const float* A; int lda;
-    const float* W; int ldw;
-    int M, N, K;
+    Seg seg[3];            // up to three K segments ([x | h] W = x W_x + h W_h: the LSTM gates); K_s % 32 == 0
+    int nseg;
+    int M, N;
     float* y; int ldy;
     const float* bias; const float* bias2;
     const float* addend; int ld_addend;
@@ -680,13 +680,24 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
     const int m0 = (blockIdx.x % mtiles) * NB_T, n0 = (blockIdx.x / mtiles) * NB_T;
     // staging: thread -> (row = tid >> 3 (+64), float4 c4 = tid & 7 of the 32-deep stage)
     const int srow = tid >> 3, c4 = tid & 7;
-    const float* ap[2];
-    const float* wp[2];
+    int arow[2], wrow[2];
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
-        ap[p] = a.A + (size_t)min(m0 + srow + 64 * p, a.M - 1) * a.lda + 4 * c4;
-        wp[p] = a.W + (size_t)min(n0 + srow + 64 * p, a.N - 1) * a.ldw + 4 * c4;
+        arow[p] = min(m0 + srow + 64 * p, a.M - 1);
+        wrow[p] = min(n0 + srow + 64 * p, a.N - 1);
     }
+    const int st0 = a.seg[0].K / NB_K, st1 = a.nseg > 1 ? a.seg[1].K / NB_K : 0, st2 = a.nseg > 2 ? a.seg[2].K / NB_K : 0;
+    // stage s -> its segment and depth offset (wave-uniform selects)
+    auto gload = [&](int s, float4 (&ra)[2], float4 (&rw)[2]) {
+        const int g = s < st0 ? 0 : (s < st0 + st1 ? 1 : 2);
+        const int k0 = (s - (g > 0 ? st0 : 0) - (g > 1 ? st1 : 0)) * NB_K + 4 * c4;
+        const Seg& sg = a.seg[g];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            ra[p] = ld4(sg.A + (size_t)arow[p] * sg.lda + k0);
+            rw[p] = ld4(sg.W + (size_t)wrow[p] * sg.ldw + k0);
+        }
+    };
     const int soff = srow * 64 + ((c4 & 3) << 4) + ((c4 >> 2) << 3);  // byte offset of this thread's 8 bytes inside a plane
     auto stage_store = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
         unsigned char* base = nb_smem + buf * (6 * NB_PLANE);
@@ -710,16 +721,14 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) hi[i][j] = lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int stages = a.K / NB_K;
+    const int stages = st0 + st1 + st2;
     float4 ra[2], rw[2];
-#pragma unroll
-    for (int p = 0; p < 2; ++p) { ra[p] = ld4(ap[p]); rw[p] = ld4(wp[p]); }
+    gload(0, ra, rw);
     stage_store(0, ra, rw);
     __syncthreads();
     for (int s = 0; s < stages; ++s) {
         const int nxt = min(s + 1, stages - 1);                       // (clamped, not predicated: the last prefetch is unused)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) { ra[p] = ld4(ap[p] + nxt * NB_K); rw[p] = ld4(wp[p] + nxt * NB_K); }
+        gload(nxt, ra, rw);
         const unsigned char* Ab = nb_smem + (s & 1) * (6 * NB_PLANE) + (wm * 64 + li) * 64 + kk * 16;
         const unsigned char* Wb = nb_smem + (s & 1) * (6 * NB_PLANE) + 3 * NB_PLANE + (wn * 32 + li) * 64 + kk * 16;
         Split8 wf[2];
@@ -1696,11 +1705,21 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         if (ksplit_out) *ksplit_out = 1;
         return rc;
     }
-    if (!raw_slabs && nseg == 1 && M >= 512 && N >= 64 && segs[0].K % NB_K == 0 && segs[0].K >= 64 && !out.r1_s &&
-        (out.epi == EPI_NONE || out.epi == EPI_TANH) && !(out.accumulate && out.epi != EPI_NONE) && g_nt_big) {
+    // (raw_slabs: the caller sums split-K slabs itself -- the LSTM cell kernel; here ONE slab without bias)
+    bool big = M >= 512 && N >= 64 && chunks >= 4 && !out.r1_s && g_nt_big &&
+               (out.epi == EPI_NONE || out.epi == EPI_TANH) && !(out.accumulate && out.epi != EPI_NONE) &&
+               (!raw_slabs || (ws && ws_floats >= (size_t)M * N));
+    for (int s = 0; s < nseg; ++s) big = big && segs[s].K % NB_K == 0;
+    if (big) {
         // many rows: 128 x 128 tiles through LDS on the bf16 matrix cores (gemm_nt_big_kernel)
-        NtBigArgs b{segs[0].A, segs[0].lda, segs[0].W, segs[0].ldw, M, N, segs[0].K, out.y, out.ldy, out.bias, out.bias2,
-                    out.addend, out.ld_addend, (int)out.epi, out.accumulate};
+        NtBigArgs b{};
+        for (int s = 0; s < nseg; ++s) b.seg[s] = segs[s];
+        b.nseg = nseg; b.M = M; b.N = N; b.y = out.y; b.ldy = out.ldy; b.bias = out.bias; b.bias2 = out.bias2;
+        b.addend = out.addend; b.ld_addend = out.ld_addend; b.epi = (int)out.epi; b.accumulate = out.accumulate;
+        if (raw_slabs) {
+            b.y = ws; b.ldy = N; b.bias = b.bias2 = b.addend = nullptr; b.epi = EPI_NONE; b.accumulate = 0;
+            *raw_slabs = ws;
+        }
         static bool attr_set = false;
         if (!attr_set) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_big_kernel),

@@ -1,10 +1,10 @@
-"""A/B (round 5): the decoder's gate product with 64-column blocks x 8 K-splits (gemm_nt_split_kernel) vs 128-column blocks x
+"""(runs with tools/exp/gate_product_wide.patch applied)  A/B (round 5): the decoder's gate product with 64-column blocks x 8 K-splits (gemm_nt_split_kernel) vs 128-column blocks x
 16 K-splits (gemm_nt_split_wide_kernel): correctness against float64, kernel time, cell-kernel time, whole rollout."""
 import ctypes as C
 import os
 import sys
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np                                             # noqa: E402
 import torch                                                   # noqa: E402
 from speaker_follower_amd._lib import call, lib, kernel_profile       # noqa: E402

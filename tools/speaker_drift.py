@@ -106,6 +106,7 @@ def main():
         _lib.lib.sf_debug_precise_attention(precise)
         eng = speaker.SpeakerEngine(enc, dec, store)
         eng.persistent = persistent
+        eng.teacher_batched = False          # (this tool reads the word loops' own tapes)
         with torch.no_grad():
             st = eng.score(batch, n, feedback, train=False)
         torch.cuda.synchronize()
