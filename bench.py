@@ -331,6 +331,18 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
         enc.eval()
         dec.eval()
     rows = B * world if global_rows is None else global_rows
+    if graph is not None:
+        # one process, no collectives: the iteration as it would be run in production is ONE graph replay; the eager
+        # issue of the same launches is reported beside it
+        eager = dict(ms_per_iteration=1e3 * dt, value=rows * S / dt, what='the same iteration issued launch by launch')
+        dt_pub = 1e-3 * graph['ms_per_iteration']
+        return dict(value=rows * S / dt_pub, unit='agent-steps/s', ms_per_iteration=1e3 * dt_pub, iterations=iters,
+                    scaling='weak', global_batch=rows, rows_this_rank=B, roofline=kernels, health=health, eager=eager,
+                    launch='hipGraph replay (runtime.TrainingGraph): dropout sites and Adam steps are device words written '
+                           'in front of each replay; bit-identical to the eager loop (tests/test_gpu_training_graph.py)',
+                    allreduce_bytes=flat.flat.numel() * 4, **ar,
+                    what='student-forcing rollout (dropout 0.5) + BPTT + 2x Adam (one HIP launch each), batch %d per GPU, '
+                         '%d decode steps' % (B, S), loss=graph['loss'])
     return dict(value=rows * S / dt, graph=graph, unit='agent-steps/s', ms_per_iteration=1e3 * dt, iterations=iters,
                 scaling='weak' if global_rows is None else 'strong', global_batch=rows, rows_this_rank=B,
                 roofline=kernels, health=health,
@@ -718,7 +730,10 @@ def main(argv=None):
         if not args.no_train_extra:
             # (ten timed iterations behind five warm-up ones: the extra in front of it ends with host-bound work,
             # during which the device clocks fall)
-            out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(10, args.steps // 2), 5)
+            import gc
+            gc.collect()
+            gc.freeze()        # (the full world built above is ~10^6 live Python objects: keep the collector off them)
+            out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(10, args.steps // 2), 10)
     # (the host-only baseline comes LAST: seconds of CPU work let the GPU clocks fall, and the extras above were
     # measured with a warm device)
     if not args.no_cpu_baseline and world == 1:      # reported baseline: rank 0 at N = 1 only

@@ -413,7 +413,7 @@ def speaker_train_iteration(store, device, batch=100, words=80, iters=10):
         oe.step()
         od.step()
         return st
-    for _ in range(3):
+    for _ in range(10):
         it()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
