@@ -660,13 +660,14 @@ __global__ __launch_bounds__(512) void gemm_nt_split_kernel(NtArgs a) {
 // what one lane feeds one v_mfma_f32_16x16x32_bf16 (the K order inside an MFMA is free as long as A and B agree).
 // ------------------------------------------------------------------------------------------------
 struct NtBigArgs {
-    Seg seg[3];            // up to three K segments ([x | h] W = x W_x + h W_h: the LSTM gates); K_s % 32 == 0
+    Seg seg[3];            // up to three K segments ([x | h] W = x W_x + h W_h: the LSTM gates); K_s % 4 == 0
     int nseg;
     int M, N;
     float* y; int ldy;
     const float* bias; const float* bias2;
     const float* addend; int ld_addend;
     int epi, accumulate;
+    int ksplit;            // > 1: grid.y K-splits, split z writes its partial tile to slab y + z * M * N (ldy = N, plain)
 };
 constexpr int NB_T = 128, NB_K = 32, NB_PLANE = NB_T * 64;          // bytes per plane and stage (128 rows x 64 B)
 
@@ -686,16 +687,22 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
         arow[p] = min(m0 + srow + 64 * p, a.M - 1);
         wrow[p] = min(n0 + srow + 64 * p, a.N - 1);
     }
-    const int st0 = a.seg[0].K / NB_K, st1 = a.nseg > 1 ? a.seg[1].K / NB_K : 0, st2 = a.nseg > 2 ? a.seg[2].K / NB_K : 0;
-    // stage s -> its segment and depth offset (wave-uniform selects)
+    const int st0 = (a.seg[0].K + NB_K - 1) / NB_K, st1 = a.nseg > 1 ? (a.seg[1].K + NB_K - 1) / NB_K : 0,
+              st2 = a.nseg > 2 ? (a.seg[2].K + NB_K - 1) / NB_K : 0;
+    // stage s -> its segment and depth offset (wave-uniform selects); a segment's last stage may be partial (K_s % 4 == 0):
+    // loads beyond K_s are clamped and replaced by zeros
     auto gload = [&](int s, float4 (&ra)[2], float4 (&rw)[2]) {
         const int g = s < st0 ? 0 : (s < st0 + st1 ? 1 : 2);
         const int k0 = (s - (g > 0 ? st0 : 0) - (g > 1 ? st1 : 0)) * NB_K + 4 * c4;
         const Seg& sg = a.seg[g];
+        const bool ok = k0 < sg.K;
+        const int kc = ok ? k0 : 0;
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int p = 0; p < 2; ++p) {
-            ra[p] = ld4(sg.A + (size_t)arow[p] * sg.lda + k0);
-            rw[p] = ld4(sg.W + (size_t)wrow[p] * sg.ldw + k0);
+            const float4 x = ld4(sg.A + (size_t)arow[p] * sg.lda + kc), y = ld4(sg.W + (size_t)wrow[p] * sg.ldw + kc);
+            ra[p] = ok ? x : z;
+            rw[p] = ok ? y : z;
         }
     };
     const int soff = srow * 64 + ((c4 & 3) << 4) + ((c4 >> 2) << 3);  // byte offset of this thread's 8 bytes inside a plane
@@ -721,13 +728,16 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) hi[i][j] = lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const int stages = st0 + st1 + st2;
+    const int stages_all = st0 + st1 + st2;
+    const int ks = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
+    const int s_lo = (int)(((long)split * stages_all) / ks), s_hi = (int)(((long)(split + 1) * stages_all) / ks);
+    const int stages = s_hi - s_lo;
     float4 ra[2], rw[2];
-    gload(0, ra, rw);
+    gload(s_lo, ra, rw);
     stage_store(0, ra, rw);
     __syncthreads();
     for (int s = 0; s < stages; ++s) {
-        const int nxt = min(s + 1, stages - 1);                       // (clamped, not predicated: the last prefetch is unused)
+        const int nxt = s_lo + min(s + 1, stages - 1);                // (clamped, not predicated: the last prefetch is unused)
         gload(nxt, ra, rw);
         const unsigned char* Ab = nb_smem + (s & 1) * (6 * NB_PLANE) + (wm * 64 + li) * 64 + kk * 16;
         const unsigned char* Wb = nb_smem + (s & 1) * (6 * NB_PLANE) + 3 * NB_PLANE + (wn * 32 + li) * 64 + kk * 16;
@@ -747,6 +757,22 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
         __syncthreads();
     }
     // epilogue: lane (li, kk) holds rows 4 kk + r, column li of every 16 x 16 tile
+    if (ks > 1) {                                                     // K-split: the plain partial tile into this split's slab
+        float* slab = a.y + (size_t)split * a.M * a.N;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 32 + j * 16 + li;
+            if (col >= a.N) continue;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int row = m0 + wm * 64 + i * 16 + kk * 4 + r;
+                    if (row < a.M) slab[(size_t)row * a.N + col] = hi[i][j][r] + lo[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 32 + j * 16 + li;
@@ -1686,6 +1712,20 @@ static int launch_small_plan(const SmallPlan& p, hipStream_t st) {
 
 int launch_small_plan_x(const SmallPlan& p, hipStream_t st) { return launch_small_plan(p, st); }
 
+int transpose_ld(const float* src, int lds, int R, int C, float* dst, hipStream_t st);     // sf_pointwise.hip
+
+static int nt_big_launch(const NtBigArgs& b, hipStream_t st) {
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_big_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr_set = true;
+    }
+    SF_LAUNCH(gemm_nt_big_kernel, dim3(ceil_div(b.M, NB_T) * ceil_div(b.N, NB_T), b.ksplit > 1 ? b.ksplit : 1), dim3(512),
+              (size_t)2 * 6 * NB_PLANE, st, b);
+    return launch_status();
+}
+
 int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, float* ws,
               size_t ws_floats, hipStream_t st, float** raw_slabs, int* ksplit_out) {
     SF_CHECK_ARG(nseg >= 1 && nseg <= 3 && M > 0 && N > 0);
@@ -1709,7 +1749,7 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
     bool big = M >= 512 && N >= 64 && chunks >= 4 && !out.r1_s && g_nt_big &&
                (out.epi == EPI_NONE || out.epi == EPI_TANH) && !(out.accumulate && out.epi != EPI_NONE) &&
                (!raw_slabs || (ws && ws_floats >= (size_t)M * N));
-    for (int s = 0; s < nseg; ++s) big = big && segs[s].K % NB_K == 0;
+    for (int s = 0; s < nseg; ++s) big = big && segs[s].K >= NB_K;        // (a partial last stage per segment is fine)
     if (big) {
         // many rows: 128 x 128 tiles through LDS on the bf16 matrix cores (gemm_nt_big_kernel)
         NtBigArgs b{};
@@ -1720,15 +1760,8 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
             b.y = ws; b.ldy = N; b.bias = b.bias2 = b.addend = nullptr; b.epi = EPI_NONE; b.accumulate = 0;
             *raw_slabs = ws;
         }
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_big_kernel),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
-        SF_LAUNCH(gemm_nt_big_kernel, dim3(ceil_div(M, NB_T) * ceil_div(N, NB_T)), dim3(512), (size_t)2 * 6 * NB_PLANE, st, b);
         if (ksplit_out) *ksplit_out = 1;
-        return launch_status();
+        return nt_big_launch(b, st);
     }
     if (out.addend || out.r1_s || out.epi == EPI_TANHBWD) return SF_ERR_UNSUPPORTED;   // small kernel only
     nt_shape(M, N, chunks, &mt, &mblocks, &ks);
@@ -1934,6 +1967,39 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
             int ldo, int accumulate, hipStream_t st, float* ws, size_t ws_floats) {
     SF_CHECK_ARG(M > 0 && P > 0 && Q > 0 && Q % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 &&
                  ldo % 4 == 0);
+    // Round 5: a SMALL weight matrix with a deep reduction (the eight [256..512] x [512..2176] weight gradients of the decoder
+    // over 2 000 stacked rows: 25 TFLOP/s in gemm_tn_kernel, 90 us each) as an NT product of the two TRANSPOSED operands on
+    // the LDS-tiled many-row kernel: dW[P,Q] += Y^T[P,M] (X^T[Q,M])^T.  Two 32 x 32-tiled transposes into the workspace
+    // (~6 us each) + gemm_nt_big_kernel (bf16x6, 3x closer to float64 than the fp32 kernels).
+    if (g_nt_big && !g_nt_force_f32 && M >= 1024 && M % 4 == 0 && P >= 64 && Q >= 64 && (size_t)P * Q <= (size_t)1536 * 1024 &&
+        !(P % TNS_B == 0 && Q % TNS_B == 0 && M >= g_tn_split_min_rows) && ws) {
+        const int tiles = ceil_div(P, NB_T) * ceil_div(Q, NB_T), stages = ceil_div(M, NB_K);
+        int ks = std::max(1, std::min(std::min(16, 256 / tiles), stages / 4));
+        const size_t off_x = ((size_t)P * M + 63) & ~(size_t)63, off_s = off_x + (((size_t)Q * M + 63) & ~(size_t)63);
+        if (ws_floats >= off_s + (ks > 1 ? (size_t)ks * P * Q : 0)) {
+            float* yt = ws;
+            float* xt = ws + off_x;
+            int rc = transpose_ld(Y, ldy, M, P, yt, st);
+            if (rc != SF_OK) return rc;
+            rc = transpose_ld(X, ldx, M, Q, xt, st);
+            if (rc != SF_OK) return rc;
+            NtBigArgs b{};
+            b.seg[0] = Seg{yt, M, xt, M, M};
+            b.nseg = 1; b.M = P; b.N = Q; b.epi = EPI_NONE; b.ksplit = ks;
+            if (ks > 1) {
+                b.y = ws + off_s; b.ldy = Q;
+                rc = nt_big_launch(b, st);
+                if (rc != SF_OK) return rc;
+                RedArgs r{};
+                r.slabs = ws + off_s; r.ks = ks; r.M = P; r.N = Q; r.y = out; r.ldy = ldo; r.epi = EPI_NONE;
+                r.accumulate = accumulate;
+                SF_LAUNCH(reduce_slabs_kernel, dim3(red_grid((size_t)P * Q)), dim3(256), 0, st, r);
+                return launch_status();
+            }
+            b.y = out; b.ldy = ldo; b.accumulate = accumulate;
+            return nt_big_launch(b, st);
+        }
+    }
     // A small weight matrix with a deep reduction (e.g. [256, 2176] over 2000 stacked rows) is a
     // handful of waves each walking all M rows: split the rows over grid.z into slabs and add them
     // up (deterministic order) until the chip is covered.

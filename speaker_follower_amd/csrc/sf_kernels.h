@@ -142,6 +142,7 @@ int adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double
 int site_advance(uint32_t* word, uint32_t by, hipStream_t st);      // *word += by (sf_site_advance)
 int store_u32x4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, hipStream_t st);   // sf_store_u32x4
 int transpose(const float* src, int R, int C, float* dst, hipStream_t st);   // dst[C,R] = src^T
+int transpose_ld(const float* src, int lds, int R, int C, float* dst, hipStream_t st);     // the same, src row stride lds
 int dropout_tm(float* x, int T, int B, int E, const Dropout& d, const int* rev, hipStream_t st);
 int embedding_bwd(const float* demb, int ldd, const int64_t* seq, int Lpad, int T, int B, int E, int padding_idx,
                   const Dropout& d, const int* rev, float* grad, hipStream_t st);

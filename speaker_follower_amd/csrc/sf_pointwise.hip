@@ -244,12 +244,12 @@ __global__ void sum_accum_kernel(const float* s, int M, float* out) {     // one
     if (lane == 0) out[0] += t;
 }
 // 32x32 LDS-tiled transpose (both sides coalesced)
-__global__ __launch_bounds__(256) void transpose_kernel(const float* src, int R, int C, float* dst) {
+__global__ __launch_bounds__(256) void transpose_kernel(const float* src, int lds, int R, int C, float* dst) {
     __shared__ float tile[32][33];
     const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
     for (int i = ty; i < 32; i += 8)
-        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(size_t)(r0 + i) * C + c0 + tx];
+        if (r0 + i < R && c0 + tx < C) tile[i][tx] = src[(size_t)(r0 + i) * lds + c0 + tx];
     __syncthreads();
     for (int i = ty; i < 32; i += 8)
         if (c0 + i < C && r0 + tx < R) dst[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
@@ -951,7 +951,12 @@ int fill(float* p, size_t n, float v, hipStream_t st) {
     return launch_status();
 }
 int transpose(const float* src, int R, int C, float* dst, hipStream_t st) {
-    SF_LAUNCH(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, st, src,
+    SF_LAUNCH(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, st, src, C,
+                       R, C, dst);
+    return launch_status();
+}
+int transpose_ld(const float* src, int lds, int R, int C, float* dst, hipStream_t st) {     // dst [C,R] contiguous
+    SF_LAUNCH(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, st, src, lds,
                        R, C, dst);
     return launch_status();
 }

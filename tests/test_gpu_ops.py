@@ -98,7 +98,8 @@ def test_weight_gradient_on_the_bf16_matrix_cores(sf, M, N, K):
 
 
 @pytest.mark.parametrize('M,N,K,act', [(8000, 512, 512, 0), (8000, 512, 1024, 1), (8000, 991, 512, 0), (2560, 512, 512, 0),
-                                       (515, 130, 96, 1), (4100, 64, 64, 0), (1000, 2048, 992, 0)])
+                                       (515, 130, 96, 1), (4100, 64, 64, 0), (1000, 2048, 992, 0),
+                                       (991, 2048, 300, 0), (4100, 256, 304, 0)])       # partial last stage (K % 32 != 0)
 def test_many_row_product_on_the_bf16_matrix_cores(sf, M, N, K, act):
     """y = act(x W^T + b) for M >= 512 through gemm_nt_big_kernel (128 x 128 tiles, both operands staged through LDS as
     three bf16 planes) against float64: asymmetric, badly scaled operands (a swapped fragment mapping, a wrong chunk
@@ -125,6 +126,34 @@ def test_many_row_product_on_the_bf16_matrix_cores(sf, M, N, K, act):
           % (M, N, K, errs[1], errs[0]))
     # (with tanh the error of the pre-activation -- up to |x W^T| ~ 30 here -- passes through a slope <= 1)
     assert errs[1] <= 1e-6 * (max(1.0, pre_scale) if act else 1.0) and errs[1] <= 1.5 * errs[0] + 1e-7
+
+
+@pytest.mark.parametrize('M,N,K', [(2000, 256, 2176), (2000, 512, 1024), (2000, 256, 512), (1024, 100, 300), (8000, 992, 512),
+                                   (2004, 64, 64)])
+def test_small_weight_gradient_through_the_many_row_kernel(sf, M, N, K):
+    """dW [N,K] += dY^T X for a small weight over >= 1 024 stacked rows (the decoder's eight small weight gradients over
+    S*B = 2 000 rows): two tiled transposes + gemm_nt_big_kernel with a K-split, against float64 -- accumulated INTO a
+    non-zero dW, asymmetric operands, ragged tiles, a reduction that is not a multiple of the stage depth; at least as
+    accurate as the kernels of rounds 1-4."""
+    rng = np.random.default_rng(M + N + K)
+    x = (rnd(rng, M, K) + (np.arange(K) % 7)[None, :] * 0.1).astype(np.float32)
+    dy = (rnd(rng, M, N) * (1.0 + (np.arange(N) % 5)[None, :])).astype(np.float32)
+    w = rnd(rng, N, K, scale=K ** -0.5)
+    dw0 = rnd(rng, N, K)
+    ref = dw0.astype(np.float64) + dy.astype(np.float64).T @ x.astype(np.float64)
+    scale = float(np.abs(ref).max())
+    errs = {}
+    for big in (1, 0):
+        sf.lib.lib.sf_debug_many_row_product(big)
+        try:
+            dw = dev(dw0.copy())
+            sf.ops.linear_bwd(dev(x), dev(w), None, dev(dy), 0, False, dw, None)
+            torch.cuda.synchronize()
+        finally:
+            sf.lib.lib.sf_debug_many_row_product(1)
+        errs[big] = float(np.abs(dw.cpu().numpy() - ref).max()) / scale
+    print('[small wgrad %dx%dx%d] max error / scale: transposes + bf16x6 tiles %.2e, rounds 1-4 kernels %.2e' % (M, N, K, errs[1], errs[0]))
+    assert errs[1] <= 2e-6 and errs[1] <= 1.5 * errs[0] + 1e-7
 
 
 def test_gemm_is_transpose_safe(sf):

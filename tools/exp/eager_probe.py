@@ -31,5 +31,5 @@ fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=10567)
 batch = follower.DeviceFollowerBatch.from_synth(fb, device=dev)
 enc, dec, _, _ = bench.build_models(101, dev)
 t = bench.measure_train(enc, dec, store, batch, 20, 10, 5)
-print('follower eager %.3f graph %.3f' % (t['ms_per_iteration'], t['graph']['ms_per_iteration']), flush=True)
+print('follower eager %.3f graph %.3f' % (t['eager']['ms_per_iteration'], t['ms_per_iteration']), flush=True)
 spk('behind the follower measurement (graph captured)', prof=True)
