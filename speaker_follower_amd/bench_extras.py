@@ -372,6 +372,22 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
         st = it()
     torch.cuda.synchronize()
     dtt = (time.perf_counter() - t1) / train_iters
+    # the same iteration as ONE hipGraph replay (runtime.TrainingGraph): the sampled actions, the environment steps they
+    # drive and the dropout masks differ from replay to replay through device words only
+    dtg = loss_g = None
+    try:
+        tg = eng2.capture_training(navb, steps, 'sample', optimizers=(oe, od), zero=flat)
+        for _ in range(2):
+            tg.replay()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(train_iters):
+            tg.replay()
+        torch.cuda.synchronize()
+        dtg = (time.perf_counter() - t1) / train_iters
+        loss_g = float(tg.state.loss_buf)
+    except Exception as exc:                     # (reported, not fatal: the eager figure stands)
+        out['train_sample_feedback_graph_error'] = repr(exc)[:300]
     # (c) configs[4] on the same world: state-factored search K = 40 over a minibatch of 64 instructions
     from . import agents
     n_mb = 8
@@ -401,6 +417,10 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
                                         loss=float(st.loss.detach()),
                                         what='rollout with dropout 0.5 + sampled actions on the device env, BPTT, '
                                              '2x Adam; eager issue, same minibatch every iteration')
+    if dtg is not None:
+        out['train_sample_feedback']['graph_replay'] = dict(
+            value=batch * steps / dtg, ms_per_iteration=1e3 * dtg, loss=loss_g,
+            what='the same iteration as one hipGraph replay: fresh samples / masks per replay through device words')
     return out
 
 

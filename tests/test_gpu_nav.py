@@ -173,6 +173,62 @@ def test_device_rollout_trains_and_replays_as_a_graph(world):
     assert [t['trajectory'] for t in navb.trajectories(gst)] == [t['trajectory'] for t in navb.trajectories(st)]
 
 
+def test_training_graph_over_the_device_environment(world):
+    """The reference's own training configuration -- `sample` feedback, the environment stepped ON THE DEVICE by the action
+    just drawn -- as hipGraph replays (runtime.TrainingGraph): the sampled walks, losses and weights of the eager loop."""
+    from speaker_follower_amd import follower, nav, optim, model, synth
+    env, agent, store, nt, enc0, dec0 = world
+    env.reset_epoch()
+    env._next_minibatch(True)
+    items = list(env.batch)
+    d = synth.FULL
+    out = {}
+    for mode in ('eager', 'graph'):
+        enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc0.embedding.weight.detach().cpu().numpy())
+        dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+        enc.load_state_dict(enc0.state_dict())
+        dec.load_state_dict(dec0.state_dict())
+        enc.cuda().train()
+        dec.cuda().train()
+        navb = nav.DeviceNavBatch(nt, items, EPISODE)
+        oe = optim.FusedAdam([p for p in enc.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-4)
+        od = optim.FusedAdam([p for p in dec.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-4)
+        eng = follower.FollowerEngine(enc, dec, store)
+        eng.dropout_seed = 31
+        losses, walks = [], []
+
+        def note(st, loss):
+            torch.cuda.synchronize()
+            losses.append(float(loss))
+            walks.append([t['trajectory'] for t in navb.trajectories(st)])
+        if mode == 'eager':
+            for _ in range(4):
+                oe.zero_grad()
+                od.zero_grad()
+                st = eng.rollout(navb, EPISODE, 'sample', train=True)
+                st.loss.backward()
+                oe.step()
+                od.step()
+                note(st, st.loss.detach())
+        else:
+            tg = eng.capture_training(navb, EPISODE, 'sample', optimizers=(oe, od))
+            # (the eager first iteration's walk was overwritten by the capture's buffers: compare from replay 1 on)
+            losses.append(float(tg.first.loss_buf))
+            walks.append(None)
+            for _ in range(3):
+                st = tg.replay()
+                note(st, st.loss_buf)
+        torch.cuda.synchronize()
+        out[mode] = (losses, walks, torch.cat([p.detach().reshape(-1) for m in (enc, dec) for p in m.parameters()]).clone())
+    np.testing.assert_allclose(out['graph'][0], out['eager'][0], rtol=2e-6)
+    assert len(set(out['eager'][0])) == 4
+    for a, b in list(zip(out['eager'][1], out['graph'][1]))[1:]:
+        assert a == b                                               # the same sampled walks through the graphs
+    assert out['eager'][1][1] != out['eager'][1][2]                 # (and they differ from iteration to iteration)
+    we, wg = out['eager'][2], out['graph'][2]
+    assert float((we - wg).abs().max()) <= 2e-6 * float(we.abs().max())
+
+
 def test_agent_api_with_device_env_trains_and_tests(world, tmp_path):
     """Seq2SeqAgent.train / test (follower.py:987-1020) over the device-resident env: same walk as the
     host loop in eval mode, finite falling loss over a few Adam iterations in train mode."""

@@ -210,3 +210,4 @@ def test_adam_step_with_a_device_side_counter():
     assert int(word) == 4 and ob.host_steps() == [4]
     for p, q in zip(a, b):
         assert torch.equal(p.detach(), q.detach())
+
