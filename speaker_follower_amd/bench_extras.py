@@ -208,9 +208,22 @@ def search_full(conn_dir, device, scans=('YmJkqBEsHnH', 'gZ6f7yhEvPG', 'GdvgFV5R
         dt = time.perf_counter() - t0
         best = dt if best is None else min(best, dt)
         n_c = sum(len(t) for t in trajs)
+    # follower.py:541-718 on the same minibatch: plain beam search, K hypotheses per instruction
+    best_b = None
+    for _ in range(3):
+        e.reset_epoch()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            agent.beam_search(k)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        best_b = dt if best_b is None else min(best_b, dt)
     return dict(what='state_factored_search(K=%d, 1), %d instructions, %d-viewpoint fixture graphs, episode_len %d'
                      % (k, instances, n, episode_len), value=instances / best, unit='instructions/s',
-                seconds=best, candidates=n_c)
+                seconds=best, candidates=n_c,
+                beam_search=dict(seconds=best_b, value=instances / best_b, unit='instructions/s',
+                                 what='beam_search(K=%d) over the same minibatch (up to %d states per step)' % (k, instances * k)))
 
 
 @_guard
@@ -593,7 +606,26 @@ def search_step(enc, dec, store, device, instances=64, k=40, words=80):
             with torch.no_grad():
                 fd.step(obs, udesc, rows, inst, k)
         dt = _timed(step, 2, 5)
-        out[label] = dict(value=n / dt, ms_per_step=1e3 * dt, states=n)
+        out[label] = dict(value=n / dt, ms_per_step=1e3 * dt, states=n,
+                          how='dictionary observations packed on the host (the round-1 entry point FlatDecoder.step)')
+        # what frontier.beam_search / state_factored_search issue since round 3: the same step over INDEX ARRAYS
+        # (FlatDecoder.step_arrays: one upload, ~8 library calls, one download)
+        a_max = 14
+        a_num = (1 + np.clip(rng.poisson(4, n), 1, a_max - 1)).astype(np.int64)
+        inp = dict(vp=rng.integers(0, n_vp, n), view=rng.integers(0, 36, n), a_num=a_num,
+                   cand_view=rng.integers(0, 36, (n, a_max)), sincos=rng.standard_normal((n, a_max, 4)).astype(np.float32),
+                   hrow=np.asarray(rows, np.int64), crow=np.asarray(inst, np.int64), has_u=rng.random(n) < 0.9,
+                   u_vp=rng.integers(0, n_vp, n), u_view=rng.integers(0, 36, n),
+                   u_sincos=rng.standard_normal((n, 4)).astype(np.float32))
+
+        def step_a():
+            fd = search.FlatDecoder(dec, store, ctx, mask)
+            fd.seed(h_t, c_t)
+            with torch.no_grad():
+                fd.step_arrays(inp, k)
+        dt_a = _timed(step_a, 2, 5)
+        out[label]['index_arrays'] = dict(value=n / dt_a, ms_per_step=1e3 * dt_a,
+                                          how='FlatDecoder.step_arrays: what the searches issue per step')
     # speaker rescoring of instances x k candidate paths (teacher-forced NLL of the instruction)
     senc, sdec = _speaker_models(device)
     n = instances * k

@@ -732,15 +732,12 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
     const int ks = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
     const int s_lo = (int)(((long)split * stages_all) / ks), s_hi = (int)(((long)(split + 1) * stages_all) / ks);
     const int stages = s_hi - s_lo;
-    float4 ra[2], rw[2];
-    gload(s_lo, ra, rw);
-    stage_store(0, ra, rw);
-    __syncthreads();
-    for (int s = 0; s < stages; ++s) {
-        const int nxt = s_lo + min(s + 1, stages - 1);                // (clamped, not predicated: the last prefetch is unused)
-        gload(nxt, ra, rw);
-        const unsigned char* Ab = nb_smem + (s & 1) * (6 * NB_PLANE) + (wm * 64 + li) * 64 + kk * 16;
-        const unsigned char* Wb = nb_smem + (s & 1) * (6 * NB_PLANE) + 3 * NB_PLANE + (wn * 32 + li) * 64 + kk * 16;
+    // Two register sets: the loads of stage s + 2 are issued at the top of stage s and stored to LDS at the end of stage
+    // s + 1 -- two stages (~1.2 us) of latency hiding; one stage is less than an HBM round trip under load.
+    float4 ra[2][2], rw[2][2];
+    auto compute = [&](int buf) {
+        const unsigned char* Ab = nb_smem + buf * (6 * NB_PLANE) + (wm * 64 + li) * 64 + kk * 16;
+        const unsigned char* Wb = nb_smem + buf * (6 * NB_PLANE) + 3 * NB_PLANE + (wn * 32 + li) * 64 + kk * 16;
         Split8 wf[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -753,7 +750,21 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
             for (int pl = 0; pl < 3; ++pl) af.p[pl] = *reinterpret_cast<const bf16x8*>(Ab + pl * NB_PLANE + i * 16 * 64);
             mfma_split6_across<2>(af, [&](int j) -> const Split8& { return wf[j]; }, hi[i], lo[i]);
         }
-        if (s + 1 < stages) stage_store((s + 1) & 1, ra, rw);
+    };
+    const int last = s_hi - 1;
+    gload(s_lo, ra[0], rw[0]);
+    stage_store(0, ra[0], rw[0]);
+    gload(min(s_lo + 1, last), ra[1], rw[1]);                        // set 1 <- stage 1 (in flight during stage 0)
+    __syncthreads();
+    for (int s = 0; s < stages; s += 2) {
+        gload(min(s_lo + s + 2, last), ra[0], rw[0]);                 // set 0 <- stage s + 2
+        compute(0);
+        if (s + 1 < stages) stage_store(1, ra[1], rw[1]);             // stage s + 1 (issued one stage ago) -> buffer 1
+        __syncthreads();
+        if (s + 1 >= stages) break;
+        gload(min(s_lo + s + 3, last), ra[1], rw[1]);                 // set 1 <- stage s + 3
+        compute(1);
+        if (s + 2 < stages) stage_store(0, ra[0], rw[0]);             // stage s + 2 -> buffer 0
         __syncthreads();
     }
     // epilogue: lane (li, kk) holds rows 4 kk + r, column li of every 16 x 16 tile
