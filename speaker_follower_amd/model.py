@@ -589,12 +589,20 @@ class _AttnLstmStepFn(torch.autograd.Function):
         h1, c1, gates = new(B, H), new(B, H), new(B, 4 * H)
         p, seed, site = drop_cfg
         d = dropout_arg(p, seed)
-        vw = struct_of(_lib.VisualW, params[0:4])
+        # (the speaker's path encoder forms its attention query and scores in float64 -- csrc/sf_precise.hip -- on the module
+        # path as on the engines'; shapes outside that kernel take the fp32 one)
+        vw = _lib.VisualW(*(p_.data_ptr() for p_ in params[0:4]), transposed(params[2]).data_ptr(),
+                          transposed(params[0]).data_ptr())
         lw = struct_of(_lib.LstmW, params[4:8])
         pano = pano_dense(X)
         xin_f = C.c_void_p(xin.data_ptr() + 4 * F)
-        call('sf_visual_attention_fwd', byref(vw), byref(pano), B, H, D, ptr(h0), xin_f, 2 * F,
-             ptr(alpha), ptr(t_v), ptr(q), d, 2 * site, F, *ws_args(dev))
+        rc = _lib.lib.sf_visual_attention_fwd_f64(byref(vw), byref(pano), B, H, D, ptr(h0), xin_f, 2 * F,
+                                                  ptr(alpha), ptr(t_v), ptr(q), d, 2 * site, F, *ws_args(dev))
+        if rc == 2:                                  # SF_ERR_UNSUPPORTED
+            call('sf_visual_attention_fwd', byref(vw), byref(pano), B, H, D, ptr(h0), xin_f, 2 * F,
+                 ptr(alpha), ptr(t_v), ptr(q), d, 2 * site, F, *ws_args(dev))
+        else:
+            _lib.check(rc, 'sf_visual_attention_fwd_f64')
         call('sf_dropout_copy', ptr(act_emb), F, B, F, ptr(xin), 2 * F, d, 2 * site, 0, stream())
         call('sf_lstm_cell_fwd', byref(lw), B, 2 * F, H, ptr(xin), 2 * F, ptr(h0), ptr(c0), ptr(h1),
              ptr(c1), ptr(gates), None, 0, None, 0, *ws_args(dev))

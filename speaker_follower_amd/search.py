@@ -510,6 +510,82 @@ def rational_mix(candidate_lists_by_instr_id, speaker_weight):
     return results, index_count
 
 
+# ------------------------------------------------------------------------------ rational speaker
+def generate_and_score_candidates(envir, speaker, follower, n_candidates, include_gold=False):
+    """rational_speaker.py:9-106: for every gold path of the environment the speaker's `n_candidates` beam
+    instructions (speaker.py:211-318), each scored by the follower with teacher forcing along that path
+    (follower.py:342-428: how likely is THIS route given that instruction).  Returns {instr_id: [candidate, ...]},
+    every candidate with `speaker_score`, `follower_score` and the follower's `actions`; stops when an instruction
+    comes round again (one epoch)."""
+    from .follower import EOS
+    follower.env = envir
+    speaker.env = envir
+    envir.reset_epoch()
+    speaker.feedback = 'argmax'
+    for module in (follower.encoder, follower.decoder, speaker.encoder, speaker.decoder):
+        module.eval()
+    follower.set_beam_size(1)
+    by_id = {}
+    n_per_instance = []
+    looped = False
+    while not looped:
+        path_obs, path_actions, gold_instr = envir.gold_obs_actions_and_instructions(speaker.max_episode_len,
+                                                                                     load_next_minibatch=True)
+        with torch.no_grad():
+            gold = []
+            if include_gold:
+                gold, _ = speaker._score_obs_actions_and_instructions(path_obs, path_actions, gold_instr, 'teacher')
+            beams = speaker.beam_search(n_candidates, path_obs, path_actions)
+            if include_gold:
+                assert len(gold) == len(beams)
+                for g, bc in zip(gold, beams):
+                    assert g['instr_id'] == bc[0]['instr_id']
+                    bc.insert(0, g)
+            cand_obs, cand_actions, cand_words = [], [], []
+            for i, beam in enumerate(beams):
+                n_per_instance.append(len(beam))
+                for cand in beam:
+                    cand_obs.append(path_obs[i])
+                    cand_actions.append(path_actions[i])
+                    idx = list(cand['word_indices'])
+                    cand_words.append(idx[:-1] if idx and idx[-1] == EOS else idx)      # rational_speaker.py:63-65
+            scored, _ = follower._score_obs_actions_and_instructions(cand_obs, cand_actions, cand_words)
+        assert len(scored) == sum(len(b) for b in beams)
+        k = 0
+        for beam in beams:
+            for cand in beam:
+                fs = scored[k]
+                k += 1
+                assert cand['instr_id'] == fs['instr_id']
+                cand['speaker_score'], cand['follower_score'], cand['actions'] = cand['score'], fs['score'], fs['actions']
+            instr_id = beam[0]['instr_id']
+            assert all(c['instr_id'] == instr_id for c in beam)
+            if instr_id in by_id:
+                looped = True
+            else:
+                by_id[instr_id] = beam
+    return by_id
+
+
+def predict_from_candidates(candidate_lists_by_instr_id, speaker_weights):
+    """rational_speaker.py:109-137: scores standardised over ALL candidates; per weight and instruction the
+    candidate with the highest weighted sum (first maximum).  Returns {weight: {instr_id: candidate}}."""
+    return {w: rational_mix(candidate_lists_by_instr_id, w)[0] for w in speaker_weights}
+
+
+def run_rational_speaker(envir, speaker_evaluator, speaker, follower, n_candidates, include_gold=False):
+    """rational_speaker.py:140-165 without the file output: candidates, re-ranking for the 21 speaker weights 0, 0.05 ..
+    1, and -- with an evaluator (eval_speaker.py, out of scope here) -- its score summary per weight.  Returns
+    (scores_by_weight or None, results_by_weight)."""
+    by_id = generate_and_score_candidates(envir, speaker, follower, n_candidates, include_gold)
+    weights = [float(w) for w in np.arange(0, 20 + 1) / 20.0]
+    results = predict_from_candidates(by_id, weights)
+    scores = None
+    if speaker_evaluator is not None:
+        scores = {w: speaker_evaluator.score_results(r)[0] for w, r in results.items()}
+    return scores, results
+
+
 def _follower_candidates(follower, beam_size, include_gold, mask_undo, state_factored, key_fields):
     """One minibatch of candidate routes per instruction (rational_follower.py:35-62): optionally the gold route
     (a teacher-forced rollout) first, then the (state-factored) beam search's completions."""

@@ -443,3 +443,80 @@ def test_rational_follower_with_scores_issued_by_the_search_equals_the_plain_pip
             assert a['actions'] == b['actions'] and a['trajectory'] == b['trajectory']
             assert abs(a['speaker_score'] - b['speaker_score']) <= 2e-4 * max(1.0, abs(b['speaker_score']))
             assert a['follower_score'] == b['follower_score']
+
+
+def test_rational_speaker_pipeline_matches_reference():
+    """rational_speaker.py:9-137 (`generate_and_score_candidates` + `predict_from_candidates`): golden G13 is the output of
+    the reference's own module over this fixture world (tests/golden/make_golden_rational_speaker.py).  Per instruction
+    the same candidate instructions in the same order (word ids identical), speaker and follower scores within 3e-4, the
+    follower's teacher-forced actions identical; per speaker weight the same candidate is chosen wherever the reference's
+    own margin between its two best candidates exceeds the score tolerance."""
+    from speaker_follower_amd import model, features, agents, synth, search
+    with open(os.path.join(HERE, 'golden', 'g13_rational_speaker.json')) as f:
+        gold = json.load(f)
+    cfg = gold['config']
+    env, table = W.build_world(dense=True)
+    d = synth.FULL
+    enc_w, dec_w = synth.follower_weights_peaky(cfg['follower_seed'])
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc_w['embedding.weight'])
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict({k: torch.tensor(v) for k, v in enc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in dec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    follower = agents.Seq2SeqAgent(env, '/tmp/sf_rs.json', enc, dec, episode_len=cfg['episode_len'],
+                                   max_instruction_length=cfg['instruction_len'])
+    follower.store = features.FeatureStore(table)
+    senc_w, sdec_w = synth.speaker_weights_peaky(cfg['speaker_seed'])
+    senc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    sdec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'])
+    senc.load_state_dict({k: torch.tensor(v) for k, v in senc_w.items()})
+    sdec.load_state_dict({k: torch.tensor(v) for k, v in sdec_w.items()})
+    senc.cuda().eval()
+    sdec.cuda().eval()
+    speaker = agents.Seq2SeqSpeaker(env, '/tmp/sf_rs_spk.json', senc, sdec, cfg['instruction_len'],
+                                    max_episode_len=cfg['episode_len'])
+    speaker.store = follower.store
+    # (ONE epoch over a fresh environment, as the golden run: the environment reshuffles its items when it wraps around,
+    # and the speaker encoder's padded path steps make a candidate list depend on its minibatch's longest path -- the
+    # reference's own behaviour, model.py:445-451)
+    by_id = search.generate_and_score_candidates(env, speaker, follower, cfg['n_candidates'])
+    assert {str(k) for k in by_id} == set(gold['candidates'])
+    worst_s = worst_f = 0.0
+    for k, lst in by_id.items():
+        want = gold['candidates'][str(k)]
+        assert len(lst) == len(want)
+        for c, w in zip(lst, want):
+            assert [int(x) for x in c['word_indices']] == w['word_indices']
+            assert [int(a) for a in c['actions']] == w['actions']
+            worst_s = max(worst_s, abs(c['speaker_score'] - w['speaker_score']) / max(1.0, abs(w['speaker_score'])))
+            worst_f = max(worst_f, abs(c['follower_score'] - w['follower_score']) / max(1.0, abs(w['follower_score'])))
+    print('rational speaker: %d instructions, %d candidates; worst relative score difference speaker %.2e, follower %.2e'
+          % (len(by_id), sum(len(v) for v in by_id.values()), worst_s, worst_f))
+    assert worst_s <= SCORE_TOL and worst_f <= SCORE_TOL
+    # the re-ranking: the reference's choice wherever its own top-two margin is not within the score tolerance
+    ss = np.array([c['speaker_score'] for lst in gold['candidates'].values() for c in lst])
+    fs = np.array([c['follower_score'] for lst in gold['candidates'].values() for c in lst])
+    res = search.predict_from_candidates(by_id, [float(w) for w in np.arange(0, 21) / 20.0])
+    agree = total = 0
+    for w, chosen in res.items():
+        sw, fw = w / ss.std(), (1 - w) / fs.std()
+        for k, best in chosen.items():
+            want = gold['candidates'][str(k)]
+            mixed = sorted((c['speaker_score'] * sw + c['follower_score'] * fw for c in want), reverse=True)
+            got = next(i for i, c in enumerate(by_id[k]) if c is best)
+            total += 1
+            if got == gold['chosen']['%.2f' % w][str(k)]:
+                agree += 1
+            else:
+                assert mixed[0] - mixed[1] <= 1e-3 * max(1.0, abs(mixed[0])), (w, k, mixed[:2])
+    print('re-ranking: %d of %d (weight, instruction) choices equal the reference\'s' % (agree, total))
+    assert agree >= 0.97 * total
+    # the whole pipeline in one call (rational_speaker.py:140-165) on a fresh world
+    env2, _ = W.build_world(dense=True)
+    scores, results = search.run_rational_speaker(env2, None, speaker, follower, cfg['n_candidates'])
+    assert scores is None and len(results) == 21 and all(len(r) == W.N_ITEMS for r in results.values())
+    for w in (0.0, 1.0):
+        for k, best in results[w].items():
+            key = 'follower_score' if w == 0.0 else 'speaker_score'
+            assert best[key] == max(c[key] for c in by_id[k])

@@ -254,3 +254,22 @@ def test_native_state_factored_bookkeeping_equals_the_numpy_restatement(monkeypa
     agent.env.reset_epoch()
     frontier.state_factored_search(agent, 5, 1)
     assert agent.tie_log
+
+
+def test_rational_speaker_reranking_matches_reference():
+    """rational_speaker.py:109-137 (`predict_from_candidates`) is host arithmetic: fed the REFERENCE's candidates and
+    scores (golden G13, tests/golden/make_golden_rational_speaker.py) it must choose the reference's candidate for all 21
+    speaker weights x 16 instructions."""
+    import json
+    import os
+    from speaker_follower_amd import search
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'g13_rational_speaker.json')) as f:
+        gold = json.load(f)
+    by_id = {k: [dict(c) for c in lst] for k, lst in gold['candidates'].items()}
+    weights = [float(w) for w in np.arange(0, 21) / 20.0]
+    res = search.predict_from_candidates(by_id, weights)
+    assert len(res) == 21
+    for w in weights:
+        for k, best in res[w].items():
+            got = next(i for i, c in enumerate(by_id[k]) if c is best)
+            assert got == gold['chosen']['%.2f' % w][k], (w, k)
