@@ -264,6 +264,16 @@ int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int 
                               float* dh, int lddh, float* dctx, void* ws, size_t ws_bytes,
                               sf_stream stream);
 
+/* ---- ContextOnlySoftDotAttention.forward behind its linear_in (model.py:166-177; SpeakerDecoderLSTM with
+ * use_input_att_feed, model.py:500-503): attn = softmax_l(ctx[b,l,:] . t[b,:]) with mask[b,l] != 0 -> -inf,
+ * wc[b,:] = sum_l attn[b,l] ctx[b,l,:].  ctx [B,L,H], mask [B,L] uint8 or NULL, t [B,H] (row stride ldt) = linear_in(h),
+ * alpha [B,L], wc [B,H] (row stride ldwc). */
+int sf_text_attention_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t, int ldt,
+                          float* alpha, float* wc, int ldwc, sf_stream stream);
+/* dwc [B,H] in; dt [B,H] out (overwritten); dctx [B,L,H] accumulated (NULL: not formed). */
+int sf_text_attention_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc, const float* t, int ldt,
+                          const float* alpha, float* dt, int lddt, float* dctx, sf_stream stream);
+
 /* ---- EltwiseProdScoring.forward (model.py:342-352) -------------------------------------------
  * logit[b,a] = w_out . (t_a[b] * (W_a u[b,a] + b_a)) + b_out,  t_a = W_h h + b_h; implemented as
  * u[b,a] . r[b] + wt[b] . b_a + b_out with wt = w_out * t_a, r = W_a^T wt.  Saves t_a, wt [B,D], r. */

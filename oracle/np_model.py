@@ -226,6 +226,30 @@ def speaker_decoder_step(dec, prev_word, h0, c0, ctx, ctx_mask):
     return h1, c1, alpha, logit
 
 
+def context_only_soft_dot_attention(h, context, mask, w_in):
+    """ContextOnlySoftDotAttention.forward, model.py:161-177."""
+    target = linear(h, w_in)                                               # :166
+    attn = np.einsum('bld,bd->bl', context, target).astype(f32)            # :169
+    if mask is not None:
+        attn = np.where(mask, f32(-np.inf), attn)                          # :172
+    attn = softmax(attn, axis=1)                                           # :173
+    weighted = np.einsum('bl,bld->bd', attn, context).astype(f32)          # :176
+    return weighted, attn
+
+
+def speaker_decoder_step_att_feed(dec, prev_word, h0, c0, ctx, ctx_mask):
+    """SpeakerDecoderLSTM.forward, the use_input_att_feed branch, model.py:497-513 (eval mode: dropout is identity)."""
+    emb = dec['embedding.weight'][prev_word]                               # :497-498
+    h_tilde, alpha = context_only_soft_dot_attention(h0, ctx, ctx_mask, dec['attention_layer.linear_in.weight'])   # :502-503
+    concat_input = np.concatenate((emb, h_tilde), 1)                       # :504
+    h1, c1 = lstm_cell(concat_input, h0, c0, dec['lstm.weight_ih'], dec['lstm.weight_hh'],
+                       dec['lstm.bias_ih'], dec['lstm.bias_hh'])           # :505
+    x = np.concatenate((h1, h_tilde), 1)                                   # :506
+    x = np.tanh(linear(x, dec['output_l1.weight'], dec['output_l1.bias'])).astype(f32)        # :508-509
+    logit = linear(x, dec['decoder2action.weight'], dec['decoder2action.bias'])               # :510
+    return h1, c1, alpha, logit
+
+
 def speaker_score(enc, dec, action_embs, world_feats, path_mask, instr_seq, steps,
                   feedback, pad_idx=0, bos_idx=3, eos_idx=2):
     """Seq2SeqSpeaker._score_obs_actions_and_instructions, speaker.py:135-197."""

@@ -171,6 +171,8 @@ _SIGNATURES = {
                                             c_f, c_f, c_f, c_f] + WS),
     'sf_soft_dot_attention_bwd': (C.c_int, [P(SoftdotW), P(SoftdotW), i32, i32, i32, c_f, c_f, c_f,
                                             c_f, c_f, c_f, c_f, i32, c_f] + WS),
+    'sf_text_attention_fwd': (C.c_int, [c_f, c_p, i32, i32, i32, c_f, i32, c_f, c_f, i32, c_p]),
+    'sf_text_attention_bwd': (C.c_int, [c_f, i32, i32, i32, c_f, i32, c_f, i32, c_f, c_f, i32, c_f, c_p]),
     'sf_eltwise_prod_scoring_fwd': (C.c_int, [P(ScoringW), P(Cands), i32, i32, i32, c_f, c_f, c_f,
                                               c_f, c_f] + WS),
     'sf_eltwise_prod_scoring_bwd': (C.c_int, [P(ScoringW), P(ScoringW), P(Cands), i32, i32, i32,

@@ -585,6 +585,21 @@ int sf_soft_dot_attention_bwd(const sf_softdot_w* w, const sf_softdot_g* g, int 
                          arena(ws, ws_bytes), S(stream));
 }
 
+// ContextOnlySoftDotAttention core (model.py:166-177 behind its linear_in): scores, masked softmax, weighted context
+int sf_text_attention_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t, int ldt,
+                          float* alpha, float* wc, int ldwc, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(ctx && t && alpha && wc && B > 0 && L > 0 && H > 0);
+    return text_attn_fwd(ctx, mask, B, L, H, t, ldt, alpha, wc, ldwc, S(stream));
+}
+
+int sf_text_attention_bwd(const float* ctx, int B, int L, int H, const float* dwc, int lddwc, const float* t, int ldt,
+                          const float* alpha, float* dt, int lddt, float* dctx, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(ctx && dwc && t && alpha && dt && B > 0 && L > 0 && H > 0);
+    return text_attn_bwd(ctx, B, L, H, dwc, lddwc, t, ldt, alpha, dt, lddt, dctx, S(stream));
+}
+
 int sf_eltwise_prod_scoring_fwd(const sf_scoring_w* w, const sf_cands* U, int B, int H, int D,
                                 const float* h, float* logit, float* t_a, float* wt, float* r,
                                 void* ws, size_t ws_bytes, sf_stream stream) {

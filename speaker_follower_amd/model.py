@@ -90,8 +90,48 @@ class _LinearFn(torch.autograd.Function):
         return None, None, dx, None, None
 
 
+class _PaddedLinearFn(torch.autograd.Function):
+    """nn.Linear whose output width is not a multiple of 4 (decoder2action: vocab 991): computed with the weight and bias
+    padded by zero rows to the next multiple of 4 -- the kernels read rows of the output gradient 16 bytes at a time --
+    and sliced; the padded gradients' first rows are added to the parameters' gradients."""
+
+    @staticmethod
+    def forward(ctx, lin, x, w, b):
+        N, K = w.shape
+        Np = (N + 3) & ~3
+        wp = torch.zeros(Np, K, device=w.device, dtype=torch.float32)
+        wp[:N].copy_(w.detach())
+        bp = None
+        if b is not None:
+            bp = torch.zeros(Np, device=w.device, dtype=torch.float32)
+            bp[:N].copy_(b.detach())
+        y = ops.linear_fwd(x, wp, bp, 0)
+        ctx.lin, ctx.N = lin, N
+        ctx.save_for_backward(x, wp, y)
+        return y[:, :N]
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, wp, y = ctx.saved_tensors
+        lin, N = ctx.lin, ctx.N
+        dyp = torch.zeros_like(y)
+        dyp[:, :N].copy_(dy)
+        dwp = torch.zeros_like(wp) if lin.weight.requires_grad else None
+        dbp = torch.zeros(wp.shape[0], device=wp.device) if (lin.bias is not None and lin.bias.requires_grad) else None
+        dx = ops.linear_bwd(x, wp, y, dyp, 0, need_dx=ctx.needs_input_grad[1], dw=dwp, db=dbp)
+        if dwp is not None:
+            grad_ptr(lin.weight)
+            lin.weight.grad.add_(dwp[:N])
+        if dbp is not None:
+            grad_ptr(lin.bias)
+            lin.bias.grad.add_(dbp[:N])
+        return None, dx, None, None
+
+
 def linear(lin, x, act=0):
     require_gpu(x)
+    if lin.weight.shape[0] % 4 and act == 0:
+        return _PaddedLinearFn.apply(lin, x.contiguous(), lin.weight, lin.bias)
     return _LinearFn.apply(lin, act, x.contiguous(), lin.weight, lin.bias)
 
 
@@ -154,6 +194,73 @@ class SoftDotAttention(nn.Module):
         require_gpu(h, context)
         return _SoftDotFn.apply(self, h.contiguous(), context.contiguous(), mask,
                                 self.linear_in.weight, self.linear_out.weight)
+
+
+class _TextAttnFn(torch.autograd.Function):
+    """The attention core of ContextOnlySoftDotAttention (model.py:166-177): t = linear_in(h) -> (weighted context,
+    attn)."""
+
+    @staticmethod
+    def forward(ctx, t, context, mask):
+        B, L, H = context.shape
+        alpha = torch.empty(B, L, device=t.device, dtype=torch.float32)
+        wc = torch.empty(B, H, device=t.device, dtype=torch.float32)
+        call('sf_text_attention_fwd', ptr(context), ptr(mask), B, L, H, ptr(t), H, ptr(alpha), ptr(wc), H, stream())
+        ctx.save_for_backward(t, context, alpha)
+        ctx.mark_non_differentiable(alpha)
+        return wc, alpha
+
+    @staticmethod
+    def backward(ctx, dwc, _dalpha):
+        t, context, alpha = ctx.saved_tensors
+        B, L, H = context.shape
+        dt = torch.empty_like(t)
+        dctx = torch.zeros_like(context) if ctx.needs_input_grad[1] else None
+        call('sf_text_attention_bwd', ptr(context), B, L, H, ptr(dwc.contiguous()), H, ptr(t), H, ptr(alpha), ptr(dt), H,
+             ptr(dctx), stream())
+        return dt, dctx, None
+
+
+class ContextOnlySoftDotAttention(nn.Module):
+    """model.py:146-177: like SoftDotAttention without the concatenation / tanh: forward(h, context, mask=None) ->
+    (weighted_context, attn)."""
+
+    def __init__(self, dim, context_dim=None):
+        super().__init__()
+        self.linear_in = nn.Linear(dim, dim if context_dim is None else context_dim, bias=False)
+
+    def forward(self, h, context, mask=None):
+        require_gpu(h, context)
+        t = linear(self.linear_in, h)                                  # :166
+        return _TextAttnFn.apply(t, context.contiguous(), ops.mask_u8(mask))
+
+
+class _LstmCellFn(torch.autograd.Function):
+    """nn.LSTMCell (model.py:505): (x, h0, c0) -> (h1, c1)."""
+
+    @staticmethod
+    def forward(ctx, cell, x, h0, c0, *params):
+        h1, c1, gates = ops.lstm_cell_fwd(tuple(p.detach() for p in params), x, h0, c0)
+        ctx.cell = cell
+        ctx.save_for_backward(x, h0, c0, c1, gates)
+        return h1, c1
+
+    @staticmethod
+    def backward(ctx, dh1, dc1):
+        x, h0, c0, c1, gates = ctx.saved_tensors
+        cell = ctx.cell
+        ps = (cell.weight_ih, cell.weight_hh, cell.bias_ih, cell.bias_hh)
+        for p in ps:
+            grad_ptr(p)
+        zero = lambda t, like: torch.zeros_like(like) if t is None else t.contiguous()   # noqa: E731
+        dx, dh0, dc0 = ops.lstm_cell_bwd(tuple(p.detach() for p in ps), tuple(p.grad if p.requires_grad else None for p in ps),
+                                         x, h0, c0, c1, gates, zero(dh1, h0), zero(dc1, c0), need_dx=True)
+        return (None, dx, dh0, dc0) + (None,) * 4
+
+
+def lstm_cell(cell, x, h0, c0):
+    return _LstmCellFn.apply(cell, x.contiguous(), h0.contiguous(), c0.contiguous(), cell.weight_ih, cell.weight_hh,
+                             cell.bias_ih, cell.bias_hh)
 
 
 # ------------------------------------------------------------------------------------------------
@@ -743,9 +850,6 @@ class SpeakerDecoderLSTM(nn.Module):
     def __init__(self, vocab_size, vocab_embedding_size, hidden_size, dropout_ratio, glove=None,
                  use_input_att_feed=False):
         super().__init__()
-        if use_input_att_feed:
-            raise NotImplementedError('use_input_att_feed is not on the HIP path '
-                                      '(no reference script enables it)')
         self.vocab_size = vocab_size
         self.vocab_embedding_size = vocab_embedding_size
         self.hidden_size = hidden_size
@@ -756,9 +860,19 @@ class SpeakerDecoderLSTM(nn.Module):
             self.embedding.weight.data[...] = torch.from_numpy(glove)
             self.embedding.weight.requires_grad = False
         self.drop = nn.Dropout(p=dropout_ratio)
-        self.use_input_att_feed = False
-        self.lstm = nn.LSTMCell(vocab_embedding_size, hidden_size)
-        self.attention_layer = SoftDotAttention(hidden_size)
+        self.use_input_att_feed = bool(use_input_att_feed)
+        if self.use_input_att_feed:
+            # model.py:475-481 (round 5; no reference script passes the flag): attention over the path context FIRST,
+            # its output fed into the LSTM input.  Module-level path: every step is a composition of C-ABI operators
+            # (Linear, text attention, LSTMCell, dropout) under torch autograd; the engines' fused word loops do not cover
+            # this variant and step through the module (SpeakerEngine.score).
+            print('using input attention feed in SpeakerDecoderLSTM')
+            self.lstm = nn.LSTMCell(vocab_embedding_size + hidden_size, hidden_size)
+            self.attention_layer = ContextOnlySoftDotAttention(hidden_size)
+            self.output_l1 = nn.Linear(hidden_size * 2, hidden_size)
+        else:
+            self.lstm = nn.LSTMCell(vocab_embedding_size, hidden_size)
+            self.attention_layer = SoftDotAttention(hidden_size)
         self.decoder2action = nn.Linear(hidden_size, vocab_size)
         self._drop_state = _DropState(4)
 
@@ -804,8 +918,32 @@ class SpeakerDecoderLSTM(nn.Module):
         row lookup by the previous word."""
         return xw_table(self, self.embedding.weight, self.lstm.weight_ih)
 
+    def _forward_att_feed(self, previous_word, h_0, c_0, ctx, ctx_mask):
+        """model.py:497-513, the use_input_att_feed branch.  Dropout sites 4 s + k of this module's s-th training call."""
+        p, seed, site = self._drop_state.next(self, self.drop.p)
+        drop = (lambda x, k: _DropoutFn.apply(x, p, seed, 4 * site + k)) if p > 0 else (lambda x, k: x)
+        words = previous_word.reshape(-1)
+        B = words.shape[0]
+        emb = torch.empty(B, self.vocab_embedding_size, device=h_0.device, dtype=torch.float32)
+        E = self.vocab_embedding_size
+        call('sf_gather_rows', ptr(self.embedding.weight.detach()), E, ptr(words.to(torch.int32).contiguous()), B, E,
+             ptr(emb), E, stream())                                    # :497-498
+        if not self.use_glove:
+            if self.embedding.weight.requires_grad:
+                raise NotImplementedError('use_input_att_feed with a trainable embedding')
+            emb = drop(emb, 0)                                         # :499-500
+        h_tilde, alpha = self.attention_layer(drop(h_0, 1), ctx, ctx_mask)        # :502-503
+        concat_input = torch.cat((emb, drop(h_tilde, 2)), 1)           # :504
+        h_1, c_1 = lstm_cell(self.lstm, concat_input, h_0, c_0)        # :505
+        x = drop(torch.cat((h_1, h_tilde), 1), 3)                      # :506-507
+        x = linear(self.output_l1, x, act=1)                           # :508-509
+        logit = linear(self.decoder2action, x)                         # :510
+        return h_1, c_1, alpha, logit
+
     def forward(self, previous_word, h_0, c_0, ctx, ctx_mask=None):
         require_gpu(previous_word, h_0, c_0, ctx)
+        if self.use_input_att_feed:
+            return self._forward_att_feed(previous_word, h_0, c_0, ctx, ctx_mask)
         cfg = self._drop_state.next(self, self.drop.p)
         words = previous_word.reshape(-1).contiguous()                 # model.py:497-498
         return _SpeakerDecoderFn.apply(self, cfg, not trainable_embedding(self), words, h_0.contiguous(), c_0.contiguous(),

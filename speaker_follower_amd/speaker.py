@@ -76,6 +76,31 @@ class _SpeakerLossFn(torch.autograd.Function):
 _DEC_TAPE = ('emb', 'gates', 'c1', 'h1', 'cat2', 't_text', 'alpha', 'h_tilde', 'logit')
 
 
+class _StepNllFn(torch.autograd.Function):
+    """One word step's glue (speaker.py:163-191) for the module-stepped path: picks the next word, records score / NLL /
+    liveness, returns the step's mean NLL over the non-PAD targets (0 when there is none); backward = gscale (softmax - onehot)."""
+
+    @staticmethod
+    def forward(ctx, logit, target, feedback, ended, w_next, score, smp):
+        B, vocab = logit.shape
+        nll, live = torch.empty(B, device=logit.device), torch.empty(B, device=logit.device)
+        call('sf_speaker_glue_fwd', B, vocab, vocab, ptr(logit), ptr(target), feedback, PAD, EOS, ptr(ended), ptr(w_next),
+             ptr(score), ptr(nll), ptr(live), smp, stream())
+        n = live.sum()
+        inv = torch.where(n > 0, 1.0 / n.clamp(min=1.0), torch.zeros_like(n))
+        ctx.save_for_backward(logit, target, inv)
+        return nll.sum() * inv
+
+    @staticmethod
+    def backward(ctx, dloss):
+        logit, target, inv = ctx.saved_tensors
+        B, vocab = logit.shape
+        dlogit = torch.empty_like(logit)
+        gs = (dloss * inv).reshape(1).to(torch.float32).contiguous()
+        call('sf_speaker_glue_bwd', B, vocab, vocab, ptr(logit), ptr(target), PAD, ptr(gs), ptr(dlogit), stream())
+        return dlogit, None, None, None, None, None, None
+
+
 class SpeakerEngine:
     def __init__(self, encoder, decoder, store, group=None):
         self.encoder, self.decoder, self.store = encoder, decoder, store
@@ -136,9 +161,70 @@ class SpeakerEngine:
         st.capture_stream = side
         return replay, st
 
+    def _score_modules(self, batch, steps, feedback, train):
+        """speaker.py:123-202 stepped through the MODULES' own forward (torch autograd over C-ABI operators): the path
+        for decoder variants the fused word loops do not cover (`use_input_att_feed`, model.py:500-513).  One launch
+        sequence per word, one host sync at the end; slower than the fused paths by design."""
+        enc, dec, store = self.encoder, self.decoder, self.store
+        dev = store.device
+        B, S = batch.batch_size, steps
+        Tp = batch.vp.shape[0]
+        F = store.F
+        training = dec.training if train is None else train
+        was = (enc.training, dec.training)
+        enc.train(training)
+        dec.train(training)
+        try:
+            st = SpeakerState()
+            st.batch, st.steps, st.feedback = batch, S, FEEDBACK[feedback]
+            st.teacher_path = st.persistent = False
+            st.site0 = self.site_next
+            st.site_stride = max(256, S + 2, Tp + 2)
+            self.site_next += st.site_stride
+            self.iteration += 1
+            # dense inputs of the module API: action embeddings [Tp] x [B,F], panoramas [Tp] x [B,V,F] (zero on padded steps)
+            act = torch.empty(Tp, B, F, device=dev)
+            call('sf_gather_path_actions', ptr(store.table), store.V, store.IMG, store.LOC, ptr(batch.vp), ptr(batch.act_view),
+                 ptr(batch.act_sincos), ptr(batch.act), Tp * B, ptr(act), F, stream())
+            live_step = (batch.vp >= 0)
+            feats = [store.gather_panorama(batch.vp[t].clamp(min=0), batch.view[t]) * live_step[t].view(B, 1, 1).float()
+                     for t in range(Tp)]
+            ctx, h, c = enc([act[t] for t in range(Tp)], feats)
+            st.ctx = ctx
+            mask = batch.path_mask
+            st.words = torch.empty(S + 1, B, dtype=torch.int64, device=dev)
+            st.words[0] = BOS
+            st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
+            st.step_scores = torch.zeros(S, B, device=dev)
+            targets = batch.instr_seq[:, :S].t().contiguous()
+            seed = (self.dropout_seed if self.dropout_seed is not None else torch.initial_seed()) & 0xFFFFFFFF
+            logits, terms, all_ended = [], [], []
+            for t in range(S):
+                h, c, alpha, logit = dec(st.words[t].view(-1, 1), h, c, ctx, mask)
+                smp = byref(_lib.Sample((seed ^ 0x3C6EF372) & 0xFFFFFFFF, st.site0 + t, batch.row0)) if st.feedback == 2 else None
+                terms.append(_StepNllFn.apply(logit.contiguous(), targets[t], st.feedback, st.ended, st.words[t + 1],
+                                              st.step_scores[t], smp))
+                all_ended.append(st.ended.min().to(torch.float32))       # 1 once every row has produced EOS
+                logits.append(logit.detach())
+            # the reference leaves its loop behind the first step at which every row has ended (speaker.py:196-197): the
+            # steps up to and INCLUDING that one count (no host sync: the cut is a device-side weight vector)
+            done = torch.stack(all_ended)
+            keep = ((torch.cumsum(done, 0) - done) == 0).to(torch.float32)
+            loss = (torch.stack(terms) * keep).sum()
+            st.logits = torch.stack(logits)
+            st.h, st.c = h, c
+            st.loss = loss
+            st.loss_buf = loss.detach().reshape(1)
+            return st
+        finally:
+            enc.train(was[0])
+            dec.train(was[1])
+
     def score(self, batch, steps, feedback='teacher', train=None):
         """Returns a SpeakerState: .words [S,B], .logits [S,B,vocab], .step_scores [S,B],
         .loss (differentiable), .ctx [B,Tp,H]."""
+        if getattr(self.decoder, 'use_input_att_feed', False):
+            return self._score_modules(batch, steps, feedback, train)
         enc, dec, store = self.encoder, self.decoder, self.store
         dev = store.device
         B, S = batch.batch_size, steps

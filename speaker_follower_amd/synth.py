@@ -174,6 +174,26 @@ def speaker_weights(seed, dims=FULL):
     return enc, dec
 
 
+def speaker_decoder_att_feed_weights(seed, dims=FULL):
+    """State of SpeakerDecoderLSTM(use_input_att_feed=True) (model.py:475-485): LSTMCell(E + H -> H),
+    ContextOnlySoftDotAttention.linear_in, output_l1 (2H -> H), decoder2action; gains as in `speaker_weights_peaky`."""
+    rng = np.random.default_rng([seed, 0xA77F])
+    H, E, V = dims.hidden, dims.word, dims.vocab
+    kh = 1.0 / np.sqrt(H)
+    dec = OrderedDict()
+    dec['embedding.weight'] = (rng.standard_normal((V, E)) * 0.4).astype(np.float32)
+    dec['lstm.weight_ih'] = (_uniform(rng, (4 * H, E + H), kh) * np.float32(2.0)).astype(np.float32)
+    dec['lstm.weight_hh'] = (_uniform(rng, (4 * H, H), kh) * np.float32(2.0)).astype(np.float32)
+    dec['lstm.bias_ih'] = _uniform(rng, (4 * H,), kh)
+    dec['lstm.bias_hh'] = _uniform(rng, (4 * H,), kh)
+    dec['attention_layer.linear_in.weight'] = (_uniform(rng, (H, H), kh) * np.float32(20.0)).astype(np.float32)
+    dec['output_l1.weight'] = (_uniform(rng, (H, 2 * H), 1.0 / np.sqrt(2 * H)) * np.float32(3.0)).astype(np.float32)
+    dec['output_l1.bias'] = _uniform(rng, (H,), 1.0 / np.sqrt(2 * H))
+    dec['decoder2action.weight'] = (_uniform(rng, (V, H), kh) * np.float32(20.0)).astype(np.float32)
+    dec['decoder2action.bias'] = _uniform(rng, (V,), kh)
+    return dec
+
+
 def feature_table(seed, n_viewpoints, dims=FULL):
     """[n_viewpoints, views, img] fp32, ResNet-pool5-like: 0.5*N(0,1) clipped at 0."""
     rng = np.random.default_rng([seed, 0x7AB1E])

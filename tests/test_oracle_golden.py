@@ -376,3 +376,18 @@ def test_eval_restatement_reproduces_the_reference_evaluation():
     for k in ('success_rate', 'oracle_rate', 'nav_error', 'oracle_error', 'steps', 'lengths'):
         np.testing.assert_allclose(summary[k], gold['summary'][k], rtol=1e-9)
     assert summary['success_rate'] == 10 / 156
+
+
+def test_speaker_decoder_input_att_feed_oracle_vs_reference(golden):
+    """G14: SpeakerDecoderLSTM(use_input_att_feed=True) of the reference (model.py:500-513), three chained word steps;
+    oracle/np_model.speaker_decoder_step_att_feed restates it."""
+    from speaker_follower_amd import synth
+    g = golden('g14_speaker_att_feed')
+    dec = synth.speaker_decoder_att_feed_weights(int(g['weight_seed']))
+    h, c = g['h0'], g['c0']
+    for t in range(3):
+        h, c, alpha, logit = np_model.speaker_decoder_step_att_feed(dec, g['words'][t], h, c, g['ctx'], g['mask'])
+        np.testing.assert_allclose(h, g['h1_%d' % t], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(c, g['c1_%d' % t], rtol=1e-4, atol=1e-5)
+        np.testing.assert_allclose(alpha, g['alpha_%d' % t], rtol=1e-4, atol=1e-6)
+        np.testing.assert_allclose(logit, g['logit_%d' % t], rtol=1e-4, atol=1e-4)
