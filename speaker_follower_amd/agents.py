@@ -19,6 +19,7 @@ import torch
 
 from . import _lib
 from ._lib import call
+from .lazydict import LazyDict
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .runtime import ptr, stream, require_gpu, cands_dense, PersistentLaunchFault, gc_paused
 
@@ -438,6 +439,25 @@ class _SpeakerGlueFn(torch.autograd.Function):
         return dl[:, :V] * dnll.reshape(B, 1), None, None, None, None, None, None
 
 
+class _ScoredInstruction(LazyDict):
+    """One output of Seq2SeqSpeaker._score_obs_actions_and_instructions (speaker.py:139-141, 198-202): 'instr_id' and
+    'score' are there; 'word_indices', 'scores' and 'words' are cut from the batch's arrays when somebody reads them
+    (the pragmatic re-ranking reads the score of 2 500 routes and nothing else, rational_follower.py:70-74)."""
+    __slots__ = ('_w', '_s', '_m', '_tok')
+
+    def __init__(self, instr_id, score, words_row, scores_row, m, tok):
+        LazyDict.__init__(self, {'instr_id': instr_id, 'score': score}, ('word_indices', 'scores', 'words'))
+        self._w, self._s, self._m, self._tok = words_row, scores_row, m, tok
+
+    def _make(self, key):
+        if key == 'scores':
+            return self._s[:self._m].tolist()
+        wi = self['word_indices'] if key == 'words' else self._w[:self._m].tolist()
+        if key == 'words' and self._tok is not None:
+            return self._tok.decode_sentence(wi, break_on_eos=True, join=False)
+        return wi
+
+
 class _PendingScores:
     """A chunked scoring sweep that has been issued and not collected yet (Seq2SeqSpeaker._issue_scores)."""
     obs_lists = None
@@ -524,7 +544,8 @@ class Seq2SeqSpeaker(object):
         mark = (lambda name: marks.append((name, time.perf_counter()))) if marks is not None else (lambda name: None)
         mark('start')
         B = len(path_obs)
-        instr_ids = [obs[0]['instr_id'] for obs in path_obs]
+        # (a search's RouteObservations knows its instruction without building its dictionaries)
+        instr_ids = [obs.instr_id if hasattr(obs, 'instr_id') else obs[0]['instr_id'] for obs in path_obs]
         pend = self.__dict__.pop('_pending_scores', None)
         if pend is not None:
             if pend.matches(path_obs, feedback) and not torch.is_grad_enabled():   # issued by the search itself: collect
@@ -667,13 +688,9 @@ class Seq2SeqSpeaker(object):
             loss = torch.tensor(float(total), device=device)
         totals = np.cumsum(sc, axis=1, dtype=np.float32)                   # (sequential float32 partial sums)
         tok = getattr(self.env, 'tokenizer', None)
-        outputs = []
-        for i in range(B):
-            m = int(m_all[i])
-            wi = words[i, :m].tolist()
-            outputs.append({'instr_id': instr_ids[i], 'word_indices': wi, 'scores': sc[i, :m].tolist(),
-                            'score': float(totals[i, m - 1]),
-                            'words': tok.decode_sentence(wi, break_on_eos=True, join=False) if tok is not None else wi})
+        ends = m_all.tolist()
+        last = totals[np.arange(B), m_all - 1].tolist()
+        outputs = [_ScoredInstruction(instr_ids[i], last[i], words[i], sc[i], ends[i], tok) for i in range(B)]
         mark('outputs')
         return outputs, loss
 

@@ -129,6 +129,26 @@ def panorama_sweep(sim):
     return st.viewIndex, [stop] + sorted(adj.values(), key=lambda x: abs(x['rel_heading']))
 
 
+def snapped_view(heading, elevation=0.0):
+    """The view index the simulator snaps a continuous pose to (MatterSim.cpp:339-367 with discretized viewing angles:
+    heading to the nearest of 12 steps of 30 degrees, halves away from zero; elevation to -30 / 0 / +30 degrees), as
+    sim/mattersim_nav.cpp's setHeadingElevation does -- without a simulator call (tests/test_env.py checks the two)."""
+    h = math.fmod(heading, 2.0 * math.pi)
+    while h < 0.0:
+        h += 2.0 * math.pi
+    x = h / (2.0 * math.pi / 12)
+    step = int(x)
+    if x - step >= 0.5:                                              # lround
+        step += 1
+    if step == 12:
+        step = 0
+    if elevation < -ANGLE_INC / 2.0:
+        return step
+    if elevation > ANGLE_INC / 2.0:
+        return step + 24
+    return step + 12
+
+
 class R2RIndexEnv:
     """R2RBatch (env.py:664-854) over index-form observations.
 
@@ -188,8 +208,7 @@ class R2RIndexEnv:
 
     def start_view(self, ws):
         """The discrete view index newEpisode snaps a pose to (env.py:814-819), without the panorama sweep."""
-        self.sim.newEpisode(ws.scanId, ws.viewpointId, ws.heading, ws.elevation)
-        return self.sim.getState().viewIndex
+        return snapped_view(ws.heading, ws.elevation)
 
     # ---- cached panorama sweep
     def panorama(self, ws):

@@ -21,12 +21,17 @@ repository's own form:
     indexing from the host copies of the same tables the device holds.
 
 Observation dictionaries (the reference's result format carries them: rational_follower.py:79-82 feeds them to
-the speaker) are materialised once per distinct state of the RETURNED candidates only.
+the speaker) are materialised once per distinct state, and only when a caller READS them: a result dictionary
+is a `Candidate` whose 'observations' / 'trajectory' are built on first access (the speaker scores the routes in
+index form: `_trajectories`' hook).
 """
+from collections.abc import Sequence
+
 import numpy as np
 import torch
 
 from .env import ANGLE_INC, WorldState
+from .lazydict import LazyDict
 from .runtime import gc_paused as _gc_paused
 
 V = 36
@@ -129,43 +134,27 @@ class StateSpace:
         k = (int(inst), int(sid), bool(start_pose))
         ob = self._obs.get(k)
         if ob is None:
-            ws = self.world_state(*k)
-            pk = (ws.scanId, ws.viewpointId, k[1] % V)
-            if pk not in self.env._pano:                           # the candidate list from the tables, not a sweep
-                self.env._pano[pk] = (k[1] % V, self.nav.adj_loc_list(k[1]))
-            ob = self.env._observe_one(ws, self.items[k[0]], False, self.env.host_table is not None, view=k[1] % V)
-            self._obs[k] = ob
+            ob = self._obs[k] = self._build(k)
         return ob
 
-    def observations(self, inst, sid, start_pose):
-        """`observation` for arrays of any shape: an object array of the same shape, every distinct state built once."""
-        code = (inst * (self.nav.n_rows * V) + sid) * 2 + start_pose
-        uniq, first, inv = np.unique(code.reshape(-1), return_index=True, return_inverse=True)
-        fi, fs, fp = (x.reshape(-1)[first].tolist() for x in (inst, sid, start_pose))
-        objs = np.empty(len(uniq), object)
-        env, nav, items, cache, pano = self.env, self.nav, self.items, self._obs, self.env._pano
-        plain = env.host_table is None                              # index-form observations: the dictionary is built inline
-        for j, k in enumerate(zip(fi, fs, fp)):
-            ob = cache.get(k)
-            if ob is None and plain:
-                b, s, sp = k
-                it = items[b]
-                view = s % V
-                scan = it['scan']
-                if sp:
-                    vp, heading, elevation = it['path'][0], it['heading'], 0
-                else:
-                    vp, heading, elevation = nav.vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC
-                hit = pano.get((scan, vp, view))
-                if hit is None:                                     # the candidate list from the tables, not a sweep
-                    hit = pano[(scan, vp, view)] = (view, nav.adj_loc_list(s))
-                ob = cache[k] = dict(instr_id=it['instr_id'], scan=scan, viewpoint=vp, viewIndex=view, heading=heading,
-                                     elevation=elevation, adj_loc_list=hit[1], vp_row=env.row_of[scan + '_' + vp],
-                                     instr_encoding=it['instr_encoding'], instructions=it.get('instructions', ''))
-            elif ob is None:
-                ob = self.observation(*k)
-            objs[j] = ob
-        return objs[inv].reshape(code.shape)
+    def _build(self, k):
+        env, nav = self.env, self.nav
+        b, s, sp = k
+        it = self.items[b]
+        view = s % V
+        scan = it['scan']
+        if sp:
+            vp, heading, elevation = it['path'][0], it['heading'], 0
+        else:
+            vp, heading, elevation = nav.vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC
+        hit = env._pano.get((scan, vp, view))
+        if hit is None:                                             # the candidate list from the tables, not a sweep
+            hit = env._pano[(scan, vp, view)] = (view, nav.adj_loc_list(s))
+        if env.host_table is None:                                  # index-form observations: the dictionary is built inline
+            return dict(instr_id=it['instr_id'], scan=scan, viewpoint=vp, viewIndex=view, heading=heading,
+                        elevation=elevation, adj_loc_list=hit[1], vp_row=env.row_of[scan + '_' + vp],
+                        instr_encoding=it['instr_encoding'], instructions=it.get('instructions', ''))
+        return env._observe_one(WorldState(scan, vp, heading, elevation), it, False, True, view=view)
 
 
 class Hyp:
@@ -244,12 +233,91 @@ def _lineage_matrix(t, nodes, depth):
     return L, (L >= 0).sum(1)
 
 
+class _Routes:
+    """What the result dictionaries of one search are made from, kept so that their expensive fields -- the observation
+    dictionaries and the pose tuples of every route -- are built when somebody reads them (rational_follower.py:67-69
+    hands the observation lists to the speaker, which scores them in index form, and then deletes them; only the 64
+    chosen routes of ~2 500 ever show their trajectory)."""
+
+    def __init__(self, t, space, L, ln):
+        self.space = space
+        self.inst, self.sid, self.start = t.inst[L], t.sid[L], t.start_pose[L]      # (copies: [routes, depth + 1])
+        self.lens = ln.tolist()
+        self._obs = [None] * len(self.lens)
+
+    def states(self, i):
+        m = self.lens[i]
+        return zip(self.inst[i, :m].tolist(), self.sid[i, :m].tolist(), self.start[i, :m].tolist())
+
+    def observations(self, i):
+        obs = self._obs[i]
+        if obs is None:
+            one = self.space.observation
+            obs = self._obs[i] = [one(b, s, p) for b, s, p in self.states(i)]
+        return obs
+
+    def trajectory(self, i):
+        """(viewpoint, heading, elevation) per state (follower.py:700): the pose fields of `observations`, without them."""
+        items, vp_of, out = self.space.items, self.space.nav.vp_of, []
+        for b, s, p in self.states(i):
+            if p:
+                it = items[b]
+                out.append((it['path'][0], it['heading'], 0))
+            else:
+                view = s % V
+                out.append((vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC))
+        return out
+
+
+class RouteObservations(Sequence):
+    """The observation list of one candidate route: a read-only sequence whose dictionaries are built on first access."""
+    __slots__ = ('_routes', '_i')
+
+    def __init__(self, routes, i):
+        self._routes, self._i = routes, i
+
+    def __len__(self):
+        return self._routes.lens[self._i]
+
+    def __getitem__(self, k):
+        return self._routes.observations(self._i)[k]
+
+    def __iter__(self):
+        return iter(self._routes.observations(self._i))
+
+    def __eq__(self, other):
+        return list(self) == list(other) if isinstance(other, (list, tuple, RouteObservations)) else NotImplemented
+
+    def __repr__(self):
+        return 'RouteObservations(%d states)' % len(self)
+
+    def __reduce__(self):                      # (pickled / deep-copied as the plain list it stands for)
+        return list, (list(self),)
+
+    @property
+    def instr_id(self):
+        return self._routes.space.items[int(self._routes.inst[self._i, 0])]['instr_id']
+
+
+class Candidate(LazyDict):
+    """One result dictionary (follower.py:694-716 / 953-975).  'trajectory' and 'observations' are made when first read
+    ('observations' as a RouteObservations); every way of reading that a plain dict offers sees them."""
+    __slots__ = ('_routes', '_i')
+
+    def __init__(self, routes, i, fields):
+        LazyDict.__init__(self, fields, ('trajectory', 'observations'))
+        self._routes, self._i = routes, i
+
+    def _make(self, key):
+        return self._routes.trajectory(self._i) if key == 'trajectory' else RouteObservations(self._routes, self._i)
+
+
 def _trajectories(fd, t, space, completed_lists, depth, hook=None, fp32_steps=False):
     """Result dictionaries (follower.py:694-716 / 953-975) of the final hypotheses of every instance.
     `hook(n, rows, instructions)` (Seq2SeqSpeaker.route_scores_hook): called with the routes in index form -- per
     route its number of steps, per step (feature row, view index, the action's view, rel_heading, rel_elevation,
     is_stop), per route its instruction -- once the device is idle and BEFORE the dictionaries are built; what it
-    returns is called with the routes' observation lists when they exist."""
+    returns is called with the routes' observation lists (RouteObservations: nothing is built for that)."""
     flat = np.array([n for lst in completed_lists for n in lst], np.int64)
     L, ln = _lineage_matrix(t, flat, depth)
     # root first: column j of every row = the j-th hypothesis of the path (columns >= its length: junk, sliced off)
@@ -274,34 +342,27 @@ def _trajectories(fd, t, space, completed_lists, depth, hook=None, fp32_steps=Fa
                          (~move).astype(np.float64)), axis=1).astype(np.float64)
         items = space.items
         bind = hook(ln - 1, rows, [items[b]['instr_encoding'] for b in t.inst[L[:, 0]].tolist()])
-    all_obs = space.observations(t.inst[L], t.sid[L], t.start_pose[L])
-    pose = np.empty(L.shape, object)
-    uniq = {}
-    flat_obs, flat_pose = all_obs.reshape(-1), pose.reshape(-1)
-    for j, ob in enumerate(flat_obs.tolist()):                      # (viewpoint, heading, elevation), one tuple per state
-        p = uniq.get(id(ob))
-        if p is None:
-            p = uniq[id(ob)] = (ob['viewpoint'], ob['heading'], ob['elevation'])
-        flat_pose[j] = p
+    routes = _Routes(t, space, L, ln)
     # per-action scores = differences of the cumulative ones: the reference's beam search holds them as Python floats
     # (follower.py:636: float64 differences of fp32-rounded sums), its state-factored search as fp32 tensors
     # (follower.py:851, :46: the difference is rounded to fp32)
     step_sc = (t.score[L][:, 1:] - t.score[L][:, :-1]).astype(np.float64) if fp32_steps else sc[:, 1:] - sc[:, :-1]
     # (whole matrices to nested Python lists ONCE; a candidate's fields are then plain list slices)
-    obs_l, pose_l, act_l, step_l, att_l = all_obs.tolist(), pose.tolist(), act.tolist(), step_sc.tolist(), att.tolist()
+    act_l, step_l, att_l = act.tolist(), step_sc.tolist(), att.tolist()
     last_sc = sc[np.arange(len(flat)), ln - 1].tolist()
-    lens = ln.tolist()
+    lens = routes.lens
+    items = space.items
+    inst0 = t.inst[L[:, 0]].tolist()
     out, i = [], 0
     for lst in completed_lists:
         assert lst
         cands = []
         for _ in lst:
             m = lens[i]
-            obs = obs_l[i][:m]
-            cands.append({
-                'instr_id': obs[0]['instr_id'], 'instr_encoding': obs[0]['instr_encoding'],
-                'trajectory': pose_l[i][:m], 'observations': obs, 'actions': act_l[i][1:m],
-                'score': last_sc[i], 'scores': step_l[i][:m - 1], 'attentions': att_l[i][1:m]})
+            it = items[inst0[i]]
+            cands.append(Candidate(routes, i, {
+                'instr_id': it['instr_id'], 'instr_encoding': it['instr_encoding'], 'actions': act_l[i][1:m],
+                'score': last_sc[i], 'scores': step_l[i][:m - 1], 'attentions': att_l[i][1:m]}))
             i += 1
         out.append(cands)
     if bind is not None:
@@ -509,7 +570,7 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
     trajs = _trajectories(fd, t, space, completed, agent.episode_len, getattr(agent, 'candidates_hook', None),
                           fp32_steps=True)
     mark('results')
-    traversed = [HypList(t, space, w) for w in physical_walks(t, visits, agent.episode_len)]
+    traversed = _Walks(t, space, visits, agent.episode_len)
     mark('walks')
     return trajs, [HypList(t, space, lst) for lst in completed], traversed
 
@@ -621,6 +682,29 @@ def _state_factored_search_numpy(agent, completion_size, successor_size, load_ne
     traversed = [HypList(t, space, w) for w in physical_walks(t, visits, episode_len)]
     return (_trajectories(fd, t, space, completed, episode_len, fp32_steps=True),
             [HypList(t, space, lst) for lst in completed], traversed)
+
+
+class _Walks(Sequence):
+    """The physical traversal of every instance (a list of HypList), worked out when first read: only
+    `physical_traversal=True` (rational_follower.py:87-96) looks at it."""
+
+    def __init__(self, t, space, visits, depth):
+        self._args, self._lists = (t, space, visits, depth), None
+
+    def _get(self):
+        if self._lists is None:
+            t, space, visits, depth = self._args
+            self._lists = [HypList(t, space, w) for w in physical_walks(t, visits, depth)]
+        return self._lists
+
+    def __len__(self):
+        return len(self._args[2])
+
+    def __getitem__(self, i):
+        return self._get()[i]
+
+    def __iter__(self):
+        return iter(self._get())
 
 
 def physical_walks(t, visits, depth):

@@ -50,6 +50,23 @@ def test_panorama_sweep_finds_exactly_the_graph_neighbours(envmod, setup):
                     assert -math.pi <= a['rel_heading'] <= math.pi
 
 
+def test_snapped_view_is_the_simulators_own_snapping(setup, envmod):
+    """env.snapped_view (what the searches' start states use) against newEpisode + getState of the simulator: random poses,
+    negative and multi-turn headings, and the exact half-way headings between two views (lround: away from zero)."""
+    e = setup['env'] if isinstance(setup, dict) else setup[0]
+    item = e.data[0]
+    scan, vp = item['scan'], item['path'][0]
+    rng = np.random.RandomState(3)
+    headings = list(rng.uniform(-15.0, 15.0, 400)) + [k * math.pi / 12 for k in range(-30, 31)] + [0.0, 2 * math.pi, -2 * math.pi]
+    elevations = [0.0, -0.6, 0.6, -math.pi / 12, math.pi / 12, 0.2617, -0.2619]
+    n = 0
+    for hd in headings:
+        for el in (elevations if n % 7 == 0 else [0.0]):
+            e.sim.newEpisode(scan, vp, hd, el)
+            assert envmod.snapped_view(hd, el) == e.sim.getState().viewIndex, (hd, el)
+        n += 1
+
+
 def test_panorama_cache_hits(setup, envmod):
     e, graphs, _ = setup
     scan = SCANS[0]

@@ -5,6 +5,7 @@ import sys
 from collections import namedtuple
 
 import numpy as np
+import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
@@ -273,3 +274,51 @@ def test_rational_speaker_reranking_matches_reference():
         for k, best in res[w].items():
             got = next(i for i, c in enumerate(by_id[k]) if c is best)
             assert got == gold['chosen']['%.2f' % w][k], (w, k)
+
+
+def test_result_dictionaries_build_their_expensive_fields_on_demand():
+    """frontier.Candidate: a search result (follower.py:694-716) whose 'observations' / 'trajectory' are made when read;
+    every dict operation the reference's callers use (rational_follower.py:67-96: item reads, `del`, `in`, json.dump)
+    must behave like the plain dictionary."""
+    import copy
+    import json
+    import pickle
+    from speaker_follower_amd import frontier
+
+    built = []
+
+    class Routes:
+        lens = [3]
+        inst = np.zeros((1, 4), np.int64)
+
+        class space:
+            items = [{'instr_id': '7_0'}]
+
+        def trajectory(self, i):
+            built.append('trajectory')
+            return [('a', 0.0, 0.0), ('b', 0.5, 0.0), ('c', 1.0, 0.0)]
+
+        def observations(self, i):
+            built.append('observations')
+            return [{'viewpoint': v} for v in 'abc']
+
+    plain = {'instr_id': '7_0', 'score': 1.0, 'trajectory': Routes().trajectory(0), 'observations': Routes().observations(0)}
+    built.clear()
+    c = frontier.Candidate(Routes(), 0, {'instr_id': '7_0', 'score': 1.0})
+    assert 'observations' in c and 'trajectory' in c and c['score'] == 1.0 and not built
+    obs = c['observations']
+    assert obs is c['observations'] and len(obs) == 3 and obs.instr_id == '7_0' and not built     # still nothing built
+    assert obs[-1]['viewpoint'] == 'c' and [o['viewpoint'] for o in obs[:-1]] == ['a', 'b'] and 'trajectory' not in built
+    assert c == plain and plain == dict(c) and sorted(c) == sorted(plain) and len(c) == 4
+    assert isinstance(pickle.loads(pickle.dumps(c))['observations'], list) and copy.deepcopy(c) == plain
+    del c['observations']
+    assert 'observations' not in c and c.get('observations') is None
+    with pytest.raises(KeyError):
+        c['observations']
+    assert json.loads(json.dumps(c))['trajectory'][1] == ['b', 0.5, 0.0]
+    # deleting a field nobody read builds nothing
+    built.clear()
+    d = frontier.Candidate(Routes(), 0, {'instr_id': '7_0'})
+    del d['observations']
+    d['trajectory'] = ['walked']
+    assert dict(d) == {'instr_id': '7_0', 'trajectory': ['walked']} and not built
