@@ -719,6 +719,19 @@ int sf_scatter_rows(const float* src, int ld_src, const int32_t* idx, int n, int
 /* Small utilities used by the host mirror (kept on the stream so rollouts never sync). */
 int sf_fill_f32(float* p, size_t n, float v, sf_stream stream);
 int sf_add_f32(float* dst, const float* src, size_t n, sf_stream stream); /* dst += src */
+/* Up to SF_FILL_MAX_REGIONS buffers set to a constant each in ONE launch: the initial conditions of a pass -- zero
+ * states (model.py:67-79 init_state, :368 u_begin), the <BOS> word of every row (speaker.py:137), cleared `ended`
+ * flags (follower.py:380, speaker.py:136) -- which a host mirror would otherwise issue as one fill per tensor.
+ * `count` elements of `width` bytes (1, 4 or 8; ptr aligned to it) are set to the low `width` bytes of `value`
+ * (a float travels as its bit pattern).  Regions with count 0 are skipped. */
+#define SF_FILL_MAX_REGIONS 8
+typedef struct sf_fill_region {
+    void* ptr;
+    uint64_t count;
+    uint64_t value;
+    int32_t width;
+} sf_fill_region;
+int sf_fill_regions(const sf_fill_region* regions, int n, sf_stream stream);
 /* dst[b, :N] (row stride ldd) = dropout(src[b, :N]) at site `drop_stream`, columns col0.. */
 int sf_dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd,
                     const sf_dropout* drop, uint32_t drop_stream, int col0, sf_stream stream);

@@ -113,6 +113,11 @@ class Sample(C.Structure):
     _fields_ = [('seed', C.c_uint32), ('stream', C.c_uint32), ('row0', C.c_int32), ('stream_dev', c_p)]
 
 
+class FillRegion(C.Structure):
+    """sf_fill_region."""
+    _fields_ = [('ptr', c_p), ('count', C.c_uint64), ('value', C.c_uint64), ('width', C.c_int32)]
+
+
 class NavTableS(C.Structure):
     _fields_ = [('a_num', c_p), ('next_row', c_p), ('cand_view', c_p), ('cand_sincos', c_p),
                 ('feat_row', c_p), ('A', C.c_int32), ('V', C.c_int32)]
@@ -236,6 +241,7 @@ _SIGNATURES = {
                                          c_f, c_f, P(SpkDecoderTape), c_f, c_f, c_f, c_f, P(Dropout), u32,
                                          P(SpkDecoderGTape), c_f, c_f, c_f] + WS),
     'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
+    'sf_fill_regions': (C.c_int, [c_p, C.c_int, c_p]),
     'sf_add_f32': (C.c_int, [c_f, c_f, C.c_size_t, c_p]),
     'sf_adam_step': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                               C.c_double, C.c_int, c_p]),

@@ -1939,6 +1939,23 @@ int sf_fill_f32(float* p, size_t n, float v, sf_stream stream) {
     return fill(p, n, v, S(stream));
 }
 
+int sf_fill_regions(const sf_fill_region* regions, int n, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(n >= 0 && n <= SF_FILL_MAX_REGIONS && (regions || n == 0));
+    FillRegions fr;
+    fr.n = 0;
+    for (int i = 0; i < n; ++i) {
+        const sf_fill_region& r = regions[i];
+        SF_CHECK_ARG(r.width == 1 || r.width == 4 || r.width == 8);
+        SF_CHECK_ARG(r.ptr || r.count == 0);
+        SF_CHECK_ARG(((uintptr_t)r.ptr & (uintptr_t)(r.width - 1)) == 0);
+        if (r.count == 0) continue;
+        fr.r[fr.n++] = FillRegions::R{r.ptr, (unsigned long long)r.count, (unsigned long long)r.value, r.width};
+    }
+    if (fr.n == 0) return SF_OK;
+    return fill_regions(fr, S(stream));
+}
+
 int sf_add_f32(float* dst, const float* src, size_t n, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG((dst && src) || n == 0);

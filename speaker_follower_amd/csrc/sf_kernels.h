@@ -139,6 +139,11 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr,
 // the same with the 1-based step counter ON THE DEVICE (incremented by the call; coef: 2 floats of scratch)
 int adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
                   double eps, double wd, int* step_dev, float* coef, hipStream_t st);
+struct FillRegions {                      // sf_fill_regions
+    struct R { void* ptr; unsigned long long count, value; int width; } r[8];
+    int n;
+};
+int fill_regions(const FillRegions& fr, hipStream_t st);
 int site_advance(uint32_t* word, uint32_t by, hipStream_t st);      // *word += by (sf_site_advance)
 int store_u32x4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, hipStream_t st);   // sf_store_u32x4
 int transpose(const float* src, int R, int C, float* dst, hipStream_t st);   // dst[C,R] = src^T

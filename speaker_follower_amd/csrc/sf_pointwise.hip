@@ -917,6 +917,26 @@ int store_u32x4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, h
     SF_LAUNCH(store_u32x4_kernel, dim3(1), dim3(64), 0, st, dst, a, b, c, d);
     return launch_status();
 }
+// sf_fill_regions: the initial conditions of a pass (zero states, BOS words, cleared flags) in ONE launch instead of
+// one fill per tensor.  blockIdx.y = region; elements of 1, 4 or 8 bytes.
+__global__ __launch_bounds__(256) void fill_regions_kernel(FillRegions fr) {
+    const FillRegions::R r = fr.r[blockIdx.y];
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const size_t i0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r.width == 4)
+        for (size_t i = i0; i < r.count; i += stride) ((uint32_t*)r.ptr)[i] = (uint32_t)r.value;
+    else if (r.width == 8)
+        for (size_t i = i0; i < r.count; i += stride) ((unsigned long long*)r.ptr)[i] = r.value;
+    else
+        for (size_t i = i0; i < r.count; i += stride) ((unsigned char*)r.ptr)[i] = (unsigned char)r.value;
+}
+int fill_regions(const FillRegions& fr, hipStream_t st) {
+    size_t most = 1;
+    for (int i = 0; i < fr.n; ++i) most = fr.r[i].count > most ? fr.r[i].count : most;
+    const unsigned gx = (unsigned)((most + 256 * 4 - 1) / (256 * 4));
+    SF_LAUNCH(fill_regions_kernel, dim3(gx < 1 ? 1 : (gx > 256 ? 256 : gx), fr.n), dim3(256), 0, st, fr);
+    return launch_status();
+}
 int site_advance(uint32_t* word, uint32_t by, hipStream_t st) {
     SF_LAUNCH(site_advance_kernel, dim3(1), dim3(64), 0, st, word, by);
     return launch_status();

@@ -22,7 +22,7 @@ from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, trainable_embedding)
-from .runtime import ptr, stream, ws_args, dropout_arg, take_fault, PersistentLaunchFault, concurrent_stream
+from .runtime import ptr, stream, ws_args, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream
 from .dp import collectives_on
 
 byref = C.byref
@@ -254,8 +254,10 @@ class FollowerEngine:
         # batched weight-gradient products read hs[0:S] as one [S*B, H] matrix
         st.hs, st.cs = st.hs_all, st.cs_all
         st.tape['h1'], st.tape['c1'] = st.hs[1:], st.cs[1:]
-        call('sf_fill_f32', ptr(st.tape['xin'][0]), B * 2 * F, 0.0, stream())   # u_begin = 0 (model.py:368)
-        st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
+        st.ended = torch.empty(B, dtype=torch.uint8, device=dev)
+        # u_begin = 0 (model.py:368; the feature half of the row is written by the attention), no row has ended
+        # (follower.py:380): one launch
+        fill_regions((st.tape['xin'][0], 0.0), (st.ended, 0))
         st.actions = torch.empty(S, B, dtype=torch.int64, device=dev)
         st.target_used = torch.empty(S, B, dtype=torch.int64, device=dev)
         st.step_scores, st.ce_term, st.live = new(S, B), new(S, B), new(S, B)
@@ -419,7 +421,7 @@ class FollowerEngine:
         if st.differentiable:
             st.loss = _RolloutLossFn.apply(self, st, *st.all_params)
         else:
-            st.loss = st.loss_buf.clone().reshape(())
+            st.loss = st.loss_buf.reshape(())
         return st
 
     def _baked_pointers(self):

@@ -197,6 +197,24 @@ def site_advance(word, by):
     _lib.call('sf_site_advance', C.c_void_p(word.data_ptr()), int(by), stream())
 
 
+def fill_regions(*pairs):
+    """sf_fill_regions: contiguous tensors set to a constant each in one launch -- `fill_regions((hs[0], 0.0), (words[0],
+    BOS), (ended, 0))` instead of one torch fill kernel per tensor.  Up to 8 (tensor, value) pairs."""
+    import struct
+    regs = (_lib.FillRegion * len(pairs))()
+    for r, (x, v) in zip(regs, pairs):
+        assert x.is_contiguous() and x.is_cuda
+        width = x.element_size()
+        if x.dtype == torch.float32:
+            v = struct.unpack('<I', struct.pack('<f', float(v)))[0]
+        elif x.dtype in (torch.int64, torch.int32, torch.uint8, torch.int8, torch.bool):
+            v = int(v) & ((1 << (8 * width)) - 1)
+        else:
+            raise TypeError('fill_regions: %s' % x.dtype)
+        r.ptr, r.count, r.value, r.width = x.data_ptr(), x.numel(), v, width
+    _lib.call('sf_fill_regions', regs, len(pairs), stream())
+
+
 class TrainingGraph:
     """ONE whole training iteration -- zero the gradients, rollout / scoring pass in train mode, backward through
     time, optimizer steps -- as a hipGraph (follower.py:1001-1020, speaker.py:376-395 per replay).

@@ -19,7 +19,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .model import _grads, trainable_embedding
-from .runtime import ptr, stream, ws_args, dropout_arg, struct_of, transposed, take_fault, PersistentLaunchFault
+from .runtime import ptr, stream, ws_args, dropout_arg, fill_regions, struct_of, transposed, take_fault, PersistentLaunchFault
 
 byref = C.byref
 
@@ -266,8 +266,12 @@ class SpeakerEngine:
         vw = _lib.VisualW(*(p_.data_ptr() for p_ in ep[0:4]), transposed(ep[2]).data_ptr(), transposed(ep[0]).data_ptr())
         lw = struct_of(_lib.LstmW, ep[4:8])
         st.e = dict(xin=new(Tp, B, 2 * F), alpha=new(Tp, B, V), t_v=new(Tp, B, D), q=new(Tp, B, F),
-                    gates=new(Tp, B, 4 * H), hs=torch.zeros(Tp + 1, B, H, device=dev),
-                    cs=torch.zeros(Tp + 1, B, H, device=dev))
+                    gates=new(Tp, B, 4 * H), hs=new(Tp + 1, B, H), cs=new(Tp + 1, B, H))
+        st.words = torch.empty(S + 1, B, dtype=torch.int64, device=dev)
+        st.ended = torch.empty(B, dtype=torch.uint8, device=dev)
+        # the initial conditions of the pass in one launch: zero encoder state (model.py:420-427), <BOS> (speaker.py:137),
+        # no row has ended (speaker.py:136)
+        fill_regions((st.e['hs'][0], 0.0), (st.e['cs'][0], 0.0), (st.words[0], BOS), (st.ended, 0))
         d_enc = dropout_arg(*st.drop_enc)
         # the chosen-action embeddings of ALL path steps in one gather ([Tp*B] rows: the index arrays are
         # [Tp,B] contiguous), and -- without dropout -- one strided copy into the LSTM inputs of all steps
@@ -308,9 +312,6 @@ class SpeakerEngine:
         st.tape['h1'] = st.hs_all[1:]
         st.cs_all = new(S + 1, B, H)              # cell states likewise: slot 0 = c_init, slot t + 1 = c1 of step t
         st.tape['c1'] = st.cs_all[1:]
-        st.words = torch.empty(S + 1, B, dtype=torch.int64, device=dev)
-        st.words[0] = BOS                                                  # speaker.py:137
-        st.ended = torch.zeros(B, dtype=torch.uint8, device=dev)
         st.step_scores, st.nll_term, st.live = new(S, B), new(S, B), new(S, B)
         st.sum_cnt, st.gscale, st.loss_buf = new(S, 2), new(S), new(1)
         d_dec = dropout_arg(*st.drop_dec)
@@ -377,7 +378,7 @@ class SpeakerEngine:
         if differentiable:
             st.loss = _SpeakerLossFn.apply(self, st, *params)
         else:
-            st.loss = st.loss_buf.clone().reshape(())
+            st.loss = st.loss_buf.reshape(())
         return st
 
     def capture_training(self, batch, steps, optimizers=(), feedback='teacher'):

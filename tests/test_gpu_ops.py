@@ -370,6 +370,26 @@ def test_dropout_mask_matches_oracle_mirror(sf):
     assert 0.4 < (ref == 0).mean() < 0.6
 
 
+def test_fill_regions_sets_every_buffer_and_nothing_else(sf):
+    """sf_fill_regions: the initial conditions of a pass (zero states, <BOS> words, cleared flags) in one launch."""
+    from speaker_follower_amd.runtime import fill_regions
+    big = torch.full((3, 100, 512), 7.0, device='cuda')
+    words = torch.full((5, 101), -3, dtype=torch.int64, device='cuda')
+    ended = torch.full((103,), 9, dtype=torch.uint8, device='cuda')
+    idx = torch.full((2, 37), 11, dtype=torch.int32, device='cuda')
+    long_one = torch.full((300001,), 1.0, device='cuda')                   # more elements than one pass of the grid
+    fill_regions((big[1], -0.5), (words[0], 1), (ended[:101], 0), (idx[1], -2), (long_one, 2.25), (big[2, :0], 3.0))
+    torch.cuda.synchronize()
+    assert (big[0] == 7).all() and (big[1] == -0.5).all() and (big[2] == 7).all()
+    assert (words[0] == 1).all() and (words[1:] == -3).all()
+    assert (ended[:101] == 0).all() and (ended[101:] == 9).all()
+    assert (idx[0] == 11).all() and (idx[1] == -2).all() and (long_one == 2.25).all()
+    with pytest.raises(RuntimeError):
+        fill_regions(*[(ended, 0)] * 9)                                    # at most SF_FILL_MAX_REGIONS
+    fill_regions((words[4], 2 ** 40 + 5))                                  # all 8 bytes of a 64-bit value
+    assert (words[4] == 2 ** 40 + 5).all()
+
+
 def test_linear_slabs_sum_to_the_product():
     """sf_linear_slabs_fwd: the gate product as split-K slabs (what bench.py's roofline object times)."""
     import ctypes as C
