@@ -716,6 +716,21 @@ int sf_logprob_topk(float* logit, int ld, int N, int n, const int32_t* n_valid, 
 int sf_scatter_rows(const float* src, int ld_src, const int32_t* idx, int n, int width, float* dst,
                     int ld_dst, sf_stream stream);
 
+/* Up to SF_ROW_MOVES_MAX row gathers (scatter = 0: dst[i, :width] = src[idx[i], :width], idx < 0 => zeros) and row
+ * scatters (scatter = 1: dst[idx[i], :width] = src[i, :width], idx < 0 => row skipped; the idx >= 0 distinct) over the
+ * same n rows in ONE launch: `h_t[flat_indices]` and `c_t[flat_indices]` of a search step (follower.py:588-589, 826-827)
+ * together, and the h / c / attention rows of its new states into the state pool together.  width, ld_src, ld_dst
+ * multiples of 4.  The moves must not overlap one another. */
+#define SF_ROW_MOVES_MAX 4
+typedef struct sf_row_move {
+    const float* src;
+    float* dst;
+    const int32_t* idx;
+    int32_t ld_src, ld_dst, width;
+    int32_t scatter;
+} sf_row_move;
+int sf_move_rows(const sf_row_move* moves, int n_moves, int n, sf_stream stream);
+
 /* Small utilities used by the host mirror (kept on the stream so rollouts never sync). */
 int sf_fill_f32(float* p, size_t n, float v, sf_stream stream);
 int sf_add_f32(float* dst, const float* src, size_t n, sf_stream stream); /* dst += src */

@@ -113,6 +113,12 @@ class Sample(C.Structure):
     _fields_ = [('seed', C.c_uint32), ('stream', C.c_uint32), ('row0', C.c_int32), ('stream_dev', c_p)]
 
 
+class RowMove(C.Structure):
+    """sf_row_move."""
+    _fields_ = [('src', c_p), ('dst', c_p), ('idx', c_p), ('ld_src', C.c_int32), ('ld_dst', C.c_int32),
+                ('width', C.c_int32), ('scatter', C.c_int32)]
+
+
 class FillRegion(C.Structure):
     """sf_fill_region."""
     _fields_ = [('ptr', c_p), ('count', C.c_uint64), ('value', C.c_uint64), ('width', C.c_int32)]
@@ -242,6 +248,7 @@ _SIGNATURES = {
                                          P(SpkDecoderGTape), c_f, c_f, c_f] + WS),
     'sf_fill_f32': (C.c_int, [c_f, C.c_size_t, C.c_float, c_p]),
     'sf_fill_regions': (C.c_int, [c_p, C.c_int, c_p]),
+    'sf_move_rows': (C.c_int, [c_p, C.c_int, C.c_int, c_p]),
     'sf_add_f32': (C.c_int, [c_f, c_f, C.c_size_t, c_p]),
     'sf_adam_step': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
                               C.c_double, C.c_int, c_p]),

@@ -1939,6 +1939,20 @@ int sf_fill_f32(float* p, size_t n, float v, sf_stream stream) {
     return fill(p, n, v, S(stream));
 }
 
+int sf_move_rows(const sf_row_move* moves, int n_moves, int n, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(moves && n_moves >= 1 && n_moves <= SF_ROW_MOVES_MAX && n >= 0);
+    if (n == 0) return SF_OK;
+    RowMoves mv;
+    mv.n = n_moves;
+    for (int i = 0; i < n_moves; ++i) {
+        const sf_row_move& m = moves[i];
+        SF_CHECK_ARG(m.src && m.dst && m.idx && m.width > 0 && m.ld_src >= m.width && m.ld_dst >= m.width);
+        mv.m[i] = RowMoves::M{m.src, m.dst, m.idx, m.ld_src, m.ld_dst, m.width, m.scatter ? 1 : 0};
+    }
+    return move_rows(mv, n, S(stream));
+}
+
 int sf_fill_regions(const sf_fill_region* regions, int n, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(n >= 0 && n <= SF_FILL_MAX_REGIONS && (regions || n == 0));

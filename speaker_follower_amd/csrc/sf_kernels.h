@@ -139,6 +139,11 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr,
 // the same with the 1-based step counter ON THE DEVICE (incremented by the call; coef: 2 floats of scratch)
 int adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
                   double eps, double wd, int* step_dev, float* coef, hipStream_t st);
+struct RowMoves {                         // sf_move_rows
+    struct M { const float* src; float* dst; const int* idx; int lds, ldd, w, scatter; } m[4];
+    int n;
+};
+int move_rows(const RowMoves& mv, int n, hipStream_t st);
 struct FillRegions {                      // sf_fill_regions
     struct R { void* ptr; unsigned long long count, value; int width; } r[8];
     int n;

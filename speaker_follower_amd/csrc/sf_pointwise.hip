@@ -369,6 +369,27 @@ __global__ __launch_bounds__(TPB) void scatter_rows_kernel(const float* src, int
     }
 }
 
+// sf_move_rows: several gathers / scatters over n rows in one launch (blockIdx.y = the move): h and c of the expanded
+// search states out of the state pool, h / c / attention of the new states into it.
+__global__ __launch_bounds__(TPB) void move_rows_kernel(RowMoves mv, int n) {
+    const RowMoves::M m = mv.m[blockIdx.y];
+    const int w4 = m.w >> 2;
+    const size_t total = (size_t)n * w4;
+    for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
+        const int c = (int)(i % w4), r = (int)(i / w4);
+        const int k = m.idx[r];
+        if (m.scatter) {
+            if (k >= 0)
+                reinterpret_cast<float4*>(m.dst + (size_t)k * m.ldd)[c] =
+                    reinterpret_cast<const float4*>(m.src + (size_t)r * m.lds)[c];
+        } else {
+            float4 v = f4zero();
+            if (k >= 0) v = reinterpret_cast<const float4*>(m.src + (size_t)k * m.lds)[c];
+            reinterpret_cast<float4*>(m.dst + (size_t)r * m.ldd)[c] = v;
+        }
+    }
+}
+
 // Masked log-softmax + the k best columns of every row in descending order (ties: lower column
 // first).  One block per row, up to TOPK_E * TPB columns, k rounds of a block-wide arg-max.
 constexpr int TOPK_E = 4;
@@ -1076,6 +1097,15 @@ int scatter_rows(const float* src, int lds, const int* idx, int n, int w, float*
     if ((w & 3) || (lds & 3) || (ldd & 3)) return SF_ERR_UNSUPPORTED;
     SF_LAUNCH(scatter_rows_kernel, dim3(grid1d((size_t)n * (w >> 2))), dim3(TPB), 0, st, src,
                        lds, idx, n, w, dst, ldd);
+    return launch_status();
+}
+int move_rows(const RowMoves& mv, int n, hipStream_t st) {
+    int widest = 4;
+    for (int i = 0; i < mv.n; ++i) {
+        if ((mv.m[i].w & 3) || (mv.m[i].lds & 3) || (mv.m[i].ldd & 3)) return SF_ERR_UNSUPPORTED;
+        widest = mv.m[i].w > widest ? mv.m[i].w : widest;
+    }
+    SF_LAUNCH(move_rows_kernel, dim3(grid1d((size_t)n * (widest >> 2)), mv.n), dim3(TPB), 0, st, mv, n);
     return launch_status();
 }
 int logprob_topk(float* logit, int ld, int N, int n, const int* n_valid, int k, int* idx,

@@ -515,7 +515,7 @@ def _inputs_from_block(space, block, n):
     """The index-form inputs of `search.FlatDecoder.step_arrays` from the [8, cap] block of
     frontier_core.cpp:fill_inputs (host-issued decoder steps: fakes in the host tests, agents without a graph)."""
     h = space.h
-    row, view, prow, pview, act, hrow, crow = (block[j, :n].astype(np.int64) for j in range(7))
+    row, prow, view, pview, act, hrow, crow = (block[j, :n].astype(np.int64) for j in range(7))
     sid, psid = row * V + view, prow * V + pview
     return dict(vp=h['feat_row'][row], view=view, a_num=h['a_num'][sid], cand_view=h['cand_view'][sid],
                 sincos=h['sincos'][sid], hrow=hrow, crow=crow, has_u=act != 0,      # (an expanded state never follows

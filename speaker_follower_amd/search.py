@@ -274,8 +274,10 @@ class GraphStep:
         self.inputs = self.pin_in.numpy()                                            # what fill_inputs writes
         self.dev_in = i32(8, cap)
         A = self.A
-        self.obs = [dict(row=i32(cap), vp=i32(cap), view=i32(cap), a_num=i32(cap), cand_view=i32(cap, A),
-                         sincos=f32(cap, A, 4)) for _ in range(2)]                   # the states, their parents
+        # observations of the states [0] and of their parents [1]: halves of one [2 cap] look-up
+        self.obs2 = dict(row=i32(2 * cap), vp=i32(2 * cap), view=i32(2 * cap), a_num=i32(2 * cap),
+                         cand_view=i32(2 * cap, A), sincos=f32(2 * cap, A, 4))
+        self.obs = [{k: v[j * cap:(j + 1) * cap] for k, v in self.obs2.items()} for j in range(2)]
         self.h0, self.c0, self.u_prev = f32(cap, self.H), f32(cap, self.H), f32(cap, store.F)
         self.tape = decoder_tape(cap, self.H, store.F, self.D, store.V, t_max, A, dev)
         self.logp = f32(cap, A)
@@ -308,16 +310,19 @@ class GraphStep:
         st, nav, cap, A = self.store, self.nav, self.cap, self.A
         s = stream()
         self.dev_in.copy_(self.pin_in, non_blocking=True)
-        row, view, prow, pview, act, hrow, crow, dst = (self.dev_in[j] for j in range(8))
+        act, hrow, crow, dst = (self.dev_in[j] for j in range(4, 8))
         ns = nav.struct()
-        for o, (r_, v_) in zip(self.obs, ((row, view), (prow, pview))):
-            call('sf_nav_step', byref(ns), cap, ptr(r_), ptr(v_), None, None, None, 0, None, ptr(o['row']), ptr(o['vp']),
-                 ptr(o['view']), ptr(o['a_num']), ptr(o['cand_view']), ptr(o['sincos']), None, s)
+        # rows 0-1 of the block: nav rows of the states, then of their parents; rows 2-3 their views (fill_inputs)
+        o = self.obs2
+        call('sf_nav_step', byref(ns), 2 * cap, ptr(self.dev_in[0]), ptr(self.dev_in[2]), None, None, None, 0, None,
+             ptr(o['row']), ptr(o['vp']), ptr(o['view']), ptr(o['a_num']), ptr(o['cand_view']), ptr(o['sincos']), None, s)
         cur, par = self.obs
         ucand = st.cands(par['vp'], par['cand_view'], par['sincos'], par['a_num'], A)
         call('sf_gather_actions', byref(ucand), cap, ptr(act), ptr(self.u_prev), s)
-        call('sf_gather_rows', ptr(self.hpool), self.H, ptr(hrow), cap, self.H, ptr(self.h0), self.H, s)
-        call('sf_gather_rows', ptr(self.cpool), self.H, ptr(hrow), cap, self.H, ptr(self.c0), self.H, s)
+        H = self.H
+        gat = (_lib.RowMove * 2)(_lib.RowMove(self.hpool.data_ptr(), self.h0.data_ptr(), hrow.data_ptr(), H, H, H, 0),
+                                 _lib.RowMove(self.cpool.data_ptr(), self.c0.data_ptr(), hrow.data_ptr(), H, H, H, 0))
+        call('sf_move_rows', gat, 2, cap, s)
         pano = st.pano(cur['vp'], cur['view'])
         cnd = st.cands(cur['vp'], cur['cand_view'], cur['sincos'], cur['a_num'], A)
         w = decoder_w_struct(decoder_params(self.dec))
@@ -326,11 +331,12 @@ class GraphStep:
              ptr(self.u_prev), ptr(self.h0), ptr(self.c0), ptr(self.ctx), ptr(self.mask), ptr(crow), byref(tp), None,
              None, 0, *ws_args(self.dev))
         call('sf_logprob_topk', ptr(self.tape['logit']), A, cap, A, ptr(cur['a_num']), A, None, ptr(self.logp), s)
-        for src, pool, width in ((self.tape['h1'], self.hpool, self.H), (self.tape['c1'], self.cpool, self.H),
-                                 (self.tape['alpha'], self.apool, self.T)):
-            call('sf_scatter_rows', ptr(src), width, ptr(dst), cap, width, ptr(pool), width, s)
+        sca = (_lib.RowMove * 3)(*(_lib.RowMove(src.data_ptr(), pool.data_ptr(), dst.data_ptr(), width, width, width, 1)
+                                   for src, pool, width in ((self.tape['h1'], self.hpool, H), (self.tape['c1'], self.cpool, H),
+                                                            (self.tape['alpha'], self.apool, self.T))))
+        call('sf_move_rows', sca, 3, cap, s)
         self.pin_out.copy_(self.logp, non_blocking=True)
-        self._keep = (ns, ucand, pano, cnd, w, tp)
+        self._keep = (ns, ucand, pano, cnd, w, tp, gat, sca)
 
     def _capture(self):
         self.pin_in.zero_()

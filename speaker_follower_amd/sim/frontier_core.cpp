@@ -124,9 +124,11 @@ class StateFactored {
             const i64 f = frontier_[i < N ? i : 0];
             const i64 s = sid_[f], p = parent_[f];
             const i64 ps = p >= 0 ? sid_[p] : s;
+            // (rows 0-1: nav rows of the states, then of their parents; rows 2-3: their views likewise -- one
+            // navigation look-up over 2 cap entries serves both)
             o[0 * cap + i] = (int32_t)(s / V_);
-            o[1 * cap + i] = (int32_t)(s % V_);
-            o[2 * cap + i] = (int32_t)(ps / V_);
+            o[1 * cap + i] = (int32_t)(ps / V_);
+            o[2 * cap + i] = (int32_t)(s % V_);
             o[3 * cap + i] = (int32_t)(ps % V_);
             o[4 * cap + i] = p >= 0 ? (int32_t)action_[f] : 0;
             o[5 * cap + i] = (int32_t)pool_[f];

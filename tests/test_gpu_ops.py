@@ -390,6 +390,41 @@ def test_fill_regions_sets_every_buffer_and_nothing_else(sf):
     assert (words[4] == 2 ** 40 + 5).all()
 
 
+def test_move_rows_is_the_separate_gathers_and_scatters(sf):
+    """sf_move_rows against sf_gather_rows / sf_scatter_rows semantics: several moves in one launch."""
+    import ctypes as C
+    from speaker_follower_amd.runtime import stream
+    rng = np.random.default_rng(5)
+    n, H, T = 77, 512, 80
+    hpool, cpool = dev(rnd(rng, 300, H)), dev(rnd(rng, 300, H))
+    idx = rng.integers(-1, 300, n).astype(np.int32)
+    idx_d = dev(idx)
+    h0, c0 = torch.full((n, H), 9.0, device='cuda'), torch.full((n, H + 4), 9.0, device='cuda')
+    L = sf.lib
+    gat = (L.RowMove * 2)(L.RowMove(hpool.data_ptr(), h0.data_ptr(), idx_d.data_ptr(), H, H, H, 0),
+                          L.RowMove(cpool.data_ptr(), c0.data_ptr(), idx_d.data_ptr(), H, H + 4, H, 0))
+    L.call('sf_move_rows', gat, 2, n, stream())
+    ref_h = np.where(idx[:, None] >= 0, hpool.cpu().numpy()[np.maximum(idx, 0)], 0.0)
+    ref_c = np.where(idx[:, None] >= 0, cpool.cpu().numpy()[np.maximum(idx, 0)], 0.0)
+    np.testing.assert_array_equal(h0.cpu().numpy(), ref_h)
+    np.testing.assert_array_equal(c0[:, :H].cpu().numpy(), ref_c)
+    assert (c0[:, H:] == 9).all()                                          # the padding columns are not touched
+    # scatters: three widths, rows with idx < 0 skipped
+    dst = np.where(rng.random(n) < 0.2, -1, rng.permutation(400)[:n]).astype(np.int32)
+    dst_d = dev(dst)
+    srcs = [dev(rnd(rng, n, w)) for w in (H, H, T)]
+    pools = [torch.full((400, w), -1.0, device='cuda') for w in (H, H, T)]
+    sca = (L.RowMove * 3)(*(L.RowMove(a.data_ptr(), b.data_ptr(), dst_d.data_ptr(), w, w, w, 1)
+                            for a, b, w in zip(srcs, pools, (H, H, T))))
+    L.call('sf_move_rows', sca, 3, n, stream())
+    for a, b in zip(srcs, pools):
+        ref = np.full(b.shape, -1.0, np.float32)
+        ref[dst[dst >= 0]] = a.cpu().numpy()[dst >= 0]
+        np.testing.assert_array_equal(b.cpu().numpy(), ref)
+    with pytest.raises(RuntimeError):
+        L.call('sf_move_rows', sca, 5, n, stream())                        # at most SF_ROW_MOVES_MAX
+
+
 def test_linear_slabs_sum_to_the_product():
     """sf_linear_slabs_fwd: the gate product as split-K slabs (what bench.py's roofline object times)."""
     import ctypes as C
