@@ -812,6 +812,10 @@ void sf_debug_gate_product_f32(int on);
  * the beam search's flat steps) back to the register-streaming kernel of rounds 1-4 instead of the LDS-tiled 128 x 128
  * bf16x6 kernel (csrc/sf_gemm.hip: gemm_nt_big_kernel; the default). */
 void sf_debug_many_row_product(int on);
+/* A/B switch (round 5): on == 0 forms the decoder's small weight gradients one product at a time (two transposes, the
+ * many-row product, the slab sum: four dependent launches each) instead of three grouped launches for all of them
+ * (csrc/sf_gemm.hip: gemm_tn_group; the default). */
+void sf_debug_grouped_weight_gradients(int on);
 /* A/B switch: on == 0 makes sf_speaker_encoder_fwd run its visual attention on the fp32 kernels (rounds 1-4) instead
  * of the float64 query / score path (sf_visual_attention_fwd_f64; the default). */
 void sf_debug_precise_attention(int on);

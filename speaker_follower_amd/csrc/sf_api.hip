@@ -47,7 +47,7 @@ void prof_events(const char* name, hipEvent_t* e0, hipEvent_t* e1) {
 
 namespace {
 
-constexpr size_t WORKSPACE_BYTES = 64u << 20;
+constexpr size_t WORKSPACE_BYTES = 256u << 20;     // (round 5: the grouped weight gradients keep ~135 MB of transposed operands + slabs)
 
 // Bump allocator over the caller's workspace.  Passed BY VALUE into helpers so that their
 // temporaries are released on return; whatever is left is handed to the GEMMs for split-K slabs.
@@ -431,6 +431,7 @@ const char* sf_build_id(void) { static const char id[] = "SF_BUILD_ID=" SF_BUILD
 void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; }
 void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
 void sf_debug_many_row_product(int on) { sf::g_nt_big = on; }
+void sf_debug_grouped_weight_gradients(int on) { sf::g_tn_group = on; }
 int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, sf_stream stream) {
     SF_ENTER();
     return sf::cotenant(blocks, threads, lds_bytes, ticks, sink, S(stream));
@@ -1275,23 +1276,32 @@ int sf_attn_decoder_wgrad(const sf_decoder_w* w, const sf_decoder_g* g, int M, i
     SF_CHECK_ARG(w && g && h0_all && tp && gt && M > 0);
     hipStream_t st = S(stream);
     Arena ar = arena(ws, ws_bytes);
-    // LSTMCell (model.py:393)
-    if (g->lstm.w_ih) TRY(gemm_tn(gt->dgates, 4 * H, tp->xin, 2 * F, M, 4 * H, 2 * F, g->lstm.w_ih, 2 * F, 1, st, ar.rest(), ar.rest_n()));
-    if (g->lstm.w_hh) TRY(gemm_tn(gt->dgates, 4 * H, h0_all, H, M, 4 * H, H, g->lstm.w_hh, H, 1, st, ar.rest(), ar.rest_n()));
-    TRY(colsum_pair(gt->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
-    // visual attention (model.py:389)
-    if (g->visual.w_v) TRY(gemm_tn(tp->t_v, D, gt->dq, F, M, D, F, g->visual.w_v, F, 1, st, ar.rest(), ar.rest_n()));
-    if (g->visual.w_h) TRY(gemm_tn(gt->dt_v, D, h0_all, H, M, D, H, g->visual.w_h, H, 1, st, ar.rest(), ar.rest_n()));
+    // LSTMCell (model.py:393): dW_ih's leading columns (whole rounds of the chip) as one large product, its narrow tail
+    // with the small matrices below
+    const int q_main = gemm_tn_main_columns(M, 4 * H, 2 * F);
+    if (g->lstm.w_ih) TRY(gemm_tn(gt->dgates, 4 * H, tp->xin, 2 * F, M, 4 * H, q_main, g->lstm.w_ih, 2 * F, 1, st, ar.rest(), ar.rest_n()));
+    // the other matrices (a few dozen output tiles each over the same M stacked rows): one grouped launch sequence
+    TnJob jobs[8];
+    int nj = 0;
+    auto job = [&](const float* Y, int ldy, const float* X, int ldx, int P, int Q, float* out, int ldo = 0) {
+        if (out) jobs[nj++] = TnJob{Y, ldy, X, ldx, M, P, Q, out, ldo ? ldo : Q, 1};
+    };
+    if (g->lstm.w_ih && q_main < 2 * F)
+        job(gt->dgates, 4 * H, tp->xin + q_main, 2 * F, 4 * H, 2 * F - q_main, g->lstm.w_ih + q_main, 2 * F);
+    job(gt->dgates, 4 * H, h0_all, H, 4 * H, H, g->lstm.w_hh);
+    job(tp->t_v, D, gt->dq, F, D, F, g->visual.w_v);                     // visual attention (model.py:389)
+    job(gt->dt_v, D, h0_all, H, D, H, g->visual.w_h);
+    job(gt->dpre, H, tp->cat2, 2 * H, H, 2 * H, g->text.w_out);          // text attention (model.py:395)
+    job(gt->dt_text, H, tp->cat2 + H, 2 * H, H, H, g->text.w_in);
+    job(tp->wt, D, gt->dr, F, D, F, g->action.w_a);                      // action scoring (model.py:396)
+    job(gt->dta, D, tp->h_tilde, H, D, H, g->action.w_h);
+    if (nj) TRY(gemm_tn_group(jobs, nj, st, ar.rest(), ar.rest_n()));
+    if (g->lstm.w_ih || g->lstm.w_hh || g->lstm.b_ih || g->lstm.b_hh)
+        TRY(colsum_pair(gt->dgates, 4 * H, M, 4 * H, g->lstm.b_ih, g->lstm.b_hh, ar, st));
     if (g->visual.b_h) TRY(colsum(gt->dt_v, D, M, D, g->visual.b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
-    // text attention (model.py:395)
-    if (g->text.w_out) TRY(gemm_tn(gt->dpre, H, tp->cat2, 2 * H, M, H, 2 * H, g->text.w_out, 2 * H, 1, st, ar.rest(), ar.rest_n()));
-    if (g->text.w_in) TRY(gemm_tn(gt->dt_text, H, tp->cat2 + H, 2 * H, M, H, H, g->text.w_in, H, 1, st, ar.rest(), ar.rest_n()));
-    // action scoring (model.py:396)
-    if (g->action.w_a) TRY(gemm_tn(tp->wt, D, gt->dr, F, M, D, F, g->action.w_a, F, 1, st, ar.rest(), ar.rest_n()));
     if (g->action.b_a) TRY(dot_rows_accum(gt->dc, tp->wt, D, M, D, g->action.b_a, st));
     if (g->action.b_out) TRY(sum_accum(gt->dc, M, g->action.b_out, st));
     if (g->action.w_out) TRY(colsum_prod(gt->dwt, D, tp->t_a, D, M, D, g->action.w_out, st));
-    if (g->action.w_h) TRY(gemm_tn(gt->dta, D, tp->h_tilde, H, M, D, H, g->action.w_h, H, 1, st, ar.rest(), ar.rest_n()));
     if (g->action.b_h) TRY(colsum(gt->dta, D, M, D, g->action.b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
     return SF_OK;
 }

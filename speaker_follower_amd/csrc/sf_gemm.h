@@ -59,6 +59,16 @@ int gemm_nn(const float* A, int lda, const float* W, int ldw, int M, int N, int 
 
 // out[P,Q] (+)= Y[M,P]^T * X[M,Q]   (weight gradients; ldy % 4 == 0, ldx % 4 == 0, Q % 4 == 0)
 // ws (optional): scratch for splitting a deep reduction over M into up to 16 slabs of [P,Q]
+struct TnJob {                        // one weight gradient out[P,Q] (+)= Y[M,P]^T X[M,Q] of gemm_tn_group
+    const float* Y; int ldy;
+    const float* X; int ldx;
+    int M, P, Q;
+    float* out; int ldo;
+    int accumulate;
+};
+int gemm_tn_group(const TnJob* jobs, int n, hipStream_t st, float* ws, size_t ws_floats);
+int gemm_tn_main_columns(int M, int P, int Q);
+extern int g_tn_group;                // sf_debug_grouped_weight_gradients
 int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int Q, float* out,
             int ldo, int accumulate, hipStream_t st, float* ws = nullptr, size_t ws_floats = 0);
 

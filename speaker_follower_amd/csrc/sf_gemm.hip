@@ -671,14 +671,14 @@ struct NtBigArgs {
 };
 constexpr int NB_T = 128, NB_K = 32, NB_PLANE = NB_T * 64;          // bytes per plane and stage (128 rows x 64 B)
 
-__global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
+__device__ __forceinline__ void nt_big_body(const NtBigArgs& a, const int tile, const int split_of_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char nb_smem[];   // [2 buffers][A | W][3 planes][128 rows][64 B]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
     const int wm = wave >> 2, wn = wave & 3;                          // 64-row half, 32-column quarter of the tile
     // tile map: consecutive workgroups walk down the rows of one column block (W's 128 rows stay hot in the L2s)
     const int mtiles = (a.M + NB_T - 1) / NB_T;
-    const int m0 = (blockIdx.x % mtiles) * NB_T, n0 = (blockIdx.x / mtiles) * NB_T;
+    const int m0 = (tile % mtiles) * NB_T, n0 = (tile / mtiles) * NB_T;
     // staging: thread -> (row = tid >> 3 (+64), float4 c4 = tid & 7 of the 32-deep stage)
     const int srow = tid >> 3, c4 = tid & 7;
     int arow[2], wrow[2];
@@ -729,7 +729,7 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) hi[i][j] = lo[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int stages_all = st0 + st1 + st2;
-    const int ks = a.ksplit > 1 ? a.ksplit : 1, split = blockIdx.y;
+    const int ks = a.ksplit > 1 ? a.ksplit : 1, split = split_of_block;
     const int s_lo = (int)(((long)split * stages_all) / ks), s_hi = (int)(((long)(split + 1) * stages_all) / ks);
     const int stages = s_hi - s_lo;
     // Two register sets: the loads of stage s + 2 are issued at the top of stage s and stored to LDS at the end of stage
@@ -803,6 +803,66 @@ __global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) {
                 float* o = a.y + (size_t)row * a.ldy + col;
                 *o = a.accumulate ? *o + v : v;
             }
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_nt_big_kernel(NtBigArgs a) { nt_big_body(a, blockIdx.x, blockIdx.y); }
+
+// SEVERAL many-row products in one launch (gemm_tn_group: the decoder's small weight gradients -- each a few dozen tiles,
+// 35 dependent launches of 5-28 us between them when issued one by one): block b belongs to job j with
+// first[j] <= b < first[j + 1]; inside the job blocks walk its tiles, then its K splits.
+constexpr int NB_GROUP = 8;
+struct NtBigGroup {
+    NtBigArgs job[NB_GROUP];
+    int first[NB_GROUP + 1];
+    int n;
+};
+__global__ __launch_bounds__(512) void gemm_nt_big_group_kernel(NtBigGroup g) {
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < NB_GROUP; ++k) j += (k < g.n && (int)blockIdx.x >= g.first[k]) ? 1 : 0;
+    const NtBigArgs& a = g.job[j];
+    const int local = (int)blockIdx.x - g.first[j];
+    const int tiles = ((a.M + NB_T - 1) / NB_T) * ((a.N + NB_T - 1) / NB_T);
+    nt_big_body(a, local % tiles, local / tiles);
+}
+
+// Several transposes in one launch: problem p's 32 x 32 tiles are blocks first[p] .. first[p + 1] - 1
+constexpr int TR_GROUP = 16;
+struct TrGroup {
+    struct P { const float* src; float* dst; int lds, R, C; } p[TR_GROUP];
+    int first[TR_GROUP + 1];
+    int n;
+};
+__global__ __launch_bounds__(256) void transpose_group_kernel(TrGroup g) {
+    __shared__ float tile[32][33];
+    int j = 0;
+#pragma unroll
+    for (int k = 1; k < TR_GROUP; ++k) j += (k < g.n && (int)blockIdx.x >= g.first[k]) ? 1 : 0;
+    const TrGroup::P q = g.p[j];
+    const int local = (int)blockIdx.x - g.first[j], ct = (q.C + 31) / 32;
+    const int c0 = (local % ct) * 32, r0 = (local / ct) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < q.R && c0 + tx < q.C) tile[i][tx] = q.src[(size_t)(r0 + i) * q.lds + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < q.C && r0 + tx < q.R) q.dst[(size_t)(c0 + i) * q.R + r0 + tx] = tile[tx][i];
+}
+
+// out_j (+)= sum of job j's K-split slabs, all jobs in one launch (grid.y = job; fixed slab order: deterministic)
+struct RedGroup {
+    struct J { const float* slabs; float* y; int ks, M, N, ldy, accumulate; } j[NB_GROUP];
+};
+__global__ __launch_bounds__(256) void reduce_slabs_group_kernel(RedGroup g) {
+    const RedGroup::J a = g.j[blockIdx.y];
+    const size_t total = (size_t)a.M * a.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int row = (int)(i / a.N), col = (int)(i % a.N);
+        float v = 0.f;
+        for (int s = 0; s < a.ks; ++s) v += a.slabs[(size_t)s * total + i];
+        float* o = a.y + (size_t)row * a.ldy + col;
+        *o = a.accumulate ? *o + v : v;
     }
 }
 
@@ -1974,6 +2034,119 @@ int gemm_nn(const float* A, int lda, const float* W, int ldw, int M, int N, int 
     return gemm_nn_ws(A, lda, W, ldw, M, N, K, y, ldy, accumulate, nullptr, 0, st);
 }
 
+// The leading columns of a LARGE gemm_tn output [P,Q] that fill whole rounds of the chip's 1024 SIMDs with 64 x 64 wave
+// tiles (dW_ih of the decoder LSTM: 2176 tiles = 2.125 per SIMD, so some SIMDs would run 3); the narrow remainder is a
+// product of its own (a row split or the many-row kernel spreads it over the chip).  Q when the output is not cut.
+int gemm_tn_main_columns(int M, int P, int Q) {
+    const int waves = ceil_div(Q, 64) * ceil_div(P, 64);
+    const int pb = ceil_div(P, 64), qb = ceil_div(Q, 256);
+    const int rem = waves % 1024;
+    if (!(waves > 1024 && rem > 0 && rem <= 384 && rem % (4 * pb) == 0)) return Q;
+    const int r = rem / (4 * pb);                       // column blocks of 256 in the remainder
+    const int q_main = (qb - r) * 256, q_tail = Q - q_main;
+    if (!(r < qb && q_tail > 0)) return Q;
+    const int tail_waves = ceil_div(q_tail, 64) * pb;
+    const int tail_ms = std::min(16, std::max(1, 1024 / tail_waves));
+    if (!(tail_ms > 1 && M / 64 >= tail_ms)) return Q;
+    return q_main;
+}
+
+// Whether gemm_tn runs this product as an NT product of the transposed operands on the many-row kernel (below)
+static bool tn_as_many_row(int M, int P, int Q) {
+    return g_nt_big && !g_nt_force_f32 && M >= 1024 && M % 4 == 0 && P >= 64 && Q >= 64 &&
+           (size_t)P * Q <= (size_t)1536 * 1024 && !(P % TNS_B == 0 && Q % TNS_B == 0 && M >= g_tn_split_min_rows);
+}
+
+int g_tn_group = 1;          // sf_debug_grouped_weight_gradients (0: one gemm_tn per product, the round-5 first form)
+
+// Several weight gradients dW_j[P_j, Q_j] (+)= Y_j^T X_j over the same kind of stacked rows in THREE launches -- all the
+// transposes (an operand two products share is transposed once), all the many-row products (gemm_nt_big_group_kernel),
+// all the slab sums -- instead of four dependent launches per product.  Products outside the many-row form (or when
+// the workspace is short) go through gemm_tn one by one.
+int gemm_tn_group(const TnJob* jobs, int n, hipStream_t st, float* ws, size_t ws_floats) {
+    int pick[NB_GROUP], np = 0;
+    for (int i = 0; i < n; ++i) {
+        const TnJob& t = jobs[i];
+        SF_CHECK_ARG(t.M > 0 && t.P > 0 && t.Q > 0 && t.Q % 4 == 0 && t.ldy % 4 == 0 && t.ldx % 4 == 0 && t.ldo % 4 == 0);
+        if (g_tn_group && ws && np < NB_GROUP && tn_as_many_row(t.M, t.P, t.Q)) pick[np++] = i;
+    }
+    // the plan: distinct transposes, K splits (every job alike: ~3 rounds of the chip between them), workspace layout
+    TrGroup tr{};
+    NtBigGroup gg{};
+    RedGroup rg{};
+    size_t off = 0;
+    auto transposed = [&](const float* src, int ld, int M, int C) -> const float* {
+        for (int k = 0; k < tr.n; ++k)
+            if (tr.p[k].src == src && tr.p[k].lds == ld && tr.p[k].R == M && tr.p[k].C == C) return tr.p[k].dst;
+        if (tr.n == TR_GROUP) return nullptr;
+        float* dst = ws + off;
+        off += ((size_t)C * M + 63) & ~(size_t)63;
+        tr.p[tr.n] = TrGroup::P{src, dst, ld, M, C};
+        tr.first[tr.n + 1] = tr.first[tr.n] + ceil_div(C, 32) * ceil_div(M, 32);
+        ++tr.n;
+        return dst;
+    };
+    bool grouped = np >= 2;
+    int tiles_all = 0;
+    for (int k = 0; k < np; ++k) tiles_all += ceil_div(jobs[pick[k]].P, NB_T) * ceil_div(jobs[pick[k]].Q, NB_T);
+    for (int k = 0; grouped && k < np; ++k) {
+        const TnJob& t = jobs[pick[k]];
+        const float* yt = transposed(t.Y, t.ldy, t.M, t.P);
+        const float* xt = yt ? transposed(t.X, t.ldx, t.M, t.Q) : nullptr;
+        if (!xt) { grouped = false; break; }
+        const int stages = ceil_div(t.M, NB_K);
+        const int ks = std::max(1, std::min(std::min(16, 768 / std::max(1, tiles_all)), stages / 4));
+        NtBigArgs& b = gg.job[k];
+        b.seg[0] = Seg{yt, t.M, xt, t.M, t.M};
+        b.nseg = 1; b.M = t.P; b.N = t.Q; b.epi = EPI_NONE; b.ksplit = ks;
+        gg.first[k + 1] = gg.first[k] + ceil_div(t.P, NB_T) * ceil_div(t.Q, NB_T) * ks;
+        if (ks > 1) {
+            b.y = nullptr; b.ldy = t.Q;                  // (slab base: below, behind every transposed operand)
+            rg.j[k] = RedGroup::J{nullptr, t.out, ks, t.P, t.Q, t.ldo, t.accumulate};
+        } else {
+            b.y = t.out; b.ldy = t.ldo; b.accumulate = t.accumulate;
+            rg.j[k] = RedGroup::J{nullptr, nullptr, 0, 0, 0, 0, 0};
+        }
+    }
+    if (grouped) {
+        size_t most = 1;
+        for (int k = 0; k < np; ++k) {
+            if (gg.job[k].ksplit > 1) {
+                gg.job[k].y = ws + off;
+                rg.j[k].slabs = ws + off;
+                off += (((size_t)gg.job[k].ksplit * gg.job[k].M * gg.job[k].N) + 63) & ~(size_t)63;
+                most = std::max(most, (size_t)gg.job[k].M * gg.job[k].N);
+            }
+        }
+        if (off > ws_floats) grouped = false;
+        if (grouped) {
+            gg.n = np;
+            static bool attr_set = false;
+            if (!attr_set) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_nt_big_group_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                attr_set = true;
+            }
+            SF_LAUNCH(transpose_group_kernel, dim3(tr.first[tr.n]), dim3(256), 0, st, tr);
+            SF_LAUNCH(gemm_nt_big_group_kernel, dim3(gg.first[np]), dim3(512), (size_t)2 * 6 * NB_PLANE, st, gg);
+            bool any = false;
+            for (int k = 0; k < np; ++k) any = any || gg.job[k].ksplit > 1;
+            if (any) SF_LAUNCH(reduce_slabs_group_kernel, dim3(red_grid(most), np), dim3(256), 0, st, rg);
+            const int rc = launch_status();
+            if (rc != SF_OK) return rc;
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        bool done = false;
+        for (int k = 0; grouped && k < np; ++k) done = done || pick[k] == i;
+        if (done) continue;
+        const TnJob& t = jobs[i];
+        const int rc = gemm_tn(t.Y, t.ldy, t.X, t.ldx, t.M, t.P, t.Q, t.out, t.ldo, t.accumulate, st, ws, ws_floats);
+        if (rc != SF_OK) return rc;
+    }
+    return SF_OK;
+}
+
 int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int Q, float* out,
             int ldo, int accumulate, hipStream_t st, float* ws, size_t ws_floats) {
     SF_CHECK_ARG(M > 0 && P > 0 && Q > 0 && Q % 4 == 0 && ldy % 4 == 0 && ldx % 4 == 0 &&
@@ -1982,8 +2155,7 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
     // over 2 000 stacked rows: 25 TFLOP/s in gemm_tn_kernel, 90 us each) as an NT product of the two TRANSPOSED operands on
     // the LDS-tiled many-row kernel: dW[P,Q] += Y^T[P,M] (X^T[Q,M])^T.  Two 32 x 32-tiled transposes into the workspace
     // (~6 us each) + gemm_nt_big_kernel (bf16x6, 3x closer to float64 than the fp32 kernels).
-    if (g_nt_big && !g_nt_force_f32 && M >= 1024 && M % 4 == 0 && P >= 64 && Q >= 64 && (size_t)P * Q <= (size_t)1536 * 1024 &&
-        !(P % TNS_B == 0 && Q % TNS_B == 0 && M >= g_tn_split_min_rows) && ws) {
+    if (tn_as_many_row(M, P, Q) && ws) {
         const int tiles = ceil_div(P, NB_T) * ceil_div(Q, NB_T), stages = ceil_div(M, NB_K);
         int ks = std::max(1, std::min(std::min(16, 256 / tiles), stages / 4));
         const size_t off_x = ((size_t)P * M + 63) & ~(size_t)63, off_s = off_x + (((size_t)Q * M + 63) & ~(size_t)63);
@@ -2065,15 +2237,10 @@ int gemm_tn(const float* Y, int ldy, const float* X, int ldx, int M, int P, int 
         // number of rounds over the chip's 1024 SIMDs (dW_ih of the decoder LSTM: 2176 tiles = 2.125
         // per SIMD, so some SIMDs run 3) is cut into the columns that fill whole rounds and a
         // narrow remainder, which the row split below spreads over the chip on its own.
-        const int pb = ceil_div(P, 64), qb = ceil_div(Q, 256);
-        const int rem = waves % 1024;
-        if (waves > 1024 && rem > 0 && rem <= 384 && rem % (4 * pb) == 0) {
-            const int r = rem / (4 * pb);                       // column blocks of 256 in the remainder
-            const int q_main = (qb - r) * 256, q_tail = Q - q_main;
-            const int tail_waves = ceil_div(q_tail, 64) * pb;
-            const int tail_ms = std::min(16, std::max(1, 1024 / tail_waves));
-            if (r < qb && q_tail > 0 && tail_ms > 1 && ws && ws_floats >= (size_t)tail_ms * P * q_tail &&
-                M / 64 >= tail_ms) {
+        const int q_main = gemm_tn_main_columns(M, P, Q), q_tail = Q - q_main;
+        if (q_tail > 0) {
+            const int tail_ms = std::min(16, std::max(1, 1024 / (ceil_div(q_tail, 64) * ceil_div(P, 64))));
+            if (ws && ws_floats >= (size_t)tail_ms * P * q_tail) {
                 const int rc = gemm_tn(Y, ldy, X, ldx, M, P, q_main, out, ldo, accumulate, st, ws, ws_floats);
                 if (rc != SF_OK) return rc;
                 return gemm_tn(Y, ldy, X + q_main, ldx, M, P, q_tail, out + q_main, ldo, accumulate, st, ws,

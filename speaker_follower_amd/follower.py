@@ -674,6 +674,10 @@ class FollowerEngine:
                     self._wgrad_stream = concurrent_stream(dev, exclude=[x for x in (self._side_stream,) if x is not None])
                 third = self._wgrad_stream if self._wgrad_stream is not side else self._side_stream
                 third.wait_stream(torch.cuda.current_stream())
+        # (Measured in round 5, profiles/r05_s_*: the pieces of this tail do not overlap whatever the order of issue --
+        # the persistent encoder backward holds one 256-VGPR workgroup on every CU and the many-row weight-gradient
+        # tiles (512 threads x 188 VGPRs, 96 KB LDS) cannot sit beside it; issued side by side they both take twice as
+        # long.  What shortened the tail was fewer launches: gemm_tn_group.)
         if overlap and not self.encoder_backward_first:
             self._issue_wgrad(side, third, dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, dev, sync)
         elif not overlap:

@@ -207,6 +207,43 @@ def test_chunked_backward_through_time_matches_the_reference_gradients(follower_
         m.zero_grad(set_to_none=True)
 
 
+def test_grouped_weight_gradients_match_the_reference_and_the_single_products(follower_modules, golden):
+    """gemm_tn_group: the decoder's seven small weight gradients in three launches (all transposes, all many-row
+    products, all slab sums) give the reference's gradients (G4, B=100, 20 steps) and, to summation order, those of
+    one product at a time (sf_debug_grouped_weight_gradients(0))."""
+    from speaker_follower_amd import _lib
+    enc, dec, _, _ = follower_modules
+    fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=256)
+    table = synth.feature_table(0, 256)
+    g = golden('g4_rollout_b100_teacher')
+    engine, follower = _engine(follower_modules, table)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    grads = {}
+    for grouped in (1, 0):
+        _lib.lib.sf_debug_grouped_weight_gradients(grouped)
+        try:
+            for m in (enc, dec):
+                m.zero_grad(set_to_none=True)
+            st = engine.rollout(batch, int(g['n_steps']), 'teacher', train=False)
+            st.loss.backward()
+            torch.cuda.synchronize()
+        finally:
+            _lib.lib.sf_debug_grouped_weight_gradients(1)
+        grads[grouped] = {k: p.grad.clone() for m, pre in ((enc, 'enc/'), (dec, 'dec/'))
+                          for k, p in ((pre + k, p) for k, p in m.named_parameters()) if p.grad is not None}
+    _check_grads({k[4:]: v for k, v in grads[1].items() if k.startswith('enc/')}, g, 'enc/')
+    _check_grads({k[4:]: v for k, v in grads[1].items() if k.startswith('dec/')}, g, 'dec/')
+    worst = 0.0
+    for k, a in grads[1].items():
+        b = grads[0][k]
+        scale = float(b.abs().max()) + 1e-30
+        worst = max(worst, float((a - b).abs().max()) / scale)
+    print('[grouped weight gradients] max difference from the single products / scale: %.2e' % worst)
+    assert worst < 2e-6
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+
+
 def test_module_api_teacher_gradients_match_engine(follower_modules, batch8):
     """The per-step nn.Module path (autograd Functions) and the fused engine agree."""
     enc, dec, _, _ = follower_modules
