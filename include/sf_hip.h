@@ -767,9 +767,14 @@ int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double 
                  double beta2, double eps, double weight_decay, int step, sf_stream stream);
 /* The same step with its 1-based step counter IN DEVICE MEMORY (ABI 8): `*step_dev` is incremented by the call and the
  * bias corrections are formed from it on the device (double, rounded once, as on the host), so that a hipGraph which
- * captured the call performs step n + 1 on its n-th replay.  coef: 2 floats of device scratch owned by the optimizer. */
+ * captured the call performs step n + 1 on its n-th replay.  coef: 4 floats of device scratch owned by the optimizer.
+ * skip_if_nonzero (optional): a device word read on the stream; non-zero turns the call into a no-op (parameters,
+ * moments and `*step_dev` untouched).  Given the fault word of the persistent launches (sf_workspace_fault_offset) a
+ * captured iteration never steps on gradients a starved launch has poisoned; the host sees the word at its next
+ * sync and re-issues the iteration (agents.Seq2SeqAgent.train). */
 int sf_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
-                     double eps, double weight_decay, int32_t* step_dev, float* coef, sf_stream stream);
+                     double eps, double weight_decay, int32_t* step_dev, float* coef, const uint32_t* skip_if_nonzero,
+                     sf_stream stream);
 
 /* Development aid (no reference counterpart): while `buf` is non-null, the visual-attention body of
  * the pipelined decode step stamps wall_clock64() (100 MHz) per workgroup into buf[block * 8 + k]

@@ -154,7 +154,7 @@ _SIGNATURES = {
     'sf_site_advance': (C.c_int, [c_p, u32, c_p]),
     'sf_store_u32x4': (C.c_int, [c_p, u32, u32, u32, u32, c_p]),
     'sf_adam_step_dev': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,
-                                   C.c_double, c_p, c_f, c_p]),
+                                   C.c_double, c_p, c_f, c_p, c_p]),
     'sf_debug_cotenant': (C.c_int, [i32, i32, i32, C.c_longlong, c_f, c_p]),
     'sf_gate_product_strict': (None, [C.c_int]),
     'sf_gate_product_is_strict': (C.c_int, []),

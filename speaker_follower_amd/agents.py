@@ -363,6 +363,8 @@ class Seq2SeqAgent(BaseAgent):
         self.encoder.train()
         self.decoder.train()
         self.losses = []
+        if self._graph_trainable(encoder_optimizer, decoder_optimizer):
+            return self._train_on_graph(encoder_optimizer, decoder_optimizer, n_iters)
         for _ in range(1, n_iters + 1):
             encoder_optimizer.zero_grad()
             decoder_optimizer.zero_grad()
@@ -387,6 +389,78 @@ class Seq2SeqAgent(BaseAgent):
                     raise PersistentLaunchFault('the per-step re-issue of a training iteration raised a fault again')
             encoder_optimizer.step()
             decoder_optimizer.step()
+
+    # ---- training iterations as hipGraph replays (runtime.TrainingGraph) ------------------------------------------
+    train_graph = True           # False: every iteration issued launch by launch (the loop above)
+
+    def _graph_trainable(self, encoder_optimizer, decoder_optimizer):
+        """Whole iterations can be replayed when the environment is walked on the device, both optimizers keep their
+        state in flat buffers with device-side step counters (optim.FusedAdam) and nothing leaves the process."""
+        from .optim import FusedAdam
+        if not self.train_graph or '+' in self.feedback or self.beam_size != 1:
+            return False
+        if not (isinstance(encoder_optimizer, FusedAdam) and isinstance(decoder_optimizer, FusedAdam)):
+            return False
+        if self._device_table() is None or self._engine is None:
+            return False
+        eng = self._engine
+        return (eng.group is None and eng.grad_sync is None and getattr(self.encoder, 'num_directions', 1) == 1
+                and getattr(self.encoder, 'persistent', True))
+
+    def _train_on_graph(self, encoder_optimizer, decoder_optimizer, n_iters):
+        """follower.py:1001-1020 with every iteration after the first ONE graph replay: the next minibatch is written
+        into the captured batch's tensors (nav.DeviceNavBatch.load), dropout sites / samples / Adam steps advance
+        through device words, and the optimizer steps are GUARDED by the fault word of the persistent launches
+        (sf_adam_step_dev: a starved launch turns them into no-ops) -- the host looks at the word where it reads the
+        loss and re-issues that iteration on the per-step kernels.  Same sites, same numbers as the eager loop
+        (tests/test_gpu_agents.py)."""
+        from .nav import DeviceNavBatch
+        from .runtime import take_fault
+        table, eng, dev = self._device_table(), self._engine, self._device()
+        opts = (encoder_optimizer, decoder_optimizer)
+        key = (id(encoder_optimizer), id(decoder_optimizer), self.feedback, id(table), self.episode_len)
+        cached = self.__dict__.get('_train_graph_state')
+        take_fault(dev)                                       # (whatever an earlier pass left behind is not ours)
+        for _ in range(n_iters):
+            self.env.reset(sort=True)
+            items = list(self.env.batch)
+            before = [o.host_steps() for o in opts]
+            if cached is not None and (cached[0] != key or cached[2].batch_size != len(items)):
+                cached = None
+            if cached is None:
+                batch = DeviceNavBatch(table, items, self.episode_len, max_length=self.max_instruction_length,
+                                       reverse=self.reverse_instruction, fixed_shapes=True)
+                for o in opts:
+                    o.guard_faults = True
+                tg = eng.capture_training(batch, self.episode_len, self.feedback, optimizers=opts)
+                cached = self._train_graph_state = (key, tg, batch)
+                st = tg.first                                 # (the capture ran this iteration eagerly)
+            else:
+                _, tg, batch = cached
+                batch.load(items)
+                st = tg.replay()
+            loss = float(st.loss_buf)                         # the iteration's one host sync
+            if take_fault(dev):
+                # a persistent launch starved: the guarded optimizer steps did nothing.  The same minibatch again on
+                # the per-step kernels, launch by launch
+                for o, b in zip(opts, before):
+                    o.set_host_steps(b)
+                    o.zero_grad()
+                keep = getattr(self.encoder, 'persistent', True)
+                self.encoder.persistent = False
+                try:
+                    st = eng.rollout(batch, self.episode_len, self.feedback, train=True)
+                    st.loss.backward()
+                finally:
+                    self.encoder.persistent = keep
+                loss = float(st.loss_buf)
+                if take_fault(dev):
+                    raise PersistentLaunchFault('the per-step re-issue of a training iteration raised a fault again')
+                eng.fallbacks += 1
+                for o in opts:
+                    o.step()
+            self.loss = st.loss_buf.reshape(())
+            self.losses.append(loss)
 
     def _encoder_and_decoder_paths(self, base_path):
         return base_path + '_enc', base_path + '_dec'

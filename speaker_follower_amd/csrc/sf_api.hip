@@ -1997,11 +1997,11 @@ int sf_adam_step(float* p, const float* g, float* m, float* v, size_t n, double 
 }
 
 int sf_adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
-                     double eps, double weight_decay, int32_t* step_dev, float* coef, sf_stream stream) {
+                     double eps, double weight_decay, int32_t* step_dev, float* coef, const uint32_t* skip_if_nonzero, sf_stream stream) {
     SF_ENTER();
     SF_CHECK_ARG(((p && g && m && v) || n == 0) && step_dev && coef);
     SF_CHECK_ARG(beta1 >= 0. && beta1 < 1. && beta2 >= 0. && beta2 < 1.);
-    return adam_step_dev(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, coef, S(stream));
+    return adam_step_dev(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step_dev, coef, skip_if_nonzero, S(stream));
 }
 
 int sf_store_u32x4(uint32_t* dst, uint32_t a, uint32_t b, uint32_t c, uint32_t d, sf_stream stream) {

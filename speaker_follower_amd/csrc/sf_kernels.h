@@ -138,7 +138,7 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr,
               double beta2, double eps, double wd, int step, hipStream_t st);
 // the same with the 1-based step counter ON THE DEVICE (incremented by the call; coef: 2 floats of scratch)
 int adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
-                  double eps, double wd, int* step_dev, float* coef, hipStream_t st);
+                  double eps, double wd, int* step_dev, float* coef, const unsigned* guard, hipStream_t st);
 struct RowMoves {                         // sf_move_rows
     struct M { const float* src; float* dst; const int* idx; int lds, ldd, w, scatter; } m[4];
     int n;

@@ -760,16 +760,25 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 }
 // the step counter of a CAPTURED optimizer step lives on the device: ++step, then the two step-dependent constants in
 // double, rounded to float once (what adam_step does on the host)
-__global__ void adam_coef_kernel(int* step, double lr, double beta1, double beta2, float* coef) {
+// `guard` (optional): a device word -- the fault word of the persistent launches -- that, when non-zero, turns this
+// optimizer step into a no-op (coef[2] = 1: adam_kernel returns, the counter stays): a captured training iteration must
+// not step on gradients a starved launch has poisoned, and nobody can look at the word between two nodes of a graph.
+__global__ void adam_coef_kernel(int* step, double lr, double beta1, double beta2, float* coef, const unsigned* guard) {
     if (threadIdx.x != 0) return;
+    if (guard && *guard != 0u) {
+        coef[2] = 1.f;
+        return;
+    }
     const int s = *step + 1;
     *step = s;
     const double bc1 = 1.0 - pow(beta1, (double)s), bc2 = 1.0 - pow(beta2, (double)s);
     coef[0] = (float)(lr / bc1);
     coef[1] = (float)(1.0 / sqrt(bc2));
+    coef[2] = 0.f;
 }
 __global__ __launch_bounds__(TPB) void adam_kernel(AdamArgs a) {
     if (a.coef) {
+        if (a.coef[2] != 0.f) return;                            // guarded step: see adam_coef_kernel
         a.step_size = a.coef[0];
         a.inv_sqrt_bc2 = a.coef[1];
     }
@@ -880,8 +889,8 @@ int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr,
     return launch_status();
 }
 int adam_step_dev(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1, double beta2,
-                  double eps, double wd, int* step_dev, float* coef, hipStream_t st) {
-    SF_LAUNCH(adam_coef_kernel, dim3(1), dim3(64), 0, st, step_dev, lr, beta1, beta2, coef);
+                  double eps, double wd, int* step_dev, float* coef, const unsigned* guard, hipStream_t st) {
+    SF_LAUNCH(adam_coef_kernel, dim3(1), dim3(64), 0, st, step_dev, lr, beta1, beta2, coef, guard);
     AdamArgs a{p, g, m, v, n, (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps,
                (float)wd, 0.f, 0.f, coef};
     const size_t n4 = (n + 3) >> 2;

@@ -179,7 +179,7 @@ class FollowerEngine:
         H, E = enc.hidden_size * enc.num_directions, enc.embedding_size
         F, V = store.F, store.V
         D = dec.visual_attention_layer.linear_in_h.weight.shape[0]
-        T = max(batch.lengths)
+        T = batch.mask.shape[1]                  # (= max(batch.lengths), or wider: a batch of fixed shapes, nav.DeviceNavBatch)
         Lpad = batch.seq.shape[1]
         training = dec.training if train is None else train
         new = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)  # noqa: E731

@@ -141,14 +141,18 @@ class DeviceNavBatch:
     `vp/view/a_num/cand_view/sincos/target` are [S+1, B, ...] buffers that `advance` fills one step
     ahead of the decoder (slot 0 = the initial observation)."""
 
-    def __init__(self, nav, items, steps, max_length=80, reverse=True, row0=0):
-        env, dev = nav.env, nav.device
+    def __init__(self, nav, items, steps, max_length=80, reverse=True, row0=0, fixed_shapes=False):
+        """fixed_shapes: every tensor gets the shape of the LARGEST minibatch of this size (instructions padded to
+        max_length, goal-hop rows as long as the largest scan) so that `load(items)` can refresh the batch in place --
+        what a captured training graph reads (runtime.TrainingGraph) must keep its addresses."""
+        dev = nav.device
         self.nav, self.items, self.steps = nav, items, steps
+        self.max_length, self.reverse, self.fixed = max_length, reverse, fixed_shapes
         B, A, S = len(items), nav.A, steps
-        self.seq, mask, self.lengths = batch_instructions_from_encoded(
-            [it['instr_encoding'] for it in items], max_length, reverse=reverse, device=dev)
-        self.mask = mask.to(torch.uint8).contiguous()
-        self.lengths_dev = torch.tensor(self.lengths, dtype=torch.int32, device=dev)
+        h = self._host_arrays(items)
+        self.lengths = h['lengths'].tolist()
+        to = lambda x: torch.from_numpy(x).to(dev)                                        # noqa: E731
+        self.seq, self.mask, self.lengths_dev = to(h['seq']), to(h['mask']), to(h['lengths'])
         self.a_max, self.row0 = A, row0
         z = lambda *s, dt=torch.int32: torch.zeros(*s, dtype=dt, device=dev)             # noqa: E731
         self.row = z(S + 1, B)
@@ -156,24 +160,44 @@ class DeviceNavBatch:
         self.cand_view = z(S + 1, B, A)
         self.sincos = z(S + 1, B, A, 4, dt=torch.float32)
         self.target = z(S + 1, B, dt=torch.int64)
-        # start states: newEpisode snaps the item's heading to the discrete view (env.py:814-819)
-        rows, views = [], []
-        ld = max(nav.scan_rows[it['scan']] for it in items)
-        hop = np.zeros((B, ld), np.int32)
-        base = np.zeros(B, np.int32)
-        for b, it in enumerate(items):
-            view = env.start_view(WorldState(it['scan'], it['path'][0], it['heading'], 0))
-            rows.append(nav.row_of[(it['scan'], it['path'][0])])
-            views.append(view)
-            h = nav.hops(it['scan'], it['path'][-1])
-            hop[b, :len(h)] = h
-            base[b] = nav.base[it['scan']]
-        self.row0_state = torch.tensor(rows, dtype=torch.int32, device=dev)
-        self.view0_state = torch.tensor(views, dtype=torch.int32, device=dev)
-        self.goal_hop = torch.from_numpy(hop).to(dev)
-        self.hop_base = torch.from_numpy(base).to(dev)
-        self.ld_hop = ld
+        self.row0_state, self.view0_state = to(h['rows']), to(h['views'])
+        self.goal_hop, self.hop_base = to(h['hop']), to(h['base'])
+        self.ld_hop = h['hop'].shape[1]
         self._nav_struct = nav.struct()
+
+    def _host_arrays(self, items):
+        """What a minibatch contributes: the encoded instructions (follower.py:75-105) and, per item, the start state
+        (newEpisode snaps the item's heading to the discrete view, env.py:814-819) and the hop table towards its goal."""
+        nav, env = self.nav, self.nav.env
+        seq, mask, lengths = batch_instructions_from_encoded([it['instr_encoding'] for it in items], self.max_length,
+                                                             reverse=self.reverse, device='cpu')
+        seq = seq.numpy()
+        mask = (seq == 0) if self.fixed else mask.numpy()                                 # (PAD = 0; full width when fixed)
+        B = len(items)
+        ld = max(nav.scan_rows.values()) if self.fixed else max(nav.scan_rows[it['scan']] for it in items)
+        rows, views = np.zeros(B, np.int32), np.zeros(B, np.int32)
+        hop, base = np.zeros((B, ld), np.int32), np.zeros(B, np.int32)
+        for b, it in enumerate(items):
+            views[b] = env.start_view(WorldState(it['scan'], it['path'][0], it['heading'], 0))
+            rows[b] = nav.row_of[(it['scan'], it['path'][0])]
+            hp = nav.hops(it['scan'], it['path'][-1])
+            hop[b, :len(hp)] = hp
+            base[b] = nav.base[it['scan']]
+        return dict(seq=np.ascontiguousarray(seq), mask=np.ascontiguousarray(mask.astype(np.uint8)),
+                    lengths=np.asarray(lengths, np.int32), rows=rows, views=views, hop=hop, base=base)
+
+    def load(self, items):
+        """The next minibatch INTO the same device tensors (fixed_shapes only): seven small H2D copies on the current
+        stream; the observation slots are rewritten by the rollout itself."""
+        if not self.fixed:
+            raise ValueError('DeviceNavBatch.load needs fixed_shapes=True')
+        if len(items) != self.batch_size:
+            raise ValueError('DeviceNavBatch.load: %d items for a batch of %d' % (len(items), self.batch_size))
+        h = self._host_arrays(items)
+        self.items, self.lengths = items, h['lengths'].tolist()
+        for dst, key in ((self.seq, 'seq'), (self.mask, 'mask'), (self.lengths_dev, 'lengths'), (self.row0_state, 'rows'),
+                         (self.view0_state, 'views'), (self.goal_hop, 'hop'), (self.hop_base, 'base')):
+            dst.copy_(torch.from_numpy(h[key]))
 
     @property
     def batch_size(self):

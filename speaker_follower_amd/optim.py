@@ -104,7 +104,8 @@ class FusedAdam(torch.optim.Optimizer):
                 # the step counter lives on the device (bind_device_steps): the kernel increments and uses it
                 _lib.call('sf_adam_step_dev', ptr(f['p']), ptr(g), ptr(f['m']), ptr(f['v']), f['p'].numel(),
                           float(group['lr']), float(b1), float(b2), float(group['eps']),
-                          float(group['weight_decay']), f['step_dev'], ptr(f['coef']), stream())
+                          float(group['weight_decay']), f['step_dev'], ptr(f['coef']), self._guard_ptr(f['p'].device),
+                          stream())
             else:
                 _lib.call('sf_adam_step', ptr(f['p']), ptr(g), ptr(f['m']), ptr(f['v']), f['p'].numel(),
                           float(group['lr']), float(b1), float(b2), float(group['eps']),
@@ -114,6 +115,16 @@ class FusedAdam(torch.optim.Optimizer):
             ps = f['params']
             torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
         return loss
+
+    # `guard_faults = True`: a device-side step (bind_device_steps) becomes a no-op while the fault word of the CURRENT
+    # stream's workspace is set -- a captured iteration never steps on gradients a starved persistent launch poisoned
+    guard_faults = False
+
+    def _guard_ptr(self, device):
+        if not self.guard_faults:
+            return None
+        from .runtime import fault_word
+        return _lib.C.c_void_p(fault_word(device).data_ptr())
 
     # ---- a step that can live inside a hipGraph (runtime.TrainingGraph): the 1-based step counter is a device word the
     # host writes in front of every replay (kernel arguments are frozen in a graph, device memory is not)
@@ -130,7 +141,7 @@ class FusedAdam(torch.optim.Optimizer):
         assert len(words) == len(live)
         for f, w in zip(live, words):
             f['step_dev'] = _lib.C.c_void_p(w.data_ptr())
-            f['coef'] = torch.zeros(2, dtype=torch.float32, device=f['p'].device)
+            f['coef'] = torch.zeros(4, dtype=torch.float32, device=f['p'].device)
             f['step_word'] = w
 
     def host_steps(self):

@@ -162,6 +162,12 @@ def _fault_view(ws):
     return ws[off:off + 4].view(torch.int32)
 
 
+def fault_word(device):
+    """The fault word (int32[1] view) of the CURRENT stream's workspace: what the persistent launches issued on this
+    stream raise, what optim.FusedAdam.guard_faults makes a device-side optimizer step look at."""
+    return _fault_view(workspace(device))
+
+
 def take_fault(device):
     """Reads AND clears the fault words of EVERY workspace of `device` (one per stream that ever ran library
     calls: the backward's side streams and captured rollouts have their own).  A host sync: callers put it where

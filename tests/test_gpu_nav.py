@@ -256,3 +256,88 @@ def test_agent_api_with_device_env_trains_and_tests(world, tmp_path):
     agent.train(oe, od, 6, feedback='teacher')
     assert len(agent.losses) == 6 and all(np.isfinite(agent.losses))
     assert min(agent.losses[3:]) < agent.losses[0]
+
+
+def _fresh_agent(world, graph, lr=1e-3):
+    from speaker_follower_amd import agents, model, optim, synth
+    env, _, store, nt, enc0, dec0 = world
+    d = synth.FULL
+    enc = model.EncoderLSTM(d.vocab, d.word, d.hidden, 0, 0.5, glove=enc0.embedding.weight.detach().cpu().numpy())
+    dec = model.AttnDecoderLSTM(d.feat, d.hidden, 0.5, feature_size=d.feat)
+    enc.load_state_dict(enc0.state_dict())
+    dec.load_state_dict(dec0.state_dict())
+    enc.cuda()
+    dec.cuda()
+    torch.manual_seed(4)
+    ag = agents.Seq2SeqAgent(env, '/tmp/sf_nav_train.json', enc, dec, episode_len=EPISODE)
+    ag.store = store
+    ag.use_device_env(nt)
+    ag.train_graph = graph
+    oe = optim.FusedAdam([p for p in enc.parameters() if p.requires_grad], lr=lr, weight_decay=5e-4)
+    od = optim.FusedAdam([p for p in dec.parameters() if p.requires_grad], lr=lr, weight_decay=5e-4)
+    # (the env reshuffles its items with `random` when an epoch wraps, env.py:601-614: same order, same generator state
+    # for every agent built here)
+    import random
+    if not hasattr(env, '_items_in_order'):
+        env._items_in_order = list(env.data)
+    env.data[:] = env._items_in_order
+    random.seed(11)
+    env.reset_epoch()
+    return ag, oe, od, lambda: torch.cat([p.detach().reshape(-1) for m in (enc, dec) for p in m.parameters()]).clone()
+
+
+def test_agent_train_runs_whole_iterations_as_graph_replays(world):
+    """Seq2SeqAgent.train (follower.py:1001-1020) with optim.FusedAdam on the device environment: after the first
+    iteration every iteration is one replay over the NEXT minibatch (nav.DeviceNavBatch.load) -- the losses and the
+    weights of the loop that issues every launch (instructions padded to the minibatch's longest there, to
+    max_instruction_length here: equal up to the summation order of the padded attention columns)."""
+    out = {}
+    for graph in (False, True):
+        # (teacher feedback, dropout 0.5, lr 1e-4: a drawn action would turn a 1e-7 difference in a probability into a
+        # different walk sooner or later; that a replay draws the eager loop's samples is pinned bit for bit at engine
+        # level, test_training_graph_over_the_device_environment)
+        ag, oe, od, weights = _fresh_agent(world, graph, lr=1e-4)
+        ag.train(oe, od, 3, feedback='teacher')
+        first = list(ag.losses)
+        ag.train(oe, od, 3, feedback='teacher')                # (a second call: the graph is kept)
+        assert (ag.__dict__.get('_train_graph_state') is not None) == graph
+        if graph:
+            assert ag._train_graph_state[1].replays == 5 and oe.host_steps() == [6] and od.host_steps() == [6]
+        out[graph] = (first + list(ag.losses), weights())
+    print('[agent.train] losses eager', out[False][0], 'graph', out[True][0])
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-4)
+    assert len(set(out[True][0])) == 6
+    d = (out[True][1] - out[False][1]).abs().max().item()
+    print('[agent.train] max weight difference graph vs eager after 6 iterations: %.2e' % d)
+    assert d < 3e-4 and torch.isfinite(out[True][1]).all()     # (Adam: a near-zero gradient whose sign differs moves a weight by lr per step)
+
+
+def test_agent_train_on_graphs_survives_a_starved_persistent_launch(world):
+    """A fault word raised inside a replayed iteration: the guarded optimizer steps do nothing on the device
+    (sf_adam_step_dev), the agent sees the word where it reads the loss, restores its step counters and trains that
+    minibatch again on the per-step kernels."""
+    from speaker_follower_amd import runtime
+    ag, oe, od, weights = _fresh_agent(world, True)
+    ag.train(oe, od, 2, feedback='sample')
+    tg = ag._train_graph_state[1]
+    w0 = weights()
+    with torch.cuda.stream(tg.stream):
+        fw = runtime.fault_word(torch.device('cuda', 0))       # the capture stream's workspace: what the graph raises
+    replay = tg.replay
+
+    def poisoned():
+        fw.fill_(runtime.FAULT_ENC_BWD)                            # as if the backward's persistent launch had starved
+        st = replay()
+        torch.cuda.synchronize()
+        assert torch.equal(weights(), w0)                          # the guarded steps did not touch the weights
+        return st
+    tg.replay = poisoned
+    try:
+        ag.train(oe, od, 1, feedback='sample')
+    finally:
+        tg.replay = replay
+    assert ag._engine.fallbacks == 1 and oe.host_steps() == [3] and od.host_steps() == [3]
+    w1 = weights()
+    assert torch.isfinite(w1).all() and not torch.equal(w1, w0) and np.isfinite(ag.losses).all()
+    ag.train(oe, od, 2, feedback='sample')                         # and the graph goes on behind it
+    assert oe.host_steps() == [5] and torch.isfinite(weights()).all()

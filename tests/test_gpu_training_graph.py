@@ -211,3 +211,37 @@ def test_adam_step_with_a_device_side_counter():
     for p, q in zip(a, b):
         assert torch.equal(p.detach(), q.detach())
 
+
+
+def test_guarded_adam_step_skips_while_the_fault_word_is_set():
+    """optim.FusedAdam.guard_faults: a device-side step is a no-op (parameters, moments, counter untouched) while the
+    fault word of the current stream's workspace is non-zero, and an ordinary step once it is cleared."""
+    from speaker_follower_amd import optim, runtime
+    torch.manual_seed(1)
+    p = [torch.nn.Parameter(torch.randn(515, device='cuda'))]
+    q = [torch.nn.Parameter(p[0].detach().clone())]
+    guarded, plain = optim.FusedAdam(p, lr=1e-3, weight_decay=5e-4), optim.FusedAdam(q, lr=1e-3, weight_decay=5e-4)
+    word, word_q = (torch.zeros(1, dtype=torch.int32, device='cuda') for _ in range(2))
+    guarded.bind_device_steps([word])
+    plain.bind_device_steps([word_q])
+    guarded.guard_faults = True
+    fw = runtime.fault_word(torch.device('cuda', 0))
+    assert int(fw) == 0
+    try:
+        for it in range(4):
+            g = torch.randn_like(p[0])
+            p[0].grad, q[0].grad = g.clone(), g.clone()
+            before = p[0].detach().clone()
+            if it == 2:
+                fw.fill_(runtime.FAULT_ENC_BWD)                     # a starved backward launch raised its bit
+                guarded.step()
+                torch.cuda.synchronize()
+                assert torch.equal(p[0].detach(), before) and int(word) == 2
+                fw.zero_()
+                guarded.set_host_steps([2])                         # (what the host does when it sees the fault)
+            guarded.step()
+            plain.step()
+        torch.cuda.synchronize()
+    finally:
+        fw.zero_()
+    assert int(word) == 4 and torch.equal(p[0].detach(), q[0].detach())
