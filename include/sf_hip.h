@@ -172,6 +172,11 @@ typedef struct sf_decoder_tape {
  * after allocation (its last 4 KB hold self-maintaining ticket counters of multi-workgroup
  * kernels); after that the library owns its contents.  One workspace per concurrently used stream. */
 size_t sf_workspace_bytes(void);
+/* Recommended size of the scratch buffer handed to the WEIGHT-GRADIENT entry points (sf_attn_decoder_wgrad): with this
+ * much they form the decoder's small weight gradients in three grouped launches (transposed operands + K-split slabs of
+ * all of them at once); with sf_workspace_bytes() they fall back to one product at a time.  No zero-fill needed; a
+ * buffer of its own -- not a bigger workspace for every call: the decode steps run 2 % slower over a 256 MB workspace. */
+size_t sf_wgrad_workspace_bytes(void);
 int sf_abi_version(void);
 /* Hash (16 hex digits) of the sources, headers and compiler flags this library was built from
  * (speaker_follower_amd/build.py: build_id()).  The Python binding compares it with the sources on disk at import

@@ -144,6 +144,7 @@ WS = [c_p, C.c_size_t, c_p]          # ws, ws_bytes, stream
 
 _SIGNATURES = {
     'sf_workspace_bytes': (C.c_size_t, []),
+    'sf_wgrad_workspace_bytes': (C.c_size_t, []),
     'sf_abi_version': (C.c_int, []),
     'sf_build_id': (C.c_char_p, []),
     'sf_debug_persist_timeout': (None, [C.c_longlong]),

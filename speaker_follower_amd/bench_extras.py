@@ -401,8 +401,31 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
         loss_g = float(tg.state.loss_buf)
     except Exception as exc:                     # (reported, not fatal: the eager figure stands)
         out['train_sample_feedback_graph_error'] = repr(exc)[:300]
-    # (c) configs[4] on the same world: state-factored search K = 40 over a minibatch of 64 instructions
+    # (b') the same training through the agents' API (Seq2SeqAgent.train, follower.py:1001-1020) on a NEW minibatch every
+    # iteration, host packing of the minibatch and the loss read included: replayed graphs (the default with
+    # optim.FusedAdam on the device environment) and launch by launch
     from . import agents
+    try:
+        api = {}
+        for mode in ('graph', 'eager'):
+            e.reset_epoch()
+            ag = agents.Seq2SeqAgent(e, '/tmp/sf_bench_agent_train.json', enc2, dec2, episode_len=steps)
+            ag.store = store
+            ag.use_device_env(nt)
+            ag.train_graph = mode == 'graph'
+            ag.train(oe, od, 3, feedback='sample')                  # warm-up (graph mode: one eager iteration + capture)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            ag.train(oe, od, train_iters, feedback='sample')
+            torch.cuda.synchronize()
+            api[mode] = dict(ms_per_iteration=1e3 * (time.perf_counter() - t1) / train_iters, loss=float(ag.losses[-1]),
+                             fallbacks=int(ag._engine.fallbacks))
+        api['what'] = ('Seq2SeqAgent.train(FusedAdam, FusedAdam, n, feedback="sample") on the device environment, a new '
+                       'minibatch of %d per iteration (packing, 7 small H2D copies and the loss read inside the time)' % batch)
+        out['train_through_the_agent_api'] = api
+    except Exception as exc:                     # (reported, not fatal)
+        out['train_through_the_agent_api_error'] = repr(exc)[:300]
+    # (c) configs[4] on the same world: state-factored search K = 40 over a minibatch of 64 instructions
     n_mb = 8
     e64, _ = full_world(store, 64, seed=15, n_items=64 * (n_mb + 2))
     agent = agents.Seq2SeqAgent(e64, '/tmp/sf_bench_search_full.json', enc, dec, episode_len=8)

@@ -22,7 +22,7 @@ from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, trainable_embedding)
-from .runtime import ptr, stream, ws_args, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream
+from .runtime import ptr, stream, ws_args, wgrad_ws_args, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream
 from .dp import collectives_on
 
 byref = C.byref
@@ -681,7 +681,7 @@ class FollowerEngine:
         if overlap and not self.encoder_backward_first:
             self._issue_wgrad(side, third, dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, dev, sync)
         elif not overlap:
-            self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, ws, sync)
+            self._decoder_wgrad(dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, wgrad_ws_args(dev), sync)
         if enc.num_directions == 2:
             if st.enc_graph is not None:         # the two directions' tapes: entered with the decoder's gradients
                 torch.autograd.backward(list(st.enc_graph), [dctx, dh1, dc1])
@@ -704,11 +704,11 @@ class FollowerEngine:
     def _issue_wgrad(self, side, third, dw, dg, params, M, H, D, F, st, tp0, gt0, dev, sync):
         """The decoder's weight gradients on the side stream(s) (which already wait for the backward through time)."""
         with torch.cuda.stream(side):
-            self._decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws_args(dev), sync,
+            self._decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, wgrad_ws_args(dev), sync,
                                 part='lstm' if third is not None else 'all')
         if third is not None:
             with torch.cuda.stream(third):
-                self._decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws_args(dev), sync, part='rest')
+                self._decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, wgrad_ws_args(dev), sync, part='rest')
 
     @staticmethod
     def _decoder_wgrad(dw, dg, params, M, H, D, F, st, tp0, gt0, ws, sync, part='all'):

@@ -123,6 +123,20 @@ def workspace(device):
     return ws
 
 
+_wgrad_workspaces = {}
+
+
+def wgrad_ws_args(device):
+    """(pointer, bytes, stream) of the larger scratch buffer of the weight-gradient entry points (sf_hip.h:
+    sf_wgrad_workspace_bytes), one per (device, stream), allocated on first use -- inference never touches it."""
+    key = (device.index if device.index is not None else torch.cuda.current_device(),
+           torch.cuda.current_stream().cuda_stream)
+    ws = _wgrad_workspaces.get(key)
+    if ws is None:
+        ws = _wgrad_workspaces[key] = torch.empty(lib.sf_wgrad_workspace_bytes(), dtype=torch.uint8, device=device)
+    return C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), stream()
+
+
 def ws_args(device):
     ws = workspace(device)
     return C.c_void_p(ws.data_ptr()), C.c_size_t(ws.numel()), stream()
