@@ -452,6 +452,9 @@ def main(argv=None):
 
     import numpy as np
     import torch
+    # stdout carries the ONE JSON line and nothing else: whatever the modules print on the way (the reference's own
+    # "Using GloVe embedding", model.py:57) goes to stderr
+    result_out, sys.stdout = sys.stdout, sys.stderr
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = 0 if args.share_gpu else int(os.environ.get('LOCAL_RANK', '0'))
@@ -769,8 +772,8 @@ def main(argv=None):
     # a starved persistent launch would have poisoned a rollout with NaN: the fault words say so (0 = healthy)
     from speaker_follower_amd import runtime as _rt
     out['persistent_launch_faults'] = _rt.take_fault(device)
-    print(json.dumps(out))
-    sys.stdout.flush()
+    print(json.dumps(out), file=result_out)
+    result_out.flush()
     if coll:
         torch.distributed.destroy_process_group()
     # a data-parallel run in which ANY rank's persistent launch gave up a wait is not a valid measurement: say so
