@@ -643,6 +643,21 @@ int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const flo
                            float* q, float* gates, float* hs, float* cs, float* ctx, const float* act_emb,
                            float* h_init, const sf_dropout* drop, uint32_t step0, void* ws, size_t ws_bytes,
                            sf_stream stream);
+/* The visual attention's query through ONE float64 product (inference; ABI 8 addition): M_v = W_v^T W_h [F,H] and
+ * c_v = W_v^T b_h [F], formed and kept in float64 by sf_visual_query_fold_f64 (needs w_v_t, w_h_t, b_h; redo it when a
+ * weight changes), turn t_v = W_h h + b_h, q = W_v^T t_v (model.py:310-316) into q = M_v h + c_v: one dependent launch
+ * fewer per path step and one rounding fewer.  sf_speaker_encoder_fwd_folded is sf_speaker_encoder_fwd with that query
+ * (the t_v tape is not written: no backward can follow; `fold` must not be NULL). */
+typedef struct sf_visual_fold64 {
+    const double* m_v; /* [F,H] */
+    const double* c_v; /* [F] */
+} sf_visual_fold64;
+int sf_visual_query_fold_f64(const sf_visual_w* w, int H, int D, int F, double* m_v, double* c_v, sf_stream stream);
+int sf_speaker_encoder_fwd_folded(const sf_visual_fold64* fold, const sf_visual_w* vw, const sf_lstm_w* lw, const float* w_e2d,
+                                  const float* b_e2d, const sf_pano* X0, int Tp, int B, int H, int D, float* xin, float* alpha,
+                                  float* t_v, float* q, float* gates, float* hs, float* cs, float* ctx, const float* act_emb,
+                                  float* h_init, const sf_dropout* drop, uint32_t step0, void* ws, size_t ws_bytes,
+                                  sf_stream stream);
 
 /* ---- the speaker's word loop with its tape, in one call each way (speaker.py:158-197 forward, the backward
  * `loss.backward()` of speaker.py:385 walks) -- what a TRAINING iteration runs (sf_speaker_decode keeps no tape):

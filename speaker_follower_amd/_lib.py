@@ -113,6 +113,11 @@ class Sample(C.Structure):
     _fields_ = [('seed', C.c_uint32), ('stream', C.c_uint32), ('row0', C.c_int32), ('stream_dev', c_p)]
 
 
+class VisualFold64(C.Structure):
+    """sf_visual_fold64."""
+    _fields_ = [('m_v', c_p), ('c_v', c_p)]
+
+
 class RowMove(C.Structure):
     """sf_row_move."""
     _fields_ = [('src', c_p), ('dst', c_p), ('idx', c_p), ('ld_src', C.c_int32), ('ld_dst', C.c_int32),
@@ -238,6 +243,9 @@ _SIGNATURES = {
     'sf_speaker_glue_bwd': (C.c_int, [i32, i32, i32, c_f, i64p, i32, c_f, c_f, c_p]),
     'sf_speaker_encoder_fwd': (C.c_int, [P(VisualW), P(LstmW), c_f, c_f, P(Pano), i32, i32, i32, i32, c_f, c_f, c_f, c_f,
                                          c_f, c_f, c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),
+    'sf_speaker_encoder_fwd_folded': (C.c_int, [P(VisualFold64), P(VisualW), P(LstmW), c_f, c_f, P(Pano), i32, i32, i32, i32,
+                                                c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, c_f, P(Dropout), u32] + WS),
+    'sf_visual_query_fold_f64': (C.c_int, [P(VisualW), i32, i32, i32, c_p, c_p, c_p]),
     'sf_speaker_words_fwd': (C.c_int, [P(SpkDecoderW), i32, i32, i32, i32, i32, i32, i32, i32, i32, i64p, c_f, c_f, c_f,
                                        c_p, i64p, c_p, c_f, c_f, c_f, P(SpkDecoderTape), P(Dropout), u32, P(Sample)] + WS),
     'sf_speaker_words_bwd': (C.c_int, [P(SpkDecoderW), P(SpkDecoderG), i32, i32, i32, i32, i32, i32, i32, i64p, i64p, c_f,

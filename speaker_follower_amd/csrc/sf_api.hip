@@ -229,8 +229,18 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
 // ---- a1 VisualSoftDotAttention ---------------------------------------------------------------------
 int visual_fwd_i(const sf_visual_w* w, const PanoSrc& X, int B, int H, int D, const float* h,
                  float* out, int ldo, float* alpha, float* t_v, float* q, const Dropout& drop,
-                 int col0, Arena ar, hipStream_t st, const sf_decoder_fold* fold = nullptr, bool precise = false) {
+                 int col0, Arena ar, hipStream_t st, const sf_decoder_fold* fold = nullptr, bool precise = false,
+                 const sf_visual_fold64* fold64 = nullptr) {
     const int F = X.IMG + X.LOC;
+    if (precise && !fold && fold64 && fold64->m_v && fold64->c_v && visual_attn_f64_supported(X, B) && !(H & 3)) {
+        // inference through the float64 fold: q = M_v h + c_v in ONE product (t_v is not formed: no backward follows)
+        double* q64 = reinterpret_cast<double*>(ar.take((size_t)B * F * 2));
+        float* part = ar.take(visual_attn_split_floats(B, F));
+        if (q64 && part && ar.tickets()) {
+            TRY(linear_f64_w64(h, H, fold64->m_v, H, fold64->c_v, B, F, H, q64, F, q, F, st));
+            return visual_attn(0, X, B, q, F, alpha, out, ldo, drop, col0, st, part, ar.tickets(), q64);
+        }
+    }
     if (precise && !fold && w->w_v_t && visual_attn_f64_supported(X, B) && !(H & 3) && !(D & 3)) {
         // The speaker's path encoder (csrc/sf_precise.hip): t_v, q and the scores in float64 -- each intermediate is
         // rounded ONCE.  t_v / q also land in their fp32 tapes (the backward reads those).
@@ -1678,12 +1688,11 @@ int sf_speaker_glue_fwd(int B, int vocab, int ldv, const float* logit, const int
 }
 
 // ---- a8 SpeakerEncoderLSTM.forward (model.py:437-457), all path steps in one call -------------------------------------
-int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const float* w_e2d, const float* b_e2d,
+static int speaker_encoder_fwd_i(const sf_visual_fold64* fold64, const sf_visual_w* vw, const sf_lstm_w* lw, const float* w_e2d, const float* b_e2d,
                            const sf_pano* X0, int Tp, int B, int H, int D, float* xin, float* alpha, float* t_v,
                            float* q, float* gates, float* hs, float* cs, float* ctx, const float* act_emb,
                            float* h_init, const sf_dropout* drop, uint32_t step0, void* ws, size_t ws_bytes,
                            sf_stream stream) {
-    SF_ENTER();
     SF_CHECK_ARG(vw && lw && w_e2d && X0 && X0->vp && X0->view && Tp > 0 && B > 0 && xin && alpha && t_v && q && gates && hs &&
                  cs && h_init && (!act_emb || drop) && (!ctx || !drop));
     const int F = X0->IMG + X0->LOC, V = X0->V;
@@ -1696,7 +1705,7 @@ int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const flo
         // (float64 query and scores: see visual_fwd_i / csrc/sf_precise.hip; sf_debug_precise_attention(0) = fp32)
         TRY(visual_fwd_i(vw, pano(&X), B, H, D, hs + t * BH, x_t + F, 2 * F, alpha + (size_t)t * B * V,
                          t_v + (size_t)t * B * D, q + (size_t)t * B * F, make_dropout(drop, 2 * (step0 + t), 2), F,
-                         arena(ws, ws_bytes), S(stream), nullptr, g_precise_attention != 0));
+                         arena(ws, ws_bytes), S(stream), nullptr, g_precise_attention != 0, fold64));
         if (act_emb)
             TRY(dropout_copy(act_emb + (size_t)t * B * F, F, B, F, x_t, 2 * F, make_dropout(drop, 2 * (step0 + t), 2), 0,
                              S(stream)));
@@ -1705,6 +1714,35 @@ int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const flo
                              ws, ws_bytes, stream));
     }
     return sf_linear_fwd(hs + Tp * BH, H, w_e2d, b_e2d, B, H, H, 1, h_init, H, ws, ws_bytes, stream);
+}
+
+int sf_speaker_encoder_fwd(const sf_visual_w* vw, const sf_lstm_w* lw, const float* w_e2d, const float* b_e2d,
+                           const sf_pano* X0, int Tp, int B, int H, int D, float* xin, float* alpha, float* t_v,
+                           float* q, float* gates, float* hs, float* cs, float* ctx, const float* act_emb,
+                           float* h_init, const sf_dropout* drop, uint32_t step0, void* ws, size_t ws_bytes,
+                           sf_stream stream) {
+    SF_ENTER();
+    return speaker_encoder_fwd_i(nullptr, vw, lw, w_e2d, b_e2d, X0, Tp, B, H, D, xin, alpha, t_v, q, gates, hs, cs, ctx, act_emb,
+                                 h_init, drop, step0, ws, ws_bytes, stream);
+}
+
+int sf_speaker_encoder_fwd_folded(const sf_visual_fold64* fold, const sf_visual_w* vw, const sf_lstm_w* lw, const float* w_e2d,
+                                  const float* b_e2d, const sf_pano* X0, int Tp, int B, int H, int D, float* xin, float* alpha,
+                                  float* t_v, float* q, float* gates, float* hs, float* cs, float* ctx, const float* act_emb,
+                                  float* h_init, const sf_dropout* drop, uint32_t step0, void* ws, size_t ws_bytes,
+                                  sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(fold && fold->m_v && fold->c_v);
+    return speaker_encoder_fwd_i(fold, vw, lw, w_e2d, b_e2d, X0, Tp, B, H, D, xin, alpha, t_v, q, gates, hs, cs, ctx, act_emb,
+                                 h_init, drop, step0, ws, ws_bytes, stream);
+}
+
+int sf_visual_query_fold_f64(const sf_visual_w* w, int H, int D, int F, double* m_v, double* c_v, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(w && w->w_v_t && w->w_h_t && w->b_h && m_v && c_v && H > 0 && D > 0 && F > 0 && !(D & 3));
+    // M_v[F,H] = W_v^T[F,D] (W_h^T[H,D])^T, c_v[1,F] = b_h[1,D] (W_v^T[F,D])^T -- both accumulated and kept in float64
+    TRY(linear_f64(w->w_v_t, nullptr, D, w->w_h_t, D, nullptr, F, H, D, m_v, H, nullptr, 0, S(stream)));
+    return linear_f64(w->b_h, nullptr, D, w->w_v_t, D, nullptr, 1, F, D, c_v, F, nullptr, 0, S(stream));
 }
 
 // ---- the speaker's word loop with its tape, one call each way (speaker.py:158-197 and its backward) ------------------

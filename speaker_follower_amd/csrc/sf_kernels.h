@@ -20,6 +20,8 @@ bool visual_attn_f64_supported(const PanoSrc& src, int B);
 // ---- sf_precise.hip: y64 = A W^T + bias on the float64 matrix cores (A fp32 or f64; optional fp32 copy) --------
 int linear_f64(const float* A32, const double* A64, int lda, const float* W, int ldw, const float* bias, int M, int N,
                int K, double* y64, int ldy64, float* y32, int ldy32, hipStream_t st);
+int linear_f64_w64(const float* A32, int lda, const double* W, int ldw, const double* bias, int M, int N, int K,
+                   double* y64, int ldy64, float* y32, int ldy32, hipStream_t st);
 extern int g_precise_attention;       // sf_debug_precise_attention (default 1)
 int text_attn_fwd(const float* ctx, const uint8_t* mask, int B, int L, int H, const float* t,
                   int ldt, float* alpha, float* wc, int ldwc, hipStream_t st,

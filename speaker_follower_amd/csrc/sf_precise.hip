@@ -37,9 +37,9 @@ __device__ __forceinline__ void load4<double>(const double* p, double (&v)[4]) {
     v[0] = t0.x; v[1] = t0.y; v[2] = t1.x; v[3] = t1.y;
 }
 
-template <typename TA>
-__global__ __launch_bounds__(256) void linear_f64_kernel(const TA* __restrict__ A, int lda, const float* __restrict__ W,
-                                                         int ldw, const float* __restrict__ bias, int M, int N, int K,
+template <typename TA, typename TW = float>
+__global__ __launch_bounds__(256) void linear_f64_kernel(const TA* __restrict__ A, int lda, const TW* __restrict__ W,
+                                                         int ldw, const TW* __restrict__ bias, int M, int N, int K,
                                                          double* __restrict__ y64, int ldy64, float* __restrict__ y32,
                                                          int ldy32) {
     __shared__ double red[4][256];
@@ -47,14 +47,14 @@ __global__ __launch_bounds__(256) void linear_f64_kernel(const TA* __restrict__ 
     const int r = lane & 15, kq = lane >> 4;
     const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
     const TA* arow = A + (size_t)min(m0 + r, M - 1) * lda;
-    const float* wrow = W + (size_t)min(n0 + r, N - 1) * ldw;
+    const TW* wrow = W + (size_t)min(n0 + r, N - 1) * ldw;
     f64x4 acc = {0.0, 0.0, 0.0, 0.0};
     for (int kc = wave * 16; kc < K; kc += 64) {
         const int k = kc + 4 * kq;
         const bool ok = k < K;                       // K % 4 == 0 (checked by the launcher): a partial last chunk
         double a[4], w[4];
         load4<TA>(arow + (ok ? k : 0), a);
-        load4<float>(wrow + (ok ? k : 0), w);
+        load4<TW>(wrow + (ok ? k : 0), w);
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             acc = __builtin_amdgcn_mfma_f64_16x16x4f64(ok ? a[j] : 0.0, ok ? w[j] : 0.0, acc, 0, 0, 0);
@@ -85,6 +85,18 @@ int linear_f64(const float* A32, const double* A64, int lda, const float* W, int
     else
         SF_LAUNCH_AS("linear_f64_kernel<f64 in>", linear_f64_kernel<double>, grid, dim3(256), 0, st, A64, lda, W, ldw, bias,
                      M, N, K, y64, ldy64, y32, ldy32);
+    return launch_status();
+}
+
+// The same with FLOAT64 weights and bias (A fp32): the query of the visual attention through the folded matrix
+// M_v = W_v^T W_h [F,H] and c_v = W_v^T b_h [F], both formed and kept in float64 (sf_visual_query_fold_f64) -- one
+// product per path step instead of two dependent ones, and one rounding fewer.
+int linear_f64_w64(const float* A32, int lda, const double* W, int ldw, const double* bias, int M, int N, int K,
+                   double* y64, int ldy64, float* y32, int ldy32, hipStream_t st) {
+    if ((K & 3) || (lda & 3) || (ldw & 3) || M <= 0 || N <= 0 || !A32 || !W) return SF_ERR_UNSUPPORTED;
+    const dim3 grid(ceil_div(N, 16), ceil_div(M, 16));
+    SF_LAUNCH_AS("linear_f64_kernel<f32 in, f64 w>", (linear_f64_kernel<float, double>), grid, dim3(256), 0, st, A32, lda, W,
+                 ldw, bias, M, N, K, y64, ldy64, y32, ldy32);
     return launch_status();
 }
 

@@ -388,6 +388,36 @@ def xw_table(owner, emb, w_ih):
     return owner._xw
 
 
+_query_folds = {}
+
+
+def visual_query_fold(w_h, b_h, w_v):
+    """sf_visual_fold64 of a VisualSoftDotAttention (model.py:303-316): M_v = W_v^T W_h [F,H] and c_v = W_v^T b_h [F] as
+    float64 device tensors, rebuilt (in place) only when one of the three weights changed.  Returns (struct, keep-alive)."""
+    import weakref
+    key = (w_h.data_ptr(), b_h.data_ptr(), w_v.data_ptr())
+    ver = (w_h._version, b_h._version, w_v._version, _cache_epoch)
+    hit = _query_folds.get(key)
+    if hit is not None and hit[0]() is w_h and hit[1] == ver:
+        return hit[2], hit[3]
+    D, H = w_h.shape
+    F = w_v.shape[1]
+    if hit is not None and hit[0]() is w_h:
+        m_v, c_v = hit[3]
+    else:
+        m_v = torch.empty(F, H, device=w_h.device, dtype=torch.float64)
+        c_v = torch.empty(F, device=w_h.device, dtype=torch.float64)
+    vw = _lib.VisualW(w_h.data_ptr(), b_h.data_ptr(), w_v.data_ptr(), None, transposed(w_v).data_ptr(),
+                      transposed(w_h).data_ptr())
+    _lib.call('sf_visual_query_fold_f64', C.byref(vw), H, D, F, C.c_void_p(m_v.data_ptr()), C.c_void_p(c_v.data_ptr()), stream())
+    fold = _lib.VisualFold64(m_v.data_ptr(), c_v.data_ptr())
+    if len(_query_folds) > 64:
+        for k in [k for k, v in _query_folds.items() if v[0]() is None]:
+            del _query_folds[k]
+    _query_folds[key] = (weakref.ref(w_h), ver, fold, (m_v, c_v))
+    return fold, (m_v, c_v)
+
+
 def transposed(w):
     """Device copy of w^T for a 2-D weight, rebuilt (in place) only when the weight changed (torch
     bumps `_version` on every in-place update, e.g. optimizer.step(); see invalidate_caches for

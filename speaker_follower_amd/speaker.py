@@ -19,7 +19,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .model import _grads, trainable_embedding
-from .runtime import ptr, stream, ws_args, dropout_arg, fill_regions, struct_of, transposed, take_fault, PersistentLaunchFault
+from .runtime import ptr, stream, ws_args, dropout_arg, fill_regions, visual_query_fold, struct_of, transposed, take_fault, PersistentLaunchFault
 
 byref = C.byref
 
@@ -115,6 +115,7 @@ class SpeakerEngine:
         # teacher-forced passes: the recurrence as one persistent launch + the attention / projection / glue of all S*B
         # rows at once (sf_speaker_teacher_fwd / _bwd); False: the word loop step by step (or sf_speaker_decode)
         self.teacher_batched = True
+        self.fold_query = True          # inference: the path encoder's attention query through the float64 fold (runtime.visual_query_fold)
         self.fallbacks = 0              # passes re-issued on the per-step kernels after a persistent-launch fault (run)
 
     def capture(self, batch, steps, feedback='teacher'):
@@ -148,6 +149,13 @@ class SpeakerEngine:
             # re-allocated weight cannot be patched into the graph (FollowerEngine.capture)
             if bytes(self.decoder._w_struct()) != baked:
                 raise RuntimeError('a speaker weight moved since this pass was captured; capture() again')
+            # (the encoder's derived layouts likewise: transposed copies and the float64 query fold are rebuilt IN PLACE
+            # when a weight's version moved -- the graph reads the same buffers)
+            ep_ = self.encoder._params8()
+            transposed(ep_[2])
+            transposed(ep_[0])
+            if self.fold_query:
+                visual_query_fold(ep_[0], ep_[1], ep_[2])
             if sampled:
                 call('sf_store_u32x4', C.c_void_p(ctl.data_ptr()), int(self.site_next) & 0xFFFFFFFF, 0, 0, 0, stream())
                 st.site0 = self.site_next
@@ -295,10 +303,19 @@ class SpeakerEngine:
         # all Tp path steps (attention -> [action | feature] -> dropout -> cell) and decoder_init = tanh(encoder2decoder(h))
         # (model.py:437-453) as ONE library call
         pano0 = store.pano(batch.vp, batch.view)
-        call('sf_speaker_encoder_fwd', byref(vw), byref(lw), ptr(e2d.weight), ptr(e2d.bias), byref(pano0), Tp, B, H, D,
-             ptr(st.e['xin']), ptr(st.e['alpha']), ptr(st.e['t_v']), ptr(st.e['q']), ptr(st.e['gates']), ptr(st.e['hs']),
-             ptr(st.e['cs']), ptr(st.ctx) if d_enc is None else None, ptr(st.e['act_emb']), ptr(st.h_init), d_enc,
-             st.site_rel, *ws)
+        enc_args = (byref(vw), byref(lw), ptr(e2d.weight), ptr(e2d.bias), byref(pano0), Tp, B, H, D,
+                    ptr(st.e['xin']), ptr(st.e['alpha']), ptr(st.e['t_v']), ptr(st.e['q']), ptr(st.e['gates']), ptr(st.e['hs']),
+                    ptr(st.e['cs']), ptr(st.ctx) if d_enc is None else None, ptr(st.e['act_emb']), ptr(st.h_init), d_enc,
+                    st.site_rel) + tuple(ws)
+        no_backward = not training and not (torch.is_grad_enabled() and any(
+            p_.requires_grad for p_ in list(ep) + [e2d.weight, e2d.bias] + list(dec._params9())))
+        if no_backward and self.fold_query:
+            # inference: the attention query through the float64 fold M_v = W_v^T W_h (one product per path step instead
+            # of two dependent ones, one rounding fewer); cached per weight version
+            fold, st.e['fold'] = visual_query_fold(ep[0], ep[1], ep[2])
+            call('sf_speaker_encoder_fwd_folded', byref(fold), *enc_args)
+        else:
+            call('sf_speaker_encoder_fwd', *enc_args)
         st.c_init = st.e['cs'][Tp]
         if d_enc is not None:
             ctx_raw = st.e['hs'][1:].permute(1, 0, 2).contiguous()      # [B,Tp,H]

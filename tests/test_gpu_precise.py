@@ -93,3 +93,50 @@ def test_visual_attention_float64_scores(B, indexed):
     assert errs['sf_visual_attention_fwd_f64'][0] <= 1e-6
     assert errs['sf_visual_attention_fwd_f64'][1] <= 5e-6 * max(1.0, float(np.abs(out64).max()))
     assert errs['sf_visual_attention_fwd'][0] <= 1e-3                                   # (sanity of the comparison)
+
+
+def test_folded_attention_query_of_the_speaker_encoder():
+    """Inference through the float64 fold M_v = W_v^T W_h (sf_visual_query_fold_f64, sf_speaker_encoder_fwd_folded): the
+    same words, logits within 2e-5 of the two-product float64 path (both are within 3e-5 of exact arithmetic, G9), the
+    fold follows a weight update in place, and a pass that will be differentiated does not use it."""
+    from speaker_follower_amd import model, features, speaker, synth
+    d = synth.FULL
+    w_enc, w_dec = synth.speaker_weights(23)
+    enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=w_dec['embedding.weight'])
+    enc.load_state_dict({k: torch.tensor(v) for k, v in w_enc.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in w_dec.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    store = features.FeatureStore(synth.feature_table(5, 64))
+    sb = synth.speaker_batch(seed=3, batch=24, n_viewpoints=64, min_path=3, max_path=7, min_len=8, max_len=30)
+    batch = speaker.DeviceSpeakerBatch.from_synth(sb)
+    eng = speaker.SpeakerEngine(enc, dec, store)
+    out = {}
+    with torch.no_grad():
+        for fold in (True, False):
+            eng.fold_query = fold
+            for fb in ('teacher', 'argmax'):
+                st = eng.score(batch, 30, fb, train=False)
+                torch.cuda.synchronize()
+                out[fold, fb] = (st.words.clone(), st.logits.clone(), st.e['q'].clone())
+        for fb in ('teacher', 'argmax'):
+            assert torch.equal(out[True, fb][0], out[False, fb][0])
+            dl = float((out[True, fb][1] - out[False, fb][1]).abs().max())
+            dq = float((out[True, fb][2] - out[False, fb][2]).abs().max() / out[False, fb][2].abs().max())
+            print('[query fold, %s] max |logit difference| %.2e, query difference / scale %.2e' % (fb, dl, dq))
+            assert dl < 2e-5 and dq < 2e-7
+        # a weight update: the fold is rebuilt in place (same buffers) and follows it
+        eng.fold_query = True
+        fold0 = eng.score(batch, 30, 'teacher', train=False).e['fold']
+        ptrs = [t.data_ptr() for t in fold0]
+        before = fold0[0].clone()
+        enc.visual_attention_layer.linear_in_h.weight.mul_(1.01)
+        st = eng.score(batch, 30, 'teacher', train=False)
+        assert [t.data_ptr() for t in st.e['fold']] == ptrs and not torch.equal(st.e['fold'][0], before)
+        eng.fold_query = False
+        ref = eng.score(batch, 30, 'teacher', train=False)
+        assert float((st.logits - ref.logits).abs().max()) < 2e-5
+    eng.fold_query = True
+    st = eng.score(batch, 30, 'teacher', train=False)            # grad enabled, trainable weights: the tape path
+    assert 'fold' not in st.e and st.loss.requires_grad
