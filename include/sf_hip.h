@@ -841,6 +841,10 @@ void sf_debug_many_row_product(int on);
  * many-row product, the slab sum: four dependent launches each) instead of three grouped launches for all of them
  * (csrc/sf_gemm.hip: gemm_tn_group; the default). */
 void sf_debug_grouped_weight_gradients(int on);
+/* A/B switch (round 5): on == 0 puts the slab-sum launch back between the LSTM's data gradient and the visual-attention
+ * backward of a decoder step (the default: the attention backward adds up the K-split slabs of d(feature) itself --
+ * same order, same bits). */
+void sf_debug_slab_consumers(int on);
 /* A/B switch: on == 0 makes sf_speaker_encoder_fwd run its visual attention on the fp32 kernels (rounds 1-4) instead
  * of the float64 query / score path (sf_visual_attention_fwd_f64; the default). */
 void sf_debug_precise_attention(int on);

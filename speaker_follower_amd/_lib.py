@@ -157,6 +157,7 @@ _SIGNATURES = {
     'sf_debug_precise_attention': (None, [C.c_int]),
     'sf_debug_many_row_product': (None, [C.c_int]),
     'sf_debug_grouped_weight_gradients': (None, [C.c_int]),
+    'sf_debug_slab_consumers': (None, [C.c_int]),
     'sf_site_advance': (C.c_int, [c_p, u32, c_p]),
     'sf_store_u32x4': (C.c_int, [c_p, u32, u32, u32, u32, c_p]),
     'sf_adam_step_dev': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,

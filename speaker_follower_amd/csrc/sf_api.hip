@@ -179,13 +179,18 @@ int lstm_fwd_i(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx,
     return lstm_pointwise_fwd(p, st);
 }
 
+static int g_slab_consumers = 1;     // sf_debug_slab_consumers: consumers add up K-split slabs themselves (0: a reduce launch in between)
+
 int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, const float* x, int ldx,
                const float* h0, const float* c0, const float* c1, const float* gates,
                const float* dh1, const float* dh1_b, const float* dc1, float* dx, int lddx,
                float* dh0, float* dc0, Arena ar, hipStream_t st, float* dgates_out = nullptr,
                int dx_col0 = 0,            // dx is only formed for input columns >= dx_col0
                const Dropout* dh1b_drop = nullptr,     // mask still to be applied to dh1_b
-               SmallPlan* dh0_plan = nullptr, bool* dh0_deferred = nullptr) {
+               SmallPlan* dh0_plan = nullptr, bool* dh0_deferred = nullptr,
+               const float** dx_slabs = nullptr, int* dx_ks = nullptr) {   // (with dx_col0 > 0) leave d(x[:, dx_col0:]) as the
+    // K-split slabs of its product: *dx_slabs -> [*dx_ks][B, I - dx_col0] (the consumer adds them up: one launch fewer);
+    // *dx_ks == 0: dx was formed as usual
     // dh0_plan: do not launch dh0 = dgates W_hh; hand its launch plan to the caller (who pairs it with
     // an independent kernel) when the short-reduction kernel covers the shape
     float* dgates = dgates_out ? dgates_out : ar.take((size_t)B * 4 * H);
@@ -199,11 +204,20 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
         TRY(data_grad(dgates, 4 * H, w->w_ih, w->w_ih_t, B, 4 * H, I, dx, lddx, 0, ar, st));
     } else if (dx) {
         const int I2 = I - dx_col0;
+        if (dx_ks) *dx_ks = 0;
         if (w->w_ih_t) {
             Seg sg{dgates, 4 * H, w->w_ih_t + (size_t)dx_col0 * 4 * H, 4 * H, 4 * H};
             LinearOut o{};
             o.y = dx + dx_col0; o.ldy = lddx; o.epi = EPI_NONE;
-            TRY(linear_nt(&sg, 1, B, I2, o, ar.rest(), ar.rest_n(), st));
+            float* slabs = (dx_slabs && dx_ks && g_slab_consumers) ? ar.take((size_t)16 * B * I2) : nullptr;
+            int ks = 0;
+            float* raw = nullptr;
+            if (slabs && linear_nt(&sg, 1, B, I2, o, slabs, (size_t)16 * B * I2, st, &raw, &ks) == SF_OK && raw == slabs && ks >= 1) {
+                *dx_slabs = slabs;
+                *dx_ks = ks;
+            } else {
+                TRY(linear_nt(&sg, 1, B, I2, o, ar.rest(), ar.rest_n(), st));
+            }
         } else {
             TRY(gemm_nn_ws(dgates, 4 * H, w->w_ih + dx_col0, I, B, I2, 4 * H, dx + dx_col0, lddx, 0,
                            ar.rest(), ar.rest_n(), st));
@@ -275,7 +289,8 @@ int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, i
                  const float* h, const float* alpha, const float* t_v, const float* dout, int lddo,
                  const Dropout& drop, int col0, float* dh, Arena ar, hipStream_t st,
                  float* dq_out = nullptr, float* dt_out = nullptr,
-                 const SmallPlan* beside = nullptr) {   // an independent small product to launch with
+                 const SmallPlan* beside = nullptr,     // an independent small product to launch with
+                 int dout_slabs = 0, long dout_slab_stride = 0) {   // dout = the sum of K-split slabs (added up in the kernel)
     const int F = X.IMG + X.LOC;                        // the attention backward (must run either way)
     float* dq = dq_out ? dq_out : ar.take((size_t)B * F);
     float* dt = dt_out ? dt_out : ar.take((size_t)B * D);
@@ -283,12 +298,13 @@ int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, i
     bool paired = false;
     if (beside) {
         const int rc = pair_visbwd_small(X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0,
-                                         *beside, st);
+                                         *beside, st, dout_slabs, dout_slab_stride);
         if (rc == SF_OK) paired = true;
         else if (rc != SF_ERR_UNSUPPORTED) return rc;
         else TRY(launch_small_plan_x(*beside, st));
     }
-    if (!paired) TRY(visual_attn(1, X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0, st));
+    if (!paired) TRY(visual_attn(1, X, B, dout, lddo, const_cast<float*>(alpha), dq, F, drop, col0, st, nullptr, nullptr,
+                                 nullptr, dout_slabs, dout_slab_stride));
     TRY(linear_plain(dq, F, w->w_v, F, nullptr, B, D, F, EPI_NONE, dt, D, ar, st));
     if (g && g->w_v) TRY(gemm_tn(t_v, D, dq, F, B, D, F, g->w_v, F, 1, st, ar.rest(), ar.rest_n()));
     // g->b_v: the bias shifts all V scores of a row equally; its gradient is identically zero.
@@ -447,6 +463,7 @@ void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; 
 void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
 void sf_debug_many_row_product(int on) { sf::g_nt_big = on; }
 void sf_debug_grouped_weight_gradients(int on) { sf::g_tn_group = on; }
+void sf_debug_slab_consumers(int on) { g_slab_consumers = on; }
 int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, sf_stream stream) {
     SF_ENTER();
     return sf::cotenant(blocks, threads, lds_bytes, ticks, sink, S(stream));
@@ -940,12 +957,20 @@ static int decoder_bwd_tail_i(const sf_decoder_w* w, const sf_decoder_g* g, cons
     NEED(dxin);
     SmallPlan dh0_plan;
     bool dh0_deferred = false;
+    const float* df_slabs = nullptr;
+    int df_ks = 0;
     // (the dropout between h1 and the text attention is undone inside the LSTM pointwise backward)
     TRY(lstm_bwd_i(&w->lstm, g ? &g->lstm : nullptr, B, 2 * F, H, tp->xin, 2 * F, h0, c0, tp->c1,
                    tp->gates, dh1, dh1d, dc1, dxin, 2 * F, dh0, dc0, ar, st,
                    gt ? gt->dgates : nullptr, F, &d_h,   // u_prev is detached (follower.py:502): only
-                   &dh0_plan, &dh0_deferred));          // the feature half of d(LSTM input) is needed
-    // dh0 = dgates W_hh rides beside the visual-attention backward (both only need the LSTM backward)
+                   &dh0_plan, &dh0_deferred,            // the feature half of d(LSTM input) is needed
+                   &df_slabs, &df_ks));
+    // dh0 = dgates W_hh rides beside the visual-attention backward (both only need the LSTM backward); the feature
+    // half of d(LSTM input) reaches it as the K-split slabs of its product (no reduce launch in between)
+    if (df_ks >= 1)
+        return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
+                            df_slabs, F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
+                            gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr, df_ks, (long)B * F);
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                         dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
                         gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr);

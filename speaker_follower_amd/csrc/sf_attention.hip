@@ -27,6 +27,8 @@ struct VisArgs {
     Dropout drop;          // fwd: applied to out; bwd: applied to vec (same mask)
     int drop_col0;
     const double* vec64;   // the query in float64 (visual_split_body<0, true>: scores accumulated in float64), or null
+    int vec_slabs;         // MODE 1: `vec` is the sum of this many K-split slabs (0 / 1: a plain vector) ...
+    long vec_slab_stride;  // ... `vec_slab_stride` floats apart: the workgroup adds them up itself (no reduce launch)
 };
 
 __device__ __forceinline__ double wave_sum_f64(double v) {
@@ -67,9 +69,29 @@ __device__ __forceinline__ void visual_attn_body(const VisArgs& a, int b) {
     // (all chunks of the vector requested before the first use: behind the dropout branch below each load
     //  would otherwise be its own memory round trip)
     float4 qv[VIS_CPL];
+    if (MODE == 1 && a.vec_slabs > 1) {
+        // the vector arrives as K-split slabs of the product that formed it (the LSTM's data gradient): thread c adds
+        // up float4 c of this row in slab order (the order reduce_slabs_kernel uses: same bits) into LDS, once per
+        // workgroup, while the panorama rows are still on their way
+        __shared__ float4 s_vec[VIS_CPL * 64];
+        const int c = threadIdx.x;
+        if (c < n4) {
+            const float4* p0 = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec) + c;
+            float4 t = *p0;
+            for (int sl = 1; sl < a.vec_slabs; ++sl) {
+                const float4 u = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p0) + (size_t)sl * a.vec_slab_stride);
+                t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+            }
+            s_vec[c] = t;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < VIS_CPL; ++i) qv[i] = s_vec[min(lane + 64 * i, n4 - 1)];
+    } else {
 #pragma unroll
     for (int i = 0; i < VIS_CPL; ++i)
         qv[i] = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[min(lane + 64 * i, n4 - 1)];
+    }
 #pragma unroll
     for (int i = 0; i < VIS_CPL; ++i) {
         const int c = lane + 64 * i;
@@ -852,12 +874,13 @@ bool visual_attn_f64_supported(const PanoSrc& src, int B) {
 
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
                 float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st,
-                float* split_part, unsigned* split_counter, const double* vec64) {
+                float* split_part, unsigned* split_counter, const double* vec64, int vec_slabs, long vec_slab_stride) {
     const int F = src.IMG + src.LOC;
     if (src.V > VIS_RPW * VIS_NW || src.V > 64 || F > VIS_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) || (ldvec & 3) || (ldo & 3))
         return SF_ERR_UNSUPPORTED;
-    VisArgs a{src, vec, ldvec, alpha, out, ldo, drop, drop_col0, vec64};
+    VisArgs a{src, vec, ldvec, alpha, out, ldo, drop, drop_col0, vec64, mode == 1 ? vec_slabs : 0, vec_slab_stride};
+    if (mode != 1 && vec_slabs > 1) return SF_ERR_UNSUPPORTED;
     if (vec64) {        // float64 scores: the two-workgroup forward only (callers check visual_attn_f64_supported)
         if (mode != 0 || !split_part || !split_counter || !visual_attn_f64_supported(src, B)) return SF_ERR_UNSUPPORTED;
         SF_LAUNCH(visual_attn_split_f64_kernel, dim3(VSP_G, B), dim3(VSP_NW * 64), 0, st, a,
@@ -1021,13 +1044,14 @@ int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, i
 // visual-attention backward (mode 1 of visual_attn) paired with a small product (mt 1, cpw 16: the
 // K = 4H recurrent data gradient); SF_ERR_UNSUPPORTED = not pairable, launch separately
 int pair_visbwd_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
-                      int ldo, const Dropout& drop, int drop_col0, const SmallPlan& b, hipStream_t st) {
+                      int ldo, const Dropout& drop, int drop_col0, const SmallPlan& b, hipStream_t st, int vec_slabs,
+                      long vec_slab_stride) {
     const int F = src.IMG + src.LOC;
     if (!(b.mt == 1 && b.cpw == 16)) return SF_ERR_UNSUPPORTED;
     if (src.V > VIS_RPW * VIS_NW || src.V > 64 || F > VIS_CPL * 256 || (F & 3) ||
         (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) || (ldvec & 3) || (ldo & 3))
         return SF_ERR_UNSUPPORTED;
-    VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0};
+    VisArgs va{src, vec, ldvec, alpha, out, ldo, drop, drop_col0, nullptr, vec_slabs, vec_slab_stride};
     const int nb = b.gx * b.gy;
     SF_LAUNCH((pair_visbwd_small_kernel<1, 16>), dim3(B + nb), dim3(VIS_NW * 64), 0, st, va, B,
                        b.args, b.gx);

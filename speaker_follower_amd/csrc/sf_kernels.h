@@ -13,7 +13,8 @@ namespace sf {
 size_t visual_attn_split_floats(int B, int F);
 int visual_attn(int mode, const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha,
                 float* out, int ldo, const Dropout& drop, int drop_col0, hipStream_t st,
-                float* split_part = nullptr, unsigned* split_counter = nullptr, const double* vec64 = nullptr);
+                float* split_part = nullptr, unsigned* split_counter = nullptr, const double* vec64 = nullptr,
+                int vec_slabs = 0, long vec_slab_stride = 0);   // (mode 1: vec = sum of K-split slabs, added up in the kernel)
 // vec64: the forward with its scores accumulated in float64 from a float64 query (csrc/sf_precise.hip)
 bool visual_attn_f64_supported(const PanoSrc& src, int B);
 
@@ -185,7 +186,8 @@ int pair_small_text(const SmallPlan& a, const float* ctx, const uint8_t* mask, i
                     const float* t, int ldt, float* alpha, float* wc, int ldwc,
                     const int32_t* ctx_row, hipStream_t st);
 int pair_visbwd_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
-                      int ldo, const Dropout& drop, int drop_col0, const SmallPlan& b, hipStream_t st);
+                      int ldo, const Dropout& drop, int drop_col0, const SmallPlan& b, hipStream_t st, int vec_slabs = 0,
+                      long vec_slab_stride = 0);
 int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out,
                    int ldo, const Dropout& drop, int drop_col0, float* split_part,
                    unsigned* split_counter, const SmallPlan& b, hipStream_t st, int phase = 0);

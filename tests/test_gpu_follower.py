@@ -244,6 +244,39 @@ def test_grouped_weight_gradients_match_the_reference_and_the_single_products(fo
         m.zero_grad(set_to_none=True)
 
 
+def test_attention_backward_adds_up_the_data_gradient_slabs_itself(follower_modules, golden):
+    """The feature half of d(LSTM input) reaches the visual-attention backward as the K-split slabs of its product
+    (sf_debug_slab_consumers): one launch fewer per backward step, the SAME bits as the slab-sum launch it replaces
+    (same order of additions), on one stream and on two, and the reference's gradients (G4, B = 100)."""
+    from speaker_follower_amd import _lib
+    enc, dec, _, _ = follower_modules
+    fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=256)
+    table = synth.feature_table(0, 256)
+    g = golden('g4_rollout_b100_teacher')
+    engine, follower = _engine(follower_modules, table)
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    for two_stream in (True, False):
+        engine.two_stream_backward = two_stream
+        grads = {}
+        for on in (1, 0):
+            _lib.lib.sf_debug_slab_consumers(on)
+            try:
+                for m in (enc, dec):
+                    m.zero_grad(set_to_none=True)
+                st = engine.rollout(batch, int(g['n_steps']), 'teacher', train=False)
+                st.loss.backward()
+                torch.cuda.synchronize()
+            finally:
+                _lib.lib.sf_debug_slab_consumers(1)
+            grads[on] = {k: p.grad.clone() for m, pre in ((enc, 'enc/'), (dec, 'dec/'))
+                         for k, p in ((pre + k, p) for k, p in m.named_parameters()) if p.grad is not None}
+        for k, a in grads[1].items():
+            assert torch.equal(a, grads[0][k]), k
+        _check_grads({k[4:]: v for k, v in grads[1].items() if k.startswith('dec/')}, g, 'dec/')
+    for m in (enc, dec):
+        m.zero_grad(set_to_none=True)
+
+
 def test_module_api_teacher_gradients_match_engine(follower_modules, batch8):
     """The per-step nn.Module path (autograd Functions) and the fused engine agree."""
     enc, dec, _, _ = follower_modules

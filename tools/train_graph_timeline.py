@@ -18,6 +18,8 @@ oe = optim.FusedAdam([p for p in enc.parameters() if p.requires_grad], lr=1e-4, 
 od = optim.FusedAdam([p for p in dec.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4)
 eng = follower.FollowerEngine(enc, dec, store)
 from speaker_follower_amd import _lib
+if 'SF_SLAB_CONSUMERS' in os.environ:
+    _lib.lib.sf_debug_slab_consumers(int(os.environ['SF_SLAB_CONSUMERS']))
 if 'SF_GROUPED' in os.environ:
     _lib.lib.sf_debug_grouped_weight_gradients(int(os.environ['SF_GROUPED']))
 for k, v in os.environ.items():                       # e.g. SF_ENGINE_split_wgrad_streams=1
