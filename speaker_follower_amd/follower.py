@@ -22,7 +22,7 @@ from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, trainable_embedding)
-from .runtime import ptr, stream, ws_args, wgrad_ws_args, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream
+from .runtime import ptr, stream, ws_args, wgrad_ws_args, ensure_workspace, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream
 from .dp import collectives_on
 
 byref = C.byref
@@ -473,6 +473,7 @@ class FollowerEngine:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
+            ensure_workspace(side, self.store.device)                  # (created and zero-filled OUTSIDE the graph)
             side.wait_stream(torch.cuda.current_stream())
             keep = (self.site_next, self.iteration)
             self.site_word = ctl[0:1] if sampled else None

@@ -118,9 +118,22 @@ def workspace(device):
            torch.cuda.current_stream().cuda_stream)
     ws = _workspaces.get(key)
     if ws is None:
+        if torch.cuda.is_current_stream_capturing():
+            # a zero-fill issued here would become a node of the graph: 64 MB re-zeroed by EVERY replay (15-30 us; it
+            # rode in every captured rollout until round 5: profiles/r05_z_*)
+            raise RuntimeError('the workspace of a capture stream must exist before the capture begins: '
+                               'runtime.ensure_workspace(stream, device)')
         ws = torch.zeros(lib.sf_workspace_bytes(), dtype=torch.uint8, device=device)   # zero ONCE: sf_hip.h
         _workspaces[key] = ws
     return ws
+
+
+def ensure_workspace(stream_, device):
+    """Creates (and zero-fills, eagerly) the workspace of `stream_` -- what every capture does for its capture stream
+    BEFORE torch.cuda.graph(...): a workspace first touched inside a capture would be zero-filled by every replay."""
+    with torch.cuda.stream(stream_):
+        workspace(device)
+    stream_.synchronize()
 
 
 _wgrad_workspaces = {}

@@ -19,7 +19,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .model import _grads, trainable_embedding
-from .runtime import ptr, stream, ws_args, dropout_arg, fill_regions, visual_query_fold, struct_of, transposed, take_fault, PersistentLaunchFault
+from .runtime import ptr, stream, ws_args, ensure_workspace, dropout_arg, fill_regions, visual_query_fold, struct_of, transposed, take_fault, PersistentLaunchFault
 
 byref = C.byref
 
@@ -130,6 +130,7 @@ class SpeakerEngine:
             torch.cuda.synchronize()
             graph = torch.cuda.CUDAGraph()
             side = torch.cuda.Stream()
+            ensure_workspace(side, self.store.device)              # (created and zero-filled OUTSIDE the graph)
             side.wait_stream(torch.cuda.current_stream())
             keep = (self.site_next, self.iteration)
             self.site_word = ctl[0:1] if sampled else None
