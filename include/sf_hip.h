@@ -845,6 +845,17 @@ void sf_debug_grouped_weight_gradients(int on);
  * backward of a decoder step (the default: the attention backward adds up the K-split slabs of d(feature) itself --
  * same order, same bits). */
 void sf_debug_slab_consumers(int on);
+/* Experiment switch (round 5): on != 0 runs the LSTM cell's pointwise backward of a decoder step as the epilogue of the
+ * small product that completes that step's dh1 (the last launch of the backward step before it) instead of its own
+ * launch: same arithmetic, same bits (tested), one launch fewer per step -- and no faster (4.81 vs 4.79 ms). */
+void sf_debug_fused_cell_backward(int on);
+/* Experiment switch: the two-stream backward through time issues the head of step t - steps right before the tail of
+ * step t (steps >= 1) instead of every head first (steps < 0, the default). */
+void sf_debug_bptt_lookahead(int steps);
+/* Experiment switch (round 5): on != 0 orders the two chains of the two-stream backward through time (heads: scoring /
+ * text attention; tails: LSTM / visual attention) with one-shot device flags instead of events (a flag wait that gives
+ * up raises bit 16 of the fault word).  Measured equal: the chains do not overlap either way. */
+void sf_debug_bptt_flags(int on);
 /* A/B switch: on == 0 makes sf_speaker_encoder_fwd run its visual attention on the fp32 kernels (rounds 1-4) instead
  * of the float64 query / score path (sf_visual_attention_fwd_f64; the default). */
 void sf_debug_precise_attention(int on);

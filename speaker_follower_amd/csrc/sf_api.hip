@@ -179,6 +179,22 @@ int lstm_fwd_i(const sf_lstm_w* w, int B, int I, int H, const float* x, int ldx,
     return lstm_pointwise_fwd(p, st);
 }
 
+// the cell's pointwise backward of one decoder / speaker step (no packed-sequence or ctx terms)
+static LstmPwBwd cell_pw_bwd(const float* gates, const float* c0, const float* c1, const float* dh1, const float* dh1_b,
+                             const float* dc1, int B, int H, float* dgates, float* dc0, const Dropout* dh1b_drop) {
+    LstmPwBwd p{};
+    p.gates = gates; p.c0 = c0; p.c1 = c1; p.dh1 = dh1; p.dh1_b = dh1_b; p.dc1 = dc1;
+    p.B = B; p.H = H; p.dgates = dgates; p.dc0 = dc0; p.lengths = nullptr; p.dh0_pass = nullptr;
+    if (dh1b_drop) p.dh1b_drop = *dh1b_drop;
+    return p;
+}
+
+static int g_bptt_flags = 0;       // sf_debug_bptt_flags: per-step device flags between the two chains of the backward instead of events
+                                   // (measured equal, profiles/r05_zz_*: the chains do not overlap either way; off by default)
+static int g_bptt_lookahead = -1;  // sf_debug_bptt_lookahead (< 0: every head first)
+static int g_fuse_cell_bwd = 0;    // sf_debug_fused_cell_backward: the cell's pointwise backward as the epilogue of the product
+                                   // that completes dh1 instead of its own launch.  Bit-identical; measured 4.81 vs 4.79 ms per
+                                   // iteration (one launch fewer per step, no gain): off by default
 static int g_slab_consumers = 1;     // sf_debug_slab_consumers: consumers add up K-split slabs themselves (0: a reduce launch in between)
 
 int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, const float* x, int ldx,
@@ -188,18 +204,18 @@ int lstm_bwd_i(const sf_lstm_w* w, const sf_lstm_g* g, int B, int I, int H, cons
                int dx_col0 = 0,            // dx is only formed for input columns >= dx_col0
                const Dropout* dh1b_drop = nullptr,     // mask still to be applied to dh1_b
                SmallPlan* dh0_plan = nullptr, bool* dh0_deferred = nullptr,
-               const float** dx_slabs = nullptr, int* dx_ks = nullptr) {   // (with dx_col0 > 0) leave d(x[:, dx_col0:]) as the
+               const float** dx_slabs = nullptr, int* dx_ks = nullptr,     // (with dx_col0 > 0) leave d(x[:, dx_col0:]) as the
+               bool pointwise_done = false) {   // dgates / dc0 were already formed (the epilogue of the product that completed dh1)
     // K-split slabs of its product: *dx_slabs -> [*dx_ks][B, I - dx_col0] (the consumer adds them up: one launch fewer);
     // *dx_ks == 0: dx was formed as usual
     // dh0_plan: do not launch dh0 = dgates W_hh; hand its launch plan to the caller (who pairs it with
     // an independent kernel) when the short-reduction kernel covers the shape
     float* dgates = dgates_out ? dgates_out : ar.take((size_t)B * 4 * H);
     NEED(dgates);
-    LstmPwBwd p{};
-    p.gates = gates; p.c0 = c0; p.c1 = c1; p.dh1 = dh1; p.dh1_b = dh1_b; p.dc1 = dc1;
-    p.B = B; p.H = H; p.dgates = dgates; p.dc0 = dc0; p.lengths = nullptr; p.dh0_pass = nullptr;
-    if (dh1b_drop) p.dh1b_drop = *dh1b_drop;
-    TRY(lstm_pointwise_bwd(p, st));
+    if (!pointwise_done) {
+        const LstmPwBwd p = cell_pw_bwd(gates, c0, c1, dh1, dh1_b, dc1, B, H, dgates, dc0, dh1b_drop);
+        TRY(lstm_pointwise_bwd(p, st));
+    }
     if (dx && dx_col0 == 0) {
         TRY(data_grad(dgates, 4 * H, w->w_ih, w->w_ih_t, B, 4 * H, I, dx, lddx, 0, ar, st));
     } else if (dx) {
@@ -290,7 +306,9 @@ int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, i
                  const Dropout& drop, int col0, float* dh, Arena ar, hipStream_t st,
                  float* dq_out = nullptr, float* dt_out = nullptr,
                  const SmallPlan* beside = nullptr,     // an independent small product to launch with
-                 int dout_slabs = 0, long dout_slab_stride = 0) {   // dout = the sum of K-split slabs (added up in the kernel)
+                 int dout_slabs = 0, long dout_slab_stride = 0,     // dout = the sum of K-split slabs (added up in the kernel)
+                 const LstmPwBwd* next_pw = nullptr, bool* next_fused = nullptr) {   // dh completes the NEXT backward step's dh1:
+                                                        // run that step's pointwise backward as the product's epilogue
     const int F = X.IMG + X.LOC;                        // the attention backward (must run either way)
     float* dq = dq_out ? dq_out : ar.take((size_t)B * F);
     float* dt = dt_out ? dt_out : ar.take((size_t)B * D);
@@ -308,7 +326,22 @@ int visual_bwd_i(const sf_visual_w* w, const sf_visual_g* g, const PanoSrc& X, i
     TRY(linear_plain(dq, F, w->w_v, F, nullptr, B, D, F, EPI_NONE, dt, D, ar, st));
     if (g && g->w_v) TRY(gemm_tn(t_v, D, dq, F, B, D, F, g->w_v, F, 1, st, ar.rest(), ar.rest_n()));
     // g->b_v: the bias shifts all V scores of a row equally; its gradient is identically zero.
-    if (dh) TRY(data_grad(dt, D, w->w_h, w->w_h_t, B, D, H, dh, H, 1, ar, st));
+    if (next_fused) *next_fused = false;
+    if (dh) {
+        bool done = false;
+        if (next_pw && next_fused && g_fuse_cell_bwd && w->w_h_t && H % 4 == 0) {
+            Seg sg{dt, D, w->w_h_t, D, D};
+            LinearOut o{};
+            o.y = dh; o.ldy = H; o.epi = EPI_NONE; o.accumulate = 1;
+            SmallPlan sp;
+            if (linear_small_plan(&sg, 1, B, H, o, &sp)) {
+                const int rc = launch_small_plan_pw(sp, *next_pw, st);
+                if (rc == SF_OK) done = *next_fused = true;
+                else if (rc != SF_ERR_UNSUPPORTED) return rc;
+            }
+        }
+        if (!done) TRY(data_grad(dt, D, w->w_h, w->w_h_t, B, D, H, dh, H, 1, ar, st));
+    }
     if (g && g->w_h) TRY(gemm_tn(dt, D, h, H, B, D, H, g->w_h, H, 1, st, ar.rest(), ar.rest_n()));
     if (g && g->b_h) TRY(colsum(dt, D, B, D, g->b_h, 1, st, nullptr, ar.rest(), ar.rest_n()));
     return SF_OK;
@@ -464,6 +497,9 @@ void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
 void sf_debug_many_row_product(int on) { sf::g_nt_big = on; }
 void sf_debug_grouped_weight_gradients(int on) { sf::g_tn_group = on; }
 void sf_debug_slab_consumers(int on) { g_slab_consumers = on; }
+void sf_debug_fused_cell_backward(int on) { g_fuse_cell_bwd = on; }
+void sf_debug_bptt_lookahead(int steps) { g_bptt_lookahead = steps; }
+void sf_debug_bptt_flags(int on) { g_bptt_flags = on; }
 int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, sf_stream stream) {
     SF_ENTER();
     return sf::cotenant(blocks, threads, lds_bytes, ticks, sink, S(stream));
@@ -949,7 +985,9 @@ static int decoder_bwd_tail_i(const sf_decoder_w* w, const sf_decoder_g* g, cons
                               int H, int D, const float* h0, const float* c0,
                               const sf_decoder_tape* tp, const sf_decoder_gtape* gt, const float* dh1,
                               const float* dh1d, const float* dc1, float* dh0, float* dc0,
-                              const sf_dropout* drop, uint32_t step_id, Arena ar, hipStream_t st) {
+                              const sf_dropout* drop, uint32_t step_id, Arena ar, hipStream_t st,
+                              const LstmPwBwd* next_pw = nullptr, bool* next_fused = nullptr,   // see visual_bwd_i
+                              bool pointwise_done = false) {        // this step's dgates / dc0 exist already
     const PanoSrc xs = pano(X);
     const int F = xs.IMG + xs.LOC;
     const Dropout d_in = make_dropout(drop, 2 * step_id, 2), d_h = make_dropout(drop, 2 * step_id + 1, 2);
@@ -964,16 +1002,17 @@ static int decoder_bwd_tail_i(const sf_decoder_w* w, const sf_decoder_g* g, cons
                    tp->gates, dh1, dh1d, dc1, dxin, 2 * F, dh0, dc0, ar, st,
                    gt ? gt->dgates : nullptr, F, &d_h,   // u_prev is detached (follower.py:502): only
                    &dh0_plan, &dh0_deferred,            // the feature half of d(LSTM input) is needed
-                   &df_slabs, &df_ks));
+                   &df_slabs, &df_ks, pointwise_done));
     // dh0 = dgates W_hh rides beside the visual-attention backward (both only need the LSTM backward); the feature
     // half of d(LSTM input) reaches it as the K-split slabs of its product (no reduce launch in between)
     if (df_ks >= 1)
         return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                             df_slabs, F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
-                            gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr, df_ks, (long)B * F);
+                            gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr, df_ks, (long)B * F, next_pw,
+                            next_fused);
     return visual_bwd_i(&w->visual, g ? &g->visual : nullptr, xs, B, H, D, h0, tp->alpha_v, tp->t_v,
                         dxin + F, 2 * F, d_in, F, dh0, ar, st, gt ? gt->dq : nullptr,
-                        gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr);
+                        gt ? gt->dt_v : nullptr, dh0_deferred ? &dh0_plan : nullptr, 0, 0, next_pw, next_fused);
 }
 
 static int decoder_bwd_i(const sf_decoder_w* w, const sf_decoder_g* g, const sf_pano* X,
@@ -1262,22 +1301,63 @@ int sf_follower_episode_bwd_range(const sf_decoder_w* w, const sf_follower_episo
         // 0.73 ms chain of recurrent steps beside 0.87 ms of gate products takes 1.35 ms, beside
         // chip-filling library GEMMs the plain sum, stream priority changes nothing -- so the gain of
         // the second stream is the small kernels of the heads filling the gaps of the tails.)
+        const bool use_flags = g_bptt_flags && whole.tk && e->S <= 512;
+        unsigned* bflags = whole.tk ? whole.tk + 1200 : nullptr;           // [S] one-shot flags (zero between uses)
+        unsigned* fault_word = whole.tk ? whole.tk + PERSIST_TICKET + persistent_fault_word() : nullptr;
+        // (g_bptt_lookahead: heads are issued this many steps ahead of their tails instead of all first)
+        int th = t_hi - 1;               // the next head to issue
+        auto issue_heads_down_to = [&](int t_stop) -> int {
+            for (; th >= t_lo && th >= t_stop; --th) {
+                StepView v = step_view(e, th);
+                const sf_decoder_gtape g = gtape_view(gtape, e, th);
+                const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + th, -1, (int)e->A};
+                TRY(decoder_bwd_head_i(w, nullptr, &v.U, e->B, e->H, e->D, e->L, e->ctx, &v.tp, &g, dlogit,
+                                       g.dh1d, dctx, head_ar, side_st, &ce));
+                if (use_flags) TRY(flag_set(bflags + th, 1u, side_st));
+                else if (hipEventRecord(ev[th], side_st) != hipSuccess) return SF_ERR_LAUNCH;
+            }
+            return SF_OK;
+        };
+        // tail t may run once head t is complete: an event per step, or (sf_debug_bptt_flags) a one-shot device flag set
+        // by a one-thread kernel behind the head and waited for / cleared by a one-wave kernel in front of the tail.
+        // MEASURED (round 5, profiles/r05_zz_train_timeline_fused_cell.txt): on this stack the two chains do NOT run
+        // side by side either way -- replayed as a graph or issued eagerly, with events, with flags, with the heads
+        // issued all first or two steps ahead: every head runs first (0.94 ms), then every tail (1.02 ms).  Two
+        // backlogged queues are served one after the other; what does overlap is work PAIRED into one launch.
+        int waited_down_to = t_hi;       // heads >= this index have been waited for
+        auto wait_heads_down_to = [&](int t_need) -> int {
+            for (int k = waited_down_to - 1; k >= t_need; --k) {
+                if (use_flags) TRY(flag_wait_clear(bflags + k, fault_word, 16u /* FAULT_BPTT */, main_st));
+                else if (hipStreamWaitEvent(main_st, ev[k], 0) != hipSuccess) return SF_ERR_LAUNCH;
+            }
+            if (t_need < waited_down_to) waited_down_to = t_need;
+            return SF_OK;
+        };
+        bool cell_done = false;          // this step's pointwise backward ran as the epilogue of the step before
         for (int t = t_hi - 1; t >= t_lo; --t) {
-            StepView v = step_view(e, t);
-            const sf_decoder_gtape g = gtape_view(gtape, e, t);
-            const CeSrc ce{v.tp.logit, v.glue.target_used, gscale + t, -1, (int)e->A};
-            TRY(decoder_bwd_head_i(w, nullptr, &v.U, e->B, e->H, e->D, e->L, e->ctx, &v.tp, &g, dlogit,
-                                   g.dh1d, dctx, head_ar, side_st, &ce));
-            if (hipEventRecord(ev[t], side_st) != hipSuccess) return SF_ERR_LAUNCH;
-        }
-        for (int t = t_hi - 1; t >= t_lo; --t) {
+            TRY(issue_heads_down_to(g_bptt_lookahead < 0 ? t_lo : t - g_bptt_lookahead));
             StepView v = step_view(e, t);
             const sf_decoder_gtape g = gtape_view(gtape, e, t);
             const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
             const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
-            if (hipStreamWaitEvent(main_st, ev[t], 0) != hipSuccess) return SF_ERR_LAUNCH;
+            // the last product of this tail completes dh1 of step t - 1: that step's pointwise backward (it needs the
+            // head of step t - 1 as well) rides in its epilogue
+            LstmPwBwd next_pw{};
+            bool next_fused = false;
+            const bool try_fuse = g_fuse_cell_bwd && t > t_lo && g.dgates;
+            Dropout d_next;
+            TRY(wait_heads_down_to(try_fuse ? t - 1 : t));
+            if (try_fuse) {
+                StepView vn = step_view(e, t - 1);
+                const sf_decoder_gtape gn = gtape_view(gtape, e, t - 1);
+                const float* c0n = t - 1 == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 2) * BH;
+                d_next = make_dropout(drop, 2 * (e->step0 + t - 1) + 1, 2);
+                next_pw = cell_pw_bwd(vn.tp.gates, c0n, vn.tp.c1, nullptr, gn.dh1d, dco, e->B, e->H, gn.dgates, dcn, &d_next);
+            }
             TRY(decoder_bwd_tail_i(w, nullptr, &v.X, e->B, e->H, e->D, h0, c0, &v.tp, &g, dh1, g.dh1d, dc1,
-                                   dho, dco, drop, e->step0 + t, tail_ar, main_st));
+                                   dho, dco, drop, e->step0 + t, tail_ar, main_st, try_fuse ? &next_pw : nullptr,
+                                   &next_fused, cell_done));
+            cell_done = next_fused;
             dh1 = dho;
             dc1 = dco;
             std::swap(dho, dhn);

@@ -880,6 +880,10 @@ template <int MT, int CPW>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_kernel(SmallArgs a) {
     small_gemm_body<MT, CPW>(a, blockIdx.x, blockIdx.y);
 }
+template <int MT, int CPW>     // the product that completes dh1 + the LSTM cell's pointwise backward (see small_gemm_body)
+__global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_pw_kernel(SmallArgs a, LstmPwBwd pw) {
+    small_gemm_body<MT, CPW, true, true>(a, blockIdx.x, blockIdx.y, &pw);
+}
 template <int MT, int CPW>     // with the fused backward epilogues (see small_gemm_body)
 __global__ __launch_bounds__(SMALL_WAVES * 64) void gemm_nt_small_x_kernel(SmallArgs a) {
     small_gemm_body<MT, CPW, true>(a, blockIdx.x, blockIdx.y);
@@ -1782,6 +1786,19 @@ static int launch_small_plan(const SmallPlan& p, hipStream_t st) {
 }
 
 int launch_small_plan_x(const SmallPlan& p, hipStream_t st) { return launch_small_plan(p, st); }
+
+int launch_small_plan_pw(const SmallPlan& p, const LstmPwBwd& pw, hipStream_t st) {
+    const SmallArgs& sa = p.args;
+    if (sa.N != pw.H || sa.M != pw.B || sa.epi != EPI_NONE) return SF_ERR_UNSUPPORTED;
+    const dim3 grid(ceil_div(sa.N, 16), ceil_div(ceil_div(sa.M, 16), p.mt));
+    switch (p.mt * 32 + p.cpw) {
+        case 1 * 32 + 2: SF_LAUNCH((gemm_nt_small_pw_kernel<1, 2>), grid, dim3(SMALL_WAVES * 64), 0, st, sa, pw); break;
+        case 2 * 32 + 2: SF_LAUNCH((gemm_nt_small_pw_kernel<2, 2>), grid, dim3(SMALL_WAVES * 64), 0, st, sa, pw); break;
+        case 4 * 32 + 2: SF_LAUNCH((gemm_nt_small_pw_kernel<4, 2>), grid, dim3(SMALL_WAVES * 64), 0, st, sa, pw); break;
+        default: return SF_ERR_UNSUPPORTED;
+    }
+    return launch_status();
+}
 
 int transpose_ld(const float* src, int lds, int R, int C, float* dst, hipStream_t st);     // sf_pointwise.hip
 

@@ -3,6 +3,7 @@
 // attention body in one grid.
 #pragma once
 #include "sf_gemm.h"
+#include "sf_lstm_pw.h"
 
 namespace sf {
 
@@ -90,8 +91,11 @@ struct SmallArgs {
 // 16-col n-tile x MT m-tiles.  Threads >= 512 of a larger (paired) block must not enter.
 // EXTRA: the fused backward epilogues (aux / addend / rank-1 operands); a separate instantiation so
 // that the forward products carry none of their registers or branches.
-template <int MT, int CPW, bool EXTRA = false>
-__device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int by) {
+// PW: the LSTM cell's pointwise backward as the epilogue (sf_lstm_pw.h): the product completes dh1 of a decoder step
+// (y += ...), and element (row, col) -- all it needs of dh1 -- goes straight through the cell's backward: dgates and dc0
+// of that step without the stand-alone launch.
+template <int MT, int CPW, bool EXTRA = false, bool PW = false>
+__device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int by, const LstmPwBwd* pw = nullptr) {
     __shared__ float s_part[SMALL_WAVES][MT][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int n0 = bx * 16, m0 = by * (16 * MT);
@@ -157,7 +161,9 @@ __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int 
             v *= e_mul;
         }
         float* o = a.y + (size_t)row * a.ldy + col;
-        *o = a.accumulate ? *o + v : v;
+        const float out = a.accumulate ? *o + v : v;
+        *o = out;
+        if (PW) lstm_pw_bwd_elem(*pw, row, col, out);
     }
 }
 
@@ -169,5 +175,8 @@ struct SmallPlan {
 };
 bool linear_small_plan(const Seg* segs, int nseg, int M, int N, const LinearOut& out, SmallPlan* plan);
 int launch_small_plan_x(const SmallPlan& p, hipStream_t st);      // launch a plan on its own
+// ... with the LSTM pointwise backward as its epilogue (N == pw.H columns, M == pw.B rows); SF_ERR_UNSUPPORTED for
+// shapes without that instantiation
+int launch_small_plan_pw(const SmallPlan& p, const LstmPwBwd& pw, hipStream_t st);
 
 }  // namespace sf

@@ -3,6 +3,7 @@
 #include "sf_common.h"
 #include "sf_gemm.h"
 #include "sf_lstm.h"
+#include "sf_lstm_pw.h"
 #include "sf_rows.h"
 
 namespace sf {
@@ -93,21 +94,6 @@ int encoder_bwd_persistent(const float* w_hh, const int* lengths, int B, int H, 
                            // dc0_out [B,H] = gradient wrt a given initial cell state; lengths may be null
                            long dctx_sb = 0, long dctx_st = 0, float* dc0_out = nullptr);
 
-struct LstmPwBwd {
-    const float* gates; const float* c0; const float* c1;
-    const float* dh1; const float* dh1_b;   // two optional contributions to dh1 (either may be null)
-    const float* dc1;
-    int B, H;
-    float* dgates;               // [B,4H] pre-activation gate gradients
-    float* dc0;                  // [B,H]
-    const int* lengths; int t;   // encoder: dead rows pass dh1/dc1 through untouched, dgates = 0
-    float* dh0_pass;             // encoder: for dead rows dh0 = dh1 (written here), live rows 0
-                                 // (may alias dh1: element-wise in place)
-    const float* dctx; int T;    // encoder: + dropout-masked dctx[b, t, :] (row stride T*H), or null
-    Dropout ctx_drop;
-    Dropout dh1b_drop;           // mask applied to dh1_b on load (column = j): the backward of the
-                                 // dropout between h1 and the text attention (model.py:394)
-};
 int lstm_pointwise_bwd(const LstmPwBwd& a, hipStream_t st);
 
 int dropout_copy(const float* src, int lds, int B, int N, float* dst, int ldd, const Dropout& d,
@@ -137,6 +123,7 @@ int cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sin
 // device-flag ordering between two streams (sf_pointwise.hip)
 int flag_wait(const unsigned* flag, unsigned target, hipStream_t st);
 int flag_set(unsigned* flag, unsigned value, hipStream_t st);
+int flag_wait_clear(unsigned* flag, unsigned* fault, unsigned fault_code, hipStream_t st);   // one-shot: wait for != 0, then clear
 int adam_step(float* p, const float* g, float* m, float* v, size_t n, double lr, double beta1,
               double beta2, double eps, double wd, int step, hipStream_t st);
 // the same with the 1-based step counter ON THE DEVICE (incremented by the call; coef: 2 floats of scratch)

@@ -61,43 +61,7 @@ __global__ __launch_bounds__(TPB) void lstm_pw_bwd_kernel(LstmPwBwd a) {
     const int H = a.H, B = a.B;
     for (int idx = blockIdx.x * TPB + threadIdx.x; idx < B * H; idx += gridDim.x * TPB) {
         const int b = idx / H, j = idx - b * H;
-        // all operands first (block-uniform branches around optional ones), then the arithmetic
-        const float* gp = a.gates + (size_t)b * 4 * H + j;
-        const float ig = gp[0], fg = gp[H], gg = gp[2 * H], og = gp[3 * H];
-        const float c1 = a.c1[idx], c0 = a.c0[idx];
-        float dh = 0.f, dc = 0.f;
-        if (a.dh1) dh = a.dh1[idx];
-        if (a.dh1_b) {
-            float v = a.dh1_b[idx];
-            if (a.dh1b_drop.on()) {
-                const uint32_t rk = drop_key(a.dh1b_drop, (uint32_t)(a.dh1b_drop.row0 + b));
-                v = dropout_keep(rk, (uint32_t)j, a.dh1b_drop.thresh) ? v * a.dh1b_drop.scale : 0.f;
-            }
-            dh += v;
-        }
-        if (a.dc1) dc = a.dc1[idx];
-        bool dead = false;
-        if (a.lengths) dead = a.t >= a.lengths[b];
-        if (a.dctx) {                                     // encoder: gradient of ctx[b, t, :]
-            float v = a.dctx[((size_t)b * a.T + a.t) * H + j];
-            if (a.ctx_drop.on()) {
-                const uint32_t rk = drop_key(a.ctx_drop, (uint32_t)(a.ctx_drop.row0 + b));
-                v = dropout_keep(rk, (uint32_t)(a.t * H + j), a.ctx_drop.thresh)
-                        ? v * a.ctx_drop.scale : 0.f;
-            }
-            dh += v;
-        }
-        float* dg = a.dgates + (size_t)b * 4 * H + j;
-        const float tc = tanhf(c1);
-        const float dout = dh * tc;
-        const float dcl = dc + dh * og * (1.f - tc * tc);
-        // packed sequence: a step that did not happen passes dh / dc through, dgates = 0
-        dg[0] = dead ? 0.f : dcl * gg * ig * (1.f - ig);
-        dg[H] = dead ? 0.f : dcl * c0 * fg * (1.f - fg);
-        dg[2 * H] = dead ? 0.f : dcl * ig * (1.f - gg * gg);
-        dg[3 * H] = dead ? 0.f : dout * og * (1.f - og);
-        a.dc0[idx] = dead ? dc : dcl * fg;
-        if (a.dh0_pass) a.dh0_pass[idx] = dead ? dh : 0.f;
+        lstm_pw_bwd_elem(a, b, j, a.dh1 ? a.dh1[idx] : 0.f);         // (sf_lstm_pw.h)
     }
 }
 
@@ -917,6 +881,24 @@ __global__ void flag_wait_kernel(const unsigned* flag, unsigned target) {
 }
 __global__ void flag_set_kernel(unsigned* flag, unsigned value) {
     if (threadIdx.x == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Consumer side of a one-shot flag: spin until the word is non-zero, then clear it for the next use.  A wait that gives
+// up (0.5 s) raises `fault_code` in the fault word: the host re-issues the pass (runtime.take_fault).
+__global__ void flag_wait_clear_kernel(unsigned* flag, unsigned* fault, unsigned fault_code) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) {
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > 50000000LL) {           // never hang a stream
+            if (fault) atomicOr(fault, fault_code);
+            break;
+        }
+    }
+    __hip_atomic_store(flag, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+int flag_wait_clear(unsigned* flag, unsigned* fault, unsigned fault_code, hipStream_t st) {
+    SF_LAUNCH(flag_wait_clear_kernel, dim3(1), dim3(64), 0, st, flag, fault, fault_code);
+    return launch_status();
 }
 int flag_wait(const unsigned* flag, unsigned target, hipStream_t st) {
     SF_LAUNCH(flag_wait_kernel, dim3(1), dim3(64), 0, st, flag, target);

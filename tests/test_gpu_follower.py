@@ -244,10 +244,14 @@ def test_grouped_weight_gradients_match_the_reference_and_the_single_products(fo
         m.zero_grad(set_to_none=True)
 
 
-def test_attention_backward_adds_up_the_data_gradient_slabs_itself(follower_modules, golden):
-    """The feature half of d(LSTM input) reaches the visual-attention backward as the K-split slabs of its product
-    (sf_debug_slab_consumers): one launch fewer per backward step, the SAME bits as the slab-sum launch it replaces
-    (same order of additions), on one stream and on two, and the reference's gradients (G4, B = 100)."""
+@pytest.mark.parametrize('switch', ['sf_debug_slab_consumers', 'sf_debug_fused_cell_backward'])
+def test_launches_taken_off_the_backward_chain_leave_the_same_bits(follower_modules, golden, switch):
+    """Two launches less on the critical chain of every backward step, each with an A/B switch: the feature half of
+    d(LSTM input) reaches the visual-attention backward as the K-split slabs of its product and is added up there
+    (sf_debug_slab_consumers); the LSTM cell's pointwise backward of step t - 1 is the epilogue of the product that
+    completes its dh1, the last launch of step t (sf_debug_fused_cell_backward).  Same order of additions, same
+    arithmetic: the SAME bits as the launches they replace, on one stream and on two, with dropout, and the reference's
+    gradients (G4, B = 100)."""
     from speaker_follower_amd import _lib
     enc, dec, _, _ = follower_modules
     fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=256)
@@ -258,8 +262,9 @@ def test_attention_backward_adds_up_the_data_gradient_slabs_itself(follower_modu
     for two_stream in (True, False):
         engine.two_stream_backward = two_stream
         grads = {}
+        default = {'sf_debug_slab_consumers': 1, 'sf_debug_fused_cell_backward': 0}[switch]
         for on in (1, 0):
-            _lib.lib.sf_debug_slab_consumers(on)
+            getattr(_lib.lib, switch)(on)
             try:
                 for m in (enc, dec):
                     m.zero_grad(set_to_none=True)
@@ -267,12 +272,28 @@ def test_attention_backward_adds_up_the_data_gradient_slabs_itself(follower_modu
                 st.loss.backward()
                 torch.cuda.synchronize()
             finally:
-                _lib.lib.sf_debug_slab_consumers(1)
+                getattr(_lib.lib, switch)(default)
             grads[on] = {k: p.grad.clone() for m, pre in ((enc, 'enc/'), (dec, 'dec/'))
                          for k, p in ((pre + k, p) for k, p in m.named_parameters()) if p.grad is not None}
         for k, a in grads[1].items():
             assert torch.equal(a, grads[0][k]), k
         _check_grads({k[4:]: v for k, v in grads[1].items() if k.startswith('dec/')}, g, 'dec/')
+        # train mode: the dropout between h1 and the text attention is undone inside the cell's backward
+        engine.dropout_seed = 99
+        tr = {}
+        for on in (1, 0):
+            getattr(_lib.lib, switch)(on)
+            try:
+                for m in (enc, dec):
+                    m.zero_grad(set_to_none=True)
+                engine.site_next = 0
+                st = engine.rollout(batch, int(g['n_steps']), 'teacher', train=True)
+                st.loss.backward()
+                torch.cuda.synchronize()
+            finally:
+                getattr(_lib.lib, switch)(default)
+            tr[on] = [p.grad.clone() for m in (enc, dec) for p in m.parameters() if p.grad is not None]
+        assert all(torch.equal(a, b) for a, b in zip(tr[1], tr[0]))
     for m in (enc, dec):
         m.zero_grad(set_to_none=True)
 

@@ -18,6 +18,12 @@ oe = optim.FusedAdam([p for p in enc.parameters() if p.requires_grad], lr=1e-4, 
 od = optim.FusedAdam([p for p in dec.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4)
 eng = follower.FollowerEngine(enc, dec, store)
 from speaker_follower_amd import _lib
+if 'SF_BPTT_FLAGS' in os.environ:
+    _lib.lib.sf_debug_bptt_flags(int(os.environ['SF_BPTT_FLAGS']))
+if 'SF_LOOKAHEAD' in os.environ:
+    _lib.lib.sf_debug_bptt_lookahead(int(os.environ['SF_LOOKAHEAD']))
+if 'SF_FUSED_CELL' in os.environ:
+    _lib.lib.sf_debug_fused_cell_backward(int(os.environ['SF_FUSED_CELL']))
 if 'SF_SLAB_CONSUMERS' in os.environ:
     _lib.lib.sf_debug_slab_consumers(int(os.environ['SF_SLAB_CONSUMERS']))
 if 'SF_GROUPED' in os.environ:
