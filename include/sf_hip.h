@@ -854,8 +854,11 @@ void sf_debug_fused_cell_backward(int on);
 void sf_debug_bptt_lookahead(int steps);
 /* Experiment switch (round 5): on != 0 orders the two chains of the two-stream backward through time (heads: scoring /
  * text attention; tails: LSTM / visual attention) with one-shot device flags instead of events (a flag wait that gives
- * up raises bit 16 of the fault word).  Measured equal: the chains do not overlap either way. */
+ * up raises bit 16 of the fault word).  Measured equal. */
 void sf_debug_bptt_flags(int on);
+/* Experiment switch (tools/bptt_overlap_probe.py): 1 = the two-stream backward issues its heads only, 2 = its tails only
+ * (no waits): the two chains as separately captured graphs. */
+void sf_debug_bptt_part(int part);
 /* A/B switch: on == 0 makes sf_speaker_encoder_fwd run its visual attention on the fp32 kernels (rounds 1-4) instead
  * of the float64 query / score path (sf_visual_attention_fwd_f64; the default). */
 void sf_debug_precise_attention(int on);

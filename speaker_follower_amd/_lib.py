@@ -161,6 +161,7 @@ _SIGNATURES = {
     'sf_debug_fused_cell_backward': (None, [C.c_int]),
     'sf_debug_bptt_lookahead': (None, [C.c_int]),
     'sf_debug_bptt_flags': (None, [C.c_int]),
+    'sf_debug_bptt_part': (None, [C.c_int]),
     'sf_site_advance': (C.c_int, [c_p, u32, c_p]),
     'sf_store_u32x4': (C.c_int, [c_p, u32, u32, u32, u32, c_p]),
     'sf_adam_step_dev': (C.c_int, [c_f, c_f, c_f, c_f, C.c_size_t, C.c_double, C.c_double, C.c_double, C.c_double,

@@ -189,8 +189,9 @@ static LstmPwBwd cell_pw_bwd(const float* gates, const float* c0, const float* c
     return p;
 }
 
+static int g_bptt_part = 0;        // EXPERIMENT (sf_debug_bptt_part): 1 = issue the heads only, 2 = the tails only (no waits)
 static int g_bptt_flags = 0;       // sf_debug_bptt_flags: per-step device flags between the two chains of the backward instead of events
-                                   // (measured equal, profiles/r05_zz_*: the chains do not overlap either way; off by default)
+                                   // (measured equal; off by default)
 static int g_bptt_lookahead = -1;  // sf_debug_bptt_lookahead (< 0: every head first)
 static int g_fuse_cell_bwd = 0;    // sf_debug_fused_cell_backward: the cell's pointwise backward as the epilogue of the product
                                    // that completes dh1 instead of its own launch.  Bit-identical; measured 4.81 vs 4.79 ms per
@@ -500,6 +501,7 @@ void sf_debug_slab_consumers(int on) { g_slab_consumers = on; }
 void sf_debug_fused_cell_backward(int on) { g_fuse_cell_bwd = on; }
 void sf_debug_bptt_lookahead(int steps) { g_bptt_lookahead = steps; }
 void sf_debug_bptt_flags(int on) { g_bptt_flags = on; }
+void sf_debug_bptt_part(int part) { g_bptt_part = part; }
 int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, float* sink, sf_stream stream) {
     SF_ENTER();
     return sf::cotenant(blocks, threads, lds_bytes, ticks, sink, S(stream));
@@ -1320,10 +1322,9 @@ int sf_follower_episode_bwd_range(const sf_decoder_w* w, const sf_follower_episo
         };
         // tail t may run once head t is complete: an event per step, or (sf_debug_bptt_flags) a one-shot device flag set
         // by a one-thread kernel behind the head and waited for / cleared by a one-wave kernel in front of the tail.
-        // MEASURED (round 5, profiles/r05_zz_train_timeline_fused_cell.txt): on this stack the two chains do NOT run
-        // side by side either way -- replayed as a graph or issued eagerly, with events, with flags, with the heads
-        // issued all first or two steps ahead: every head runs first (0.94 ms), then every tail (1.02 ms).  Two
-        // backlogged queues are served one after the other; what does overlap is work PAIRED into one launch.
+        // Measured by wall clock (tools/bptt_overlap_probe.py): heads alone 0.93 ms, tails alone 1.14 ms, both chains in
+        // one graph 1.46 ms, as two graphs on two streams 1.43 ms -- they overlap either way; events and flags are equal.
+        // (rocprofv3 --kernel-trace serialises the queues: its timelines show every head before the first tail.)
         int waited_down_to = t_hi;       // heads >= this index have been waited for
         auto wait_heads_down_to = [&](int t_need) -> int {
             for (int k = waited_down_to - 1; k >= t_need; --k) {
@@ -1335,7 +1336,8 @@ int sf_follower_episode_bwd_range(const sf_decoder_w* w, const sf_follower_episo
         };
         bool cell_done = false;          // this step's pointwise backward ran as the epilogue of the step before
         for (int t = t_hi - 1; t >= t_lo; --t) {
-            TRY(issue_heads_down_to(g_bptt_lookahead < 0 ? t_lo : t - g_bptt_lookahead));
+            if (g_bptt_part != 2) TRY(issue_heads_down_to(g_bptt_lookahead < 0 ? t_lo : t - g_bptt_lookahead));
+            if (g_bptt_part == 1) continue;
             StepView v = step_view(e, t);
             const sf_decoder_gtape g = gtape_view(gtape, e, t);
             const float* h0 = t == 0 ? e->h_init : e->tape.h1 + (size_t)(t - 1) * BH;
@@ -1346,7 +1348,7 @@ int sf_follower_episode_bwd_range(const sf_decoder_w* w, const sf_follower_episo
             bool next_fused = false;
             const bool try_fuse = g_fuse_cell_bwd && t > t_lo && g.dgates;
             Dropout d_next;
-            TRY(wait_heads_down_to(try_fuse ? t - 1 : t));
+            if (g_bptt_part != 2) TRY(wait_heads_down_to(try_fuse ? t - 1 : t));
             if (try_fuse) {
                 StepView vn = step_view(e, t - 1);
                 const sf_decoder_gtape gn = gtape_view(gtape, e, t - 1);

@@ -639,6 +639,10 @@ class FollowerEngine:
                         call('sf_attn_decoder_wgrad', byref(dw), byref(dg), (hi - lo) * B, H, D, F, ptr(st.hs[lo:]),
                              byref(tpk), byref(gtk), *ws_args(dev))
                     st.wgrad_done_from = lo
+        if getattr(self, '_bptt_only', False):          # (tools/bptt_overlap_probe.py times the backward through time alone)
+            if self._side_stream is not None:
+                torch.cuda.current_stream().wait_stream(self._side_stream)
+            return
         for t in range(S - 1 if st.episode is None else -1, -1, -1):
             pano = store.pano(batch.vp[t], batch.view[t])
             cnd = store.cands(batch.vp[t], batch.cand_view[t], batch.sincos[t], batch.a_num[t], A)
@@ -675,10 +679,11 @@ class FollowerEngine:
                     self._wgrad_stream = concurrent_stream(dev, exclude=[x for x in (self._side_stream,) if x is not None])
                 third = self._wgrad_stream if self._wgrad_stream is not side else self._side_stream
                 third.wait_stream(torch.cuda.current_stream())
-        # (Measured in round 5, profiles/r05_s_*: the pieces of this tail do not overlap whatever the order of issue --
-        # the persistent encoder backward holds one 256-VGPR workgroup on every CU and the many-row weight-gradient
-        # tiles (512 threads x 188 VGPRs, 96 KB LDS) cannot sit beside it; issued side by side they both take twice as
-        # long.  What shortened the tail was fewer launches: gemm_tn_group.)
+        # (Measured in round 5 by wall clock: the encoder first, the two latency-bound pieces side by side, a third stream
+        # and chunked weight gradients are all equal or slower than this order; what shortened the tail was fewer launches,
+        # gemm_tn_group.  The many-row weight-gradient tiles -- 512 threads x 188 VGPRs, 96 KB LDS -- cannot sit beside the
+        # persistent encoder backward's 256-VGPR workgroup on a CU.  NOTE: rocprofv3 --kernel-trace serialises the queues;
+        # its timelines show no overlap at all and must not be read for concurrency, tools/bptt_overlap_probe.py.)
         if overlap and not self.encoder_backward_first:
             self._issue_wgrad(side, third, dw, dg, params, Sw * B, H, D, F, st, tp0, gt0, dev, sync)
         elif not overlap:
