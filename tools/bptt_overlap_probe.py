@@ -41,6 +41,9 @@ def capture(part, stream):
     torch.cuda.synchronize()
     return g
 
+for name in ('fused_cell_backward', 'slab_consumers', 'bptt_flags'):
+    if 'SF_' + name.upper() in os.environ:
+        getattr(_lib.lib, 'sf_debug_' + name)(int(os.environ['SF_' + name.upper()]))
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 g_both = capture(0, s1)
 g_heads = capture(1, s1)

@@ -26,7 +26,11 @@ for _ in range(20): it()
 torch.cuda.synchronize(); print('eager   %.3f ms / iteration' % ((time.perf_counter() - t0) / 20 * 1e3))
 g = torch.cuda.CUDAGraph()
 s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+from speaker_follower_amd import runtime
+runtime.ensure_workspace(s, dev)          # (a workspace first touched inside a capture would be zero-filled by every replay)
 with torch.cuda.stream(s):
+    it()                                   # warm-up on the capture stream (side streams, caches)
+    torch.cuda.synchronize()
     with torch.cuda.graph(g, stream=s):
         it()
 torch.cuda.current_stream().wait_stream(s)
