@@ -74,6 +74,8 @@ def parse(argv=None):
     ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
                     help='weak (default): every rank takes its own batch of --batch rows; strong: ONE global batch of --batch '
                          'rows (the reference\'s batch is 100 globally, train.py:28) split over the ranks with dp.shard_rows')
+    ap.add_argument('--extras-budget', type=int, default=240,
+                    help='N > 1: seconds the data-parallel training extra may take before the headline line is printed without it')
     ap.add_argument('--plan', action='store_true',
                     help='print the child commands / environment `--gpus N` would start (JSON) and exit; touches no GPU')
     return ap.parse_args(argv)
@@ -453,8 +455,13 @@ def main(argv=None):
     import numpy as np
     import torch
     # stdout carries the ONE JSON line and nothing else: whatever the modules print on the way (the reference's own
-    # "Using GloVe embedding", model.py:57) goes to stderr
-    result_out, sys.stdout = sys.stdout, sys.stderr
+    # "Using GloVe embedding", model.py:57) goes to stderr -- and so does what NATIVE code writes to file descriptor 1
+    # (RCCL's version banner, gloo's rank messages): the descriptor itself is pointed at stderr, the line goes to a
+    # duplicate of the original
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), 'w')
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local = 0 if args.share_gpu else int(os.environ.get('LOCAL_RANK', '0'))
@@ -579,7 +586,30 @@ def main(argv=None):
     # ---- extra (not `value`), N > 1: the data-parallel TRAINING iteration (BASELINE configs[3]) on the
     # same per-GPU batch, with the gradient all-reduce timed on its own.  Every rank takes part.
     train_dp = None
+    # The headline is measured; what follows at N > 1 issues collectives from every rank.  If that part raises on one
+    # rank or hangs (a rank lost, a collective that never completes), the line with the headline is still printed: a
+    # watchdog on every rank gives the extras a budget, then rank 0 prints the line it has and every rank leaves.
+    headline = dict(metric='agent-steps/sec (follower rollout, batch %d)' % B, value=value, unit='agent-steps/s',
+                    n_gpus=world, steps=args.steps, warmup=args.warmup, ms_per_step=1e3 * elapsed / args.steps,
+                    higher_is_better=True, scaling=args.scaling, vs_baseline=None, dtype='f32', data='synthetic',
+                    config=dict(workload='follower rollout: batch %d per GPU, %d decode steps, encoder included'
+                                         % (B, S)))
+    watchdog = None
+    if world > 1:
+        import threading
+
+        def bail():
+            if rank == 0:
+                headline['train_dp'] = dict(error='the data-parallel training extra did not finish within %d s; the '
+                                                  'headline above was measured before it' % args.extras_budget)
+                print(json.dumps(headline), file=result_out)
+                result_out.flush()
+            os._exit(4)
+        watchdog = threading.Timer(args.extras_budget, bail)
+        watchdog.daemon = True
+        watchdog.start()
     if (extras or forced) and coll and not train and not args.no_train_extra:
+      try:
         n_it = max(3, args.steps // 4)
         if strong:
             train_dp = measure_train(enc, dec, store, batch, S, n_it, 2, group=group, world=world, coll=coll, global_rows=B)
@@ -594,6 +624,12 @@ def main(argv=None):
         if forced:
             train_dp['forced_collectives'] = ('TEST RUN: one rank, every collective of the data-parallel path issued anyway '
                                               '(%s); proves the path executes, says nothing about scaling' % args.backend)
+      except Exception as exc:                      # (reported in the line; the other ranks run into the watchdog)
+        import traceback
+        train_dp = dict(error=repr(exc)[:400], where=traceback.format_exc()[-600:])
+    if watchdog is not None:
+        watchdog.cancel()
+    dp_failed = bool(train_dp and train_dp.get('error'))
 
     # ---- extra (not `value`): serving-style throughput with several independent rollouts in flight.
     concurrent = None
@@ -620,8 +656,10 @@ def main(argv=None):
                           unit='agent-steps/s', ms_per_rollout=1e3 * dt / kk)
 
     if rank != 0:
-        if coll:
+        if coll and not dp_failed:
             torch.distributed.destroy_process_group()
+        if dp_failed:
+            os._exit(5)
         return
 
     # ---- roofline: every kernel of the rollout timed IN THIS RUN.  Three eager rollouts are issued
@@ -774,8 +812,9 @@ def main(argv=None):
     out['persistent_launch_faults'] = _rt.take_fault(device)
     print(json.dumps(out), file=result_out)
     result_out.flush()
-    if coll:
+    if coll and not dp_failed:
         torch.distributed.destroy_process_group()
+    # (after a failed data-parallel extra the group may be wedged on the other ranks: no tear-down that could block)
     # a data-parallel run in which ANY rank's persistent launch gave up a wait is not a valid measurement: say so
     # with the exit status (the line above still carries the per-rank words)
     bad = out['persistent_launch_faults'] != 0
@@ -785,6 +824,10 @@ def main(argv=None):
     if bad:
         sys.stderr.write('bench.py: persistent-launch faults were raised (see persistent_launch_faults / train_dp.health)\n')
         sys.exit(3)
+    if dp_failed:
+        sys.stderr.write('bench.py: the data-parallel training extra failed (train_dp.error); the headline stands\n')
+        sys.stderr.flush()
+        os._exit(5)
 
 
 if __name__ == '__main__':
