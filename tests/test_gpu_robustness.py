@@ -463,3 +463,28 @@ def test_chunked_route_scoring_survives_starved_persistent_launches(forced_timeo
     for a, b in zip(out, ref):
         assert a['word_indices'] == b['word_indices'] and np.isfinite(a['score'])
         assert abs(a['score'] - b['score']) <= 2e-4 * max(1.0, abs(b['score']))
+
+
+def test_a_capture_never_creates_its_workspace_inside_the_graph():
+    """runtime.workspace under stream capture: a workspace first touched inside a capture would be zero-filled (64 MB) by
+    EVERY replay -- it rode in every captured rollout until round 5.  Creating one under capture raises; the engines
+    create their capture stream's workspace first (runtime.ensure_workspace) and their captures go through."""
+    from speaker_follower_amd import runtime
+    dev = torch.device('cuda', 0)
+    fresh = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph()
+    raised = False
+    with torch.cuda.stream(fresh):
+        with torch.cuda.graph(g, stream=fresh):
+            try:
+                runtime.workspace(dev)
+            except RuntimeError as exc:
+                raised = 'ensure_workspace' in str(exc)
+    assert raised
+    other = torch.cuda.Stream()
+    runtime.ensure_workspace(other, dev)
+    g2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(other):
+        with torch.cuda.graph(g2, stream=other):
+            ws = runtime.workspace(dev)                     # exists: nothing is allocated or filled in the graph
+    assert ws.numel() == runtime.lib.sf_workspace_bytes()
