@@ -541,6 +541,10 @@ int sf_gather_candidates(const sf_cands* U, int B, float* all_u /* [B,A,F] */,
                          float* is_valid /* [B,A] */, sf_stream stream);
 /* rows [B,F] of single chosen actions (speaker.py:104): a == 0 / vp < 0 => zeros */
 int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf_stream stream);
+/* The same with a row stride on the output (a multiple of 4, >= F): the previous action's embedding straight into the
+ * first half of a decoder step's LSTM input rows (sf_decoder_tape.xin, ld 2F; follower.py:588-590 `u_t_prev`), after which
+ * sf_attn_decoder_fwd is called with u_prev = NULL -- one copy launch fewer per search step. */
+int sf_gather_actions_ld(const sf_cands* U, int B, const int32_t* a, float* out, int ld_out, sf_stream stream);
 /* The chosen-action embeddings of all N = Tp*B (path step, path) pairs of a speaker batch (speaker.py:87-104:
  * `ob['action_embedding'][a]`, zeros for a stop action or a padded step) in one launch: row n of `out` (row stride
  * ld_out floats >= IMG + LOC, so the rows can be the first half of the encoder's LSTM inputs) =

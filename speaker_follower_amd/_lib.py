@@ -231,6 +231,7 @@ _SIGNATURES = {
     'sf_gather_panorama': (C.c_int, [P(Pano), i32, c_f, c_p]),
     'sf_gather_candidates': (C.c_int, [P(Cands), i32, c_f, c_f, c_p]),
     'sf_gather_actions': (C.c_int, [P(Cands), i32, c_p, c_f, c_p]),
+    'sf_gather_actions_ld': (C.c_int, [P(Cands), i32, c_p, c_f, i32, c_p]),
     'sf_gather_path_actions': (C.c_int, [c_f, i32, i32, i32, c_p, c_p, c_f, c_p, i32, c_f, i32, c_p]),
     'sf_gather_rows': (C.c_int, [c_f, i32, c_p, i32, i32, c_f, i32, c_p]),
     'sf_scatter_rows': (C.c_int, [c_f, i32, c_p, i32, i32, c_f, i32, c_p]),

@@ -1638,6 +1638,12 @@ int sf_gather_actions(const sf_cands* U, int B, const int32_t* a, float* out, sf
     return gather_actions(cands(U), B, a, out, S(stream));
 }
 
+int sf_gather_actions_ld(const sf_cands* U, int B, const int32_t* a, float* out, int ld_out, sf_stream stream) {
+    SF_ENTER();
+    SF_CHECK_ARG(U && a && out && B > 0 && ld_out > 0);
+    return gather_actions(cands(U), B, a, out, S(stream), ld_out);
+}
+
 int sf_gather_path_actions(const float* table, int V, int IMG, int LOC, const int32_t* vp, const int32_t* act_view,
                            const float* act_sincos, const int32_t* act, int N, float* out, int ld_out,
                            sf_stream stream) {

@@ -155,7 +155,7 @@ int ctx_grad_slice(const float* dctx, int T, int H, int B, int t, const Dropout&
 
 int gather_panorama(const PanoSrc& s, int B, float* out, hipStream_t st);
 int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hipStream_t st);
-int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st);
+int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st, int ldo = 0);   // ldo: row stride of out (0 = F)
 int gather_path_actions(const float* table, int V, int IMG, int LOC, const int* vp, const int* act_view,
                         const float* sincos, const int* act, int N, float* out, int ldo, hipStream_t st);
 

@@ -272,14 +272,14 @@ __global__ __launch_bounds__(TPB) void gather_cand_kernel(CandSrc s, int B, floa
     }
 }
 __global__ __launch_bounds__(TPB) void gather_action_kernel(CandSrc s, int B, const int* act,
-                                                            float* out) {
+                                                            float* out, int ldo4) {     // ldo4: row stride in float4
     const int n4 = (s.IMG + s.LOC) >> 2;
     const size_t total = (size_t)B * n4;
     for (size_t i = (size_t)blockIdx.x * TPB + threadIdx.x; i < total; i += (size_t)gridDim.x * TPB) {
         const int c = (int)(i % n4), b = (int)(i / n4);
         const int a = act[b];
         const CandRow row = cand_row(s, b, a);                   // a <= 0, padding or vp < 0: zeros
-        reinterpret_cast<float4*>(out)[i] = cand_load(row, c, a > 0 && !row.zero, n4);
+        reinterpret_cast<float4*>(out)[(size_t)b * ldo4 + c] = cand_load(row, c, a > 0 && !row.zero, n4);
     }
 }
 
@@ -1064,9 +1064,12 @@ int gather_candidates(const CandSrc& s, int B, float* all_u, float* is_valid, hi
                        all_u, is_valid);
     return launch_status();
 }
-int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st) {
-    SF_LAUNCH(gather_action_kernel, dim3(grid1d((size_t)B * ((s.IMG + s.LOC) >> 2))),
-                       dim3(TPB), 0, st, s, B, a, out);
+int gather_actions(const CandSrc& s, int B, const int* a, float* out, hipStream_t st, int ldo) {
+    const int F = s.IMG + s.LOC;
+    if (ldo == 0) ldo = F;
+    if ((ldo & 3) || ldo < F) return SF_ERR_UNSUPPORTED;
+    SF_LAUNCH(gather_action_kernel, dim3(grid1d((size_t)B * (F >> 2))),
+                       dim3(TPB), 0, st, s, B, a, out, ldo >> 2);
     return launch_status();
 }
 int gather_path_actions(const float* table, int V, int IMG, int LOC, const int* vp, const int* act_view,

@@ -203,13 +203,16 @@ class FlatDecoder:
         df = None
         s = stream()
         new = lambda *sh: torch.empty(*sh, device=dev, dtype=torch.float32)  # noqa: E731
-        h0, c0, u_prev = new(N, self.H), new(N, self.H), new(N, st.F)
-        call('sf_gather_rows', ptr(self.hpool.buf), self.H, ptr(hrow), N, self.H, ptr(h0), self.H, s)
-        call('sf_gather_rows', ptr(self.cpool.buf), self.H, ptr(hrow), N, self.H, ptr(c0), self.H, s)
+        h0, c0 = new(N, self.H), new(N, self.H)
+        H = self.H
+        gat = (_lib.RowMove * 2)(_lib.RowMove(self.hpool.buf.data_ptr(), h0.data_ptr(), hrow.data_ptr(), H, H, H, 0),
+                                 _lib.RowMove(self.cpool.buf.data_ptr(), c0.data_ptr(), hrow.data_ptr(), H, H, H, 0))
+        call('sf_move_rows', gat, 2, N, s)                 # h_t[flat_indices], c_t[flat_indices]: one launch
         ucand = st.cands(u_vp, u_cv, u_sc, two, 2)
-        call('sf_gather_actions', byref(ucand), N, ptr(u_act), ptr(u_prev), s)
 
         tape = decoder_tape(N, self.H, st.F, self.D, st.V, self.T, A, dev)
+        # the previous action's embedding straight into the first half of the LSTM input rows (no copy in the step)
+        call('sf_gather_actions_ld', byref(ucand), N, ptr(u_act), ptr(tape['xin']), 2 * st.F, s)
         base, tape['h1'] = self.hpool.reserve(N)
         _, tape['c1'] = self.cpool.reserve(N)
         _, tape['alpha'] = self.apool.reserve(N)
@@ -217,12 +220,12 @@ class FlatDecoder:
         cnd = st.cands(vp, cv, sc, a_num, A)
         tp = tape_struct(tape)
         call('sf_attn_decoder_fwd', byref(self.w), byref(pano), byref(cnd), N, self.H, self.D, self.T,
-             ptr(u_prev), ptr(h0), ptr(c0), ptr(self.ctx), ptr(self.mask), ptr(crow), byref(tp), None,
+             None, ptr(h0), ptr(c0), ptr(self.ctx), ptr(self.mask), ptr(crow), byref(tp), None,
              None, 0, *ws_args(dev))
         idx = torch.empty(N, k, dtype=torch.int32, device=dev)
         logp = new(N, k)
         call('sf_logprob_topk', ptr(tape['logit']), A, N, A, ptr(a_num), k, ptr(idx), ptr(logp), s)
-        self._keep = (di, df, tape, h0, c0, u_prev, two, vp, view, a_num, hrow, crow, u_vp, u_act,
+        self._keep = (di, df, tape, h0, c0, gat, two, vp, view, a_num, hrow, crow, u_vp, u_act,
                       u_cv, cv, u_sc, sc)
         both = torch.cat((idx.to(torch.float32), logp), dim=1).cpu().numpy()       # ONE D2H copy per iteration
         return base, both[:, :k].astype(np.int64), both[:, k:]
@@ -278,7 +281,7 @@ class GraphStep:
         self.obs2 = dict(row=i32(2 * cap), vp=i32(2 * cap), view=i32(2 * cap), a_num=i32(2 * cap),
                          cand_view=i32(2 * cap, A), sincos=f32(2 * cap, A, 4))
         self.obs = [{k: v[j * cap:(j + 1) * cap] for k, v in self.obs2.items()} for j in range(2)]
-        self.h0, self.c0, self.u_prev = f32(cap, self.H), f32(cap, self.H), f32(cap, store.F)
+        self.h0, self.c0 = f32(cap, self.H), f32(cap, self.H)
         self.tape = decoder_tape(cap, self.H, store.F, self.D, store.V, t_max, A, dev)
         self.logp = f32(cap, A)
         self.pin_out = torch.zeros(cap, A, dtype=torch.float32).pin_memory()
@@ -318,7 +321,8 @@ class GraphStep:
              ptr(o['row']), ptr(o['vp']), ptr(o['view']), ptr(o['a_num']), ptr(o['cand_view']), ptr(o['sincos']), None, s)
         cur, par = self.obs
         ucand = st.cands(par['vp'], par['cand_view'], par['sincos'], par['a_num'], A)
-        call('sf_gather_actions', byref(ucand), cap, ptr(act), ptr(self.u_prev), s)
+        # (the previous action's embedding straight into the first half of the LSTM input rows: no copy in the step)
+        call('sf_gather_actions_ld', byref(ucand), cap, ptr(act), ptr(self.tape['xin']), 2 * st.F, s)
         H = self.H
         gat = (_lib.RowMove * 2)(_lib.RowMove(self.hpool.data_ptr(), self.h0.data_ptr(), hrow.data_ptr(), H, H, H, 0),
                                  _lib.RowMove(self.cpool.data_ptr(), self.c0.data_ptr(), hrow.data_ptr(), H, H, H, 0))
@@ -328,7 +332,7 @@ class GraphStep:
         w = decoder_w_struct(decoder_params(self.dec))
         tp = tape_struct(self.tape)
         call('sf_attn_decoder_fwd', byref(w), byref(pano), byref(cnd), cap, self.H, self.D, self.T,
-             ptr(self.u_prev), ptr(self.h0), ptr(self.c0), ptr(self.ctx), ptr(self.mask), ptr(crow), byref(tp), None,
+             None, ptr(self.h0), ptr(self.c0), ptr(self.ctx), ptr(self.mask), ptr(crow), byref(tp), None,
              None, 0, *ws_args(self.dev))
         call('sf_logprob_topk', ptr(self.tape['logit']), A, cap, A, ptr(cur['a_num']), A, None, ptr(self.logp), s)
         sca = (_lib.RowMove * 3)(*(_lib.RowMove(src.data_ptr(), pool.data_ptr(), dst.data_ptr(), width, width, width, 1)
