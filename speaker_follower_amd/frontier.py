@@ -554,7 +554,8 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
                                          space.root_key)
     block = fd.inputs if use_graph else np.zeros((8, cap), np.int32)
     mark('setup')
-    while True:
+    native_loop = use_graph and getattr(agent, 'search_native_loop', True) and fd.native_loop_ready()
+    while not native_loop:
         if use_graph:
             base = fd.n
             logp = fd.run(core.fill_inputs(block, base))
@@ -563,6 +564,15 @@ def state_factored_search(agent, completion_size, successor_size, load_next_mini
             base, logp = fd.step_logprobs(_inputs_from_block(space, block, n))
         if core.advance(logp, base) == 0 or core.done():
             break
+    while native_loop:
+        # the same loop inside the native module: inputs -> graph launch -> stream sync -> bookkeeping without coming
+        # back to Python between iterations (sim/frontier_core.cpp: run_graph); it returns when the pool must grow
+        status, fd.n, _ = core.run_graph(*fd.native_launch_args(), block, fd.out, fd.n, fd.pool_rows)
+        if status == 0:
+            break
+        if status != 1:
+            raise RuntimeError('hipGraphLaunch / hipStreamSynchronize failed in the native search loop (hip error %d)' % -status)
+        fd._grow(fd.n + cap)
     mark('iterations')
     t = Hypotheses.from_arrays(*core.hypotheses())
     completed, visits = core.results()

@@ -357,6 +357,15 @@ class GraphStep:
         self.graph, self._stream = graph, side                       # (the graph bakes the capture stream's workspace)
         self.baked = bytes(decoder_w_struct(decoder_params(self.dec)))
 
+    # ---- the native loop (sim/frontier_core.cpp: run_graph) launches the graph itself
+    def native_loop_ready(self):
+        return self.graph is not None and hasattr(self.graph, 'raw_cuda_graph_exec') and _hip_entry_points() is not None
+
+    def native_launch_args(self):
+        """(hipGraphLaunch, hipStreamSynchronize, graph exec handle, stream handle) as integers."""
+        launch, sync = _hip_entry_points()
+        return launch, sync, int(self.graph.raw_cuda_graph_exec()), int(torch.cuda.current_stream(self.dev).cuda_stream)
+
     # ---- per iteration
     def run(self, n):
         """Inputs are in `self.inputs` (columns 0..n-1; the rest padding with destination -1).  Returns the
@@ -386,6 +395,30 @@ class GraphStep:
             return []
         r = torch.tensor(rows, dtype=torch.int64, device=self.dev)
         return list(self.apool[r].cpu().numpy())
+
+
+_HIP_ENTRY = []
+
+
+def _hip_entry_points():
+    """Addresses of hipGraphLaunch / hipStreamSynchronize in the HIP runtime THIS process has loaded (the one torch and
+    libsf_hip.so run on), for the native search loop -- or None."""
+    if not _HIP_ENTRY:
+        found = None
+        try:
+            path = None
+            with open('/proc/self/maps') as f:
+                for line in f:
+                    if 'libamdhip64' in line:
+                        path = line.split()[-1]
+                        break
+            if path:
+                hip = C.CDLL(path)
+                found = (C.cast(hip.hipGraphLaunch, C.c_void_p).value, C.cast(hip.hipStreamSynchronize, C.c_void_p).value)
+        except (OSError, AttributeError):
+            found = None
+        _HIP_ENTRY.append(found)
+    return _HIP_ENTRY[0]
 
 
 def graph_step_for(agent, nav, n_inst, cap):

@@ -117,9 +117,11 @@ class StateFactored {
     // repeat column 0 with destination -1.
     int fill_inputs(py::array_t<int32_t, py::array::c_style> out, i64 base) const {
         if (out.ndim() != 2 || out.shape(0) != 8) throw std::invalid_argument("inputs buffer must be int32 [8, cap]");
-        const int cap = (int)out.shape(1), N = (int)frontier_.size();
+        return fill_inputs_raw(out.mutable_data(), (int)out.shape(1), base);
+    }
+    int fill_inputs_raw(int32_t* o, int cap, i64 base) const {
+        const int N = (int)frontier_.size();
         if (N > cap || N == 0) throw std::invalid_argument("frontier does not fit the inputs buffer");
-        int32_t* o = out.mutable_data();
         for (int i = 0; i < cap; ++i) {
             const i64 f = frontier_[i < N ? i : 0];
             const i64 s = sid_[f], p = parent_[f];
@@ -143,10 +145,49 @@ class StateFactored {
     // the size of the next frontier.
     int advance(py::array_t<float, py::array::c_style> logp, i64 base) {
         if (logp.ndim() != 2) throw std::invalid_argument("logp must be float32 [states, actions]");
-        const int N = (int)frontier_.size();
-        if (logp.shape(0) < N) throw std::invalid_argument("logp has fewer rows than the frontier");
+        if (logp.shape(0) < (i64)frontier_.size()) throw std::invalid_argument("logp has fewer rows than the frontier");
+        return advance_raw(logp.data(), logp.shape(1), base);
+    }
+    // The whole loop of the search natively (follower.py:783-905 iterated): inputs of the frontier into the pinned
+    // block -> launch of the decoder-step graph -> stream sync -> bookkeeping, until every instance has its completions,
+    // the frontier is empty, or the next states would not fit the state pool (the caller grows it and calls again).
+    // `launch` / `sync` are hipGraphLaunch / hipStreamSynchronize of the process's HIP runtime, handed over as
+    // addresses (this module does not link against HIP); the GIL is released while it runs.
+    // Returns (status, base, iterations): 0 finished, 1 pool full, < 0: -(hip error of the launch / sync).
+    py::tuple run_graph(std::uintptr_t launch, std::uintptr_t sync, std::uintptr_t graph_exec, std::uintptr_t stream,
+                        py::array_t<int32_t, py::array::c_style> inputs, py::array_t<float, py::array::c_style> logp,
+                        i64 base, i64 pool_rows) {
+        if (inputs.ndim() != 2 || inputs.shape(0) != 8) throw std::invalid_argument("inputs buffer must be int32 [8, cap]");
+        if (logp.ndim() != 2 || logp.shape(0) < inputs.shape(1)) throw std::invalid_argument("logp must be float32 [>= cap, actions]");
+        using LaunchFn = int (*)(void*, void*);
+        using SyncFn = int (*)(void*);
+        const LaunchFn do_launch = reinterpret_cast<LaunchFn>(launch);
+        const SyncFn do_sync = reinterpret_cast<SyncFn>(sync);
+        int32_t* in = inputs.mutable_data();
+        const int cap = (int)inputs.shape(1);
         const float* lp = logp.data();
         const i64 ld = logp.shape(1);
+        int status = 0, iterations = 0;
+        {
+            py::gil_scoped_release nogil;
+            for (;;) {
+                const int n = (int)frontier_.size();
+                if (n == 0 || done()) break;
+                if (base + n > pool_rows) { status = 1; break; }
+                fill_inputs_raw(in, cap, base);
+                int rc = do_launch(reinterpret_cast<void*>(graph_exec), reinterpret_cast<void*>(stream));
+                if (rc == 0) rc = do_sync(reinterpret_cast<void*>(stream));
+                if (rc != 0) { status = -rc; break; }
+                ++iterations;
+                const int next = advance_raw(lp, ld, base);
+                base += n;
+                if (next == 0) break;
+            }
+        }
+        return py::make_tuple(status, base, iterations);
+    }
+    int advance_raw(const float* lp, const i64 ld, i64 base) {
+        const int N = (int)frontier_.size();
         // ---- successors of every expanded state, instance by instance (the frontier is grouped by instance)
         int i = 0;
         while (i < N) {
@@ -307,6 +348,8 @@ PYBIND11_MODULE(sf_frontier, m) {
         .def("done", &StateFactored::done)
         .def("fill_inputs", &StateFactored::fill_inputs, py::arg("out"), py::arg("base"))
         .def("advance", &StateFactored::advance, py::arg("logp"), py::arg("base"))
+        .def("run_graph", &StateFactored::run_graph, py::arg("launch"), py::arg("sync"), py::arg("graph_exec"), py::arg("stream"),
+             py::arg("inputs"), py::arg("logp"), py::arg("base"), py::arg("pool_rows"))
         .def("hypotheses", &StateFactored::hypotheses)
         .def("results", &StateFactored::results);
 }
