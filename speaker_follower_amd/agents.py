@@ -599,6 +599,10 @@ class Seq2SeqSpeaker(object):
         return getattr(feats[0], 'store', None) or getattr(self, 'store', None)
 
     SCORE_CHUNK = 128          # rows of one persistent word-loop launch (csrc/sf_persist.hip)
+    # large teacher-forced scoring sweeps: the full chunks as replayed graphs on two streams (speaker.SpeakerSweep) instead
+    # of launch-by-launch issue: -3.5 ms per minibatch of 64 instructions once every (stream, path-step count) graph is
+    # captured, ~0.3 s of captures before that (tools/pragmatic_scoring_ab.py): pays after ~85 minibatches.  Off by default.
+    score_graphs = False
 
     @gc_paused
     def _score_on_device(self, path_obs, path_actions, encoded_instructions, feedback, store):
@@ -720,17 +724,42 @@ class Seq2SeqSpeaker(object):
             return parts
         pend = _PendingScores()
         pend.B, pend.S, pend.feedback, pend.store, pend.sweep, pend.site = B, S, feedback, store, sweep, eng.site_next
-        pend.parts = sweep()
+        pend.graphs = None
+        n_full = B // self.SCORE_CHUNK
+        if self.score_graphs and feedback == 'teacher' and n_full >= 4 and eng.persistent and eng.group is None:
+            # the full chunks as replayed graphs on two streams (speaker.SpeakerSweep: one captured pass per stream and
+            # path-step count; the encoder steps of one chunk run beside the other stream's word recurrence), the
+            # remainder issued launch by launch behind them
+            key = (id(store), S, self.instruction_len)
+            sw = self.__dict__.setdefault('_score_sweeps', {}).get(key)
+            if sw is None or sw.enc is not self.encoder or sw.dec is not self.decoder:
+                sw = self._score_sweeps[key] = spk.SpeakerSweep(self.encoder, self.decoder, store, self.SCORE_CHUNK, S,
+                                                                feedback='teacher', Lmax=self.instruction_len, with_scores=True)
+            full = [self._index_batch(n, rows_of, encoded_instructions, lo, lo + self.SCORE_CHUNK)
+                    for lo in range(0, n_full * self.SCORE_CHUNK, self.SCORE_CHUNK)]
+            pend.graphs = (sw, sw.issue(full))
+            lo = n_full * self.SCORE_CHUNK
+            pend.parts = []
+            if lo < B:
+                st = eng.score(staged_batch(0, lo, B), S, feedback, train=False)
+                pend.parts.append((st.words[1:].to(torch.float32), st.step_scores, st.sum_cnt))
+        else:
+            pend.parts = sweep()
         mark('issued')
         return pend
 
     def _finish_scores(self, pend, instr_ids, mark=lambda name: None):
         from .runtime import take_fault
         eng, dev = self._engine, pend.store.device
+        swept = None
+        if pend.graphs is not None:
+            sw, handle = pend.graphs
+            swept = sw.finish(handle, check_faults=False)                     # (waits for its two streams)
         bits = take_fault(dev)                                                # (one sync for the whole sweep)
         mark('device done')
         parts = pend.parts
         if bits:                                                              # a starved persistent launch: per-step kernels
+            swept = None                                                      # (everything again, launch by launch)
             eng.fallbacks += 1
             keep, eng.persistent, eng.site_next = eng.persistent, False, pend.site
             try:
@@ -740,9 +769,23 @@ class Seq2SeqSpeaker(object):
             again = take_fault(dev)
             if again:
                 raise PersistentLaunchFault('fault bits %d, and %d after the per-step re-issue' % (bits, again))
-        both = torch.cat((torch.cat([p_[0] for p_ in parts], dim=1), torch.cat([p_[1] for p_ in parts], dim=1)),
-                         dim=0).cpu().numpy()
-        sum_cnt = torch.stack([p_[2] for p_ in parts]).sum(0).cpu().numpy()            # [S,2]: all rows
+        if swept is not None:
+            w16, sc, cnt = swept                                              # [n,S,128] int16 / f32, [n,S,2]
+            S_ = pend.S
+            words_h = w16.transpose(1, 0, 2).reshape(S_, -1).astype(np.float32)
+            scores_h = sc.transpose(1, 0, 2).reshape(S_, -1)
+            sum_cnt = cnt.astype(np.float32).sum(0)
+            if parts:
+                tail = torch.cat((parts[0][0], parts[0][1]), dim=0).cpu().numpy()
+                words_h = np.concatenate((words_h, tail[:S_]), axis=1)
+                scores_h = np.concatenate((scores_h, tail[S_:]), axis=1)
+                # (float32 sums chunk by chunk, as the stacked device sum does)
+                sum_cnt = sum_cnt + parts[0][2].cpu().numpy()
+            both = np.concatenate((words_h, scores_h), axis=0)
+        else:
+            both = torch.cat((torch.cat([p_[0] for p_ in parts], dim=1), torch.cat([p_[1] for p_ in parts], dim=1)),
+                             dim=0).cpu().numpy()
+            sum_cnt = torch.stack([p_[2] for p_ in parts]).sum(0).cpu().numpy()        # [S,2]: all rows
         mark('downloaded')
         return self._score_outputs(instr_ids, both, pend.S, None, sum_cnt, dev, mark)
 

@@ -581,7 +581,11 @@ class SpeakerSweep:
     graphs captured with the per-step kernels (`fallbacks` counts them).  `sample` feedback needs vocab <= 1024 (the
     two-level draw of sf_sampling.h); the pinned staging buffers grow with the longest path met."""
 
-    def __init__(self, encoder, decoder, store, batch_size, words, feedback='argmax', Lmax=80, n_streams=2, slots=2):
+    def __init__(self, encoder, decoder, store, batch_size, words, feedback='argmax', Lmax=80, n_streams=2, slots=2,
+                 with_scores=False):
+        """with_scores: every minibatch also returns its per-word scores [S,B] and its per-step (sum, count) table [S,2]
+        (teacher-forced scoring sweeps: Seq2SeqSpeaker._issue_scores)."""
+        self.with_scores = with_scores
         self.enc, self.dec, self.store = encoder, decoder, store
         self.B, self.S, self.Lmax, self.feedback = batch_size, words, Lmax, feedback
         self.streams = [torch.cuda.Stream(device=store.device) for _ in range(n_streams)]
@@ -618,14 +622,29 @@ class SpeakerSweep:
 
     def run(self, batches, _persistent=True):
         """`batches`: sequence of synth.SpeakerBatch-like index batches of `batch_size` paths.  Returns an int16 array
-        [n, S, B] of generated word ids (pinned host memory)."""
+        [n, S, B] of generated word ids (pinned host memory); with_scores: (words, scores [n,S,B] f32, sum_cnt [n,S,2])."""
+        return self.finish(self.issue(batches, _persistent))
+
+    def issue(self, batches, _persistent=True):
+        """Everything of `run` that does not wait: packs, copies and replays every minibatch on its stream and returns
+        the handle `finish` collects (the host is free in between: Seq2SeqSpeaker's pragmatic scoring builds its result
+        dictionaries there)."""
         import time
         dev = self.store.device
         n = len(batches)
         out = torch.empty(n, self.S, self.B, dtype=torch.int16).pin_memory()
+        sc = torch.empty(n, self.S, self.B, dtype=torch.float32).pin_memory() if self.with_scores else None
+        cnt = torch.empty(n, self.S, 2, dtype=torch.float32).pin_memory() if self.with_scores else None
         self.host_pack_s = 0.0
         from .runtime import take_fault
         take_fault(dev)
+        for s_ in self.streams:                                  # (the weights' derived layouts are refreshed on the caller's stream)
+            s_.wait_stream(torch.cuda.current_stream(dev))
+        # a path-step count met for the first time is captured for EVERY stream at once (a capture is tens of
+        # milliseconds: better in front of the sweep than in the middle of it)
+        for Tp in sorted({int(sb.path_len.max()) for sb in batches}):
+            for si in range(len(self.streams)):
+                self._graph(si, Tp, _persistent)
         for i, sb in enumerate(batches):
             si, slot = i % len(self.streams), (i // len(self.streams)) % self.slots
             pin = self.pinned[si][slot]
@@ -648,13 +667,25 @@ class SpeakerSweep:
                 replay()
                 words16.copy_(st.words[1:])                      # int64 -> int16 on the device (ids < 2^15)
                 out[i].copy_(words16, non_blocking=True)
+                if self.with_scores:
+                    sc[i].copy_(st.step_scores, non_blocking=True)
+                    cnt[i].copy_(st.sum_cnt, non_blocking=True)
+        return dict(batches=batches, out=out, scores=sc, cnt=cnt, persistent=_persistent)
+
+    def finish(self, handle, check_faults=True):
+        """Waits for the sweep `issue` started; a sweep that saw a persistent-launch fault is re-run -- all of it -- on
+        the per-step kernels (check_faults=False: the caller reads the fault words itself, runtime.take_fault)."""
+        from .runtime import take_fault
+        dev = self.store.device
         for s in self.streams:
             s.synchronize()
-        bits = take_fault(dev)
+        bits = take_fault(dev) if check_faults else 0
         if bits:
-            if not _persistent:
+            if not handle['persistent']:
                 raise PersistentLaunchFault('fault bits %d raised by a sweep on the per-step kernels' % bits)
             # a starved persistent launch poisoned some minibatch: the whole sweep again on the per-step kernels
             self.fallbacks += 1
-            return self.run(batches, _persistent=False)
-        return out.numpy()
+            return self.finish(self.issue(handle['batches'], _persistent=False))
+        if self.with_scores:
+            return handle['out'].numpy(), handle['scores'].numpy(), handle['cnt'].numpy()
+        return handle['out'].numpy()

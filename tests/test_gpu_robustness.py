@@ -465,13 +465,56 @@ def test_chunked_route_scoring_survives_starved_persistent_launches(forced_timeo
         assert abs(a['score'] - b['score']) <= 2e-4 * max(1.0, abs(b['score']))
 
 
+def test_route_scoring_as_replayed_graphs_equals_the_launch_by_launch_sweep(forced_timeout):
+    """Seq2SeqSpeaker.score_graphs: the full chunks of a large teacher-forced scoring sweep as replayed graphs on two
+    streams (speaker.SpeakerSweep with scores), the remainder launch by launch -- every route's words and scores and the
+    loss of the launch-by-launch sweep, on first use (captures) and on replay; a starved launch re-issues everything on
+    the per-step kernels."""
+    from speaker_follower_amd import _lib
+    env, agent, speaker = _index_world()
+    _lib.lib.sf_debug_persist_timeout(-1)
+    obs, acts, instr = _routes(agent, env)
+    cls = type(speaker)
+    keep = cls.SCORE_CHUNK
+    try:
+        cls.SCORE_CHUNK = 16
+        assert len(obs) // 16 >= 4 and len(obs) % 16 != 0                 # full chunks + a remainder
+        with torch.no_grad():
+            ref, loss_ref = speaker._score_obs_actions_and_instructions(obs, acts, instr, feedback='teacher')
+            speaker.score_graphs = True
+            first, loss_first = speaker._score_obs_actions_and_instructions(obs, acts, instr, feedback='teacher')
+            again, loss_again = speaker._score_obs_actions_and_instructions(obs, acts, instr, feedback='teacher')
+            assert len(speaker._score_sweeps) == 1 and speaker._engine.fallbacks == 0
+            _lib.lib.sf_debug_persist_timeout(0)                           # every persistent launch gives up its first wait
+            starved, _ = speaker._score_obs_actions_and_instructions(obs, acts, instr, feedback='teacher')
+            assert speaker._engine.fallbacks == 1
+    finally:
+        cls.SCORE_CHUNK = keep
+        speaker.score_graphs = False
+        _lib.lib.sf_debug_persist_timeout(-1)
+    assert abs(float(loss_first) - float(loss_ref)) <= 1e-5 * abs(float(loss_ref)) and float(loss_again) == float(loss_first)
+    for a, b, c, d in zip(ref, first, again, starved):
+        assert a['instr_id'] == b['instr_id'] == c['instr_id'] == d['instr_id']
+        assert a['word_indices'] == b['word_indices'] == c['word_indices'] == d['word_indices']
+        assert a['score'] == b['score'] == c['score'] and a['scores'] == b['scores']
+        assert abs(d['score'] - a['score']) <= 2e-4 * max(1.0, abs(a['score']))
+
+
 def test_a_capture_never_creates_its_workspace_inside_the_graph():
     """runtime.workspace under stream capture: a workspace first touched inside a capture would be zero-filled (64 MB) by
     EVERY replay -- it rode in every captured rollout until round 5.  Creating one under capture raises; the engines
     create their capture stream's workspace first (runtime.ensure_workspace) and their captures go through."""
     from speaker_follower_amd import runtime
     dev = torch.device('cuda', 0)
-    fresh = torch.cuda.Stream()
+    # a stream that has no workspace yet (torch recycles stream handles: one handed out before may come back)
+    keep = []
+    for _ in range(64):
+        fresh = torch.cuda.Stream()
+        keep.append(fresh)
+        if (0, fresh.cuda_stream) not in runtime._workspaces:
+            break
+    else:
+        pytest.skip('every stream handle torch hands out already has a workspace')
     g = torch.cuda.CUDAGraph()
     raised = False
     with torch.cuda.stream(fresh):
