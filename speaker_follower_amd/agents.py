@@ -399,8 +399,9 @@ class Seq2SeqAgent(BaseAgent):
         from .optim import FusedAdam
         if not self.train_graph or '+' in self.feedback or self.beam_size != 1:
             return False
-        if not (isinstance(encoder_optimizer, FusedAdam) and isinstance(decoder_optimizer, FusedAdam)):
-            return False
+        for o in (encoder_optimizer, decoder_optimizer):
+            if not (isinstance(o, FusedAdam) or (self.adopt_torch_adam and FusedAdam.adoptable(o))):
+                return False
         if self._device_table() is None or self._engine is None:
             return False
         eng = self._engine
@@ -417,8 +418,42 @@ class Seq2SeqAgent(BaseAgent):
         from .nav import DeviceNavBatch
         from .runtime import take_fault
         table, eng, dev = self._device_table(), self._engine, self._device()
-        opts = (encoder_optimizer, decoder_optimizer)
-        key = (id(encoder_optimizer), id(decoder_optimizer), self.feedback, id(table), self.episode_len)
+        given = (encoder_optimizer, decoder_optimizer)
+        opts = tuple(self._fused_for(o) for o in given)
+        try:
+            return self._replay_iterations(opts, n_iters, table, eng, dev)
+        finally:
+            for o, f in zip(given, opts):             # the reference's own optimizer objects get their state back
+                if f is not o:
+                    f.store_torch_state(o)
+
+    adopt_torch_adam = True      # train(): a plain torch.optim.Adam (train.py:263-268) is mirrored by an optim.FusedAdam
+
+    def _fused_for(self, opt):
+        """`opt` itself (optim.FusedAdam), or the FusedAdam that mirrors this torch.optim.Adam: same parameters (their
+        data moves into one flat buffer, once), hyper-parameters and state taken over at the start of every train() call
+        and handed back at its end -- checkpoints of `opt.state_dict()` and steps taken elsewhere stay consistent."""
+        import weakref
+        from .optim import FusedAdam
+        if isinstance(opt, FusedAdam):
+            return opt
+        mirrors = self.__dict__.setdefault('_fused_mirrors', {})
+        hit = mirrors.get(id(opt))
+        if hit is None or hit[0]() is not opt:
+            g = opt.param_groups[0]
+            fused = FusedAdam(g['params'], lr=g['lr'], betas=tuple(g['betas']), eps=g['eps'], weight_decay=g['weight_decay'])
+            mirrors[id(opt)] = hit = (weakref.ref(opt), fused)
+        hit[1].load_torch_state(opt)
+        return hit[1]
+
+    def _replay_iterations(self, opts, n_iters, table, eng, dev):
+        from .nav import DeviceNavBatch
+        from .runtime import take_fault
+        encoder_optimizer, decoder_optimizer = opts
+        # (a captured iteration holds the optimizers' hyper-parameters as kernel arguments: a changed learning rate is a
+        # new graph)
+        hyper = tuple((g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']) for o in opts for g in o.param_groups)
+        key = (id(encoder_optimizer), id(decoder_optimizer), self.feedback, id(table), self.episode_len, hyper)
         cached = self.__dict__.get('_train_graph_state')
         take_fault(dev)                                       # (whatever an earlier pass left behind is not ours)
         for _ in range(n_iters):

@@ -156,6 +156,56 @@ class FusedAdam(torch.optim.Optimizer):
             ps = f['params']
             torch._C._autograd._unsafe_set_version_counter(ps, [p._version + 1 for p in ps])
 
+    # ---- torch.optim.Adam <-> this optimizer (agents.Seq2SeqAgent.train adopts the reference's own `optim.Adam` objects,
+    # train.py:263-268, for its replayed iterations and hands the state back afterwards)
+    @staticmethod
+    def adoptable(opt):
+        """A torch.optim.Adam this class reproduces exactly: one parameter group, no amsgrad / maximize."""
+        if type(opt) is not torch.optim.Adam or len(opt.param_groups) != 1:
+            return False
+        g = opt.param_groups[0]
+        return not (g.get('amsgrad') or g.get('maximize') or g.get('differentiable'))
+
+    @torch.no_grad()
+    def load_torch_state(self, opt):
+        """Hyper-parameters, moments and step count of `opt` (same parameters, same order) into this optimizer."""
+        g = opt.param_groups[0]
+        mine = self.param_groups[0]
+        mine['lr'], mine['betas'], mine['eps'], mine['weight_decay'] = g['lr'], tuple(g['betas']), g['eps'], g['weight_decay']
+        f = self._flat[0]
+        off, step = 0, 0
+        for p in f['params']:
+            n = p.numel()
+            st = opt.state.get(p)
+            if st:
+                f['m'][off:off + n].copy_(st['exp_avg'].reshape(-1))
+                f['v'][off:off + n].copy_(st['exp_avg_sq'].reshape(-1))
+                step = max(step, int(st['step']))
+            else:
+                f['m'][off:off + n].zero_()
+                f['v'][off:off + n].zero_()
+            off += n
+        f['step'] = step
+
+    @torch.no_grad()
+    def store_torch_state(self, opt):
+        """The other way: `opt.state` as torch.optim.Adam would hold it after the same steps."""
+        f = self._flat[0]
+        if f['step'] == 0:
+            return
+        off = 0
+        for p in f['params']:
+            n = p.numel()
+            st = opt.state[p]
+            if 'exp_avg' not in st or st['exp_avg'].shape != p.shape:
+                st['exp_avg'], st['exp_avg_sq'] = torch.zeros_like(p), torch.zeros_like(p)
+            st['exp_avg'].copy_(f['m'][off:off + n].view_as(p))
+            st['exp_avg_sq'].copy_(f['v'][off:off + n].view_as(p))
+            old = st.get('step')
+            st['step'] = (torch.tensor(float(f['step']), dtype=old.dtype, device=old.device) if torch.is_tensor(old)
+                          else torch.tensor(float(f['step'])))
+            off += n
+
     # moments in the layout of torch.optim.Adam's state (per parameter), for inspection / tests
     def moments(self, p):
         for f in self._flat:

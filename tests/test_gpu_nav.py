@@ -258,7 +258,7 @@ def test_agent_api_with_device_env_trains_and_tests(world, tmp_path):
     assert min(agent.losses[3:]) < agent.losses[0]
 
 
-def _fresh_agent(world, graph, lr=1e-3):
+def _fresh_agent(world, graph, lr=1e-3, torch_adam=False):
     from speaker_follower_amd import agents, model, optim, synth
     env, _, store, nt, enc0, dec0 = world
     d = synth.FULL
@@ -273,8 +273,9 @@ def _fresh_agent(world, graph, lr=1e-3):
     ag.store = store
     ag.use_device_env(nt)
     ag.train_graph = graph
-    oe = optim.FusedAdam([p for p in enc.parameters() if p.requires_grad], lr=lr, weight_decay=5e-4)
-    od = optim.FusedAdam([p for p in dec.parameters() if p.requires_grad], lr=lr, weight_decay=5e-4)
+    Adam = torch.optim.Adam if torch_adam else optim.FusedAdam
+    oe = Adam([p for p in enc.parameters() if p.requires_grad], lr=lr, weight_decay=5e-4)
+    od = Adam([p for p in dec.parameters() if p.requires_grad], lr=lr, weight_decay=5e-4)
     # (the env reshuffles its items with `random` when an epoch wraps, env.py:601-614: same order, same generator state
     # for every agent built here)
     import random
@@ -341,3 +342,33 @@ def test_agent_train_on_graphs_survives_a_starved_persistent_launch(world):
     assert torch.isfinite(w1).all() and not torch.equal(w1, w0) and np.isfinite(ag.losses).all()
     ag.train(oe, od, 2, feedback='sample')                         # and the graph goes on behind it
     assert oe.host_steps() == [5] and torch.isfinite(weights()).all()
+
+
+def test_agent_train_adopts_the_references_own_torch_adam(world):
+    """train.py:263-268 hands Seq2SeqAgent.train two plain torch.optim.Adam objects.  The agent mirrors each by an
+    optim.FusedAdam (same parameters, hyper-parameters and state, taken over at the start of a train() call and handed back
+    at its end) and replays whole iterations; losses, weights and the optimizers' own state follow the loop in which torch's
+    Adam steps on launch-by-launch iterations; a changed learning rate is a new graph."""
+    out = {}
+    for graph in (False, True):
+        ag, oe, od, weights = _fresh_agent(world, graph, lr=1e-4, torch_adam=True)
+        ag.adopt_torch_adam = graph
+        ag.train(oe, od, 3, feedback='teacher')
+        first = list(ag.losses)
+        assert (ag.__dict__.get('_train_graph_state') is not None) == graph
+        for o in (oe, od):
+            steps = {int(st['step']) for st in o.state.values()}
+            assert steps == {3} and len(o.state) == len(o.param_groups[0]['params'])
+        for g in od.param_groups:
+            g['lr'] = 5e-5                                          # (a schedule: the next call captures anew)
+        ag.train(oe, od, 2, feedback='teacher')
+        out[graph] = (first + list(ag.losses), weights(), {k: v.clone() for k, v in next(iter(od.state.values())).items()
+                                                           if torch.is_tensor(v) and v.dim() > 0})
+        assert {int(st['step']) for st in od.state.values()} == {5}
+    np.testing.assert_allclose(out[True][0], out[False][0], rtol=2e-4)
+    d = (out[True][1] - out[False][1]).abs().max().item()
+    print('[agent.train, torch Adam adopted] max weight difference after 5 iterations: %.2e' % d)
+    assert d < 3e-4 and torch.isfinite(out[True][1]).all()
+    for k in out[True][2]:                                           # the moments torch's Adam would hold
+        ref = out[False][2][k]
+        assert float((out[True][2][k] - ref).abs().max()) <= 2e-3 * float(ref.abs().max()) + 1e-12, k
