@@ -688,6 +688,13 @@ class Seq2SeqSpeaker(object):
                         seen[k] = r
                     rows.append(r)
             return np.array(rows, np.float64).reshape(-1, 6)
+        return self._score_index_routes(n, pair_rows, encoded_instructions, instr_ids, feedback, store, mark)
+
+    def _score_index_routes(self, n, pair_rows, encoded_instructions, instr_ids, feedback, store, mark=lambda name: None):
+        """The scoring pass over routes in INDEX FORM: n [routes] steps each, pair_rows(lo, hi) = the [sum n[lo:hi], 6] rows
+        (vp_row, viewIndex, absViewIndex, rel_heading, rel_elevation, is_stop) of routes lo..hi-1, route-major."""
+        from . import speaker as spk
+        B = len(n)
         if getattr(self, '_engine', None) is None or self._engine.store is not store:
             self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
         eng = self._engine
@@ -935,7 +942,26 @@ class Seq2SeqSpeaker(object):
                              if tok is not None else list(item['word_indices']))
         return outputs, loss
 
+    index_gold_routes = True   # rollout(): the minibatch's gold routes from the navigation tables (nav.NavTable.gold_routes)
+                               # instead of a lock-step walk of the host environment
+
     def rollout(self, load_next_minibatch=True):
+        store = self._env_store()
+        if (self.index_gold_routes and store is not None and getattr(self.env, 'host_table', 1) is None
+                and hasattr(self.env, 'graphs')):
+            # speaker.py:348-360 without the per-step host loop of env.py:823-848: teacher actions and transitions are
+            # table look-ups over the whole minibatch, the routes arrive in index form (what the device consumes)
+            from .nav import table_for
+            self.env.reset(load_next_minibatch=load_next_minibatch)
+            items = list(self.env.batch)
+            n, rows = table_for(self.env, store).gold_routes(items, self.max_episode_len)
+            first = np.concatenate(([0], np.cumsum(n)))
+            outputs, loss = gc_paused(self._score_index_routes)(
+                n, lambda lo, hi: rows[first[lo]:first[hi]], [it['instr_encoding'] for it in items],
+                [it['instr_id'] for it in items], self.feedback, store)
+            self.loss = loss
+            self.losses.append(float(loss.detach()) if torch.is_tensor(loss) else float(loss))
+            return outputs
         path_obs, path_actions, enc = self.env.gold_obs_actions_and_instructions(
             self.max_episode_len, load_next_minibatch=load_next_minibatch)
         outputs, loss = self._score_obs_actions_and_instructions(path_obs, path_actions, enc,

@@ -50,9 +50,48 @@ class NavGraph:
     def nodes(self):
         return list(self.adj.keys())
 
+    def _all_pairs(self):
+        """Every source at once with scipy's Dijkstra (C): (node list, index, dist [n,n], pred [n,n]) -- or None when
+        scipy is missing or a shortest path of this graph is not unique to the last bit (two predecessors of a node at
+        exactly equal distance: then the per-source search below, whose relaxation order decides, stays the authority).
+        The first pass over a new scan asked for ~150 Python searches (one per viewpoint, nav.NavTable.hops); this is one
+        native call per scan."""
+        if not hasattr(self, '_ap'):
+            self._ap = None
+            try:
+                from scipy.sparse import csr_matrix
+                from scipy.sparse.csgraph import dijkstra
+                nodes = self.nodes()
+                ix = {v: i for i, v in enumerate(nodes)}
+                n = len(nodes)
+                rows, cols, vals = [], [], []
+                for u, nb in self.adj.items():
+                    for v, w in nb.items():
+                        rows.append(ix[u]); cols.append(ix[v]); vals.append(w)
+                rows, cols, vals = np.array(rows), np.array(cols), np.array(vals, np.float64)
+                if n and (vals > 0).all():
+                    dist, pred = dijkstra(csr_matrix((vals, (rows, cols)), shape=(n, n)), directed=True,
+                                          return_predecessors=True)
+                    # unique to the last bit?  an edge (u, v) with dist[s, u] + w == dist[s, v] that is not v's predecessor
+                    via = dist[:, rows] + vals[None, :]                      # [sources, edges]
+                    tie = (via == dist[:, cols]) & (pred[:, cols] != rows[None, :]) & np.isfinite(via)
+                    if not tie.any():
+                        self._ap = (nodes, ix, dist, pred)
+            except ImportError:
+                pass
+        return self._ap
+
     def shortest(self, src):
         """(dist, prev) from src to every reachable node."""
         if src not in self._sp:
+            ap = self._all_pairs()
+            if ap is not None and src in ap[1]:
+                nodes, ix, dist, pred = ap
+                i = ix[src]
+                reach = np.flatnonzero(np.isfinite(dist[i]))
+                d = {nodes[j]: float(dist[i, j]) for j in reach}
+                self._sp[src] = (d, {nodes[j]: nodes[pred[i, j]] for j in reach if j != i})
+                return self._sp[src]
             dist, prev, heap = {src: 0.0}, {}, [(0.0, src)]
             while heap:
                 d, u = heapq.heappop(heap)
@@ -65,6 +104,32 @@ class NavGraph:
                         heapq.heappush(heap, (nd, v))
             self._sp[src] = (dist, prev)
         return self._sp[src]
+
+    def next_hops(self, dst):
+        """{node: the second node of path(node, dst)} for every node that has a path of at least one edge to dst -- the
+        teacher's table (env.py:742-761) for a whole scan, straight from the all-pairs predecessor matrix when there is
+        one (no per-source dictionaries), else from path()."""
+        ap = self._all_pairs()
+        if ap is None or dst not in ap[1]:
+            out = {}
+            for v in self.nodes():
+                if v != dst:
+                    p = self.path(v, dst)
+                    if p is not None:
+                        out[v] = p[1]
+            return out
+        nodes, ix, dist, pred = ap
+        n, j = len(nodes), ix[dst]
+        src = np.arange(n)
+        ok = np.isfinite(dist[:, j]) & (src != j)
+        x = np.full(n, j)
+        for _ in range(n):                                   # walk back from dst until the predecessor is the source
+            p = pred[src, x]
+            more = ok & (p != src) & (p >= 0)
+            if not more.any():
+                break
+            x = np.where(more, p, x)
+        return {nodes[i]: nodes[x[i]] for i in np.flatnonzero(ok)}
 
     def path(self, src, dst):
         dist, prev = self.shortest(src)

@@ -118,6 +118,55 @@ class NavTable:
         return _lib.NavTableS(self.a_num.data_ptr(), self.next_row.data_ptr(), self.cand_view.data_ptr(),
                               self.sincos.data_ptr(), self.feat_row.data_ptr(), self.A, V)
 
+    def gold_routes(self, items, max_steps):
+        """The shortest-path routes of a minibatch (env.py:823-848: from every item's start pose follow the teacher
+        action until it says stop, at most max_steps actions) in INDEX FORM, from the tables alone: n [B] int32 actions
+        per route and rows [sum n, 6] float64, route-major, one per (state, action): (feature row, view index, the
+        action's view index, rel_heading, rel_elevation, is_stop) -- what the speaker's scoring consumes (speaker.py:
+        68-121).  Teacher and transition rules are sf_nav_step's (csrc/sf_glue.h: nav_advance_slot): stop at the goal,
+        else the first candidate that leads to the next hop; a candidate that is the current viewpoint leaves the state."""
+        h, env = self.host, self.env
+        B = len(items)
+        row = np.array([self.row_of[(it['scan'], it['path'][0])] for it in items], np.int64)
+        view = np.array([env.start_view(WorldState(it['scan'], it['path'][0], it['heading'], 0)) for it in items], np.int64)
+        base = np.array([self.base[it['scan']] for it in items], np.int64)
+        hop_of = [self.hops(it['scan'], it['path'][-1]) for it in items]
+        hop = np.zeros((B, max(len(x) for x in hop_of)), np.int64)
+        for b, x in enumerate(hop_of):
+            hop[b, :len(x)] = x
+        A = h['next_row'].shape[1]
+        cols = np.arange(A)[None, :]
+        every = np.arange(B)
+        alive = np.ones(B, bool)
+        recs = []                                            # per step: (rows alive, their 6 columns)
+        for _ in range(max_steps):
+            s = row * V + view
+            goal_hop = hop[every, row - base]
+            nxt = h['next_row'][s]                           # [B, A]
+            leads = (nxt == goal_hop[:, None]) & (cols >= 1) & (cols < h['a_num'][s][:, None])
+            a = np.where((goal_hop != row) & leads.any(1), leads.argmax(1), 0)
+            move = a > 0
+            idx = np.flatnonzero(alive)
+            sa, aa, mv = s[idx], a[idx], move[idx]
+            recs.append((idx, np.stack((h['feat_row'][row[idx]], view[idx], np.where(mv, h['cand_view'][sa, aa], 0),
+                                        np.where(mv, h['heading'][sa, aa], 0.0), np.where(mv, h['elevation'][sa, aa], 0.0),
+                                        (~mv).astype(np.float64)), axis=1).astype(np.float64)))
+            alive = alive & move
+            if not alive.any():
+                break
+            nr = nxt[every, a]
+            go = move & (nr != row)
+            view = np.where(go, h['cand_view'][s, a], view)
+            row = np.where(go, nr, row)
+        n = np.zeros(B, np.int32)
+        for idx, _ in recs:
+            n[idx] += 1
+        first = np.concatenate(([0], np.cumsum(n)))
+        rows = np.zeros((int(first[-1]), 6), np.float64)
+        for t, (idx, part) in enumerate(recs):
+            rows[first[idx] + t] = part                      # (a route's steps are consecutive from step 0)
+        return n, rows
+
     def hops(self, scan, goal):
         """[rows of `scan`] int32: next nav row on the shortest path to `goal` (itself at the goal, and
         where no path exists), the table behind env.py:742-761."""
@@ -126,12 +175,11 @@ class NavTable:
             g = self.env.graphs[scan]
             b = self.base[scan]
             out = np.arange(b, b + self.scan_rows[scan], dtype=np.int32)
+            nxt = g.next_hops(goal)                      # (one look at the scan's all-pairs table, env.NavGraph)
             for i in range(self.scan_rows[scan]):
-                v = self.vp_of[b + i][1]
-                if v != goal:
-                    path = g.path(v, goal)
-                    if path is not None:
-                        out[i] = self.row_of[(scan, path[1])]
+                hop = nxt.get(self.vp_of[b + i][1])
+                if hop is not None:
+                    out[i] = self.row_of[(scan, hop)]
             self._hops[key] = out
         return self._hops[key]
 

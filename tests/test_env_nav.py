@@ -259,3 +259,34 @@ def test_full_r2r_geometry_table_regenerates_the_connectivity_directory(tmp_path
         a_max = max(a_max, int(a_num.max()))
         states += a_num.size * 3
     assert states == 10567 * 36 and a_max == 14          # A max 14 over the 90 graphs
+
+
+def test_gold_routes_from_the_tables_equal_the_environment_walk():
+    """nav.NavTable.gold_routes (the speaker agent's minibatch in index form, table look-ups over the whole minibatch)
+    against env.gold_obs_actions_and_instructions (env.py:823-848: the lock-step teacher walk over observation
+    dictionaries): same actions, and per (state, action) the row the speaker's scoring forms from the dictionaries
+    (speaker.py:68-121) -- feature row, view, the action's view, rel_heading / rel_elevation bit for bit, stop flag."""
+    from speaker_follower_amd import nav, features
+    from speaker_follower_amd.build import build_sim
+    build_sim(verbose=False)
+    e, n = _fixture_env(['gZ6f7yhEvPG', 'GdvgFV5R1Z5', 'YmJkqBEsHnH'])
+    store = features.FeatureStore(np.zeros((n, 36, 8), np.float32), device='cpu')
+    nt = nav.NavTable(e, store)
+    for max_steps in (10, 3):                                  # (3: routes cut before their stop action)
+        e.reset_epoch()
+        path_obs, path_actions, _ = e.gold_obs_actions_and_instructions(max_steps)
+        items = list(e.batch)
+        counts, rows = nt.gold_routes(items, max_steps)
+        assert counts.tolist() == [len(a) for a in path_actions]
+        want = []
+        for obs, actions in zip(path_obs, path_actions):
+            for t, a in enumerate(actions):
+                ob = obs[t]
+                if a > 0:
+                    d = ob['adj_loc_list'][a]
+                    want.append((ob['vp_row'], ob['viewIndex'], d['absViewIndex'], d['rel_heading'], d['rel_elevation'], 0.0))
+                else:
+                    want.append((ob['vp_row'], ob['viewIndex'], 0, 0.0, 0.0, 1.0))
+        assert np.array_equal(rows, np.array(want, np.float64))
+        if max_steps == 10:
+            assert all(a[-1] == 0 for a in path_actions) and len({len(a) for a in path_actions}) > 1

@@ -264,3 +264,46 @@ def test_speaker_agent_index_form_path_equals_the_dense_module_path(feedback):
         env.reset_epoch()
         spk.train(eo, do, 1, feedback='teacher')
     assert np.isfinite(spk.losses[0]) and spk.losses[0] < first          # the same minibatch: the loss goes down
+
+
+def test_speaker_agent_gold_routes_from_the_tables_equal_the_environment_walk():
+    """Seq2SeqSpeaker.rollout (speaker.py:348-360) over an index-form environment: the minibatch's gold routes from the
+    navigation tables (index_gold_routes, nav.NavTable.gold_routes) give the outputs and the loss of the lock-step walk
+    of the host environment -- and train() runs on them."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import search_world as W
+    from speaker_follower_amd import agents, features, model, optim
+    env, table = W.build_world(dense=False, n_items=24, batch=12, item_seed=5)
+    d = synth.FULL
+    w_enc, w_dec = synth.speaker_weights(W.SPEAKER_SEED)
+    senc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    sdec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=w_dec['embedding.weight'])
+    senc.load_state_dict({k: torch.tensor(v) for k, v in w_enc.items()})
+    sdec.load_state_dict({k: torch.tensor(v) for k, v in w_dec.items()})
+    senc.cuda().eval()
+    sdec.cuda().eval()
+    spk = agents.Seq2SeqSpeaker(env, '/tmp/sf_spk_gold.json', senc, sdec, W.INSTRUCTION_LEN, max_episode_len=W.EPISODE_LEN)
+    spk.store = features.FeatureStore(table)
+    out = {}
+    for index in (True, False):
+        spk.index_gold_routes = index
+        env.reset_epoch()
+        res = []
+        with torch.no_grad():
+            for fb in ('teacher', 'argmax'):
+                spk.feedback = fb
+                o = spk.rollout()
+                res.append(([(x['instr_id'], x['word_indices'], x['score']) for x in o], float(spk.loss)))
+        out[index] = res
+    for (a, la), (b, lb) in zip(out[True], out[False]):
+        assert [x[:2] for x in a] == [x[:2] for x in b]
+        np.testing.assert_allclose([x[2] for x in a], [x[2] for x in b], rtol=0, atol=1e-5)
+        assert abs(la - lb) <= 1e-6 * abs(lb)
+    spk.index_gold_routes = True
+    oe = optim.FusedAdam([p for p in senc.parameters() if p.requires_grad], lr=1e-4)
+    od = optim.FusedAdam([p for p in sdec.parameters() if p.requires_grad], lr=1e-4)
+    env.reset_epoch()
+    spk.train(oe, od, 3, feedback='teacher')
+    assert len(spk.losses) == 3 and np.isfinite(spk.losses).all()
