@@ -55,7 +55,7 @@ class NavGraph:
         scipy is missing or a shortest path of this graph is not unique to the last bit (two predecessors of a node at
         exactly equal distance: then the per-source search below, whose relaxation order decides, stays the authority).
         The first pass over a new scan asked for ~150 Python searches (one per viewpoint, nav.NavTable.hops); this is one
-        native call per scan."""
+        native call per scan.  Used by next_hops only."""
         if not hasattr(self, '_ap'):
             self._ap = None
             try:
@@ -84,14 +84,8 @@ class NavGraph:
     def shortest(self, src):
         """(dist, prev) from src to every reachable node."""
         if src not in self._sp:
-            ap = self._all_pairs()
-            if ap is not None and src in ap[1]:
-                nodes, ix, dist, pred = ap
-                i = ix[src]
-                reach = np.flatnonzero(np.isfinite(dist[i]))
-                d = {nodes[j]: float(dist[i, j]) for j in reach}
-                self._sp[src] = (d, {nodes[j]: nodes[pred[i, j]] for j in reach if j != i})
-                return self._sp[src]
+            # (always the Python search: callers iterate these dictionaries, and their ORDER -- the order of discovery --
+            # decides e.g. which items env.random_items draws; the all-pairs table serves next_hops only)
             dist, prev, heap = {src: 0.0}, {}, [(0.0, src)]
             while heap:
                 d, u = heapq.heappop(heap)

@@ -271,10 +271,19 @@ def test_speaker_agent_gold_routes_from_the_tables_equal_the_environment_walk():
     navigation tables (index_gold_routes, nav.NavTable.gold_routes) give the outputs and the loss of the lock-step walk
     of the host environment -- and train() runs on them."""
     import os
+    import random
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     import search_world as W
     from speaker_follower_amd import agents, features, model, optim
+    rng_state = random.getstate()       # (the env reshuffles with the global generator when an epoch wraps, env.py:601-614:
+    try:                                # tests that run later pin their minibatch order on its state)
+        _speaker_gold_routes_body(W, agents, features, model, optim)
+    finally:
+        random.setstate(rng_state)
+
+
+def _speaker_gold_routes_body(W, agents, features, model, optim):
     env, table = W.build_world(dense=False, n_items=24, batch=12, item_seed=5)
     d = synth.FULL
     w_enc, w_dec = synth.speaker_weights(W.SPEAKER_SEED)
