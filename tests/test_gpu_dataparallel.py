@@ -32,10 +32,12 @@ def fresh_modules(seed=101):
     return enc.cuda(), dec.cuda()
 
 
-@pytest.mark.parametrize('n_shards,feedback', [(2, 'argmax'), (3, 'argmax'), (3, 'sample'), (2, 'teacher')])
-def test_row_shards_reproduce_the_unsharded_batch(n_shards, feedback):
+@pytest.mark.parametrize('n_shards,feedback,B', [(2, 'argmax', 26), (3, 'argmax', 26), (3, 'sample', 26), (2, 'teacher', 26),
+                                                 # the shards of the 8-GPU runs: 3-4 rows, and BASELINE's 100 rows over 8 ranks
+                                                 (8, 'argmax', 26), (8, 'sample', 100)])
+def test_row_shards_reproduce_the_unsharded_batch(n_shards, feedback, B):
     from speaker_follower_amd import follower, features, dp
-    B, S, NVP = 26, 7, 64
+    S, NVP = 7, 64
     enc, dec = fresh_modules()
     enc.train()
     dec.train()                                            # dropout ON: masks must follow the global row
