@@ -676,9 +676,14 @@ __device__ __forceinline__ void nt_big_body(const NtBigArgs& a, const int tile, 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, kk = lane >> 4;
     const int wm = wave >> 2, wn = wave & 3;                          // 64-row half, 32-column quarter of the tile
-    // tile map: consecutive workgroups walk down the rows of one column block (W's 128 rows stay hot in the L2s)
-    const int mtiles = (a.M + NB_T - 1) / NB_T;
-    const int m0 = (tile % mtiles) * NB_T, n0 = (tile / mtiles) * NB_T;
+    // tile map (XCD-aware): workgroup b runs on XCD b % 8, each XCD with its own L2.  XCD x takes a CONTIGUOUS run of the
+    // tiles in column-fastest order, so the column blocks that share a 128-row slice of A are co-resident on one XCD and
+    // stream it through one L2 (before: rows-fastest over all XCDs, every slice of A fetched once per column block from
+    // beyond the L2s).  Measured with the bank swizzle below: +2 .. +6 % (profiles/r05_zz_many_row_kernel_lab.txt).
+    const int mtiles = (a.M + NB_T - 1) / NB_T, ntiles = (a.N + NB_T - 1) / NB_T;
+    const int tiles_all = mtiles * ntiles, xcd = tile & 7;
+    const int order = xcd * (tiles_all >> 3) + min(xcd, tiles_all & 7) + (tile >> 3);
+    const int m0 = (order / ntiles) * NB_T, n0 = (order % ntiles) * NB_T;
     // staging: thread -> (row = tid >> 3 (+64), float4 c4 = tid & 7 of the 32-deep stage)
     const int srow = tid >> 3, c4 = tid & 7;
     int arow[2], wrow[2];
@@ -705,7 +710,11 @@ __device__ __forceinline__ void nt_big_body(const NtBigArgs& a, const int tile, 
             rw[p] = ok ? y : z;
         }
     };
-    const int soff = srow * 64 + ((c4 & 3) << 4) + ((c4 >> 2) << 3);  // byte offset of this thread's 8 bytes inside a plane
+    // Bank swizzle: a ds_read_b128 is served in groups of 16 lanes over 64 banks, and rows r, r + 4, r + 8, r + 12 of a
+    // 64-byte-row plane start on the same bank: chunk kk of row r lives at position kk ^ ((-(r >> 2)) & 3), which gives the
+    // four rows of every lane group four different chunk positions (unswizzled: 2-way conflicts, 8 instead of 4 LDS cycles
+    // per fragment read).  srow, srow + 64 and the fragment rows 16 i + li all have (row >> 2) & 3 from their low bits.
+    const int soff = srow * 64 + ((((c4 & 3) ^ (-(srow >> 2))) & 3) << 4) + ((c4 >> 2) << 3);   // this thread's 8 bytes inside a plane
     auto stage_store = [&](int buf, const float4 (&ra)[2], const float4 (&rw)[2]) {
         unsigned char* base = nb_smem + buf * (6 * NB_PLANE);
 #pragma unroll
@@ -736,8 +745,9 @@ __device__ __forceinline__ void nt_big_body(const NtBigArgs& a, const int tile, 
     // s + 1 -- two stages (~1.2 us) of latency hiding; one stage is less than an HBM round trip under load.
     float4 ra[2][2], rw[2][2];
     auto compute = [&](int buf) {
-        const unsigned char* Ab = nb_smem + buf * (6 * NB_PLANE) + (wm * 64 + li) * 64 + kk * 16;
-        const unsigned char* Wb = nb_smem + buf * (6 * NB_PLANE) + 3 * NB_PLANE + (wn * 32 + li) * 64 + kk * 16;
+        const int kpos = ((kk ^ (-(li >> 2))) & 3) * 16;
+        const unsigned char* Ab = nb_smem + buf * (6 * NB_PLANE) + (wm * 64 + li) * 64 + kpos;
+        const unsigned char* Wb = nb_smem + buf * (6 * NB_PLANE) + 3 * NB_PLANE + (wn * 32 + li) * 64 + kpos;
         Split8 wf[2];
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -1809,7 +1819,8 @@ static int nt_big_launch(const NtBigArgs& b, hipStream_t st) {
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         attr_set = true;
     }
-    SF_LAUNCH(gemm_nt_big_kernel, dim3(ceil_div(b.M, NB_T) * ceil_div(b.N, NB_T), b.ksplit > 1 ? b.ksplit : 1), dim3(512),
+    const dim3 grid(ceil_div(b.M, NB_T) * ceil_div(b.N, NB_T), b.ksplit > 1 ? b.ksplit : 1);
+    SF_LAUNCH(gemm_nt_big_kernel, grid, dim3(512),
               (size_t)2 * 6 * NB_PLANE, st, b);
     return launch_status();
 }
