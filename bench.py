@@ -19,6 +19,7 @@ launcher -- it starts N children (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
 re-execs itself.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -243,12 +244,15 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
         torch.cuda.synchronize()
     for _ in range(warmup):
         it()
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for k in range(iters):
         st = it(k)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if coll:
         tt = torch.tensor([dt], device=store.device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -567,12 +571,15 @@ def main(argv=None):
 
     for _ in range(args.warmup):
         st = one_step()
+    gc.collect()
+    gc.disable()                # (as timeit does: no collector pause of the host inside the timed steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         st = one_step()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         tt = torch.tensor([elapsed], device=device, dtype=torch.float64)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -771,7 +778,6 @@ def main(argv=None):
         if not args.no_train_extra:
             # (ten timed iterations behind five warm-up ones: the extra in front of it ends with host-bound work,
             # during which the device clocks fall)
-            import gc
             gc.collect()
             gc.freeze()        # (the full world built above is ~10^6 live Python objects: keep the collector off them)
             out['train_iteration'] = measure_train(enc, dec, store, batch, S, max(10, args.steps // 2), 10)

@@ -839,7 +839,9 @@ int sf_gate_product_is_strict(void);
 void sf_debug_gate_product_f32(int on);
 /* A/B switch (round 5): on == 0 sends the many-row products (M >= 512: the speaker's teacher-forced head over all S*B rows,
  * the beam search's flat steps) back to the register-streaming kernel of rounds 1-4 instead of the LDS-tiled 128 x 128
- * bf16x6 kernel (csrc/sf_gemm.hip: gemm_nt_big_kernel; the default). */
+ * bf16x6 kernel (csrc/sf_gemm.hip: gemm_nt_big_kernel; the default).  Bit 1 of `on` (on == 3) keeps the kernel but turns off
+ * the K splits it takes where the consumer sums slabs anyway and the tile count wastes a round of the CUs (the beam
+ * step's gate product: 320 tiles -> 3 splits). */
 void sf_debug_many_row_product(int on);
 /* A/B switch (round 5): on == 0 forms the decoder's small weight gradients one product at a time (two transposes, the
  * many-row product, the slab sum: four dependent launches each) instead of three grouped launches for all of them

@@ -495,7 +495,7 @@ int sf_abi_version(void) { return SF_ABI_VERSION; }
 const char* sf_build_id(void) { static const char id[] = "SF_BUILD_ID=" SF_BUILD_ID; return id + 12; }
 void sf_debug_persist_timeout(long long ticks) { sf::g_persist_timeout = ticks; }
 void sf_debug_gate_product_f32(int on) { sf::g_nt_force_f32 = on; }
-void sf_debug_many_row_product(int on) { sf::g_nt_big = on; }
+void sf_debug_many_row_product(int on) { sf::g_nt_big = on & 1; sf::g_nt_big_ksplit = (on & 2) ? 0 : 1; }
 void sf_debug_grouped_weight_gradients(int on) { sf::g_tn_group = on; }
 void sf_debug_slab_consumers(int on) { g_slab_consumers = on; }
 void sf_debug_fused_cell_backward(int on) { g_fuse_cell_bwd = on; }

@@ -25,6 +25,7 @@
 namespace sf {
 
 int g_tn_split_min_rows = 4096;   // sf_debug_tn_split_min_rows (tests run the split weight-gradient kernel on small shapes)
+int g_nt_big_ksplit = 1;     // sf_debug_many_row_product(on | 2 * no K splits of the raw-slab many-row products)
 int g_nt_big = 1;            // sf_debug_many_row_product: M >= 512 products on gemm_nt_big_kernel (0: gemm_nt_kernel, rounds 1-4)
 int g_nt_force_f32 = 0;      // sf_debug_gate_product_f32: run the LSTM gate product on v_mfma_f32_16x16x4_f32 (round 1-3 kernel)
 
@@ -1855,11 +1856,27 @@ int linear_nt(const Seg* segs, int nseg, int M, int N, const LinearOut& out, flo
         for (int s = 0; s < nseg; ++s) b.seg[s] = segs[s];
         b.nseg = nseg; b.M = M; b.N = N; b.y = out.y; b.ldy = out.ldy; b.bias = out.bias; b.bias2 = out.bias2;
         b.addend = out.addend; b.ld_addend = out.ld_addend; b.epi = (int)out.epi; b.accumulate = out.accumulate;
+        int kb = 1;
         if (raw_slabs) {
             b.y = ws; b.ldy = N; b.bias = b.bias2 = b.addend = nullptr; b.epi = EPI_NONE; b.accumulate = 0;
             *raw_slabs = ws;
+            // The consumer adds the slabs up anyway, so K splits are free of a reduce launch: take them when the tile
+            // count wastes a round of the 256 CUs (the beam step's 2 560 x 2 048: 320 tiles = 2 rounds; 3 splits =
+            // 960 units = 4 rounds of a third each).  Cost of a split: one more slab written and read (M N floats).
+            if (ksplit_out && g_nt_big_ksplit) {
+                const int tiles = ceil_div(M, NB_T) * ceil_div(N, NB_T);
+                int stages = 0;
+                for (int s = 0; s < nseg; ++s) stages += ceil_div(segs[s].K, NB_K);
+                double best = (double)ceil_div(tiles, 256);
+                for (int c = 2; c <= 3; ++c) {
+                    if (ws_floats < (size_t)c * M * N || stages < 16 * c) break;
+                    const double t = (double)ceil_div(tiles * c, 256) / c + 0.04 * (c - 1);
+                    if (t < best - 1e-9) { best = t; kb = c; }
+                }
+            }
         }
-        if (ksplit_out) *ksplit_out = 1;
+        b.ksplit = kb;
+        if (ksplit_out) *ksplit_out = kb;
         return nt_big_launch(b, st);
     }
     if (out.addend || out.r1_s || out.epi == EPI_TANHBWD) return SF_ERR_UNSUPPORTED;   // small kernel only

@@ -56,7 +56,8 @@ int lstm_step_fused(const LstmStepArgs& p, hipStream_t st);      // sf_gemm.hip
 extern unsigned long long* g_trace;   // sf_debug_trace buffer (development aid), null = off
 extern int g_force_sc1;               // sf_debug_force_write_through
 extern int g_nt_force_f32;            // sf_debug_gate_product_f32
-extern int g_nt_big;                  // sf_debug_many_row_product
+extern int g_nt_big;                  // sf_debug_many_row_product (bit 0)
+extern int g_nt_big_ksplit;           // ... (bit 1 clear): K splits of its raw-slab products
 extern int g_tn_split_min_rows;       // sf_debug_tn_split_min_rows
 extern long long g_persist_timeout;   // sf_debug_persist_timeout (ticks of 10 ns; < 0 = default 0.25 s)
 size_t persistent_fault_word();       // dword index, behind the persistent launches' ticket word, of the fault word
