@@ -444,6 +444,40 @@ def test_linear_slabs_sum_to_the_product():
     torch.testing.assert_close(slabs.sum(0).double(), ref, rtol=1e-4, atol=1e-4)
 
 
+def test_many_row_gate_product_takes_k_splits_where_tiles_waste_a_round():
+    """csrc/sf_gemm.hip linear_nt: the beam step's gate product (2 560 states: 20 x 16 = 320 tiles of 128 x 128 on 256 CUs)
+    is issued as three K splits whose slabs the consumer adds up; the slabs' sum equals the unsplit product of the same
+    kernel to rounding of the summation order, and both stay in the fp32-roundoff class against float64."""
+    import ctypes as C
+    from speaker_follower_amd._lib import call, lib
+    from speaker_follower_amd.runtime import ptr, ws_args, workspace
+    g = torch.Generator().manual_seed(9)
+    M, N, K1, K2 = 2560, 2048, 4352, 512
+    x = torch.relu(torch.randn(M, K1, generator=g) * 0.5 + 0.4).cuda()
+    h = torch.tanh(torch.randn(M, K2, generator=g)).cuda()
+    w, u = (torch.randn(N, K1, generator=g) * 0.03).cuda(), (torch.randn(N, K2, generator=g) * 0.05).cuda()
+    ref = x.double() @ w.double().T + h.double() @ u.double().T
+    mag = x.double().abs() @ w.double().abs().T + h.double().abs() @ u.double().abs().T
+    got = {}
+    for mode in (1, 3):
+        lib.sf_debug_many_row_product(mode)
+        try:
+            ks = C.c_int(0)
+            call('sf_linear_slabs_fwd', ptr(x), K1, ptr(w), K1, ptr(h), K2, ptr(u), K2, M, N, C.byref(ks),
+                 *ws_args(x.device))
+            torch.cuda.synchronize()
+        finally:
+            lib.sf_debug_many_row_product(1)
+        slabs = workspace(x.device)[:ks.value * M * N * 4].view(torch.float32).view(ks.value, M, N)
+        got[mode] = (ks.value, slabs.sum(0).double())
+    assert got[1][0] == 3 and got[3][0] == 1, (got[1][0], got[3][0])
+    for mode in (1, 3):
+        rel = float(((got[mode][1] - ref).abs() / mag).max())
+        print('[many-row gate product, %d K splits] max error / sum|a b| = %.2e' % (got[mode][0], rel))
+        assert rel < 2.5e-7
+    assert float(((got[1][1] - got[3][1]).abs() / mag).max()) < 2.5e-7
+
+
 @pytest.mark.parametrize('M', [100, 1, 16, 37, 64, 113, 128])
 def test_gate_product_on_the_bf16_matrix_cores_keeps_fp32_accuracy(M):
     """csrc/sf_gemm.hip: gemm_nt_split_kernel (three-way error-free bf16 splitting, six bf16 MFMAs per product,
