@@ -12,6 +12,7 @@ store = features.FeatureStore(bench.device_table(10567, 1234, dev), device=dev)
 fb = synth.follower_batch(seed=0, batch=100, steps=20, n_viewpoints=10567)
 batch = follower.DeviceFollowerBatch.from_synth(fb, device=dev)
 eng = follower.FollowerEngine(enc, dec, store)
+eng.fold_inference = '--fold' in os.environ.get('ROLLOUT_FLAGS', '')          # ROLLOUT_FLAGS=--fold: the folded inference schedule
 replay, st = eng.capture(batch, 20, 'argmax')
 best = 1e9
 for rnd in range(4):
