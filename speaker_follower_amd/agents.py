@@ -427,6 +427,7 @@ class Seq2SeqAgent(BaseAgent):
                 if f is not o:
                     f.store_torch_state(o)
 
+    prepare_ahead = True         # train() on graphs: the next minibatch's host work under the current replay
     adopt_torch_adam = True      # train(): a plain torch.optim.Adam (train.py:263-268) is mirrored by an optim.FusedAdam
 
     def _fused_for(self, opt):
@@ -456,9 +457,14 @@ class Seq2SeqAgent(BaseAgent):
         key = (id(encoder_optimizer), id(decoder_optimizer), self.feedback, id(table), self.episode_len, hyper)
         cached = self.__dict__.get('_train_graph_state')
         take_fault(dev)                                       # (whatever an earlier pass left behind is not ours)
-        for _ in range(n_iters):
-            self.env.reset(sort=True)
-            items = list(self.env.batch)
+        ahead = None            # the NEXT minibatch and its host arrays, formed while the device ran this iteration
+        for it in range(n_iters):
+            if ahead is None:
+                self.env.reset(sort=True)
+                items, host = list(self.env.batch), None
+            else:
+                items, host = ahead
+                ahead = None
             before = [o.host_steps() for o in opts]
             if cached is not None and (cached[0] != key or cached[2].batch_size != len(items)):
                 cached = None
@@ -472,8 +478,14 @@ class Seq2SeqAgent(BaseAgent):
                 st = tg.first                                 # (the capture ran this iteration eagerly)
             else:
                 _, tg, batch = cached
-                batch.load(items)
+                batch.load(items, host)
                 st = tg.replay()
+            if self.prepare_ahead and it + 1 < n_iters:
+                # the replay is in flight: draw the next minibatch (the same env.reset calls in the same order, earlier)
+                # and encode it now; its copies wait until this iteration's loss has been read
+                self.env.reset(sort=True)
+                nxt = list(self.env.batch)
+                ahead = (nxt, batch._host_arrays(nxt) if len(nxt) == batch.batch_size else None)
             loss = float(st.loss_buf)                         # the iteration's one host sync
             if take_fault(dev):
                 # a persistent launch starved: the guarded optimizer steps did nothing.  The same minibatch again on

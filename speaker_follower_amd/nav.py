@@ -212,6 +212,31 @@ class DeviceNavBatch:
         self.goal_hop, self.hop_base = to(h['hop']), to(h['base'])
         self.ld_hop = h['hop'].shape[1]
         self._nav_struct = nav.struct()
+        if fixed_shapes and dev.type == 'cuda':
+            self._pack_for_load()
+
+    _LOADED = (('seq', 'seq'), ('mask', 'mask'), ('lengths_dev', 'lengths'), ('row0_state', 'rows'), ('view0_state', 'views'),
+               ('goal_hop', 'hop'), ('hop_base', 'base'))
+
+    def _pack_for_load(self):
+        """The seven tensors `load` rewrites become views of ONE device buffer with a pinned host mirror: a minibatch is
+        one asynchronous H2D copy instead of seven pageable ones (0.2 ms of the training loop's host time)."""
+        offs, total = {}, 0
+        for attr, _ in self._LOADED:
+            t = getattr(self, attr)
+            offs[attr] = total
+            total += (t.numel() * t.element_size() + 63) & ~63
+        dev_buf = torch.empty(total, dtype=torch.uint8, device=self.seq.device)
+        self._pack_host = torch.empty(total, dtype=torch.uint8).pin_memory()
+        self._pack_np = {}
+        for attr, key in self._LOADED:
+            t = getattr(self, attr)
+            n = t.numel() * t.element_size()
+            view = dev_buf[offs[attr]:offs[attr] + n].view(t.dtype).view(t.shape)
+            view.copy_(t)
+            setattr(self, attr, view)
+            self._pack_np[key] = self._pack_host[offs[attr]:offs[attr] + n].view(t.dtype).view(t.shape).numpy()
+        self._pack_dev = dev_buf
 
     def _host_arrays(self, items):
         """What a minibatch contributes: the encoded instructions (follower.py:75-105) and, per item, the start state
@@ -234,18 +259,24 @@ class DeviceNavBatch:
         return dict(seq=np.ascontiguousarray(seq), mask=np.ascontiguousarray(mask.astype(np.uint8)),
                     lengths=np.asarray(lengths, np.int32), rows=rows, views=views, hop=hop, base=base)
 
-    def load(self, items):
+    def load(self, items, host=None):
         """The next minibatch INTO the same device tensors (fixed_shapes only): seven small H2D copies on the current
-        stream; the observation slots are rewritten by the rollout itself."""
+        stream; the observation slots are rewritten by the rollout itself.  `host`: what `_host_arrays(items)` returned
+        earlier (the agents' training loop forms it while the device still runs the previous iteration)."""
         if not self.fixed:
             raise ValueError('DeviceNavBatch.load needs fixed_shapes=True')
         if len(items) != self.batch_size:
             raise ValueError('DeviceNavBatch.load: %d items for a batch of %d' % (len(items), self.batch_size))
-        h = self._host_arrays(items)
+        h = host if host is not None else self._host_arrays(items)
         self.items, self.lengths = items, h['lengths'].tolist()
-        for dst, key in ((self.seq, 'seq'), (self.mask, 'mask'), (self.lengths_dev, 'lengths'), (self.row0_state, 'rows'),
-                         (self.view0_state, 'views'), (self.goal_hop, 'hop'), (self.hop_base, 'base')):
-            dst.copy_(torch.from_numpy(h[key]))
+        if getattr(self, '_pack_dev', None) is not None:
+            # (the previous minibatch's copy has completed: its iteration's loss was read since)
+            for key, dst in self._pack_np.items():
+                np.copyto(dst, h[key], casting='same_kind')
+            self._pack_dev.copy_(self._pack_host, non_blocking=True)
+            return
+        for attr, key in self._LOADED:
+            getattr(self, attr).copy_(torch.from_numpy(h[key]))
 
     @property
     def batch_size(self):
