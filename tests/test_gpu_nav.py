@@ -313,6 +313,23 @@ def test_agent_train_runs_whole_iterations_as_graph_replays(world):
     assert d < 3e-4 and torch.isfinite(out[True][1]).all()     # (Adam: a near-zero gradient whose sign differs moves a weight by lr per step)
 
 
+def test_preparing_the_next_minibatch_under_the_replay_changes_nothing(world):
+    """agents.Seq2SeqAgent.prepare_ahead: minibatch i + 1 is drawn from the environment and encoded while replay i runs and
+    reaches the device as one pinned copy (nav.DeviceNavBatch._pack_for_load) -- the same minibatches in the same order:
+    losses and weights are bit-identical to the loop that prepares every minibatch after the previous loss was read."""
+    out = {}
+    for ahead in (False, True):
+        ag, oe, od, weights = _fresh_agent(world, True, lr=1e-4)
+        ag.prepare_ahead = ahead
+        ag.train(oe, od, 4, feedback='teacher')
+        first = list(ag.losses)
+        ag.train(oe, od, 3, feedback='teacher')
+        out[ahead] = (first + list(ag.losses), weights(), [it['instr_id'] for it in ag.env.batch])
+    assert out[True][0] == out[False][0], (out[True][0], out[False][0])
+    assert torch.equal(out[True][1], out[False][1])
+    assert out[True][2] == out[False][2]                       # (the environment ends on the same minibatch)
+
+
 def test_agent_train_on_graphs_survives_a_starved_persistent_launch(world):
     """A fault word raised inside a replayed iteration: the guarded optimizer steps do nothing on the device
     (sf_adam_step_dev), the agent sees the word where it reads the loss, restores its step counters and trains that
