@@ -167,18 +167,37 @@ class Seq2SeqAgent(BaseAgent):
         from .nav import DeviceNavBatch
         if not reissue:
             self.env.reset(sort=True)
-        batch = DeviceNavBatch(table if table is not None else self.nav_table, list(self.env.batch), self.episode_len,
-                               max_length=self.max_instruction_length, reverse=self.reverse_instruction)
+        nav = table if table is not None else self.nav_table
+        items = list(self.env.batch)
+        # what the previous rollout prepared while its kernels ran (the same items, or it is not used)
+        ahead, batch = self.__dict__.pop('_rollout_ahead', None), None
+        if (ahead is not None and ahead[0] is nav and len(ahead[1]) == len(items) and ahead[2].steps == self.episode_len
+                and all(a is b for a, b in zip(ahead[1], items))):
+            batch = ahead[2]
+        if batch is None:
+            batch = DeviceNavBatch(nav, items, self.episode_len, max_length=self.max_instruction_length,
+                                   reverse=self.reverse_instruction)
+
+        def prepare_next():
+            # the minibatch the next env.reset will draw (peeked, not drawn: nothing changes if nobody comes for it):
+            # encoded and packed on the host while this rollout's kernels run; its device tensors are filled behind them
+            peek = getattr(self.env, 'peek_next_minibatch', None)
+            nxt = peek(True) if peek is not None and self.prepare_ahead else None
+            if nxt is not None:
+                self._rollout_ahead = (nav, nxt, DeviceNavBatch(nav, nxt, self.episode_len,
+                                                                max_length=self.max_instruction_length,
+                                                                reverse=self.reverse_instruction))
         keep = getattr(self.encoder, 'persistent', True)
         if reissue:
             self.encoder.persistent = False
         try:
-            st = self._engine.run(batch, self.episode_len, self.feedback, train=self.decoder.training)
+            st = self._engine.run(batch, self.episode_len, self.feedback, train=self.decoder.training,
+                                  while_running=None if reissue else prepare_next)
         finally:
             self.encoder.persistent = keep
         self.loss = st.loss
         traj = batch.trajectories(st)                   # the one host sync of the rollout
-        for tr, it in zip(traj, self.env.batch):
+        for tr, it in zip(traj, items):
             tr['instr_encoding'] = it['instr_encoding']
         self.losses.append(float(st.loss.detach()))
         return traj

@@ -249,6 +249,14 @@ class R2RIndexEnv:
             batch = sorted(batch, key=lambda it: len(it['instr_encoding']), reverse=True)
         self.batch = batch
 
+    def peek_next_minibatch(self, sort):
+        """The minibatch the next `reset` will draw, WITHOUT drawing it -- or None where that draw wraps the epoch (it
+        reshuffles the data with `random`, env.py:601-614: not something to do ahead of time)."""
+        batch = self.data[self.ix:self.ix + self.batch_size]
+        if len(batch) < self.batch_size:
+            return None
+        return sorted(batch, key=lambda it: len(it['instr_encoding']), reverse=True) if sort else batch
+
     def reset_epoch(self):
         self.ix = 0
 

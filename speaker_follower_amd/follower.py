@@ -22,7 +22,7 @@ from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, trainable_embedding)
-from .runtime import ptr, stream, ws_args, wgrad_ws_args, ensure_workspace, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream
+from .runtime import ptr, stream, ws_args, wgrad_ws_args, ensure_workspace, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream, graph_capture
 from .dp import collectives_on
 
 byref = C.byref
@@ -365,14 +365,15 @@ class FollowerEngine:
             torch.distributed.all_reduce(st.sum_cnt, group=self.group)
         return self.finish(st)
 
-    def run(self, batch, steps, feedback='argmax', train=None, backward=False):
+    def run(self, batch, steps, feedback='argmax', train=None, backward=False, while_running=None):
         """`rollout` (and, with backward=True, `loss.backward()`) + the fault check of the persistent encoder
         launches (include/sf_hip.h: sf_workspace_fault_offset): ONE host sync; a launch that gave up a bounded wait
         (co-residency lost to another process) has poisoned its outputs with NaN, so the SAME rollout -- same
         dropout / sampling sites -- is re-issued in this process with the per-step encoder kernels
         (SF_ENC_PER_STEP), after zeroing the gradients the poisoned backward accumulated.  Under a process group
         the decision is taken on the MAX of all ranks' fault words, so every rank re-issues together; gradient
-        buckets the poisoned backward had launched are waited for and re-armed (`BucketedGrads.abort`) first.  Raises PersistentLaunchFault if a fault is still raised afterwards."""
+        buckets the poisoned backward had launched are waited for and re-armed (`BucketedGrads.abort`) first.  Raises PersistentLaunchFault if a fault is still raised afterwards.
+        `while_running()`: host work the caller wants done between the issue and the sync (the next minibatch)."""
         dev = self.store.device
         site, it = self.site_next, self.iteration
 
@@ -380,6 +381,10 @@ class FollowerEngine:
             st = self.rollout(batch, steps, feedback, train)
             if backward:
                 st.loss.backward()
+            nonlocal while_running
+            if while_running is not None:
+                while_running, cb = None, while_running
+                cb()
             bits = take_fault(dev)
             if self.group is not None and collectives_on(self.group):
                 # (MAX, not BOR: RCCL has no bitwise reductions; the caller only needs "some rank faulted")
@@ -479,7 +484,7 @@ class FollowerEngine:
             self.site_word = ctl[0:1] if sampled else None
             try:
                 with torch.cuda.stream(side):
-                    with torch.cuda.graph(graph, stream=side):
+                    with graph_capture(graph, side):
                         st = self.rollout(batch, steps, feedback, train=False)
             finally:
                 self.site_word = None
@@ -548,7 +553,7 @@ class FollowerEngine:
                     self.rollout(sh, steps, feedback, train=False)          # warm-up on this stream
                     torch.cuda.synchronize()
                     g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g, stream=s):
+                    with graph_capture(g, s):
                         states.append(self.rollout(sh, steps, feedback, train=False, finalize=False))
                 graphs.append(g)
             torch.cuda.synchronize()

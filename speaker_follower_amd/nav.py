@@ -27,6 +27,7 @@ from . import _lib
 from . import sim as _sim
 from ._lib import call
 from .env import ANGLE_INC, IMAGE_H, IMAGE_W, VFOV, WorldState
+from .lazydict import LazyDict
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded
 from .runtime import ptr, stream
@@ -189,7 +190,7 @@ class DeviceNavBatch:
     `vp/view/a_num/cand_view/sincos/target` are [S+1, B, ...] buffers that `advance` fills one step
     ahead of the decoder (slot 0 = the initial observation)."""
 
-    def __init__(self, nav, items, steps, max_length=80, reverse=True, row0=0, fixed_shapes=False):
+    def __init__(self, nav, items, steps, max_length=80, reverse=True, row0=0, fixed_shapes=False, host=None):
         """fixed_shapes: every tensor gets the shape of the LARGEST minibatch of this size (instructions padded to
         max_length, goal-hop rows as long as the largest scan) so that `load(items)` can refresh the batch in place --
         what a captured training graph reads (runtime.TrainingGraph) must keep its addresses."""
@@ -197,7 +198,7 @@ class DeviceNavBatch:
         self.nav, self.items, self.steps = nav, items, steps
         self.max_length, self.reverse, self.fixed = max_length, reverse, fixed_shapes
         B, A, S = len(items), nav.A, steps
-        h = self._host_arrays(items)
+        h = host if host is not None else self._host_arrays(items)       # (host: host_arrays_for(...) of these items)
         self.lengths = h['lengths'].tolist()
         to = lambda x: torch.from_numpy(x).to(dev)                                        # noqa: E731
         self.seq, self.mask, self.lengths_dev = to(h['seq']), to(h['mask']), to(h['lengths'])
@@ -239,15 +240,20 @@ class DeviceNavBatch:
         self._pack_dev = dev_buf
 
     def _host_arrays(self, items):
+        return self.host_arrays_for(self.nav, items, self.max_length, self.reverse, self.fixed)
+
+    @staticmethod
+    def host_arrays_for(nav, items, max_length=80, reverse=True, fixed=False):
         """What a minibatch contributes: the encoded instructions (follower.py:75-105) and, per item, the start state
-        (newEpisode snaps the item's heading to the discrete view, env.py:814-819) and the hop table towards its goal."""
-        nav, env = self.nav, self.nav.env
-        seq, mask, lengths = batch_instructions_from_encoded([it['instr_encoding'] for it in items], self.max_length,
-                                                             reverse=self.reverse, device='cpu')
+        (newEpisode snaps the item's heading to the discrete view, env.py:814-819) and the hop table towards its goal.
+        Host work only: callers form it for the NEXT minibatch while the device runs the current one."""
+        env = nav.env
+        seq, mask, lengths = batch_instructions_from_encoded([it['instr_encoding'] for it in items], max_length,
+                                                             reverse=reverse, device='cpu')
         seq = seq.numpy()
-        mask = (seq == 0) if self.fixed else mask.numpy()                                 # (PAD = 0; full width when fixed)
+        mask = (seq == 0) if fixed else mask.numpy()                                      # (PAD = 0; full width when fixed)
         B = len(items)
-        ld = max(nav.scan_rows.values()) if self.fixed else max(nav.scan_rows[it['scan']] for it in items)
+        ld = max(nav.scan_rows.values()) if fixed else max(nav.scan_rows[it['scan']] for it in items)
         rows, views = np.zeros(B, np.int32), np.zeros(B, np.int32)
         hop, base = np.zeros((B, ld), np.int32), np.zeros(B, np.int32)
         for b, it in enumerate(items):
@@ -306,35 +312,44 @@ class DeviceNavBatch:
     def trajectories(self, st):
         """The rollout's result dictionaries (follower.py:446-456, 517-524): per sample instr_id,
         trajectory [(viewpointId, heading, elevation)], actions, scores -- the stop action and the
-        duplicated final state included, nothing after it.  One D2H copy."""
+        duplicated final state included, nothing after it.  The device arrays come down once; the per-sample lists are
+        cut from them with numpy, and 'trajectory' (a tuple per visited pose) is built when somebody reads it."""
         S = st.steps
         rows = self.row[:S + 1].cpu().numpy()
         views = self.view[:S + 1].cpu().numpy()
         acts = st.actions.cpu().numpy()
         sc = st.step_scores.cpu().numpy()
+        B = len(self.items)
+        stopped = acts[:S] == 0
+        n = np.where(stopped.any(0), stopped.argmax(0) + 1, S)                  # steps up to and including the stop action
+        totals = np.cumsum(sc[:S], axis=0, dtype=np.float32)                    # (sequential float32 sums, as the loop's)
+        # still in the start pose at slot t (its heading is the item's, not a discrete view's)
+        moved = np.cumsum((rows != rows[0]) | (views != views[0]), axis=0) > 0
+        acts_t, sc_t = np.ascontiguousarray(acts[:S].T), np.ascontiguousarray(sc[:S].T)
+        last = totals[n - 1, np.arange(B)].tolist()
+        return [_Trajectory(self.nav, it, int(n[b]), acts_t[b], sc_t[b], last[b], rows[:, b], views[:, b], moved[:, b])
+                for b, it in enumerate(self.items)]
+
+
+class _Trajectory(LazyDict):
+    """One result of a device rollout: 'instr_id', 'actions', 'scores', 'score' are there, 'trajectory' is made on demand."""
+    __slots__ = ('_nav', '_it', '_n', '_rows', '_views', '_moved')
+
+    def __init__(self, nav, it, n, acts, sc, score, rows, views, moved):
+        LazyDict.__init__(self, {'instr_id': it['instr_id'], 'actions': acts[:n].tolist(), 'scores': sc[:n].tolist(),
+                                 'score': score}, ('trajectory',))
+        self._nav, self._it, self._n, self._rows, self._views, self._moved = nav, it, n, rows, views, moved
+
+    def _make(self, key):
+        vp_of, heading = self._nav.vp_of, self._it['heading']
         out = []
-        for b, it in enumerate(self.items):
-            def elem(t, first=False):
-                vp = self.nav.vp_of[rows[t, b]][1]
-                if first:
-                    return (vp, it['heading'], 0)
-                v = int(views[t, b])
-                moved = any(int(rows[k, b]) != int(rows[0, b]) or int(views[k, b]) != int(views[0, b])
-                            for k in range(1, t + 1))
-                if not moved:                      # still in the start pose: its heading is the item's
-                    return (vp, it['heading'], 0)
-                return (vp, (v % 12) * ANGLE_INC, (v // 12 - 1) * ANGLE_INC)
-            tr = dict(instr_id=it['instr_id'], trajectory=[elem(0, True)], actions=[], scores=[], score=0.0)
-            total = np.float32(0)
-            for t in range(S):
-                tr['trajectory'].append(elem(t + 1))
-                tr['actions'].append(int(acts[t, b]))
-                tr['scores'].append(float(sc[t, b]))
-                total = np.float32(total + sc[t, b])
-                tr['score'] = float(total)
-                if acts[t, b] == 0:
-                    break
-            out.append(tr)
+        for t in range(self._n + 1):
+            vp = vp_of[self._rows[t]][1]
+            if not self._moved[t]:
+                out.append((vp, heading, 0))
+            else:
+                v = int(self._views[t])
+                out.append((vp, (v % 12) * ANGLE_INC, (v // 12 - 1) * ANGLE_INC))
         return out
 
 

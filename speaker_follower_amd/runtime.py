@@ -36,6 +36,27 @@ def gc_paused(fn):
     return run
 
 
+import contextlib
+
+
+@contextlib.contextmanager
+def graph_capture(graph, stream_):
+    """`torch.cuda.graph(graph, stream=...)` with the cyclic collector OFF for the duration (torch collects once before
+    it starts).  A collection that happens to run inside a capture -- on this thread or on autograd's worker -- may
+    finalise an older hipGraph, stream or event left in a reference cycle; destroying those is not permitted while a
+    stream captures, the error is raised inside a destructor and the process aborts (seen once the agents' loops
+    shifted where the collector's thresholds fall: tests/test_gpu_agents.py under round 5's prefetching)."""
+    import gc
+    was = gc.isenabled()
+    try:
+        with torch.cuda.graph(graph, stream=stream_):
+            gc.disable()                                 # (torch's own gc.collect() has just run)
+            yield
+    finally:
+        if was:
+            gc.enable()
+
+
 _concurrent = {}
 
 
@@ -286,7 +307,7 @@ class TrainingGraph:
                 invalidate_caches()                     # every derived weight copy is refreshed INSIDE the graph
                 keep = (engine.site_next, engine.iteration, [o.host_steps() for o in self.optimizers])
                 self.graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(self.graph, stream=self.stream):
+                with graph_capture(self.graph, self.stream):
                     self.state = body()
                 # the capture advanced the host mirrors without running anything
                 engine.site_next, engine.iteration = keep[0], keep[1]

@@ -35,7 +35,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, EOS, BOS
 from .model import decoder_params, decoder_w_struct, decoder_tape, tape_struct
-from .runtime import ptr, stream, ws_args, gc_paused
+from .runtime import ptr, stream, ws_args, gc_paused, graph_capture
 
 byref = C.byref
 
@@ -351,7 +351,7 @@ class GraphStep:
             self._issue()                                            # warm-up: workspace, cached layouts
             side.synchronize()
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, stream=side):
+            with graph_capture(graph, side):
                 self._issue()
         torch.cuda.current_stream().wait_stream(side)
         self.graph, self._stream = graph, side                       # (the graph bakes the capture stream's workspace)

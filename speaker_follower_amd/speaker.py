@@ -19,7 +19,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .model import _grads, trainable_embedding
-from .runtime import ptr, stream, ws_args, ensure_workspace, dropout_arg, fill_regions, visual_query_fold, struct_of, transposed, take_fault, PersistentLaunchFault
+from .runtime import ptr, stream, ws_args, ensure_workspace, dropout_arg, fill_regions, visual_query_fold, struct_of, transposed, take_fault, PersistentLaunchFault, graph_capture
 
 byref = C.byref
 
@@ -136,7 +136,7 @@ class SpeakerEngine:
             self.site_word = ctl[0:1] if sampled else None
             try:
                 with torch.cuda.stream(side):
-                    with torch.cuda.graph(graph, stream=side):
+                    with graph_capture(graph, side):
                         st = self.score(batch, steps, feedback, train=False)
             finally:
                 self.site_word = None

@@ -531,3 +531,28 @@ def test_a_capture_never_creates_its_workspace_inside_the_graph():
         with torch.cuda.graph(g2, stream=other):
             ws = runtime.workspace(dev)                     # exists: nothing is allocated or filled in the graph
     assert ws.numel() == runtime.lib.sf_workspace_bytes()
+
+
+def test_the_collector_is_off_while_a_stream_captures():
+    """runtime.graph_capture: a cyclic collection inside a capture may finalise an older graph / stream / event, which HIP
+    refuses while a stream captures -- raised in a destructor, that aborts the process (seen under pytest once the
+    agents' loops moved the collector's thresholds).  Every capture of the package goes through this context."""
+    import gc
+    from speaker_follower_amd import runtime
+    g, s = torch.cuda.CUDAGraph(), torch.cuda.Stream()
+    x = torch.zeros(8, device='cuda')
+    torch.cuda.synchronize()
+    assert gc.isenabled()
+    with runtime.graph_capture(g, s):
+        assert not gc.isenabled()
+        x += 1
+    assert gc.isenabled()
+    g.replay()
+    g.replay()
+    torch.cuda.synchronize()
+    assert x.tolist() == [2.0] * 8
+    import inspect
+    from speaker_follower_amd import follower, search, speaker
+    for mod in (follower, search, speaker, runtime):
+        src = inspect.getsource(mod)
+        assert 'with torch.cuda.graph(' not in src.replace('with torch.cuda.graph(graph, stream=stream_)', ''), mod.__name__
