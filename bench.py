@@ -242,10 +242,10 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
         if coll:
             torch.distributed.barrier()
         torch.cuda.synchronize()
-    for _ in range(warmup):
-        it()
     gc.collect()
     gc.disable()
+    for _ in range(warmup):
+        it()
     barrier()
     t0 = time.perf_counter()
     for k in range(iters):
@@ -569,10 +569,10 @@ def main(argv=None):
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    gc.collect()                # (BEFORE the warm-up: a collection is host time during which the device clocks fall)
+    gc.disable()                # (as timeit does: no collector pause of the host inside the timed steps)
     for _ in range(args.warmup):
         st = one_step()
-    gc.collect()
-    gc.disable()                # (as timeit does: no collector pause of the host inside the timed steps)
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):

@@ -30,13 +30,13 @@ def _guard(fn):
 
 def _timed(fn, warm, reps):
     import gc
-    for _ in range(warm):
-        fn()
-    torch.cuda.synchronize()
     was = gc.isenabled()
-    gc.collect()
+    gc.collect()                # (before the warm-up: the device clocks fall during host-only time)
     gc.disable()                # a full collection inside ten 2 ms replays once turned 1.9 ms into 8.9 (round 5)
     try:
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(reps):
             fn()
