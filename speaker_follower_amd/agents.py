@@ -1027,6 +1027,70 @@ class Seq2SeqSpeaker(object):
                 break
         return self.results
 
+    train_without_outputs = True     # train(): forward and backward issued back to back, ONE host sync per iteration
+
+    def _routes_of(self, items, store):
+        """Host side of a training minibatch: its gold routes from the navigation tables, in the index form the device
+        consumes (synth.SpeakerBatch), and the number of word steps."""
+        from .nav import table_for
+        n, rows = table_for(self.env, store).gold_routes(items, self.max_episode_len)
+        first = np.concatenate(([0], np.cumsum(n)))
+        enc = [it['instr_encoding'] for it in items]
+        return (self._index_batch(n, lambda lo, hi: rows[first[lo]:first[hi]], enc, 0, len(items)),
+                self._score_steps(enc, self.feedback))
+
+    def _train_iteration_on_index_routes(self):
+        """speaker.py:376-395's rollout + backward for train(), which reads nothing but the loss: the scoring pass and its
+        backward are issued back to back (no download of words and scores, no result dictionaries, no sync between
+        them), the NEXT minibatch's routes are formed while the device works (peeked, not drawn), and the fault word of
+        the persistent launches is read once, where the loss is read; a fault re-issues the SAME minibatch on the
+        per-step kernels.  Same kernels, same dropout sites as `rollout()` + `loss.backward()`.  False: not applicable
+        (dense environment, row-sharded engine): the caller takes that path."""
+        store = self._env_store()
+        if not (self.train_without_outputs and self.index_gold_routes and store is not None
+                and getattr(self.env, 'host_table', 1) is None and hasattr(self.env, 'graphs')):
+            return False
+        from . import speaker as spk
+        from .runtime import take_fault
+        if getattr(self, '_engine', None) is None or self._engine.store is not store:
+            self._engine = spk.SpeakerEngine(self.encoder, self.decoder, store)
+        eng, dev = self._engine, store.device
+        if eng.group is not None:
+            return False
+        self.env.reset()
+        items = list(self.env.batch)
+        ahead, prep = self.__dict__.pop('_routes_ahead', None), None
+        if (ahead is not None and ahead[0] == self.feedback and len(ahead[1]) == len(items)
+                and all(a is b for a, b in zip(ahead[1], items))):
+            prep = ahead[2]
+        sb, S = prep if prep is not None else self._routes_of(items, store)
+        batch = spk.DeviceSpeakerBatch.from_synth(sb, device=dev, max_length=self.instruction_len)
+        take_fault(dev)                                       # (whatever an earlier pass left behind is not ours)
+        site = eng.site_next
+        st = eng.score(batch, S, self.feedback, train=True)
+        st.loss.backward()
+        peek = getattr(self.env, 'peek_next_minibatch', None)
+        nxt = peek(False) if peek is not None else None
+        if nxt is not None:
+            self._routes_ahead = (self.feedback, nxt, self._routes_of(nxt, store))
+        if take_fault(dev):                                   # the iteration's host sync
+            for m in (self.encoder, self.decoder):
+                for p_ in m.parameters():
+                    if p_.grad is not None:
+                        p_.grad.zero_()
+            keep, eng.persistent, eng.site_next = eng.persistent, False, site
+            eng.fallbacks += 1
+            try:
+                st = eng.score(batch, S, self.feedback, train=True)
+                st.loss.backward()
+            finally:
+                eng.persistent = keep
+            if take_fault(dev):
+                raise PersistentLaunchFault('the per-step re-issue of a training iteration raised a fault again')
+        self.loss = st.loss
+        self.losses.append(float(st.loss.detach()))
+        return True
+
     def train(self, encoder_optimizer, decoder_optimizer, n_iters, feedback='teacher'):
         assert feedback in self.feedback_options
         self.feedback = feedback
@@ -1036,6 +1100,10 @@ class Seq2SeqSpeaker(object):
         for _ in range(1, n_iters + 1):
             encoder_optimizer.zero_grad()
             decoder_optimizer.zero_grad()
+            if self._train_iteration_on_index_routes():
+                encoder_optimizer.step()
+                decoder_optimizer.step()
+                continue
             self.rollout()
             self.loss.backward()
             # teacher-forced passes run their recurrence (forward and backward) as persistent launches since round 5: a

@@ -316,3 +316,46 @@ def _speaker_gold_routes_body(W, agents, features, model, optim):
     env.reset_epoch()
     spk.train(oe, od, 3, feedback='teacher')
     assert len(spk.losses) == 3 and np.isfinite(spk.losses).all()
+
+
+def test_speaker_train_without_outputs_is_the_same_training():
+    """Seq2SeqSpeaker.train: the iteration that issues forward and backward back to back, forms the next minibatch's
+    routes under them and syncs once (train_without_outputs) against rollout() + loss.backward() (speaker.py:376-395):
+    the same minibatches, kernels and dropout sites -- losses and weights bit-identical."""
+    import os
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import search_world as W
+    from speaker_follower_amd import agents, features, model, optim
+    rng_state = random.getstate()
+    try:
+        env, table = W.build_world(dense=False, n_items=60, batch=12, item_seed=7)
+        store = features.FeatureStore(table)
+        d = synth.FULL
+        w_enc, w_dec = synth.speaker_weights(W.SPEAKER_SEED)
+        out = {}
+        for fast in (False, True):
+            senc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+            sdec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=w_dec['embedding.weight'])
+            senc.load_state_dict({k: torch.tensor(v) for k, v in w_enc.items()})
+            sdec.load_state_dict({k: torch.tensor(v) for k, v in w_dec.items()})
+            senc.cuda()
+            sdec.cuda()
+            torch.manual_seed(3)
+            spk = agents.Seq2SeqSpeaker(env, '/tmp/sf_spk_fast.json', senc, sdec, W.INSTRUCTION_LEN,
+                                        max_episode_len=W.EPISODE_LEN)
+            spk.store = store
+            spk.train_without_outputs = fast
+            oe = optim.FusedAdam([p for p in senc.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4)
+            od = optim.FusedAdam([p for p in sdec.parameters() if p.requires_grad], lr=1e-4, weight_decay=5e-4)
+            env.reset_epoch()
+            spk.train(oe, od, 4, feedback='teacher')             # (5 minibatches per epoch: no wrap, no reshuffle)
+            w = torch.cat([p.detach().reshape(-1) for m in (senc, sdec) for p in m.parameters()]).clone()
+            out[fast] = (list(spk.losses), w, [it['instr_id'] for it in env.batch], spk._engine.fallbacks)
+        print('[speaker.train] losses', out[True][0])
+        assert out[True][0] == out[False][0] and len(set(out[True][0])) == 4
+        assert torch.equal(out[True][1], out[False][1])
+        assert out[True][2] == out[False][2] and out[True][3] == out[False][3] == 0
+    finally:
+        random.setstate(rng_state)
