@@ -171,8 +171,13 @@ class Seq2SeqAgent(BaseAgent):
         items = list(self.env.batch)
         # what the previous rollout prepared while its kernels ran (the same items, or it is not used)
         ahead, batch = self.__dict__.pop('_rollout_ahead', None), None
-        if (ahead is not None and ahead[0] is nav and len(ahead[1]) == len(items) and ahead[2].steps == self.episode_len
+        if not (ahead is not None and ahead[0] is nav and len(ahead[1]) == len(items)
                 and all(a is b for a, b in zip(ahead[1], items))):
+            ahead = None
+        if (self.test_graph and not reissue and not self.decoder.training and self.feedback == 'argmax'
+                and self._engine.group is None):
+            return self._rollout_on_graph(nav, items, ahead[2] if ahead is not None and isinstance(ahead[2], dict) else None)
+        if ahead is not None and isinstance(ahead[2], DeviceNavBatch) and ahead[2].steps == self.episode_len:
             batch = ahead[2]
         if batch is None:
             batch = DeviceNavBatch(nav, items, self.episode_len, max_length=self.max_instruction_length,
@@ -197,6 +202,63 @@ class Seq2SeqAgent(BaseAgent):
             self.encoder.persistent = keep
         self.loss = st.loss
         traj = batch.trajectories(st)                   # the one host sync of the rollout
+        for tr, it in zip(traj, items):
+            tr['instr_encoding'] = it['instr_encoding']
+        self.losses.append(float(st.loss.detach()))
+        return traj
+
+    test_graph = True            # argmax inference rollouts on the device environment: one hipGraph replay per minibatch
+
+    def _rollout_on_graph(self, nav, items, host=None):
+        """An inference rollout (agent.test, follower.py:987-999) as ONE graph replay over a fixed-shape minibatch: the
+        items are written into the captured batch's tensors (one pinned copy), the next minibatch is peeked and encoded
+        while the replay runs, the fault word is read where the results are.  A starved persistent launch re-issues the
+        minibatch on the per-step kernels; weights that MOVED since the capture (load_state_dict into new tensors) mean
+        a new capture.  Instructions are padded to max_instruction_length (the eager rollout pads to the minibatch's
+        longest: equal up to the summation order of the padded attention columns)."""
+        from .nav import DeviceNavBatch
+        from .runtime import take_fault
+        eng, dev = self._engine, self._device()
+        key = (id(nav), id(eng), self.episode_len, len(items), self.max_instruction_length, self.reverse_instruction)
+        graphs = self.__dict__.setdefault('_test_graphs', {})  # (train.py alternates between its validation environments)
+        for attempt in (0, 1):
+            cached = graphs.get(key)
+            if cached is None:
+                batch = DeviceNavBatch(nav, items, self.episode_len, max_length=self.max_instruction_length,
+                                       reverse=self.reverse_instruction, fixed_shapes=True, host=host)
+                replay, st = eng.capture(batch, self.episode_len, 'argmax')
+                while len(graphs) >= 3:
+                    graphs.pop(next(iter(graphs)))
+                graphs[key] = (replay, st, batch, nav)         # (nav kept alive: the key holds its id)
+            else:
+                replay, st, batch, _ = cached
+                batch.load(items, host)
+            take_fault(dev)                                   # (whatever an earlier pass left behind is not ours)
+            try:
+                replay()
+                break
+            except RuntimeError:
+                if attempt:
+                    raise
+                graphs.pop(key, None)                         # a weight moved: capture again
+        peek = getattr(self.env, 'peek_next_minibatch', None)
+        nxt = peek(True) if peek is not None and self.prepare_ahead else None
+        if nxt is not None:
+            self._rollout_ahead = (nav, nxt, DeviceNavBatch.host_arrays_for(
+                nav, nxt, self.max_instruction_length, self.reverse_instruction, True))
+        if take_fault(dev):                                   # the rollout's host sync
+            keep = getattr(self.encoder, 'persistent', True)
+            self.encoder.persistent = False
+            try:
+                with torch.no_grad():
+                    st = eng.rollout(batch, self.episode_len, 'argmax', train=False)
+            finally:
+                self.encoder.persistent = keep
+            if take_fault(dev):
+                raise PersistentLaunchFault('the per-step re-issue of an inference rollout raised a fault again')
+            eng.fallbacks += 1
+        self.loss = st.loss
+        traj = batch.trajectories(st)
         for tr, it in zip(traj, items):
             tr['instr_encoding'] = it['instr_encoding']
         self.losses.append(float(st.loss.detach()))

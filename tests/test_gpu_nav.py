@@ -313,6 +313,29 @@ def test_agent_train_runs_whole_iterations_as_graph_replays(world):
     assert d < 3e-4 and torch.isfinite(out[True][1]).all()     # (Adam: a near-zero gradient whose sign differs moves a weight by lr per step)
 
 
+def test_agent_test_replays_one_graph_per_minibatch(world):
+    """Seq2SeqAgent.test (follower.py:987-999) on the device environment: every minibatch after the first is one replay of
+    a captured inference rollout over a fixed-shape batch (test_graph), the next minibatch encoded under it -- the results
+    of the loop that issues every rollout launch by launch (instructions padded to the minibatch's longest there)."""
+    out = {}
+    for graph in (False, True):
+        ag, oe, od, weights = _fresh_agent(world, False)
+        ag.test_graph = graph
+        res = ag.test(use_dropout=False, feedback='argmax')
+        again = ag.test(use_dropout=False, feedback='argmax')
+        assert sorted(res) == sorted(again)
+        assert (len(ag.__dict__.get('_test_graphs', {})) == 1) == graph
+        out[graph] = (res, list(ag.losses), ag._engine.fallbacks)
+    a, b = out[True][0], out[False][0]
+    assert sorted(a) == sorted(b) and len(a) > 0
+    for k in a:
+        assert a[k]['instr_id'] == b[k]['instr_id'] and a[k]['actions'] == b[k]['actions']
+        assert a[k]['trajectory'] == b[k]['trajectory']
+        np.testing.assert_allclose(a[k]['scores'], b[k]['scores'], rtol=0, atol=2e-5)
+    np.testing.assert_allclose(out[True][1], out[False][1], rtol=2e-5)
+    assert out[True][2] == out[False][2] == 0
+
+
 def test_preparing_the_next_minibatch_under_the_replay_changes_nothing(world):
     """agents.Seq2SeqAgent.prepare_ahead: minibatch i + 1 is drawn from the environment and encoded while replay i runs and
     reaches the device as one pinned copy (nav.DeviceNavBatch._pack_for_load) -- the same minibatches in the same order:
