@@ -1068,6 +1068,57 @@ class Seq2SeqSpeaker(object):
         from . import search
         return search.speaker_beam_search(self, beam_size, path_obs, path_actions)
 
+    sweep_test_after = 30            # test(): minibatches (cumulative over calls) before the split is decoded as a sweep
+
+    def _test_as_a_sweep(self):
+        """test() over an index-form environment (speaker.py:397-414; data_augmentation_from_speaker.py's loop) through
+        speaker.SpeakerSweep: the epoch's minibatches are drawn first (the same env.reset calls, the same use of
+        `random` where the epoch wraps), their gold routes come from the navigation tables, and the device decodes them
+        as replayed graphs on two streams -- packing, copies and decoding overlapped -- instead of one launch-by-launch
+        pass per minibatch (4.6 -> 2.1 ms per minibatch of 100).  The graphs of a sweep (one per stream and route
+        length) cost ~40 ms once: taken once this agent's test() calls have seen `sweep_test_after` minibatches (a
+        data-augmentation pass at once, periodic validations from their second).  False: not applicable, the caller
+        loops over rollout()."""
+        store = self._env_store()
+        if not (self.beam_size == 1 and self.index_gold_routes and store is not None and not self.decoder.training
+                and self.feedback == 'argmax' and getattr(self.env, 'host_table', 1) is None
+                and hasattr(self.env, 'graphs') and hasattr(self.env, 'data') and store.device.type == 'cuda'):
+            return False
+        from . import speaker as spk
+        B = self.env.batch_size
+        n_batches = -(-len(self.env.data) // B)
+        seen = self.__dict__.get('_test_minibatches', 0)
+        self._test_minibatches = seen + n_batches
+        if seen + n_batches < self.sweep_test_after:
+            return False
+        drawn, ids, looped = [], set(), False
+        while not looped:                                      # (the loop of speaker.py:404-413 over the items themselves)
+            self.env.reset()
+            items = list(self.env.batch)
+            drawn.append(items)
+            for it in items:
+                if it['instr_id'] in ids:
+                    looped = True
+                ids.add(it['instr_id'])
+        key = (id(store), B, self.instruction_len)
+        cached = self.__dict__.get('_test_sweep')
+        if cached is None or cached[0] != key:
+            cached = self._test_sweep = (key, spk.SpeakerSweep(self.encoder, self.decoder, store, B, self.instruction_len,
+                                                               feedback='argmax', Lmax=self.instruction_len,
+                                                               with_scores=True), store)
+        sweep = cached[1]
+        words, scores, cnt = sweep.run([self._routes_of(items, store)[0] for items in drawn])
+        S = self.instruction_len
+        for k, items in enumerate(drawn):
+            both = np.concatenate((words[k].astype(np.float32), scores[k]), axis=0)
+            outputs, loss = self._score_outputs([it['instr_id'] for it in items], both, S, None, cnt[k], store.device)
+            self.loss = loss
+            self.losses.append(float(loss))
+            for result in outputs:
+                if result['instr_id'] not in self.results:
+                    self.results[result['instr_id']] = result
+        return True
+
     def test(self, use_dropout=False, feedback='argmax', allow_cheat=False, beam_size=1):
         if not allow_cheat:
             assert feedback in ['argmax', 'sample']
@@ -1078,6 +1129,8 @@ class Seq2SeqSpeaker(object):
         self.env.reset_epoch()
         self.losses = []
         self.results = {}
+        if self._test_as_a_sweep():
+            return self.results
         looped = False
         while True:
             for result in self.rollout():

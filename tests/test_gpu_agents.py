@@ -359,3 +359,57 @@ def test_speaker_train_without_outputs_is_the_same_training():
         assert out[True][2] == out[False][2] and out[True][3] == out[False][3] == 0
     finally:
         random.setstate(rng_state)
+
+
+def test_speaker_test_as_a_sweep_equals_the_loop_over_rollouts():
+    """Seq2SeqSpeaker.test (speaker.py:397-414) decoded as one speaker.SpeakerSweep over the epoch's minibatches against the
+    loop over rollout(): the same instructions, word for word, scores and losses to rounding -- before and AFTER training
+    steps (the sweep's graphs are captured once and must follow the weights)."""
+    import os
+    import random
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import search_world as W
+    from speaker_follower_amd import agents, features, model, optim
+    rng_state = random.getstate()
+    try:
+        env, table = W.build_world(dense=False, n_items=60, batch=12, item_seed=9)
+        d = synth.FULL
+        w_enc, w_dec = synth.speaker_weights(W.SPEAKER_SEED)
+        senc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+        sdec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=w_dec['embedding.weight'])
+        senc.load_state_dict({k: torch.tensor(v) for k, v in w_enc.items()})
+        sdec.load_state_dict({k: torch.tensor(v) for k, v in w_dec.items()})
+        senc.cuda()
+        sdec.cuda()
+        spk = agents.Seq2SeqSpeaker(env, '/tmp/sf_spk_sweep.json', senc, sdec, W.INSTRUCTION_LEN, max_episode_len=W.EPISODE_LEN)
+        spk.store = features.FeatureStore(table)
+        oe = optim.FusedAdam([p for p in senc.parameters() if p.requires_grad], lr=1e-3)
+        od = optim.FusedAdam([p for p in sdec.parameters() if p.requires_grad], lr=1e-3)
+
+        def both_ways():
+            out = []
+            for after in (10 ** 9, 0):
+                spk.sweep_test_after = after
+                random.seed(17)                        # (the epoch wraps inside test(): the same reshuffle both ways)
+                env.data.sort(key=lambda it: it['instr_id'])
+                res = spk.test(use_dropout=False, feedback='argmax')
+                out.append(({k: (v['word_indices'], v['score'], v['scores']) for k, v in res.items()}, list(spk.losses),
+                            [it['instr_id'] for it in env.batch]))
+            loop, sweep = out
+            assert ('_test_sweep' in spk.__dict__)
+            assert sorted(loop[0]) == sorted(sweep[0]) and len(loop[0]) == 60 and loop[2] == sweep[2]
+            for k in loop[0]:
+                assert loop[0][k][0] == sweep[0][k][0], k
+                np.testing.assert_allclose(sweep[0][k][2], loop[0][k][2], rtol=0, atol=2e-5)
+                assert abs(loop[0][k][1] - sweep[0][k][1]) < 1e-4
+            np.testing.assert_allclose(sweep[1], loop[1], rtol=1e-5)
+            return loop[0]
+        first = both_ways()
+        env.reset_epoch()
+        spk.train(oe, od, 5, feedback='teacher')
+        second = both_ways()
+        assert any(first[k][0] != second[k][0] for k in first)          # (the training steps changed what is generated)
+        assert spk._test_sweep[1].fallbacks == 0
+    finally:
+        random.setstate(rng_state)
