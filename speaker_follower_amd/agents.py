@@ -435,7 +435,10 @@ class Seq2SeqAgent(BaseAgent):
         for m in (self.encoder, self.decoder):
             m.train() if use_dropout else m.eval()
         self.set_beam_size(beam_size)
-        return super().test()
+        # (test() reads results, nothing differentiates them: without autograd a rollout keeps no tape -- a differentiable
+        # state lives until the cyclic collector finds it, a few hundred MB per minibatch)
+        with torch.no_grad():
+            return super().test()
 
     def train(self, encoder_optimizer, decoder_optimizer, n_iters, feedback='teacher'):
         """follower.py:1001-1020."""
@@ -1131,6 +1134,10 @@ class Seq2SeqSpeaker(object):
         self.results = {}
         if self._test_as_a_sweep():
             return self.results
+        with torch.no_grad():
+            return self._test_loop()
+
+    def _test_loop(self):
         looped = False
         while True:
             for result in self.rollout():

@@ -69,7 +69,12 @@ class _SpeakerLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dloss):
+        if ctx.state is None:
+            raise RuntimeError('second backward through a pass whose tape the first backward released')
         ctx.engine._backward(ctx.state, dloss)
+        # state -> loss -> grad_fn -> ctx -> state is a reference cycle: a few hundred MB of tape per pass that only
+        # the cyclic collector would free (seen as a 4 GB sawtooth under a training loop).  The tape has been consumed.
+        ctx.state = None
         return (None, None) + (None,) * (len(ctx.needs_input_grad) - 2)
 
 
