@@ -433,6 +433,53 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
         out['train_through_the_agent_api'] = api
     except Exception as exc:                     # (reported, not fatal)
         out['train_through_the_agent_api_error'] = repr(exc)[:300]
+    # (b'') validation through the agents' API: Seq2SeqAgent.test (follower.py:987-999: argmax rollouts over a whole split,
+    # the results dictionary) -- one inference graph replay per minibatch, the next minibatch encoded under it
+    try:
+        et, _ = full_world(store, batch, seed=41, n_items=20 * batch)
+        ag = agents.Seq2SeqAgent(et, '/tmp/sf_bench_agent_test.json', enc, dec, episode_len=steps)
+        ag.store = store
+        ag.use_device_env(nt)
+        ag.test(use_dropout=False, feedback='argmax')              # (first epoch: hop tables, the capture)
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = ag.test(use_dropout=False, feedback='argmax')
+            torch.cuda.synchronize()
+            dtt = time.perf_counter() - t1
+            best = dtt if best is None else min(best, dtt)
+        out['test_through_the_agent_api'] = dict(
+            value=len(res) / best, unit='instructions/s', ms_per_minibatch=1e3 * best / (len(res) / batch),
+            fallbacks=int(ag._engine.fallbacks),
+            what='Seq2SeqAgent.test(feedback="argmax") over %d instructions in minibatches of %d on the device environment: '
+                 'result dictionaries included (best of 3 epochs)' % (len(res), batch))
+    except Exception as exc:                     # (reported, not fatal)
+        out['test_through_the_agent_api_error'] = repr(exc)[:300]
+    # (b''') configs[2] through the agents' API: Seq2SeqSpeaker.test (speaker.py:397-414, what
+    # data_augmentation_from_speaker.py drives): greedy instructions for the gold paths of a split, routes from the
+    # navigation tables, the split decoded as one two-stream sweep of replayed graphs
+    try:
+        senc, sdec = _speaker_models(store.device)
+        es, _ = full_world(store, batch, seed=33, n_items=20 * batch)
+        spk = agents.Seq2SeqSpeaker(es, '/tmp/sf_bench_speaker_test.json', senc, sdec, 80)
+        spk.store = store
+        spk.sweep_test_after = 0
+        spk.test(use_dropout=False, feedback='argmax')             # (hop tables; the sweep's graphs)
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = spk.test(use_dropout=False, feedback='argmax')
+            torch.cuda.synchronize()
+            dtt = time.perf_counter() - t1
+            best = dtt if best is None else min(best, dtt)
+        out['speaker_test_through_the_agent_api'] = dict(
+            value=len(res) / best, unit='paths/s', ms_per_minibatch=1e3 * best / (len(res) / batch),
+            what='Seq2SeqSpeaker.test(feedback="argmax") over %d gold paths in minibatches of %d, 80 words each: result '
+                 'dictionaries included (best of 3 epochs)' % (len(res), batch))
+    except Exception as exc:                     # (reported, not fatal)
+        out['speaker_test_through_the_agent_api_error'] = repr(exc)[:300]
     # (c) configs[4] on the same world: state-factored search K = 40 over a minibatch of 64 instructions
     n_mb = 8
     e64, _ = full_world(store, 64, seed=15, n_items=64 * (n_mb + 2))
