@@ -217,21 +217,32 @@ class Seq2SeqAgent(BaseAgent):
         a new capture.  Instructions are padded to max_instruction_length (the eager rollout pads to the minibatch's
         longest: equal up to the summation order of the padded attention columns)."""
         from .nav import DeviceNavBatch
-        from .runtime import take_fault
+        from .runtime import take_fault, fault_views
         eng, dev = self._engine, self._device()
         key = (id(nav), id(eng), self.episode_len, len(items), self.max_instruction_length, self.reverse_instruction)
         graphs = self.__dict__.setdefault('_test_graphs', {})  # (train.py alternates between its validation environments)
-        for attempt in (0, 1):
+        S = self.episode_len
+        # (key, items, weight versions): the replay the previous call issued ahead -- good for exactly these items under
+        # exactly these weights
+        versions = sum(p_._version for m in (self.encoder, self.decoder) for p_ in m.parameters())
+        flying = self.__dict__.pop('_rollout_inflight', None)
+        hit = (flying is not None and flying[0] == key and key in graphs and flying[2] == versions
+               and len(flying[1]) == len(items) and all(a is b for a, b in zip(flying[1], items)))
+        if hit:
+            replay, st, batch, _, pinned = graphs[key]         # already loaded and replayed: its results wait on the device
+        for attempt in () if hit else (0, 1):
             cached = graphs.get(key)
             if cached is None:
-                batch = DeviceNavBatch(nav, items, self.episode_len, max_length=self.max_instruction_length,
+                batch = DeviceNavBatch(nav, items, S, max_length=self.max_instruction_length,
                                        reverse=self.reverse_instruction, fixed_shapes=True, host=host)
-                replay, st = eng.capture(batch, self.episode_len, 'argmax')
+                replay, st = eng.capture(batch, S, 'argmax')
+                pinned = [torch.empty(t.shape, dtype=t.dtype).pin_memory()
+                          for t in (batch.row[:S + 1], batch.view[:S + 1], st.actions, st.step_scores, st.loss_buf)]
                 while len(graphs) >= 3:
                     graphs.pop(next(iter(graphs)))
-                graphs[key] = (replay, st, batch, nav)         # (nav kept alive: the key holds its id)
+                graphs[key] = (replay, st, batch, nav, pinned)  # (nav kept alive: the key holds its id)
             else:
-                replay, st, batch, _ = cached
+                replay, st, batch, _, pinned = cached
                 batch.load(items, host)
             take_fault(dev)                                   # (whatever an earlier pass left behind is not ours)
             try:
@@ -241,27 +252,53 @@ class Seq2SeqAgent(BaseAgent):
                 if attempt:
                     raise
                 graphs.pop(key, None)                         # a weight moved: capture again
+        # this minibatch's results leave the device buffers before anything else is written into them ...
+        for dst, src in zip(pinned, (batch.row[:S + 1], batch.view[:S + 1], st.actions, st.step_scores, st.loss_buf)):
+            dst.copy_(src, non_blocking=True)
+        # (the fault words travel with them: runtime.take_fault's synchronous copy would wait for the replay issued below)
+        faults = fault_views(dev)
+        fpin = self.__dict__.get('_fault_pin')
+        if fpin is None or fpin.numel() != len(faults):
+            fpin = self._fault_pin = torch.empty(len(faults), dtype=torch.int32).pin_memory()
+        fpin.copy_(torch.cat(faults) if len(faults) > 1 else faults[0], non_blocking=True)
+        done = torch.cuda.Event()
+        done.record()
+        # ... and the NEXT minibatch (peeked, not drawn) is encoded, loaded and replayed right behind them: the device
+        # runs it while the host builds this minibatch's dictionaries
         peek = getattr(self.env, 'peek_next_minibatch', None)
         nxt = peek(True) if peek is not None and self.prepare_ahead else None
-        if nxt is not None:
-            self._rollout_ahead = (nav, nxt, DeviceNavBatch.host_arrays_for(
-                nav, nxt, self.max_instruction_length, self.reverse_instruction, True))
-        if take_fault(dev):                                   # the rollout's host sync
+        if nxt is not None and len(nxt) == len(items):
+            nhost = DeviceNavBatch.host_arrays_for(nav, nxt, self.max_instruction_length, self.reverse_instruction, True)
+            try:
+                batch.load(nxt, nhost)
+                replay()
+                self._rollout_inflight = (key, nxt, versions)
+            except RuntimeError:
+                self._rollout_ahead = (nav, nxt, nhost)
+        done.synchronize()
+        rows, views, acts, sc, loss = (p_.numpy().copy() for p_ in pinned)
+        if any(fpin.tolist()):
+            self.__dict__.pop('_rollout_inflight', None)      # (what was issued ahead is not trusted either: reloaded next)
+            torch.cuda.synchronize(dev)
+            take_fault(dev)                                   # (read and cleared)
+            batch.load(items)
             keep = getattr(self.encoder, 'persistent', True)
             self.encoder.persistent = False
             try:
                 with torch.no_grad():
-                    st = eng.rollout(batch, self.episode_len, 'argmax', train=False)
+                    st2 = eng.rollout(batch, S, 'argmax', train=False)
             finally:
                 self.encoder.persistent = keep
             if take_fault(dev):
                 raise PersistentLaunchFault('the per-step re-issue of an inference rollout raised a fault again')
             eng.fallbacks += 1
-        self.loss = st.loss
-        traj = batch.trajectories(st)
+            rows, views = batch.row[:S + 1].cpu().numpy(), batch.view[:S + 1].cpu().numpy()
+            acts, sc, loss = st2.actions.cpu().numpy(), st2.step_scores.cpu().numpy(), st2.loss_buf.cpu().numpy()
+        self.loss = torch.tensor(float(loss.reshape(-1)[0]))        # (a host tensor: a copy to the device would queue behind the replay issued ahead)
+        traj = batch.trajectories_from(items, S, rows, views, acts, sc)
         for tr, it in zip(traj, items):
             tr['instr_encoding'] = it['instr_encoding']
-        self.losses.append(float(st.loss.detach()))
+        self.losses.append(float(loss.reshape(-1)[0]))
         return traj
 
     # ---- tensor assembly (follower.py:291-332): numpy stacks -> device tensors
@@ -435,6 +472,7 @@ class Seq2SeqAgent(BaseAgent):
         for m in (self.encoder, self.decoder):
             m.train() if use_dropout else m.eval()
         self.set_beam_size(beam_size)
+        self.__dict__.pop('_rollout_inflight', None)          # (nothing issued ahead by an earlier loop is ours)
         # (test() reads results, nothing differentiates them: without autograd a rollout keeps no tape -- a differentiable
         # state lives until the cyclic collector finds it, a few hundred MB per minibatch)
         with torch.no_grad():

@@ -315,11 +315,13 @@ class DeviceNavBatch:
         duplicated final state included, nothing after it.  The device arrays come down once; the per-sample lists are
         cut from them with numpy, and 'trajectory' (a tuple per visited pose) is built when somebody reads it."""
         S = st.steps
-        rows = self.row[:S + 1].cpu().numpy()
-        views = self.view[:S + 1].cpu().numpy()
-        acts = st.actions.cpu().numpy()
-        sc = st.step_scores.cpu().numpy()
-        B = len(self.items)
+        return self.trajectories_from(self.items, S, self.row[:S + 1].cpu().numpy(), self.view[:S + 1].cpu().numpy(),
+                                      st.actions.cpu().numpy(), st.step_scores.cpu().numpy())
+
+    def trajectories_from(self, items, S, rows, views, acts, sc):
+        """`trajectories` over host copies of the rollout's arrays (rows / views [S+1,B], actions / step scores [S,B]); the
+        result dictionaries keep slices of them."""
+        B = len(items)
         stopped = acts[:S] == 0
         n = np.where(stopped.any(0), stopped.argmax(0) + 1, S)                  # steps up to and including the stop action
         totals = np.cumsum(sc[:S], axis=0, dtype=np.float32)                    # (sequential float32 sums, as the loop's)
@@ -328,7 +330,7 @@ class DeviceNavBatch:
         acts_t, sc_t = np.ascontiguousarray(acts[:S].T), np.ascontiguousarray(sc[:S].T)
         last = totals[n - 1, np.arange(B)].tolist()
         return [_Trajectory(self.nav, it, int(n[b]), acts_t[b], sc_t[b], last[b], rows[:, b], views[:, b], moved[:, b])
-                for b, it in enumerate(self.items)]
+                for b, it in enumerate(items)]
 
 
 class _Trajectory(LazyDict):

@@ -216,13 +216,20 @@ def fault_word(device):
     return _fault_view(workspace(device))
 
 
+def fault_views(device):
+    """The fault words (int32[1] views) of every workspace of `device`: for callers that read them with their own
+    asynchronous copy (`torch.cat(views)` into pinned memory) instead of take_fault's synchronous one, and zero the
+    ones they found raised."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return [_fault_view(ws) for (d, _), ws in _workspaces.items() if d == idx]
+
+
 def take_fault(device):
     """Reads AND clears the fault words of EVERY workspace of `device` (one per stream that ever ran library
     calls: the backward's side streams and captured rollouts have their own).  A host sync: callers put it where
     they synchronise anyway (the D2H copy of a rollout's actions, the loss read of a training iteration).  Returns
     the OR of the FAULT_* bits raised since the last call; 0 in a healthy process."""
-    idx = device.index if device.index is not None else torch.cuda.current_device()
-    views = [_fault_view(ws) for (d, _), ws in _workspaces.items() if d == idx]
+    views = fault_views(device)
     if not views:
         return 0
     words = (torch.cat(views) if len(views) > 1 else views[0]).cpu()        # (the sync)
