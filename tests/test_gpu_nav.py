@@ -336,6 +336,31 @@ def test_agent_test_replays_one_graph_per_minibatch(world):
     assert out[True][2] == out[False][2] == 0
 
 
+def test_a_replay_issued_ahead_is_not_used_once_the_weights_changed(world):
+    """Seq2SeqAgent._rollout_on_graph issues minibatch k + 1's replay behind minibatch k's download; a caller that changes
+    the weights between two rollouts (in place: the parameters' versions move) must get minibatch k + 1 under the NEW
+    weights -- the rollout of the launch-by-launch path with the same changes."""
+    out = {}
+    for graph in (True, False):
+        ag, oe, od, weights = _fresh_agent(world, False)
+        ag.test_graph = graph
+        ag.feedback = 'argmax'
+        for m in (ag.encoder, ag.decoder):
+            m.eval()
+        with torch.no_grad():
+            first = ag.rollout()
+            assert ('_rollout_inflight' in ag.__dict__) == graph
+            for p_ in ag.decoder.parameters():
+                p_.mul_(0.7)
+            second = ag.rollout()
+            third = ag.rollout()                               # (and the pipeline goes on under the new weights)
+        out[graph] = [[(t['instr_id'], t['actions'], t['scores']) for t in r] for r in (first, second, third)]
+    for a, b in zip(out[True], out[False]):
+        assert [x[:2] for x in a] == [x[:2] for x in b]
+        for x, y in zip(a, b):
+            np.testing.assert_allclose(x[2], y[2], rtol=0, atol=2e-5)
+
+
 def test_preparing_the_next_minibatch_under_the_replay_changes_nothing(world):
     """agents.Seq2SeqAgent.prepare_ahead: minibatch i + 1 is drawn from the environment and encoded while replay i runs and
     reaches the device as one pinned copy (nav.DeviceNavBatch._pack_for_load) -- the same minibatches in the same order:
