@@ -212,10 +212,14 @@ class Seq2SeqAgent(BaseAgent):
     def _rollout_on_graph(self, nav, items, host=None):
         """An inference rollout (agent.test, follower.py:987-999) as ONE graph replay over a fixed-shape minibatch: the
         items are written into the captured batch's tensors (one pinned copy), the next minibatch is peeked and encoded
-        while the replay runs, the fault word is read where the results are.  A starved persistent launch re-issues the
-        minibatch on the per-step kernels; weights that MOVED since the capture (load_state_dict into new tensors) mean
-        a new capture.  Instructions are padded to max_instruction_length (the eager rollout pads to the minibatch's
-        longest: equal up to the summation order of the padded attention columns)."""
+        while the replay runs, the fault word is read where the results are.  The results (and the fault words) come
+        down asynchronously, and the NEXT minibatch's replay is issued right behind that download: the device runs it
+        while the host builds this minibatch's dictionaries; the next call takes it over only for exactly the peeked
+        items under exactly the current weight versions.  A starved persistent launch re-issues the minibatch on the
+        per-step kernels (and drops what was issued ahead); weights that MOVED since the capture (load_state_dict into
+        new tensors) mean a new capture.  Instructions are padded to max_instruction_length (the eager rollout pads to
+        the minibatch's longest: equal up to the summation order of the padded attention columns).  `self.loss` is a
+        host tensor on this path."""
         from .nav import DeviceNavBatch
         from .runtime import take_fault, fault_views
         eng, dev = self._engine, self._device()
