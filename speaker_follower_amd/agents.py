@@ -585,6 +585,10 @@ class Seq2SeqAgent(BaseAgent):
         take_fault(dev)                                       # (whatever an earlier pass left behind is not ours)
         ahead = None            # the NEXT minibatch and its host arrays, formed while the device ran this iteration
         for it in range(n_iters):
+            if (self.pipeline_replays and self.prepare_ahead and cached is not None and cached[0] == key
+                    and cached[2].batch_size == self.env.batch_size):
+                # the graph exists: the remaining iterations with one replay always queued behind the running one
+                return self._replay_pipelined(opts, n_iters - it, cached, eng, dev, ahead)
             if ahead is None:
                 self.env.reset(sort=True)
                 items, host = list(self.env.batch), None
@@ -634,6 +638,88 @@ class Seq2SeqAgent(BaseAgent):
                     o.step()
             self.loss = st.loss_buf.reshape(())
             self.losses.append(loss)
+
+    pipeline_replays = True      # train() on graphs: replay i + 1 is queued before the loss of replay i is read
+
+    def _replay_pipelined(self, opts, n, cached, eng, dev, first=None):
+        """`n` iterations of `_replay_iterations` with the device never waiting for the host: replay i + 1 (its minibatch
+        loaded behind replay i on the same stream) is queued BEFORE the host waits for iteration i, whose loss and fault
+        words come down asynchronously into pinned memory.  Nothing on the device depends on the host reading a loss;
+        the one thing that does is the fault path: the guarded optimizer steps of a faulted iteration AND of the one
+        queued behind it do nothing (the fault word stays raised until the host clears it), so the host re-issues the
+        faulted minibatch on the per-step kernels and queues the other one again.  Same minibatches in the same order,
+        same sites, same steps: losses and weights of the serial loop (tests/test_gpu_nav.py)."""
+        import collections
+        from .runtime import take_fault, fault_views
+        _, tg, batch = cached
+        n_words = len(fault_views(dev))
+        pins = self.__dict__.get('_train_pins')
+        if pins is None or pins[0][1].numel() != n_words:
+            pins = self._train_pins = [(torch.empty(1, dtype=torch.float32).pin_memory(),
+                                        torch.empty(n_words, dtype=torch.int32).pin_memory()) for _ in range(2)]
+        todo = collections.deque()     # minibatches drawn and not issued yet: (items, host arrays or None)
+        drawn = issued = 0
+        if first is not None:          # (what the serial loop had already drawn for its next iteration)
+            todo.append(first)
+            drawn = 1
+        flight = None                  # the iteration whose loss has not been read: (slot, event, steps before it, items)
+
+        def draw():
+            nonlocal drawn
+            self.env.reset(sort=True)
+            nxt = list(self.env.batch)
+            todo.append((nxt, batch._host_arrays(nxt) if len(nxt) == batch.batch_size else None))
+            drawn += 1
+        while issued < n or flight is not None:
+            cur = None
+            if issued < n:
+                if not todo:
+                    draw()
+                items, host = todo.popleft()
+                before = [o.host_steps() for o in opts]
+                batch.load(items, host)
+                st = tg.replay()
+                slot = issued & 1
+                pins[slot][0].copy_(st.loss_buf.reshape(1), non_blocking=True)
+                views = fault_views(dev)
+                pins[slot][1].copy_(torch.cat(views) if len(views) > 1 else views[0], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                cur = (slot, ev, before, items)
+                issued += 1
+            if flight is not None:
+                slot, ev, before_f, items_f = flight
+                ev.synchronize()
+                if any(pins[slot][1].tolist()):
+                    torch.cuda.synchronize(dev)               # (the replay queued behind it did nothing either)
+                    take_fault(dev)
+                    for o, b in zip(opts, before_f):
+                        o.set_host_steps(b)
+                        o.zero_grad()
+                    batch.load(items_f)
+                    keep = getattr(self.encoder, 'persistent', True)
+                    self.encoder.persistent = False
+                    try:
+                        st2 = eng.rollout(batch, self.episode_len, self.feedback, train=True)
+                        st2.loss.backward()
+                    finally:
+                        self.encoder.persistent = keep
+                    self.losses.append(float(st2.loss_buf))
+                    if take_fault(dev):
+                        raise PersistentLaunchFault('the per-step re-issue of a training iteration raised a fault again')
+                    eng.fallbacks += 1
+                    for o in opts:
+                        o.step()
+                    if cur is not None:                       # queue the other one again, in front of what was drawn since
+                        todo.appendleft((cur[3], None))
+                        issued -= 1
+                        cur = None
+                else:
+                    self.losses.append(float(pins[slot][0]))
+            flight = cur
+            if flight is not None and drawn < n and not todo:
+                draw()                                        # (host work under the replay that is running)
+        self.loss = tg.state.loss_buf.reshape(())
 
     def _encoder_and_decoder_paths(self, base_path):
         return base_path + '_enc', base_path + '_dec'

@@ -409,6 +409,51 @@ def test_agent_train_on_graphs_survives_a_starved_persistent_launch(world):
     assert oe.host_steps() == [5] and torch.isfinite(weights()).all()
 
 
+def test_a_fault_in_the_middle_of_pipelined_replays_is_repaired_in_order(world):
+    """Seq2SeqAgent._replay_pipelined queues replay i + 1 before it reads iteration i's fault words.  A fault raised
+    inside replay i: neither i nor i + 1 stepped (the word stays raised on the device), the host re-issues minibatch i on
+    the per-step kernels, queues minibatch i + 1 again, and the loop ends with every iteration trained once, on the
+    minibatches the serial loop trains on, in its order."""
+    from speaker_follower_amd import runtime
+    seen = {}
+    for pipelined in (True, False):
+        ag, oe, od, weights = _fresh_agent(world, True)
+        ag.pipeline_replays = pipelined
+        ag.train(oe, od, 2, feedback='teacher')
+        tg = ag._train_graph_state[1]
+        with torch.cuda.stream(tg.stream):
+            fw = runtime.fault_word(torch.device('cuda', 0))
+        replay, calls, loaded = tg.replay, [], []
+        load = ag._train_graph_state[2].load
+
+        def counting_load(items, host=None):
+            loaded.append([it['instr_id'] for it in items])
+            return load(items, host)
+
+        def poisoned():
+            calls.append(len(calls))
+            if len(calls) == 2:                                    # the second of this call's replays
+                fw.fill_(runtime.FAULT_ENC_BWD)
+            return replay()
+        tg.replay = poisoned
+        ag._train_graph_state[2].load = counting_load
+        try:
+            ag.train(oe, od, 5, feedback='teacher')
+        finally:
+            tg.replay = replay
+            ag._train_graph_state[2].load = load
+        assert ag._engine.fallbacks == 1 and oe.host_steps() == [7] and od.host_steps() == [7]
+        assert len(ag.losses) == 5 and np.isfinite(ag.losses).all() and torch.isfinite(weights()).all()
+        # every minibatch of the call, in order, once -- apart from the reloads of the repair
+        order = []
+        for ids in loaded:
+            if ids not in order:
+                order.append(ids)
+        seen[pipelined] = (order, [it['instr_id'] for it in ag.env.batch], len(calls))
+    assert seen[True][0] == seen[False][0] and len(seen[True][0]) == 5 and seen[True][1] == seen[False][1]
+    assert seen[True][2] == 6 and seen[False][2] == 5              # (the replay queued behind the fault ran twice)
+
+
 def test_agent_train_adopts_the_references_own_torch_adam(world):
     """train.py:263-268 hands Seq2SeqAgent.train two plain torch.optim.Adam objects.  The agent mirrors each by an
     optim.FusedAdam (same parameters, hyper-parameters and state, taken over at the start of a train() call and handed back
