@@ -476,6 +476,8 @@ def real_env_full(enc, dec, store, device, batch=100, steps=20, train_iters=6):
             best = dtt if best is None else min(best, dtt)
         out['speaker_test_through_the_agent_api'] = dict(
             value=len(res) / best, unit='paths/s', ms_per_minibatch=1e3 * best / (len(res) / batch),
+            as_a_sweep='_test_sweep' in spk.__dict__,
+            fallbacks=int(spk._test_sweep[1].fallbacks) if '_test_sweep' in spk.__dict__ else 0,
             what='Seq2SeqSpeaker.test(feedback="argmax") over %d gold paths in minibatches of %d, 80 words each: result '
                  'dictionaries included (best of 3 epochs)' % (len(res), batch))
     except Exception as exc:                     # (reported, not fatal)
