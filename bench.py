@@ -77,6 +77,9 @@ def parse(argv=None):
                          'rows (the reference\'s batch is 100 globally, train.py:28) split over the ranks with dp.shard_rows')
     ap.add_argument('--extras-budget', type=int, default=240,
                     help='N > 1: seconds the data-parallel training extra may take before the headline line is printed without it')
+    ap.add_argument('--extras-out', default=os.path.join(ROOT, 'bench_extras.json'),
+                    help='file that receives the FULL result object (per-kernel tables, the other BASELINE configs, the '
+                         'training iteration); stdout carries only the compact headline line (< 4 KB)')
     ap.add_argument('--plan', action='store_true',
                     help='print the child commands / environment `--gpus N` would start (JSON) and exit; touches no GPU')
     return ap.parse_args(argv)
@@ -437,6 +440,136 @@ def roofline_table(prof_rows, n_rollouts, B, S, T, A_mean, dims, pmc):
     return out, total
 
 
+
+# ------------------------------------------------------------------------------------------ the printed line
+HEADLINE_LIMIT = 4096        # bytes; the driver reads ONE line from stdout, and a 20 KB line was once lost on the way
+
+
+def _cut(s, n):
+    s = str(s)
+    return s if len(s) <= n else s[:n - 3] + '...'
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def headline_of(full, extras_file):
+    """The compact object that is printed: the contract keys, the dominant kernel's roofline (both prices: the
+    algorithmic fp32 work against the fp32 MFMA peak AND what the launch executes on the bf16 matrix cores against the
+    bf16 peak), the CPU baseline, the parity check of this run, and a few scalars of the extras.  Everything else
+    (per-kernel tables, prose, the other configs) is in `extras_file`."""
+    keep = ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+            'vs_baseline', 'dtype', 'data')
+    h = {k: full[k] for k in keep if k in full}
+    cfg = dict(full.get('config', {}))
+    cfg['workload'] = _cut(cfg.get('workload', ''), 260)
+    h['config'] = cfg
+    r = full.get('roofline')
+    if r:
+        rr = _pick(r, ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic', 'launch_us', 'flops_per_launch',
+                       'bytes_per_launch', 'mfma_frac', 'hbm_frac', 'mfma_busy_frac', 'kernel_time_ms_per_rollout'))
+        rr.setdefault('traffic', None)
+        rr['kernel'] = _cut(r.get('kernel', '').split(' (')[0], 80)
+        if r.get('executed'):
+            rr['executed'] = _pick(r['executed'], ('dtype', 'tflops', 'peak', 'frac'))
+            rr['executed']['dtype'] = 'bf16'
+        if r.get('rollout'):
+            rr['rollout'] = _pick(r['rollout'], ('flops_frac', 'executed_flops_frac', 'hbm_frac'))
+        rr['kernels'] = [_pick(k, ('kernel', 'avg_us', 'share', 'mfma_frac', 'hbm_frac', 'mfma_busy_frac'))
+                         for k in r.get('kernels', [])[:5]]
+        for k in rr['kernels']:
+            k['kernel'] = _cut(k['kernel'], 48)
+        rr['note'] = ('frac = algorithmic fp32 FLOPs / launch time / fp32 MFMA peak; executed = the 6 bf16 MFMA products '
+                      'per fp32 product the launch runs, against the dense bf16 peak; mfma_busy_frac = '
+                      'SQ_VALU_MFMA_BUSY_CYCLES / SQ_BUSY_CYCLES from the committed rocprofv3 --pmc pass')
+        h['roofline'] = rr
+    if full.get('cpu_baseline'):
+        c = _pick(full['cpu_baseline'], ('value', 'unit', 'cores', 'kind', 'sample'))
+        c['sample'] = _cut(c.get('sample', ''), 200)
+        h['cpu_baseline'] = c
+        h['speedup_vs_cpu_1_core'] = full['value'] / c['value'] if c.get('value') else None
+    if full.get('parity_vs_cpu_port'):
+        h['parity_vs_cpu_port'] = _pick(full['parity_vs_cpu_port'],
+                                        ('actions_bit_exact', 'max_abs_logit_diff', 'loss_abs_diff', 'max_abs_logit'))
+    for k in ('launch', 'persistent_launch_faults', 'oversubscribed'):
+        if k in full:
+            h[k] = _cut(full[k], 120) if isinstance(full[k], str) else full[k]
+    ex = {}
+    for name, keys in (('concurrent', ('value', 'rollouts_in_flight')),
+                       ('train_iteration', ('value', 'ms_per_iteration')),
+                       ('speaker_decode', ('value', 'unit', 'ms_per_batch')),
+                       ('speaker_sweep', ('value', 'unit', 'seconds')),
+                       ('speaker_train_iteration', ('value', 'unit', 'ms_per_iteration')),
+                       ('search_step', ('value', 'unit')),
+                       ('real_env_full', ('value', 'unit')),
+                       ('pragmatic_inference', ('value', 'unit')),
+                       ('cpu_baseline_all_cores', ('value', 'cores'))):
+        v = full.get(name)
+        if isinstance(v, dict):
+            if 'error' in v:
+                ex[name] = dict(error=_cut(v['error'], 80))
+            elif 'value' in v:
+                ex[name] = _pick(v, keys)
+    if ex:
+        h['extras'] = ex
+    td = full.get('train_dp')
+    if isinstance(td, dict):
+        keys = ('value', 'unit', 'ms_per_iteration', 'allreduce_ms', 'allreduce_exposed_ms_overlapped',
+                'ms_per_iteration_no_exchange', 'allreduce_bytes', 'global_batch', 'scaling', 'launch_mode')
+        c = _pick(td, keys)
+        if 'error' in td:
+            c['error'] = _cut(td['error'], 200)
+        if isinstance(td.get('strong'), dict):
+            c['strong'] = _pick(td['strong'], keys)
+        if isinstance(td.get('health'), dict):
+            c['faults'] = sum(td['health'].get('persistent_launch_faults', []))
+        h['train_dp'] = c
+    h['extras_file'] = extras_file
+    return h
+
+
+def print_result(full, result_out, extras_path):
+    """Write the full object to `extras_path` (best effort) and print the compact headline as ONE line on the
+    original stdout.  NaN / Infinity would make the line invalid JSON: refuse them (allow_nan=False), falling back to a
+    line that says which part was not finite."""
+    written = None
+    for path in (extras_path, os.path.join(ROOT, 'gpurun_out', 'bench_extras.json')):
+        try:
+            if path and os.path.isdir(os.path.dirname(path)):
+                with open(path, 'w') as f:
+                    json.dump(full, f, indent=1, default=str)
+                written = written or os.path.relpath(path, ROOT)
+        except OSError:
+            pass
+    h = headline_of(full, written)
+    try:
+        line = json.dumps(h, allow_nan=False)
+    except ValueError:
+        def clean(o):
+            if isinstance(o, float) and (o != o or o in (float('inf'), float('-inf'))):
+                return None
+            if isinstance(o, dict):
+                return {k: clean(v) for k, v in o.items()}
+            if isinstance(o, (list, tuple)):
+                return [clean(v) for v in o]
+            return o
+        h = clean(h)
+        h['non_finite_values_replaced_by_null'] = True
+        line = json.dumps(h, allow_nan=False)
+    if len(line) >= HEADLINE_LIMIT:          # never again a line the driver cannot hold: drop the optional parts
+        for k in ('extras', 'train_dp'):
+            h.pop(k, None)
+        if 'roofline' in h:
+            h['roofline'].pop('kernels', None)
+            h['roofline'].pop('note', None)
+        line = json.dumps(h, allow_nan=False)
+    assert len(line) < HEADLINE_LIMIT, len(line)
+    print(line, file=result_out)
+    result_out.flush()
+    return h
+
+
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse(argv)
@@ -609,8 +742,7 @@ def main(argv=None):
             if rank == 0:
                 headline['train_dp'] = dict(error='the data-parallel training extra did not finish within %d s; the '
                                                   'headline above was measured before it' % args.extras_budget)
-                print(json.dumps(headline), file=result_out)
-                result_out.flush()
+                print_result(headline, result_out, args.extras_out)
             os._exit(4)
         watchdog = threading.Timer(args.extras_budget, bail)
         watchdog.daemon = True
@@ -816,8 +948,7 @@ def main(argv=None):
     # a starved persistent launch would have poisoned a rollout with NaN: the fault words say so (0 = healthy)
     from speaker_follower_amd import runtime as _rt
     out['persistent_launch_faults'] = _rt.take_fault(device)
-    print(json.dumps(out), file=result_out)
-    result_out.flush()
+    print_result(out, result_out, args.extras_out)
     if coll and not dp_failed:
         torch.distributed.destroy_process_group()
     # (after a failed data-parallel extra the group may be wedged on the other ranks: no tear-down that could block)

@@ -21,7 +21,7 @@ from . import _lib
 from ._lib import call
 from .lazydict import LazyDict
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
-from .runtime import ptr, stream, require_gpu, cands_dense, PersistentLaunchFault, gc_paused
+from .runtime import ptr, stream, require_gpu, cands_dense, PersistentLaunchFault, gc_paused, WeightsMoved
 
 byref = C.byref
 
@@ -228,7 +228,7 @@ class Seq2SeqAgent(BaseAgent):
         S = self.episode_len
         # (key, items, weight versions): the replay the previous call issued ahead -- good for exactly these items under
         # exactly these weights
-        versions = sum(p_._version for m in (self.encoder, self.decoder) for p_ in m.parameters())
+        versions = tuple((p_.data_ptr(), p_._version) for m in (self.encoder, self.decoder) for p_ in m.parameters())
         flying = self.__dict__.pop('_rollout_inflight', None)
         hit = (flying is not None and flying[0] == key and key in graphs and flying[2] == versions
                and len(flying[1]) == len(items) and all(a is b for a, b in zip(flying[1], items)))
@@ -252,7 +252,7 @@ class Seq2SeqAgent(BaseAgent):
             try:
                 replay()
                 break
-            except RuntimeError:
+            except WeightsMoved:                              # (only this: a device error is not a reason to recapture)
                 if attempt:
                     raise
                 graphs.pop(key, None)                         # a weight moved: capture again
@@ -277,7 +277,7 @@ class Seq2SeqAgent(BaseAgent):
                 batch.load(nxt, nhost)
                 replay()
                 self._rollout_inflight = (key, nxt, versions)
-            except RuntimeError:
+            except WeightsMoved:
                 self._rollout_ahead = (nav, nxt, nhost)
         done.synchronize()
         rows, views, acts, sc, loss = (p_.numpy().copy() for p_ in pinned)
@@ -596,6 +596,7 @@ class Seq2SeqAgent(BaseAgent):
                 items, host = ahead
                 ahead = None
             before = [o.host_steps() for o in opts]
+            where = (eng.site_next, eng.iteration)            # the dropout / sample sites this iteration starts at
             if cached is not None and (cached[0] != key or cached[2].batch_size != len(items)):
                 cached = None
             if cached is None:
@@ -623,6 +624,7 @@ class Seq2SeqAgent(BaseAgent):
                 for o, b in zip(opts, before):
                     o.set_host_steps(b)
                     o.zero_grad()
+                eng.site_next, eng.iteration = where          # (the re-issue draws the masks / samples the replay drew)
                 keep = getattr(self.encoder, 'persistent', True)
                 self.encoder.persistent = False
                 try:
@@ -652,11 +654,14 @@ class Seq2SeqAgent(BaseAgent):
         import collections
         from .runtime import take_fault, fault_views
         _, tg, batch = cached
-        n_words = len(fault_views(dev))
-        pins = self.__dict__.get('_train_pins')
-        if pins is None or pins[0][1].numel() != n_words:
-            pins = self._train_pins = [(torch.empty(1, dtype=torch.float32).pin_memory(),
-                                        torch.empty(n_words, dtype=torch.int32).pin_memory()) for _ in range(2)]
+        def pins_for(n_words):
+            # (one fault word per workspace; a workspace created later -- a side stream of the per-step fallback --
+            # makes the list longer: the pinned pair is re-made to match)
+            pins = self.__dict__.get('_train_pins')
+            if pins is None or pins[0][1].numel() != n_words:
+                pins = self._train_pins = [(torch.empty(1, dtype=torch.float32).pin_memory(),
+                                            torch.empty(n_words, dtype=torch.int32).pin_memory()) for _ in range(2)]
+            return pins
         todo = collections.deque()     # minibatches drawn and not issued yet: (items, host arrays or None)
         drawn = issued = 0
         if first is not None:          # (what the serial loop had already drawn for its next iteration)
@@ -676,26 +681,31 @@ class Seq2SeqAgent(BaseAgent):
                 if not todo:
                     draw()
                 items, host = todo.popleft()
-                before = [o.host_steps() for o in opts]
+                before = ([o.host_steps() for o in opts], eng.site_next, eng.iteration)
                 batch.load(items, host)
                 st = tg.replay()
                 slot = issued & 1
-                pins[slot][0].copy_(st.loss_buf.reshape(1), non_blocking=True)
                 views = fault_views(dev)
+                if flight is not None and flight[4][0][1].numel() != len(views):
+                    flight[1].synchronize()                   # (the pair in flight is read before it is replaced)
+                pins = pins_for(len(views))
+                pins[slot][0].copy_(st.loss_buf.reshape(1), non_blocking=True)
                 pins[slot][1].copy_(torch.cat(views) if len(views) > 1 else views[0], non_blocking=True)
                 ev = torch.cuda.Event()
                 ev.record()
-                cur = (slot, ev, before, items)
+                cur = (slot, ev, before, items, pins)
                 issued += 1
             if flight is not None:
-                slot, ev, before_f, items_f = flight
+                slot, ev, before_f, items_f, pins = flight
                 ev.synchronize()
                 if any(pins[slot][1].tolist()):
                     torch.cuda.synchronize(dev)               # (the replay queued behind it did nothing either)
                     take_fault(dev)
-                    for o, b in zip(opts, before_f):
+                    for o, b in zip(opts, before_f[0]):
                         o.set_host_steps(b)
                         o.zero_grad()
+                    # the same sites too: the faulted replay and the one queued behind it advanced the host mirrors
+                    eng.site_next, eng.iteration = before_f[1], before_f[2]
                     batch.load(items_f)
                     keep = getattr(self.encoder, 'persistent', True)
                     self.encoder.persistent = False

@@ -120,7 +120,9 @@ struct Dropout {            // p == 0 (thresh == 0) means "eval mode": everythin
 const uint32_t* site_zero();        // a device word that holds 0 (sf_pointwise.hip)
 
 // key of (seed, stream + mul * *site, row): seed + G * (stream + off) == (seed + G * off) + G * stream
-__device__ __forceinline__ uint32_t drop_seed(const Dropout& d) { return d.seed + 0x9E3779B9u * (d.site_mul * *d.site); }
+// (a null site pointer reads as site 0: site_zero() returns null when the symbol lookup failed on this device)
+__device__ __forceinline__ uint32_t site_value(const uint32_t* p) { return p ? *p : 0u; }
+__device__ __forceinline__ uint32_t drop_seed(const Dropout& d) { return d.seed + 0x9E3779B9u * (d.site_mul * site_value(d.site)); }
 __device__ __forceinline__ uint32_t drop_key(const Dropout& d, uint32_t row) {
     return dropout_row_key(drop_seed(d), d.stream, row);
 }

@@ -125,7 +125,7 @@ __device__ __forceinline__ int follower_glue_row(const FGlue& g, int b, float ra
         // follower.py:491-497: sample from softmax(logit) (invalid candidates have probability 0).
         // Inverse CDF over <= 64 lanes with a counter-based uniform (the reference's torch RNG
         // stream cannot be reproduced; parity is defined on teacher / argmax).
-        const uint32_t key = dropout_row_key(g.sample_seed + 0x9E3779B9u * *g.sample_site, g.sample_stream, (uint32_t)(g.row0 + b));
+        const uint32_t key = dropout_row_key(g.sample_seed + 0x9E3779B9u * site_value(g.sample_site), g.sample_stream, (uint32_t)(g.row0 + b));
         const float u = (float)(fmix32(key) >> 8) * (1.0f / 16777216.0f) * se;
         float cdf = e;                                           // inclusive prefix sum over lanes
 #pragma unroll

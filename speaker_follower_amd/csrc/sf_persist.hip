@@ -950,7 +950,7 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
                 // word falls into its 32 columns (second uniform of the row); which workgroup's draw counts is
                 // decided in phase H from the first uniform and the published masses (sf_sampling.h)
                 float u1, u2;
-                sample_uniforms(p.sample_seed + 0x9E3779B9u * *p.sample_site, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
+                sample_uniforms(p.sample_seed + 0x9E3779B9u * site_value(p.sample_site), p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
                 const int it = row16_pick32(e0, e1, u2 * se, eu);
                 const int sc_ = it != 0x7FFFFFFF ? 32 * slot + it : min(32 * slot + 31, vocab - 1);
                 const float sl_ = row16_sum((sc_ == col0 ? l0 : 0.f) + (sc_ == col1 ? l1 : 0.f));
@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256, 1) void spk_persist_kernel(SpkPersistArgs p) {
             if (sampling) {
                 // which workgroup's draw counts: inverse CDF over the 32 masses z_s exp(m_s - M) with the row's first uniform
                 float u1, u2;
-                sample_uniforms(p.sample_seed + 0x9E3779B9u * *p.sample_site, p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
+                sample_uniforms(p.sample_seed + 0x9E3779B9u * site_value(p.sample_site), p.sample_stream + (uint32_t)t, (uint32_t)(p.sample_row0 + eb), &u1, &u2);
                 int cs = row16_pick32(z0 * wexp(m0, M), z1 * wexp(m1, M), u1 * Z, eu);
                 if (cs == 0x7FFFFFFF) cs = arg >> 5;                                 // u1 Z rounded up to the total
                 const unsigned qc = (cs & 16) ? q1c : q0c, ql = (cs & 16) ? q1l : q0l;

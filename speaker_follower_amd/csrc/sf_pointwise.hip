@@ -1,5 +1,6 @@
 // Streaming (HBM-bound) kernels of the path: LSTM gate math, dropout, gathers from the feature
 // table, the follower/speaker per-step glue, and the small vector helpers the backward needs.
+#include <atomic>
 #include "sf_kernels.h"
 
 #include <algorithm>
@@ -531,7 +532,7 @@ __device__ __forceinline__ int speaker_sample_row(const SGlue& g, const float* r
     const float so = __shfl_xor(sl, 1, WAVE);
     const float zs = (lane & 1) ? so + sl : sl + so;
     float u1, u2;
-    sample_uniforms(g.sample_seed + 0x9E3779B9u * *g.sample_site, g.sample_stream, (uint32_t)(g.sample_row0 + b), &u1, &u2);
+    sample_uniforms(g.sample_seed + 0x9E3779B9u * site_value(g.sample_site), g.sample_stream, (uint32_t)(g.sample_row0 + b), &u1, &u2);
     // level 2: this slot's column
     const float thr2 = u2 * zs;
     float cum = (lane & 1) ? so : 0.f;
@@ -912,12 +913,22 @@ int flag_set(unsigned* flag, unsigned value, hipStream_t st) {
 // ---- device-side site counters (include/sf_hip.h: sf_dropout.site_dev, sf_site_advance) -----------------------------
 __device__ uint32_t g_site_zero_word = 0;
 const uint32_t* site_zero() {
-    static const uint32_t* p = [] {
-        void* q = nullptr;
-        (void)hipGetSymbolAddress(&q, HIP_SYMBOL(g_site_zero_word));
-        return static_cast<const uint32_t*>(q);
-    }();
-    return p;
+    // the symbol has one address PER DEVICE: cached by the current device's ordinal (a process that drives several
+    // GPUs must not hand device 0's word to a kernel on device 1).  A failed lookup yields null, which the kernels read
+    // as site 0 (site_value) -- never a wild pointer.
+    constexpr int kMaxDev = 64;
+    static std::atomic<const uint32_t*> cache[kMaxDev];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDev) return nullptr;
+    const uint32_t* p = cache[dev].load(std::memory_order_acquire);
+    if (p) return p;
+    void* q = nullptr;
+    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_site_zero_word)) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    cache[dev].store(static_cast<const uint32_t*>(q), std::memory_order_release);
+    return static_cast<const uint32_t*>(q);
 }
 __global__ void site_advance_kernel(uint32_t* word, uint32_t by) {
     if (threadIdx.x == 0) *word += by;

@@ -142,7 +142,9 @@ class BucketedGrads(FlatGrads):
     def wait(self):
         if sorted(self.launched) != list(range(self.n_buckets)):
             missing = sorted(set(range(self.n_buckets)) - set(self.launched))
-            self.launched = []
+            # refuse -- but never with a collective still in flight: whoever catches this owns a QUIESCENT buffer
+            # (every rank launched the same buckets, so the waits complete)
+            self.abort()
             raise RuntimeError('gradient buckets %s were never launched: the backward did not run to the end' % missing)
         for w in self._works:
             w.wait()

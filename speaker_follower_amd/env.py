@@ -309,8 +309,10 @@ class R2RIndexEnv:
         consulted without waking the simulator."""
         hit = self._pano.get((ws.scanId, ws.viewpointId, view)) if view is not None else None
         view, adj = hit if hit is not None else self.panorama(ws)
+        # heading / elevation are the SIMULATOR's (env.py:783-784: state.heading after newEpisode snapped the pose to the
+        # discrete view, MatterSim.cpp:339-367), not the world state's: an item's start heading is continuous
         ob = dict(instr_id=item['instr_id'], scan=ws.scanId, viewpoint=ws.viewpointId,
-                  viewIndex=view, heading=ws.heading, elevation=ws.elevation,
+                  viewIndex=view, heading=(view % 12) * ANGLE_INC, elevation=(view // 12 - 1) * ANGLE_INC,
                   adj_loc_list=adj, vp_row=self.row_of[ws.scanId + '_' + ws.viewpointId],
                   instr_encoding=item['instr_encoding'], instructions=item.get('instructions', ''))
         if include_teacher:

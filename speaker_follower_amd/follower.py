@@ -22,7 +22,7 @@ from ._lib import call
 from .features import cand_sincos
 from .model import (decoder_params, decoder_w_struct, decoder_fold, _encoder_structs, _TAPE_KEYS,
                     grad_ptr, trainable_embedding)
-from .runtime import ptr, stream, ws_args, wgrad_ws_args, ensure_workspace, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream, graph_capture
+from .runtime import ptr, stream, ws_args, wgrad_ws_args, ensure_workspace, dropout_arg, fill_regions, take_fault, PersistentLaunchFault, concurrent_stream, graph_capture, WeightsMoved
 from .dp import collectives_on
 
 byref = C.byref
@@ -457,7 +457,7 @@ class FollowerEngine:
             # rebuilt in place here, ahead of the replay on the same stream, so the graph reads current
             # data everywhere.  A MOVED tensor cannot be patched into the graph: refuse.
             if self._baked_pointers() != baked:
-                raise RuntimeError('a weight (or one of its cached layouts) moved since this rollout was '
+                raise WeightsMoved('a weight (or one of its cached layouts) moved since this rollout was '
                                    'captured; capture() again')
             graph_replay()
         return replay

@@ -143,10 +143,9 @@ class StateSpace:
         it = self.items[b]
         view = s % V
         scan = it['scan']
-        if sp:
-            vp, heading, elevation = it['path'][0], it['heading'], 0
-        else:
-            vp, heading, elevation = nav.vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC
+        # (the observation carries the simulator's snapped pose, env.py:783-784 -- for the start pose too; only the WORLD
+        # STATE of the start keeps the item's continuous heading, world_state())
+        vp, heading, elevation = nav.vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC
         hit = env._pano.get((scan, vp, view))
         if hit is None:                                             # the candidate list from the tables, not a sweep
             hit = env._pano[(scan, vp, view)] = (view, nav.adj_loc_list(s))
@@ -258,14 +257,10 @@ class _Routes:
 
     def trajectory(self, i):
         """(viewpoint, heading, elevation) per state (follower.py:700): the pose fields of `observations`, without them."""
-        items, vp_of, out = self.space.items, self.space.nav.vp_of, []
+        vp_of, out = self.space.nav.vp_of, []
         for b, s, p in self.states(i):
-            if p:
-                it = items[b]
-                out.append((it['path'][0], it['heading'], 0))
-            else:
-                view = s % V
-                out.append((vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC))
+            view = s % V
+            out.append((vp_of[s // V][1], (view % 12) * ANGLE_INC, (view // 12 - 1) * ANGLE_INC))
         return out
 
 

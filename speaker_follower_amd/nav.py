@@ -276,10 +276,19 @@ class DeviceNavBatch:
         h = host if host is not None else self._host_arrays(items)
         self.items, self.lengths = items, h['lengths'].tolist()
         if getattr(self, '_pack_dev', None) is not None:
-            # (the previous minibatch's copy has completed: its iteration's loss was read since)
+            # ONE pinned mirror, rewritten per minibatch: the previous asynchronous copy OUT of it must have completed
+            # before the host writes it again.  Nothing in the pipelined training loop guarantees that by itself (the
+            # copy is queued behind the previous replay; the host runs ahead of the device), so the copy is followed
+            # by an event and the next load waits on it -- normally long reached, then the wait costs nothing.
+            ev = getattr(self, '_pack_copied', None)
+            if ev is not None:
+                ev.synchronize()
             for key, dst in self._pack_np.items():
                 np.copyto(dst, h[key], casting='same_kind')
             self._pack_dev.copy_(self._pack_host, non_blocking=True)
+            if ev is None:
+                ev = self._pack_copied = torch.cuda.Event()
+            ev.record()
             return
         for attr, key in self._LOADED:
             getattr(self, attr).copy_(torch.from_numpy(h[key]))
@@ -325,33 +334,29 @@ class DeviceNavBatch:
         stopped = acts[:S] == 0
         n = np.where(stopped.any(0), stopped.argmax(0) + 1, S)                  # steps up to and including the stop action
         totals = np.cumsum(sc[:S], axis=0, dtype=np.float32)                    # (sequential float32 sums, as the loop's)
-        # still in the start pose at slot t (its heading is the item's, not a discrete view's)
-        moved = np.cumsum((rows != rows[0]) | (views != views[0]), axis=0) > 0
         acts_t, sc_t = np.ascontiguousarray(acts[:S].T), np.ascontiguousarray(sc[:S].T)
         last = totals[n - 1, np.arange(B)].tolist()
-        return [_Trajectory(self.nav, it, int(n[b]), acts_t[b], sc_t[b], last[b], rows[:, b], views[:, b], moved[:, b])
+        return [_Trajectory(self.nav, it, int(n[b]), acts_t[b], sc_t[b], last[b], rows[:, b], views[:, b])
                 for b, it in enumerate(items)]
 
 
 class _Trajectory(LazyDict):
     """One result of a device rollout: 'instr_id', 'actions', 'scores', 'score' are there, 'trajectory' is made on demand."""
-    __slots__ = ('_nav', '_it', '_n', '_rows', '_views', '_moved')
+    __slots__ = ('_nav', '_it', '_n', '_rows', '_views')
 
-    def __init__(self, nav, it, n, acts, sc, score, rows, views, moved):
+    def __init__(self, nav, it, n, acts, sc, score, rows, views):
         LazyDict.__init__(self, {'instr_id': it['instr_id'], 'actions': acts[:n].tolist(), 'scores': sc[:n].tolist(),
                                  'score': score}, ('trajectory',))
-        self._nav, self._it, self._n, self._rows, self._views, self._moved = nav, it, n, rows, views, moved
+        self._nav, self._it, self._n, self._rows, self._views = nav, it, n, rows, views
 
     def _make(self, key):
-        vp_of, heading = self._nav.vp_of, self._it['heading']
+        # (vp, heading, elevation) of every observation on the way: the SNAPPED pose of the simulator state (env.py:783-784),
+        # for the start pose too -- an item's continuous start heading never appears in a result
+        vp_of = self._nav.vp_of
         out = []
         for t in range(self._n + 1):
-            vp = vp_of[self._rows[t]][1]
-            if not self._moved[t]:
-                out.append((vp, heading, 0))
-            else:
-                v = int(self._views[t])
-                out.append((vp, (v % 12) * ANGLE_INC, (v // 12 - 1) * ANGLE_INC))
+            v = int(self._views[t])
+            out.append((vp_of[self._rows[t]][1], (v % 12) * ANGLE_INC, (v // 12 - 1) * ANGLE_INC))
         return out
 
 

@@ -135,14 +135,23 @@ class FusedAdam(torch.optim.Optimizer):
         """words: device int32 tensor views, one per live parameter group (None: back to host-side counters)."""
         live = self.live_groups()
         if words is None:
+            # back to host-side counters.  The `coef` scratch STAYS allocated for the life of the optimizer: its address
+            # is a frozen kernel argument of every graph captured while it was bound, and each replay of such a graph
+            # writes and reads it -- handing the block back to the caching allocator here would let any later small
+            # tensor land under those writes (advisor, round 5)
             for f in live:
-                f['step_dev'] = f['coef'] = None
+                f['step_dev'] = None
             return
         assert len(words) == len(live)
         for f, w in zip(live, words):
             f['step_dev'] = _lib.C.c_void_p(w.data_ptr())
-            f['coef'] = torch.zeros(4, dtype=torch.float32, device=f['p'].device)
+            if f['coef'] is None:
+                f['coef'] = torch.zeros(4, dtype=torch.float32, device=f['p'].device)
             f['step_word'] = w
+
+    def device_scratch(self):
+        """Tensors whose addresses are baked into a graph captured under bind_device_steps (a TrainingGraph keeps them)."""
+        return [f['coef'] for f in self.live_groups() if f['coef'] is not None]
 
     def host_steps(self):
         return [f['step'] for f in self.live_groups()]

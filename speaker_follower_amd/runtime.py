@@ -200,6 +200,12 @@ class strict_gate_product:
 FAULT_ENC_FWD, FAULT_ENC_BWD, FAULT_SPEAKER, FAULT_LOCK = 1, 2, 4, 8
 
 
+class WeightsMoved(RuntimeError):
+    """A captured pass refuses to replay: a weight tensor (or one of its cached derived layouts) was re-allocated since
+    the capture, and an address cannot be patched into a graph.  Callers that can re-capture catch THIS type -- a
+    HIP launch or graph error surfaced by torch is a plain RuntimeError and must not be mistaken for it."""
+
+
 class PersistentLaunchFault(RuntimeError):
     """A persistent launch gave up a bounded wait (its outputs are NaN-poisoned) and the per-step re-issue
     failed as well, or no re-issue was possible."""
@@ -302,6 +308,8 @@ class TrainingGraph:
             n = len(o.live_groups())
             o.bind_device_steps([self.ctl[k + i:k + i + 1] for i in range(n)])
             k += n
+        # every device block whose ADDRESS the captured launches carry lives as long as the graph does
+        self._scratch = [t for o in self.optimizers for t in o.device_scratch()]
         engine.site_word = self.ctl[0:1]
         self.stream = torch.cuda.Stream(device=device)
         cur = torch.cuda.current_stream(device)

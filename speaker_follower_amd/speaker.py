@@ -19,7 +19,7 @@ from ._lib import call
 from .features import cand_sincos
 from .follower import batch_instructions_from_encoded, FEEDBACK, PAD, EOS, BOS
 from .model import _grads, trainable_embedding
-from .runtime import ptr, stream, ws_args, ensure_workspace, dropout_arg, fill_regions, visual_query_fold, struct_of, transposed, take_fault, PersistentLaunchFault, graph_capture
+from .runtime import ptr, stream, ws_args, ensure_workspace, dropout_arg, fill_regions, visual_query_fold, struct_of, transposed, take_fault, PersistentLaunchFault, graph_capture, WeightsMoved
 
 byref = C.byref
 
@@ -154,7 +154,7 @@ class SpeakerEngine:
             # the [vocab,4H] input-product table is refreshed in place when the weights changed; a
             # re-allocated weight cannot be patched into the graph (FollowerEngine.capture)
             if bytes(self.decoder._w_struct()) != baked:
-                raise RuntimeError('a speaker weight moved since this pass was captured; capture() again')
+                raise WeightsMoved('a speaker weight moved since this pass was captured; capture() again')
             # (the encoder's derived layouts likewise: transposed copies and the float64 query fold are rebuilt IN PLACE
             # when a weight's version moved -- the graph reads the same buffers)
             ep_ = self.encoder._params8()

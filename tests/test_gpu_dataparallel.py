@@ -199,13 +199,13 @@ def test_dropout_sites_do_not_collide_for_long_rollouts():
     assert a.site0 == 0 and b.site0 == 72 and c.site0 == 72 + 64
 
 
-def test_bench_two_ranks_on_one_gpu_over_gloo():
+def test_bench_two_ranks_on_one_gpu_over_gloo(tmp_path):
     """The N > 1 code path of bench.py end to end -- self-launch, rendezvous, weak-scaling rollout,
     data-parallel training iteration with the flat gradient all-reduce, one JSON line from rank 0 --
     with both ranks sharing this box's single GPU and gloo standing in for RCCL."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-gpu',
                           '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--n-viewpoints', '96',
-                          '--batch', '16', '--decode-steps', '5'],
+                          '--batch', '16', '--decode-steps', '5', '--extras-out', str(tmp_path / 'x.json')],
                          capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
     assert out.returncode == 0, out.stderr[-3000:]
@@ -215,7 +215,11 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 32 and d['config']['parallelism'] == 'dp2'
     assert d['scaling'] == 'weak' and 'oversubscribed' in d
     assert abs(d['value'] - 2 * 16 * 5 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
-    t = d['train_dp']
+    # the line is compact (the driver holds a few KB): scalars of the data-parallel iteration only; the full object is
+    # in the extras file
+    assert len(lines[0]) < 4096 and d['train_dp']['allreduce_ms'] > 0 and d['train_dp']['faults'] == 0
+    assert d['train_dp']['strong']['global_batch'] == 16
+    t = json.load(open(tmp_path / 'x.json'))['train_dp']
     assert t['allreduce_ms'] > 0 and t['allreduce_bytes'] == 4 * 14059265 and np.isfinite(t['loss'])
     # the bucketed schedule: decoder LSTM (weight_ih, weight_hh, two biases), other decoder weights, encoder
     assert t['buckets_bytes'] == [4 * (2048 * 4352 + 2048 * 512 + 4096), 4 * (12129537 - 2048 * 4864 - 4096), 4 * 1929728]
@@ -228,16 +232,18 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
     assert ts['health']['persistent_launch_faults'] == [0, 0] and np.isfinite(ts['loss'])
 
 
-def test_bench_strong_scaling_two_ranks_on_one_gpu_over_gloo():
+def test_bench_strong_scaling_two_ranks_on_one_gpu_over_gloo(tmp_path):
     """`--scaling strong`: the headline loop itself over ONE global batch split with dp.shard_rows."""
     out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--share-gpu',
                           '--backend', 'gloo', '--steps', '2', '--warmup', '1', '--n-viewpoints', '96',
-                          '--batch', '18', '--decode-steps', '5', '--scaling', 'strong', '--no-cpu-baseline'],
+                          '--batch', '18', '--decode-steps', '5', '--scaling', 'strong', '--no-cpu-baseline',
+                          '--extras-out', str(tmp_path / 'x.json')],
                          capture_output=True, text=True, timeout=900, cwd=ROOT,
                          env={k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK')})
     assert out.returncode == 0, out.stderr[-3000:]
     d = json.loads([l for l in out.stdout.splitlines() if l.startswith('{')][-1])
     assert d['scaling'] == 'strong' and d['n_gpus'] == 2 and d['config']['global_batch'] == 18
     assert abs(d['value'] - 18 * 5 / (d['ms_per_step'] * 1e-3)) < 1e-3 * d['value']
-    t = d['train_dp']
+    assert d['train_dp']['scaling'] == 'strong' and d['train_dp']['global_batch'] == 18
+    t = json.load(open(tmp_path / 'x.json'))['train_dp']
     assert t['scaling'] == 'strong' and t['global_batch'] == 18 and t['rows_this_rank'] == 9 and 'strong' not in t

@@ -41,13 +41,15 @@ def test_rccl_one_rank_training_iteration_is_bit_identical_to_no_collectives():
     assert f['grad_rel_diff'] <= 1e-4, f
 
 
-def test_bench_force_collectives_reports_train_dp():
+def test_bench_force_collectives_reports_train_dp(tmp_path):
     cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--backend', 'nccl', '--force-collectives',
-           '--steps', '3', '--warmup', '2', '--n-viewpoints', '512', '--no-extras', '--no-cpu-baseline']
+           '--steps', '3', '--warmup', '2', '--n-viewpoints', '512', '--no-extras', '--no-cpu-baseline',
+           '--extras-out', str(tmp_path / 'x.json')]
     res = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=900)
     assert res.returncode == 0, res.stdout[-2000:] + res.stderr[-4000:]
     out = json.loads([l for l in res.stdout.splitlines() if l.startswith('{')][-1])
-    td = out['train_dp']
+    assert out['train_dp']['ms_per_iteration'] > 0 and out['train_dp']['allreduce_bytes'] > 50e6      # the compact line
+    td = json.load(open(tmp_path / 'x.json'))['train_dp']
     assert 'forced_collectives' in td and td['allreduce_bytes'] > 50e6
     assert td['allreduce_total_ms_blocking'] > 0 and td['ms_per_iteration'] > 0
     assert out['persistent_launch_faults'] == 0

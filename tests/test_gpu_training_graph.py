@@ -245,3 +245,36 @@ def test_guarded_adam_step_skips_while_the_fault_word_is_set():
     finally:
         fw.zero_()
     assert int(word) == 4 and torch.equal(p[0].detach(), q[0].detach())
+
+
+def test_small_tensors_allocated_after_the_capture_survive_replays():
+    """Advisor, round 5: the optimizers' `coef` scratch is a frozen kernel argument of the captured Adam launches.  It
+    must stay allocated as long as the graph: blocks handed out by the caching allocator AFTER the capture may never
+    lie under the words each replay writes, and the replays must keep stepping with their own coefficients."""
+    from speaker_follower_amd import features, follower as fol, optim
+    B, S, NVP = 16, 4, 64
+    fb = synth.follower_batch(seed=4, batch=B, steps=S, n_viewpoints=NVP, min_len=6, max_len=20)
+    store = features.FeatureStore(synth.feature_table(4, NVP))
+    batch = fol.DeviceFollowerBatch.from_synth(fb)
+    enc, dec = _follower()
+    oe = optim.FusedAdam([p for p in enc.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-4)
+    od = optim.FusedAdam([p for p in dec.parameters() if p.requires_grad], lr=1e-3, weight_decay=5e-4)
+    eng = fol.FollowerEngine(enc, dec, store)
+    tg = eng.capture_training(batch, S, 'teacher', optimizers=(oe, od))
+    scratch = [t for o in (oe, od) for t in o.device_scratch()]
+    assert len(scratch) == 2 and all(t is not None for t in scratch)          # still owned after the capture ended
+    held = {t.data_ptr() for t in scratch}
+    torch.cuda.synchronize()
+    # many small blocks of the size class the scratch came from: none may alias it
+    small = [torch.full((4,), float(i), device='cuda') for i in range(4096)]
+    assert not held & {t.data_ptr() for t in small}
+    w0 = _weights((enc, dec))
+    for _ in range(3):
+        tg.replay()
+    torch.cuda.synchronize()
+    got = torch.stack(small)
+    assert torch.equal(got, torch.arange(4096, device='cuda', dtype=torch.float32)[:, None].expand(4096, 4))
+    w3 = _weights((enc, dec))
+    assert torch.isfinite(w3).all() and float((w3 - w0).abs().max()) > 0          # the replays stepped
+    # the step sizes the replays used are Adam's for steps 2..4 (bias corrections of THIS optimizer): |dw| <= lr * ~1
+    assert float((w3 - w0).abs().max()) < 3 * 1e-3 * 1.5

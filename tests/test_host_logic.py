@@ -182,14 +182,24 @@ def _bucket_worker(rank, world, port, out):
         bk.launch(b)
     bk.wait()
     one.allreduce()
+    reduced = bk.flat.clone()                 # (snapshot BEFORE the refusal stage below reduces bucket 0 a second time)
     again = None
     try:
         bk.launch(0)
         bk.wait()                             # buckets 1, 2 never launched: the optimizer must not run
     except RuntimeError as e:
         again = 'never launched' in str(e)
-    out[rank] = (bk.flat.clone(), one.flat.clone(), bk.bounds, bk.attached(), again,
-                 dec_lstm.weight.grad.data_ptr() == bk.flat.data_ptr())
+    # the refusal left nothing in flight: the buffer is quiescent and holds exactly one more reduction of bucket 0
+    quiet = (bk._works == [] and bk.launched == [])
+    lo, hi = bk.bounds[0]
+    expect = reduced.clone()
+    expect[lo:hi] *= world
+    quiet = quiet and torch.equal(bk.flat, expect)
+    for b in range(bk.n_buckets):             # ... and the object is usable again
+        bk.launch(b)
+    bk.wait()
+    out[rank] = (reduced, one.flat.clone(), bk.bounds, bk.attached(), again,
+                 dec_lstm.weight.grad.data_ptr() == bk.flat.data_ptr(), quiet)
     dist.destroy_process_group()
 
 
@@ -202,11 +212,81 @@ def test_bucketed_gradient_allreduce_equals_single_buffer_gloo_world2():
     out = mp.Manager().dict()
     _spawn_world(_bucket_worker, world, out)
     for r in range(world):
-        bucketed, single, bounds, attached, refused, first = out[r]
+        bucketed, single, bounds, attached, refused, first, quiet = out[r]
         assert torch.equal(bucketed, single)
         assert bounds == [(0, 54), (54, 72), (72, 82)]            # 8*6+6 | 5*3+3 | 4*2+2
-        assert attached and refused and first
+        assert attached and refused and first and quiet
     assert torch.equal(out[0][0], out[1][0])
+
+
+def _uneven_worker(rank, world, port, out):
+    """SURVEY 8(e) end to end on the host: ONE global batch of 100 rows split with dp.shard_rows (uneven: 100 = 8 x 12 + 4),
+    the per-step (CE sum, live count) table all-reduced, every rank's loss scaled by the GLOBAL count, gradients summed
+    through the production-order buckets.  The result must be the gradient of the unsharded batch's loss
+    (follower.py:278, 481: per-step mean over the non-ignored rows of the whole batch, summed over steps)."""
+    import torch.distributed as dist
+    import torch.nn.functional as Fn
+    from speaker_follower_amd import dp
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    B, S, A, F = 100, 6, 5, 7
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(S, B, F, generator=g)
+    target = torch.randint(0, A, (S, B), generator=g)
+    ended = torch.rand(S, B, generator=g) < torch.linspace(0.0, 0.8, S)[:, None]
+    ended[3, :] = True                                            # a step with NO live row anywhere: contributes 0
+    ended[3 + 1:, :13] = False
+    target = torch.where(ended, torch.full_like(target, -1), target)
+    torch.manual_seed(3)
+    m1, m2, m3 = torch.nn.Linear(F, 9), torch.nn.Linear(9, A), torch.nn.Linear(F, A)
+
+    def terms(rows):
+        h = torch.tanh(m1(x[:, rows]))
+        logit = m2(h) + m3(x[:, rows])
+        ce = Fn.cross_entropy(logit.reshape(-1, A), target[:, rows].reshape(-1), ignore_index=-1, reduction='none')
+        return ce.reshape(S, -1).sum(1), (target[:, rows] >= 0).sum(1).to(torch.float32)
+
+    params = [p for m in (m1, m2, m3) for p in m.parameters()]
+    # the unsharded reference: follower.py's loss on all 100 rows
+    s_all, c_all = terms(slice(0, B))
+    live = c_all > 0
+    full = (s_all[live] / c_all[live]).sum()
+    want = torch.autograd.grad(full, params)
+    # this rank's shard
+    rows = dp.shard_rows(B, rank, world)
+    bk = dp.BucketedGrads([list(m.parameters()) for m in (m2, m3, m1)])
+    s_r, c_r = terms(rows)
+    table = torch.stack([s_r.detach(), c_r], 1)
+    dp.allreduce_step_counts(table)
+    loss, gscale = dp.step_losses(table)
+    mine = torch.autograd.grad((s_r * gscale).sum(), params)
+    for p, gp in zip(params, mine):
+        p.grad += gp                                               # in place, into the bucket buffer
+    for b in range(bk.n_buckets):
+        bk.launch(b)
+    bk.wait()
+    err = max(float((p.grad - w).abs().max()) / float(w.abs().max()) for p, w in zip(params, want))
+    out[rank] = (rows.start, rows.stop, float(loss), float(full), err, table[:, 1].tolist(), c_all.tolist())
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [4, 8])
+def test_uneven_row_shards_give_the_unsharded_gradient_gloo(world):
+    import torch.multiprocessing as mp
+    out = mp.Manager().dict()
+    _spawn_world(_uneven_worker, world, out)
+    covered = []
+    for r in range(world):
+        lo, hi, loss, full, err, counts, c_all = out[r]
+        covered += list(range(lo, hi))
+        assert abs(loss - full) <= 2e-6 * abs(full)               # every rank holds the GLOBAL loss
+        assert err <= 2e-5                                         # (fp32 sums in a different order)
+        assert counts == c_all and counts[3] == 0.0
+    assert covered == list(range(100))                             # contiguous, disjoint, complete
+    sizes = [out[r][1] - out[r][0] for r in range(world)]
+    assert max(sizes) - min(sizes) <= (1 if 100 % world else 0)
 
 
 def test_feature_store_reads_reference_tsv_format(tmp_path):
