@@ -413,8 +413,21 @@ def kernel_work(name, B, S, T, A_mean, dims):
     return (None, None, '')
 
 
-def roofline_table(prof_rows, n_rollouts, B, S, T, A_mean, dims, pmc):
+def mfma_counters(workload='rollout'):
+    """{kernel name: matrix-pipe busy cycles per SIMD per dispatch} from the committed rocprofv3 --pmc pass
+    (profiles/pmc_mfma.json <- profiles/r06_a_mfma_counters.txt; tools/pmc_mfma.sh).  OFFLINE constants of the batch-100
+    default workload; divided by a launch time measured in THIS run they give `mfma_busy_frac`."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_mfma.json')
+    if not os.path.exists(path):
+        return {}, 2.4
+    d = json.load(open(path))
+    return ({k: v[workload]['mfma_busy_cycles_per_simd'] for k, v in d['kernels'].items() if workload in v},
+            float(d.get('clock_ghz', 2.4)))
+
+
+def roofline_table(prof_rows, n_rollouts, B, S, T, A_mean, dims, pmc, busy=None, clock_ghz=2.4):
     """Top kernels of the profiled eager rollouts, each priced against both ceilings."""
+    busy = busy or {}
     total = sum(r['total_us'] for r in prof_rows.values())
     out = []
     for name, r in sorted(prof_rows.items(), key=lambda kv: -kv[1]['total_us']):
@@ -436,6 +449,11 @@ def roofline_table(prof_rows, n_rollouts, B, S, T, A_mean, dims, pmc):
         for key, v in pmc.items():
             if key in name:
                 row['traffic_offline_pmc'] = v
+        for key, cyc in busy.items():
+            if name == key:
+                # SQ_VALU_MFMA_BUSY_CYCLES per SIMD (counter, offline) / this run's launch time in shader cycles
+                row['mfma_busy_frac'] = cyc / (r['avg_us'] * 1e-6 * clock_ghz * 1e9)
+                row['mfma_busy_cycles_per_simd'] = cyc
         out.append(row)
     return out, total
 
@@ -837,7 +855,8 @@ def main(argv=None):
     pmc_path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(pmc_path) and B == 100:
         pmc = json.load(open(pmc_path))['hbm_bytes_per_launch']
-    kernels, kernel_us = roofline_table(prof.rows, n_prof, B, S, T, A_mean, (H, F, D, 36), pmc)
+    busy, ghz = mfma_counters('rollout') if B == 100 else ({}, 2.4)
+    kernels, kernel_us = roofline_table(prof.rows, n_prof, B, S, T, A_mean, (H, F, D, 36), pmc, busy, ghz)
     priced = [k for k in kernels if 'tflops' in k]
     top = priced[0]
     bound = 'mfma' if top['mfma_frac'] >= top['hbm_frac'] else 'hbm'
@@ -853,7 +872,7 @@ def main(argv=None):
                % (top['kernel'], top['what'], 100 * top['share']),
         launch_us=top['avg_us'], flops_per_launch=top['flops_per_launch'],
         bytes_per_launch=top['bytes_per_launch'],
-        mfma_frac=top['mfma_frac'], hbm_frac=top['hbm_frac'],
+        mfma_frac=top['mfma_frac'], hbm_frac=top['hbm_frac'], mfma_busy_frac=top.get('mfma_busy_frac'),
         executed=top.get('executed'),
         kernels=kernels[:8],
         kernel_time_ms_per_rollout=1e-3 * kernel_us / n_prof,
