@@ -28,13 +28,17 @@ def load_env_golden():
     return json.load(gzip.open(os.path.join(GOLDEN, 'g15_env_reference.json.gz'), 'rt'))
 
 
-def build_env(items, batch_size=100, host_table=None, table_seed=None):
-    """env.R2RIndexEnv over the items' scans; feature rows = the included viewpoints of those scans, scan by scan
-    (sorted), in connectivity-file order.  Returns (env, row_of, n_rows)."""
+def load_sr_golden():
+    return json.load(gzip.open(os.path.join(GOLDEN, 'g10b_val_seen_eval.json.gz'), 'rt'))
+
+
+def build_env(items, batch_size=100, host_table=None, table_seed=None, scans=None):
+    """env.R2RIndexEnv over `scans` (default: the items' scans); feature rows = the included viewpoints of those scans,
+    scan by scan (sorted), in connectivity-file order.  Returns (env, row_of, n_rows)."""
     from speaker_follower_amd.build import build_sim
     build_sim(verbose=False)
     from speaker_follower_amd import env, nav_data
-    scans = sorted({it['scan'] for it in items})
+    scans = sorted(scans if scans is not None else {it['scan'] for it in items})
     conn = nav_data.connectivity_dir(scans=scans)
     geo = nav_data.load_geometry()
     row_of, n = {}, 0
@@ -46,5 +50,5 @@ def build_env(items, batch_size=100, host_table=None, table_seed=None):
     if table_seed is not None:
         from speaker_follower_amd import synth
         host_table = synth.feature_table(table_seed, n)
-    e = env.R2RIndexEnv(list(items), row_of, conn, batch_size=batch_size, seed=10, host_table=host_table)
+    e = env.R2RIndexEnv(list(items), row_of, conn, batch_size=batch_size, seed=10, host_table=host_table, scans=scans)
     return e, row_of, n
