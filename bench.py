@@ -510,6 +510,10 @@ def headline_of(full, extras_file):
     if full.get('parity_vs_cpu_port'):
         h['parity_vs_cpu_port'] = _pick(full['parity_vs_cpu_port'],
                                         ('actions_bit_exact', 'max_abs_logit_diff', 'loss_abs_diff', 'max_abs_logit'))
+    g9 = full.get('speaker_parity_g9')
+    if isinstance(g9, dict) and 'argmax' in g9:
+        h['parity_speaker_g9'] = {fb: _pick(g9[fb], ('words_bit_exact', 'vs_fp32_reference', 'vs_float64',
+                                                       'reference_fp32_vs_its_float64')) for fb in ('argmax', 'teacher')}
     for k in ('launch', 'persistent_launch_faults', 'oversubscribed'):
         if k in full:
             h[k] = _cut(full[k], 120) if isinstance(full[k], str) else full[k]
@@ -915,6 +919,7 @@ def main(argv=None):
         out['speaker_decode'] = bench_extras.speaker_decode(store, device)          # configs[2], one batch
         out['speaker_sweep'] = bench_extras.speaker_sweep(store, device)            # configs[2]: all 178 300 paths, measured
         out['speaker_train_iteration'] = bench_extras.speaker_train_iteration(store, device)   # a13, the speaker's half
+        out['speaker_parity_g9'] = bench_extras.speaker_parity_g9(device)           # the hard parity set, both distances
         out['search_step'] = bench_extras.search_step(enc, dec, store, device)      # configs[4]
         conn = os.path.join(ROOT, 'tests', 'golden', 'connectivity')
         if os.path.isdir(conn):

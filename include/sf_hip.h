@@ -589,7 +589,11 @@ int sf_speaker_decoder_fwd(const sf_spk_decoder_w* w, int B, int E, int H, int T
 /* `sample` feedback of the speaker (speaker.py:170-174, D.Categorical(probs).sample()): counter-based draw keyed on
  * (seed, stream, row0 + b) -- csrc/sf_sampling.h; oracle/rng.py mirrors it.  `stream` names the word step (callers
  * pass site + t; sf_speaker_decode uses stream + t for its step t); row0 = global id of local row 0 (data-parallel
- * shards draw what the unsharded batch would). */
+ * shards draw what the unsharded batch would).
+ * LIMIT: the draw is two-level over at most 32 x 32 probabilities -- feedback 2 (`sample`) needs vocab <= 1024 in
+ * sf_speaker_glue_fwd and sf_speaker_decode (SF_ERR_UNSUPPORTED above; the host classes raise NotImplementedError).
+ * The live vocabularies fit (train_vocab.txt 991, sub_train_vocab.txt 935); trainval_vocab.txt (1 086) does not:
+ * teacher / argmax passes over it run on the per-step entry points (tests/test_gpu_speaker.py). */
 typedef struct sf_sample {
     uint32_t seed, stream;
     int32_t row0;

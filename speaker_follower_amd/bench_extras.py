@@ -175,6 +175,56 @@ def speaker_sweep(store, device, n_paths=178300, batch=100, words=80):
 
 
 @_guard
+def speaker_parity_g9(device):
+    """The speaker's HARD parity set (golden G9: B = 100, peaky weights, attention scores up to +-80, |logit| up to 17),
+    measured in this run: max |logit difference| of the HIP path at the first and the last word step against (a) the
+    REFERENCE's own fp32 output (north_star's letter: 1e-4) and (b) the same reference modules evaluated in float64.
+    The reference's fp32 run is itself 1e-4 .. 2.3e-4 from its float64 evaluation; the HIP path (float64 attention
+    query / scores in the path encoder, bf16x6 products) sits ~3e-5 from float64 -- so its distance to the fp32
+    reference is dominated by the REFERENCE's rounding and exceeds 1e-4 on this set: a known deviation from the
+    letter, stated here instead of hidden behind the float64 assertion.  Words are bit-exact."""
+    import os
+    from . import synth, model, features, speaker
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+    def load(name):
+        with np.load(os.path.join(root, 'tests', 'golden', name + '.npz')) as z:
+            return {k: z[k] for k in z.files}
+    f64 = load('g9_speaker_b100_f64')
+    out = {}
+    for feedback in ('argmax', 'teacher'):
+        g = load('g9_speaker_b100_' + feedback)
+        d = synth.FULL
+        senc_w, sdec_w = synth.speaker_weights_peaky(int(g['weight_seed']))
+        enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+        dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'])
+        enc.load_state_dict({k: torch.tensor(v) for k, v in senc_w.items()})
+        dec.load_state_dict({k: torch.tensor(v) for k, v in sdec_w.items()})
+        enc.to(device).eval()
+        dec.to(device).eval()
+        sb = synth.speaker_batch(seed=int(g['batch_seed']), batch=100, n_viewpoints=256, min_len=10, max_len=79)
+        store = features.FeatureStore(synth.feature_table(int(g['table_seed']), 256), device=device)
+        n = int(g['n_steps'])
+        with torch.no_grad():
+            st = speaker.SpeakerEngine(enc, dec, store).score(speaker.DeviceSpeakerBatch.from_synth(sb, device=device), n,
+                                                              feedback, train=False)
+        lg = st.logits.cpu().numpy()
+        V = g['logit_last'].shape[-1]
+        first, last = lg[0][:, :V], lg[n - 1][:, :V]
+        out[feedback] = dict(
+            words_bit_exact=bool(np.array_equal(st.words[1:].cpu().numpy(), g['words'])), word_steps=n,
+            max_abs_logit=float(np.abs(g['logit_last']).max()),
+            vs_fp32_reference=float(max(np.abs(first - g['logits_first'][0]).max(), np.abs(last - g['logit_last']).max())),
+            vs_float64=float(max(np.abs(first - f64[feedback + '/logits_first']).max(),
+                                 np.abs(last - f64[feedback + '/logit_last']).max())),
+            reference_fp32_vs_its_float64=float(max(f64[feedback + '/ref32_dist_first'], f64[feedback + '/ref32_dist_last'])))
+    out['note'] = ('north_star asks for 1e-4 of the reference CPU path: met against the float64 evaluation of the reference '
+                   'modules; vs the reference\'s OWN fp32 output this set measures ~2e-4 because that output is itself '
+                   '1e-4 .. 2.3e-4 from exact arithmetic (tests/test_gpu_hard_parity.py)')
+    return out
+
+
+@_guard
 def search_full(conn_dir, device, scans=('YmJkqBEsHnH', 'gZ6f7yhEvPG', 'GdvgFV5R1Z5'), instances=64, k=40,
                 episode_len=8):
     """configs[4] end to end on real connectivity graphs: Seq2SeqAgent.state_factored_search(K = 40, 1)

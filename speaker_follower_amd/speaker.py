@@ -576,7 +576,14 @@ def batch_from_packed(buf, B, Tp, Lmax=80, row0=0):
 class SpeakerSweep:
     """Greedy (or sampled) decoding of MANY path minibatches at full device rate.
 
-    Per stream (two by default) and per path-step count Tp one captured hipGraph of the whole pass (encoder + the
+    ONE stream by default since round 6: with two, the kernels of the two streams do not overlap -- the first kernel of a
+    stream's graph waits for the other stream's persistent word loop (it holds a workgroup on every CU and the
+    persistent launches of a process are serialised by a device-wide lock): 773 us average "duration" of
+    gather_path_actions_kernel under rocprofv3 against 5.3 us on one stream (profiles/r06_e_speaker_sweep_streams.txt);
+    what the second stream bought was copy / host overlap only (1.23 - 1.34 ms per minibatch against 1.34, box to box).
+    `n_streams=2` remains available.
+
+    Per stream and per path-step count Tp one captured hipGraph of the whole pass (encoder + the
     persistent word loop) over a static device staging buffer; per minibatch the host packs the index arrays into a
     pinned buffer (its own, one per stream and slot: packing minibatch n+1 overlaps the device work of n), ONE
     asynchronous H2D copy, a graph replay, and an asynchronous D2H copy of the words (int16) into a pinned result
@@ -586,7 +593,7 @@ class SpeakerSweep:
     graphs captured with the per-step kernels (`fallbacks` counts them).  `sample` feedback needs vocab <= 1024 (the
     two-level draw of sf_sampling.h); the pinned staging buffers grow with the longest path met."""
 
-    def __init__(self, encoder, decoder, store, batch_size, words, feedback='argmax', Lmax=80, n_streams=2, slots=2,
+    def __init__(self, encoder, decoder, store, batch_size, words, feedback='argmax', Lmax=80, n_streams=1, slots=2,
                  with_scores=False):
         """with_scores: every minibatch also returns its per-word scores [S,B] and its per-step (sum, count) table [S,2]
         (teacher-forced scoring sweeps: Seq2SeqSpeaker._issue_scores)."""

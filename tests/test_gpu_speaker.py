@@ -193,3 +193,43 @@ def test_stacked_weight_gradients_equal_the_per_step_ones(glove):
     for k in ga:
         scale = float(gb[k].abs().max())
         assert float((ga[k] - gb[k]).abs().max()) <= 2e-5 * max(scale, 1e-6), k
+
+
+@pytest.mark.parametrize('feedback', ['argmax', 'teacher'])
+def test_vocabulary_above_1024_runs_on_the_per_step_kernels(feedback):
+    """include/sf_hip.h: the persistent word loop needs vocab <= 1 024 (32 vocabulary columns per workgroup x 32
+    workgroups) and H = 512; the live vocabularies (991 train, 935 sub_train) fit.  The reference's trainval
+    vocabulary (tasks/R2R/data/trainval_vocab.txt: 1 086 words with the base tokens) does NOT: the engine must fall
+    back to the per-step kernels by itself and produce the oracle's words and logits there."""
+    import dataclasses
+    from speaker_follower_amd import model, features, speaker
+    from oracle import np_model
+    d = dataclasses.replace(synth.FULL, vocab=1086)
+    senc_w, sdec_w = synth.speaker_weights_peaky(31, d)
+    enc = model.SpeakerEncoderLSTM(d.feat, d.feat, d.hidden, 0.5)
+    dec = model.SpeakerDecoderLSTM(d.vocab, d.word, d.hidden, 0.5, glove=sdec_w['embedding.weight'])
+    enc.load_state_dict({k: torch.tensor(v) for k, v in senc_w.items()})
+    dec.load_state_dict({k: torch.tensor(v) for k, v in sdec_w.items()})
+    enc.cuda().eval()
+    dec.cuda().eval()
+    B, S, NVP = 12, 14, 48
+    sb = synth.speaker_batch(seed=9, batch=B, n_viewpoints=NVP, min_path=3, max_path=5, min_len=4, max_len=S - 2, dims=d)
+    table = synth.feature_table(7, NVP)
+    eng = speaker.SpeakerEngine(enc, dec, features.FeatureStore(table))
+    with torch.no_grad():
+        st = eng.score(speaker.DeviceSpeakerBatch.from_synth(sb), S, feedback, train=False)
+    assert not st.persistent                                   # refused by speaker_persistent_supported, not by an error
+    acts, feats, path_mask = np_env.dense_speaker_inputs(sb, table, np_env.static_loc_embeddings())
+    instr_seq, _, _ = np_env.batch_instructions_from_encoded(sb.instr, 80)
+    ref = np_model.speaker_score(senc_w, sdec_w, acts, feats, path_mask, instr_seq, S, feedback)
+    n = len(ref['logits'])
+    np.testing.assert_array_equal(st.words[1:n + 1].cpu().numpy(), ref['words'])
+    lg = st.logits.cpu().numpy()
+    assert lg.shape[-1] >= 1086
+    for t in range(n):
+        np.testing.assert_allclose(lg[t][:, :1086], ref['logits'][t], **TOL)
+    # ... and `sample` feedback says so instead of drawing from a truncated table (sf_sampling.h: two-level draw, <= 1 024)
+    with pytest.raises((NotImplementedError, RuntimeError, ValueError)):
+        with torch.no_grad():
+            eng.score(speaker.DeviceSpeakerBatch.from_synth(sb), S, 'sample', train=False)
+        torch.cuda.synchronize()
