@@ -288,6 +288,29 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
                   buckets_bytes=[4 * (hi - lo) for lo, hi in flat.bounds],
                   schedule='buckets in production order (decoder LSTM, other decoder weights, encoder), each all-reduce '
                            'launched async behind the launches that complete it; wait before Adam')
+    if coll:
+        # the SAME data-parallel iteration as replayed graph segments (runtime.TrainingGraph, segmented: the capture is cut
+        # at every collective point; a replay = segment, all-reduce start, segment, ...): what a data-parallel job runs
+        try:
+            engine.grad_sync = flat
+            enc.train()
+            dec.train()
+            tg = engine.capture_training(batch, S, 'argmax', optimizers=(opt_e, opt_d), zero=flat)
+            for _ in range(2):
+                tg.replay()
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(iters):
+                tg.replay()
+            barrier()
+            tt = torch.tensor([(time.perf_counter() - t1) / iters], device=store.device, dtype=torch.float64)
+            torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+            ar['ms_per_iteration_graph_segments'] = 1e3 * float(tt)
+            ar['graph_segments'] = len(tg.segments)
+            ar['loss_graph_segments'] = float(tg.state.loss_buf)
+        except Exception as exc:                            # (reported; the eager figures above stand)
+            ar['graph_segments_error'] = repr(exc)[:300]
+        engine.grad_sync = None
     # the fault words of the persistent launches (0 = healthy), and the production entry point once: FollowerEngine.run
     # (rollout + backward + fault check, the flag reduced over the group, per-step re-issue on a fault) -- per rank
     from speaker_follower_amd import runtime as _rt
@@ -537,8 +560,9 @@ def headline_of(full, extras_file):
         h['extras'] = ex
     td = full.get('train_dp')
     if isinstance(td, dict):
-        keys = ('value', 'unit', 'ms_per_iteration', 'allreduce_ms', 'allreduce_exposed_ms_overlapped',
-                'ms_per_iteration_no_exchange', 'allreduce_bytes', 'global_batch', 'scaling', 'launch_mode')
+        keys = ('value', 'unit', 'ms_per_iteration', 'ms_per_iteration_graph_segments', 'allreduce_ms',
+                'allreduce_exposed_ms_overlapped', 'ms_per_iteration_no_exchange', 'allreduce_bytes', 'global_batch',
+                'scaling', 'graph_segments_error')
         c = _pick(td, keys)
         if 'error' in td:
             c['error'] = _cut(td['error'], 200)

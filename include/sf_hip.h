@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 8
+#define SF_ABI_VERSION 9
 
 enum {
     SF_OK = 0,
@@ -444,6 +444,14 @@ typedef struct sf_follower_episode {
      * `stream` (they only meet at the LSTM pointwise backward); the two are ordered with events and the
      * call leaves `stream` behind all of the side stream's work. */
     sf_stream side_stream;
+    /* ABI 9, optional, INFERENCE ONLY (drop.p == 0, no backward through this pass: t_text / cat2[:H] / h_tilde of the
+     * tape are NOT written; alpha is): two [B,L,H] scratch tensors.  With them sf_follower_episode_fwd forms
+     * ctx_q = ctx W_in and ctx_o = ctx W_out[:, :H]^T ONCE (the context is constant over an episode) and runs the text
+     * attention of every step but the last in folded form -- scores ctx_q[l] . h1, h~ = tanh(sum alpha_l ctx_o[l] +
+     * W_out[:, H:] h1): the same function (fp32 re-association, like q = W_v^T t_v), two dependent launches fewer per
+     * decode step.  Needs w->text.w_in_t and w->action.w_a_t; one stream (side_stream NULL); pre-drawn observations or a
+     * device-resident environment (glue.nav). */
+    float *ctx_q, *ctx_o;
 } sf_follower_episode;
 int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e, void* ws,
                             size_t ws_bytes, sf_stream stream);

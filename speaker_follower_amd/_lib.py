@@ -78,7 +78,8 @@ class FollowerEpisode(C.Structure):
                 ('L', C.c_int32), ('A', C.c_int32), ('X', Pano), ('U', Cands), ('h_init', c_p),
                 ('c_init', c_p), ('ctx', c_p), ('ctx_mask', c_p), ('tape', DecoderTape),
                 ('glue', FollowerGlue), ('drop', Dropout), ('step0', C.c_uint32),
-                ('side_stream', C.c_void_p)]
+                ('side_stream', C.c_void_p),
+                ('ctx_q', c_p), ('ctx_o', c_p)]                     # ABI 9: folded text attention (inference only)
 
 
 class EncoderW(C.Structure):
@@ -284,7 +285,7 @@ SF_ENC_REVERSED = 8
 SF_SPK_EMB_DROPOUT = 1        # sf_spk_decoder_w.flags
 
 EXPORTS = tuple(_SIGNATURES)
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 def _load():

@@ -531,7 +531,10 @@ class Seq2SeqAgent(BaseAgent):
         if self._device_table() is None or self._engine is None:
             return False
         eng = self._engine
-        return (eng.group is None and eng.grad_sync is None and getattr(self.encoder, 'num_directions', 1) == 1
+        # (a process group: iterations replay as SEGMENTS cut at the collective points, FollowerEngine._capture_training_dp;
+        # that needs the gradient buckets the all-reduces work on)
+        dp_ok = (eng.group is None and eng.grad_sync is None) or (eng.group is not None and eng.grad_sync is not None)
+        return (dp_ok and getattr(self.encoder, 'num_directions', 1) == 1
                 and getattr(self.encoder, 'persistent', True))
 
     def _train_on_graph(self, encoder_optimizer, decoder_optimizer, n_iters):
@@ -586,7 +589,7 @@ class Seq2SeqAgent(BaseAgent):
         ahead = None            # the NEXT minibatch and its host arrays, formed while the device ran this iteration
         for it in range(n_iters):
             if (self.pipeline_replays and self.prepare_ahead and cached is not None and cached[0] == key
-                    and cached[2].batch_size == self.env.batch_size):
+                    and cached[2].batch_size == self.env.batch_size and eng.group is None):
                 # the graph exists: the remaining iterations with one replay always queued behind the running one
                 return self._replay_pipelined(opts, n_iters - it, cached, eng, dev, ahead)
             if ahead is None:
@@ -604,7 +607,7 @@ class Seq2SeqAgent(BaseAgent):
                                        reverse=self.reverse_instruction, fixed_shapes=True)
                 for o in opts:
                     o.guard_faults = True
-                tg = eng.capture_training(batch, self.episode_len, self.feedback, optimizers=opts)
+                tg = eng.capture_training(batch, self.episode_len, self.feedback, optimizers=opts, zero=eng.grad_sync)
                 cached = self._train_graph_state = (key, tg, batch)
                 st = tg.first                                 # (the capture ran this iteration eagerly)
             else:
@@ -618,9 +621,18 @@ class Seq2SeqAgent(BaseAgent):
                 nxt = list(self.env.batch)
                 ahead = (nxt, batch._host_arrays(nxt) if len(nxt) == batch.batch_size else None)
             loss = float(st.loss_buf)                         # the iteration's one host sync
-            if take_fault(dev):
+            bits = take_fault(dev)
+            if eng.group is not None:
+                # every rank takes the same decision (MAX: RCCL has no bitwise reductions): a re-issue launches
+                # collectives, and those only match if all ranks re-issue
+                t_ = torch.tensor([bits], device=dev, dtype=torch.int32)
+                torch.distributed.all_reduce(t_, op=torch.distributed.ReduceOp.MAX, group=eng.group)
+                bits = int(t_.item())
+            if bits:
                 # a persistent launch starved: the guarded optimizer steps did nothing.  The same minibatch again on
                 # the per-step kernels, launch by launch
+                if eng.grad_sync is not None:
+                    eng.grad_sync.abort()                     # (nothing of the faulted round is in flight: replays wait)
                 for o, b in zip(opts, before):
                     o.set_host_steps(b)
                     o.zero_grad()
@@ -632,6 +644,8 @@ class Seq2SeqAgent(BaseAgent):
                     st.loss.backward()
                 finally:
                     self.encoder.persistent = keep
+                if eng.grad_sync is not None:
+                    eng.grad_sync.wait()
                 loss = float(st.loss_buf)
                 if take_fault(dev):
                     raise PersistentLaunchFault('the per-step re-issue of a training iteration raised a fault again')

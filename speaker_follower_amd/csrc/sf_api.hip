@@ -749,12 +749,18 @@ static int plan_linear(const float* x, int ldx, const float* wgt, int ldw, const
     return linear_small_plan(&sg, 1, M, N, o, p) ? SF_OK : SF_ERR_UNSUPPORTED;
 }
 
+// the episode's folded context tensors (sf_follower_episode.ctx_q / ctx_o; sf_attention.hip: text_fold_body)
+struct TextFold {
+    const float* ctx_q;
+    const float* ctx_o;
+};
+
 static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
                           const float* u_prev, const float* h0, const float* c0, const float* ctx,
                           const uint8_t* ctx_mask, const int32_t* ctx_row, const sf_decoder_tape* tp,
                           const sf_follower_glue* glue, const sf_dropout* drop, uint32_t step_id,
                           const sf_pano* X_next, const sf_decoder_tape* tn, void* ws, size_t ws_bytes,
-                          sf_stream stream) {
+                          sf_stream stream, const TextFold* tf = nullptr) {
     SF_CHECK_ARG(w && U && h0 && c0 && ctx && tp && B > 0 && L > 0 && (!glue || glue_ok(U, glue)) &&
                  (!X_next || tn));
     Arena ar = arena(ws, ws_bytes);
@@ -773,6 +779,57 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     const sf_softdot_w* tw = &w->text;
     const sf_visual_w* vw = &w->visual;
     bool paired = X_next && vw->w_v_t;     // (a scoring fold, if any, is applied by scoring_fwd_i)
+    if ((paired || query_only) && tf && !w->fold && !ctx_row && !d_h.on() && tw->w_out && w->action.w_a_t) {
+        // Folded text stage (inference; sf_attention.hip: text_fold_body): FOUR dependent launches behind the cell
+        // instead of six:
+        //   (1) folded text attention (2 groups per sample)  ||  y = W_out[:, H:] h1  ||  t_v' = W_h h1 + b_h
+        //   (2) t_a = W_h tanh(z + y) + b_h, wt = t_a * w_out (A-prologue)   ||  q' = W_v^T t_v'
+        //   (3) r = W_a^T wt            ||  visual attention of step t+1 (partials, ticket, merge by the last arriver)
+        //   (4) scoring + glue
+        // (query_only -- a device-resident environment: the panorama of step t+1 is not known yet -- stage (3) is the
+        // r product alone and the attention follows the environment step, sf_attn_decoder_attend_fwd)
+        const PanoSrc xn = paired ? pano(X_next) : PanoSrc{};
+        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1), 2);
+        Arena af = ar;                                           // (released when this branch is left)
+        float* tpart = af.take(text_fold_part_floats(B, H));
+        float* ybuf = af.take((size_t)B * H);
+        float* part = (paired && B <= 1024) ? af.take(visual_attn_split_floats(B, F)) : nullptr;
+        SmallPlan py, pv, pta, pq, pr;
+        bool ok = tpart && ybuf && (part || !paired) && af.tickets() &&
+            plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK &&
+            plan_linear(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, &pv) == SF_OK &&
+            plan_linear(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, &pq) == SF_OK &&
+            plan_linear(tp->wt, D, w->action.w_a_t, D, nullptr, B, F, D, EPI_NONE, tp->r, F, &pr) == SF_OK;
+        if (ok) {
+            Seg sg{ybuf, H, w->action.w_h, H, H};
+            LinearOut o{};
+            o.y = tp->wt; o.ldy = D; o.bias = w->action.b_h; o.mul = w->action.w_out; o.y_pre = tp->t_a;
+            o.ldy_pre = D; o.epi = EPI_MUL;
+            ok = linear_small_plan(&sg, 1, B, D, o, &pta) && pta.mt == 1 && pta.cpw == 4 && pq.cpw == 2 && pr.cpw == 2;
+            pta.args.apro_part = tpart;
+            pta.args.apro_stride = H + 64;
+            pta.args.apro_alpha = tp->alpha;                      // the tape's text-attention weights [B, L]
+            pta.args.apro_L = L;
+            pta.args.apro_LG = text_fold_group_rows(L);
+        }
+        if (ok) {
+            const int rc = pair_textfold_small_small(tf->ctx_q, tf->ctx_o, ctx_mask, B, L, H, tp->cat2 + H, 2 * H, tpart,
+                                                     py, pv, st);
+            if (rc == SF_OK) {
+                TRY(pair_apro_small(pta, pq, st));
+                if (paired)
+                    TRY(pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, af.tickets(), pr, st, 0));
+                else
+                    TRY(launch_small_plan_x(pr, st));
+                if (glue)
+                    return score_glue_fwd(us, B, D, tp->r, tp->wt, w->action.b_a, w->action.b_out,
+                                          make_glue(us, B, tp->logit, glue), st);
+                return score_fwd(us, B, D, tp->r, tp->wt, w->action.b_a, w->action.b_out, tp->logit, st);
+            }
+            if (rc != SF_ERR_UNSUPPORTED) return rc;
+        }
+        // (shapes outside the instantiations: the unfolded stages below)
+    }
     if (paired && w->fold) {
         // Folded inference step (sf_decoder_fold): two dependent stages fewer, and the attention
         // partials of step t+1 ride beside the text attention (the longest small stage) instead of
@@ -1169,6 +1226,17 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
     StepView cur = step_view(e, 0);
     TRY(decoder_head_i(w, &cur.X, e->B, e->H, e->D, e->h_init, &cur.tp, drop, e->step0, ws, ws_bytes,
                        stream));
+    // the folded text attention (ABI 9): ctx_q = ctx W_in, ctx_o = ctx W_out[:, :H]^T, once per episode
+    TextFold tfold{e->ctx_q, e->ctx_o};
+    const TextFold* tf = nullptr;
+    if (e->ctx_q && e->ctx_o && !drop && !w->fold && e->S > 1 && w->text.w_in_t && w->text.w_out && w->action.w_a_t &&
+        !(e->side_stream && e->side_stream != stream)) {
+        const int M = e->B * e->L, H = e->H;
+        Arena ar = arena(ws, ws_bytes);
+        TRY(linear_plain(e->ctx, H, w->text.w_in_t, H, nullptr, M, H, H, EPI_NONE, e->ctx_q, H, ar, S(stream)));
+        TRY(linear_plain(e->ctx, H, w->text.w_out, 2 * H, nullptr, M, H, H, EPI_NONE, e->ctx_o, H, ar, S(stream)));
+        tf = &tfold;
+    }
     if (e->glue.nav) {
         // A device-resident environment (sf_nav_io of step 0 in glue.nav; state buffers stacked [S + 1][...]): the
         // panorama of step t + 1 is only known once the glue of step t has chosen its action and stepped the
@@ -1185,7 +1253,7 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
             const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
             TRY(decoder_tail_i(w, &cur.U, e->B, e->H, e->D, e->L, nullptr, h0, c0, e->ctx, e->ctx_mask,
                                nullptr, &cur.tp, &cur.glue, drop, e->step0 + t, nullptr, more ? &nxt.tp : nullptr, ws,
-                               ws_bytes, stream));
+                               ws_bytes, stream, tf));
             if (more)
                 TRY(sf_attn_decoder_attend_fwd(&nxt.X, e->B, &nxt.tp, drop, e->step0 + t + 1, ws, ws_bytes, stream));
             cur = nxt;
@@ -1240,7 +1308,7 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
         const float* c0 = t == 0 ? e->c_init : e->tape.c1 + (size_t)(t - 1) * BH;
         TRY(decoder_tail_i(w, &cur.U, e->B, e->H, e->D, e->L, nullptr, h0, c0, e->ctx, e->ctx_mask,
                            nullptr, &cur.tp, &cur.glue, drop, e->step0 + t, more ? &nxt.X : nullptr,
-                           more ? &nxt.tp : nullptr, ws, ws_bytes, stream));
+                           more ? &nxt.tp : nullptr, ws, ws_bytes, stream, tf));
         cur = nxt;
     }
     return SF_OK;

@@ -797,6 +797,127 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArg
 }
 
 
+
+// =================================================================================================
+// The text attention in FOLDED form (inference only: nothing here is taped for a backward).
+// model.py:129-141 per decode step: t = W_in h1, s_l = ctx_l . t, alpha = softmax(s), wc = sum alpha_l ctx_l,
+// h~ = tanh(W_out [wc ; h1]).  The context does not change during an episode, so two products leave the per-step
+// chain for good (sf_text_fold_build, once per episode):
+//     ctx_q = ctx W_in           s_l = ctx_q[l] . h1                     (no t = W_in h1 product per step)
+//     ctx_o = ctx W_out[:, :H]^T W_out [wc ; h1] = sum alpha_l ctx_o[l] + W_out[:, H:] h1
+// A step then needs, behind the cell: this body (scores + softmax + z = sum e_l ctx_o[l]) BESIDE the product
+// y = W_out[:, H:] h1 in one launch, and h~ = tanh(z / l + y) is formed by the A-prologue of the next product
+// (t_a = W_h h~ + b: sf_gemm_small.h, APRO) -- two dependent launches fewer per decode step.
+// The body reads TWO context tensors, so a sample is split over TXF_G = 2 workgroups (positions [g Lg, (g + 1) Lg)):
+// each pulls what the unfolded body pulled (a CU sustains ~25-45 GB/s of loads; bytes per workgroup are what the
+// stage costs) and keeps a flash-style partial (m, l, unnormalised z) that the consumer merges.
+// =================================================================================================
+constexpr int TXF_G = 2;
+
+struct TxtFoldArgs {
+    const float* ctx_q;    // [B, L, H]
+    const float* ctx_o;    // [B, L, H]
+    const uint8_t* mask;   // [B, L] (1 = padding) or null
+    int L, H;
+    const float* vec;      // h1 as the text attention sees it (eval: h1 itself) [B, ldvec]
+    int ldvec;
+    float* part;           // [B][TXF_G][H + 64]: z | e[l - g Lg] (<= 62) | m at H + 62 | l at H + 63
+};
+
+template <int RPW>
+__device__ __forceinline__ void text_fold_body(const TxtFoldArgs& a, int g, int b) {
+    constexpr int NW = SMALL_WAVES, SL = 4, LG = NW * RPW;
+    static_assert(LG <= 62, "a group's weights live in 62 record slots");
+    __shared__ float4 slots[SL][TXT_CPL * 64];
+    __shared__ float s_score[LG];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int L = a.L, n4 = a.H >> 2;
+    const float4* cq = reinterpret_cast<const float4*>(a.ctx_q) + (size_t)b * L * n4;
+    const float4* co = reinterpret_cast<const float4*>(a.ctx_o) + (size_t)b * L * n4;
+    const bool use_mask = a.mask != nullptr;
+    const uint8_t* mrow = use_mask ? a.mask + (size_t)b * L : reinterpret_cast<const uint8_t*>(cq);
+    // straight-line loads, clamped indices, value selects (sf_rows.h): every row of both tensors is in flight at once
+    float4 xq[RPW][TXT_CPL], xo[RPW][TXT_CPL];
+    uint8_t mk[RPW];
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const int l = g * LG + wave * RPW + r;
+        const int lc = min(l, L - 1);
+#pragma unroll
+        for (int i = 0; i < TXT_CPL; ++i) {
+            const int c = lane + 64 * i;
+            const float4 tq = cq[(size_t)lc * n4 + min(c, n4 - 1)];
+            const float4 to = co[(size_t)lc * n4 + min(c, n4 - 1)];
+            const bool ok = l < L && c < n4;
+            xq[r][i] = ok ? tq : f4zero();
+            xo[r][i] = ok ? to : f4zero();
+        }
+        mk[r] = mrow[lc];
+    }
+    float4 v[TXT_CPL];
+#pragma unroll
+    for (int i = 0; i < TXT_CPL; ++i) {
+        const int c = lane + 64 * i;
+        const float4 t = reinterpret_cast<const float4*>(a.vec + (size_t)b * a.ldvec)[min(c, n4 - 1)];
+        v[i] = c < n4 ? t : f4zero();
+    }
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        float d = 0.f;
+#pragma unroll
+        for (int i = 0; i < TXT_CPL; ++i) d += dot4(xq[r][i], v[i]);
+        d = wave_sum(d);
+        const int l = g * LG + wave * RPW + r;
+        if (lane == 0) s_score[wave * RPW + r] = (l >= L || (use_mask && mk[r])) ? -INFINITY : d;
+    }
+    __syncthreads();
+    const float sc = lane < LG ? s_score[lane] : -INFINITY;
+    const float m = wave_max(sc);                                  // -inf: every position of this group is padding
+    const float e = sc > -INFINITY ? expf(sc - m) : 0.f;
+    const float lsum = wave_sum(e);
+    float4 p[TXT_CPL];
+#pragma unroll
+    for (int i = 0; i < TXT_CPL; ++i) p[i] = f4zero();
+#pragma unroll
+    for (int r = 0; r < RPW; ++r) {
+        const float er = __shfl(e, wave * RPW + r, WAVE);
+#pragma unroll
+        for (int i = 0; i < TXT_CPL; ++i) f4fma(p[i], er, xo[r][i]);
+    }
+    float* rec = a.part + ((size_t)b * TXF_G + g) * (a.H + 64);
+    block_row_sum<TXT_CPL, NW, SL>(p, slots, n4, [&](int c, float4 t) { reinterpret_cast<float4*>(rec)[c] = t; });
+    if (wave == 0) {
+        if (lane < LG) rec[a.H + lane] = e;
+        if (lane == 0) {
+            rec[a.H + 62] = m;
+            rec[a.H + 63] = lsum;
+        }
+    }
+}
+
+// the folded text stage: [text_fold groups | y = W_out[:, H:] h1 | t_v' = W_h h1 + b] in ONE grid
+template <int RPW>
+__global__ __launch_bounds__(SMALL_WAVES * 64) void pair_textfold_small_small_kernel(TxtFoldArgs t, int nt, SmallArgs a,
+                                                                                    int gxa, int na, SmallArgs b, int gxb) {
+    const int bid = blockIdx.x;
+    if (bid < nt)
+        text_fold_body<RPW>(t, bid % TXF_G, bid / TXF_G);
+    else if (bid < nt + na)
+        small_gemm_body<1, 4>(a, (bid - nt) % gxa, (bid - nt) / gxa);
+    else
+        small_gemm_body<1, 4>(b, (bid - nt - na) % gxb, (bid - nt - na) / gxb);
+}
+
+// t_a = W_h tanh(z + y) + b (A-prologue) beside q' = W_v^T t_v'
+template <int MTB>
+__global__ __launch_bounds__(SMALL_WAVES * 64) void pair_apro_small_kernel(SmallArgs a, int gxa, int na, SmallArgs b, int gxb) {
+    const int bid = blockIdx.x;
+    if (bid < na)
+        small_gemm_body<1, 4, false, false, true>(a, bid % gxa, bid / gxa);
+    else
+        small_gemm_body<MTB, 2>(b, (bid - na) % gxb, (bid - na) / gxb);
+}
+
 // Deferred gradient of the instruction context (model.py:129-139 backward, summed over an episode):
 // dctx[b,l,:] += sum_t ( alpha[t,b,l] dwc[t,b,:] + ds[t,b,l] tt[t,b,:] ).  The per-step form reads and
 // writes the whole [B,L,H] gradient S times (2 x 16 MB per step at the headline shape); this reads each
@@ -998,6 +1119,52 @@ int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
     return launch_status();
 }
 
+
+// The folded text stage of an inference decode step (see text_fold_body): SF_ERR_UNSUPPORTED = shapes outside the
+// instantiations (the caller runs the unfolded stages).
+int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint8_t* mask, int B, int L, int H,
+                              const float* vec, int ldvec, float* part, const SmallPlan& a, const SmallPlan& b,
+                              hipStream_t st) {
+    if (!(a.mt == 1 && a.cpw == 4 && b.mt == 1 && b.cpw == 4)) return SF_ERR_UNSUPPORTED;
+    if (H > TXT_CPL * 256 || (H & 3) || (ldvec & 3) || L < 1 || L > TXF_G * SMALL_WAVES * 5 || B > 1024)
+        return SF_ERR_UNSUPPORTED;
+    const TxtFoldArgs ta{ctx_q, ctx_o, mask, L, H, vec, ldvec, part};
+    const int nt = TXF_G * B, na = a.gx * a.gy, nb = b.gx * b.gy;
+    const dim3 grid(nt + na + nb), block(SMALL_WAVES * 64);
+    const int rpw = (L + TXF_G * SMALL_WAVES - 1) / (TXF_G * SMALL_WAVES);
+    if (rpw <= 1)
+        SF_LAUNCH((pair_textfold_small_small_kernel<1>), grid, block, 0, st, ta, nt, a.args, a.gx, na, b.args, b.gx);
+    else if (rpw <= 2)
+        SF_LAUNCH((pair_textfold_small_small_kernel<2>), grid, block, 0, st, ta, nt, a.args, a.gx, na, b.args, b.gx);
+    else if (rpw <= 3)
+        SF_LAUNCH((pair_textfold_small_small_kernel<3>), grid, block, 0, st, ta, nt, a.args, a.gx, na, b.args, b.gx);
+    else
+        SF_LAUNCH((pair_textfold_small_small_kernel<5>), grid, block, 0, st, ta, nt, a.args, a.gx, na, b.args, b.gx);
+    return launch_status();
+}
+size_t text_fold_part_floats(int B, int H) { return (size_t)B * TXF_G * (H + 64); }
+// positions per group for a context of L positions (the template the launcher above picks)
+int text_fold_group_rows(int L) {
+    const int rpw = (L + TXF_G * SMALL_WAVES - 1) / (TXF_G * SMALL_WAVES);
+    return SMALL_WAVES * (rpw <= 1 ? 1 : (rpw <= 2 ? 2 : (rpw <= 3 ? 3 : 5)));
+}
+
+// a: the product whose A operand the prologue forms (a.args.apro_part set by the caller), b: a plain small product
+int pair_apro_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
+    if (!(a.mt == 1 && a.cpw == 4 && b.cpw == 2 && (b.mt == 1 || b.mt == 2 || b.mt == 4)) || !a.args.apro_part ||
+        a.args.sg.total != a.args.sg.n0)
+        return SF_ERR_UNSUPPORTED;
+    const int na = a.gx * a.gy, nb = b.gx * b.gy;
+    const dim3 grid(na + nb), block(SMALL_WAVES * 64);
+    if (b.mt == 4)
+        SF_LAUNCH((pair_apro_small_kernel<4>), grid, block, 0, st, a.args, a.gx, na, b.args, b.gx);
+    else if (b.mt == 2)
+        SF_LAUNCH((pair_apro_small_kernel<2>), grid, block, 0, st, a.args, a.gx, na, b.args, b.gx);
+    else
+        SF_LAUNCH((pair_apro_small_kernel<1>), grid, block, 0, st, a.args, a.gx, na, b.args, b.gx);
+    return launch_status();
+}
+
 // visual-attention partials (phase 1 of the split attention) beside the text attention
 int pair_vis_text(const PanoSrc& src, int B, const float* vec, int ldvec, float* alpha, float* out, int ldo,
                   const Dropout& drop, int drop_col0, float* split_part, const float* ctx, const uint8_t* mask,
@@ -1065,7 +1232,9 @@ int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float
                    int ldo, const Dropout& drop, int drop_col0, float* split_part,
                    unsigned* split_counter, const SmallPlan& b, hipStream_t st, int phase) {
     const int F = src.IMG + src.LOC;
-    if (!(b.mt == 1 && (b.cpw == 8 || (phase == 2 && b.cpw == 4)))) return SF_ERR_UNSUPPORTED;
+    // (the r = W_a^T wt product of the folded text chain: K = D = 256 -> two chunks per wave)
+    const bool wide = b.cpw == 2 && (b.mt == 1 || b.mt == 2 || b.mt == 4) && phase == 0;
+    if (!wide && !(b.mt == 1 && (b.cpw == 8 || (phase == 2 && b.cpw == 4)))) return SF_ERR_UNSUPPORTED;
     if (!split_part || (phase == 0 && !split_counter) || src.V <= (VSP_G - 1) * VSP_RPG || src.V > VSP_G * VSP_RPG ||
         B > 256 ||
         F > VIS_CPL * 256 || (F & 3) || (!src.dense && ((src.IMG & 3) || (src.LOC & 3))) ||
@@ -1075,7 +1244,13 @@ int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float
     const int nv = (phase == 2 ? 1 : VSP_G) * B, nb = b.gx * b.gy;
     const dim3 grid(nv + nb), block(SMALL_WAVES * 64);
     const VisSplit sp{split_part, split_counter, g_trace};
-    if (phase == 0)
+    if (wide && b.mt == 4)
+        SF_LAUNCH((pair_vis_small_kernel<4, 2, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (wide && b.mt == 2)
+        SF_LAUNCH((pair_vis_small_kernel<2, 2, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (wide)
+        SF_LAUNCH((pair_vis_small_kernel<1, 2, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (phase == 0)
         SF_LAUNCH((pair_vis_small_kernel<1, 8, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     else if (phase == 1)
         SF_LAUNCH((pair_vis_small_kernel<1, 8, 1>), grid, block, 0, st, va, sp, nv, b.args, b.gx);

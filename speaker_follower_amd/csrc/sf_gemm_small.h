@@ -27,6 +27,78 @@ struct Frags {
     float4 a[CPW][MT];
 };
 
+// a = tanh(s0 z0 + s1 z1 + y) of one float4 (the A-prologue, see SmallArgs::apro_part)
+__device__ __forceinline__ float4 apro_form(const float4& y, const float4& z0, const float4& z1, float s0, float s1) {
+    return make_float4(tanhf(fmaf(s0, z0.x, fmaf(s1, z1.x, y.x))), tanhf(fmaf(s0, z0.y, fmaf(s1, z1.y, y.y))),
+                       tanhf(fmaf(s0, z0.z, fmaf(s1, z1.z, y.z))), tanhf(fmaf(s0, z0.w, fmaf(s1, z1.w, y.w))));
+}
+
+// The same loads with the A-prologue: one segment (K = sg.s0.K), A = y [M, lda].
+template <int MT, int CPW>
+__device__ __forceinline__ void upfront_load_apro(Frags<MT, CPW>& f, const Seg2& sg, int c_lo, int c_hi, int n,
+                                                  const int (&mrow)[MT], int kk, const float* part, int stride) {
+    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int K = sg.s0.K;
+    float4 bv[CPW], yv[CPW][MT], z0[CPW][MT], z1[CPW][MT];
+    float m0[MT], l0[MT], m1[MT], l1[MT];
+    bool ok[CPW];
+    // every load first (straight line), the transcendental arithmetic behind them
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const float* r0 = part + (size_t)mrow[t] * 2 * stride;
+        m0[t] = r0[K + 62]; l0[t] = r0[K + 63];
+        m1[t] = r0[stride + K + 62]; l1[t] = r0[stride + K + 63];
+    }
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        const int c = min(c_lo + i, c_hi - 1);
+        const int k = c * 16 + 4 * kk;
+        ok[i] = k < K;
+        const int kc = ok[i] ? k : 0;
+        bv[i] = ld4(sg.s0.W + (size_t)n * sg.s0.ldw + kc);
+#pragma unroll
+        for (int t = 0; t < MT; ++t) {
+            yv[i][t] = ld4(sg.s0.A + (size_t)mrow[t] * sg.s0.lda + kc);
+            const float* r0 = part + (size_t)mrow[t] * 2 * stride + kc;
+            z0[i][t] = ld4(r0);
+            z1[i][t] = ld4(r0 + stride);
+        }
+    }
+    float s0[MT], s1[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) {
+        const float mm = fmaxf(m0[t], m1[t]);                      // (a sample always has one unmasked position: finite)
+        const float w0 = m0[t] > -INFINITY ? expf(m0[t] - mm) : 0.f;
+        const float w1 = m1[t] > -INFINITY ? expf(m1[t] - mm) : 0.f;
+        const float inv = 1.0f / fmaf(l0[t], w0, l1[t] * w1);
+        s0[t] = w0 * inv;
+        s1[t] = w1 * inv;
+    }
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+        f.b[i] = ok[i] ? bv[i] : z;
+#pragma unroll
+        for (int t = 0; t < MT; ++t) f.a[i][t] = ok[i] ? apro_form(yv[i][t], z0[i][t], z1[i][t], s0[t], s1[t]) : z;
+    }
+}
+
+// alpha[row, l] = e_g[l - g LG] * s_g for the MT * 16 rows of a block (every thread of the block takes part)
+template <int MT>
+__device__ __forceinline__ void apro_write_alpha(const float* part, int stride, int K, float* alpha, int L, int LG,
+                                                 int m0, int M) {
+    for (int e = threadIdx.x; e < MT * 16 * L; e += blockDim.x) {
+        const int row = m0 + e / L, l = e % L;
+        if (row >= M) break;
+        const float* r0 = part + (size_t)row * 2 * stride;
+        const float ma = r0[K + 62], la = r0[K + 63], mb = r0[stride + K + 62], lb = r0[stride + K + 63];
+        const float mm = fmaxf(ma, mb);
+        const float wa = ma > -INFINITY ? expf(ma - mm) : 0.f, wb = mb > -INFINITY ? expf(mb - mm) : 0.f;
+        const float inv = 1.0f / fmaf(la, wa, lb * wb);
+        const int g = l >= LG ? 1 : 0;
+        alpha[(size_t)row * L + l] = r0[g * stride + K + (l - g * LG)] * (g ? wb : wa) * inv;
+    }
+}
+
 template <int MT, int CPW>
 __device__ __forceinline__ void upfront_load(Frags<MT, CPW>& f, const Seg2& sg, int c_lo, int c_hi,
                                              int n, const int (&mrow)[MT], int kk) {
@@ -85,6 +157,14 @@ struct SmallArgs {
     const float* aux; int ld_aux;          // see LinearOut
     const float* addend; int ld_addend;
     const float* r1_s; const float* r1_v;
+    // A-PROLOGUE (APRO bodies only; the folded inference text stage, sf_attention.hip: text_fold_body): the A operand is
+    // not read but FORMED on the fly, a[row, k] = tanh(s0 z0[row, k] + s1 z1[row, k] + y[row, k]), where y = the `A` of
+    // segment 0, z0 / z1 = the two groups' unnormalised attention sums in `apro_part` ([M][2][apro_stride] floats:
+    // z [K] | e .. | m at K + 62 | l at K + 63) and (s0, s1) merge the two softmax pieces of the row.
+    const float* apro_part; int apro_stride;
+    // ... and the blocks of column tile 0 also write the merged attention weights alpha[row, l] (the tape's contract):
+    // positions [g LG, (g + 1) LG) of a row are group g's e values times the group's merge scale
+    float* apro_alpha; int apro_L, apro_LG;
 };
 
 // Block (bx, by) of the grid (ceil(N/16), ceil(mtiles/MT)); 512 threads = 8 waves = 8 K-slices of one
@@ -94,7 +174,8 @@ struct SmallArgs {
 // PW: the LSTM cell's pointwise backward as the epilogue (sf_lstm_pw.h): the product completes dh1 of a decoder step
 // (y += ...), and element (row, col) -- all it needs of dh1 -- goes straight through the cell's backward: dgates and dc0
 // of that step without the stand-alone launch.
-template <int MT, int CPW, bool EXTRA = false, bool PW = false>
+// APRO: the A operand is formed by the A-prologue (SmallArgs::apro_part) instead of loaded.
+template <int MT, int CPW, bool EXTRA = false, bool PW = false, bool APRO = false>
 __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int by, const LstmPwBwd* pw = nullptr) {
     __shared__ float s_part[SMALL_WAVES][MT][256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -126,6 +207,8 @@ __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int 
         if (a.r1_s) e_r1[i] = a.r1_s[row] * a.r1_v[ecol];
     }
 
+    if (APRO && bx == 0 && a.apro_alpha)                                   // block-uniform
+        apro_write_alpha<MT>(a.apro_part, a.apro_stride, a.sg.s0.K, a.apro_alpha, a.apro_L, a.apro_LG, m0, a.M);
     const int c_lo = (wave * a.sg.total) / SMALL_WAVES;
     const int c_hi = ((wave + 1) * a.sg.total) / SMALL_WAVES;
     f32x4 acc[MT];
@@ -133,7 +216,10 @@ __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int 
     for (int t = 0; t < MT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     if (c_hi > c_lo) {
         Frags<MT, CPW> f;
-        upfront_load<MT, CPW>(f, a.sg, c_lo, c_hi, n, mrow, kk);
+        if (APRO)
+            upfront_load_apro<MT, CPW>(f, a.sg, c_lo, c_hi, n, mrow, kk, a.apro_part, a.apro_stride);
+        else
+            upfront_load<MT, CPW>(f, a.sg, c_lo, c_hi, n, mrow, kk);
         upfront_mma<MT, CPW>(f, c_hi - c_lo, acc);
     }
 #pragma unroll

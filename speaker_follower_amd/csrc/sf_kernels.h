@@ -187,6 +187,14 @@ int pair_vis_text(const PanoSrc& src, int B, const float* vec, int ldvec, float*
                   int L, int H, const float* t, int ldt, float* talpha, float* wc, int ldwc,
                   const int32_t* ctx_row, hipStream_t st);
 
+// the folded text stage of an inference decode step (sf_attention.hip: text_fold_body) and its consumer
+int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint8_t* mask, int B, int L, int H,
+                              const float* vec, int ldvec, float* part, const SmallPlan& a, const SmallPlan& b,
+                              hipStream_t st);
+size_t text_fold_part_floats(int B, int H);
+int text_fold_group_rows(int L);
+int pair_apro_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st);
+
 struct FGlue;
 int follower_glue_fwd(const FGlue& g, hipStream_t st);
 // scoring + glue in one launch (sf_attention.hip); g.logit receives the masked logits

@@ -117,6 +117,16 @@ class BucketedGrads(FlatGrads):
             off += n
         self._works = []
         self.launched = []
+        # runtime.TrainingGraph (segmented capture): a callable that takes the HOST action of a collective point
+        # -- start bucket b's all-reduce, wait for all of them -- instead of it being run on the spot: the graph is cut
+        # there and the action becomes the step between two replayed segments
+        self.hook = None
+
+    def _do(self, action):
+        if self.hook is not None:
+            self.hook(action)
+        else:
+            action()
 
     @property
     def n_buckets(self):
@@ -135,9 +145,16 @@ class BucketedGrads(FlatGrads):
                                'zero_grad(set_to_none=True)); gradients would silently not be reduced')
         self.launched.append(b)
         if self._active():
-            lo, hi = self.bounds[b]
-            self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group,
-                                               async_op=True))
+            self._do(lambda: self._start(b))
+
+    def _start(self, b):
+        lo, hi = self.bounds[b]
+        self._works.append(dist.all_reduce(self.flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _wait_works(self):
+        for w in self._works:
+            w.wait()
+        self._works = []
 
     def wait(self):
         if sorted(self.launched) != list(range(self.n_buckets)):
@@ -146,9 +163,9 @@ class BucketedGrads(FlatGrads):
             # (every rank launched the same buckets, so the waits complete)
             self.abort()
             raise RuntimeError('gradient buckets %s were never launched: the backward did not run to the end' % missing)
-        for w in self._works:
-            w.wait()
-        self._works, self.launched = [], []
+        self.launched = []
+        if self._active():
+            self._do(self._wait_works)
         return self.flat
 
     def abort(self):

@@ -160,6 +160,8 @@ class FollowerEngine:
         self.split_wgrad_streams = False
         self.encoder_backward_first = os.environ.get('SF_ENC_BWD_FIRST', '0') == '1'   # (experiment switch, see _backward)
         self.grad_sync = None            # dp.BucketedGrads(dp.follower_buckets(enc, dec)): all-reduce launched from the backward
+        self._open_forks = []            # side streams forked from the current one and not joined yet (_backward)
+        self.fold_text = True            # inference rollouts: text attention over ctx W_in / ctx W_out[:, :H]^T (ABI 9)
         self._wgrad_stream = None
         # model.decoder_fold for no-grad eval rollouts (folded Linears + the folded paired schedule of
         # sf_attn_decoder_tail_fwd).  Correct (tests/test_gpu_follower.py) but SLOWER on MI355X: the two
@@ -315,6 +317,15 @@ class FollowerEngine:
                 if self._side_stream is None:
                     self._side_stream = concurrent_stream(dev)
                 ep.side_stream = self._side_stream.cuda_stream
+            # INFERENCE: the text attention in folded form (include/sf_hip.h, ABI 9: ctx_q / ctx_o; csrc/sf_attention.hip:
+            # text_fold_body) -- the context is constant over the episode, so W_in and W_out[:, :H] are applied to it ONCE
+            # and two dependent launches leave every decode step.  Nothing is taped for a backward, hence never for a
+            # differentiable or train-mode rollout; one stream only.
+            st.text_folded = (self.fold_text and not st.differentiable and not training and fold is None
+                              and ep.side_stream is None and S > 1 and T <= 80 and not bidir)
+            if st.text_folded:
+                st.ctx_fold = new(2, B, T, H)
+                ep.ctx_q, ep.ctx_o = st.ctx_fold[0].data_ptr(), st.ctx_fold[1].data_ptr()
             call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
             st.episode = (ep, dw)
         tapes = [] if st.episode else [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
@@ -367,8 +378,18 @@ class FollowerEngine:
             return st               # and calls finish(st, total)
         if self.group is not None:
             # global per-step normaliser so that the sharded loss equals the reference's batch mean
-            torch.distributed.all_reduce(st.sum_cnt, group=self.group)
+            # (a collective point: under a segmented capture the graph is cut here, runtime.TrainingGraph)
+            table, grp = st.sum_cnt, self.group
+            self._collective(lambda: torch.distributed.all_reduce(table, group=grp))
         return self.finish(st)
+
+    collective_hook = None        # runtime.TrainingGraph (segmented): takes the host action of a collective point
+
+    def _collective(self, action):
+        if self.collective_hook is not None:
+            self.collective_hook(action)
+        else:
+            action()
 
     def run(self, batch, steps, feedback='argmax', train=None, backward=False, while_running=None):
         """`rollout` (and, with backward=True, `loss.backward()`) + the fault check of the persistent encoder
@@ -520,11 +541,11 @@ class FollowerEngine:
         Single process only (a gradient all-reduce cannot live in the graph); unidirectional encoder; pre-drawn
         observations or a device-resident environment (nav.DeviceNavBatch)."""
         from .runtime import TrainingGraph
-        if self.group is not None or self.grad_sync is not None:
-            raise NotImplementedError('capture_training: data-parallel iterations are issued eagerly')
         if self.encoder.num_directions == 2:
             raise NotImplementedError('capture_training: unidirectional encoder only')
         opts = list(optimizers)
+        if self.group is not None or self.grad_sync is not None:
+            return self._capture_training_dp(batch, steps, feedback, opts, zero)
 
         def body():
             if zero is not None:
@@ -538,6 +559,35 @@ class FollowerEngine:
                 o.step()
             return st
         return TrainingGraph(self, body, opts, self.store.device)
+
+    def _capture_training_dp(self, batch, steps, feedback, opts, zero):
+        """The DATA-PARALLEL iteration as replayed SEGMENTS (runtime.TrainingGraph, segmented): a collective cannot
+        live in the graph (gloo stages through the host; RCCL's kernels belong to the process group's own stream), so the
+        capture is CUT at every collective point -- the all-reduce of the per-step (CE sum, count) table behind the
+        forward, the start of each gradient bucket's all-reduce behind the launches that complete it, the wait in front
+        of the optimizers -- and a replay is: segment, host action, segment, ...: the launches of an iteration are still
+        issued as a handful of graph launches instead of ~400 kernel launches, the collectives keep the order and the
+        overlap of the eager loop (each is started behind exactly the work that precedes it on the replay stream; the
+        persistent encoder backward runs in the segment BEHIND the 40 MB bucket's start).  Same sites, same Adam steps,
+        same numbers as the eager data-parallel loop (tests/test_gpu_dataparallel.py)."""
+        from .runtime import TrainingGraph
+        sync = self.grad_sync
+        if sync is None:
+            raise ValueError('a data-parallel capture needs engine.grad_sync (dp.BucketedGrads: the buffer the '
+                             'all-reduces work on)')
+        zero = zero if zero is not None else sync
+        dev = self.store.device
+
+        def body():
+            zero.zero()
+            with torch.no_grad():                       # (the backward is called directly: every launch on this thread)
+                st = self.rollout(batch, steps, feedback, train=True)
+                self._backward(st, torch.ones((), device=dev))
+            sync.wait()
+            for o in opts:
+                o.step()
+            return st
+        return TrainingGraph(self, body, opts, dev, segmented=(sync,))
 
     def capture_sharded(self, shards, steps, feedback='argmax'):
         """Runs the row shards of ONE batch as concurrent chains (inference): one hipGraph per
@@ -681,6 +731,7 @@ class FollowerEngine:
             if side is None:
                 side = self._side_stream = concurrent_stream(dev)
             side.wait_stream(torch.cuda.current_stream())
+            self._open_forks = [side]                    # (a segmented capture joins / re-opens these at its cuts)
             third = None
             if self.split_wgrad_streams:
                 # the eight small products (25 TFLOP/s between them) beside the two LSTM ones (dW_ih alone fills the chip
@@ -689,6 +740,7 @@ class FollowerEngine:
                     self._wgrad_stream = concurrent_stream(dev, exclude=[x for x in (self._side_stream,) if x is not None])
                 third = self._wgrad_stream if self._wgrad_stream is not side else self._side_stream
                 third.wait_stream(torch.cuda.current_stream())
+                self._open_forks.append(third)
         # (Measured in round 5 by wall clock: the encoder first, the two latency-bound pieces side by side, a third stream
         # and chunked weight gradients are all equal or slower than this order; what shortened the tail was fewer launches,
         # gemm_tn_group.  The many-row weight-gradient tiles -- 512 threads x 188 VGPRs, 96 KB LDS -- cannot sit beside the
@@ -716,6 +768,7 @@ class FollowerEngine:
             torch.cuda.current_stream().wait_stream(side)
             if third is not None:
                 torch.cuda.current_stream().wait_stream(third)
+            self._open_forks = []
 
     def _issue_wgrad(self, side, third, dw, dg, params, M, H, D, F, st, tp0, gt0, dev, sync):
         """The decoder's weight gradients on the side stream(s) (which already wait for the backward through time)."""

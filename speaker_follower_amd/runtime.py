@@ -297,7 +297,10 @@ class TrainingGraph:
     tensors every replay overwrites).  `engine` carries `site_next`
     (host mirror of the counter), `iteration` and `site_word`."""
 
-    def __init__(self, engine, body, optimizers, device):
+    def __init__(self, engine, body, optimizers, device, segmented=None):
+        """segmented: None, or the objects (besides `engine`) whose collective points cut the capture -- each has a
+        `.hook` attribute (dp.BucketedGrads); the engine's is `collective_hook`.  A replay is then a SEQUENCE of graph
+        launches with the host actions of the collective points between them (FollowerEngine._capture_training_dp)."""
         self.engine, self.optimizers = engine, list(optimizers)
         groups = sum(len(o.live_groups()) for o in self.optimizers)
         if groups > 3:
@@ -314,6 +317,8 @@ class TrainingGraph:
         self.stream = torch.cuda.Stream(device=device)
         cur = torch.cuda.current_stream(device)
         self.stream.wait_stream(cur)
+        self.segments = None
+        hooked = ()
         try:
             with torch.cuda.stream(self.stream):
                 self._store()
@@ -321,9 +326,13 @@ class TrainingGraph:
                 torch.cuda.synchronize(device)
                 invalidate_caches()                     # every derived weight copy is refreshed INSIDE the graph
                 keep = (engine.site_next, engine.iteration, [o.host_steps() for o in self.optimizers])
-                self.graph = torch.cuda.CUDAGraph()
-                with graph_capture(self.graph, self.stream):
-                    self.state = body()
+                if segmented is None:
+                    self.graph = torch.cuda.CUDAGraph()
+                    with graph_capture(self.graph, self.stream):
+                        self.state = body()
+                else:
+                    hooked = tuple(segmented)
+                    self._capture_segments(engine, hooked, body, device)
                 # the capture advanced the host mirrors without running anything
                 engine.site_next, engine.iteration = keep[0], keep[1]
                 for o, st_ in zip(self.optimizers, keep[2]):
@@ -331,10 +340,60 @@ class TrainingGraph:
             cur.wait_stream(self.stream)
         finally:
             engine.site_word = None
+            engine.collective_hook = None
+            for h in hooked:
+                h.hook = None
             for o in self.optimizers:
                 o.bind_device_steps(None)
         self.stride = self.state.site_stride
         self.replays = 0
+
+    def _capture_segments(self, engine, hooked, body, device):
+        """Captures `body()` as a chain of graphs cut at its collective points.  At a cut: every stream the body has
+        forked from the capture stream and not joined yet (the engine lists them in `_open_forks`) is joined, the
+        capture ends, the host action is RECORDED (not run: a capture executes nothing), a new capture begins in the
+        same memory pool and the forks are re-opened, so the launches that follow on a side stream land in it."""
+        import gc
+        origin = self.stream
+        pool = torch.cuda.graph_pool_handle()
+        self.segments = []
+        cur = {'g': None}
+
+        def begin():
+            cur['g'] = torch.cuda.CUDAGraph()
+            # (thread_local: a process group's watchdog thread may touch the runtime while this thread captures)
+            cur['g'].capture_begin(pool=pool, capture_error_mode='thread_local')
+
+        def end(action):
+            cur['g'].capture_end()
+            self.segments.append((cur['g'], action))
+
+        def cut(action):
+            here = torch.cuda.current_stream(device)
+            forks = [s_ for s_ in list(getattr(engine, '_open_forks', ())) + [here] if s_ != origin]
+            for s_ in forks:
+                origin.wait_stream(s_)
+            with torch.cuda.stream(origin):
+                end(action)
+                begin()
+            for s_ in forks:
+                s_.wait_stream(origin)
+
+        torch.cuda.synchronize(device)
+        gc.collect()
+        was = gc.isenabled()
+        gc.disable()                                     # (see graph_capture: no finaliser may run inside a capture)
+        engine.collective_hook = cut
+        for h in hooked:
+            h.hook = cut
+        try:
+            begin()
+            self.state = body()
+            end(None)
+        finally:
+            if was:
+                gc.enable()
+        self.graph = None
 
     def _store(self):
         steps = [s for o in self.optimizers for s in o.host_steps()] + [0, 0, 0]
@@ -346,7 +405,13 @@ class TrainingGraph:
         overwritten by every replay; `state.site0` is the host mirror of the sites this replay uses."""
         eng = self.engine
         self._store()
-        self.graph.replay()
+        if self.segments is None:
+            self.graph.replay()
+        else:
+            for g, action in self.segments:              # (one stream: every host action is ordered behind its segment)
+                g.replay()
+                if action is not None:
+                    action()
         self.state.site0 = eng.site_next
         eng.site_next += self.stride
         eng.iteration += 1

@@ -17,7 +17,7 @@ def test_library_builds_and_loads():
     __graft_entry__.build()
     from speaker_follower_amd import _lib
     assert os.path.exists(_lib.LIB_PATH)
-    assert _lib.lib.sf_abi_version() == 8
+    assert _lib.lib.sf_abi_version() == 9
     from speaker_follower_amd import build
     assert _lib.lib.sf_build_id().decode() == build.build_id() == build.lib_build_id()
     assert _lib.lib.sf_workspace_bytes() >= 32 << 20

@@ -247,3 +247,44 @@ def test_bench_strong_scaling_two_ranks_on_one_gpu_over_gloo(tmp_path):
     assert d['train_dp']['scaling'] == 'strong' and d['train_dp']['global_batch'] == 18
     t = json.load(open(tmp_path / 'x.json'))['train_dp']
     assert t['scaling'] == 'strong' and t['global_batch'] == 18 and t['rows_this_rank'] == 9 and 'strong' not in t
+
+
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+@pytest.mark.parametrize('backend,world,feedback', [('gloo', 2, 'sample'), ('gloo', 2, 'teacher'), ('nccl', 1, 'sample')])
+def test_data_parallel_iteration_as_graph_segments(backend, world, feedback):
+    """a process group no longer forces the training iteration back to launch-by-launch issue.
+    FollowerEngine.capture_training under a group captures the iteration as SEGMENTS cut at the collective points
+    (count-table all-reduce, the three gradient buckets, the wait): per rank the replayed iterations give the eager
+    data-parallel loop's losses, sampled actions, Adam steps and weights; every rank ends with the same weights."""
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK')}
+        env.update(RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_graph_worker.py'), backend, feedback],
+                                      env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        so, se = p.communicate(timeout=900)
+        assert p.returncode == 0, so[-1500:] + se[-4000:]
+        outs.append(json.loads([l for l in so.splitlines() if l.startswith('DP_GRAPH_WORKER ')][-1][len('DP_GRAPH_WORKER '):]))
+    for o in outs:
+        print({k: o[k] for k in ('rank', 'rows', 'segments', 'losses_eager', 'losses_graph', 'weight_rel_diff')})
+        assert o['segments'] == 6                                   # counts | bucket 0 | bucket 1 | bucket 2 | wait | (Adam)
+        assert o['actions_equal'] and o['steps'][0] == o['steps'][1] == [4, 4]
+        np.testing.assert_allclose(o['losses_graph'], o['losses_eager'], rtol=2e-6)
+        assert len(set(o['losses_eager'])) == 4 and o['weights_finite'] and o['moved'] > 0
+        assert o['weight_rel_diff'] <= 2e-6                          # (two-stream backward: accumulation order across streams)
+    sums = outs[0]['weight_sums_by_rank']
+    assert all(abs(s - sums[0]) <= 1e-9 * abs(sums[0]) for s in sums)       # replicas stay replicas
+    if world > 1:
+        assert outs[0]['losses_eager'] == outs[1]['losses_eager']           # every rank holds the GLOBAL loss
