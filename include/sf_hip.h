@@ -849,6 +849,9 @@ int sf_gate_product_is_strict(void);
  * error-free operand splitting (csrc/sf_gemm.hip: gemm_nt_split_kernel; same fp32 accuracy class, measured closer
  * to the exact sum, 6/16 of the matrix-pipe time).  For A/B timing and for the accuracy tests. */
 void sf_debug_gate_product_f32(int on);
+/* folded inference chain (ABI 9): 1 (default) = attention partials beside r and their merge beside scoring + glue;
+ * 0 = partials, ticket and merge in one launch beside r */
+void sf_debug_fold_merge_with_glue(int on);
 /* A/B switch (round 5): on == 0 sends the many-row products (M >= 512: the speaker's teacher-forced head over all S*B rows,
  * the beam search's flat steps) back to the register-streaming kernel of rounds 1-4 instead of the LDS-tiled 128 x 128
  * bf16x6 kernel (csrc/sf_gemm.hip: gemm_nt_big_kernel; the default).  Bit 1 of `on` (on == 3) keeps the kernel but turns off

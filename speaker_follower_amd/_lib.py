@@ -155,6 +155,7 @@ _SIGNATURES = {
     'sf_build_id': (C.c_char_p, []),
     'sf_debug_persist_timeout': (None, [C.c_longlong]),
     'sf_debug_gate_product_f32': (None, [C.c_int]),
+    'sf_debug_fold_merge_with_glue': (None, [C.c_int]),
     'sf_debug_precise_attention': (None, [C.c_int]),
     'sf_debug_many_row_product': (None, [C.c_int]),
     'sf_debug_grouped_weight_gradients': (None, [C.c_int]),

@@ -189,6 +189,7 @@ static LstmPwBwd cell_pw_bwd(const float* gates, const float* c0, const float* c
     return p;
 }
 
+static int g_fold_merge_with_glue = 1;      // sf_debug_fold_merge_with_glue (0: partials + merge in ONE launch, phase 0)
 static int g_bptt_part = 0;        // EXPERIMENT (sf_debug_bptt_part): 1 = issue the heads only, 2 = the tails only (no waits)
 static int g_bptt_flags = 0;       // sf_debug_bptt_flags: per-step device flags between the two chains of the backward instead of events
                                    // (measured equal; off by default)
@@ -508,6 +509,7 @@ int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, f
 }
 void sf_gate_product_strict(int on) { sf::g_nt_force_f32 = on ? 1 : 0; }
 int sf_gate_product_is_strict(void) { return sf::g_nt_force_f32 != 0; }
+void sf_debug_fold_merge_with_glue(int on) { g_fold_merge_with_glue = on; }
 void sf_debug_precise_attention(int on) { sf::g_precise_attention = on; }
 void sf_debug_tn_split_min_rows(int rows) { sf::g_tn_split_min_rows = rows < 0 ? 4096 : rows; }
 size_t sf_workspace_fault_offset(size_t ws_bytes) {
@@ -779,7 +781,8 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     const sf_softdot_w* tw = &w->text;
     const sf_visual_w* vw = &w->visual;
     bool paired = X_next && vw->w_v_t;     // (a scoring fold, if any, is applied by scoring_fwd_i)
-    if ((paired || query_only) && tf && !w->fold && !ctx_row && !d_h.on() && tw->w_out && w->action.w_a_t) {
+    const bool last_step = !X_next && !tn;      // (nothing of a next step to prepare: the text chain alone)
+    if ((paired || query_only || last_step) && tf && !w->fold && !ctx_row && !d_h.on() && tw->w_out && w->action.w_a_t) {
         // Folded text stage (inference; sf_attention.hip: text_fold_body): FOUR dependent launches behind the cell
         // instead of six:
         //   (1) folded text attention (2 groups per sample)  ||  y = W_out[:, H:] h1  ||  t_v' = W_h h1 + b_h
@@ -797,9 +800,16 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         SmallPlan py, pv, pta, pq, pr;
         bool ok = tpart && ybuf && (part || !paired) && af.tickets() &&
             plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK &&
-            plan_linear(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, &pv) == SF_OK &&
-            plan_linear(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, &pq) == SF_OK &&
             plan_linear(tp->wt, D, w->action.w_a_t, D, nullptr, B, F, D, EPI_NONE, tp->r, F, &pr) == SF_OK;
+        if (ok && !last_step) {
+            ok = plan_linear(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, &pv) == SF_OK &&
+                 plan_linear(tn->t_v, D, vw->w_v_t, D, nullptr, B, F, D, EPI_NONE, tn->q, F, &pq) == SF_OK;
+        } else if (ok) {                                       // no next step: the second bodies of (1) and (2) are empty
+            pv = py;
+            pv.gx = pv.gy = 0;
+            pq = pr;
+            pq.gx = pq.gy = 0;
+        }
         if (ok) {
             Seg sg{ybuf, H, w->action.w_h, H, H};
             LinearOut o{};
@@ -817,10 +827,18 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
                                                      py, pv, st);
             if (rc == SF_OK) {
                 TRY(pair_apro_small(pta, pq, st));
-                if (paired)
+                if (paired && glue && g_fold_merge_with_glue) {
+                    // partials beside r, their merge beside the scoring + glue launch (same depth, no in-launch ticket)
+                    TRY(pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, nullptr, pr, st, 1));
+                    const int rc2 = pair_score_merge(us, B, D, tp->r, tp->wt, w->action.b_a, w->action.b_out,
+                                                     make_glue(us, B, tp->logit, glue), xn, tn->alpha_v, tn->xin + F, 2 * F,
+                                                     dn_in, F, part, st);
+                    return rc2;                 // (its shape limits are score_glue_fwd's and pair_vis_small's)
+                } else if (paired) {
                     TRY(pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, af.tickets(), pr, st, 0));
-                else
+                } else {
                     TRY(launch_small_plan_x(pr, st));
+                }
                 if (glue)
                     return score_glue_fwd(us, B, D, tp->r, tp->wt, w->action.b_a, w->action.b_out,
                                           make_glue(us, B, tp->logit, glue), st);

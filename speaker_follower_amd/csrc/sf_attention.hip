@@ -644,10 +644,9 @@ __global__ __launch_bounds__(SC_NW * 64) void score_fwd_kernel(ScoreArgs a) {
 // Scoring + per-step glue fused (one dependent stage instead of two): wave a keeps candidate a's row
 // in registers, the 16 logits meet in LDS, wave 0 masks / soft-maxes / picks the action, and the wave
 // that owns the chosen row writes dropout(u_next) straight into the next step's LSTM input.
-__global__ __launch_bounds__(SC_NW * 64) void score_glue_kernel(ScoreArgs a, FGlue g) {
+__device__ __forceinline__ void score_glue_body(const ScoreArgs& a, const FGlue& g, int b) {
     __shared__ float s_logit[64];
     __shared__ int s_at;
-    const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int A = a.src.A;
     const int n4 = (a.src.IMG + a.src.LOC) >> 2;
@@ -689,6 +688,8 @@ __global__ __launch_bounds__(SC_NW * 64) void score_glue_kernel(ScoreArgs a, FGl
         }
     }
 }
+
+__global__ __launch_bounds__(SC_NW * 64) void score_glue_kernel(ScoreArgs a, FGlue g) { score_glue_body(a, g, blockIdx.x); }
 
 __global__ __launch_bounds__(SC_NW * 64) void score_bwd_kernel(ScoreArgs a) {
     __shared__ float4 slots[SC_SLOTS][SC_CPL * 64];
@@ -796,6 +797,18 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArg
     }
 }
 
+
+// scoring + glue of step t beside the merge of the attention partials of step t+1 (folded inference chain: the two
+// halves of the next step's LSTM input -- u_next from the glue, the attended feature from the merge -- land in one launch)
+__global__ __launch_bounds__(SC_NW * 64) void pair_score_merge_kernel(ScoreArgs a, FGlue g, int nb, VisArgs v, VisSplit sp) {
+    const int bid = blockIdx.x;
+    if (bid < nb) {
+        score_glue_body(a, g, bid);
+    } else {
+        if (threadIdx.x >= VSP_NW * 64) return;
+        visual_split_body<2>(v, sp, 0, bid - nb);
+    }
+}
 
 
 // =================================================================================================
@@ -912,10 +925,17 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_textfold_small_small_ke
 template <int MTB>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_apro_small_kernel(SmallArgs a, int gxa, int na, SmallArgs b, int gxb) {
     const int bid = blockIdx.x;
-    if (bid < na)
+    if (bid < na) {
         small_gemm_body<1, 4, false, false, true>(a, bid % gxa, bid / gxa);
-    else
+        if ((int)gridDim.x == na && a.apro_alpha)                 // (no second body -- an episode's last step)
+            apro_write_alpha(a.apro_part, a.apro_stride, a.sg.s0.K, a.apro_alpha, a.apro_L, a.apro_LG, a.M, bid, na);
+    } else {
         small_gemm_body<MTB, 2>(b, (bid - na) % gxb, (bid - na) / gxb);
+        // (the tape's merged attention weights: written by the blocks of the SHORTER body)
+        if (a.apro_alpha)
+            apro_write_alpha(a.apro_part, a.apro_stride, a.sg.s0.K, a.apro_alpha, a.apro_L, a.apro_LG, a.M, bid - na,
+                             (int)gridDim.x - na);
+    }
 }
 
 // Deferred gradient of the instruction context (model.py:129-139 backward, summed over an episode):
@@ -1091,6 +1111,22 @@ int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float
     return launch_status();
 }
 
+// score_glue_fwd beside the phase-2 merge of visual-attention partials written by an earlier phase-1 launch
+int pair_score_merge(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
+                     const float* b_out, const FGlue& g, const PanoSrc& psrc, float* alpha, float* out, int ldo,
+                     const Dropout& drop, int drop_col0, float* split_part, hipStream_t st) {
+    const int F = src.IMG + src.LOC;
+    if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) || (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
+        return SF_ERR_UNSUPPORTED;
+    if (!split_part || psrc.V <= (VSP_G - 1) * VSP_RPG || psrc.V > VSP_G * VSP_RPG || B > 256 || (ldo & 3))
+        return SF_ERR_UNSUPPORTED;
+    ScoreArgs a{src, F, nullptr, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr, CeSrc{}};
+    VisArgs va{psrc, nullptr, 0, alpha, out, ldo, drop, drop_col0};
+    const VisSplit sp{split_part, nullptr, g_trace};
+    SF_LAUNCH(pair_score_merge_kernel, dim3(2 * B), dim3(SC_NW * 64), 0, st, a, g, B, va, sp);
+    return launch_status();
+}
+
 int score_bwd(const CandSrc& src, int B, const float* dlogit, float* dr, float* dc,
               hipStream_t st, const CeSrc* ce) {
     const int F = src.IMG + src.LOC;
@@ -1233,7 +1269,7 @@ int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float
                    unsigned* split_counter, const SmallPlan& b, hipStream_t st, int phase) {
     const int F = src.IMG + src.LOC;
     // (the r = W_a^T wt product of the folded text chain: K = D = 256 -> two chunks per wave)
-    const bool wide = b.cpw == 2 && (b.mt == 1 || b.mt == 2 || b.mt == 4) && phase == 0;
+    const bool wide = b.cpw == 2 && (b.mt == 1 || b.mt == 2 || b.mt == 4) && phase != 2;
     if (!wide && !(b.mt == 1 && (b.cpw == 8 || (phase == 2 && b.cpw == 4)))) return SF_ERR_UNSUPPORTED;
     if (!split_part || (phase == 0 && !split_counter) || src.V <= (VSP_G - 1) * VSP_RPG || src.V > VSP_G * VSP_RPG ||
         B > 256 ||
@@ -1244,12 +1280,18 @@ int pair_vis_small(const PanoSrc& src, int B, const float* vec, int ldvec, float
     const int nv = (phase == 2 ? 1 : VSP_G) * B, nb = b.gx * b.gy;
     const dim3 grid(nv + nb), block(SMALL_WAVES * 64);
     const VisSplit sp{split_part, split_counter, g_trace};
-    if (wide && b.mt == 4)
+    if (wide && b.mt == 4 && phase == 0)
         SF_LAUNCH((pair_vis_small_kernel<4, 2, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
-    else if (wide && b.mt == 2)
+    else if (wide && b.mt == 4)
+        SF_LAUNCH((pair_vis_small_kernel<4, 2, 1>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (wide && b.mt == 2 && phase == 0)
         SF_LAUNCH((pair_vis_small_kernel<2, 2, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
-    else if (wide)
+    else if (wide && b.mt == 2)
+        SF_LAUNCH((pair_vis_small_kernel<2, 2, 1>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (wide && phase == 0)
         SF_LAUNCH((pair_vis_small_kernel<1, 2, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (wide)
+        SF_LAUNCH((pair_vis_small_kernel<1, 2, 1>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     else if (phase == 0)
         SF_LAUNCH((pair_vis_small_kernel<1, 8, 0>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     else if (phase == 1)

@@ -82,13 +82,13 @@ __device__ __forceinline__ void upfront_load_apro(Frags<MT, CPW>& f, const Seg2&
     }
 }
 
-// alpha[row, l] = e_g[l - g LG] * s_g for the MT * 16 rows of a block (every thread of the block takes part)
-template <int MT>
+// alpha[row, l] = e_g[l - g LG] * s_g: the merged text-attention weights of the tape.  Slice `j` of `nj` of the M * L
+// elements (the launcher hands the slices to blocks that have time to spare: the plain product beside the A-prologue one)
 __device__ __forceinline__ void apro_write_alpha(const float* part, int stride, int K, float* alpha, int L, int LG,
-                                                 int m0, int M) {
-    for (int e = threadIdx.x; e < MT * 16 * L; e += blockDim.x) {
-        const int row = m0 + e / L, l = e % L;
-        if (row >= M) break;
+                                                 int M, int j, int nj) {
+    const int total = M * L, per = (total + nj - 1) / nj;
+    for (int e = j * per + (int)threadIdx.x; e < min(total, (j + 1) * per); e += blockDim.x) {
+        const int row = e / L, l = e % L;
         const float* r0 = part + (size_t)row * 2 * stride;
         const float ma = r0[K + 62], la = r0[K + 63], mb = r0[stride + K + 62], lb = r0[stride + K + 63];
         const float mm = fmaxf(ma, mb);
@@ -207,8 +207,6 @@ __device__ __forceinline__ void small_gemm_body(const SmallArgs& a, int bx, int 
         if (a.r1_s) e_r1[i] = a.r1_s[row] * a.r1_v[ecol];
     }
 
-    if (APRO && bx == 0 && a.apro_alpha)                                   // block-uniform
-        apro_write_alpha<MT>(a.apro_part, a.apro_stride, a.sg.s0.K, a.apro_alpha, a.apro_L, a.apro_LG, m0, a.M);
     const int c_lo = (wave * a.sg.total) / SMALL_WAVES;
     const int c_hi = ((wave + 1) * a.sg.total) / SMALL_WAVES;
     f32x4 acc[MT];

@@ -194,6 +194,10 @@ int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint
 size_t text_fold_part_floats(int B, int H);
 int text_fold_group_rows(int L);
 int pair_apro_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st);
+struct FGlue;
+int pair_score_merge(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
+                     const float* b_out, const FGlue& g, const PanoSrc& psrc, float* alpha, float* out, int ldo,
+                     const Dropout& drop, int drop_col0, float* split_part, hipStream_t st);
 
 struct FGlue;
 int follower_glue_fwd(const FGlue& g, hipStream_t st);

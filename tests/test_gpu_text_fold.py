@@ -47,9 +47,9 @@ def test_folded_text_attention_equals_the_unfolded_path_and_the_oracle(B, S, min
         torch.cuda.synchronize()
         assert bool(getattr(st, 'text_folded', False)) == fold
         res[fold] = (st.logits.cpu().numpy().copy(), st.actions.cpu().numpy().copy(), float(st.loss_buf),
-                     st.tape['h1'].cpu().numpy().copy(), st.tape['alpha'][:S - 1].cpu().numpy().copy())
+                     st.tape['h1'].cpu().numpy().copy(), st.tape['alpha'].cpu().numpy().copy())
     (lf, af, lossf, hf, alf), (lu, au, lossu, hu, alu) = res[True], res[False]
-    # the text-attention weights of the tape (every step but the last runs folded): distributions, equal to the unfolded ones
+    # the text-attention weights of the tape: distributions, equal to the unfolded ones
     np.testing.assert_allclose(alf.sum(-1), 1.0, atol=1e-5)
     np.testing.assert_allclose(alf, alu, rtol=1e-4, atol=1e-6)
     fin = np.isfinite(lu)
