@@ -411,6 +411,27 @@ def kernel_work(name, B, S, T, A_mean, dims):
     if 'gemm_nt_tiled' in name:
         return (2.0 * B * (2 * F + H) * 4 * H, f4 * (4 * H * (2 * F + H) + B * (2 * F + H) + B * 4 * H),
                 'decoder LSTMCell gate product [B,2F+H] x [4H,2F+H]^T')
+    # ---- the folded inference chain (round 6: text attention over ctx W_in / ctx W_out[:, :H]^T)
+    if 'pair_textfold_small_small' in name:
+        fl, by = small(B, H, H)
+        fl2, by2 = small(B, D, H)
+        return (fl + fl2 + 4.0 * B * T * H, by + by2 + f4 * 2 * B * T * H,
+                'folded text attention (scores over ctx W_in, sum over ctx W_out1^T; 4 groups per sample merged in the '
+                'launch) || y = W_out[:, H:] h1 || t_v = W_h h1 + b')
+    if 'pair_apro_small' in name:
+        fl, by = small(B, D, H)
+        fl2, by2 = small(B, F, D)
+        return (fl + fl2, by + by2 + f4 * B * H, 't_a = W_h tanh(z + y) + b (A-prologue) || q = W_v^T t_v')
+    if 'pair_vis_small_kernel<4, 2' in name or 'pair_vis_small_kernel<2, 2' in name or 'pair_vis_small_kernel<1, 2' in name:
+        fl, by = small(B, F, D)
+        return (fl + 4.0 * B * V * F, by + f4 * B * V * F,
+                'visual-attention partials of step t+1 (panorama rows read once) || r = W_a^T wt')
+    if 'pair_score_merge' in name:
+        return (2.0 * B * A_mean * F + 2.0 * B * F, f4 * B * (A_mean + 1) * F + f4 * B * F + f4 * 3 * B * F,
+                'candidate rows . r, mask, CE, argmax, u_next gather || merge of the attention partials')
+    if 'gemm_nt_big_kernel' in name:
+        return (2.0 * B * T * H * H, f4 * (H * H + 2 * B * T * H),
+                'once per episode: ctx W_in and ctx W_out[:, :H]^T ([B T, H] x [H, H], many-row bf16x6 kernel)')
     if 'pair_vis_small_kernel<1, 8' in name:
         fl, by = small(B, H, 2 * H)
         return (fl + 4.0 * B * V * F, by + f4 * B * V * F,

@@ -74,6 +74,7 @@ struct Arena {
 };
 constexpr size_t SYNC_WORDS = 2048;        // [0, 1024): per-sample tickets of the split attention kernels
 constexpr size_t PERSIST_TICKET = 1100;   // [1100, 1140): arrival counter + placement record of the persistent launches
+constexpr size_t TEXT_TICKET = 1200;      // [1200, 1712): per-sample tickets of the folded text attention (B <= 512)
 
 inline Arena arena(void* ws, size_t bytes) {
     const size_t n = ws ? bytes / 4 : 0;
@@ -785,7 +786,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     if ((paired || query_only || last_step) && tf && !w->fold && !ctx_row && !d_h.on() && tw->w_out && w->action.w_a_t) {
         // Folded text stage (inference; sf_attention.hip: text_fold_body): FOUR dependent launches behind the cell
         // instead of six:
-        //   (1) folded text attention (2 groups per sample)  ||  y = W_out[:, H:] h1  ||  t_v' = W_h h1 + b_h
+        //   (1) folded text attention (4 groups per sample, merged by the last arriver)  ||  y = W_out[:, H:] h1  ||  t_v' = W_h h1 + b_h
         //   (2) t_a = W_h tanh(z + y) + b_h, wt = t_a * w_out (A-prologue)   ||  q' = W_v^T t_v'
         //   (3) r = W_a^T wt            ||  visual attention of step t+1 (partials, ticket, merge by the last arriver)
         //   (4) scoring + glue
@@ -796,9 +797,11 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         Arena af = ar;                                           // (released when this branch is left)
         float* tpart = af.take(text_fold_part_floats(B, H));
         float* ybuf = af.take((size_t)B * H);
+        float* zbuf = af.take((size_t)B * H);
+        unsigned* tcount = af.tickets() ? af.tickets() + TEXT_TICKET : nullptr;
         float* part = (paired && B <= 1024) ? af.take(visual_attn_split_floats(B, F)) : nullptr;
         SmallPlan py, pv, pta, pq, pr;
-        bool ok = tpart && ybuf && (part || !paired) && af.tickets() &&
+        bool ok = tpart && ybuf && zbuf && (part || !paired) && tcount && B <= 512 &&
             plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK &&
             plan_linear(tp->wt, D, w->action.w_a_t, D, nullptr, B, F, D, EPI_NONE, tp->r, F, &pr) == SF_OK;
         if (ok && !last_step) {
@@ -816,15 +819,12 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
             o.y = tp->wt; o.ldy = D; o.bias = w->action.b_h; o.mul = w->action.w_out; o.y_pre = tp->t_a;
             o.ldy_pre = D; o.epi = EPI_MUL;
             ok = linear_small_plan(&sg, 1, B, D, o, &pta) && pta.mt == 1 && pta.cpw == 4 && pq.cpw == 2 && pr.cpw == 2;
-            pta.args.apro_part = tpart;
-            pta.args.apro_stride = H + 64;
-            pta.args.apro_alpha = tp->alpha;                      // the tape's text-attention weights [B, L]
-            pta.args.apro_L = L;
-            pta.args.apro_LG = text_fold_group_rows(L);
+            pta.args.apro_part = zbuf;                            // (the merged attention sum of launch (1))
+            pta.args.apro_stride = H;
         }
         if (ok) {
             const int rc = pair_textfold_small_small(tf->ctx_q, tf->ctx_o, ctx_mask, B, L, H, tp->cat2 + H, 2 * H, tpart,
-                                                     py, pv, st);
+                                                     tcount, zbuf, tp->alpha, py, pv, st);
             if (rc == SF_OK) {
                 TRY(pair_apro_small(pta, pq, st));
                 if (paired && glue && g_fold_merge_with_glue) {

@@ -818,14 +818,15 @@ __global__ __launch_bounds__(SC_NW * 64) void pair_score_merge_kernel(ScoreArgs 
 // chain for good (sf_text_fold_build, once per episode):
 //     ctx_q = ctx W_in           s_l = ctx_q[l] . h1                     (no t = W_in h1 product per step)
 //     ctx_o = ctx W_out[:, :H]^T W_out [wc ; h1] = sum alpha_l ctx_o[l] + W_out[:, H:] h1
-// A step then needs, behind the cell: this body (scores + softmax + z = sum e_l ctx_o[l]) BESIDE the product
-// y = W_out[:, H:] h1 in one launch, and h~ = tanh(z / l + y) is formed by the A-prologue of the next product
+// A step then needs, behind the cell: this body (scores + softmax + z = sum alpha_l ctx_o[l]) BESIDE the product
+// y = W_out[:, H:] h1 in one launch, and h~ = tanh(z + y) is formed by the A-prologue of the next product
 // (t_a = W_h h~ + b: sf_gemm_small.h, APRO) -- two dependent launches fewer per decode step.
-// The body reads TWO context tensors, so a sample is split over TXF_G = 2 workgroups (positions [g Lg, (g + 1) Lg)):
-// each pulls what the unfolded body pulled (a CU sustains ~25-45 GB/s of loads; bytes per workgroup are what the
-// stage costs) and keeps a flash-style partial (m, l, unnormalised z) that the consumer merges.
+// The body reads TWO context tensors, so a sample is split over TXF_G = 4 workgroups (positions [g Lg, (g + 1) Lg)): a
+// CU sustains ~25-45 GB/s of loads and bytes per workgroup are what the stage costs.  Each keeps a flash-style piece
+// (m, l, unnormalised z); the last arriver of a sample merges them in the same launch (measured, round 6: two groups
+// merged by the consumer's prologue: stage 10.3 us + consumer 9.4 us; four groups merged here: 10.9 + 7.4).
 // =================================================================================================
-constexpr int TXF_G = 2;
+constexpr int TXF_G = 4;          // workgroups per sample (fixed: the per-sample ticket arithmetic counts in fours)
 
 struct TxtFoldArgs {
     const float* ctx_q;    // [B, L, H]
@@ -835,16 +836,26 @@ struct TxtFoldArgs {
     const float* vec;      // h1 as the text attention sees it (eval: h1 itself) [B, ldvec]
     int ldvec;
     float* part;           // [B][TXF_G][H + 64]: z | e[l - g Lg] (<= 62) | m at H + 62 | l at H + 63
+    unsigned* counter;     // [B] monotonic tickets (zero before the first launch; every launch adds TXF_G per sample)
+    float* z;              // out [B, H]: sum_l alpha_l ctx_o[l] (merged, normalised)
+    float* alpha;          // out [B, L]: the attention weights (the tape's contract), or null
 };
 
+// One group's share -- positions [g LG, (g + 1) LG) of sample b: scores, local softmax piece (m, l, e), unnormalised
+// z = sum e_l ctx_o[l] -- published WRITE-THROUGH like the split visual attention's partials (visual_split_body<0>:
+// sc1 stores, drain, agent-scope ticket; no cache-wide fence), and the workgroup that draws the sample's LAST ticket
+// merges the TXF_G pieces (sc1 loads) into z [H] and alpha [L]: no spinning, no extra launch.
 template <int RPW>
 __device__ __forceinline__ void text_fold_body(const TxtFoldArgs& a, int g, int b) {
     constexpr int NW = SMALL_WAVES, SL = 4, LG = NW * RPW;
     static_assert(LG <= 62, "a group's weights live in 62 record slots");
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
     __shared__ float4 slots[SL][TXT_CPL * 64];
     __shared__ float s_score[LG];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int L = a.L, n4 = a.H >> 2;
+    __shared__ int s_last;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L = a.L, H = a.H, n4 = H >> 2;
+    const int pstride = H + 64;
     const float4* cq = reinterpret_cast<const float4*>(a.ctx_q) + (size_t)b * L * n4;
     const float4* co = reinterpret_cast<const float4*>(a.ctx_o) + (size_t)b * L * n4;
     const bool use_mask = a.mask != nullptr;
@@ -897,14 +908,68 @@ __device__ __forceinline__ void text_fold_body(const TxtFoldArgs& a, int g, int 
 #pragma unroll
         for (int i = 0; i < TXT_CPL; ++i) f4fma(p[i], er, xo[r][i]);
     }
-    float* rec = a.part + ((size_t)b * TXF_G + g) * (a.H + 64);
-    block_row_sum<TXT_CPL, NW, SL>(p, slots, n4, [&](int c, float4 t) { reinterpret_cast<float4*>(rec)[c] = t; });
+    float* r0 = a.part + (size_t)b * TXF_G * pstride;
+    float* rec = r0 + (size_t)g * pstride;
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, pstride * 4, 0x00020000);
+    block_row_sum<TXT_CPL, NW, SL>(p, slots, n4, [&](int c, float4 t) {
+        const v4u w{__float_as_uint(t.x), __float_as_uint(t.y), __float_as_uint(t.z), __float_as_uint(t.w)};
+        __builtin_amdgcn_raw_buffer_store_b128(w, rs, c * 16, 0, 16);
+    });
     if (wave == 0) {
-        if (lane < LG) rec[a.H + lane] = e;
+        if (lane < LG) __hip_atomic_store(rec + H + lane, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (lane == 0) {
-            rec[a.H + 62] = m;
-            rec[a.H + 63] = lsum;
+            __hip_atomic_store(rec + H + 62, m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(rec + H + 63, lsum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // EVERY storing wave drains
+    __syncthreads();
+    if (tid == 0)
+        s_last = (__hip_atomic_fetch_add(a.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &
+                  (unsigned)(TXF_G - 1)) == (unsigned)(TXF_G - 1);
+    __syncthreads();
+    if (!s_last) return;
+
+    // ---- the sample's last arriver merges the pieces
+    auto ldf = [&](float* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    float mg[TXF_G], kk[TXF_G];
+    float M = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < TXF_G; ++k) {
+        mg[k] = ldf(r0 + (size_t)k * pstride + H + 62);
+        M = fmaxf(M, mg[k]);
+    }
+    float Lsum = 0.f;
+#pragma unroll
+    for (int k = 0; k < TXF_G; ++k) {
+        kk[k] = mg[k] > -INFINITY ? expf(mg[k] - M) : 0.f;      // an empty group: weight 0 (its l is 0 too)
+        Lsum = fmaf(ldf(r0 + (size_t)k * pstride + H + 63), kk[k], Lsum);
+    }
+    const float inv = 1.0f / Lsum;                              // (a sample always has an unmasked position)
+#pragma unroll
+    for (int k = 0; k < TXF_G; ++k) kk[k] *= inv;
+    if (a.alpha) {
+        for (int l = tid; l < L; l += NW * 64) {
+            const int gk = l / LG;
+            float w = kk[0];
+#pragma unroll
+            for (int k = 1; k < TXF_G; ++k) w = gk == k ? kk[k] : w;
+            a.alpha[(size_t)b * L + l] = ldf(r0 + (size_t)gk * pstride + H + (l - gk * LG)) * w;
+        }
+    }
+    const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(r0, 0, TXF_G * pstride * 4, 0x00020000);
+    float4* zrow = reinterpret_cast<float4*>(a.z + (size_t)b * H);
+    for (int c = tid; c < n4; c += NW * 64) {
+        float4 t = f4zero();
+#pragma unroll
+        for (int k = 0; k < TXF_G; ++k) {
+            const v4u pk = __builtin_amdgcn_raw_buffer_load_b128(rs0, k * pstride * 4 + c * 16, 0, 16);
+            t.x = fmaf(kk[k], __uint_as_float(pk.x), t.x);
+            t.y = fmaf(kk[k], __uint_as_float(pk.y), t.y);
+            t.z = fmaf(kk[k], __uint_as_float(pk.z), t.z);
+            t.w = fmaf(kk[k], __uint_as_float(pk.w), t.w);
+        }
+        zrow[c] = t;
     }
 }
 
@@ -921,21 +986,14 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_textfold_small_small_ke
         small_gemm_body<1, 4>(b, (bid - nt - na) % gxb, (bid - nt - na) / gxb);
 }
 
-// t_a = W_h tanh(z + y) + b (A-prologue) beside q' = W_v^T t_v'
+// t_a = W_h tanh(z + y) + b (A-prologue: z = the merged attention sum of the text_fold launch) beside q' = W_v^T t_v'
 template <int MTB>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_apro_small_kernel(SmallArgs a, int gxa, int na, SmallArgs b, int gxb) {
     const int bid = blockIdx.x;
-    if (bid < na) {
+    if (bid < na)
         small_gemm_body<1, 4, false, false, true>(a, bid % gxa, bid / gxa);
-        if ((int)gridDim.x == na && a.apro_alpha)                 // (no second body -- an episode's last step)
-            apro_write_alpha(a.apro_part, a.apro_stride, a.sg.s0.K, a.apro_alpha, a.apro_L, a.apro_LG, a.M, bid, na);
-    } else {
+    else
         small_gemm_body<MTB, 2>(b, (bid - na) % gxb, (bid - na) / gxb);
-        // (the tape's merged attention weights: written by the blocks of the SHORTER body)
-        if (a.apro_alpha)
-            apro_write_alpha(a.apro_part, a.apro_stride, a.sg.s0.K, a.apro_alpha, a.apro_L, a.apro_LG, a.M, bid - na,
-                             (int)gridDim.x - na);
-    }
 }
 
 // Deferred gradient of the instruction context (model.py:129-139 backward, summed over an episode):
@@ -1159,12 +1217,12 @@ int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
 // The folded text stage of an inference decode step (see text_fold_body): SF_ERR_UNSUPPORTED = shapes outside the
 // instantiations (the caller runs the unfolded stages).
 int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint8_t* mask, int B, int L, int H,
-                              const float* vec, int ldvec, float* part, const SmallPlan& a, const SmallPlan& b,
-                              hipStream_t st) {
+                              const float* vec, int ldvec, float* part, unsigned* counter, float* z, float* alpha,
+                              const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
     if (!(a.mt == 1 && a.cpw == 4 && b.mt == 1 && b.cpw == 4)) return SF_ERR_UNSUPPORTED;
-    if (H > TXT_CPL * 256 || (H & 3) || (ldvec & 3) || L < 1 || L > TXF_G * SMALL_WAVES * 5 || B > 1024)
+    if (H > TXT_CPL * 256 || (H & 3) || (ldvec & 3) || L < 1 || L > TXF_G * SMALL_WAVES * 5 || B > 512 || !counter || !z)
         return SF_ERR_UNSUPPORTED;
-    const TxtFoldArgs ta{ctx_q, ctx_o, mask, L, H, vec, ldvec, part};
+    const TxtFoldArgs ta{ctx_q, ctx_o, mask, L, H, vec, ldvec, part, counter, z, alpha};
     const int nt = TXF_G * B, na = a.gx * a.gy, nb = b.gx * b.gy;
     const dim3 grid(nt + na + nb), block(SMALL_WAVES * 64);
     const int rpw = (L + TXF_G * SMALL_WAVES - 1) / (TXF_G * SMALL_WAVES);
@@ -1179,11 +1237,7 @@ int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint
     return launch_status();
 }
 size_t text_fold_part_floats(int B, int H) { return (size_t)B * TXF_G * (H + 64); }
-// positions per group for a context of L positions (the template the launcher above picks)
-int text_fold_group_rows(int L) {
-    const int rpw = (L + TXF_G * SMALL_WAVES - 1) / (TXF_G * SMALL_WAVES);
-    return SMALL_WAVES * (rpw <= 1 ? 1 : (rpw <= 2 ? 2 : (rpw <= 3 ? 3 : 5)));
-}
+
 
 // a: the product whose A operand the prologue forms (a.args.apro_part set by the caller), b: a plain small product
 int pair_apro_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {

@@ -27,28 +27,20 @@ struct Frags {
     float4 a[CPW][MT];
 };
 
-// a = tanh(s0 z0 + s1 z1 + y) of one float4 (the A-prologue, see SmallArgs::apro_part)
-__device__ __forceinline__ float4 apro_form(const float4& y, const float4& z0, const float4& z1, float s0, float s1) {
-    return make_float4(tanhf(fmaf(s0, z0.x, fmaf(s1, z1.x, y.x))), tanhf(fmaf(s0, z0.y, fmaf(s1, z1.y, y.y))),
-                       tanhf(fmaf(s0, z0.z, fmaf(s1, z1.z, y.z))), tanhf(fmaf(s0, z0.w, fmaf(s1, z1.w, y.w))));
+// a = tanh(z + y) of one float4 (the A-prologue, see SmallArgs::apro_part)
+__device__ __forceinline__ float4 apro_form(const float4& y, const float4& z) {
+    return make_float4(tanhf(z.x + y.x), tanhf(z.y + y.y), tanhf(z.z + y.z), tanhf(z.w + y.w));
 }
 
-// The same loads with the A-prologue: one segment (K = sg.s0.K), A = y [M, lda].
+// The same loads with the A-prologue: one segment (K = sg.s0.K), A = y [M, lda], z [M, stride].
 template <int MT, int CPW>
 __device__ __forceinline__ void upfront_load_apro(Frags<MT, CPW>& f, const Seg2& sg, int c_lo, int c_hi, int n,
-                                                  const int (&mrow)[MT], int kk, const float* part, int stride) {
-    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                                                  const int (&mrow)[MT], int kk, const float* zbuf, int stride) {
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
     const int K = sg.s0.K;
-    float4 bv[CPW], yv[CPW][MT], z0[CPW][MT], z1[CPW][MT];
-    float m0[MT], l0[MT], m1[MT], l1[MT];
+    float4 bv[CPW], yv[CPW][MT], zv[CPW][MT];
     bool ok[CPW];
     // every load first (straight line), the transcendental arithmetic behind them
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const float* r0 = part + (size_t)mrow[t] * 2 * stride;
-        m0[t] = r0[K + 62]; l0[t] = r0[K + 63];
-        m1[t] = r0[stride + K + 62]; l1[t] = r0[stride + K + 63];
-    }
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
         const int c = min(c_lo + i, c_hi - 1);
@@ -59,43 +51,14 @@ __device__ __forceinline__ void upfront_load_apro(Frags<MT, CPW>& f, const Seg2&
 #pragma unroll
         for (int t = 0; t < MT; ++t) {
             yv[i][t] = ld4(sg.s0.A + (size_t)mrow[t] * sg.s0.lda + kc);
-            const float* r0 = part + (size_t)mrow[t] * 2 * stride + kc;
-            z0[i][t] = ld4(r0);
-            z1[i][t] = ld4(r0 + stride);
+            zv[i][t] = ld4(zbuf + (size_t)mrow[t] * stride + kc);
         }
-    }
-    float s0[MT], s1[MT];
-#pragma unroll
-    for (int t = 0; t < MT; ++t) {
-        const float mm = fmaxf(m0[t], m1[t]);                      // (a sample always has one unmasked position: finite)
-        const float w0 = m0[t] > -INFINITY ? expf(m0[t] - mm) : 0.f;
-        const float w1 = m1[t] > -INFINITY ? expf(m1[t] - mm) : 0.f;
-        const float inv = 1.0f / fmaf(l0[t], w0, l1[t] * w1);
-        s0[t] = w0 * inv;
-        s1[t] = w1 * inv;
     }
 #pragma unroll
     for (int i = 0; i < CPW; ++i) {
-        f.b[i] = ok[i] ? bv[i] : z;
+        f.b[i] = ok[i] ? bv[i] : zero;
 #pragma unroll
-        for (int t = 0; t < MT; ++t) f.a[i][t] = ok[i] ? apro_form(yv[i][t], z0[i][t], z1[i][t], s0[t], s1[t]) : z;
-    }
-}
-
-// alpha[row, l] = e_g[l - g LG] * s_g: the merged text-attention weights of the tape.  Slice `j` of `nj` of the M * L
-// elements (the launcher hands the slices to blocks that have time to spare: the plain product beside the A-prologue one)
-__device__ __forceinline__ void apro_write_alpha(const float* part, int stride, int K, float* alpha, int L, int LG,
-                                                 int M, int j, int nj) {
-    const int total = M * L, per = (total + nj - 1) / nj;
-    for (int e = j * per + (int)threadIdx.x; e < min(total, (j + 1) * per); e += blockDim.x) {
-        const int row = e / L, l = e % L;
-        const float* r0 = part + (size_t)row * 2 * stride;
-        const float ma = r0[K + 62], la = r0[K + 63], mb = r0[stride + K + 62], lb = r0[stride + K + 63];
-        const float mm = fmaxf(ma, mb);
-        const float wa = ma > -INFINITY ? expf(ma - mm) : 0.f, wb = mb > -INFINITY ? expf(mb - mm) : 0.f;
-        const float inv = 1.0f / fmaf(la, wa, lb * wb);
-        const int g = l >= LG ? 1 : 0;
-        alpha[(size_t)row * L + l] = r0[g * stride + K + (l - g * LG)] * (g ? wb : wa) * inv;
+        for (int t = 0; t < MT; ++t) f.a[i][t] = ok[i] ? apro_form(yv[i][t], zv[i][t]) : zero;
     }
 }
 
@@ -158,13 +121,9 @@ struct SmallArgs {
     const float* addend; int ld_addend;
     const float* r1_s; const float* r1_v;
     // A-PROLOGUE (APRO bodies only; the folded inference text stage, sf_attention.hip: text_fold_body): the A operand is
-    // not read but FORMED on the fly, a[row, k] = tanh(s0 z0[row, k] + s1 z1[row, k] + y[row, k]), where y = the `A` of
-    // segment 0, z0 / z1 = the two groups' unnormalised attention sums in `apro_part` ([M][2][apro_stride] floats:
-    // z [K] | e .. | m at K + 62 | l at K + 63) and (s0, s1) merge the two softmax pieces of the row.
+    // not read but FORMED on the fly, a[row, k] = tanh(z[row, k] + y[row, k]), where y = the `A` of segment 0 and
+    // z = `apro_part` [M, apro_stride]: the merged attention sum the text_fold launch left.
     const float* apro_part; int apro_stride;
-    // ... and the blocks of column tile 0 also write the merged attention weights alpha[row, l] (the tape's contract):
-    // positions [g LG, (g + 1) LG) of a row are group g's e values times the group's merge scale
-    float* apro_alpha; int apro_L, apro_LG;
 };
 
 // Block (bx, by) of the grid (ceil(N/16), ceil(mtiles/MT)); 512 threads = 8 waves = 8 K-slices of one

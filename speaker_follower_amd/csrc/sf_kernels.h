@@ -189,10 +189,9 @@ int pair_vis_text(const PanoSrc& src, int B, const float* vec, int ldvec, float*
 
 // the folded text stage of an inference decode step (sf_attention.hip: text_fold_body) and its consumer
 int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint8_t* mask, int B, int L, int H,
-                              const float* vec, int ldvec, float* part, const SmallPlan& a, const SmallPlan& b,
-                              hipStream_t st);
+                              const float* vec, int ldvec, float* part, unsigned* counter, float* z, float* alpha,
+                              const SmallPlan& a, const SmallPlan& b, hipStream_t st);
 size_t text_fold_part_floats(int B, int H);
-int text_fold_group_rows(int L);
 int pair_apro_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st);
 struct FGlue;
 int pair_score_merge(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
