@@ -860,6 +860,16 @@ __device__ __forceinline__ void text_fold_body(const TxtFoldArgs& a, int g, int 
     const float4* co = reinterpret_cast<const float4*>(a.ctx_o) + (size_t)b * L * n4;
     const bool use_mask = a.mask != nullptr;
     const uint8_t* mrow = use_mask ? a.mask + (size_t)b * L : reinterpret_cast<const uint8_t*>(cq);
+    // a group whose positions are ALL padding (short instructions: the length-sorted minibatch ends far below L)
+    // pulls nothing: its piece is (m = -inf, l = 0, z = 0) and it only draws its ticket
+    const int lt = g * LG + tid;
+    const bool padded = tid >= LG || lt >= L || (use_mask && mrow[min(lt, L - 1)] != 0);
+    const bool empty = __syncthreads_and(padded) != 0;              // block-uniform
+    float m = -INFINITY, e = 0.f, lsum = 0.f;
+    float4 p[TXT_CPL];
+#pragma unroll
+    for (int i = 0; i < TXT_CPL; ++i) p[i] = f4zero();
+    if (!empty) {
     // straight-line loads, clamped indices, value selects (sf_rows.h): every row of both tensors is in flight at once
     float4 xq[RPW][TXT_CPL], xo[RPW][TXT_CPL];
     uint8_t mk[RPW];
@@ -896,18 +906,16 @@ __device__ __forceinline__ void text_fold_body(const TxtFoldArgs& a, int g, int 
     }
     __syncthreads();
     const float sc = lane < LG ? s_score[lane] : -INFINITY;
-    const float m = wave_max(sc);                                  // -inf: every position of this group is padding
-    const float e = sc > -INFINITY ? expf(sc - m) : 0.f;
-    const float lsum = wave_sum(e);
-    float4 p[TXT_CPL];
-#pragma unroll
-    for (int i = 0; i < TXT_CPL; ++i) p[i] = f4zero();
+    m = wave_max(sc);                                              // -inf: every position of this group is padding
+    e = sc > -INFINITY ? expf(sc - m) : 0.f;
+    lsum = wave_sum(e);
 #pragma unroll
     for (int r = 0; r < RPW; ++r) {
         const float er = __shfl(e, wave * RPW + r, WAVE);
 #pragma unroll
         for (int i = 0; i < TXT_CPL; ++i) f4fma(p[i], er, xo[r][i]);
     }
+    }   // !empty
     float* r0 = a.part + (size_t)b * TXF_G * pstride;
     float* rec = r0 + (size_t)g * pstride;
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(rec, 0, pstride * 4, 0x00020000);
