@@ -288,3 +288,18 @@ def test_data_parallel_iteration_as_graph_segments(backend, world, feedback):
     assert all(abs(s - sums[0]) <= 1e-9 * abs(sums[0]) for s in sums)       # replicas stay replicas
     if world > 1:
         assert outs[0]['losses_eager'] == outs[1]['losses_eager']           # every rank holds the GLOBAL loss
+
+
+def test_agent_train_under_a_process_group_replays_segments():
+    """agents.Seq2SeqAgent.train with an engine that carries a process group and gradient buckets no longer falls back to
+    launch-by-launch issue (agents._graph_trainable): iterations replay as segments, with the fault word reduced over the
+    group before any rank re-issues.  One rank, every collective issued: the numbers of the plain graph loop."""
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    res = subprocess.run([sys.executable, os.path.join(ROOT, 'tests', 'dp_agent_worker.py')], env=env, capture_output=True,
+                         text=True, timeout=900)
+    assert res.returncode == 0, res.stdout[-1500:] + res.stderr[-4000:]
+    o = json.loads([l for l in res.stdout.splitlines() if l.startswith('DP_AGENT_WORKER ')][-1][len('DP_AGENT_WORKER '):])
+    print(o)
+    assert o['segments'] == [0, 6] and o['replays'] == [4, 4] and o['fallbacks'] == [0, 0] and o['finite']
+    np.testing.assert_allclose(o['losses_group'], o['losses_plain'], rtol=2e-6)
+    assert len(set(o['losses_plain'])) == 5 and o['weight_rel_diff'] <= 2e-6
