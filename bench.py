@@ -609,7 +609,20 @@ def print_result(full, result_out, extras_path):
                 written = written or os.path.relpath(path, ROOT)
         except OSError:
             pass
-    h = headline_of(full, written)
+    def shorten(o):                     # six significant digits are more than any of these measurements carries
+        if isinstance(o, float) and o == o and o not in (float('inf'), float('-inf')):
+            return float('%.6g' % o)
+        if isinstance(o, dict):
+            return {k: shorten(v) for k, v in o.items()}
+        if isinstance(o, (list, tuple)):
+            return [shorten(v) for v in o]
+        return o
+    h = shorten(headline_of(full, written))
+    r = h.get('roofline')
+    if isinstance(r, dict) and r.get('peak'):
+        r['frac'] = r['achieved'] / r['peak']            # (exactly the quotient of the two numbers PRINTED beside it)
+        if isinstance(r.get('executed'), dict) and r['executed'].get('peak'):
+            r['executed']['frac'] = r['executed']['tflops'] / r['executed']['peak']
     try:
         line = json.dumps(h, allow_nan=False)
     except ValueError:

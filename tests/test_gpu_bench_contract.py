@@ -46,7 +46,7 @@ def _check_headline(d, steps, warmup):
         # the 6x bf16 work it executes against the dense bf16 peak (executed.frac)
         e = r['executed']
         assert e['dtype'] == 'bf16' and e['peak'] == 2500.0 and 0 < e['frac'] < 1
-        assert abs(e['tflops'] - 6 * r['achieved']) < 1e-6 * e['tflops']
+        assert abs(e['tflops'] - 6 * r['achieved']) < 1e-4 * e['tflops']      # (the line carries six significant digits)
     assert 0 < r['rollout']['flops_frac'] < 1 and 0 < r['rollout']['hbm_frac'] < 1
     assert r['kernel_time_ms_per_rollout'] < 1.5 * d['ms_per_step']
     c = d['cpu_baseline']
