@@ -1,4 +1,5 @@
-"""How the visual attention (36 cold panorama rows per sample from the 3.1 GB table) scales with the number of
+"""(MODE=warm: the same rows in every call -- the upper bound of what prefetching the next step's rows could buy.)
+How the visual attention (36 cold panorama rows per sample from the 3.1 GB table) scales with the number of
 samples: per-workgroup-latency-bound (flat), per-CU-bandwidth-bound, or HBM-bound (linear)?"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,7 +19,10 @@ for B in (16, 32, 64, 100, 128, 200, 256, 400):
     h = torch.randn(B, 512, device=dev)
     outs = []
     for rep in range(12):       # fresh viewpoints every call: cold rows (random, or one contiguous run of rows)
-        if MODE == 'random':
+        if MODE == 'warm' and outs:     # the SAME rows every call: warm in the memory-side cache (what a prefetch could buy at best)
+            outs.append(outs[0])
+            continue
+        if MODE in ('random', 'warm'):
             vp = torch.from_numpy(rng.integers(0, 10567, size=B).astype(np.int32)).to(dev)
         else:
             vp = torch.from_numpy(((rng.integers(0, 10567) + np.arange(B)) % 10567).astype(np.int32)).to(dev)
