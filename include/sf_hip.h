@@ -452,6 +452,11 @@ typedef struct sf_follower_episode {
      * decode step.  Needs w->text.w_in_t and w->action.w_a_t; one stream (side_stream NULL); pre-drawn observations or a
      * device-resident environment (glue.nav). */
     float *ctx_q, *ctx_o;
+    /* ... and, with the folded matrices of sf_decoder_fold (built once per weight version, sf_decoder_fold_build): the next
+     * step's visual query as ONE product q' = M_v h1 + c_v beside the folded attention, the scoring vector / constant as
+     * ONE product [r | c] = M_a h~ + c_a whose operand h~ the A-prologue forms -- THREE dependent launches behind the cell
+     * (t_v, t_a, wt, r of the tape are not written either).  NULL: the four-launch chain.  `w->fold` stays NULL. */
+    const sf_decoder_fold* chain_fold;
 } sf_follower_episode;
 int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e, void* ws,
                             size_t ws_bytes, sf_stream stream);
@@ -852,6 +857,8 @@ void sf_debug_gate_product_f32(int on);
 /* folded inference chain (ABI 9): 1 (default) = attention partials beside r and their merge beside scoring + glue;
  * 0 = partials, ticket and merge in one launch beside r */
 void sf_debug_fold_merge_with_glue(int on);
+/* 0: the four-launch folded chain even when sf_follower_episode.chain_fold is given (A/B switch) */
+void sf_debug_fold_chain3(int on);
 /* A/B switch (round 5): on == 0 sends the many-row products (M >= 512: the speaker's teacher-forced head over all S*B rows,
  * the beam search's flat steps) back to the register-streaming kernel of rounds 1-4 instead of the LDS-tiled 128 x 128
  * bf16x6 kernel (csrc/sf_gemm.hip: gemm_nt_big_kernel; the default).  Bit 1 of `on` (on == 3) keeps the kernel but turns off

@@ -79,7 +79,8 @@ class FollowerEpisode(C.Structure):
                 ('c_init', c_p), ('ctx', c_p), ('ctx_mask', c_p), ('tape', DecoderTape),
                 ('glue', FollowerGlue), ('drop', Dropout), ('step0', C.c_uint32),
                 ('side_stream', C.c_void_p),
-                ('ctx_q', c_p), ('ctx_o', c_p)]                     # ABI 9: folded text attention (inference only)
+                ('ctx_q', c_p), ('ctx_o', c_p),                     # ABI 9: folded text attention (inference only)
+                ('chain_fold', c_p)]                                # ... + folded query / scoring products (sf_decoder_fold*)
 
 
 class EncoderW(C.Structure):
@@ -156,6 +157,7 @@ _SIGNATURES = {
     'sf_debug_persist_timeout': (None, [C.c_longlong]),
     'sf_debug_gate_product_f32': (None, [C.c_int]),
     'sf_debug_fold_merge_with_glue': (None, [C.c_int]),
+    'sf_debug_fold_chain3': (None, [C.c_int]),
     'sf_debug_precise_attention': (None, [C.c_int]),
     'sf_debug_many_row_product': (None, [C.c_int]),
     'sf_debug_grouped_weight_gradients': (None, [C.c_int]),

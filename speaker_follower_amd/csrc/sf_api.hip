@@ -190,6 +190,7 @@ static LstmPwBwd cell_pw_bwd(const float* gates, const float* c0, const float* c
     return p;
 }
 
+static int g_fold_chain3 = 1;               // sf_debug_fold_chain3 (0: the four-launch folded chain even with chain_fold)
 static int g_fold_merge_with_glue = 1;      // sf_debug_fold_merge_with_glue (0: partials + merge in ONE launch, phase 0)
 static int g_bptt_part = 0;        // EXPERIMENT (sf_debug_bptt_part): 1 = issue the heads only, 2 = the tails only (no waits)
 static int g_bptt_flags = 0;       // sf_debug_bptt_flags: per-step device flags between the two chains of the backward instead of events
@@ -511,6 +512,7 @@ int sf_debug_cotenant(int blocks, int threads, int lds_bytes, long long ticks, f
 void sf_gate_product_strict(int on) { sf::g_nt_force_f32 = on ? 1 : 0; }
 int sf_gate_product_is_strict(void) { return sf::g_nt_force_f32 != 0; }
 void sf_debug_fold_merge_with_glue(int on) { g_fold_merge_with_glue = on; }
+void sf_debug_fold_chain3(int on) { g_fold_chain3 = on; }
 void sf_debug_precise_attention(int on) { sf::g_precise_attention = on; }
 void sf_debug_tn_split_min_rows(int rows) { sf::g_tn_split_min_rows = rows < 0 ? 4096 : rows; }
 size_t sf_workspace_fault_offset(size_t ws_bytes) {
@@ -756,6 +758,7 @@ static int plan_linear(const float* x, int ldx, const float* wgt, int ldw, const
 struct TextFold {
     const float* ctx_q;
     const float* ctx_o;
+    const sf_decoder_fold* mats;      // optional (sf_follower_episode.chain_fold): the THREE-launch chain
 };
 
 static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H, int D, int L,
@@ -783,6 +786,65 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     const sf_visual_w* vw = &w->visual;
     bool paired = X_next && vw->w_v_t;     // (a scoring fold, if any, is applied by scoring_fwd_i)
     const bool last_step = !X_next && !tn;      // (nothing of a next step to prepare: the text chain alone)
+    const bool glue_or_plain_ok = true;
+    if ((paired || query_only || last_step) && tf && tf->mats && g_fold_chain3 && !w->fold && !ctx_row && !d_h.on() &&
+        tw->w_out && glue_or_plain_ok) {
+        // Folded text stage + folded query / scoring products (sf_decoder_fold through sf_follower_episode.chain_fold):
+        // THREE dependent launches behind the cell --
+        //   (1) folded text attention  ||  y = W_out[:, H:] h1  ||  q' = M_v h1 + c_v      (t_v' is never formed)
+        //   (2) [r | c] = M_a tanh(z + y) + c_a (A-prologue)   ||  visual-attention partials of step t+1
+        //   (3) scoring + glue (logit = u . r + c)             ||  merge of the partials
+        // (a device-resident environment: (2) is the product alone, the attention follows the environment step)
+        const sf_decoder_fold* fm = tf->mats;
+        const PanoSrc xn = paired ? pano(X_next) : PanoSrc{};
+        const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1), 2);
+        Arena af = ar;
+        float* tpart = af.take(text_fold_part_floats(B, H));
+        float* ybuf = af.take((size_t)B * H);
+        float* zbuf = af.take((size_t)B * H);
+        float* rext = af.take((size_t)B * (F + 4));
+        unsigned* tcount = af.tickets() ? af.tickets() + TEXT_TICKET : nullptr;
+        float* part = (paired && B <= 1024) ? af.take(visual_attn_split_floats(B, F)) : nullptr;
+        SmallPlan py, pq, pm;
+        bool ok = tpart && ybuf && zbuf && rext && (part || !paired) && tcount && B <= 512 && fm->m_v && fm->c_v && fm->m_a &&
+                  fm->c_a &&
+                  plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK;
+        if (ok && !last_step) {
+            ok = plan_linear(tp->h1, H, fm->m_v, H, fm->c_v, B, F, H, EPI_NONE, tn->q, F, &pq) == SF_OK;
+        } else if (ok) {
+            pq = py;
+            pq.gx = pq.gy = 0;
+        }
+        if (ok) {
+            Seg sg{ybuf, H, fm->m_a, H, H};
+            LinearOut o{};
+            o.y = rext; o.ldy = F + 4; o.bias = fm->c_a; o.epi = EPI_NONE;
+            ok = linear_small_plan(&sg, 1, B, F + 4, o, &pm) && pm.cpw == 4 && py.mt == 1 && py.cpw == 4 && pq.cpw == 4;
+            pm.args.apro_part = zbuf;
+            pm.args.apro_stride = H;
+        }
+        if (ok) {
+            const int rc = pair_textfold_small_small(tf->ctx_q, tf->ctx_o, ctx_mask, B, L, H, tp->cat2 + H, 2 * H, tpart,
+                                                     tcount, zbuf, tp->alpha, py, pq, st);
+            if (rc == SF_OK) {
+                TRY(pair_vis_apro(paired ? &xn : nullptr, B, paired ? tn->q : nullptr, F, part, pm, st));
+                if (paired && glue)
+                    return pair_score_merge(us, B, D, rext, nullptr, nullptr, nullptr, make_glue(us, B, tp->logit, glue), xn,
+                                            tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, st, F + 4, rext + F);
+                if (paired) {                               // (no glue: the module-API step; merge by its own launch)
+                    SmallPlan none = py;
+                    none.gx = none.gy = 0;
+                    TRY(pair_vis_small(xn, B, tn->q, F, tn->alpha_v, tn->xin + F, 2 * F, dn_in, F, part, nullptr, none, st, 2));
+                }
+                if (glue)
+                    return score_glue_fwd(us, B, D, rext, nullptr, nullptr, nullptr, make_glue(us, B, tp->logit, glue), st,
+                                          F + 4, rext + F);
+                return score_fwd(us, B, D, rext, nullptr, nullptr, nullptr, tp->logit, st, F + 4, rext + F);
+            }
+            if (rc != SF_ERR_UNSUPPORTED) return rc;
+        }
+        // (shapes outside the instantiations: the four-launch chain below)
+    }
     if ((paired || query_only || last_step) && tf && !w->fold && !ctx_row && !d_h.on() && tw->w_out && w->action.w_a_t) {
         // Folded text stage (inference; sf_attention.hip: text_fold_body): FOUR dependent launches behind the cell
         // instead of six:
@@ -1245,7 +1307,7 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
     TRY(decoder_head_i(w, &cur.X, e->B, e->H, e->D, e->h_init, &cur.tp, drop, e->step0, ws, ws_bytes,
                        stream));
     // the folded text attention (ABI 9): ctx_q = ctx W_in, ctx_o = ctx W_out[:, :H]^T, once per episode
-    TextFold tfold{e->ctx_q, e->ctx_o};
+    TextFold tfold{e->ctx_q, e->ctx_o, e->chain_fold};
     const TextFold* tf = nullptr;
     if (e->ctx_q && e->ctx_o && !drop && !w->fold && e->S > 1 && w->text.w_in_t && w->text.w_out && w->action.w_a_t &&
         !(e->side_stream && e->side_stream != stream)) {

@@ -781,7 +781,7 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_text_kernel(VisArgs
     }
 }
 
-template <int MT, int CPW, int PHASE>
+template <int MT, int CPW, int PHASE, bool APRO = false>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArgs v, VisSplit sp,
                                                                          int nv, SmallArgs b,
                                                                          int gxb) {
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_vis_small_kernel(VisArg
         else
             visual_split_body<PHASE>(v, sp, bid % VSP_G, bid / VSP_G);
     } else {
-        small_gemm_body<MT, CPW>(b, (bid - nv) % gxb, (bid - nv) / gxb);
+        small_gemm_body<MT, CPW, false, false, APRO>(b, (bid - nv) % gxb, (bid - nv) / gxb);
     }
 }
 
@@ -994,6 +994,19 @@ __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_textfold_small_small_ke
         small_gemm_body<1, 4>(b, (bid - nt - na) % gxb, (bid - nt - na) / gxb);
 }
 
+// ... the same with the next step's visual query as ONE folded product q' = M_v h1 + c_v (sf_decoder_fold) for third body
+template <int RPW, int MTB>
+__global__ __launch_bounds__(SMALL_WAVES * 64) void pair_textfold_small_wide_kernel(TxtFoldArgs t, int nt, SmallArgs a,
+                                                                                   int gxa, int na, SmallArgs b, int gxb) {
+    const int bid = blockIdx.x;
+    if (bid < nt)
+        text_fold_body<RPW>(t, bid % TXF_G, bid / TXF_G);
+    else if (bid < nt + na)
+        small_gemm_body<1, 4>(a, (bid - nt) % gxa, (bid - nt) / gxa);
+    else
+        small_gemm_body<MTB, 4>(b, (bid - nt - na) % gxb, (bid - nt - na) / gxb);
+}
+
 // t_a = W_h tanh(z + y) + b (A-prologue: z = the merged attention sum of the text_fold launch) beside q' = W_v^T t_v'
 template <int MTB>
 __global__ __launch_bounds__(SMALL_WAVES * 64) void pair_apro_small_kernel(SmallArgs a, int gxa, int na, SmallArgs b, int gxb) {
@@ -1180,13 +1193,14 @@ int score_glue_fwd(const CandSrc& src, int B, int D, const float* r, const float
 // score_glue_fwd beside the phase-2 merge of visual-attention partials written by an earlier phase-1 launch
 int pair_score_merge(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
                      const float* b_out, const FGlue& g, const PanoSrc& psrc, float* alpha, float* out, int ldo,
-                     const Dropout& drop, int drop_col0, float* split_part, hipStream_t st) {
+                     const Dropout& drop, int drop_col0, float* split_part, hipStream_t st, int ldr, const float* cst) {
     const int F = src.IMG + src.LOC;
+    if (ldr <= 0) ldr = F;
     if (src.A > SC_NW || src.A < 1 || F > SC_CPL * 256 || (F & 3) || (!src.dense && ((src.IMG & 3) || (src.LOC & 15))))
         return SF_ERR_UNSUPPORTED;
     if (!split_part || psrc.V <= (VSP_G - 1) * VSP_RPG || psrc.V > VSP_G * VSP_RPG || B > 256 || (ldo & 3))
         return SF_ERR_UNSUPPORTED;
-    ScoreArgs a{src, F, nullptr, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr, CeSrc{}};
+    ScoreArgs a{src, ldr, cst, r, wt, b_a, b_out, D, g.logit, nullptr, nullptr, CeSrc{}};
     VisArgs va{psrc, nullptr, 0, alpha, out, ldo, drop, drop_col0};
     const VisSplit sp{split_part, nullptr, g_trace};
     SF_LAUNCH(pair_score_merge_kernel, dim3(2 * B), dim3(SC_NW * 64), 0, st, a, g, B, va, sp);
@@ -1227,13 +1241,23 @@ int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
 int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint8_t* mask, int B, int L, int H,
                               const float* vec, int ldvec, float* part, unsigned* counter, float* z, float* alpha,
                               const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
-    if (!(a.mt == 1 && a.cpw == 4 && b.mt == 1 && b.cpw == 4)) return SF_ERR_UNSUPPORTED;
+    if (!(a.mt == 1 && a.cpw == 4 && b.cpw == 4 && (b.mt == 1 || b.mt == 2 || b.mt == 4))) return SF_ERR_UNSUPPORTED;
     if (H > TXT_CPL * 256 || (H & 3) || (ldvec & 3) || L < 1 || L > TXF_G * SMALL_WAVES * 5 || B > 512 || !counter || !z)
         return SF_ERR_UNSUPPORTED;
     const TxtFoldArgs ta{ctx_q, ctx_o, mask, L, H, vec, ldvec, part, counter, z, alpha};
     const int nt = TXF_G * B, na = a.gx * a.gy, nb = b.gx * b.gy;
     const dim3 grid(nt + na + nb), block(SMALL_WAVES * 64);
     const int rpw = (L + TXF_G * SMALL_WAVES - 1) / (TXF_G * SMALL_WAVES);
+    if (b.mt > 1) {                                   // (the folded visual query: N = F columns)
+#define SF_TFW(R, M) SF_LAUNCH((pair_textfold_small_wide_kernel<R, M>), grid, block, 0, st, ta, nt, a.args, a.gx, na, b.args, b.gx)
+        if (b.mt == 2) {
+            if (rpw <= 1) SF_TFW(1, 2); else if (rpw <= 2) SF_TFW(2, 2); else if (rpw <= 3) SF_TFW(3, 2); else SF_TFW(5, 2);
+        } else {
+            if (rpw <= 1) SF_TFW(1, 4); else if (rpw <= 2) SF_TFW(2, 4); else if (rpw <= 3) SF_TFW(3, 4); else SF_TFW(5, 4);
+        }
+#undef SF_TFW
+        return launch_status();
+    }
     if (rpw <= 1)
         SF_LAUNCH((pair_textfold_small_small_kernel<1>), grid, block, 0, st, ta, nt, a.args, a.gx, na, b.args, b.gx);
     else if (rpw <= 2)
@@ -1320,6 +1344,34 @@ int pair_visbwd_small(const PanoSrc& src, int B, const float* vec, int ldvec, fl
     const int nb = b.gx * b.gy;
     SF_LAUNCH((pair_visbwd_small_kernel<1, 16>), dim3(B + nb), dim3(VIS_NW * 64), 0, st, va, B,
                        b.args, b.gx);
+    return launch_status();
+}
+
+// the folded scoring product [r | c] = M_a tanh(z + y) + c_a (A-prologue; b.args.apro_part set) beside the phase-1
+// partials of the visual attention -- or alone (`src` null: a device-resident environment, an episode's last step)
+int pair_vis_apro(const PanoSrc* src, int B, const float* vec, int ldvec, float* split_part, const SmallPlan& b,
+                  hipStream_t st) {
+    if (!(b.cpw == 4 && (b.mt == 1 || b.mt == 2 || b.mt == 4)) || !b.args.apro_part || b.args.sg.total != b.args.sg.n0)
+        return SF_ERR_UNSUPPORTED;
+    int nv = 0;
+    VisArgs va{};
+    if (src) {
+        const int F = src->IMG + src->LOC;
+        if (!split_part || src->V <= (VSP_G - 1) * VSP_RPG || src->V > VSP_G * VSP_RPG || B > 256 || F > VIS_CPL * 256 ||
+            (F & 3) || (!src->dense && ((src->IMG & 3) || (src->LOC & 3))) || (ldvec & 3))
+            return SF_ERR_UNSUPPORTED;
+        va = VisArgs{*src, vec, ldvec, nullptr, nullptr, 0, Dropout{}, 0};
+        nv = VSP_G * B;
+    }
+    const VisSplit sp{split_part, nullptr, g_trace};
+    const int nb = b.gx * b.gy;
+    const dim3 grid(nv + nb), block(SMALL_WAVES * 64);
+    if (b.mt == 4)
+        SF_LAUNCH((pair_vis_small_kernel<4, 4, 1, true>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else if (b.mt == 2)
+        SF_LAUNCH((pair_vis_small_kernel<2, 4, 1, true>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
+    else
+        SF_LAUNCH((pair_vis_small_kernel<1, 4, 1, true>), grid, block, 0, st, va, sp, nv, b.args, b.gx);
     return launch_status();
 }
 

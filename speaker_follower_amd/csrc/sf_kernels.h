@@ -196,7 +196,10 @@ int pair_apro_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st);
 struct FGlue;
 int pair_score_merge(const CandSrc& src, int B, int D, const float* r, const float* wt, const float* b_a,
                      const float* b_out, const FGlue& g, const PanoSrc& psrc, float* alpha, float* out, int ldo,
-                     const Dropout& drop, int drop_col0, float* split_part, hipStream_t st);
+                     const Dropout& drop, int drop_col0, float* split_part, hipStream_t st, int ldr = 0,
+                     const float* cst = nullptr);
+int pair_vis_apro(const PanoSrc* src, int B, const float* vec, int ldvec, float* split_part, const SmallPlan& b,
+                  hipStream_t st);
 
 struct FGlue;
 int follower_glue_fwd(const FGlue& g, hipStream_t st);

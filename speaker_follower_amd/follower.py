@@ -161,6 +161,11 @@ class FollowerEngine:
         self.encoder_backward_first = os.environ.get('SF_ENC_BWD_FIRST', '0') == '1'   # (experiment switch, see _backward)
         self.grad_sync = None            # dp.BucketedGrads(dp.follower_buckets(enc, dec)): all-reduce launched from the backward
         self._open_forks = []            # side streams forked from the current one and not joined yet (_backward)
+        # ... with q' = M_v h1 + c_v and [r | c] = M_a h~ + c_a as single products (ABI 9 chain_fold): three launches behind
+        # the cell instead of four -- BUILT, CORRECT, SLOWER (round 6: 2.03 ms per rollout against 1.77: the [100 x 512] x
+        # [2176 x 512]^T products re-read their A operand per 16-column block, 18.5 + 27.9 us for the two stages that replace
+        # 10.7 + 7.5 + 14.4): off
+        self.fold_chain = False
         self.fold_text = True            # inference rollouts: text attention over ctx W_in / ctx W_out[:, :H]^T (ABI 9)
         self._wgrad_stream = None
         # model.decoder_fold for no-grad eval rollouts (folded Linears + the folded paired schedule of
@@ -326,6 +331,11 @@ class FollowerEngine:
             if st.text_folded:
                 st.ctx_fold = new(2, B, T, H)
                 ep.ctx_q, ep.ctx_o = st.ctx_fold[0].data_ptr(), st.ctx_fold[1].data_ptr()
+                if self.fold_chain:
+                    # ... and the folded query / scoring matrices (model.decoder_fold: rebuilt in place per weight
+                    # version): three dependent launches behind the cell instead of four
+                    st.chain_fold = decoder_fold(dec)
+                    ep.chain_fold = C.cast(C.pointer(st.chain_fold), C.c_void_p)
             call('sf_follower_episode_fwd', byref(dw), byref(ep), *ws)
             st.episode = (ep, dw)
         tapes = [] if st.episode else [_lib.DecoderTape(*(st.tape[k][t].data_ptr() for k in _TAPE_KEYS))
@@ -467,7 +477,7 @@ class FollowerEngine:
         else:
             ew = bytes(_encoder_structs(enc))
         dw = decoder_w_struct(decoder_params(self.decoder))
-        fold = bytes(decoder_fold(self.decoder)) if self.fold_inference else b''
+        fold = bytes(decoder_fold(self.decoder)) if (self.fold_inference or (self.fold_text and self.fold_chain)) else b''
         return ew + bytes(dw) + fold
 
     def _guarded(self, graph_replay):

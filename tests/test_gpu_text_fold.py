@@ -29,8 +29,11 @@ def _models(seed=77):
     return enc.cuda().eval(), dec.cuda().eval(), enc_w, dec_w
 
 
+@pytest.mark.parametrize('chain', [True, False])
 @pytest.mark.parametrize('B,S,min_len,max_len', [(100, 8, 10, 79), (37, 5, 3, 30), (16, 3, 2, 12)])
-def test_folded_text_attention_equals_the_unfolded_path_and_the_oracle(B, S, min_len, max_len):
+def test_folded_text_attention_equals_the_unfolded_path_and_the_oracle(B, S, min_len, max_len, chain):
+    """chain: also q' = M_v h1 + c_v and [r | c] = M_a h~ + c_a as single products (sf_follower_episode.chain_fold: three
+    dependent launches behind the cell); without: the four-launch folded chain."""
     from speaker_follower_amd import features, follower
     enc, dec, enc_w, dec_w = _models()
     NVP = 96
@@ -41,7 +44,7 @@ def test_folded_text_attention_equals_the_unfolded_path_and_the_oracle(B, S, min
     res = {}
     for fold in (True, False):
         eng = follower.FollowerEngine(enc, dec, store)
-        eng.fold_text = fold
+        eng.fold_text, eng.fold_chain = fold, chain
         with torch.no_grad():
             st = eng.rollout(batch, S, 'argmax', train=False)
         torch.cuda.synchronize()
@@ -56,7 +59,8 @@ def test_folded_text_attention_equals_the_unfolded_path_and_the_oracle(B, S, min
     assert np.array_equal(fin, np.isfinite(lf))
     scale = float(np.abs(lu[fin]).max())
     d = float(np.abs(lf[fin] - lu[fin]).max())
-    print('[text fold] B=%d S=%d: max |logit| %.2f, folded vs unfolded %.2e, h1 %.2e' % (B, S, scale, d, np.abs(hf - hu).max()))
+    print('[text fold%s] B=%d S=%d: max |logit| %.2f, folded vs unfolded %.2e, h1 %.2e'
+          % (' + chain' if chain else '', B, S, scale, d, np.abs(hf - hu).max()))
     assert 0 < d <= 3e-5 * max(scale, 1.0)                        # (> 0: the folded kernels really ran)
     assert np.array_equal(af, au)
     assert abs(lossf - lossu) <= 1e-5 * max(1.0, abs(lossu))
