@@ -806,7 +806,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         unsigned* tcount = af.tickets() ? af.tickets() + TEXT_TICKET : nullptr;
         float* part = (paired && B <= 1024) ? af.take(visual_attn_split_floats(B, F)) : nullptr;
         SmallPlan py, pq, pm;
-        bool ok = tpart && ybuf && zbuf && rext && (part || !paired) && tcount && B <= 512 && fm->m_v && fm->c_v && fm->m_a &&
+        bool ok = tpart && ybuf && zbuf && rext && (part || !paired) && tcount && B <= 256 && fm->m_v && fm->c_v && fm->m_a &&
                   fm->c_a &&
                   plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK;
         if (ok && !last_step) {
@@ -863,7 +863,7 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         unsigned* tcount = af.tickets() ? af.tickets() + TEXT_TICKET : nullptr;
         float* part = (paired && B <= 1024) ? af.take(visual_attn_split_floats(B, F)) : nullptr;
         SmallPlan py, pv, pta, pq, pr;
-        bool ok = tpart && ybuf && zbuf && (part || !paired) && tcount && B <= 512 &&
+        bool ok = tpart && ybuf && zbuf && (part || !paired) && tcount && B <= 256 &&
             plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK &&
             plan_linear(tp->wt, D, w->action.w_a_t, D, nullptr, B, F, D, EPI_NONE, tp->r, F, &pr) == SF_OK;
         if (ok && !last_step) {
