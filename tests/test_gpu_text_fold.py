@@ -154,3 +154,52 @@ def test_device_environment_rollout_folded_equals_unfolded():
     assert np.array_equal(fin, np.isfinite(lf))
     d = float(np.abs(lf[fin] - lu[fin]).max())
     assert 0 < d <= 3e-5 * max(1.0, float(np.abs(lu[fin]).max())), d     # (> 0: the folded kernels really ran)
+
+
+@pytest.mark.parametrize('L', [9, 16, 17, 33, 48, 49, 64, 80])
+def test_context_lengths_take_the_right_group_size(L):
+    """The position groups are 8 waves x RPW rows (RPW = 1, 2, 3, 5): every context width up to 80, including the widths on
+    the boundaries between two templates and rows whose later groups hold only padding."""
+    from speaker_follower_amd import features, follower
+    enc, dec, _, _ = _models()
+    B, S, NVP = 64, 3, 48
+    fb = synth.follower_batch(seed=L, batch=B, steps=S, n_viewpoints=NVP, min_len=1, max_len=L - 1)
+    fb.instr[0] = np.arange(4, 4 + L - 1, dtype=np.int64)             # (one row of exactly L - 1 tokens + EOS: width L)
+    store = features.FeatureStore(synth.feature_table(5, NVP))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    assert batch.mask.shape[1] == L
+    out = {}
+    for fold in (True, False):
+        eng = follower.FollowerEngine(enc, dec, store)
+        eng.fold_text = fold
+        with torch.no_grad():
+            st = eng.rollout(batch, S, 'argmax', train=False)
+        out[fold] = (st.logits.cpu().numpy().copy(), st.actions.cpu().numpy().copy(), st.tape['alpha'].cpu().numpy().copy())
+    fin = np.isfinite(out[False][0])
+    assert np.array_equal(out[True][1], out[False][1])
+    d = float(np.abs(out[True][0][fin] - out[False][0][fin]).max())
+    assert 0 < d <= 3e-5 * max(1.0, float(np.abs(out[False][0][fin]).max())), d
+    np.testing.assert_allclose(out[True][2], out[False][2], rtol=1e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('B', [1, 17, 49, 112, 113, 192, 193, 224, 256, 257, 300])
+def test_every_batch_size_runs_folded_or_falls_back_cleanly(B):
+    """The folded chain exists for the batch sizes whose small products take the instantiated plans; every other size must
+    take the unfolded stages by itself (never an error, never a half-folded step): same actions either way."""
+    from speaker_follower_amd import features, follower
+    enc, dec, _, _ = _models()
+    S, NVP = 2, 32
+    fb = synth.follower_batch(seed=B, batch=B, steps=S, n_viewpoints=NVP, min_len=3, max_len=20)
+    store = features.FeatureStore(synth.feature_table(5, NVP))
+    batch = follower.DeviceFollowerBatch.from_synth(fb)
+    out = {}
+    for fold in (True, False):
+        eng = follower.FollowerEngine(enc, dec, store)
+        eng.fold_text = fold
+        with torch.no_grad():
+            st = eng.rollout(batch, S, 'argmax', train=False)
+        torch.cuda.synchronize()
+        out[fold] = (st.logits.cpu().numpy().copy(), st.actions.cpu().numpy().copy())
+    fin = np.isfinite(out[False][0])
+    assert np.array_equal(fin, np.isfinite(out[True][0])) and np.array_equal(out[True][1], out[False][1])
+    assert float(np.abs(out[True][0][fin] - out[False][0][fin]).max()) <= 3e-5 * max(1.0, float(np.abs(out[False][0][fin]).max()))
