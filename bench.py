@@ -295,7 +295,17 @@ def measure_train(enc, dec, store, batch, S, iters, warmup, group=None, world=1,
             engine.grad_sync = flat
             enc.train()
             dec.train()
-            tg = engine.capture_training(batch, S, 'argmax', optimizers=(opt_e, opt_d), zero=flat)
+            tg, why = None, None
+            try:
+                tg = engine.capture_training(batch, S, 'argmax', optimizers=(opt_e, opt_d), zero=flat)
+            except Exception as exc:                        # noqa: BLE001
+                why = repr(exc)[:300]
+            # every rank replays or none does (a replay issues collectives: one rank that failed to capture would leave
+            # the others waiting in an all-reduce)
+            okf = torch.tensor([1.0 if tg is not None else 0.0], device=store.device)
+            torch.distributed.all_reduce(okf, op=torch.distributed.ReduceOp.MIN)
+            if float(okf) < 1.0:
+                raise RuntimeError(why or 'another rank could not capture the segmented iteration')
             for _ in range(2):
                 tg.replay()
             barrier()
