@@ -388,7 +388,19 @@ class TrainingGraph:
             h.hook = cut
         try:
             begin()
-            self.state = body()
+            try:
+                self.state = body()
+            except BaseException:
+                # never leave the stream capturing: end the open segment (whatever it holds is dropped with the graphs)
+                try:
+                    for s_ in list(getattr(engine, '_open_forks', ())):
+                        origin.wait_stream(s_)
+                    with torch.cuda.stream(origin):
+                        cur['g'].capture_end()
+                except Exception:                            # noqa: BLE001  (the original error is the one to report)
+                    pass
+                self.segments = None
+                raise
             end(None)
         finally:
             if was:
