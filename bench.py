@@ -29,6 +29,8 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# (kernel arguments in device memory: speaker_follower_amd/__init__.py; set here too because this script imports torch first)
+os.environ.setdefault('HIP_FORCE_DEV_KERNARG', '1')
 
 # algorithmic work of ONE agent-step (forward, fp32, A = 8, L = 80, B = 100)
 AGENT_STEP_FLOPS = 71386112.0
