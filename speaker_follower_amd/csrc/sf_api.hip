@@ -800,15 +800,17 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1), 2);
         Arena af = ar;
         float* tpart = af.take(text_fold_part_floats(B, H));
-        float* ybuf = af.take((size_t)B * H);
-        float* zbuf = af.take((size_t)B * H);
+        // (leading dimension H + 16: rows of a power-of-two stride share a few cache sets, CHANGELOG round 5 "2c")
+        const int ldp = H + 16;
+        float* ybuf = af.take((size_t)B * ldp);
+        float* zbuf = af.take((size_t)B * ldp);
         float* rext = af.take((size_t)B * (F + 4));
         unsigned* tcount = af.tickets() ? af.tickets() + TEXT_TICKET : nullptr;
         float* part = (paired && B <= 1024) ? af.take(visual_attn_split_floats(B, F)) : nullptr;
         SmallPlan py, pq, pm;
         bool ok = tpart && ybuf && zbuf && rext && (part || !paired) && tcount && B <= 256 && fm->m_v && fm->c_v && fm->m_a &&
                   fm->c_a &&
-                  plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK;
+                  plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, ldp, &py) == SF_OK;
         if (ok && !last_step) {
             ok = plan_linear(tp->h1, H, fm->m_v, H, fm->c_v, B, F, H, EPI_NONE, tn->q, F, &pq) == SF_OK;
         } else if (ok) {
@@ -816,16 +818,16 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
             pq.gx = pq.gy = 0;
         }
         if (ok) {
-            Seg sg{ybuf, H, fm->m_a, H, H};
+            Seg sg{ybuf, ldp, fm->m_a, H, H};
             LinearOut o{};
             o.y = rext; o.ldy = F + 4; o.bias = fm->c_a; o.epi = EPI_NONE;
             ok = linear_small_plan(&sg, 1, B, F + 4, o, &pm) && pm.cpw == 4 && py.mt == 1 && py.cpw == 4 && pq.cpw == 4;
             pm.args.apro_part = zbuf;
-            pm.args.apro_stride = H;
+            pm.args.apro_stride = ldp;
         }
         if (ok) {
             const int rc = pair_textfold_small_small(tf->ctx_q, tf->ctx_o, ctx_mask, B, L, H, tp->cat2 + H, 2 * H, tpart,
-                                                     tcount, zbuf, tp->alpha, py, pq, st);
+                                                     tcount, zbuf, ldp, tp->alpha, py, pq, st);
             if (rc == SF_OK) {
                 TRY(pair_vis_apro(paired ? &xn : nullptr, B, paired ? tn->q : nullptr, F, part, pm, st));
                 if (paired && glue)
@@ -858,13 +860,15 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
         const Dropout dn_in = make_dropout(drop, 2 * (step_id + 1), 2);
         Arena af = ar;                                           // (released when this branch is left)
         float* tpart = af.take(text_fold_part_floats(B, H));
-        float* ybuf = af.take((size_t)B * H);
-        float* zbuf = af.take((size_t)B * H);
+        // (leading dimension H + 16: rows of a power-of-two stride share a few cache sets, CHANGELOG round 5 "2c")
+        const int ldp = H + 16;
+        float* ybuf = af.take((size_t)B * ldp);
+        float* zbuf = af.take((size_t)B * ldp);
         unsigned* tcount = af.tickets() ? af.tickets() + TEXT_TICKET : nullptr;
         float* part = (paired && B <= 1024) ? af.take(visual_attn_split_floats(B, F)) : nullptr;
         SmallPlan py, pv, pta, pq, pr;
         bool ok = tpart && ybuf && zbuf && (part || !paired) && tcount && B <= 256 &&
-            plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, H, &py) == SF_OK &&
+            plan_linear(tp->cat2 + H, 2 * H, tw->w_out + H, 2 * H, nullptr, B, H, H, EPI_NONE, ybuf, ldp, &py) == SF_OK &&
             plan_linear(tp->wt, D, w->action.w_a_t, D, nullptr, B, F, D, EPI_NONE, tp->r, F, &pr) == SF_OK;
         if (ok && !last_step) {
             ok = plan_linear(tp->h1, H, vw->w_h, H, vw->b_h, B, D, H, EPI_NONE, tn->t_v, D, &pv) == SF_OK &&
@@ -876,17 +880,17 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
             pq.gx = pq.gy = 0;
         }
         if (ok) {
-            Seg sg{ybuf, H, w->action.w_h, H, H};
+            Seg sg{ybuf, ldp, w->action.w_h, H, H};
             LinearOut o{};
             o.y = tp->wt; o.ldy = D; o.bias = w->action.b_h; o.mul = w->action.w_out; o.y_pre = tp->t_a;
             o.ldy_pre = D; o.epi = EPI_MUL;
             ok = linear_small_plan(&sg, 1, B, D, o, &pta) && pta.mt == 1 && pta.cpw == 4 && pq.cpw == 2 && pr.cpw == 2;
             pta.args.apro_part = zbuf;                            // (the merged attention sum of launch (1))
-            pta.args.apro_stride = H;
+            pta.args.apro_stride = ldp;
         }
         if (ok) {
             const int rc = pair_textfold_small_small(tf->ctx_q, tf->ctx_o, ctx_mask, B, L, H, tp->cat2 + H, 2 * H, tpart,
-                                                     tcount, zbuf, tp->alpha, py, pv, st);
+                                                     tcount, zbuf, ldp, tp->alpha, py, pv, st);
             if (rc == SF_OK) {
                 TRY(pair_apro_small(pta, pq, st));
                 if (paired && glue && g_fold_merge_with_glue) {

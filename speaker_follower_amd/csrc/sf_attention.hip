@@ -837,7 +837,8 @@ struct TxtFoldArgs {
     int ldvec;
     float* part;           // [B][TXF_G][H + 64]: z | e[l - g Lg] (<= 62) | m at H + 62 | l at H + 63
     unsigned* counter;     // [B] monotonic tickets (zero before the first launch; every launch adds TXF_G per sample)
-    float* z;              // out [B, H]: sum_l alpha_l ctx_o[l] (merged, normalised)
+    float* z;              // out [B, ldz]: sum_l alpha_l ctx_o[l] (merged, normalised)
+    int ldz;
     float* alpha;          // out [B, L]: the attention weights (the tape's contract), or null
 };
 
@@ -966,7 +967,7 @@ __device__ __forceinline__ void text_fold_body(const TxtFoldArgs& a, int g, int 
         }
     }
     const auto rs0 = __builtin_amdgcn_make_buffer_rsrc(r0, 0, TXF_G * pstride * 4, 0x00020000);
-    float4* zrow = reinterpret_cast<float4*>(a.z + (size_t)b * H);
+    float4* zrow = reinterpret_cast<float4*>(a.z + (size_t)b * a.ldz);
     for (int c = tid; c < n4; c += NW * 64) {
         float4 t = f4zero();
 #pragma unroll
@@ -1239,12 +1240,13 @@ int pair_small_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
 // The folded text stage of an inference decode step (see text_fold_body): SF_ERR_UNSUPPORTED = shapes outside the
 // instantiations (the caller runs the unfolded stages).
 int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint8_t* mask, int B, int L, int H,
-                              const float* vec, int ldvec, float* part, unsigned* counter, float* z, float* alpha,
+                              const float* vec, int ldvec, float* part, unsigned* counter, float* z, int ldz, float* alpha,
                               const SmallPlan& a, const SmallPlan& b, hipStream_t st) {
     if (!(a.mt == 1 && a.cpw == 4 && b.cpw == 4 && (b.mt == 1 || b.mt == 2 || b.mt == 4))) return SF_ERR_UNSUPPORTED;
-    if (H > TXT_CPL * 256 || (H & 3) || (ldvec & 3) || L < 1 || L > TXF_G * SMALL_WAVES * 5 || B > 512 || !counter || !z)
+    if (H > TXT_CPL * 256 || (H & 3) || (ldvec & 3) || L < 1 || L > TXF_G * SMALL_WAVES * 5 || B > 512 || !counter || !z ||
+        (ldz & 3) || ldz < H)
         return SF_ERR_UNSUPPORTED;
-    const TxtFoldArgs ta{ctx_q, ctx_o, mask, L, H, vec, ldvec, part, counter, z, alpha};
+    const TxtFoldArgs ta{ctx_q, ctx_o, mask, L, H, vec, ldvec, part, counter, z, ldz, alpha};
     const int nt = TXF_G * B, na = a.gx * a.gy, nb = b.gx * b.gy;
     const dim3 grid(nt + na + nb), block(SMALL_WAVES * 64);
     const int rpw = (L + TXF_G * SMALL_WAVES - 1) / (TXF_G * SMALL_WAVES);

@@ -189,7 +189,7 @@ int pair_vis_text(const PanoSrc& src, int B, const float* vec, int ldvec, float*
 
 // the folded text stage of an inference decode step (sf_attention.hip: text_fold_body) and its consumer
 int pair_textfold_small_small(const float* ctx_q, const float* ctx_o, const uint8_t* mask, int B, int L, int H,
-                              const float* vec, int ldvec, float* part, unsigned* counter, float* z, float* alpha,
+                              const float* vec, int ldvec, float* part, unsigned* counter, float* z, int ldz, float* alpha,
                               const SmallPlan& a, const SmallPlan& b, hipStream_t st);
 size_t text_fold_part_floats(int B, int H);
 int pair_apro_small(const SmallPlan& a, const SmallPlan& b, hipStream_t st);
