@@ -449,8 +449,9 @@ typedef struct sf_follower_episode {
      * ctx_q = ctx W_in and ctx_o = ctx W_out[:, :H]^T ONCE (the context is constant over an episode) and runs the text
      * attention of every step but the last in folded form -- scores ctx_q[l] . h1, h~ = tanh(sum alpha_l ctx_o[l] +
      * W_out[:, H:] h1): the same function (fp32 re-association, like q = W_v^T t_v), two dependent launches fewer per
-     * decode step.  Needs w->text.w_in_t and w->action.w_a_t; one stream (side_stream NULL); pre-drawn observations or a
-     * device-resident environment (glue.nav). */
+     * decode step.  Needs w->text.w_in_t and w->action.w_a_t; pre-drawn observations or a device-resident environment
+     * (glue.nav).  With ctx_q / ctx_o, `side_stream` (if given) only carries the two fold products beside step 0's
+     * attention (one fork, one join); the two-chain forward schedule is not taken. */
     float *ctx_q, *ctx_o;
     /* ... and, with the folded matrices of sf_decoder_fold (built once per weight version, sf_decoder_fold_build): the next
      * step's visual query as ONE product q' = M_v h1 + c_v beside the folded attention, the scoring vector / constant as
@@ -859,6 +860,8 @@ void sf_debug_gate_product_f32(int on);
 void sf_debug_fold_merge_with_glue(int on);
 /* 0: the four-launch folded chain even when sf_follower_episode.chain_fold is given (A/B switch) */
 void sf_debug_fold_chain3(int on);
+/* 1 (default): with sf_follower_episode.side_stream the two fold products run on it beside step 0's attention */
+void sf_debug_fold_build_overlap(int on);
 /* A/B switch (round 5): on == 0 sends the many-row products (M >= 512: the speaker's teacher-forced head over all S*B rows,
  * the beam search's flat steps) back to the register-streaming kernel of rounds 1-4 instead of the LDS-tiled 128 x 128
  * bf16x6 kernel (csrc/sf_gemm.hip: gemm_nt_big_kernel; the default).  Bit 1 of `on` (on == 3) keeps the kernel but turns off

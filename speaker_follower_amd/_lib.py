@@ -158,6 +158,7 @@ _SIGNATURES = {
     'sf_debug_gate_product_f32': (None, [C.c_int]),
     'sf_debug_fold_merge_with_glue': (None, [C.c_int]),
     'sf_debug_fold_chain3': (None, [C.c_int]),
+    'sf_debug_fold_build_overlap': (None, [C.c_int]),
     'sf_debug_precise_attention': (None, [C.c_int]),
     'sf_debug_many_row_product': (None, [C.c_int]),
     'sf_debug_grouped_weight_gradients': (None, [C.c_int]),

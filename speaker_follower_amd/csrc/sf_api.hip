@@ -190,6 +190,7 @@ static LstmPwBwd cell_pw_bwd(const float* gates, const float* c0, const float* c
     return p;
 }
 
+static int g_fold_build_overlap = 1;        // sf_debug_fold_build_overlap (0: the fold products on the caller's stream, in front of step 0's attention)
 static int g_fold_chain3 = 1;               // sf_debug_fold_chain3 (0: the four-launch folded chain even with chain_fold)
 static int g_fold_merge_with_glue = 1;      // sf_debug_fold_merge_with_glue (0: partials + merge in ONE launch, phase 0)
 static int g_bptt_part = 0;        // EXPERIMENT (sf_debug_bptt_part): 1 = issue the heads only, 2 = the tails only (no waits)
@@ -513,6 +514,7 @@ void sf_gate_product_strict(int on) { sf::g_nt_force_f32 = on ? 1 : 0; }
 int sf_gate_product_is_strict(void) { return sf::g_nt_force_f32 != 0; }
 void sf_debug_fold_merge_with_glue(int on) { g_fold_merge_with_glue = on; }
 void sf_debug_fold_chain3(int on) { g_fold_chain3 = on; }
+void sf_debug_fold_build_overlap(int on) { g_fold_build_overlap = on; }
 void sf_debug_precise_attention(int on) { sf::g_precise_attention = on; }
 void sf_debug_tn_split_min_rows(int rows) { sf::g_tn_split_min_rows = rows < 0 ? 4096 : rows; }
 size_t sf_workspace_fault_offset(size_t ws_bytes) {
@@ -729,14 +731,19 @@ int sf_attn_decoder_fwd(const sf_decoder_w* w, const sf_pano* X, const sf_cands*
 // tail(t)   = LSTM cell, text attention, scoring (+ glue) of step t, and -- when X_next is given --
 //             head(t+1) on h1 of step t, run SIDE BY SIDE with the text / scoring half in paired
 //             launches (sf_attention.hip): the two halves are independent given h1.
-static int decoder_head_i(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
+static int decoder_head_a(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
                           const float* h0, const sf_decoder_tape* tp, const sf_dropout* drop,
-                          uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream) {
+                          uint32_t step_id, Arena ar, sf_stream stream) {
     SF_CHECK_ARG(w && X && h0 && tp && B > 0);
     const PanoSrc xs = pano(X);
     const int F = xs.IMG + xs.LOC;
     return visual_fwd_i(&w->visual, xs, B, H, D, h0, tp->xin + F, 2 * F, tp->alpha_v, tp->t_v, tp->q,
-                        make_dropout(drop, 2 * step_id, 2), F, arena(ws, ws_bytes), S(stream), w->fold);
+                        make_dropout(drop, 2 * step_id, 2), F, ar, S(stream), w->fold);
+}
+static int decoder_head_i(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
+                          const float* h0, const sf_decoder_tape* tp, const sf_dropout* drop,
+                          uint32_t step_id, void* ws, size_t ws_bytes, sf_stream stream) {
+    return decoder_head_a(w, X, B, H, D, h0, tp, drop, step_id, arena(ws, ws_bytes), stream);
 }
 
 int sf_attn_decoder_head_fwd(const sf_decoder_w* w, const sf_pano* X, int B, int H, int D,
@@ -1308,18 +1315,47 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
     const sf_dropout* drop = e->drop.p > 0.f ? &e->drop : nullptr;
     const size_t BH = (size_t)e->B * e->H;
     StepView cur = step_view(e, 0);
-    TRY(decoder_head_i(w, &cur.X, e->B, e->H, e->D, e->h_init, &cur.tp, drop, e->step0, ws, ws_bytes,
-                       stream));
+    hipEvent_t fold_join = nullptr;
+    hipStream_t fold_side = nullptr;
     // the folded text attention (ABI 9): ctx_q = ctx W_in, ctx_o = ctx W_out[:, :H]^T, once per episode
     TextFold tfold{e->ctx_q, e->ctx_o, e->chain_fold};
     const TextFold* tf = nullptr;
-    if (e->ctx_q && e->ctx_o && !drop && !w->fold && e->S > 1 && w->text.w_in_t && w->text.w_out && w->action.w_a_t &&
-        !(e->side_stream && e->side_stream != stream)) {
+    if (e->ctx_q && e->ctx_o && !drop && !w->fold && e->S > 1 && w->text.w_in_t && w->text.w_out && w->action.w_a_t) {
         const int M = e->B * e->L, H = e->H;
         Arena ar = arena(ws, ws_bytes);
-        TRY(linear_plain(e->ctx, H, w->text.w_in_t, H, nullptr, M, H, H, EPI_NONE, e->ctx_q, H, ar, S(stream)));
-        TRY(linear_plain(e->ctx, H, w->text.w_out, 2 * H, nullptr, M, H, H, EPI_NONE, e->ctx_o, H, ar, S(stream)));
+        hipStream_t ms = S(stream), bs = ms;
+        std::vector<hipEvent_t>* ev = nullptr;
+        if (e->side_stream && e->side_stream != stream && g_fold_build_overlap) {
+            // the two products need nothing but the encoder's context: on the caller's SECOND stream beside step 0's
+            // attention (one fork here, one join in front of the first decode step; the last quarter of the workspace is
+            // theirs, the head keeps the front)
+            ev = &event_pool(2);
+            if (ev->size() >= 2 && ar.cap > ((size_t)8 << 20)) {
+                bs = S(e->side_stream);
+                const size_t side_n = ar.cap / 4;
+                ar = Arena{(float*)ws + (ar.cap - side_n), side_n, 0, ar.tk};
+                if (hipEventRecord((*ev)[0], ms) != hipSuccess || hipStreamWaitEvent(bs, (*ev)[0], 0) != hipSuccess)
+                    return SF_ERR_LAUNCH;
+            }
+        }
+        TRY(linear_plain(e->ctx, H, w->text.w_in_t, H, nullptr, M, H, H, EPI_NONE, e->ctx_q, H, ar, bs));
+        TRY(linear_plain(e->ctx, H, w->text.w_out, 2 * H, nullptr, M, H, H, EPI_NONE, e->ctx_o, H, ar, bs));
         tf = &tfold;
+        if (bs != ms) {
+            // (the head -- issued below on `stream` -- runs beside them; join behind it)
+            fold_join = (*ev)[1];
+            fold_side = bs;
+        }
+    }
+    {
+        // (beside the fold products the head keeps the FRONT three quarters of the workspace -- and the same ticket words)
+        Arena ha = arena(ws, ws_bytes);
+        if (fold_side) ha.cap -= ha.cap / 4;
+        TRY(decoder_head_a(w, &cur.X, e->B, e->H, e->D, e->h_init, &cur.tp, drop, e->step0, ha, stream));
+    }
+    if (fold_side) {
+        if (hipEventRecord(fold_join, fold_side) != hipSuccess || hipStreamWaitEvent(S(stream), fold_join, 0) != hipSuccess)
+            return SF_ERR_LAUNCH;
     }
     if (e->glue.nav) {
         // A device-resident environment (sf_nav_io of step 0 in glue.nav; state buffers stacked [S + 1][...]): the
@@ -1344,7 +1380,7 @@ int sf_follower_episode_fwd(const sf_decoder_w* w, const sf_follower_episode* e,
         }
         return SF_OK;
     }
-    if (e->side_stream && e->side_stream != stream && !w->fold && e->S > 1) {
+    if (e->side_stream && e->side_stream != stream && !w->fold && e->S > 1 && !tf) {
         // Two chains, ONE fork and ONE join per episode, ordered per step by device flags
         // (flag_wait / flag_set kernels) instead of events:
         //   main:  [wait feat(t)] gate product, cell, [set h1(t)], t_text, text attention, h~, scoring + glue

@@ -160,6 +160,9 @@ class FollowerEngine:
         self.split_wgrad_streams = False
         self.encoder_backward_first = os.environ.get('SF_ENC_BWD_FIRST', '0') == '1'   # (experiment switch, see _backward)
         self.grad_sync = None            # dp.BucketedGrads(dp.follower_buckets(enc, dec)): all-reduce launched from the backward
+        # the fold's two products on a second stream beside step 0's attention: built, correct, SLOWER -- the fork and the
+        # join inside the replayed graph cost more than the 25 us they hide (1.813 against 1.759 ms per rollout): off
+        self.fold_build_overlap = False
         self._open_forks = []            # side streams forked from the current one and not joined yet (_backward)
         # ... with q' = M_v h1 + c_v and [r | c] = M_a h~ + c_a as single products (ABI 9 chain_fold): three launches behind
         # the cell instead of four -- BUILT, CORRECT, SLOWER (round 6: 2.03 ms per rollout against 1.77: the [100 x 512] x
@@ -328,6 +331,12 @@ class FollowerEngine:
             # differentiable or train-mode rollout; one stream only.
             st.text_folded = (self.fold_text and not st.differentiable and not training and fold is None
                               and ep.side_stream is None and S > 1 and T <= 80 and not bidir)
+            if st.text_folded and self.fold_build_overlap:
+                # the two fold products (they need the encoder's context only) on a second stream beside step 0's attention
+                if self._side_stream is None:
+                    self._side_stream = concurrent_stream(dev)
+                    ensure_workspace(self._side_stream, dev)
+                ep.side_stream = self._side_stream.cuda_stream
             if st.text_folded:
                 st.ctx_fold = new(2, B, T, H)
                 ep.ctx_q, ep.ctx_o = st.ctx_fold[0].data_ptr(), st.ctx_fold[1].data_ptr()
