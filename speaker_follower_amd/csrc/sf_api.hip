@@ -793,9 +793,8 @@ static int decoder_tail_i(const sf_decoder_w* w, const sf_cands* U, int B, int H
     const sf_visual_w* vw = &w->visual;
     bool paired = X_next && vw->w_v_t;     // (a scoring fold, if any, is applied by scoring_fwd_i)
     const bool last_step = !X_next && !tn;      // (nothing of a next step to prepare: the text chain alone)
-    const bool glue_or_plain_ok = true;
     if ((paired || query_only || last_step) && tf && tf->mats && g_fold_chain3 && !w->fold && !ctx_row && !d_h.on() &&
-        tw->w_out && glue_or_plain_ok) {
+        tw->w_out) {
         // Folded text stage + folded query / scoring products (sf_decoder_fold through sf_follower_episode.chain_fold):
         // THREE dependent launches behind the cell --
         //   (1) folded text attention  ||  y = W_out[:, H:] h1  ||  q' = M_v h1 + c_v      (t_v' is never formed)
